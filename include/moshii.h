@@ -1,0 +1,168 @@
+/*
+ * moshii.h -- C ABI of libmoshii.so: the MI355X-native MoSh++ Stage-II hot path.
+ *
+ * The reference (nghorbani/moshpp, pure Python) has no FFI; the boundary it offers is the
+ * function-injection point `MoSh.mosh_stageii(mosh_stageii_func)` (src/moshpp/mosh_head.py:268-301,
+ * call at :280-286) whose callee `chmosh.mosh_stageii` (src/moshpp/chmosh.py:458-741) is what this
+ * library replaces.  Each entry point below cites the reference code whose arithmetic it takes over.
+ * The Python mirror of the reference interface (moshpp_amd/chmosh.py) binds these with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, caller-owned buffers, no global state except the per-process HIP context;
+ *   - every function returns 0 on success, <0 on error; moshii_last_error() gives the message;
+ *   - all floating-point data is IEEE double unless a name ends in _f32;
+ *   - "host pointer" arguments are read during the call; handles own device copies;
+ *   - thread-safe per handle (one host thread per handle at a time).
+ */
+#ifndef MOSHII_H
+#define MOSHII_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct moshii_model_s*  moshii_model_t;   /* body model resident in HBM                    */
+typedef struct moshii_prior_s*  moshii_prior_t;   /* max-mixture pose prior resident in HBM        */
+typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact marker-vertex model */
+
+#define MOSHII_OK               0
+#define MOSHII_ERR_ARG         -1
+#define MOSHII_ERR_HIP         -2
+#define MOSHII_ERR_UNSUPPORTED -3
+#define MOSHII_ERR_NO_DEVICE   -4
+
+/* flags for moshii_chain_solve / moshii_lbs_forward_* : where the big per-frame buffers live */
+#define MOSHII_BUFFERS_HOST    0u   /* obs/vis/outputs are host pointers (library stages them)     */
+#define MOSHII_BUFFERS_DEVICE  1u   /* obs/vis/outputs are device pointers; launch is async on `stream` */
+
+const char* moshii_last_error(void);
+int  moshii_version(void);
+int  moshii_device_count(void);
+int  moshii_set_device(int device);
+
+/* ---------------------------------------------------------------------------------------------
+ * Body model.  Replaces load_surface_model + SmplModelLBS construction
+ * (src/moshpp/models/smpl_fast_derivatives.py:52-244): the arrays of the model pickle plus the
+ * pose-variable layout  fullpose = [pose[:body_dof], hands_mean + pose[body_dof:].selected_components]
+ * (:194-204).  SMPL: body_dof=72, hand_dof=0.  SMPL-H: 66/2*dof_per_hand.  SMPL-X: 75/2*dof_per_hand.
+ * MANO: 3/dof_per_hand.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct moshii_model_desc {
+    int32_t V;                      /* vertices                                                   */
+    int32_t K;                      /* joints (<= 64)                                             */
+    int32_t NB;                     /* shape coefficients held by shapedirs                       */
+    int32_t body_dof;               /* leading fullpose dofs that are pose variables themselves   */
+    int32_t hand_dof;               /* number of hand-PCA coefficients (0: none)                  */
+    const int32_t* parents;         /* [K], parents[0] = -1 (kintree_table[0])                    */
+    const double*  v_template;      /* [V][3]                                                     */
+    const double*  shapedirs;       /* [V][3][NB]                                                 */
+    const double*  posedirs;        /* [V][3][9(K-1)]                                             */
+    const double*  weights;         /* [V][K] dense skinning weights                              */
+    const double*  J_regressor;     /* [K][V] dense                                               */
+    const double*  hands_mean;      /* [3K-body_dof] or NULL                                      */
+    const double*  selected_components; /* [hand_dof][3K-body_dof] or NULL                        */
+} moshii_model_desc;
+
+int moshii_model_create(const moshii_model_desc* desc, moshii_model_t* out);
+int moshii_model_destroy(moshii_model_t m);
+
+/* v_shaped = v_template + shapedirs[:,:,:nb].betas ; J = J_regressor.v_shaped
+ * (smpl_fast_derivatives.py:186-191; chmosh.py:499-500 writes the Stage-I betas).  Betas are frozen in
+ * Stage-II, so this runs once per subject. */
+int moshii_model_set_betas(moshii_model_t m, const double* betas, int32_t nb);
+
+/* Regressed joints J[K][3] for the current betas (host buffer). */
+int moshii_model_get_joints(moshii_model_t m, double* J_out);
+
+/* Full-mesh LBS forward, SmplModelLBS.r (smpl_fast_derivatives.py:206-218,243-244 -> psbody
+ * verts_decorated): pose[F][NP] (pose *variables*), trans[F][3] -> verts[F][V][3].
+ * _f64: reference-precision path (used for the canonical body of TransformedCoeffs, chmosh.py:502).
+ * _f32: batched HBM-bound export kernel (MFMA for the W x A blend).  Buffers host or device per flags. */
+int moshii_lbs_forward_f64(moshii_model_t m, int32_t F, const double* pose, const double* trans,
+                           double* verts, uint32_t flags, void* stream);
+int moshii_lbs_forward_f32(moshii_model_t m, int32_t F, const float* pose, const float* trans,
+                           float* verts, uint32_t flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pose prior.  Replaces create_gmm_body_prior / MaxMixtureComplete
+ * (src/moshpp/prior/gmm_prior_ch.py:42-134).  The caller passes the already prepared arrays:
+ * means[G][npose], chols[G][npose][npose] (lower Cholesky factors of the precisions, :122-123) and the
+ * re-normalised weights[G] (:126-130).
+ * ------------------------------------------------------------------------------------------- */
+int moshii_prior_create(int32_t G, int32_t npose, const double* means, const double* chols,
+                        const double* weights, moshii_prior_t* out);
+int moshii_prior_destroy(moshii_prior_t p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Marker attachment.  Replaces the numeric result of TransformedCoeffs (src/moshpp/transformed_lm.py:45-113)
+ * as consumed by TransformedLms (:120-162): closest[M][3] vertex ids and coef[M][3].  Gathers the
+ * rows of v_shaped / posedirs / weights of the <= 3M attached vertices into a compact slice
+ * (requires moshii_model_set_betas first; re-create after changing betas).
+ * ------------------------------------------------------------------------------------------- */
+int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, const double* coef,
+                         moshii_attach_t* out);
+int moshii_attach_destroy(moshii_attach_t a);
+
+/* Simulated markers for given pose variables (TransformedLms.r): pose[F][NP], trans[F][3] -> markers[F][M][3].
+ * Host buffers. */
+int moshii_attach_markers(moshii_attach_t a, int32_t F, const double* pose, const double* trans,
+                          double* markers);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage-II chain solve.  Replaces the frame loop of chmosh.mosh_stageii (src/moshpp/chmosh.py:584-724)
+ * including every ch.minimize(method='dogleg') call (:651-653, 669-671, 703-705).
+ * One chain = one sequence (or a contiguous chunk of one) walked frame by frame with warm start and
+ * the 2-frame velocity term (:624-626, 656-657).  Chains of one call run concurrently, one workgroup
+ * each; they share the model, prior and options but may have different attachments.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct moshii_solve_opts {
+    /* opt_settings.weights (support_data/conf/moshpp_conf.yaml:118-125) */
+    double wt_data, wt_velo, wt_poseB, wt_poseH, wt_annealing;
+    double num_train_markers;       /* 46, chmosh.py:460                                         */
+    double e3_first, e3;            /* 1e-3 (first-frame rounds, :653) and 1e-2 (:671,705)       */
+    double delta0;                  /* 0.5                                                       */
+    int32_t maxiter;                /* opt_settings.maxiter (100)                                */
+    int32_t n_step1;                /* free pose-variable ids of Step 1 (:665-668), sorted       */
+    const int32_t* step1_ids;
+    int32_t n_step2;                /* free pose-variable ids of Step 2 (:676-692), sorted       */
+    const int32_t* step2_ids;
+    int32_t n_body;                 /* pose_body_ids: the prior's argument (:613), == prior npose or 0 */
+    const int32_t* body_ids;
+    int32_t n_finger;               /* pose_finger_ids when optimize_fingers (:681-683), else 0  */
+    const int32_t* finger_ids;
+} moshii_solve_opts;
+
+typedef struct moshii_chain_desc {
+    moshii_attach_t attach;
+    int32_t F;                      /* frames in this chain                                      */
+    int32_t first_frame_schedule;   /* 1: rigid init + annealed rounds on the first solved frame (:629-655) */
+    const double*  obs;             /* [F][M][3] metres, ordered like the latent labels (:591)   */
+    const uint8_t* vis;             /* [F][M] 1 = label observed in this frame (markers_asdict)   */
+    const double*  init_pose;       /* host [NP] or NULL (zeros)                                  */
+    const double*  init_trans;      /* host [3]  or NULL (zeros)                                  */
+    const double*  init_pose_prev;  /* host [NP] or NULL (no velocity term on the next frame)     */
+    /* outputs, one row per input frame; rows of frames without visible markers are left untouched
+     * and flagged status = 1 (the reference skips them, :586-588) */
+    double*  pose;                  /* [F][NP] pose variables                     (may be NULL)   */
+    double*  fullpose;              /* [F][3K]  opt_model.fullpose (:720)                          */
+    double*  trans;                 /* [F][3]                                                      */
+    double*  markers_sim;           /* [F][M][3] simulated markers (all M; caller selects visible) */
+    double*  errs;                  /* [F][4] SSE of data, poseB, velo, poseH (:712-714)           */
+    int32_t* iters;                 /* [F][2] dogleg outer iterations, residual evaluations        */
+    int32_t* status;                /* [F] 0 solved, 1 skipped (no markers), <0 numerical failure  */
+} moshii_chain_desc;
+
+int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL when n_body == 0 */,
+                       const moshii_solve_opts* opts, int32_t n_chains, const moshii_chain_desc* chains,
+                       uint32_t flags, void* stream);
+
+/* Introspection for benchmarks: name and dynamic-LDS bytes of the kernel the last moshii_chain_solve used. */
+int moshii_last_launch_info(char* kernel_name, int32_t name_cap, int32_t* lds_bytes, int32_t* block_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOSHII_H */

@@ -1,0 +1,55 @@
+"""Build libmoshii.so in-tree for gfx950:  python -m moshpp_amd.build [--force]"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['moshii_api.hip', 'chain_solve.hip', 'lbs_forward.hip']
+HEADERS = ['moshii_dev.h', os.path.join('..', '..', 'include', 'moshii.h')]
+OUT = os.path.join(HERE, 'libmoshii.so')
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    objs = []
+    procs = []
+    for s in SOURCES:
+        obj = os.path.join(CSRC, s.replace('.hip', '.o'))
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-value',
+               '-c', os.path.join(CSRC, s), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'hipcc failed on {s}')
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(OUT)

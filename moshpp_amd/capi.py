@@ -1,0 +1,306 @@
+"""ctypes binding of libmoshii.so (include/moshii.h).
+
+The library is the product: there is NO CPU fallback.  `load()` raises if the shared object is
+missing, and every compute entry point returns MOSHII_ERR_NO_DEVICE without a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmoshii.so')
+
+BUFFERS_HOST = 0
+BUFFERS_DEVICE = 1
+
+_c_double_p = C.POINTER(C.c_double)
+_c_float_p = C.POINTER(C.c_float)
+_c_int_p = C.POINTER(C.c_int32)
+_c_u8_p = C.POINTER(C.c_uint8)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [('V', C.c_int32), ('K', C.c_int32), ('NB', C.c_int32), ('body_dof', C.c_int32),
+                ('hand_dof', C.c_int32), ('parents', _c_int_p), ('v_template', _c_double_p),
+                ('shapedirs', _c_double_p), ('posedirs', _c_double_p), ('weights', _c_double_p),
+                ('J_regressor', _c_double_p), ('hands_mean', _c_double_p), ('selected_components', _c_double_p)]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [('wt_data', C.c_double), ('wt_velo', C.c_double), ('wt_poseB', C.c_double),
+                ('wt_poseH', C.c_double), ('wt_annealing', C.c_double), ('num_train_markers', C.c_double),
+                ('e3_first', C.c_double), ('e3', C.c_double), ('delta0', C.c_double), ('maxiter', C.c_int32),
+                ('n_step1', C.c_int32), ('step1_ids', _c_int_p), ('n_step2', C.c_int32), ('step2_ids', _c_int_p),
+                ('n_body', C.c_int32), ('body_ids', _c_int_p), ('n_finger', C.c_int32), ('finger_ids', _c_int_p)]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [('attach', C.c_void_p), ('F', C.c_int32), ('first_frame_schedule', C.c_int32),
+                ('obs', C.c_void_p), ('vis', C.c_void_p), ('init_pose', _c_double_p), ('init_trans', _c_double_p),
+                ('init_pose_prev', _c_double_p), ('pose', C.c_void_p), ('fullpose', C.c_void_p),
+                ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p),
+                ('status', C.c_void_p)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    'moshii_last_error': (C.c_char_p, []),
+    'moshii_version': (C.c_int, []),
+    'moshii_device_count': (C.c_int, []),
+    'moshii_set_device': (C.c_int, [C.c_int]),
+    'moshii_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    'moshii_model_destroy': (C.c_int, [C.c_void_p]),
+    'moshii_model_set_betas': (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
+    'moshii_model_get_joints': (C.c_int, [C.c_void_p, _c_double_p]),
+    'moshii_lbs_forward_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    'moshii_lbs_forward_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    'moshii_prior_create': (C.c_int, [C.c_int32, C.c_int32, _c_double_p, _c_double_p, _c_double_p, C.POINTER(C.c_void_p)]),
+    'moshii_prior_destroy': (C.c_int, [C.c_void_p]),
+    'moshii_attach_create': (C.c_int, [C.c_void_p, C.c_int32, _c_int_p, _c_double_p, C.POINTER(C.c_void_p)]),
+    'moshii_attach_destroy': (C.c_int, [C.c_void_p]),
+    'moshii_attach_markers': (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    'moshii_chain_solve': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SolveOpts), C.c_int32, C.POINTER(ChainDesc),
+                                     C.c_uint32, C.c_void_p]),
+    'moshii_last_launch_info': (C.c_int, [C.c_char_p, C.c_int32, _c_int_p, _c_int_p]),
+}
+
+_lib = None
+
+
+class MoshiiError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmoshii.so (built in-tree by __graft_entry__.build() / moshpp_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MoshiiError(f'{LIB_PATH} not found: build it with `python -m moshpp_amd.build` '
+                          f'(there is no CPU fallback for the Stage-II path)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().moshii_last_error()
+        raise MoshiiError(f'libmoshii error {rc}: {msg.decode() if msg else "?"}')
+
+
+def device_count():
+    return load().moshii_device_count()
+
+
+def require_device():
+    if device_count() < 1:
+        raise MoshiiError('no HIP device visible: the moshpp_amd Stage-II path runs only on the GPU')
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_c_int_p)
+
+
+class Model:
+    """moshii_model_t: body model arrays + pose-variable layout, resident in HBM."""
+
+    def __init__(self, v_template, shapedirs, posedirs, weights, J_regressor, parents, body_dof, hand_dof=0,
+                 hands_mean=None, selected_components=None):
+        lib = load()
+        require_device()
+        v_template = _f64(v_template)
+        V = v_template.shape[0]
+        parents = np.ascontiguousarray(parents, dtype=np.int32)
+        K = parents.shape[0]
+        shapedirs = _f64(shapedirs)
+        if hasattr(J_regressor, 'toarray'):
+            J_regressor = J_regressor.toarray()
+        J_regressor = _f64(J_regressor)
+        posedirs = _f64(posedirs).reshape(V, 3, -1)
+        weights = _f64(weights)
+        assert posedirs.shape[2] == 9 * (K - 1), (posedirs.shape, K)
+        assert weights.shape == (V, K) and J_regressor.shape == (K, V)
+        NB = shapedirs.shape[-1]
+        d = ModelDesc()
+        d.V, d.K, d.NB, d.body_dof, d.hand_dof = V, K, NB, int(body_dof), int(hand_dof)
+        keep = [parents, v_template, shapedirs, posedirs, weights, J_regressor]
+        d.parents = _ip(parents)
+        d.v_template = _dp(v_template); d.shapedirs = _dp(shapedirs); d.posedirs = _dp(posedirs)
+        d.weights = _dp(weights); d.J_regressor = _dp(J_regressor)
+        if hand_dof:
+            hm = _f64(hands_mean); sc = _f64(selected_components)
+            assert hm.shape == (3 * K - body_dof,) and sc.shape == (hand_dof, 3 * K - body_dof)
+            keep += [hm, sc]
+            d.hands_mean = _dp(hm); d.selected_components = _dp(sc)
+        self.V, self.K, self.NB, self.body_dof, self.hand_dof = V, K, NB, int(body_dof), int(hand_dof)
+        self.P = 3 * K
+        self.NP = self.body_dof + self.hand_dof
+        self.handle = C.c_void_p()
+        check(lib.moshii_model_create(C.byref(d), C.byref(self.handle)))
+        del keep
+
+    def set_betas(self, betas):
+        b = _f64(np.ravel(betas))
+        check(load().moshii_model_set_betas(self.handle, _dp(b), b.shape[0]))
+
+    def joints(self):
+        out = np.zeros((self.K, 3))
+        check(load().moshii_model_get_joints(self.handle, _dp(out)))
+        return out
+
+    def lbs_forward(self, pose, trans, dtype=np.float64):
+        """verts[F,V,3] for pose variables pose[F,NP], trans[F,3] (host arrays)."""
+        pose = np.ascontiguousarray(np.atleast_2d(pose), dtype=dtype)
+        trans = np.ascontiguousarray(np.atleast_2d(trans), dtype=dtype)
+        F = pose.shape[0]
+        assert pose.shape == (F, self.NP) and trans.shape == (F, 3)
+        out = np.zeros((F, self.V, 3), dtype=dtype)
+        fn = load().moshii_lbs_forward_f64 if dtype == np.float64 else load().moshii_lbs_forward_f32
+        check(fn(self.handle, F, pose.ctypes.data, trans.ctypes.data, out.ctypes.data, BUFFERS_HOST, None))
+        return out
+
+    def lbs_forward_device(self, F, pose_ptr, trans_ptr, out_ptr, stream=None, f32=True):
+        fn = load().moshii_lbs_forward_f32 if f32 else load().moshii_lbs_forward_f64
+        check(fn(self.handle, F, pose_ptr, trans_ptr, out_ptr, BUFFERS_DEVICE, stream))
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle.value:
+            load().moshii_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Prior:
+    """moshii_prior_t: prepared max-mixture prior (means, chols of precisions, re-normalised weights)."""
+
+    def __init__(self, means, chols, weights):
+        means = _f64(means); chols = _f64(chols); weights = _f64(np.ravel(weights))
+        G, npose = means.shape
+        assert chols.shape == (G, npose, npose) and weights.shape == (G,)
+        self.G, self.npose = G, npose
+        self.handle = C.c_void_p()
+        check(load().moshii_prior_create(G, npose, _dp(means), _dp(chols), _dp(weights), C.byref(self.handle)))
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle.value:
+            load().moshii_prior_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Attachment:
+    """moshii_attach_t: closest[M,3] vertex ids + coef[M,3] -> compact marker-vertex model slice."""
+
+    def __init__(self, model: Model, closest, coef):
+        closest = np.ascontiguousarray(closest, dtype=np.int32)
+        coef = _f64(coef)
+        M = closest.shape[0]
+        assert closest.shape == (M, 3) and coef.shape == (M, 3)
+        self.model = model
+        self.M = M
+        self.handle = C.c_void_p()
+        check(load().moshii_attach_create(model.handle, M, _ip(closest), _dp(coef), C.byref(self.handle)))
+
+    def markers(self, pose, trans):
+        pose = _f64(np.atleast_2d(pose)); trans = _f64(np.atleast_2d(trans))
+        F = pose.shape[0]
+        out = np.zeros((F, self.M, 3))
+        check(load().moshii_attach_markers(self.handle, F, _dp(pose), _dp(trans), _dp(out)))
+        return out
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle.value:
+            load().moshii_attach_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_opts(weights, step1_ids, step2_ids, body_ids, finger_ids, maxiter=100, e3_first=1e-3, e3=1e-2,
+              delta0=0.5, num_train_markers=46.0):
+    """SolveOpts + the arrays it points to (keep the returned tuple alive during the call)."""
+    o = SolveOpts()
+    o.wt_data = float(weights['stageii_wt_data']); o.wt_velo = float(weights['stageii_wt_velo'])
+    o.wt_poseB = float(weights['stageii_wt_poseB']); o.wt_poseH = float(weights['stageii_wt_poseH'])
+    o.wt_annealing = float(weights['stageii_wt_annealing'])
+    o.num_train_markers = float(num_train_markers)
+    o.e3_first, o.e3, o.delta0, o.maxiter = float(e3_first), float(e3), float(delta0), int(maxiter)
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (step1_ids, step2_ids, body_ids, finger_ids)]
+    o.n_step1, o.n_step2, o.n_body, o.n_finger = (len(a) for a in arrs)
+    o.step1_ids, o.step2_ids, o.body_ids, o.finger_ids = (_ip(a) for a in arrs)
+    return o, arrs
+
+
+def chain_solve_host(model: Model, prior, opts_tuple, chains):
+    """Run moshii_chain_solve on host buffers.
+    chains: list of dict(attach, obs[F,M,3], vis[F,M], first=True, init_pose=None, init_trans=None, init_pose_prev=None).
+    Returns list of dict(pose, fullpose, trans, markers_sim, errs, iters, status)."""
+    lib = load()
+    opts, _keep = opts_tuple
+    n = len(chains)
+    descs = (ChainDesc * n)()
+    outs, keep = [], []
+    for i, ch in enumerate(chains):
+        att = ch['attach']
+        obs = _f64(ch['obs']); vis = np.ascontiguousarray(ch['vis'], dtype=np.uint8)
+        F, M = vis.shape
+        assert obs.shape == (F, M, 3) and M == att.M
+        o = dict(pose=np.zeros((F, model.NP)), fullpose=np.zeros((F, model.P)), trans=np.zeros((F, 3)),
+                 markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, 4)), iters=np.zeros((F, 2), dtype=np.int32),
+                 status=np.zeros(F, dtype=np.int32))
+        d = descs[i]
+        d.attach = att.handle
+        d.F = F
+        d.first_frame_schedule = 1 if ch.get('first', True) else 0
+        d.obs = obs.ctypes.data
+        d.vis = vis.ctypes.data
+        keep += [obs, vis]
+        for key, fld in (('init_pose', 'init_pose'), ('init_trans', 'init_trans'), ('init_pose_prev', 'init_pose_prev')):
+            if ch.get(key) is not None:
+                a = _f64(ch[key]); keep.append(a)
+                setattr(d, fld, _dp(a))
+        for key in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status'):
+            setattr(d, key, o[key].ctypes.data)
+        outs.append(o)
+    check(lib.moshii_chain_solve(model.handle, prior.handle if prior is not None else None, C.byref(opts), n, descs,
+                                 BUFFERS_HOST, None))
+    del keep
+    return outs
+
+
+def last_launch_info():
+    name = C.create_string_buffer(128)
+    lds = C.c_int32(0); thr = C.c_int32(0)
+    load().moshii_last_launch_info(name, 128, C.byref(lds), C.byref(thr))
+    return name.value.decode(), lds.value, thr.value

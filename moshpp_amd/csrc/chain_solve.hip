@@ -1,0 +1,1048 @@
+// k_chain_solve: the MoSh++ Stage-II frame loop as ONE persistent HIP kernel for gfx950.
+//
+// Replaces chmosh.mosh_stageii's hot loop (src/moshpp/chmosh.py:584-724) together with everything it
+// drives through chumpy: SmplModelLBS forward (models/smpl_fast_derivatives.py:185-244), its pose
+// Jacobian (:246-258), TransformedLms (transformed_lm.py:130-162), the max-mixture prior
+// (prior/gmm_prior_ch.py:53-85), the rigid first-frame init (rigid_transformations.py:39-83) and
+// chumpy's minimize_dogleg (normal equations, Cholesky solve, trust-region control).
+//
+// Mapping: one chain (sequence or chunk) per 256-thread workgroup = 4 waves, one per SIMD of a CU.
+// All solver state is float64 and lives in LDS / registers; the only HBM/L2 traffic per evaluation is
+// the compact posedirs slice of the <= 3M attached vertices (vertex index fastest => coalesced),
+// M*3 observations in and one result row out per frame.  J^T J is accumulated in registers as
+// 16x16-thread outer-product tiles (lower triangle only), factored by a right-looking Cholesky in LDS.
+#include "moshii_dev.h"
+
+namespace moshii {
+
+enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6 };
+
+struct Ctx {
+    double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
+    double *feat, *B, *omega, *Rw, *tw, *Rloc, *acol;
+    double *vposed, *vpos, *msim, *res;
+    double *xb, *ell, *score;
+    double *g, *dsd, *dgn, *ddl, *y;
+    double *red, *scal;
+    unsigned long long* anc;
+    int *visidx, *colpid, *colprior, *pid2prior, *jointslot, *kfree;
+    double *big, *Jv, *Jrow, *Lm, *Trot, *xjs, *rest;
+};
+
+struct FrameParams {
+    const double* obs;      // [M][3] of this frame
+    double wt_data, wt_pose, wt_poseH, wt_velo;
+    int has_velo, use_fingers, nobs;
+};
+
+struct Sse { double data, prior, velo, hand, total; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum over the 256-thread block; every thread returns the bitwise-identical total.
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { red[(tid >> 6) * 3 + 0] = a; red[(tid >> 6) * 3 + 1] = b; red[(tid >> 6) * 3 + 2] = c; }
+    __syncthreads();
+    a = (red[0] + red[3]) + (red[6] + red[9]);
+    b = (red[1] + red[4]) + (red[7] + red[10]);
+    c = (red[2] + red[5]) + (red[8] + red[11]);
+}
+__device__ __forceinline__ double block_sum(double a, double* red) {
+    double b = 0.0, c = 0.0;
+    block_sum3(a, b, c, red);
+    return a;
+}
+__device__ __forceinline__ double block_max(double a, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_down(a, o, 64));
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// Rodrigues + SO(3) left Jacobian; same formulas and small-angle switch as oracle/stageii_oracle.py:rodrigues.
+__device__ __forceinline__ void rodrigues_dev(const double* r, double* R, double* Jl) {
+    const double x = r[0], y = r[1], z = r[2];
+    const double t2 = x * x + y * y + z * z;
+    double a, b, c;
+    if (t2 < 1e-6) {
+        a = 1.0 - t2 / 6.0 + t2 * t2 / 120.0;
+        b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0;
+        c = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0;
+    } else {
+        const double t = sqrt(t2);
+        double s, co;
+        sincos(t, &s, &co);
+        a = s / t;
+        b = (1.0 - co) / t2;
+        c = (t - s) / (t2 * t);
+    }
+    // K = [r]x ; K^2 = r r^T - t2 I
+    const double K2[9] = {x * x - t2, x * y, x * z, x * y, y * y - t2, y * z, x * z, y * z, z * z - t2};
+    const double Km[9] = {0.0, -z, y, z, 0.0, -x, -y, x, 0.0};
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+        R[e] = id + a * Km[e] + b * K2[e];
+        Jl[e] = id + b * Km[e] + c * K2[e];
+    }
+}
+
+__device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[i * 3 + j] = A[i * 3 + 0] * Bm[0 * 3 + j] + A[i * 3 + 1] * Bm[1 * 3 + j] + A[i * 3 + 2] * Bm[2 * 3 + j];
+}
+__device__ __forceinline__ void mat3_vec(const double* A, double x, double y, double z, double& ox, double& oy, double& oz) {
+    ox = A[0] * x + A[1] * y + A[2] * z;
+    oy = A[3] * x + A[4] * y + A[5] * z;
+    oz = A[6] * x + A[7] * y + A[8] * z;
+}
+
+// marker from its three vertices (transformed_lm.py:138-159); optionally the 3x9 Jacobian wrt (v0,v1,v2).
+__device__ __forceinline__ void marker_eval(const double* c, const double* v0, const double* v1, const double* v2,
+                                            double* mk, double* L /* 27 or nullptr */) {
+    const double e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const double e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    const double f1[3] = {e1[0] / l1, e1[1] / l1, e1[2] / l1};
+    const double nv[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double ln = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    const double f2[3] = {nv[0] / ln, nv[1] / ln, nv[2] / ln};
+    const double f3[3] = {f1[1] * f2[2] - f1[2] * f2[1], f1[2] * f2[0] - f1[0] * f2[2], f1[0] * f2[1] - f1[1] * f2[0]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mk[i] = v0[i] + c[0] * f1[i] + c[1] * f2[i] + c[2] * f3[i];
+    if (L == nullptr) return;
+    // D1 = (I - f1 f1^T)/l1 ; D2 = (I - f2 f2^T)/ln
+    double D1[9], D2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double id = (i == j) ? 1.0 : 0.0;
+            D1[i * 3 + j] = (id - f1[i] * f1[j]) / l1;
+            D2[i * 3 + j] = (id - f2[i] * f2[j]) / ln;
+        }
+    // dn/de1 = -[e2]x ; dn/de2 = [e1]x
+    const double N1[9] = {0.0, e2[2], -e2[1], -e2[2], 0.0, e2[0], e2[1], -e2[0], 0.0};
+    const double N2[9] = {0.0, -e1[2], e1[1], e1[2], 0.0, -e1[0], -e1[1], e1[0], 0.0};
+    double F21[9], F22[9];
+    mat3_mul(D2, N1, F21);
+    mat3_mul(D2, N2, F22);
+    const double S1[9] = {0.0, -f1[2], f1[1], f1[2], 0.0, -f1[0], -f1[1], f1[0], 0.0};
+    const double S2[9] = {0.0, -f2[2], f2[1], f2[2], 0.0, -f2[0], -f2[1], f2[0], 0.0};
+    double T1[9], T2[9], T3[9];
+    mat3_mul(S2, D1, T1);    // [f2]x D1
+    mat3_mul(S1, F21, T2);   // [f1]x df2/de1
+    mat3_mul(S1, F22, T3);   // [f1]x df2/de2
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = i * 3 + j;
+            const double de1 = c[0] * D1[e] + c[1] * F21[e] + c[2] * (T2[e] - T1[e]);
+            const double de2 = c[1] * F22[e] + c[2] * T3[e];
+            const double id = (i == j) ? 1.0 : 0.0;
+            L[i * 9 + j] = id - de1 - de2;
+            L[i * 9 + 3 + j] = de1;
+            L[i * 9 + 6 + j] = de2;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward evaluation of every residual block at (pose, trans): leaves joint transforms, posed
+// attached vertices, simulated markers, weighted data residuals and the prior's l-vectors in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
+                            const OptsDev& op, const double* pose, const double* trans, const FrameParams& fp,
+                            const uint8_t* visrow) {
+    const int tid = threadIdx.x;
+    const int K = md.K, P = md.P, bd = md.body_dof, hd = md.hand_dof, nhf = md.nhand_full;
+    // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
+    for (int d = tid; d < P; d += MOSHII_TPB) {
+        double v;
+        if (d < bd) v = pose[d];
+        else {
+            const int h = d - bd;
+            v = md.hands_mean[h];
+            for (int i = 0; i < hd; ++i)
+                if (h >= md.comp_lo[i] && h < md.comp_hi[i]) v += pose[bd + i] * md.comps[i * nhf + h];
+        }
+        cx.fullpose[d] = v;
+    }
+    __syncthreads();
+    // F2: per joint Rodrigues, left-Jacobian columns, pose feature R - I, dR/dtheta_c = [a_c]x R
+    if (tid < K) {
+        double R[9], Jl[9];
+        rodrigues_dev(&cx.fullpose[3 * tid], R, Jl);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            cx.Rloc[tid * 9 + e] = R[e];
+            cx.feat[tid * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double ax = Jl[0 * 3 + c], ay = Jl[1 * 3 + c], az = Jl[2 * 3 + c];
+            cx.acol[tid * 9 + c * 3 + 0] = ax;
+            cx.acol[tid * 9 + c * 3 + 1] = ay;
+            cx.acol[tid * 9 + c * 3 + 2] = az;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {   // column d of R
+                const double rx = R[0 * 3 + d], ry = R[1 * 3 + d], rz = R[2 * 3 + d];
+                cx.B[tid * 27 + c * 9 + 0 * 3 + d] = ay * rz - az * ry;
+                cx.B[tid * 27 + c * 9 + 1 * 3 + d] = az * rx - ax * rz;
+                cx.B[tid * 27 + c * 9 + 2 * 3 + d] = ax * ry - ay * rx;
+            }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) cx.Rw[e] = R[e];
+            cx.tw[0] = md.J[0]; cx.tw[1] = md.J[1]; cx.tw[2] = md.J[2];
+        }
+    }
+    // F3: kinematic chain, one tree level per barrier (G_j = G_par(j) . [R_j | J_j - J_par(j)])
+    for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
+        __syncthreads();
+        if (tid < K && md.depth[tid] == lvl) {
+            const int p = md.parents[tid];
+            double Rp[9], Rl[9], Ro[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { Rp[e] = cx.Rw[p * 9 + e]; Rl[e] = cx.Rloc[tid * 9 + e]; }
+            mat3_mul(Rp, Rl, Ro);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) cx.Rw[tid * 9 + e] = Ro[e];
+            const double dx = md.J[tid * 3 + 0] - md.J[p * 3 + 0];
+            const double dy = md.J[tid * 3 + 1] - md.J[p * 3 + 1];
+            const double dz = md.J[tid * 3 + 2] - md.J[p * 3 + 2];
+            double ox, oy, oz;
+            mat3_vec(Rp, dx, dy, dz, ox, oy, oz);
+            cx.tw[tid * 3 + 0] = ox + cx.tw[p * 3 + 0];
+            cx.tw[tid * 3 + 1] = oy + cx.tw[p * 3 + 1];
+            cx.tw[tid * 3 + 2] = oz + cx.tw[p * 3 + 2];
+        }
+    }
+    __syncthreads();
+    // world rotation axes omega_{k,c} = Rw_par(k) . Jl_k[:,c]
+    if (tid < 3 * K) {
+        const int k = tid / 3, c = tid % 3;
+        const double ax = cx.acol[k * 9 + c * 3 + 0], ay = cx.acol[k * 9 + c * 3 + 1], az = cx.acol[k * 9 + c * 3 + 2];
+        double ox = ax, oy = ay, oz = az;
+        if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
+        cx.omega[k * 9 + c * 3 + 0] = ox; cx.omega[k * 9 + c * 3 + 1] = oy; cx.omega[k * 9 + c * 3 + 2] = oz;
+    }
+    // F4: v_posed = v_shaped + posedirs . vec(R - I) for the attached vertices; item = (coordinate i, vertex a)
+    const int Nv = at.Nv, Nvp = at.Nvp;
+    for (int it = tid; it < 3 * Nv; it += MOSHII_TPB) {
+        const int i = it / Nv, a = it - i * Nv;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        const double* pp = at.Pt + (size_t)(i * 9) * Nvp + a;
+        for (int k = 1; k < K; ++k) {
+            const double* f = &cx.feat[k * 9];
+            const double* pk = pp + (size_t)((k - 1) * 27) * Nvp;
+            s0 += pk[0 * Nvp] * f[0]; s1 += pk[1 * Nvp] * f[1]; s2 += pk[2 * Nvp] * f[2];
+            s0 += pk[3 * Nvp] * f[3]; s1 += pk[4 * Nvp] * f[4]; s2 += pk[5 * Nvp] * f[5];
+            s0 += pk[6 * Nvp] * f[6]; s1 += pk[7 * Nvp] * f[7]; s2 += pk[8 * Nvp] * f[8];
+        }
+        cx.vposed[a * 3 + i] = at.vsh[a * 3 + i] + ((s0 + s1) + s2);
+    }
+    __syncthreads();
+    // F5: skinning  v = sum_j w_j (Rw_j (v_posed - J_j) + tw_j) + trans
+    const int NW = at.NW;
+    for (int a = tid; a < Nv; a += MOSHII_TPB) {
+        const double px = cx.vposed[a * 3 + 0], py = cx.vposed[a * 3 + 1], pz = cx.vposed[a * 3 + 2];
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        for (int s = 0; s < NW; ++s) {
+            const int j = at.wj[a * NW + s];
+            const double w = at.ww[a * NW + s];
+            double ox, oy, oz;
+            mat3_vec(&cx.Rw[j * 9], px - md.J[j * 3 + 0], py - md.J[j * 3 + 1], pz - md.J[j * 3 + 2], ox, oy, oz);
+            ax += w * (ox + cx.tw[j * 3 + 0]);
+            ay += w * (oy + cx.tw[j * 3 + 1]);
+            az += w * (oz + cx.tw[j * 3 + 2]);
+        }
+        cx.vpos[a * 3 + 0] = ax + trans[0];
+        cx.vpos[a * 3 + 1] = ay + trans[1];
+        cx.vpos[a * 3 + 2] = az + trans[2];
+    }
+    __syncthreads();
+    // F6: simulated markers + weighted data residual
+    double sd = 0.0;
+    const int M = at.M;
+    for (int m = tid; m < M; m += MOSHII_TPB) {
+        double mk[3];
+        const double c[3] = {at.coef[m * 3 + 0], at.coef[m * 3 + 1], at.coef[m * 3 + 2]};
+        marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, nullptr);
+        const bool v = visrow != nullptr && visrow[m] != 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            cx.msim[m * 3 + i] = mk[i];
+            const double r = v ? fp.wt_data * (mk[i] - fp.obs[m * 3 + i]) : 0.0;
+            cx.res[m * 3 + i] = r;
+            sd += r * r;
+        }
+    }
+    // F8: velocity and finger terms
+    double sv = 0.0, sh = 0.0;
+    if (fp.has_velo)
+        for (int i = tid; i < md.NP; i += MOSHII_TPB) { const double d = (pose[i] - cx.vtarget[i]) * fp.wt_velo; sv += d * d; }
+    if (fp.use_fingers)
+        for (int f = tid; f < op.nfinger; f += MOSHII_TPB) { const double d = pose[op.finger[f]] * fp.wt_poseH; sh += d * d; }
+    // F7: prior: l_g = sqrt(.5) (x - mu_g) . L_g for every component, argmin of |l_g|^2 - log w_g
+    const int np_ = op.nbody;
+    if (np_ > 0) {
+        for (int b = tid; b < np_; b += MOSHII_TPB) cx.xb[b] = pose[op.body[b]];
+        __syncthreads();
+        const int G = pr.G;
+        for (int it = tid; it < G * np_; it += MOSHII_TPB) {
+            const int gc = it / np_, a = it - gc * np_;
+            const double* Lg = pr.chols + (size_t)gc * np_ * np_;
+            const double* mu = pr.means + (size_t)gc * np_;
+            double s = 0.0;
+            for (int b = a; b < np_; ++b) s += (cx.xb[b] - mu[b]) * Lg[b * np_ + a];
+            cx.ell[it] = 0.70710678118654757 * s;
+        }
+        __syncthreads();
+        if (tid < G) {
+            double s = 0.0;
+            for (int a = 0; a < np_; ++a) { const double l = cx.ell[tid * np_ + a]; s += l * l; }
+            cx.score[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int kb = 0;
+            double best = cx.score[0] + pr.neglogw[0];
+            for (int gc = 1; gc < G; ++gc) {
+                const double sc = cx.score[gc] + pr.neglogw[gc];
+                if (sc < best) { best = sc; kb = gc; }
+            }
+            cx.scal[S_KBEST] = (double)kb;
+            cx.scal[S_PRIOR_SS] = cx.score[kb] + pr.neglogw[kb];
+        }
+    }
+    block_sum3(sd, sv, sh, cx.red);   // (contains the barriers that publish scal[])
+    Sse out;
+    out.data = sd; out.velo = sv; out.hand = sh;
+    out.prior = (np_ > 0) ? fp.wt_pose * fp.wt_pose * cx.scal[S_PRIOR_SS] : 0.0;
+    out.total = ((out.data + out.prior) + out.velo) + out.hand;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// J^T J in registers: thread (ty, tx) of a 16x16 grid owns A[bi*16+ty][bj*16+tx] for bj <= bi.
+// ------------------------------------------------------------------------------------------------
+template <int NBLK>
+struct AReg {
+    static constexpr int NE = NBLK * (NBLK + 1) / 2;
+    double a[NE];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) a[e] = 0.0;
+    }
+    // A += rows^T rows  (rows: nr x LDJ in LDS, columns >= n are zero)
+    __device__ __forceinline__ void rank_update(const double* rows, int nr, int LDJ) {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        for (int r = 0; r < nr; ++r) {
+            const double* row = rows + r * LDJ;
+            double av[NBLK], bv[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) { av[b] = row[b * 16 + ty]; bv[b] = row[b * 16 + tx]; }
+            int e = 0;
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = 0; bj <= bi; ++bj) { a[e] += av[bi] * bv[bj]; ++e; }
+        }
+    }
+    __device__ __forceinline__ void add_diag(const double* dvec /* LDS [n] */, int n) {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        if (ty != tx) return;
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                if (bi == bj) { const int q = bi * 16 + ty; if (q < n) a[e] += dvec[q]; }
+                ++e;
+            }
+    }
+    // A[q1][q2] += scale * Pk[colprior[q1]][colprior[q2]]
+    __device__ __forceinline__ void add_prior(double scale, const double* Pk, int np_, const int* colprior, int n) {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
+                if (q1 < n && q2 < n) {
+                    const int p1 = colprior[q1], p2 = colprior[q2];
+                    if (p1 >= 0 && p2 >= 0) a[e] += scale * Pk[p1 * np_ + p2];
+                }
+                ++e;
+            }
+    }
+    // sum_{q1,q2} A[q1][q2] x[q1] x[q2] over the full symmetric matrix (block partial; reduce outside)
+    __device__ __forceinline__ double quad_partial(const double* x, int n) const {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        double s = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
+                if (q1 < n && q2 <= q1) s += ((q1 == q2) ? 1.0 : 2.0) * a[e] * x[q1] * x[q2];
+                ++e;
+            }
+        return s;
+    }
+    // packed lower triangle: idx(i,j) = i(i+1)/2 + j; row n holds the right-hand side (bordered form)
+    __device__ __forceinline__ void store_packed(double* Lp, int n) const {
+        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
+                if (q1 < n && q2 <= q1) Lp[q1 * (q1 + 1) / 2 + q2] = a[e];
+                ++e;
+            }
+    }
+};
+
+// Solve A d = g by Cholesky on the bordered packed matrix [A; g^T] in LDS: factoring the first n columns
+// turns the extra row into y = L^{-1} g; wave 0 then back-substitutes L^T d = y.  Returns false if A is not
+// numerically positive definite (the reference would fall back to lstsq; callers take the Cauchy step).
+__device__ bool chol_solve(double* Lp, const double* g, double* d, double* scal, int n) {
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int q = tid; q < n; q += MOSHII_TPB) Lp[n * (n + 1) / 2 + q] = g[q];
+    bool ok = true;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        const double pj = Lp[j * (j + 1) / 2 + j];
+        if (!(pj > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS word
+        const double dj = sqrt(pj);
+        const double dinv = 1.0 / dj;
+        for (int i = j + 1 + tid; i <= n; i += MOSHII_TPB) Lp[i * (i + 1) / 2 + j] *= dinv;
+        __syncthreads();
+        if (tid == 0) Lp[j * (j + 1) / 2 + j] = dj;
+        for (int i = j + 1 + ty; i <= n; i += 16) {
+            const double lij = Lp[i * (i + 1) / 2 + j];
+            const int kend = (i < n) ? i : n - 1;     // the border row has no diagonal entry
+            for (int k = j + 1 + tx; k <= kend; k += 16) Lp[i * (i + 1) / 2 + k] -= lij * Lp[k * (k + 1) / 2 + j];
+        }
+    }
+    __syncthreads();
+    if (!ok) return false;
+    // back substitution by wave 0: lane l owns rows l and l+64
+    if (tid < 64) {
+        const int base = n * (n + 1) / 2;
+        double y0 = (tid < n) ? Lp[base + tid] : 0.0;
+        double y1 = (tid + 64 < n) ? Lp[base + tid + 64] : 0.0;
+        for (int j = n - 1; j >= 0; --j) {
+            const double ljj = Lp[j * (j + 1) / 2 + j];
+            const double yj = (j < 64) ? __shfl(y0, j, 64) : __shfl(y1, j - 64, 64);
+            const double dj = yj / ljj;
+            if (tid == (j & 63)) { if (j < 64) y0 = dj; else y1 = dj; }
+            if (tid < j) y0 -= Lp[j * (j + 1) / 2 + tid] * dj;
+            if (tid + 64 < j) y1 -= Lp[j * (j + 1) / 2 + tid + 64] * dj;
+        }
+        if (tid < n) d[tid] = y0;
+        if (tid + 64 < n) d[tid + 64] = y1;
+    }
+    __syncthreads();
+    (void)scal;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Normal equations at the point whose forward state is in LDS:  A = J^T J (registers), g = -J^T r (LDS).
+// ------------------------------------------------------------------------------------------------
+template <int NBLK>
+__device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at,
+                         const PriorDev& pr, const OptsDev& op, const double* pose, const FrameParams& fp,
+                         int n, int nkf, AReg<NBLK>& A) {
+    const int tid = threadIdx.x;
+    const int LDJ = ly.LDJ, Tm = ly.Tm, NW = at.NW, Nvp = at.Nvp, bd = md.body_dof, nhf = md.nhand_full;
+    A.zero();
+    for (int q = tid; q < n; q += MOSHII_TPB) cx.g[q] = 0.0;
+    for (int e = tid; e < 3 * Tm * LDJ; e += MOSHII_TPB) cx.Jrow[e] = 0.0;
+    __syncthreads();
+    for (int tile0 = 0; tile0 < fp.nobs; tile0 += Tm) {
+        const int cnt = min(Tm, fp.nobs - tile0);
+        const int ntv = 3 * cnt;
+        // T0: per tile vertex blended rotation + rigidly-attached positions; per tile marker local Jacobian
+        if (tid < ntv) {
+            const int m = cx.visidx[tile0 + tid / 3];
+            const int av = 3 * m + tid % 3;
+            const double px = cx.vposed[av * 3 + 0], py = cx.vposed[av * 3 + 1], pz = cx.vposed[av * 3 + 2];
+            double Tr[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Tr[e] = 0.0;
+            for (int s = 0; s < NW; ++s) {
+                const int j = at.wj[av * NW + s];
+                const double w = at.ww[av * NW + s];
+                double ox, oy, oz;
+                mat3_vec(&cx.Rw[j * 9], px - md.J[j * 3 + 0], py - md.J[j * 3 + 1], pz - md.J[j * 3 + 2], ox, oy, oz);
+                cx.xjs[(tid * NW + s) * 3 + 0] = ox + cx.tw[j * 3 + 0];
+                cx.xjs[(tid * NW + s) * 3 + 1] = oy + cx.tw[j * 3 + 1];
+                cx.xjs[(tid * NW + s) * 3 + 2] = oz + cx.tw[j * 3 + 2];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) Tr[e] += w * cx.Rw[j * 9 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) cx.Trot[tid * 9 + e] = Tr[e];
+        } else if (tid >= 128 && tid < 128 + cnt) {
+            const int ml = tid - 128;
+            const int m = cx.visidx[tile0 + ml];
+            const double c[3] = {at.coef[m * 3 + 0], at.coef[m * 3 + 1], at.coef[m * 3 + 2]};
+            double mk[3], L[27];
+            marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, L);
+#pragma unroll
+            for (int e = 0; e < 27; ++e) cx.Lm[ml * 27 + e] = L[e];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cx.rest[ml * 3 + i] = cx.res[m * 3 + i];
+        }
+        __syncthreads();
+        // T1: vertex Jacobian columns of the needed joints: item = (tile vertex, joint)
+        for (int it = tid; it < ntv * nkf; it += MOSHII_TPB) {
+            const int kfi = it / ntv, al = it - kfi * ntv;
+            const int k = cx.kfree[kfi];
+            const int m = cx.visidx[tile0 + al / 3];
+            const int av = 3 * m + al % 3;
+            const unsigned long long mask = cx.anc[k];
+            const double tkx = cx.tw[k * 3 + 0], tky = cx.tw[k * 3 + 1], tkz = cx.tw[k * 3 + 2];
+            double ax = 0.0, ay = 0.0, az = 0.0;
+            for (int s = 0; s < NW; ++s) {
+                const int j = at.wj[av * NW + s];
+                if ((mask >> j) & 1ull) {
+                    const double w = at.ww[av * NW + s];
+                    ax += w * (cx.xjs[(al * NW + s) * 3 + 0] - tkx);
+                    ay += w * (cx.xjs[(al * NW + s) * 3 + 1] - tky);
+                    az += w * (cx.xjs[(al * NW + s) * 3 + 2] - tkz);
+                }
+            }
+            double col[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double ox = cx.omega[k * 9 + c * 3 + 0], oy = cx.omega[k * 9 + c * 3 + 1], oz = cx.omega[k * 9 + c * 3 + 2];
+                col[c * 3 + 0] = oy * az - oz * ay;
+                col[c * 3 + 1] = oz * ax - ox * az;
+                col[c * 3 + 2] = ox * ay - oy * ax;
+            }
+            if (k >= 1) {
+                double p[27];
+                const double* pp = at.Pt + (size_t)((k - 1) * 27) * Nvp + av;
+#pragma unroll
+                for (int q = 0; q < 27; ++q) p[q] = pp[(size_t)q * Nvp];
+                const double* Tr = &cx.Trot[al * 9];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double* Bc = &cx.B[k * 27 + c * 9];
+                    double pd[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) s += p[i * 9 + e] * Bc[e];
+                        pd[i] = s;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) col[c * 3 + i] += Tr[i * 3 + 0] * pd[0] + Tr[i * 3 + 1] * pd[1] + Tr[i * 3 + 2] * pd[2];
+                }
+            }
+            double* out = &cx.Jv[(al * nkf + kfi) * 9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) out[e] = col[e];
+        }
+        __syncthreads();
+        // T2: marker rows: item = (tile marker, column)
+        for (int it = tid; it < cnt * n; it += MOSHII_TPB) {
+            const int ml = it / n, q = it - ml * n;
+            const double* L = &cx.Lm[ml * 27];
+            double r0, r1, r2;
+            if (q < 3) {
+                r0 = (q == 0) ? 1.0 : 0.0; r1 = (q == 1) ? 1.0 : 0.0; r2 = (q == 2) ? 1.0 : 0.0;
+            } else {
+                const int pid = cx.colpid[q];
+                double J9[9];
+                if (pid < bd) {
+                    const int k = pid / 3, c = pid - 3 * k;
+                    const int kfi = cx.jointslot[k];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) J9[s * 3 + x] = cx.Jv[((3 * ml + s) * nkf + kfi) * 9 + c * 3 + x];
+                } else {
+                    const int i = pid - bd;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) J9[e] = 0.0;
+                    for (int h = md.comp_lo[i]; h < md.comp_hi[i]; ++h) {
+                        const int d = bd + h;
+                        const int k = d / 3, c = d - 3 * k;
+                        const int kfi = cx.jointslot[k];
+                        const double cc = md.comps[i * nhf + h];
+#pragma unroll
+                        for (int s = 0; s < 3; ++s)
+#pragma unroll
+                            for (int x = 0; x < 3; ++x) J9[s * 3 + x] += cc * cx.Jv[((3 * ml + s) * nkf + kfi) * 9 + c * 3 + x];
+                    }
+                }
+                r0 = 0.0; r1 = 0.0; r2 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) { r0 += L[e] * J9[e]; r1 += L[9 + e] * J9[e]; r2 += L[18 + e] * J9[e]; }
+            }
+            cx.Jrow[(3 * ml + 0) * LDJ + q] = fp.wt_data * r0;
+            cx.Jrow[(3 * ml + 1) * LDJ + q] = fp.wt_data * r1;
+            cx.Jrow[(3 * ml + 2) * LDJ + q] = fp.wt_data * r2;
+        }
+        __syncthreads();
+        // T3: A += Jt^T Jt ; g -= Jt^T r
+        A.rank_update(cx.Jrow, ntv, LDJ);
+        for (int q = tid; q < n; q += MOSHII_TPB) {
+            double s = 0.0;
+            for (int r = 0; r < ntv; ++r) s += cx.Jrow[r * LDJ + q] * cx.rest[r];
+            cx.g[q] -= s;
+        }
+        __syncthreads();
+    }
+    // structured terms: prior (dense, precomputed 0.5 L L^T per component), velocity and finger terms (diagonal)
+    const int np_ = op.nbody;
+    double* dvec = cx.y;   // diagonal additions
+    const int kb = (np_ > 0) ? (int)cx.scal[S_KBEST] : 0;
+    for (int q = tid; q < n; q += MOSHII_TPB) {
+        double dg = 0.0, gq = 0.0;
+        if (q >= 3) {
+            const int pid = cx.colpid[q];
+            if (fp.has_velo) { const double w2 = fp.wt_velo * fp.wt_velo; dg += w2; gq -= w2 * (pose[pid] - cx.vtarget[pid]); }
+            const int pb = cx.colprior[q];
+            if (pb >= 0) {
+                const double* Lrow = pr.chols + ((size_t)kb * np_ + pb) * np_;
+                const double* ell = &cx.ell[kb * np_];
+                double s = 0.0;
+                for (int a = 0; a <= pb; ++a) s += Lrow[a] * ell[a];
+                gq -= fp.wt_pose * fp.wt_pose * 0.70710678118654757 * s;
+            }
+            if (fp.use_fingers) {
+                // finger ids are a contiguous tail of the pose vector in every supported model
+                if (op.nfinger > 0 && pid >= op.finger[0] && pid <= op.finger[op.nfinger - 1]) {
+                    const double w2 = fp.wt_poseH * fp.wt_poseH; dg += w2; gq -= w2 * pose[pid];
+                }
+            }
+        }
+        dvec[q] = dg;
+        cx.g[q] += gq;
+    }
+    __syncthreads();
+    A.add_diag(dvec, n);
+    if (np_ > 0) A.add_prior(fp.wt_pose * fp.wt_pose, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// chumpy's minimize_dogleg over x = [trans, pose[ids]]  (oracle/stageii_oracle.py:minimize_dogleg)
+// ------------------------------------------------------------------------------------------------
+template <int NBLK>
+__device__ void dogleg(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
+                       const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, double e3,
+                       int& n_iter, int& n_fev, int& fail) {
+    const int tid = threadIdx.x;
+    const int n = 3 + nids;
+    // column tables + needed-joint list
+    for (int q = tid; q < n; q += MOSHII_TPB) {
+        const int pid = (q < 3) ? -1 : ids[q - 3];
+        cx.colpid[q] = pid;
+        cx.colprior[q] = (pid >= 0) ? cx.pid2prior[pid] : -1;
+    }
+    if (tid == 0) {
+        for (int k = 0; k < md.K; ++k) cx.jointslot[k] = -1;
+        for (int i = 0; i < nids; ++i) {
+            const int pid = ids[i];
+            if (pid < md.body_dof) cx.jointslot[pid / 3] = 0;
+            else for (int k = md.body_dof / 3; k < md.K; ++k) cx.jointslot[k] = 0;
+        }
+        int c = 0;
+        for (int k = 0; k < md.K; ++k) if (cx.jointslot[k] == 0) { cx.jointslot[k] = c; cx.kfree[c] = k; ++c; }
+        cx.scal[S_TMP0] = (double)c;
+    }
+    __syncthreads();
+    const int nkf = (int)cx.scal[S_TMP0];
+    AReg<NBLK> A;
+    Sse cur = eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, visrow);
+    ++n_fev;
+    assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, A);
+    double sse = cur.total;
+    double delta = op.delta0;
+    bool done = false;
+    {
+        double gm = 0.0;
+        for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
+        if (block_max(gm, cx.red) < 1e-15) done = true;
+    }
+    int iteration = 0;
+    while (!done) {
+        ++iteration;
+        // steepest descent: d_sd = |g|^2 / |J g|^2 g, |J g|^2 = g^T A g
+        double gg = 0.0;
+        for (int q = tid; q < n; q += MOSHII_TPB) gg += cx.g[q] * cx.g[q];
+        double gAg = A.quad_partial(cx.g, n);
+        double dummy = 0.0;
+        block_sum3(gg, gAg, dummy, cx.red);
+        const double csd = gg / gAg;
+        const double norm_sd = fabs(csd) * sqrt(gg);
+        for (int q = tid; q < n; q += MOSHII_TPB) cx.dsd[q] = csd * cx.g[q];
+        bool have_gn = false, gn_ok = true;
+        double norm_gn = 0.0;
+        __syncthreads();
+        while (true) {
+            // ---- update_step
+            if (norm_sd >= delta) {
+                const double sc = delta / norm_sd;
+                for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = sc * cx.dsd[q];
+            } else {
+                if (!have_gn) {
+                    A.store_packed(cx.big, n);
+                    __syncthreads();
+                    gn_ok = chol_solve(cx.big, cx.g, cx.dgn, cx.scal, n);
+                    if (!gn_ok) { fail = 1; for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q]; __syncthreads(); }
+                    double s = 0.0;
+                    for (int q = tid; q < n; q += MOSHII_TPB) s += cx.dgn[q] * cx.dgn[q];
+                    norm_gn = sqrt(block_sum(s, cx.red));
+                    have_gn = true;
+                }
+                if (norm_gn <= delta) {
+                    for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dgn[q];
+                } else {
+                    double dd = 0.0, gs = 0.0, ds = 0.0;
+                    for (int q = tid; q < n; q += MOSHII_TPB) {
+                        const double df = cx.dgn[q] - cx.dsd[q];
+                        dd += df * df; gs += cx.dgn[q] * cx.dsd[q]; ds += df * cx.dsd[q];
+                    }
+                    block_sum3(dd, gs, ds, cx.red);
+                    const double delta_sq = delta * delta;
+                    const double sqnorm_sd = norm_sd * norm_sd;
+                    const double pnow = dd * delta_sq + gs * gs - (norm_gn * norm_gn) * sqnorm_sd;
+                    const double beta = (delta_sq - sqnorm_sd) / (ds + sqrt(pnow));
+                    for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dsd[q] + beta * (cx.dgn[q] - cx.dsd[q]);
+                }
+            }
+            __syncthreads();
+            // ---- trial point and norms
+            double s2 = 0.0, p2 = 0.0, gd = 0.0;
+            for (int q = tid; q < n; q += MOSHII_TPB) {
+                const double dq = cx.ddl[q];
+                const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
+                s2 += dq * dq; p2 += pq * pq; gd += cx.g[q] * dq;
+            }
+            block_sum3(s2, p2, gd, cx.red);
+            const double step = sqrt(s2);
+            bool improved = false;
+            if (step <= 1e-15 * sqrt(p2)) {
+                done = true;
+            } else {
+                for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+                if (tid < 3) cx.trans_t[tid] = cx.trans[tid] + cx.ddl[tid];
+                __syncthreads();
+                for (int q = 3 + tid; q < n; q += MOSHII_TPB) cx.pose_t[cx.colpid[q]] += cx.ddl[q];
+                __syncthreads();
+                const Sse tr = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow);
+                ++n_fev;
+                double rho = sse - tr.total;
+                if (rho > 0.0) {
+                    const double dAd = block_sum(A.quad_partial(cx.ddl, n), cx.red);
+                    rho = rho / (2.0 * gd - dAd);
+                }
+                improved = rho > 0.0;
+                double pnorm2 = p2;
+                if (improved) {
+                    for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose[i] = cx.pose_t[i];
+                    if (tid < 3) cx.trans[tid] = cx.trans_t[tid];
+                    __syncthreads();
+                    if (e3 > 0.0 && (sse - tr.total) / sse < e3) {
+                        done = true;
+                    } else {
+                        assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, A);
+                        sse = tr.total;
+                        double gm = 0.0;
+                        for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
+                        if (block_max(gm, cx.red) < 1e-15) done = true;
+                    }
+                    double pp = 0.0;
+                    for (int q = tid; q < n; q += MOSHII_TPB) { const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]]; pp += pq * pq; }
+                    pnorm2 = block_sum(pp, cx.red);
+                }
+                if (rho > 0.9) delta = fmax(delta, 2.5 * step);
+                else if (rho < 0.05) delta *= 0.25;
+                if (delta <= 1e-15 * sqrt(pnorm2)) done = true;
+            }
+            if (done || improved) break;
+        }
+        if (iteration >= op.maxiter) done = true;
+    }
+    n_iter += iteration;
+}
+
+// Arun/Procrustes rigid init (rigid_transformations.py:39-83), serial on one thread (first solved frame only).
+__device__ void rigid_init_serial(const Ctx& cx, const FrameParams& fp, const uint8_t* visrow, int M) {
+    double am[3] = {0, 0, 0}, bm[3] = {0, 0, 0};
+    int cnt = 0;
+    for (int m = 0; m < M; ++m) if (visrow[m]) {
+        for (int i = 0; i < 3; ++i) { am[i] += cx.msim[m * 3 + i]; bm[i] += fp.obs[m * 3 + i]; }
+        ++cnt;
+    }
+    for (int i = 0; i < 3; ++i) { am[i] /= cnt; bm[i] /= cnt; }
+    double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // C = sum (a - am)(b - bm)^T
+    for (int m = 0; m < M; ++m) if (visrow[m])
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+            G[i * 3 + j] += (cx.msim[m * 3 + i] - am[i]) * (fp.obs[m * 3 + j] - bm[j]);
+    // one-sided Jacobi: G V = U S
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            double al = 0, be = 0, ga = 0;
+            for (int i = 0; i < 3; ++i) { al += G[i * 3 + p] * G[i * 3 + p]; be += G[i * 3 + q] * G[i * 3 + q]; ga += G[i * 3 + p] * G[i * 3 + q]; }
+            if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+            off = fmax(off, fabs(ga) / sqrt(al * be));
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = ((zeta >= 0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+            for (int i = 0; i < 3; ++i) {
+                const double gp = G[i * 3 + p], gq = G[i * 3 + q];
+                G[i * 3 + p] = c * gp - s * gq; G[i * 3 + q] = s * gp + c * gq;
+                const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                V[i * 3 + p] = c * vp - s * vq; V[i * 3 + q] = s * vp + c * vq;
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    double sv[3], U[9];
+    int imin = 0, imax = 0;
+    for (int c = 0; c < 3; ++c) {
+        sv[c] = sqrt(G[0 * 3 + c] * G[0 * 3 + c] + G[1 * 3 + c] * G[1 * 3 + c] + G[2 * 3 + c] * G[2 * 3 + c]);
+        if (sv[c] < sv[imin]) imin = c;
+        if (sv[c] > sv[imax]) imax = c;
+    }
+    for (int c = 0; c < 3; ++c) for (int i = 0; i < 3; ++i) U[i * 3 + c] = (sv[c] > 0) ? G[i * 3 + c] / sv[c] : 0.0;
+    if (sv[imin] <= 1e-13 * sv[imax]) {   // rank-deficient: complete the basis
+        const int c1 = (imin + 1) % 3, c2 = (imin + 2) % 3;
+        U[0 * 3 + imin] = U[1 * 3 + c1] * U[2 * 3 + c2] - U[2 * 3 + c1] * U[1 * 3 + c2];
+        U[1 * 3 + imin] = U[2 * 3 + c1] * U[0 * 3 + c2] - U[0 * 3 + c1] * U[2 * 3 + c2];
+        U[2 * 3 + imin] = U[0 * 3 + c1] * U[1 * 3 + c2] - U[1 * 3 + c1] * U[0 * 3 + c2];
+    }
+    // here C = U S V^T with U from `a`-side rows: R = V U^T maps a -> b
+    double R[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+        R[i * 3 + j] = V[i * 3 + 0] * U[j * 3 + 0] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    if (det < 0.0)
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] -= 2.0 * V[i * 3 + imin] * U[j * 3 + imin];
+    // cv2.Rodrigues(R): matrix -> axis-angle, angle in [0, pi]
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    c = fmin(1.0, fmax(-1.0, c));
+    const double theta = acos(c);
+    double rv[3];
+    if (s < 1e-5) {
+        if (c > 0) { rv[0] = rv[1] = rv[2] = 0.0; }
+        else {
+            double x = sqrt(fmax((R[0] + 1.0) * 0.5, 0.0));
+            double y = sqrt(fmax((R[4] + 1.0) * 0.5, 0.0)) * ((R[1] >= 0) ? 1.0 : -1.0);
+            double z = sqrt(fmax((R[8] + 1.0) * 0.5, 0.0)) * ((R[2] >= 0) ? 1.0 : -1.0);
+            if (fabs(x) < fabs(y) && fabs(x) < fabs(z) && ((R[5] > 0) != (y * z > 0))) z = -z;
+            const double nn = sqrt(x * x + y * y + z * z);
+            rv[0] = x * theta / nn; rv[1] = y * theta / nn; rv[2] = z * theta / nn;
+        }
+    } else {
+        const double k = 0.5 * theta / s;
+        rv[0] = rx * k; rv[1] = ry * k; rv[2] = rz * k;
+    }
+    cx.pose[0] = rv[0]; cx.pose[1] = rv[1]; cx.pose[2] = rv[2];
+    for (int i = 0; i < 3; ++i) cx.trans[i] = bm[i] - (R[i * 3 + 0] * am[0] + R[i * 3 + 1] * am[1] + R[i * 3 + 2] * am[2]);
+}
+
+__device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
+    Ctx cx;
+    cx.pose = lds + ly.o_pose; cx.trans = lds + ly.o_trans; cx.pose_t = lds + ly.o_pose_t; cx.trans_t = lds + ly.o_trans_t;
+    cx.pose_prev = lds + ly.o_pose_prev; cx.vtarget = lds + ly.o_vtarget; cx.fullpose = lds + ly.o_fullpose;
+    cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
+    cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
+    cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
+    cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
+    cx.g = lds + ly.o_g; cx.dsd = lds + ly.o_dsd; cx.dgn = lds + ly.o_dgn; cx.ddl = lds + ly.o_ddl; cx.y = lds + ly.o_y;
+    cx.red = lds + ly.o_red; cx.scal = lds + ly.o_scal;
+    cx.anc = reinterpret_cast<unsigned long long*>(lds + ly.o_anc);
+    int* ints = reinterpret_cast<int*>(lds + ly.o_ints);
+    cx.visidx = ints + ly.i_visidx; cx.colpid = ints + ly.i_colpid; cx.colprior = ints + ly.i_colprior;
+    cx.pid2prior = ints + ly.i_pid2prior; cx.jointslot = ints + ly.i_jointslot; cx.kfree = ints + ly.i_kfree;
+    cx.big = lds + ly.o_big;
+    cx.Jv = cx.big + ly.t_Jv; cx.Jrow = cx.big + ly.t_Jrow; cx.Lm = cx.big + ly.t_Lm; cx.Trot = cx.big + ly.t_Trot;
+    cx.xjs = cx.big + ly.t_xjs; cx.rest = cx.big + ly.t_rest;
+
+    return cx;
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __restrict__ chains, ModelDev md, PriorDev pr,
+                                                             OptsDev op, ChainLayout ly) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const ChainDev ch = chains[blockIdx.x];
+    const AttachDev at = *ch.att;
+    const Ctx cx = make_ctx(lds, ly);
+
+    const int NP = md.NP, M = at.M;
+    for (int i = tid; i < NP; i += MOSHII_TPB) {
+        cx.pose[i] = ch.init_pose ? ch.init_pose[i] : 0.0;
+        cx.pose_prev[i] = ch.init_prev ? ch.init_prev[i] : 0.0;
+        cx.vtarget[i] = 0.0;
+        cx.pid2prior[i] = -1;
+    }
+    if (tid < 3) cx.trans[tid] = ch.init_trans ? ch.init_trans[tid] : 0.0;
+    if (tid < md.K) cx.anc[tid] = md.anc[tid];
+    __syncthreads();
+    for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
+    __syncthreads();
+    bool has_prev = ch.init_prev != nullptr;
+    bool first = ch.first != 0;
+
+    for (int t = 0; t < ch.F; ++t) {
+        const uint8_t* visrow = ch.vis + (size_t)t * M;
+        // visible-marker list (chmosh.py:591-594), kept in label order
+        if (tid == 0) {
+            int c = 0;
+            for (int m = 0; m < M; ++m) if (visrow[m]) cx.visidx[c++] = m;
+            cx.scal[S_TMP1] = (double)c;
+        }
+        __syncthreads();
+        const int nobs = (int)cx.scal[S_TMP1];
+        if (nobs == 0) {   // chmosh.py:586-588
+            if (tid == 0 && ch.status) ch.status[t] = 1;
+            __syncthreads();
+            continue;
+        }
+        FrameParams fp;
+        fp.obs = ch.obs + (size_t)t * M * 3;
+        fp.nobs = nobs;
+        const double n_miss = (double)(M - nobs);
+        double anneal = 1.0;
+        if (n_miss > 0.0) anneal = anneal + (n_miss / (double)M) * op.wt_annealing;   // :596-601
+        fp.wt_data = op.wt_data * (op.num_train_markers / (double)nobs);              // :603
+        const double wt_pose = op.wt_poseB * anneal;                                    // :604
+        fp.wt_pose = wt_pose;
+        fp.wt_poseH = op.wt_poseH * anneal;
+        fp.wt_velo = op.wt_velo;
+        fp.use_fingers = 0;
+        fp.has_velo = has_prev ? 1 : 0;
+        if (has_prev)   // :624-626  target = pose.r + (pose.r - pose_prev)
+            for (int i = tid; i < NP; i += MOSHII_TPB) cx.vtarget[i] = cx.pose[i] + (cx.pose[i] - cx.pose_prev[i]);
+        __syncthreads();
+        int n_iter = 0, n_fev = 0, fail = 0;
+        if (first) {
+            eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, visrow);
+            if (tid == 0) rigid_init_serial(cx, fp, visrow, M);
+            __syncthreads();
+            const double sc[3] = {10.0, 5.0, 1.0};
+            for (int r = 0; r < 3; ++r) {
+                fp.wt_pose = sc[r] * wt_pose;
+                dogleg<NBLK>(cx, ly, md, at, pr, op, fp, visrow, op.step1, op.n1, op.e3_first, n_iter, n_fev, fail);
+            }
+            first = false;
+        } else {
+            for (int i = tid; i < NP; i += MOSHII_TPB) cx.pose_prev[i] = cx.pose[i];   // :656-657
+            has_prev = true;
+            __syncthreads();
+        }
+        fp.wt_pose = wt_pose;
+        dogleg<NBLK>(cx, ly, md, at, pr, op, fp, visrow, op.step1, op.n1, op.e3, n_iter, n_fev, fail);
+        fp.use_fingers = (op.nfinger > 0) ? 1 : 0;
+        dogleg<NBLK>(cx, ly, md, at, pr, op, fp, visrow, op.step2, op.n2, op.e3, n_iter, n_fev, fail);
+        // record (chmosh.py:712-724)
+        const Sse fin = eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, visrow);
+        if (ch.pose) for (int i = tid; i < NP; i += MOSHII_TPB) ch.pose[(size_t)t * NP + i] = cx.pose[i];
+        if (ch.fullpose) for (int i = tid; i < md.P; i += MOSHII_TPB) ch.fullpose[(size_t)t * md.P + i] = cx.fullpose[i];
+        if (ch.msim) for (int i = tid; i < 3 * M; i += MOSHII_TPB) ch.msim[(size_t)t * 3 * M + i] = cx.msim[i];
+        if (tid == 0) {
+            if (ch.trans) { ch.trans[t * 3 + 0] = cx.trans[0]; ch.trans[t * 3 + 1] = cx.trans[1]; ch.trans[t * 3 + 2] = cx.trans[2]; }
+            if (ch.errs) { ch.errs[t * 4 + 0] = fin.data; ch.errs[t * 4 + 1] = fin.prior; ch.errs[t * 4 + 2] = fin.velo; ch.errs[t * 4 + 3] = fin.hand; }
+            if (ch.iters) { ch.iters[t * 2 + 0] = n_iter; ch.iters[t * 2 + 1] = n_fev; }
+            if (ch.status) ch.status[t] = fail ? -1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+template __global__ void k_chain_solve<2>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+template __global__ void k_chain_solve<4>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+template __global__ void k_chain_solve<5>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+template __global__ void k_chain_solve<7>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+template __global__ void k_chain_solve<8>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+
+
+// Simulated markers for explicit pose variables (TransformedLms.r), one frame per workgroup.
+__global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restrict__ attp, ModelDev md, ChainLayout ly,
+                                                        const double* __restrict__ pose, const double* __restrict__ trans,
+                                                        double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const AttachDev at = *attp;
+    const Ctx cx = make_ctx(lds, ly);
+    const int f = blockIdx.x;
+    for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose[i] = pose[(size_t)f * md.NP + i];
+    if (tid < 3) cx.trans[tid] = trans[(size_t)f * 3 + tid];
+    __syncthreads();
+    FrameParams fp;
+    fp.obs = nullptr; fp.wt_data = 0.0; fp.wt_pose = 0.0; fp.wt_poseH = 0.0; fp.wt_velo = 0.0;
+    fp.has_velo = 0; fp.use_fingers = 0; fp.nobs = 0;
+    PriorDev pr; pr.G = 0; pr.npose = 0; pr.means = nullptr; pr.chols = nullptr; pr.halfprec = nullptr; pr.neglogw = nullptr;
+    OptsDev op;
+    op.nbody = 0; op.nfinger = 0; op.n1 = 0; op.n2 = 0; op.maxiter = 0;
+    op.step1 = nullptr; op.step2 = nullptr; op.body = nullptr; op.finger = nullptr;
+    eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr);
+    for (int i = tid; i < 3 * at.M; i += MOSHII_TPB) out[(size_t)f * 3 * at.M + i] = cx.msim[i];
+}
+
+}  // namespace moshii
+
+extern "C" hipError_t moshii_launch_chain_solve(int nblk, int n_chains, size_t lds_bytes, hipStream_t stream,
+                                                const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
+                                                const OptsDev* op, const ChainLayout* ly) {
+    using namespace moshii;
+    void (*kern)(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout) = nullptr;
+    switch (nblk) {
+        case 2: kern = k_chain_solve<2>; break;
+        case 4: kern = k_chain_solve<4>; break;
+        case 5: kern = k_chain_solve<5>; break;
+        case 7: kern = k_chain_solve<7>; break;
+        case 8: kern = k_chain_solve<8>; break;
+        default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(MOSHII_TPB), lds_bytes, stream, chains, *md, *pr, *op, *ly);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t stream, const AttachDev* att,
+                                            const ModelDev* md, const ChainLayout* ly, const double* pose,
+                                            const double* trans, double* out) {
+    using namespace moshii;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_markers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_markers, dim3(F), dim3(MOSHII_TPB), lds_bytes, stream, att, *md, *ly, pose, trans, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,728 @@
+// libmoshii C ABI (include/moshii.h): handles, setup kernels, host-side staging and launch logic.
+#include "../../include/moshii.h"
+#include "moshii_dev.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" hipError_t moshii_launch_chain_solve(int nblk, int n_chains, size_t lds_bytes, hipStream_t stream,
+                                                const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
+                                                const OptsDev* op, const ChainLayout* ly);
+extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t stream, const AttachDev* att,
+                                            const ModelDev* md, const ChainLayout* ly, const double* pose,
+                                            const double* trans, double* out);
+extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* md, int F, const float* pose,
+                                            const float* trans, float* verts, const void* lbs32);
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(MOSHII_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+template <class T>
+int dev_upload(const T* host, size_t n, T** out) {
+    *out = nullptr;
+    if (n == 0) return MOSHII_OK;
+    HIP_TRY(hipMalloc((void**)out, n * sizeof(T)));
+    HIP_TRY(hipMemcpy(*out, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return MOSHII_OK;
+}
+
+struct Scratch {   // growable device buffer reused across calls (small control data)
+    char* ptr = nullptr;
+    size_t cap = 0;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    int reserve(size_t bytes) {
+        if (used) { hipStreamSynchronize(last_stream); used = false; }
+        if (bytes <= cap) return MOSHII_OK;
+        if (ptr) hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        size_t want = std::max<size_t>(bytes, 1 << 16);
+        if (hipMalloc((void**)&ptr, want) != hipSuccess) return fail(MOSHII_ERR_HIP, "scratch hipMalloc failed");
+        cap = want;
+        return MOSHII_OK;
+    }
+    ~Scratch() { if (ptr) hipFree(ptr); }
+};
+
+}  // namespace
+
+// single-precision copy of the model for the HBM-bound export kernel (lbs_forward.hip)
+struct Lbs32Model {
+    float* v_shaped = nullptr;     // [V][3]
+    float* posedirs_t = nullptr;   // [9(K-1)][3][Vp]  vertex fastest
+    float* weights = nullptr;      // [K][Vp] vertex fastest (dense)
+    float* J = nullptr;            // [K][3]
+    int Vp = 0;
+};
+
+struct moshii_model_s {
+    int V = 0, K = 0, NB = 0, P = 0, NP = 0, body_dof = 0, hand_dof = 0, nhand_full = 0, maxdepth = 0;
+    std::vector<int> parents, depth;
+    std::vector<double> weights_host;   // [V][K] (attachment packing)
+    double *d_vt = nullptr, *d_shapedirs = nullptr, *d_posedirs = nullptr, *d_weights = nullptr, *d_Jreg = nullptr;
+    double *d_vsh = nullptr, *d_J = nullptr, *d_hands_mean = nullptr, *d_comps = nullptr;
+    int *d_parents = nullptr, *d_depth = nullptr, *d_comp_lo = nullptr, *d_comp_hi = nullptr;
+    unsigned long long* d_anc = nullptr;
+    bool betas_set = false;
+    Lbs32Model l32;
+    bool l32_valid = false;
+    Scratch scratch;
+    ModelDev dev() const {
+        ModelDev md;
+        md.V = V; md.K = K; md.P = P; md.NP = NP; md.body_dof = body_dof; md.hand_dof = hand_dof;
+        md.nhand_full = nhand_full; md.maxdepth = maxdepth;
+        md.parents = d_parents; md.J = d_J; md.hands_mean = d_hands_mean; md.comps = d_comps;
+        md.comp_lo = d_comp_lo; md.comp_hi = d_comp_hi; md.anc = d_anc; md.depth = d_depth;
+        return md;
+    }
+};
+
+struct moshii_prior_s {
+    int G = 0, npose = 0;
+    double *d_means = nullptr, *d_chols = nullptr, *d_halfprec = nullptr, *d_neglogw = nullptr;
+    PriorDev dev() const { PriorDev p; p.G = G; p.npose = npose; p.means = d_means; p.chols = d_chols; p.halfprec = d_halfprec; p.neglogw = d_neglogw; return p; }
+};
+
+struct moshii_attach_s {
+    moshii_model_t model = nullptr;
+    int M = 0, Nv = 0, Nvp = 0, NW = 0;
+    double *d_vsh = nullptr, *d_Pt = nullptr, *d_ww = nullptr, *d_coef = nullptr;
+    int* d_wj = nullptr;
+    int* d_vids = nullptr;
+    AttachDev* d_self = nullptr;
+    AttachDev host_view;
+};
+
+namespace {
+
+// ---- setup kernels --------------------------------------------------------------------------
+__global__ void k_vshaped(int V, int NB, int nb, const double* __restrict__ vt, const double* __restrict__ sd,
+                          const double* __restrict__ betas, double* __restrict__ vsh) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (v, i)
+    if (idx >= V * 3) return;
+    const double* row = sd + (size_t)idx * NB;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += row[b] * betas[b];
+    vsh[idx] = vt[idx] + s;
+}
+
+__global__ void k_joints(int V, const double* __restrict__ Jreg, const double* __restrict__ vsh, double* __restrict__ J) {
+    const int k = blockIdx.x;
+    __shared__ double red[3][256];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const double w = Jreg[(size_t)k * V + v];
+        if (w != 0.0) { s[0] += w * vsh[v * 3 + 0]; s[1] += w * vsh[v * 3 + 1]; s[2] += w * vsh[v * 3 + 2]; }
+    }
+    for (int i = 0; i < 3; ++i) red[i][threadIdx.x] = s[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) for (int i = 0; i < 3; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) J[k * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void k_pack_attach(int Nv, int Nvp, int K, const int* __restrict__ vids, const double* __restrict__ posedirs,
+                              const double* __restrict__ vsh, double* __restrict__ Pt, double* __restrict__ vsh_out) {
+    const int nfeat = 9 * (K - 1);
+    const size_t total = (size_t)(K - 1) * 27 * Nvp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int a = (int)(idx % Nvp);
+        const int r = (int)(idx / Nvp);           // (k-1)*27 + i*9 + e
+        double v = 0.0;
+        if (a < Nv) {
+            const int km1 = r / 27, i = (r % 27) / 9, e = r % 9;
+            v = posedirs[((size_t)vids[a] * 3 + i) * nfeat + 9 * km1 + e];
+        }
+        Pt[idx] = v;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Nv * 3) vsh_out[t] = vsh[(size_t)vids[t / 3] * 3 + t % 3];
+}
+
+// Reference-precision full-mesh LBS: one block = 256 vertices of one frame.
+__global__ void k_lbs_f64(ModelDev md, const double* __restrict__ vsh, const double* __restrict__ posedirs,
+                          const double* __restrict__ weights, const double* __restrict__ pose,
+                          const double* __restrict__ trans, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int K = md.K, P = md.P;
+    double* fullpose = sm;            // P
+    double* Rl = fullpose + P;        // K*9
+    double* Rw = Rl + K * 9;          // K*9
+    double* tw = Rw + K * 9;          // K*3
+    double* feat = tw + K * 3;        // K*9
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const double* ps = pose + (size_t)f * md.NP;
+    for (int d = tid; d < P; d += blockDim.x) {
+        double v;
+        if (d < md.body_dof) v = ps[d];
+        else {
+            const int h = d - md.body_dof;
+            v = md.hands_mean[h];
+            for (int i = 0; i < md.hand_dof; ++i) v += ps[md.body_dof + i] * md.comps[i * md.nhand_full + h];
+        }
+        fullpose[d] = v;
+    }
+    __syncthreads();
+    if (tid < K) {
+        const double x = fullpose[3 * tid], y = fullpose[3 * tid + 1], z = fullpose[3 * tid + 2];
+        const double t2 = x * x + y * y + z * z;
+        double a, b;
+        if (t2 < 1e-6) { a = 1.0 - t2 / 6.0 + t2 * t2 / 120.0; b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0; }
+        else { const double t = sqrt(t2); a = sin(t) / t; b = (1.0 - cos(t)) / t2; }
+        const double K2[9] = {x * x - t2, x * y, x * z, x * y, y * y - t2, y * z, x * z, y * z, z * z - t2};
+        const double Km[9] = {0.0, -z, y, z, 0.0, -x, -y, x, 0.0};
+        for (int e = 0; e < 9; ++e) {
+            const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+            const double r = id + a * Km[e] + b * K2[e];
+            Rl[tid * 9 + e] = r;
+            feat[tid * 9 + e] = r - id;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {   // serial chain: K <= 64 joints
+        for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];
+        for (int i = 0; i < 3; ++i) tw[i] = md.J[i];
+        for (int k = 1; k < K; ++k) {
+            const int p = md.parents[k];
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j)
+                    Rw[k * 9 + i * 3 + j] = Rw[p * 9 + i * 3 + 0] * Rl[k * 9 + 0 * 3 + j] + Rw[p * 9 + i * 3 + 1] * Rl[k * 9 + 1 * 3 + j] +
+                                            Rw[p * 9 + i * 3 + 2] * Rl[k * 9 + 2 * 3 + j];
+                tw[k * 3 + i] = Rw[p * 9 + i * 3 + 0] * (md.J[k * 3 + 0] - md.J[p * 3 + 0]) + Rw[p * 9 + i * 3 + 1] * (md.J[k * 3 + 1] - md.J[p * 3 + 1]) +
+                                Rw[p * 9 + i * 3 + 2] * (md.J[k * 3 + 2] - md.J[p * 3 + 2]) + tw[p * 3 + i];
+            }
+        }
+    }
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + tid;
+    if (v >= md.V) return;
+    const int nfeat = 9 * (K - 1);
+    double vp[3];
+    for (int i = 0; i < 3; ++i) {
+        const double* row = posedirs + ((size_t)v * 3 + i) * nfeat;
+        double s = 0.0;
+        for (int q = 0; q < nfeat; ++q) s += row[q] * feat[9 + q];
+        vp[i] = vsh[v * 3 + i] + s;
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int j = 0; j < K; ++j) {
+        const double w = weights[(size_t)v * K + j];
+        if (w == 0.0) continue;
+        const double dx = vp[0] - md.J[j * 3 + 0], dy = vp[1] - md.J[j * 3 + 1], dz = vp[2] - md.J[j * 3 + 2];
+        for (int i = 0; i < 3; ++i)
+            acc[i] += w * (Rw[j * 9 + i * 3 + 0] * dx + Rw[j * 9 + i * 3 + 1] * dy + Rw[j * 9 + i * 3 + 2] * dz + tw[j * 3 + i]);
+    }
+    const double* tr = trans + (size_t)f * 3;
+    double* o = out + ((size_t)f * md.V + v) * 3;
+    o[0] = acc[0] + tr[0]; o[1] = acc[1] + tr[1]; o[2] = acc[2] + tr[2];
+}
+
+// ---- LDS layout of the chain kernel ------------------------------------------------------------
+int pick_nblk(int n) {
+    const int opts[5] = {2, 4, 5, 7, 8};
+    for (int o : opts) if (o * 16 >= n) return o;
+    return -1;
+}
+
+ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm) {
+    ChainLayout ly;
+    memset(&ly, 0, sizeof(ly));
+    const int K = m->K, NP = m->NP, P = m->P;
+    const int nblk = pick_nblk(nmax);
+    const int LDJ = nblk * 16;
+    ly.Mmax = Mmax; ly.Nvmax = Nvmax; ly.NWmax = NWmax; ly.nmax = nmax; ly.Tm = Tm; ly.nkfmax = nkfmax; ly.LDJ = LDJ;
+    int off = 0;
+    auto take = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
+    ly.o_pose = take(NP); ly.o_trans = take(4); ly.o_pose_t = take(NP); ly.o_trans_t = take(4);
+    ly.o_pose_prev = take(NP); ly.o_vtarget = take(NP); ly.o_fullpose = take(P);
+    ly.o_feat = take(K * 9); ly.o_B = take(K * 27); ly.o_omega = take(K * 9); ly.o_Rw = take(K * 9); ly.o_tw = take(K * 3);
+    ly.o_Rloc = take(K * 9); ly.o_acol = take(K * 9);
+    ly.o_vposed = take(Nvmax * 3); ly.o_vpos = take(Nvmax * 3); ly.o_msim = take(Mmax * 3); ly.o_res = take(Mmax * 3);
+    ly.o_xb = take(std::max(npose, 1)); ly.o_ell = take(std::max(G * npose, 1)); ly.o_score = take(std::max(G, 1));
+    ly.o_g = take(LDJ); ly.o_dsd = take(LDJ); ly.o_dgn = take(LDJ); ly.o_ddl = take(LDJ); ly.o_y = take(LDJ);
+    ly.o_red = take(16); ly.o_scal = take(16);
+    ly.o_anc = take(K);
+    int io = 0;
+    auto itake = [&](int ni) { int o = io; io += ni; return o; };
+    ly.i_visidx = itake(Mmax); ly.i_colpid = itake(LDJ); ly.i_colprior = itake(LDJ); ly.i_pid2prior = itake(NP);
+    ly.i_jointslot = itake(K); ly.i_kfree = itake(K);
+    ly.i_total = io;
+    ly.o_ints = take((io + 1) / 2);
+    int t = 0;
+    auto ttake = [&](int nd) { int o = t; t += (nd + 1) & ~1; return o; };
+    ly.t_Jv = ttake(3 * Tm * nkfmax * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 27);
+    ly.t_Trot = ttake(3 * Tm * 9); ly.t_xjs = ttake(3 * Tm * NWmax * 3); ly.t_rest = ttake(3 * Tm);
+    const int chol = (nmax + 1) * (nmax + 2) / 2;
+    ly.big_doubles = std::max(t, chol);
+    ly.o_big = take(ly.big_doubles);
+    ly.total_doubles = off;
+    return ly;
+}
+
+struct LaunchInfo { std::string name; int lds = 0; int threads = 0; } g_last;
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* moshii_last_error(void) { return g_err.c_str(); }
+int moshii_version(void) { return 100; }
+
+int moshii_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int moshii_set_device(int device) { HIP_TRY(hipSetDevice(device)); return MOSHII_OK; }
+
+int moshii_model_create(const moshii_model_desc* d, moshii_model_t* out) {
+    if (!d || !out) return fail(MOSHII_ERR_ARG, "null argument");
+    if (d->K < 1 || d->K > MOSHII_MAXK) return fail(MOSHII_ERR_UNSUPPORTED, "K must be in [1,64]");
+    if (moshii_device_count() < 1) return fail(MOSHII_ERR_NO_DEVICE, "no HIP device: libmoshii has no CPU path");
+    const int P = 3 * d->K;
+    if (d->body_dof < 3 || d->body_dof > P || d->body_dof % 3) return fail(MOSHII_ERR_ARG, "bad body_dof");
+    const int nhf = P - d->body_dof;
+    if ((d->hand_dof > 0) != (nhf > 0)) return fail(MOSHII_ERR_ARG, "hand_dof / body_dof mismatch");
+    if (d->hand_dof > 0 && (!d->hands_mean || !d->selected_components)) return fail(MOSHII_ERR_ARG, "hand PCA arrays missing");
+    auto* m = new moshii_model_s();
+    m->V = d->V; m->K = d->K; m->NB = d->NB; m->P = P; m->body_dof = d->body_dof; m->hand_dof = d->hand_dof;
+    m->nhand_full = nhf; m->NP = d->body_dof + d->hand_dof;
+    m->parents.assign(d->parents, d->parents + d->K);
+    m->depth.assign(d->K, 0);
+    std::vector<unsigned long long> anc(d->K, 0ull);
+    for (int j = 0; j < d->K; ++j) {
+        int a = j, dep = 0;
+        while (a >= 0) {
+            anc[a] |= (1ull << j);
+            const int p = m->parents[a];
+            if (p >= a) { delete m; return fail(MOSHII_ERR_ARG, "parents must precede children"); }
+            a = p;
+            if (a >= 0) ++dep;
+        }
+        m->depth[j] = dep;
+        m->maxdepth = std::max(m->maxdepth, dep);
+    }
+    m->weights_host.assign(d->weights, d->weights + (size_t)d->V * d->K);
+    const size_t V = d->V, K = d->K, nfeat = 9 * (K - 1);
+    int rc;
+    if ((rc = dev_upload(d->v_template, V * 3, &m->d_vt))) return rc;
+    if ((rc = dev_upload(d->shapedirs, V * 3 * d->NB, &m->d_shapedirs))) return rc;
+    if ((rc = dev_upload(d->posedirs, V * 3 * nfeat, &m->d_posedirs))) return rc;
+    if ((rc = dev_upload(d->weights, V * K, &m->d_weights))) return rc;
+    if ((rc = dev_upload(d->J_regressor, K * V, &m->d_Jreg))) return rc;
+    if ((rc = dev_upload(m->parents.data(), K, &m->d_parents))) return rc;
+    if ((rc = dev_upload(m->depth.data(), K, &m->d_depth))) return rc;
+    if ((rc = dev_upload(anc.data(), K, &m->d_anc))) return rc;
+    if (d->hand_dof > 0) {
+        std::vector<int> lo(d->hand_dof), hi(d->hand_dof);
+        for (int i = 0; i < d->hand_dof; ++i) {
+            int l = nhf, h = 0;
+            for (int c = 0; c < nhf; ++c)
+                if (d->selected_components[(size_t)i * nhf + c] != 0.0) { l = std::min(l, c); h = std::max(h, c + 1); }
+            if (l > h) { l = 0; h = 0; }
+            lo[i] = l; hi[i] = h;
+        }
+        if ((rc = dev_upload(d->hands_mean, (size_t)nhf, &m->d_hands_mean))) return rc;
+        if ((rc = dev_upload(d->selected_components, (size_t)d->hand_dof * nhf, &m->d_comps))) return rc;
+        if ((rc = dev_upload(lo.data(), lo.size(), &m->d_comp_lo))) return rc;
+        if ((rc = dev_upload(hi.data(), hi.size(), &m->d_comp_hi))) return rc;
+    }
+    HIP_TRY(hipMalloc((void**)&m->d_vsh, V * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&m->d_J, K * 3 * sizeof(double)));
+    *out = m;
+    std::vector<double> zero(std::max(1, d->NB), 0.0);
+    return moshii_model_set_betas(m, zero.data(), d->NB);
+}
+
+static void free_l32(moshii_model_s* m) {
+    if (m->l32.v_shaped) hipFree(m->l32.v_shaped);
+    if (m->l32.posedirs_t) hipFree(m->l32.posedirs_t);
+    if (m->l32.weights) hipFree(m->l32.weights);
+    if (m->l32.J) hipFree(m->l32.J);
+    m->l32 = Lbs32Model();
+    m->l32_valid = false;
+}
+
+int moshii_model_destroy(moshii_model_t m) {
+    if (!m) return MOSHII_OK;
+    hipDeviceSynchronize();
+    void* ptrs[] = {m->d_vt, m->d_shapedirs, m->d_posedirs, m->d_weights, m->d_Jreg, m->d_vsh, m->d_J, m->d_hands_mean,
+                    m->d_comps, m->d_parents, m->d_depth, m->d_comp_lo, m->d_comp_hi, m->d_anc};
+    for (void* p : ptrs) if (p) hipFree(p);
+    free_l32(m);
+    delete m;
+    return MOSHII_OK;
+}
+
+int moshii_model_set_betas(moshii_model_t m, const double* betas, int32_t nb) {
+    if (!m || (!betas && nb > 0)) return fail(MOSHII_ERR_ARG, "null argument");
+    nb = std::min<int32_t>(nb, m->NB);
+    double* d_b = nullptr;
+    int rc = dev_upload(betas, (size_t)std::max(nb, 0), &d_b);
+    if (rc) return rc;
+    const int tot = m->V * 3;
+    hipLaunchKernelGGL(k_vshaped, dim3((tot + 255) / 256), dim3(256), 0, 0, m->V, m->NB, nb, m->d_vt, m->d_shapedirs, d_b, m->d_vsh);
+    hipLaunchKernelGGL(k_joints, dim3(m->K), dim3(256), 0, 0, m->V, m->d_Jreg, m->d_vsh, m->d_J);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (d_b) hipFree(d_b);
+    m->betas_set = true;
+    m->l32_valid = false;
+    return MOSHII_OK;
+}
+
+int moshii_model_get_joints(moshii_model_t m, double* J_out) {
+    if (!m || !J_out) return fail(MOSHII_ERR_ARG, "null argument");
+    HIP_TRY(hipMemcpy(J_out, m->d_J, (size_t)m->K * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return MOSHII_OK;
+}
+
+int moshii_lbs_forward_f64(moshii_model_t m, int32_t F, const double* pose, const double* trans, double* verts,
+                           uint32_t flags, void* stream_) {
+    if (!m || !pose || !trans || !verts || F < 0) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (F == 0) return MOSHII_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
+    const double *d_pose = pose, *d_trans = trans;
+    double* d_out = verts;
+    double *t_pose = nullptr, *t_trans = nullptr, *t_out = nullptr;
+    if (!dev) {
+        int rc;
+        if ((rc = dev_upload(pose, (size_t)F * m->NP, &t_pose))) return rc;
+        if ((rc = dev_upload(trans, (size_t)F * 3, &t_trans))) return rc;
+        HIP_TRY(hipMalloc((void**)&t_out, (size_t)F * m->V * 3 * sizeof(double)));
+        d_pose = t_pose; d_trans = t_trans; d_out = t_out;
+    }
+    const size_t lds = (size_t)(m->P + m->K * 30) * sizeof(double);
+    hipLaunchKernelGGL(k_lbs_f64, dim3((m->V + 255) / 256, F), dim3(256), lds, stream, m->dev(), m->d_vsh, m->d_posedirs,
+                       m->d_weights, d_pose, d_trans, d_out);
+    HIP_TRY(hipGetLastError());
+    if (!dev) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(verts, t_out, (size_t)F * m->V * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        hipFree(t_pose); hipFree(t_trans); hipFree(t_out);
+    }
+    return MOSHII_OK;
+}
+
+// implemented in lbs_forward.hip
+int moshii_lbs32_prepare(moshii_model_t m);
+
+int moshii_lbs_forward_f32(moshii_model_t m, int32_t F, const float* pose, const float* trans, float* verts,
+                           uint32_t flags, void* stream_) {
+    if (!m || !pose || !trans || !verts || F < 0) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (F == 0) return MOSHII_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!m->l32_valid) { int rc = moshii_lbs32_prepare(m); if (rc) return rc; }
+    const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
+    const float *d_pose = pose, *d_trans = trans;
+    float* d_out = verts;
+    float *t_pose = nullptr, *t_trans = nullptr, *t_out = nullptr;
+    if (!dev) {
+        int rc;
+        if ((rc = dev_upload(pose, (size_t)F * m->NP, &t_pose))) return rc;
+        if ((rc = dev_upload(trans, (size_t)F * 3, &t_trans))) return rc;
+        HIP_TRY(hipMalloc((void**)&t_out, (size_t)F * m->V * 3 * sizeof(float)));
+        d_pose = t_pose; d_trans = t_trans; d_out = t_out;
+    }
+    ModelDev md = m->dev();
+    HIP_TRY(moshii_launch_lbs_f32(stream, &md, F, d_pose, d_trans, d_out, &m->l32));
+    if (!dev) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(verts, t_out, (size_t)F * m->V * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        hipFree(t_pose); hipFree(t_trans); hipFree(t_out);
+    }
+    return MOSHII_OK;
+}
+
+int moshii_prior_create(int32_t G, int32_t npose, const double* means, const double* chols, const double* weights,
+                        moshii_prior_t* out) {
+    if (!means || !chols || !weights || !out || G < 1 || npose < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (moshii_device_count() < 1) return fail(MOSHII_ERR_NO_DEVICE, "no HIP device: libmoshii has no CPU path");
+    auto* p = new moshii_prior_s();
+    p->G = G; p->npose = npose;
+    const size_t nn = (size_t)npose * npose;
+    std::vector<double> half((size_t)G * nn), nlw(G);
+    for (int g = 0; g < G; ++g) {
+        const double* L = chols + g * nn;
+        for (int i = 0; i < npose; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = 0.0;
+                for (int a = 0; a <= j; ++a) s += L[(size_t)i * npose + a] * L[(size_t)j * npose + a];   // (L L^T)_ij, L lower
+                half[g * nn + (size_t)i * npose + j] = 0.5 * s;
+                half[g * nn + (size_t)j * npose + i] = 0.5 * s;
+            }
+        nlw[g] = -std::log(weights[g]);
+    }
+    int rc;
+    if ((rc = dev_upload(means, (size_t)G * npose, &p->d_means))) return rc;
+    if ((rc = dev_upload(chols, (size_t)G * nn, &p->d_chols))) return rc;
+    if ((rc = dev_upload(half.data(), half.size(), &p->d_halfprec))) return rc;
+    if ((rc = dev_upload(nlw.data(), nlw.size(), &p->d_neglogw))) return rc;
+    *out = p;
+    return MOSHII_OK;
+}
+
+int moshii_prior_destroy(moshii_prior_t p) {
+    if (!p) return MOSHII_OK;
+    hipDeviceSynchronize();
+    void* ptrs[] = {p->d_means, p->d_chols, p->d_halfprec, p->d_neglogw};
+    for (void* q : ptrs) if (q) hipFree(q);
+    delete p;
+    return MOSHII_OK;
+}
+
+int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, const double* coef, moshii_attach_t* out) {
+    if (!m || !closest || !coef || !out || M < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (M > 128) return fail(MOSHII_ERR_UNSUPPORTED, "at most 128 latent markers");
+    auto* a = new moshii_attach_s();
+    a->model = m; a->M = M; a->Nv = 3 * M; a->Nvp = (a->Nv + 7) & ~7;
+    std::vector<int> vids(a->Nv);
+    int NW = 1;
+    for (int i = 0; i < a->Nv; ++i) {
+        vids[i] = closest[i];
+        if (vids[i] < 0 || vids[i] >= m->V) { delete a; return fail(MOSHII_ERR_ARG, "vertex id out of range"); }
+        int c = 0;
+        for (int j = 0; j < m->K; ++j) if (m->weights_host[(size_t)vids[i] * m->K + j] != 0.0) ++c;
+        NW = std::max(NW, c);
+    }
+    a->NW = NW;
+    std::vector<int> wj((size_t)a->Nv * NW, 0);
+    std::vector<double> ww((size_t)a->Nv * NW, 0.0);
+    for (int i = 0; i < a->Nv; ++i) {
+        int c = 0;
+        for (int j = 0; j < m->K; ++j) {
+            const double w = m->weights_host[(size_t)vids[i] * m->K + j];
+            if (w != 0.0) { wj[(size_t)i * NW + c] = j; ww[(size_t)i * NW + c] = w; ++c; }
+        }
+    }
+    int rc;
+    if ((rc = dev_upload(vids.data(), vids.size(), &a->d_vids))) return rc;
+    if ((rc = dev_upload(wj.data(), wj.size(), &a->d_wj))) return rc;
+    if ((rc = dev_upload(ww.data(), ww.size(), &a->d_ww))) return rc;
+    if ((rc = dev_upload(coef, (size_t)M * 3, &a->d_coef))) return rc;
+    HIP_TRY(hipMalloc((void**)&a->d_vsh, (size_t)a->Nv * 3 * sizeof(double)));
+    const size_t npt = (size_t)(m->K - 1) * 27 * a->Nvp;
+    HIP_TRY(hipMalloc((void**)&a->d_Pt, std::max<size_t>(npt, 1) * sizeof(double)));
+    const int blocks = (int)std::min<size_t>(4096, std::max<size_t>((npt + 255) / 256, (size_t)(a->Nv * 3 + 255) / 256));
+    hipLaunchKernelGGL(k_pack_attach, dim3(std::max(blocks, 1)), dim3(256), 0, 0, a->Nv, a->Nvp, m->K, a->d_vids, m->d_posedirs,
+                       m->d_vsh, a->d_Pt, a->d_vsh);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    AttachDev& av = a->host_view;
+    av.M = M; av.Nv = a->Nv; av.Nvp = a->Nvp; av.NW = NW;
+    av.vsh = a->d_vsh; av.Pt = a->d_Pt; av.wj = a->d_wj; av.ww = a->d_ww; av.coef = a->d_coef;
+    if ((rc = dev_upload(&av, 1, &a->d_self))) return rc;
+    *out = a;
+    return MOSHII_OK;
+}
+
+int moshii_attach_destroy(moshii_attach_t a) {
+    if (!a) return MOSHII_OK;
+    hipDeviceSynchronize();
+    void* ptrs[] = {a->d_vsh, a->d_Pt, a->d_ww, a->d_coef, a->d_wj, a->d_vids, a->d_self};
+    for (void* q : ptrs) if (q) hipFree(q);
+    delete a;
+    return MOSHII_OK;
+}
+
+int moshii_attach_markers(moshii_attach_t a, int32_t F, const double* pose, const double* trans, double* markers) {
+    if (!a || !pose || !trans || !markers || F < 0) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (F == 0) return MOSHII_OK;
+    moshii_model_t m = a->model;
+    ChainLayout ly = make_layout(m, a->M, a->Nv, a->NW, 0, 0, 16, 1, 1);
+    double *d_pose = nullptr, *d_trans = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = dev_upload(pose, (size_t)F * m->NP, &d_pose))) return rc;
+    if ((rc = dev_upload(trans, (size_t)F * 3, &d_trans))) return rc;
+    HIP_TRY(hipMalloc((void**)&d_out, (size_t)F * a->M * 3 * sizeof(double)));
+    ModelDev md = m->dev();
+    HIP_TRY(moshii_launch_markers(F, (size_t)ly.total_doubles * sizeof(double), 0, a->d_self, &md, &ly, d_pose, d_trans, d_out));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(markers, d_out, (size_t)F * a->M * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(d_pose); hipFree(d_trans); hipFree(d_out);
+    return MOSHII_OK;
+}
+
+int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* o, int32_t n_chains,
+                       const moshii_chain_desc* chains, uint32_t flags, void* stream_) {
+    if (!m || !o || !chains || n_chains < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (!m->betas_set) return fail(MOSHII_ERR_ARG, "moshii_model_set_betas has not been called");
+    if (o->n_body > 0 && (!prior || prior->npose != o->n_body)) return fail(MOSHII_ERR_ARG, "prior npose must equal n_body");
+    if (o->n_step1 < 0 || o->n_step2 < 0 || o->n_step1 > m->NP || o->n_step2 > m->NP) return fail(MOSHII_ERR_ARG, "bad free-variable lists");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
+    const int NP = m->NP, P = m->P;
+    const int nmax = 3 + std::max(o->n_step1, o->n_step2);
+    const int nblk = pick_nblk(nmax);
+    if (nblk < 0) return fail(MOSHII_ERR_UNSUPPORTED, "more than 125 free pose variables per step");
+    // needed joints (superset over both steps)
+    auto count_kf = [&](const int32_t* ids, int n) {
+        std::vector<char> need(m->K, 0);
+        for (int i = 0; i < n; ++i) {
+            if (ids[i] < 0 || ids[i] >= NP) return -1;
+            if (ids[i] < m->body_dof) need[ids[i] / 3] = 1;
+            else for (int k = m->body_dof / 3; k < m->K; ++k) need[k] = 1;
+        }
+        int c = 0; for (char b : need) c += b; return c;
+    };
+    const int kf1 = count_kf(o->step1_ids, o->n_step1), kf2 = count_kf(o->step2_ids, o->n_step2);
+    if (kf1 < 0 || kf2 < 0) return fail(MOSHII_ERR_ARG, "free pose id out of range");
+    const int nkfmax = std::max(1, std::max(kf1, kf2));
+    if (o->n_finger > 0)
+        for (int i = 1; i < o->n_finger; ++i)
+            if (o->finger_ids[i] != o->finger_ids[i - 1] + 1) return fail(MOSHII_ERR_UNSUPPORTED, "finger ids must be contiguous");
+    int Mmax = 0, Nvmax = 0, NWmax = 1;
+    for (int c = 0; c < n_chains; ++c) {
+        const moshii_chain_desc& ch = chains[c];
+        if (!ch.attach || ch.attach->model != m || ch.F < 0 || !ch.obs || !ch.vis) return fail(MOSHII_ERR_ARG, "bad chain descriptor");
+        Mmax = std::max(Mmax, ch.attach->M); Nvmax = std::max(Nvmax, ch.attach->Nv); NWmax = std::max(NWmax, ch.attach->NW);
+    }
+    const int G = prior ? prior->G : 0, npose = prior ? prior->npose : 0;
+    // marker-tile size: as large as fits the LDS budget
+    int budget = 64 * 1024;
+    if (const char* e = getenv("MOSHII_LDS_BUDGET")) budget = atoi(e);
+    int Tm = 16;
+    if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(32, atoi(e)));
+    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm);
+    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm); }
+    const size_t lds_bytes = (size_t)ly.total_doubles * sizeof(double);
+    if (lds_bytes > 160 * 1024) return fail(MOSHII_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of a CU");
+
+    // ---- control data -> scratch
+    size_t need = sizeof(ChainDev) * n_chains + sizeof(int) * (o->n_step1 + o->n_step2 + o->n_body + o->n_finger + 8) +
+                  sizeof(double) * (size_t)n_chains * (2 * NP + 4) + 256;
+    int rc = m->scratch.reserve(need);
+    if (rc) return rc;
+    std::vector<char> hostbuf(need, 0);
+    size_t off = 0;
+    auto put = [&](const void* src, size_t bytes) { off = (off + 15) & ~size_t(15); size_t o2 = off; if (src) memcpy(hostbuf.data() + off, src, bytes); off += bytes; return o2; };
+    const size_t o_step1 = put(o->step1_ids, sizeof(int) * o->n_step1);
+    const size_t o_step2 = put(o->step2_ids, sizeof(int) * o->n_step2);
+    const size_t o_body = put(o->body_ids, sizeof(int) * o->n_body);
+    const size_t o_finger = put(o->finger_ids, sizeof(int) * o->n_finger);
+    std::vector<size_t> o_ip(n_chains, (size_t)-1), o_it(n_chains, (size_t)-1), o_iv(n_chains, (size_t)-1);
+    for (int c = 0; c < n_chains; ++c) {
+        if (chains[c].init_pose) o_ip[c] = put(chains[c].init_pose, sizeof(double) * NP);
+        if (chains[c].init_trans) o_it[c] = put(chains[c].init_trans, sizeof(double) * 3);
+        if (chains[c].init_pose_prev) o_iv[c] = put(chains[c].init_pose_prev, sizeof(double) * NP);
+    }
+    const size_t o_chains = put(nullptr, sizeof(ChainDev) * n_chains);
+    if (off > need) return fail(MOSHII_ERR_ARG, "internal: scratch overflow");
+    char* dbase = m->scratch.ptr;
+
+    struct Staged { double *obs, *pose, *fullpose, *trans, *msim, *errs; uint8_t* vis; int *iters, *status; };
+    std::vector<Staged> st(dev ? 0 : n_chains);
+    std::vector<ChainDev> cds(n_chains);
+    for (int c = 0; c < n_chains; ++c) {
+        const moshii_chain_desc& ch = chains[c];
+        ChainDev& cd = cds[c];
+        const int M = ch.attach->M, F = ch.F;
+        cd.att = ch.attach->d_self; cd.F = F; cd.first = ch.first_frame_schedule;
+        cd.init_pose = (o_ip[c] == (size_t)-1) ? nullptr : (const double*)(dbase + o_ip[c]);
+        cd.init_trans = (o_it[c] == (size_t)-1) ? nullptr : (const double*)(dbase + o_it[c]);
+        cd.init_prev = (o_iv[c] == (size_t)-1) ? nullptr : (const double*)(dbase + o_iv[c]);
+        if (dev) {
+            cd.obs = ch.obs; cd.vis = ch.vis; cd.pose = ch.pose; cd.fullpose = ch.fullpose; cd.trans = ch.trans;
+            cd.msim = ch.markers_sim; cd.errs = ch.errs; cd.iters = ch.iters; cd.status = ch.status;
+        } else {
+            Staged& s = st[c];
+            memset(&s, 0, sizeof(s));
+            const size_t Fz = std::max(F, 1);
+            if ((rc = dev_upload(ch.obs, (size_t)F * M * 3, &s.obs))) return rc;
+            if ((rc = dev_upload(ch.vis, (size_t)F * M, &s.vis))) return rc;
+            HIP_TRY(hipMalloc((void**)&s.pose, Fz * NP * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&s.fullpose, Fz * P * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&s.trans, Fz * 3 * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&s.msim, Fz * M * 3 * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&s.errs, Fz * 4 * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&s.iters, Fz * 2 * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&s.status, Fz * sizeof(int)));
+            HIP_TRY(hipMemsetAsync(s.pose, 0, Fz * NP * sizeof(double), stream));
+            HIP_TRY(hipMemsetAsync(s.fullpose, 0, Fz * P * sizeof(double), stream));
+            HIP_TRY(hipMemsetAsync(s.trans, 0, Fz * 3 * sizeof(double), stream));
+            HIP_TRY(hipMemsetAsync(s.msim, 0, Fz * M * 3 * sizeof(double), stream));
+            HIP_TRY(hipMemsetAsync(s.errs, 0, Fz * 4 * sizeof(double), stream));
+            HIP_TRY(hipMemsetAsync(s.iters, 0, Fz * 2 * sizeof(int), stream));
+            HIP_TRY(hipMemsetAsync(s.status, 0, Fz * sizeof(int), stream));
+            cd.obs = s.obs; cd.vis = s.vis; cd.pose = s.pose; cd.fullpose = s.fullpose; cd.trans = s.trans;
+            cd.msim = s.msim; cd.errs = s.errs; cd.iters = s.iters; cd.status = s.status;
+        }
+    }
+    memcpy(hostbuf.data() + o_chains, cds.data(), sizeof(ChainDev) * n_chains);
+    HIP_TRY(hipMemcpyAsync(dbase, hostbuf.data(), off, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));   // hostbuf is pageable and goes out of scope
+    m->scratch.used = true; m->scratch.last_stream = stream;
+
+    OptsDev od;
+    od.wt_data = o->wt_data; od.wt_velo = o->wt_velo; od.wt_poseB = o->wt_poseB; od.wt_poseH = o->wt_poseH;
+    od.wt_annealing = o->wt_annealing; od.num_train_markers = o->num_train_markers;
+    od.e3_first = o->e3_first; od.e3 = o->e3; od.delta0 = o->delta0; od.maxiter = o->maxiter;
+    od.n1 = o->n_step1; od.n2 = o->n_step2; od.nbody = o->n_body; od.nfinger = o->n_finger;
+    od.step1 = (const int*)(dbase + o_step1); od.step2 = (const int*)(dbase + o_step2);
+    od.body = (const int*)(dbase + o_body); od.finger = (const int*)(dbase + o_finger);
+    PriorDev pd;
+    memset(&pd, 0, sizeof(pd));
+    if (prior) pd = prior->dev();
+    ModelDev md = m->dev();
+    HIP_TRY(moshii_launch_chain_solve(nblk, n_chains, lds_bytes, stream, (const ChainDev*)(dbase + o_chains), &md, &pd, &od, &ly));
+    g_last.name = "k_chain_solve<" + std::to_string(nblk) + ">";
+    g_last.lds = (int)lds_bytes; g_last.threads = MOSHII_TPB;
+    if (!dev) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < n_chains; ++c) {
+            const moshii_chain_desc& ch = chains[c];
+            Staged& s = st[c];
+            const size_t F = ch.F, M = ch.attach->M;
+            if (F) {
+                if (ch.pose) HIP_TRY(hipMemcpy(ch.pose, s.pose, F * NP * sizeof(double), hipMemcpyDeviceToHost));
+                if (ch.fullpose) HIP_TRY(hipMemcpy(ch.fullpose, s.fullpose, F * P * sizeof(double), hipMemcpyDeviceToHost));
+                if (ch.trans) HIP_TRY(hipMemcpy(ch.trans, s.trans, F * 3 * sizeof(double), hipMemcpyDeviceToHost));
+                if (ch.markers_sim) HIP_TRY(hipMemcpy(ch.markers_sim, s.msim, F * M * 3 * sizeof(double), hipMemcpyDeviceToHost));
+                if (ch.errs) HIP_TRY(hipMemcpy(ch.errs, s.errs, F * 4 * sizeof(double), hipMemcpyDeviceToHost));
+                if (ch.iters) HIP_TRY(hipMemcpy(ch.iters, s.iters, F * 2 * sizeof(int), hipMemcpyDeviceToHost));
+                if (ch.status) HIP_TRY(hipMemcpy(ch.status, s.status, F * sizeof(int), hipMemcpyDeviceToHost));
+            }
+            void* ptrs[] = {s.obs, s.vis, s.pose, s.fullpose, s.trans, s.msim, s.errs, s.iters, s.status};
+            for (void* q : ptrs) if (q) hipFree(q);
+        }
+    }
+    return MOSHII_OK;
+}
+
+int moshii_last_launch_info(char* kernel_name, int32_t name_cap, int32_t* lds_bytes, int32_t* block_threads) {
+    if (kernel_name && name_cap > 0) { strncpy(kernel_name, g_last.name.c_str(), name_cap - 1); kernel_name[name_cap - 1] = 0; }
+    if (lds_bytes) *lds_bytes = g_last.lds;
+    if (block_threads) *block_threads = g_last.threads;
+    return MOSHII_OK;
+}
+
+}  // extern "C"
+
+// accessors for lbs_forward.hip (keeps the handle layout private to this file)
+extern "C" {
+int moshii_internal_model_dims(moshii_model_t m, int* V, int* K) { *V = m->V; *K = m->K; return 0; }
+const double* moshii_internal_vsh(moshii_model_t m) { return m->d_vsh; }
+const double* moshii_internal_posedirs(moshii_model_t m) { return m->d_posedirs; }
+const double* moshii_internal_weights(moshii_model_t m) { return m->d_weights; }
+const double* moshii_internal_J(moshii_model_t m) { return m->d_J; }
+void* moshii_internal_l32(moshii_model_t m) { return &m->l32; }
+void moshii_internal_l32_set_valid(moshii_model_t m, int v) { m->l32_valid = v != 0; }
+}

@@ -1,0 +1,83 @@
+// Internal device-side structures of libmoshii (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MOSHII_MAXK 64      // joints (ancestor sets are 64-bit masks)
+#define MOSHII_TPB 256      // threads per chain workgroup: 4 waves, one per SIMD
+
+struct ModelDev {
+    int V, K, P, NP, body_dof, hand_dof, nhand_full, maxdepth;
+    const int* parents;              // [K]
+    const double* J;                 // [K][3] regressed joints (current betas)
+    const double* hands_mean;        // [nhand_full]
+    const double* comps;             // [hand_dof][nhand_full]
+    const int* comp_lo;              // [hand_dof] first non-zero column of each component row
+    const int* comp_hi;              // [hand_dof] one past the last non-zero column
+    const unsigned long long* anc;   // [K] bit j set iff k is j or an ancestor of j
+    const int* depth;                // [K]
+};
+
+struct AttachDev {
+    int M, Nv, Nvp, NW;
+    const double* vsh;     // [Nv][3] v_shaped rows of the attached vertices (a = 3*m + s)
+    const double* Pt;      // [(K-1)*27][Nvp] posedirs slice, vertex index fastest
+    const int* wj;         // [Nv][NW] joints with non-zero skinning weight (padded: joint 0, weight 0)
+    const double* ww;      // [Nv][NW]
+    const double* coef;    // [M][3]
+};
+
+struct PriorDev {
+    int G, npose;
+    const double* means;     // [G][npose]
+    const double* chols;     // [G][npose][npose] lower, L L^T = precision
+    const double* halfprec;  // [G][npose][npose] 0.5 * L L^T
+    const double* neglogw;   // [G] -log(weight)
+};
+
+struct OptsDev {
+    double wt_data, wt_velo, wt_poseB, wt_poseH, wt_annealing, num_train_markers;
+    double e3_first, e3, delta0;
+    int maxiter, n1, n2, nbody, nfinger;
+    const int* step1;
+    const int* step2;
+    const int* body;
+    const int* finger;
+};
+
+struct ChainDev {
+    const AttachDev* att;
+    int F, first;
+    const double* obs;
+    const uint8_t* vis;
+    const double* init_pose;
+    const double* init_trans;
+    const double* init_prev;
+    double* pose;
+    double* fullpose;
+    double* trans;
+    double* msim;
+    double* errs;
+    int* iters;
+    int* status;
+};
+
+// LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).
+struct ChainLayout {
+    int Mmax, Nvmax, NWmax, nmax, Tm, nkfmax, LDJ;
+    int o_pose, o_trans, o_pose_t, o_trans_t, o_pose_prev, o_vtarget, o_fullpose;
+    int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol;
+    int o_vposed, o_vpos, o_msim, o_res;
+    int o_xb, o_ell, o_score;
+    int o_g, o_dsd, o_dgn, o_ddl, o_y;
+    int o_red, o_scal;
+    int o_anc;                 // K x u64
+    int o_ints;                // int region (offset in doubles)
+    int o_big;                 // union: packed Cholesky factor | Jacobian tiles
+    int big_doubles;
+    int total_doubles;
+    // int region sub-offsets (in ints)
+    int i_visidx, i_colpid, i_colprior, i_pid2prior, i_jointslot, i_kfree, i_total;
+    // tile sub-offsets inside big (in doubles)
+    int t_Jv, t_Jrow, t_Lm, t_Trot, t_xjs, t_rest;
+};
