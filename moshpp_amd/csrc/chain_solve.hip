@@ -652,151 +652,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// chumpy's minimize_dogleg over x = [trans, pose[ids]]  (oracle/stageii_oracle.py:minimize_dogleg)
-// ------------------------------------------------------------------------------------------------
-template <int NBLK>
-__device__ void dogleg(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
-                       const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, double e3,
-                       int& n_iter, int& n_fev, int& fail) {
-    const int tid = threadIdx.x;
-    const int n = 3 + nids;
-    // column tables + needed-joint list
-    for (int q = tid; q < n; q += MOSHII_TPB) {
-        const int pid = (q < 3) ? -1 : ids[q - 3];
-        cx.colpid[q] = pid;
-        cx.colprior[q] = (pid >= 0) ? cx.pid2prior[pid] : -1;
-    }
-    if (tid == 0) {
-        for (int k = 0; k < md.K; ++k) cx.jointslot[k] = -1;
-        for (int i = 0; i < nids; ++i) {
-            const int pid = ids[i];
-            if (pid < md.body_dof) cx.jointslot[pid / 3] = 0;
-            else for (int k = md.body_dof / 3; k < md.K; ++k) cx.jointslot[k] = 0;
-        }
-        int c = 0;
-        for (int k = 0; k < md.K; ++k) if (cx.jointslot[k] == 0) { cx.jointslot[k] = c; cx.kfree[c] = k; ++c; }
-        cx.scal[S_TMP0] = (double)c;
-    }
-    __syncthreads();
-    const int nkf = (int)cx.scal[S_TMP0];
-    AReg<NBLK> A;
-    Sse cur = eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, visrow);
-    ++n_fev;
-    assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, A);
-    double sse = cur.total;
-    double delta = op.delta0;
-    bool done = false;
-    {
-        double gm = 0.0;
-        for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
-        if (block_max(gm, cx.red) < 1e-15) done = true;
-    }
-    int iteration = 0;
-    while (!done) {
-        ++iteration;
-        // steepest descent: d_sd = |g|^2 / |J g|^2 g, |J g|^2 = g^T A g
-        double gg = 0.0;
-        for (int q = tid; q < n; q += MOSHII_TPB) gg += cx.g[q] * cx.g[q];
-        double gAg = A.quad_partial(cx.g, n);
-        double dummy = 0.0;
-        block_sum3(gg, gAg, dummy, cx.red);
-        const double csd = gg / gAg;
-        const double norm_sd = fabs(csd) * sqrt(gg);
-        for (int q = tid; q < n; q += MOSHII_TPB) cx.dsd[q] = csd * cx.g[q];
-        bool have_gn = false, gn_ok = true;
-        double norm_gn = 0.0;
-        __syncthreads();
-        while (true) {
-            // ---- update_step
-            if (norm_sd >= delta) {
-                const double sc = delta / norm_sd;
-                for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = sc * cx.dsd[q];
-            } else {
-                if (!have_gn) {
-                    A.store_packed(cx.big, n);
-                    __syncthreads();
-                    gn_ok = chol_solve(cx.big, cx.g, cx.dgn, cx.scal, n);
-                    if (!gn_ok) { fail = 1; for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q]; __syncthreads(); }
-                    double s = 0.0;
-                    for (int q = tid; q < n; q += MOSHII_TPB) s += cx.dgn[q] * cx.dgn[q];
-                    norm_gn = sqrt(block_sum(s, cx.red));
-                    have_gn = true;
-                }
-                if (norm_gn <= delta) {
-                    for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dgn[q];
-                } else {
-                    double dd = 0.0, gs = 0.0, ds = 0.0;
-                    for (int q = tid; q < n; q += MOSHII_TPB) {
-                        const double df = cx.dgn[q] - cx.dsd[q];
-                        dd += df * df; gs += cx.dgn[q] * cx.dsd[q]; ds += df * cx.dsd[q];
-                    }
-                    block_sum3(dd, gs, ds, cx.red);
-                    const double delta_sq = delta * delta;
-                    const double sqnorm_sd = norm_sd * norm_sd;
-                    const double pnow = dd * delta_sq + gs * gs - (norm_gn * norm_gn) * sqnorm_sd;
-                    const double beta = (delta_sq - sqnorm_sd) / (ds + sqrt(pnow));
-                    for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dsd[q] + beta * (cx.dgn[q] - cx.dsd[q]);
-                }
-            }
-            __syncthreads();
-            // ---- trial point and norms
-            double s2 = 0.0, p2 = 0.0, gd = 0.0;
-            for (int q = tid; q < n; q += MOSHII_TPB) {
-                const double dq = cx.ddl[q];
-                const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
-                s2 += dq * dq; p2 += pq * pq; gd += cx.g[q] * dq;
-            }
-            block_sum3(s2, p2, gd, cx.red);
-            const double step = sqrt(s2);
-            bool improved = false;
-            if (step <= 1e-15 * sqrt(p2)) {
-                done = true;
-            } else {
-                for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
-                if (tid < 3) cx.trans_t[tid] = cx.trans[tid] + cx.ddl[tid];
-                __syncthreads();
-                for (int q = 3 + tid; q < n; q += MOSHII_TPB) cx.pose_t[cx.colpid[q]] += cx.ddl[q];
-                __syncthreads();
-                const Sse tr = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow);
-                ++n_fev;
-                double rho = sse - tr.total;
-                if (rho > 0.0) {
-                    const double dAd = block_sum(A.quad_partial(cx.ddl, n), cx.red);
-                    rho = rho / (2.0 * gd - dAd);
-                }
-                improved = rho > 0.0;
-                double pnorm2 = p2;
-                if (improved) {
-                    for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose[i] = cx.pose_t[i];
-                    if (tid < 3) cx.trans[tid] = cx.trans_t[tid];
-                    __syncthreads();
-                    if (e3 > 0.0 && (sse - tr.total) / sse < e3) {
-                        done = true;
-                    } else {
-                        assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, A);
-                        sse = tr.total;
-                        double gm = 0.0;
-                        for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
-                        if (block_max(gm, cx.red) < 1e-15) done = true;
-                    }
-                    double pp = 0.0;
-                    for (int q = tid; q < n; q += MOSHII_TPB) { const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]]; pp += pq * pq; }
-                    pnorm2 = block_sum(pp, cx.red);
-                }
-                if (rho > 0.9) delta = fmax(delta, 2.5 * step);
-                else if (rho < 0.05) delta *= 0.25;
-                if (delta <= 1e-15 * sqrt(pnorm2)) done = true;
-            }
-            if (done || improved) break;
-        }
-        if (iteration >= op.maxiter) done = true;
-    }
-    n_iter += iteration;
-}
-
 // Arun/Procrustes rigid init (rigid_transformations.py:39-83), serial on one thread (first solved frame only).
-__device__ void rigid_init_serial(const Ctx& cx, const FrameParams& fp, const uint8_t* visrow, int M) {
+__device__ __noinline__ void rigid_init_serial(const Ctx& cx, const FrameParams& fp, const uint8_t* visrow, int M) {
     double am[3] = {0, 0, 0}, bm[3] = {0, 0, 0};
     int cnt = 0;
     for (int m = 0; m < M; ++m) if (visrow[m]) {
@@ -875,6 +732,175 @@ __device__ void rigid_init_serial(const Ctx& cx, const FrameParams& fp, const ui
     for (int i = 0; i < 3; ++i) cx.trans[i] = bm[i] - (R[i * 3 + 0] * am[0] + R[i * 3 + 1] * am[1] + R[i * 3 + 2] * am[2]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// One solver phase = one ch.minimize(method='dogleg') call over x = [trans, pose[ids]]
+// (oracle/stageii_oracle.py:minimize_dogleg), written as a single loop around ONE forward evaluation and
+// ONE normal-equation assembly so that each is instantiated once in the kernel.
+//   rigid     : before the solve, evaluate the markers at the current state and apply the Procrustes init
+//   eval_only : no solve; just evaluate every term at the current state (per-frame record)
+// ------------------------------------------------------------------------------------------------
+template <int NBLK>
+__device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
+                         const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, double e3,
+                         bool rigid, bool eval_only, int& n_iter, int& n_fev, int& fail) {
+    const int tid = threadIdx.x;
+    const int n = 3 + nids;
+    int nkf = 0;
+    if (!eval_only) {   // column tables + needed-joint list
+        for (int q = tid; q < n; q += MOSHII_TPB) {
+            const int pid = (q < 3) ? -1 : ids[q - 3];
+            cx.colpid[q] = pid;
+            cx.colprior[q] = (pid >= 0) ? cx.pid2prior[pid] : -1;
+        }
+        if (tid == 0) {
+            for (int k = 0; k < md.K; ++k) cx.jointslot[k] = -1;
+            for (int i = 0; i < nids; ++i) {
+                const int pid = ids[i];
+                if (pid < md.body_dof) cx.jointslot[pid / 3] = 0;
+                else for (int k = md.body_dof / 3; k < md.K; ++k) cx.jointslot[k] = 0;
+            }
+            int c = 0;
+            for (int k = 0; k < md.K; ++k) if (cx.jointslot[k] == 0) { cx.jointslot[k] = c; cx.kfree[c] = k; ++c; }
+            cx.scal[S_TMP0] = (double)c;
+        }
+        __syncthreads();
+        nkf = (int)cx.scal[S_TMP0];
+    }
+    AReg<NBLK> A;
+    A.zero();
+    for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+    if (tid < 3) cx.trans_t[tid] = cx.trans[tid];
+    __syncthreads();
+    Sse last;
+    double sse = 0.0, delta = op.delta0, norm_sd = 0.0, norm_gn = 0.0, step = 0.0, p2 = 0.0, gd = 0.0;
+    bool init = true, done = false, have_gn = false;
+    int iteration = 0;
+    while (true) {
+        last = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow);
+        if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
+            if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
+            __syncthreads();
+            for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+            if (tid < 3) cx.trans_t[tid] = cx.trans[tid];
+            __syncthreads();
+            rigid = false;
+            continue;
+        }
+        if (eval_only) break;
+        ++n_fev;
+        bool improved = false, do_assemble = false;
+        double rho = 0.0;
+        if (init) {
+            sse = last.total;
+            do_assemble = true;
+        } else {
+            rho = sse - last.total;
+            if (rho > 0.0) {
+                const double dAd = block_sum(A.quad_partial(cx.ddl, n), cx.red);
+                rho = rho / (2.0 * gd - dAd);
+            }
+            improved = rho > 0.0;
+            if (improved) {
+                for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose[i] = cx.pose_t[i];
+                if (tid < 3) cx.trans[tid] = cx.trans_t[tid];
+                __syncthreads();
+                if (e3 > 0.0 && (sse - last.total) / sse < e3) done = true;
+                else { do_assemble = true; sse = last.total; }
+            }
+        }
+        if (do_assemble) {
+            assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, A);
+            double gm = 0.0;
+            for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
+            if (block_max(gm, cx.red) < 1e-15) done = true;
+        }
+        if (!init) {   // updateRadius + trust-region floor
+            double pnorm2 = p2;
+            if (improved) {
+                double pp = 0.0;
+                for (int q = tid; q < n; q += MOSHII_TPB) { const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]]; pp += pq * pq; }
+                pnorm2 = block_sum(pp, cx.red);
+            }
+            if (rho > 0.9) delta = fmax(delta, 2.5 * step);
+            else if (rho < 0.05) delta *= 0.25;
+            if (delta <= 1e-15 * sqrt(pnorm2)) done = true;
+        }
+        if (init || improved) {
+            if (!init && iteration >= op.maxiter) done = true;
+            if (done) break;
+            // start_iteration: d_sd = |g|^2 / |J g|^2 g, with |J g|^2 = g^T A g
+            ++iteration;
+            double gg = 0.0;
+            for (int q = tid; q < n; q += MOSHII_TPB) gg += cx.g[q] * cx.g[q];
+            double gAg = A.quad_partial(cx.g, n);
+            double dummy = 0.0;
+            block_sum3(gg, gAg, dummy, cx.red);
+            const double csd = gg / gAg;
+            norm_sd = fabs(csd) * sqrt(gg);
+            for (int q = tid; q < n; q += MOSHII_TPB) cx.dsd[q] = csd * cx.g[q];
+            have_gn = false;
+            __syncthreads();
+        } else if (done) {
+            break;
+        }
+        init = false;
+        // ---- update_step
+        if (norm_sd >= delta) {
+            const double sc = delta / norm_sd;
+            for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = sc * cx.dsd[q];
+        } else {
+            if (!have_gn) {
+                A.store_packed(cx.big, n);
+                __syncthreads();
+                if (!chol_solve(cx.big, cx.g, cx.dgn, cx.scal, n)) {
+                    fail = 1;
+                    for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
+                    __syncthreads();
+                }
+                double s = 0.0;
+                for (int q = tid; q < n; q += MOSHII_TPB) s += cx.dgn[q] * cx.dgn[q];
+                norm_gn = sqrt(block_sum(s, cx.red));
+                have_gn = true;
+            }
+            if (norm_gn <= delta) {
+                for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dgn[q];
+            } else {
+                double dd = 0.0, gs = 0.0, ds = 0.0;
+                for (int q = tid; q < n; q += MOSHII_TPB) {
+                    const double df = cx.dgn[q] - cx.dsd[q];
+                    dd += df * df; gs += cx.dgn[q] * cx.dsd[q]; ds += df * cx.dsd[q];
+                }
+                block_sum3(dd, gs, ds, cx.red);
+                const double delta_sq = delta * delta;
+                const double sqnorm_sd = norm_sd * norm_sd;
+                const double pnow = dd * delta_sq + gs * gs - (norm_gn * norm_gn) * sqnorm_sd;
+                const double beta = (delta_sq - sqnorm_sd) / (ds + sqrt(pnow));
+                for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dsd[q] + beta * (cx.dgn[q] - cx.dsd[q]);
+            }
+        }
+        __syncthreads();
+        // ---- trial point and norms
+        double s2 = 0.0;
+        p2 = 0.0; gd = 0.0;
+        for (int q = tid; q < n; q += MOSHII_TPB) {
+            const double dq = cx.ddl[q];
+            const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
+            s2 += dq * dq; p2 += pq * pq; gd += cx.g[q] * dq;
+        }
+        block_sum3(s2, p2, gd, cx.red);
+        step = sqrt(s2);
+        if (step <= 1e-15 * sqrt(p2)) break;   // "small step size" stop
+        for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+        if (tid < 3) cx.trans_t[tid] = cx.trans[tid] + cx.ddl[tid];
+        __syncthreads();
+        for (int q = 3 + tid; q < n; q += MOSHII_TPB) cx.pose_t[cx.colpid[q]] += cx.ddl[q];
+        __syncthreads();
+    }
+    n_iter += iteration;
+    return last;
+}
+
+
 __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     Ctx cx;
     cx.pose = lds + ly.o_pose; cx.trans = lds + ly.o_trans; cx.pose_t = lds + ly.o_pose_t; cx.trans_t = lds + ly.o_trans_t;
@@ -901,27 +927,32 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
                                                              OptsDev op, ChainLayout ly) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
-    const ChainDev ch = chains[blockIdx.x];
-    const AttachDev at = *ch.att;
+    const ChainDev* chp = chains + blockIdx.x;   // fields are (re)loaded where used: keeps SGPR pressure down
+    const AttachDev at = *chp->att;
     const Ctx cx = make_ctx(lds, ly);
 
-    const int NP = md.NP, M = at.M;
-    for (int i = tid; i < NP; i += MOSHII_TPB) {
-        cx.pose[i] = ch.init_pose ? ch.init_pose[i] : 0.0;
-        cx.pose_prev[i] = ch.init_prev ? ch.init_prev[i] : 0.0;
-        cx.vtarget[i] = 0.0;
-        cx.pid2prior[i] = -1;
+    const int NP = md.NP, M = at.M, F = chp->F;
+    {
+        const double* ip = chp->init_pose;
+        const double* iv = chp->init_prev;
+        const double* it = chp->init_trans;
+        for (int i = tid; i < NP; i += MOSHII_TPB) {
+            cx.pose[i] = ip ? ip[i] : 0.0;
+            cx.pose_prev[i] = iv ? iv[i] : 0.0;
+            cx.vtarget[i] = 0.0;
+            cx.pid2prior[i] = -1;
+        }
+        if (tid < 3) cx.trans[tid] = it ? it[tid] : 0.0;
     }
-    if (tid < 3) cx.trans[tid] = ch.init_trans ? ch.init_trans[tid] : 0.0;
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
     __syncthreads();
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
-    bool has_prev = ch.init_prev != nullptr;
-    bool first = ch.first != 0;
+    bool has_prev = chp->init_prev != nullptr;
+    bool first = chp->first != 0;
 
-    for (int t = 0; t < ch.F; ++t) {
-        const uint8_t* visrow = ch.vis + (size_t)t * M;
+    for (int t = 0; t < F; ++t) {
+        const uint8_t* visrow = chp->vis + (size_t)t * M;
         // visible-marker list (chmosh.py:591-594), kept in label order
         if (tid == 0) {
             int c = 0;
@@ -931,12 +962,13 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
         __syncthreads();
         const int nobs = (int)cx.scal[S_TMP1];
         if (nobs == 0) {   // chmosh.py:586-588
-            if (tid == 0 && ch.status) ch.status[t] = 1;
+            int* st = chp->status;
+            if (tid == 0 && st) st[t] = 1;
             __syncthreads();
             continue;
         }
         FrameParams fp;
-        fp.obs = ch.obs + (size_t)t * M * 3;
+        fp.obs = chp->obs + (size_t)t * M * 3;
         fp.nobs = nobs;
         const double n_miss = (double)(M - nobs);
         double anneal = 1.0;
@@ -950,41 +982,41 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
         fp.has_velo = has_prev ? 1 : 0;
         if (has_prev)   // :624-626  target = pose.r + (pose.r - pose_prev)
             for (int i = tid; i < NP; i += MOSHII_TPB) cx.vtarget[i] = cx.pose[i] + (cx.pose[i] - cx.pose_prev[i]);
+        if (!first) {   // :656-657
+            for (int i = tid; i < NP; i += MOSHII_TPB) cx.pose_prev[i] = cx.pose[i];
+            has_prev = true;
+        }
         __syncthreads();
         int n_iter = 0, n_fev = 0, fail = 0;
-        if (first) {
-            eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, visrow);
-            if (tid == 0) rigid_init_serial(cx, fp, visrow, M);
-            __syncthreads();
-            const double sc[3] = {10.0, 5.0, 1.0};
-            for (int r = 0; r < 3; ++r) {
-                fp.wt_pose = sc[r] * wt_pose;
-                dogleg<NBLK>(cx, ly, md, at, pr, op, fp, visrow, op.step1, op.n1, op.e3_first, n_iter, n_fev, fail);
-            }
-            first = false;
-        } else {
-            for (int i = tid; i < NP; i += MOSHII_TPB) cx.pose_prev[i] = cx.pose[i];   // :656-657
-            has_prev = true;
-            __syncthreads();
+        // phases: [rigid + annealed rounds x10 x5 x1 (first solved frame only, :629-655)] step 1 (:665-671),
+        //         step 2 (:676-705), record (:712-724)
+        Sse fin;
+        for (int kind = first ? 0 : 3; kind < 6; ++kind) {
+            const bool round = kind < 3;
+            const bool step2 = kind == 4;
+            fp.wt_pose = round ? ((kind == 0) ? 10.0 : (kind == 1) ? 5.0 : 1.0) * wt_pose : wt_pose;
+            fp.use_fingers = (kind >= 4 && op.nfinger > 0) ? 1 : 0;
+            fin = run_phase<NBLK>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
+                                  round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, n_iter, n_fev, fail);
         }
-        fp.wt_pose = wt_pose;
-        dogleg<NBLK>(cx, ly, md, at, pr, op, fp, visrow, op.step1, op.n1, op.e3, n_iter, n_fev, fail);
-        fp.use_fingers = (op.nfinger > 0) ? 1 : 0;
-        dogleg<NBLK>(cx, ly, md, at, pr, op, fp, visrow, op.step2, op.n2, op.e3, n_iter, n_fev, fail);
-        // record (chmosh.py:712-724)
-        const Sse fin = eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, visrow);
-        if (ch.pose) for (int i = tid; i < NP; i += MOSHII_TPB) ch.pose[(size_t)t * NP + i] = cx.pose[i];
-        if (ch.fullpose) for (int i = tid; i < md.P; i += MOSHII_TPB) ch.fullpose[(size_t)t * md.P + i] = cx.fullpose[i];
-        if (ch.msim) for (int i = tid; i < 3 * M; i += MOSHII_TPB) ch.msim[(size_t)t * 3 * M + i] = cx.msim[i];
-        if (tid == 0) {
-            if (ch.trans) { ch.trans[t * 3 + 0] = cx.trans[0]; ch.trans[t * 3 + 1] = cx.trans[1]; ch.trans[t * 3 + 2] = cx.trans[2]; }
-            if (ch.errs) { ch.errs[t * 4 + 0] = fin.data; ch.errs[t * 4 + 1] = fin.prior; ch.errs[t * 4 + 2] = fin.velo; ch.errs[t * 4 + 3] = fin.hand; }
-            if (ch.iters) { ch.iters[t * 2 + 0] = n_iter; ch.iters[t * 2 + 1] = n_fev; }
-            if (ch.status) ch.status[t] = fail ? -1 : 0;
+        first = false;
+        {   // record
+            double* o;
+            if ((o = chp->pose) != nullptr) for (int i = tid; i < NP; i += MOSHII_TPB) o[(size_t)t * NP + i] = cx.pose[i];
+            if ((o = chp->fullpose) != nullptr) for (int i = tid; i < md.P; i += MOSHII_TPB) o[(size_t)t * md.P + i] = cx.fullpose[i];
+            if ((o = chp->msim) != nullptr) for (int i = tid; i < 3 * M; i += MOSHII_TPB) o[(size_t)t * 3 * M + i] = cx.msim[i];
+            if (tid == 0) {
+                if ((o = chp->trans) != nullptr) { o[t * 3 + 0] = cx.trans[0]; o[t * 3 + 1] = cx.trans[1]; o[t * 3 + 2] = cx.trans[2]; }
+                if ((o = chp->errs) != nullptr) { o[t * 4 + 0] = fin.data; o[t * 4 + 1] = fin.prior; o[t * 4 + 2] = fin.velo; o[t * 4 + 3] = fin.hand; }
+                int* oi;
+                if ((oi = chp->iters) != nullptr) { oi[t * 2 + 0] = n_iter; oi[t * 2 + 1] = n_fev; }
+                if ((oi = chp->status) != nullptr) oi[t] = fail ? -1 : 0;
+            }
         }
         __syncthreads();
     }
 }
+
 
 template __global__ void k_chain_solve<2>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
 template __global__ void k_chain_solve<4>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);

@@ -240,11 +240,11 @@ int pick_nblk(int n) {
     return -1;
 }
 
-ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm) {
+ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm, int nblk = 0) {
     ChainLayout ly;
     memset(&ly, 0, sizeof(ly));
     const int K = m->K, NP = m->NP, P = m->P;
-    const int nblk = pick_nblk(nmax);
+    if (nblk <= 0) nblk = pick_nblk(nmax);
     const int LDJ = nblk * 16;
     ly.Mmax = Mmax; ly.Nvmax = Nvmax; ly.NWmax = NWmax; ly.nmax = nmax; ly.Tm = Tm; ly.nkfmax = nkfmax; ly.LDJ = LDJ;
     int off = 0;
@@ -571,8 +571,9 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
     const int NP = m->NP, P = m->P;
     const int nmax = 3 + std::max(o->n_step1, o->n_step2);
-    const int nblk = pick_nblk(nmax);
+    int nblk = pick_nblk(nmax);
     if (nblk < 0) return fail(MOSHII_ERR_UNSUPPORTED, "more than 125 free pose variables per step");
+    if (const char* e = getenv("MOSHII_FORCE_NBLK")) nblk = std::max(nblk, atoi(e));
     // needed joints (superset over both steps)
     auto count_kf = [&](const int32_t* ids, int n) {
         std::vector<char> need(m->K, 0);
@@ -601,8 +602,8 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     if (const char* e = getenv("MOSHII_LDS_BUDGET")) budget = atoi(e);
     int Tm = 16;
     if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(32, atoi(e)));
-    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm);
-    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm); }
+    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk);
+    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk); }
     const size_t lds_bytes = (size_t)ly.total_doubles * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(MOSHII_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of a CU");
 
