@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmoshii.so')
+LIB_PATH = os.environ.get('MOSHII_LIB', os.path.join(_HERE, 'libmoshii.so'))
 
 BUFFERS_HOST = 0
 BUFFERS_DEVICE = 1

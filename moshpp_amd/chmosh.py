@@ -1,0 +1,215 @@
+"""MI355X-native MoSh++ Stage-II: drop-in for the reference's `chmosh.mosh_stageii`
+(src/moshpp/chmosh.py:458-741).
+
+`mosh_stageii` keeps the reference's name, signature, cfg fields, side effects on `cfg`
+(:475-486) and return layout (:726-741), so it can be injected through the reference's own plugin
+point:  `MoSh(**cfg).mosh_stageii(moshpp_amd.chmosh.mosh_stageii)`  (mosh_head.py:268-301).
+
+Everything numeric runs in libmoshii (HIP, gfx950).  This file is host orchestration only: ingest,
+model / prior / attachment setup, free-variable sets, chain construction and output assembly.
+There is no CPU fallback: without the shared library or a GPU it raises.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from . import capi
+from .mocap_interface import MocapSession
+from .models import load_surface_model
+from .prior import create_gmm_body_prior
+from .transformed_lm import TransformedCoeffs
+
+try:   # present when this package is injected into a reference installation
+    from moshpp.marker_layout.labels_map import general_labels_map   # type: ignore
+except Exception:   # pragma: no cover - the alias table is reference data, not part of this package
+    general_labels_map = {}
+
+logger = logging.getLogger('moshpp_amd')
+
+NUM_TRAIN_MARKERS = 46   # chmosh.py:460
+ERR_KEYS = ('data', 'poseB', 'velo', 'poseH')
+
+
+def _get(node, key, default=None):
+    try:
+        v = node[key]
+    except Exception:
+        return default
+    return default if v is None else v
+
+
+def stageii_pose_ids(surface_model_type, pose_size, optimize_fingers, optimize_toes):
+    """Free-variable index sets of chmosh.py:546-579 (sets), :645-647 / :665-667 (Step 1), :676-692 (Step 2)."""
+    all_pose_ids = list(range(pose_size))
+    pose_body_ids, pose_finger_ids = [], []
+    pose_root_ids = all_pose_ids[:3]
+    if surface_model_type == 'smpl':
+        pose_body_ids = all_pose_ids[3:]
+    elif surface_model_type == 'smplh':
+        pose_body_ids = all_pose_ids[3:66]
+        if optimize_fingers:
+            pose_finger_ids = all_pose_ids[66:]
+    elif surface_model_type == 'smplx':   # orient:3, body:63, jaw:3, eyel:3, eyer:3, handl, handr
+        pose_body_ids = all_pose_ids[3:66]
+        if optimize_fingers:
+            pose_finger_ids = all_pose_ids[75:]
+    elif surface_model_type == 'mano':
+        pose_finger_ids = all_pose_ids[3:]
+    else:
+        raise NotImplementedError(f'surface model type {surface_model_type}')
+    step1 = pose_root_ids + pose_body_ids
+    if len(pose_body_ids) and not optimize_toes:
+        step1 = sorted(set(step1).difference(set(all_pose_ids[30:36])))
+    step2 = list(step1)
+    if optimize_fingers:
+        step2 += pose_finger_ids
+    step2 = sorted(set(step2))
+    return dict(root=pose_root_ids, body=pose_body_ids, finger=pose_finger_ids if optimize_fingers else [],
+                step1=list(step1), step2=step2)
+
+
+class StageIISolver:
+    """Device-resident setup of one subject + marker layout: model, betas, prior, attachment, options.
+    Reusable across sequences of the same subject (the reference rebuilds all of this per call)."""
+
+    def __init__(self, surface_model, betas, markers_latent, prior, weights, surface_model_type=None,
+                 num_betas=None, optimize_fingers=False, optimize_toes=False, maxiter=100):
+        self.sm = surface_model
+        self.model_type = surface_model_type or surface_model.model_type
+        self.dev = surface_model.device()
+        betas = np.asarray(betas, dtype=np.float64).ravel()
+        nb = len(betas) if num_betas is None else int(num_betas)
+        b = np.zeros(surface_model.num_total_betas)
+        b[:nb] = betas[:nb]                               # chmosh.py:499-500
+        self.betas = b
+        self.dev.set_betas(b)
+        can_body = self.dev.lbs_forward(np.zeros((1, surface_model.NP)), np.zeros((1, 3)))[0]   # can_model.r (:502)
+        self.can_body = can_body
+        self.tc = TransformedCoeffs(can_body, markers_latent)
+        self.attach = capi.Attachment(self.dev, self.tc.closest, self.tc.coef)
+        self.ids = stageii_pose_ids(self.model_type, surface_model.NP, optimize_fingers, optimize_toes)
+        self.prior = None
+        if len(self.ids['body']):
+            if prior is None:
+                raise ValueError('a body pose prior is required for this model type (chmosh.py:613-614)')
+            if prior['npose'] != len(self.ids['body']):
+                raise ValueError(f"prior npose {prior['npose']} != len(pose_body_ids) {len(self.ids['body'])}")
+            self.prior = capi.Prior(prior['means'], prior['chols'], prior['weights'])
+        self.opts = capi.make_opts(weights, self.ids['step1'], self.ids['step2'], self.ids['body'], self.ids['finger'],
+                                   maxiter=maxiter, num_train_markers=NUM_TRAIN_MARKERS)
+        self.optimize_fingers = bool(optimize_fingers)
+
+    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=48):
+        """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0)."""
+        F = obs.shape[0]
+        if chain_mode == 'sequential' or F == 0:
+            out = capi.chain_solve_host(self.dev, self.prior, self.opts,
+                                        [dict(attach=self.attach, obs=obs, vis=vis, first=True)])[0]
+            return out
+        if chain_mode == 'chunked':
+            from .chunking import solve_chunked
+            return solve_chunked(self, obs, vis, num_chunks=num_chunks, warmup=chunk_warmup)
+        raise ValueError(f'unknown chain_mode {chain_mode}')
+
+
+def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_labels: list, betas: np.ndarray,
+                 marker_meta: dict, v_template_fname=None) -> dict:
+    capi.load()
+    capi.require_device()
+
+    # 1. observed markers (chmosh.py:463-471)
+    mocap = MocapSession(mocap_fname,
+                         mocap_unit=cfg.mocap.unit,
+                         mocap_rotate=cfg.mocap.rotate,
+                         labels_map=general_labels_map,
+                         only_subjects=[cfg.mocap.subject_name] if cfg.mocap.multi_subject else None)
+    logger.debug('Loaded mocap markers for mosh stageii')
+
+    # 2. switch finger / face optimisation off when layout or data cannot support it (:475-486)
+    avail_labels = latent_labels
+    for body_part, cfg_key in {'finger': 'optimize_fingers', 'face': 'optimize_face'}.items():
+        if not cfg.moshpp[f'{cfg_key}']:
+            continue
+        if not np.any([body_part in m for m in marker_meta['marker_type_mask'].keys()]):
+            cfg.moshpp[f'{cfg_key}'] = False
+            logger.warning(f'{cfg_key} was activated but no {body_part} marker type detected in the marker layout: '
+                           f'{cfg_key} = {cfg.moshpp[f"{cfg_key}"]}.')
+        elif not np.any([(body_part in ltype) and l in avail_labels for l, ltype in marker_meta['marker_type'].items()]):
+            cfg.moshpp[f'{cfg_key}'] = False
+            logger.warning(f'{cfg_key} was activated but no {body_part} marker type detected in the mocaps: '
+                           f'{cfg_key} = {cfg.moshpp[f"{cfg_key}"]}.')
+    if cfg.moshpp.optimize_face:
+        raise NotImplementedError('moshpp_amd: expression / jaw free variables (chmosh.py:685-689) are the next '
+                                  'scope row (SURVEY.md 8f #2); run with moshpp.optimize_face=False')
+    if cfg.moshpp.optimize_dynamics:
+        raise NotImplementedError('moshpp_amd: DMPL free variables (chmosh.py:507-514, 694-699) are out of the '
+                                  'current scope; run with moshpp.optimize_dynamics=False')
+
+    # 3. model, prior, attachment (:488-503)
+    sm = load_surface_model(surface_model_fname=cfg.surface_model.fname,
+                            surface_model_type=cfg.surface_model.type,
+                            pose_hand_prior_fname=cfg.moshpp.pose_hand_prior_fname,
+                            use_hands_mean=cfg.surface_model.use_hands_mean,
+                            dof_per_hand=cfg.surface_model.dof_per_hand,
+                            v_template_fname=v_template_fname)
+    assert sm.model_type == cfg.surface_model.type, ValueError(f'{sm.model_type} != {cfg.surface_model.type}')
+    prior = None
+    if cfg.moshpp.pose_body_prior_fname and sm.model_type != 'mano':
+        prior = create_gmm_body_prior(cfg.moshpp.pose_body_prior_fname,
+                                      exclude_hands=sm.model_type in ['smplh', 'smplx'])
+    stageii_wts = cfg.opt_settings.weights
+    ext = _get(cfg, 'moshpp_amd', {}) or {}
+    solver = StageIISolver(sm, betas, markers_latent, prior, stageii_wts, surface_model_type=cfg.surface_model.type,
+                           num_betas=cfg.surface_model.num_betas, optimize_fingers=cfg.moshpp.optimize_fingers,
+                           optimize_toes=cfg.moshpp.optimize_toes, maxiter=cfg.opt_settings.maxiter)
+    logger.debug(f'#observed, #simulated markers: {len(mocap.labels)}, {len(markers_latent)}')
+
+    # 4. frames (:539-540) and the per-frame visible-label selection (:582-594) as arrays
+    selected_frames = range(cfg.mocap.start_fidx, len(mocap) if cfg.mocap.end_fidx == -1 else cfg.mocap.end_fidx,
+                            cfg.mocap.ds_rate)
+    logger.debug(f'Starting mosh stageii for {len(selected_frames)} frames.')
+    obs, vis = mocap.markers_aslabeled_arrays(latent_labels, selected_frames)
+
+    # 5. the frame loop (:584-724) on the GPU
+    out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', 'sequential'),
+                       num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 48)))
+    for fi in np.flatnonzero(out['status'] == 1):
+        logger.error(f'no available observed markers for frame {selected_frames[fi]}. skipping the frame.')
+    if np.any(out['status'] < 0):
+        logger.warning(f"{int(np.sum(out['status'] < 0))} frames hit a non-positive-definite normal matrix "
+                       f"(Cauchy step used instead of Gauss-Newton)")
+    solved = np.flatnonzero(out['status'] != 1)
+
+    # 6. outputs (:712-741)
+    labels_arr = np.asarray(latent_labels, dtype=object)
+    perframe = dict(markers_sim=[], markers_obs=[], labels_obs=[])
+    for fi in solved:
+        v = vis[fi]
+        perframe['markers_sim'].append(out['markers_sim'][fi][v].copy())
+        perframe['markers_obs'].append(obs[fi][v].copy())
+        perframe['labels_obs'].append(labels_arr[v].tolist())
+    errs = {'data': out['errs'][solved, 0]}
+    if len(solver.ids['body']):
+        errs['poseB'] = out['errs'][solved, 1]
+    if len(solved) > 2:
+        errs['velo'] = out['errs'][solved[2:], 2]   # the velocity term exists from the third solved frame on
+    if solver.optimize_fingers:
+        errs['poseH'] = out['errs'][solved, 3]
+    stageii_debug_details = {
+        'stageii_errs': {k: np.array(v) for k, v in errs.items()},
+        'markers_sim': perframe['markers_sim'],
+        'markers_obs': perframe['markers_obs'],
+        'labels_obs': perframe['labels_obs'],
+        'markers_orig': mocap.markers[selected_frames],
+        'labels_orig': mocap.labels,
+        'mocap_fname': mocap_fname,
+        'mocap_frame_rate': mocap.frame_rate,
+        'mocap_time_length': mocap.time_length(),
+        'stageii_iters': out['iters'][solved],          # extra: dogleg iterations / residual evaluations
+        'stageii_solved_frame_ids': np.asarray(selected_frames)[solved] if len(solved) else np.zeros(0, dtype=int),
+    }
+    stageii_data = {'fullpose': out['fullpose'][solved].copy(), 'trans': out['trans'][solved].copy(),
+                    'stageii_debug_details': stageii_debug_details}
+    return stageii_data

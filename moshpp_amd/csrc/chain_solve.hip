@@ -15,6 +15,17 @@
 
 namespace moshii {
 
+#ifdef MOSHII_PROFILE
+__device__ long long g_prof[32];
+#define PROF_BEGIN() long long _pt = clock64()
+#define PROF_LAP(slot) do { __syncthreads(); if (threadIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - _pt; _pt = _n; } else { _pt = 0; } } while (0)
+#define PROF_COUNT(slot) do { if (threadIdx.x == 0) g_prof[slot] += 1; } while (0)
+#else
+#define PROF_BEGIN() do {} while (0)
+#define PROF_LAP(slot) do {} while (0)
+#define PROF_COUNT(slot) do {} while (0)
+#endif
+
 enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6 };
 
 struct Ctx {
@@ -169,6 +180,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                             const uint8_t* visrow) {
     const int tid = threadIdx.x;
     const int K = md.K, P = md.P, bd = md.body_dof, hd = md.hand_dof, nhf = md.nhand_full;
+    PROF_BEGIN(); PROF_COUNT(20);
     // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
     for (int d = tid; d < P; d += MOSHII_TPB) {
         double v;
@@ -241,6 +253,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
         cx.omega[k * 9 + c * 3 + 0] = ox; cx.omega[k * 9 + c * 3 + 1] = oy; cx.omega[k * 9 + c * 3 + 2] = oz;
     }
+    PROF_LAP(0);
     // F4: v_posed = v_shaped + posedirs . vec(R - I) for the attached vertices; item = (coordinate i, vertex a)
     const int Nv = at.Nv, Nvp = at.Nvp;
     for (int it = tid; it < 3 * Nv; it += MOSHII_TPB) {
@@ -257,6 +270,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         cx.vposed[a * 3 + i] = at.vsh[a * 3 + i] + ((s0 + s1) + s2);
     }
     __syncthreads();
+    PROF_LAP(1);
     // F5: skinning  v = sum_j w_j (Rw_j (v_posed - J_j) + tw_j) + trans
     const int NW = at.NW;
     for (int a = tid; a < Nv; a += MOSHII_TPB) {
@@ -292,6 +306,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             sd += r * r;
         }
     }
+    PROF_LAP(2);
     // F8: velocity and finger terms
     double sv = 0.0, sh = 0.0;
     if (fp.has_velo)
@@ -331,6 +346,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         }
     }
     block_sum3(sd, sv, sh, cx.red);   // (contains the barriers that publish scal[])
+    PROF_LAP(3);
     Sse out;
     out.data = sd; out.velo = sv; out.hand = sh;
     out.prior = (np_ > 0) ? fp.wt_pose * fp.wt_pose * cx.scal[S_PRIOR_SS] : 0.0;
@@ -428,6 +444,7 @@ struct AReg {
 __device__ bool chol_solve(double* Lp, const double* g, double* d, double* scal, int n) {
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
+    PROF_BEGIN(); PROF_COUNT(22);
     for (int q = tid; q < n; q += MOSHII_TPB) Lp[n * (n + 1) / 2 + q] = g[q];
     bool ok = true;
     for (int j = 0; j < n; ++j) {
@@ -446,6 +463,7 @@ __device__ bool chol_solve(double* Lp, const double* g, double* d, double* scal,
         }
     }
     __syncthreads();
+    PROF_LAP(9);
     if (!ok) return false;
     // back substitution by wave 0: lane l owns rows l and l+64
     if (tid < 64) {
@@ -464,6 +482,7 @@ __device__ bool chol_solve(double* Lp, const double* g, double* d, double* scal,
         if (tid + 64 < n) d[tid + 64] = y1;
     }
     __syncthreads();
+    PROF_LAP(10);
     (void)scal;
     return true;
 }
@@ -477,6 +496,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                          int n, int nkf, AReg<NBLK>& A) {
     const int tid = threadIdx.x;
     const int LDJ = ly.LDJ, Tm = ly.Tm, NW = at.NW, Nvp = at.Nvp, bd = md.body_dof, nhf = md.nhand_full;
+    PROF_BEGIN(); PROF_COUNT(21);
     A.zero();
     for (int q = tid; q < n; q += MOSHII_TPB) cx.g[q] = 0.0;
     for (int e = tid; e < 3 * Tm * LDJ; e += MOSHII_TPB) cx.Jrow[e] = 0.0;
@@ -517,6 +537,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             for (int i = 0; i < 3; ++i) cx.rest[ml * 3 + i] = cx.res[m * 3 + i];
         }
         __syncthreads();
+        PROF_LAP(4);
         // T1: vertex Jacobian columns of the needed joints: item = (tile vertex, joint)
         for (int it = tid; it < ntv * nkf; it += MOSHII_TPB) {
             const int kfi = it / ntv, al = it - kfi * ntv;
@@ -569,6 +590,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             for (int e = 0; e < 9; ++e) out[e] = col[e];
         }
         __syncthreads();
+        PROF_LAP(5);
         // T2: marker rows: item = (tile marker, column)
         for (int it = tid; it < cnt * n; it += MOSHII_TPB) {
             const int ml = it / n, q = it - ml * n;
@@ -610,6 +632,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             cx.Jrow[(3 * ml + 2) * LDJ + q] = fp.wt_data * r2;
         }
         __syncthreads();
+        PROF_LAP(6);
         // T3: A += Jt^T Jt ; g -= Jt^T r
         A.rank_update(cx.Jrow, ntv, LDJ);
         for (int q = tid; q < n; q += MOSHII_TPB) {
@@ -618,6 +641,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             cx.g[q] -= s;
         }
         __syncthreads();
+        PROF_LAP(7);
     }
     // structured terms: prior (dense, precomputed 0.5 L L^T per component), velocity and finger terms (diagonal)
     const int np_ = op.nbody;
@@ -650,6 +674,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     A.add_diag(dvec, n);
     if (np_ > 0) A.add_prior(fp.wt_pose * fp.wt_pose, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
     __syncthreads();
+    PROF_LAP(8);
 }
 
 // Arun/Procrustes rigid init (rigid_transformations.py:39-83), serial on one thread (first solved frame only).
@@ -950,6 +975,7 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
     __syncthreads();
     bool has_prev = chp->init_prev != nullptr;
     bool first = chp->first != 0;
+    PROF_BEGIN();
 
     for (int t = 0; t < F; ++t) {
         const uint8_t* visrow = chp->vis + (size_t)t * M;
@@ -1015,8 +1041,8 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
         }
         __syncthreads();
     }
+    PROF_LAP(12);
 }
-
 
 template __global__ void k_chain_solve<2>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
 template __global__ void k_chain_solve<4>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
@@ -1078,3 +1104,11 @@ extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t
     hipLaunchKernelGGL(k_markers, dim3(F), dim3(MOSHII_TPB), lds_bytes, stream, att, *md, *ly, pose, trans, out);
     return hipGetLastError();
 }
+
+#ifdef MOSHII_PROFILE
+extern "C" int moshii_prof_read(long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(moshii::g_prof), sizeof(long long) * 32) != hipSuccess) return -1;
+    if (reset) { long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(moshii::g_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

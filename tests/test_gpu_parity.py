@@ -1,6 +1,8 @@
 """GPU parity: libmoshii (HIP, through the C ABI) against the float64 oracle on the same seeded inputs.
 Tolerances (BASELINE.json north_star): markers 1e-3 m RMSE, pose 1e-4 rad.  The HIP path is float64
 with the oracle's formulas, so the tests below hold it to far tighter bounds and state them."""
+import os
+
 import numpy as np
 import pytest
 
@@ -82,3 +84,102 @@ def test_chain_parity(gpu_lib, model_type, M, fingers, seed):
         np.testing.assert_allclose(out['errs'][solved, 1], ref['errs']['poseB'], rtol=1e-6)
     if 'velo' in ref['errs']:
         np.testing.assert_allclose(out['errs'][solved[2:], 2], ref['errs']['velo'], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize('name,mt,F,M,seed,fingers', [('smpl_41mk_10f', 'smpl', 10, 41, 11, False),
+                                                      ('smplh_53mk_8f', 'smplh', 8, 53, 12, False),
+                                                      ('mano_24mk_8f', 'mano', 8, 24, 13, True)])
+def test_gpu_matches_committed_golden(gpu_lib, name, mt, F, M, seed, fingers):
+    """tests/golden/oracle_golden.npz (made by tests/golden/make_oracle_golden.py)."""
+    import os
+    from moshpp_amd import capi
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_golden.npz'))
+    case = oracle_case(mt, F=F, M=M, seed=seed, empty_frames=(3,))
+    dev = device_case(case, optimize_fingers=fingers)
+    out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+    solved = np.where(out['status'] == 0)[0]
+    np.testing.assert_array_equal(solved, g[f'{name}/frame_ids'])
+    assert np.abs(out['fullpose'][solved] - g[f'{name}/fullpose']).max() < POSE_TOL
+    assert np.abs(out['fullpose'][solved] - g[f'{name}/fullpose']).max() < TIGHT
+    assert np.abs(out['trans'][solved] - g[f'{name}/trans']).max() < TIGHT
+    np.testing.assert_array_equal(out['iters'][solved, 0], g[f'{name}/iters'])
+
+
+def test_chain_continuation_equals_one_chain(gpu_lib):
+    """Splitting a chain and handing over (pose, trans, pose_prev) reproduces the unsplit chain exactly:
+    the property chunked / multi-GPU execution relies on."""
+    from moshpp_amd import capi
+    case = oracle_case('smplh', F=16, M=53, seed=21)
+    dev = device_case(case)
+    full = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                 [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+    a = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                              [dict(attach=dev['attach'], obs=case['obs'][:9], vis=case['vis'][:9], first=True)])[0]
+    b = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                              [dict(attach=dev['attach'], obs=case['obs'][9:], vis=case['vis'][9:], first=False,
+                                    init_pose=a['pose'][8], init_trans=a['trans'][8], init_pose_prev=a['pose'][7])])[0]
+    np.testing.assert_array_equal(np.vstack([a['fullpose'], b['fullpose']]), full['fullpose'])
+    np.testing.assert_array_equal(np.vstack([a['trans'], b['trans']]), full['trans'])
+
+
+def test_many_chains_one_launch(gpu_lib):
+    """Several sequences with different attachments in ONE launch equal their separate solves (bitwise)."""
+    from moshpp_amd import capi
+    case = oracle_case('smplh', F=10, M=53, seed=31)
+    dev = device_case(case)
+    rng = np.random.default_rng(0)
+    chains = []
+    for c in range(5):
+        obs = case['obs'] + rng.normal(0, 0.002, case['obs'].shape)
+        chains.append(dict(attach=dev['attach'], obs=obs, vis=case['vis'], first=True))
+    together = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], chains)
+    for c in range(5):
+        alone = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], [chains[c]])[0]
+        np.testing.assert_array_equal(together[c]['fullpose'], alone['fullpose'])
+
+
+def test_mosh_stageii_end_to_end(gpu_lib, tmp_path):
+    """The drop-in entry point on files (c3d in mm, model .pkl, prior .pkl, hand prior .npz) against the
+    oracle run on the same parsed data; checks the output dict layout of chmosh.py:726-741."""
+    import pickle
+    from moshpp_amd import synth
+    from moshpp_amd.cfg import make_cfg
+    from moshpp_amd.chmosh import mosh_stageii
+    from moshpp_amd.mocap_interface import MocapSession, write_mocap_c3d
+    s = synth.make_sequence('smplh', 14, 53, seed=40, empty_frames=(5,))
+    raw = {k: v for k, v in s['model'].items() if not k.startswith('_')}
+    with open(tmp_path / 'model.pkl', 'wb') as f:
+        pickle.dump(raw, f)
+    with open(tmp_path / 'pose_body_prior.pkl', 'wb') as f:
+        pickle.dump(s['gmm'], f)
+    np.savez(tmp_path / 'pose_hand_prior.npz', **s['hand_prior'])
+    labels = list(s['labels']) + ['EXTRA']
+    mk = np.concatenate([s['markers'], np.full((14, 1, 3), 0.5)], axis=1)
+    c3d = str(tmp_path / 'ds' / 'subj' / 'seq01.c3d')
+    os.makedirs(os.path.dirname(c3d))
+    write_mocap_c3d(mk, labels, c3d, frame_rate=120)
+    cfg = make_cfg(**{'mocap.fname': c3d, 'surface_model.type': 'smplh', 'surface_model.fname': str(tmp_path / 'model.pkl'),
+                      'moshpp.pose_body_prior_fname': str(tmp_path / 'pose_body_prior.pkl'),
+                      'moshpp.pose_hand_prior_fname': str(tmp_path / 'pose_hand_prior.npz'),
+                      'moshpp.optimize_fingers': True})   # layout has no finger markers -> switched off (:475-486)
+    out = mosh_stageii(c3d, cfg, s['markers_latent'], s['latent_labels'], s['betas'], s['marker_meta'])
+    assert cfg.moshpp.optimize_fingers is False
+    assert set(out) == {'fullpose', 'trans', 'stageii_debug_details'}
+    dd = out['stageii_debug_details']
+    for k in ('stageii_errs', 'markers_sim', 'markers_obs', 'labels_obs', 'markers_orig', 'labels_orig', 'mocap_fname',
+              'mocap_frame_rate', 'mocap_time_length'):
+        assert k in dd
+    assert out['fullpose'].shape == (13, 156) and out['trans'].shape == (13, 3)
+    assert len(dd['markers_sim']) == 13 and dd['markers_orig'].shape == (14, 54, 3) and dd['labels_orig'][-1] == 'EXTRA'
+    assert set(dd['stageii_errs']) == {'data', 'poseB', 'velo'} and len(dd['stageii_errs']['velo']) == 11
+    pickle.dumps(out)
+    # oracle on the same parsed mocap
+    ms = MocapSession(c3d, 'mm')
+    obs, vis = ms.markers_aslabeled_arrays(s['latent_labels'])
+    case = oracle_case('smplh', F=14, M=53, seed=40, empty_frames=(5,))
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], obs, vis, 'smplh')
+    assert np.abs(out['fullpose'] - ref['fullpose']).max() < TIGHT
+    assert np.abs(out['trans'] - ref['trans']).max() < TIGHT
+    for a, b, l, t in zip(dd['markers_sim'], ref['markers_sim'], dd['labels_obs'], ref['frame_ids']):
+        assert np.abs(a - b).max() < TIGHT and l == [x for x, v in zip(s['latent_labels'], vis[t]) if v]

@@ -1,0 +1,181 @@
+"""CPU tests of the host side (ingest, model loading, attachment, prior, cfg, free-variable sets)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from moshpp_amd import synth
+from moshpp_amd.c3d_io import read_c3d, write_c3d
+from moshpp_amd.cfg import make_cfg
+from moshpp_amd.chmosh import stageii_pose_ids
+from moshpp_amd.mocap_interface import MocapSession, read_mocap, write_mocap_c3d
+from moshpp_amd.models import load_surface_model
+from moshpp_amd.prior import create_gmm_body_prior
+from moshpp_amd.transformed_lm import TransformedCoeffs
+from oracle import stageii_oracle as so
+from tests.helpers import oracle_case
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_c3d_reader_on_file_from_reference_writer():
+    """The fixture was written by the reference's vendored py-c3d Writer (tests/golden/make_c3d_fixture.py)."""
+    c = read_c3d(os.path.join(GOLDEN, 'refwriter_6x41.c3d'))
+    e = np.load(os.path.join(GOLDEN, 'refwriter_6x41_expected.npz'))
+    assert c['points'].shape == (6, 41, 3) and c['frame_rate'] == 100.0
+    assert [l for l in c['labels']] == [str(l) for l in e['labels']]
+    inv = np.isnan(c['points']).any(-1)
+    np.testing.assert_array_equal(inv, e['invalid'])
+    np.testing.assert_array_equal(c['points'][~inv], e['points'][~inv].astype(np.float64))
+
+
+def test_c3d_roundtrip_and_mocap_session_rules(tmp_path):
+    rng = np.random.default_rng(0)
+    F, N = 7, 6
+    m = rng.normal(0, 0.5, (F, N, 3))            # metres
+    m[2, 1] = np.nan                              # NaN sample -> invalid
+    m[3, 2] = 0.0                                 # exact zero sample -> invalid
+    labels = ['LFHD', 'subj:RFHD', 'HEAD_TOP', '*7', 'L SHO', 'LFHD']   # prefix, alias, star, space, duplicate
+    fn = str(tmp_path / 'a.c3d')
+    write_mocap_c3d(m, labels, fn, frame_rate=60)
+    rec = read_mocap(fn)
+    assert rec['frame_rate'] == 60.0 and rec['markers'].shape == (F, N, 3)
+    assert set(rec['subject_mask']) == {'null', 'subj'}
+    ms = MocapSession(fn, 'mm', labels_map={'HEAD_TOP': 'ARIEL'})
+    assert ms.labels == ['LFHD', 'RFHD', 'ARIEL', 'LSHO', 'LFHD'] and ms.read_status
+    assert ms.markers.shape == (F, 5, 3) and ms.frame_rate == 60.0
+    good = ~np.isnan(m).any(-1) & ~(m == 0).all(-1)
+    keep = [0, 1, 2, 4, 5]
+    np.testing.assert_allclose(ms.markers[good[:, keep]], m[:, keep][good[:, keep]], atol=1e-6)   # float32 mm in the file
+    assert (ms.markers[~good[:, keep]] == 0).all()
+    d = ms.markers_asdict()
+    assert 'RFHD' not in d[2] and 'ARIEL' not in d[3] and len(d[0]) == 4   # duplicate label collapses in the dict
+    obs, vis = ms.markers_aslabeled_arrays(['ARIEL', 'LFHD', 'NOPE', 'RFHD'])
+    for t in range(F):
+        for j, l in enumerate(['ARIEL', 'LFHD', 'NOPE', 'RFHD']):
+            assert vis[t, j] == (l in d[t])
+            if vis[t, j]:
+                np.testing.assert_array_equal(obs[t, j], d[t][l])
+    # units, rotation, npz / pkl containers
+    ms2 = MocapSession(fn, 'm', mocap_rotate=[90, 0, 0], ignore_stared_labels=False)
+    assert len(ms2.labels) == 6
+    np.testing.assert_allclose(ms2.markers[0, 0], 1000 * np.array([m[0, 0, 0], -m[0, 0, 2], m[0, 0, 1]]), atol=1e-3)
+    np.savez(tmp_path / 'b.npz', markers=m * 1000, labels=np.array(labels), frame_rate=90.)
+    ms3 = MocapSession(str(tmp_path / 'b.npz'), 'mm')
+    assert ms3.frame_rate == 90.0 and ms3.labels == ['LFHD', 'RFHD', 'HEAD_TOP', 'LSHO', 'LFHD']
+    with open(tmp_path / 'c.pkl', 'wb') as f:
+        pickle.dump({'markers': m, 'labels': labels, 'frame_rate': 30}, f)
+    ms4 = MocapSession(str(tmp_path / 'c.pkl'), 'm', only_subjects=['subj'])
+    assert ms4.labels == ['RFHD'] and ms4.markers.shape == (F, 1, 3) and not ms4.multi_subject
+    assert abs(ms4.time_length() - F / 30) < 1e-12
+    with pytest.raises(ValueError):
+        read_mocap('nope.xyz')
+
+
+def test_large_c3d_many_labels(tmp_path):
+    rng = np.random.default_rng(1)
+    pts = rng.normal(0, 100, (3, 300, 3))
+    labels = [f'L{i:03d}' for i in range(300)]
+    fn = str(tmp_path / 'big.c3d')
+    write_c3d(fn, pts, labels, frame_rate=120.0)
+    c = read_c3d(fn)
+    assert c['labels'] == labels and c['points'].shape == (3, 300, 3)
+    np.testing.assert_allclose(c['points'], pts.astype(np.float32), rtol=0, atol=0)
+
+
+class _FakeCh:   # pickles as chumpy.ch.Ch would: class path 'chumpy.ch.Ch', state dict with 'x'
+    pass
+
+
+def test_model_loader_types_and_chumpy_free_pickle(tmp_path):
+    import sys
+    import types
+    dd = synth.synth_model('smplh', seed=3)
+    hp = synth.synth_hand_prior(3)
+    raw = {k: v for k, v in dd.items() if not k.startswith('_')}
+    # emulate a real SMPL pickle: shapedirs stored as a chumpy object
+    mod = types.ModuleType('chumpy'); sub = types.ModuleType('chumpy.ch')
+    Ch = type('Ch', (), {'__module__': 'chumpy.ch'})
+    sub.Ch = Ch; mod.ch = sub
+    sys.modules['chumpy'] = mod; sys.modules['chumpy.ch'] = sub
+    try:
+        obj = Ch(); obj.__dict__['x'] = raw['shapedirs']
+        raw_ch = dict(raw); raw_ch['shapedirs'] = obj
+        fn = str(tmp_path / 'model.pkl')
+        with open(fn, 'wb') as f:
+            pickle.dump(raw_ch, f)
+    finally:
+        del sys.modules['chumpy'], sys.modules['chumpy.ch']
+    np.savez(tmp_path / 'hand.npz', **hp)
+    sm = load_surface_model(fn, pose_hand_prior_fname=str(tmp_path / 'hand.npz'), use_hands_mean=True, dof_per_hand=24)
+    assert sm.model_type == 'smplh' and sm.body_dof == 66 and sm.hand_dof == 48 and sm.NP == 114 and sm.K == 52
+    np.testing.assert_array_equal(sm.shapedirs, dd['shapedirs'])
+    np.testing.assert_array_equal(sm.parents, synth.kintree_parents('smplh'))
+    assert sm.selected_components.shape == (48, 90) and (sm.selected_components[:24, 45:] == 0).all()
+    fp = sm.fullpose(np.zeros(114))
+    np.testing.assert_allclose(fp[66:], np.r_[hp['hands_meanl'], hp['hands_meanr']])
+    sm0 = load_surface_model(raw, pose_hand_prior_fname=hp, use_hands_mean=False, dof_per_hand=12)
+    assert sm0.hand_dof == 24 and (sm0.hands_mean == 0).all()
+    for mt, bd, hd in (('smpl', 72, 0), ('smplx', 75, 48), ('mano', 3, 24)):
+        d2 = {k: v for k, v in synth.synth_model(mt, seed=1, num_betas=4).items() if not k.startswith('_')}
+        s2 = load_surface_model(d2, pose_hand_prior_fname=hp, use_hands_mean=True, dof_per_hand=24)
+        assert (s2.model_type, s2.body_dof, s2.hand_dof) == (mt, bd, hd)
+    mano = {k: v for k, v in synth.synth_model('mano', seed=1, num_betas=4).items() if not k.startswith('_')}
+    assert (load_surface_model(mano, use_hands_mean=True, dof_per_hand=24).hands_mean == 0).all()   # inverted flag (:114)
+    with pytest.raises(AssertionError):
+        load_surface_model(raw, pose_hand_prior_fname=None)
+
+
+def test_attachment_and_prior_match_oracle():
+    case = oracle_case('smplh', F=2, M=53, seed=5)
+    tc = TransformedCoeffs(case['can'], case['s']['markers_latent'])
+    np.testing.assert_array_equal(tc.closest, case['closest'])
+    np.testing.assert_allclose(tc.coef, case['coef'], atol=1e-15)
+    pr = create_gmm_body_prior(case['s']['gmm'], exclude_hands=True)
+    for k in ('means', 'chols', 'weights'):
+        np.testing.assert_allclose(pr[k], case['prior'][k], rtol=1e-13)
+    assert pr['npose'] == 63 and create_gmm_body_prior(case['s']['gmm'])['npose'] == 69
+
+
+def test_attachment_collinear_fallback_and_eyeballs():
+    # three collinear nearest neighbours for one marker -> the 3rd neighbour is swapped for ALL markers (:94-101)
+    body = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 1.5, 0], [5, 5, 5], [5, 6, 5], [6, 5, 5], [9, 9, 9.]] + [[20 + i, 0, 0] for i in range(3)])
+    mk = np.array([[0.1, 0.05, 0.0], [5.1, 5.1, 5.2]])
+    tc = TransformedCoeffs(body, mk)
+    ref_closest, ref_coef = so.transformed_coeffs(body, mk)
+    np.testing.assert_array_equal(tc.closest, ref_closest)
+    np.testing.assert_allclose(tc.coef, ref_coef)
+    assert tc.closest[0, 2] == 3          # not the collinear vertex 2
+    big = np.random.default_rng(0).normal(0, 1, (10475, 3))
+    big[9383:] = 0.0                       # eyeballs sit exactly on the marker...
+    tcb = TransformedCoeffs(big, np.zeros((1, 3)))
+    assert tcb.closest.max() < 9383        # ...but are never used (:48-50, 67-69)
+
+
+def test_pose_id_sets_and_cfg():
+    for mt, NP in (('smpl', 72), ('smplh', 114), ('smplx', 123), ('mano', 27)):
+        for fingers in (False, True):
+            for toes in (False, True):
+                a = stageii_pose_ids(mt, NP, fingers, toes)
+                root, body, finger, st1, st2 = so.pose_id_sets(mt, NP, fingers, toes)
+                assert a['step1'] == list(st1) and a['step2'] == list(st2) and a['body'] == list(body)
+    ids = stageii_pose_ids('smplh', 114, False, False)
+    assert len(ids['step1']) == 60 and 30 not in ids['step1'] and 35 not in ids['step1'] and len(ids['body']) == 63
+    assert len(stageii_pose_ids('smplx', 123, True, False)['step2']) == 60 + 48
+    cfg = make_cfg(**{'surface_model.type': 'smplh', 'mocap.fname': '/a/b/c.c3d', 'moshpp.optimize_fingers': True})
+    assert cfg.opt_settings.weights.stageii_wt_data == 400 and cfg['moshpp']['optimize_fingers'] is True
+    cfg.moshpp['optimize_fingers'] = False
+    assert cfg.moshpp.optimize_fingers is False and cfg.opt_settings.maxiter == 100
+    with pytest.raises(KeyError):
+        make_cfg(**{'surface_model.type': 'smpl'})   # the reference yaml has no smpl weights table either
+    assert make_cfg(**{'surface_model.type': 'smpl', 'opt_settings.weights_type': 'smplh'}).opt_settings.weights.stageii_wt_velo == 2.5
+
+
+def test_partition_units():
+    from moshpp_amd.parallel import partition_units
+    parts = partition_units([4000] * 32, 8)
+    assert sorted(sum(parts, [])) == list(range(32)) and all(len(p) == 4 for p in parts)
+    parts = partition_units([10, 1, 1, 1, 7, 3], 2)
+    loads = [sum([10, 1, 1, 1, 7, 3][i] for i in p) for p in parts]
+    assert sorted(sum(parts, [])) == list(range(6)) and abs(loads[0] - loads[1]) <= 1
