@@ -159,6 +159,55 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL whe
                        const moshii_solve_opts* opts, int32_t n_chains, const moshii_chain_desc* chains,
                        uint32_t flags, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Chunked sequence solve: the same frame loop (src/moshpp/chmosh.py:584-724), with each sequence cut into
+ * contiguous chunks that are solved concurrently (one workgroup each) and then stitched so that the result
+ * equals the sequential chain's to within `verify_tol`:
+ *   pass 1  chunk c > 0 starts `warmup` frames early with the first-frame schedule (:629-655); those frames
+ *           are solved but not recorded.  The chain map is a contraction (data term 400 vs velocity 2.5,
+ *           moshpp_conf.yaml:118-125): the influence of the start state decays ~2.5x per frame
+ *           (tools/chunk_deviation.py: 16 frames -> <1e-7 rad).
+ *   verify  the state (pose, pose_prev, trans) with which chunk c enters its first recorded frame is compared
+ *           with the state its predecessor ended in; max|diff| <= verify_tol accepts the hand-off.
+ *   repair  a chunk that fails is re-solved from its predecessor's exact end state (warm start + velocity
+ *           term exactly as :624-626, 656-657), and its successor is re-verified; repeated until clean.
+ * The call synchronises `stream` (the verification result is read on the host).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct moshii_sequence_desc {
+    moshii_attach_t attach;
+    int32_t F;
+    const double*  obs;             /* [F][M][3]                                                   */
+    const uint8_t* vis;             /* [F][M]                                                      */
+    double*  pose;                  /* outputs as in moshii_chain_desc, one row per input frame    */
+    double*  fullpose;
+    double*  trans;
+    double*  markers_sim;
+    double*  errs;
+    int32_t* iters;
+    int32_t* status;
+} moshii_sequence_desc;
+
+typedef struct moshii_chunk_opts {
+    int32_t num_chunks;             /* chunks per sequence; 0 = fill the GPU (2 workgroups per CU)  */
+    int32_t warmup;                 /* warm-up frames per chunk (default 16)                        */
+    double  verify_tol;             /* hand-off tolerance on pose [rad] / trans [m] (default 1e-6)  */
+} moshii_chunk_opts;
+
+typedef struct moshii_chunk_report {
+    int32_t n_chunks, n_repaired, repair_rounds, warmup;
+    double  max_handoff_dev;        /* largest accepted hand-off deviation                          */
+    double  verify_tol;
+} moshii_chunk_report;
+
+/* Balanced chunk plan (pure host arithmetic, no device needed): writes starts[c] (first recorded frame) and
+ * launch_starts[c] = max(0, starts[c] - warmup) (launch_starts[0] = 0); returns the number of chunks used
+ * (<= min(num_chunks, cap, max(F,1))) or <0. */
+int moshii_plan_chunks(int32_t F, int32_t num_chunks, int32_t warmup, int32_t cap, int32_t* starts, int32_t* launch_starts);
+
+int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* opts, int32_t n_seq,
+                          const moshii_sequence_desc* seqs, const moshii_chunk_opts* chunk_opts /* NULL: defaults */,
+                          uint32_t flags, void* stream, moshii_chunk_report* report /* may be NULL */);
+
 /* Introspection for benchmarks: name and dynamic-LDS bytes of the kernel the last moshii_chain_solve used. */
 int moshii_last_launch_info(char* kernel_name, int32_t name_cap, int32_t* lds_bytes, int32_t* block_threads);
 

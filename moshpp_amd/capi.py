@@ -45,6 +45,21 @@ class ChainDesc(C.Structure):
                 ('status', C.c_void_p)]
 
 
+class SequenceDesc(C.Structure):
+    _fields_ = [('attach', C.c_void_p), ('F', C.c_int32), ('obs', C.c_void_p), ('vis', C.c_void_p),
+                ('pose', C.c_void_p), ('fullpose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p),
+                ('errs', C.c_void_p), ('iters', C.c_void_p), ('status', C.c_void_p)]
+
+
+class ChunkOpts(C.Structure):
+    _fields_ = [('num_chunks', C.c_int32), ('warmup', C.c_int32), ('verify_tol', C.c_double)]
+
+
+class ChunkReport(C.Structure):
+    _fields_ = [('n_chunks', C.c_int32), ('n_repaired', C.c_int32), ('repair_rounds', C.c_int32), ('warmup', C.c_int32),
+                ('max_handoff_dev', C.c_double), ('verify_tol', C.c_double)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     'moshii_last_error': (C.c_char_p, []),
@@ -64,6 +79,9 @@ EXPORTS = {
     'moshii_attach_markers': (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
     'moshii_chain_solve': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SolveOpts), C.c_int32, C.POINTER(ChainDesc),
                                      C.c_uint32, C.c_void_p]),
+    'moshii_plan_chunks': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _c_int_p, _c_int_p]),
+    'moshii_sequence_solve': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SolveOpts), C.c_int32, C.POINTER(SequenceDesc),
+                                        C.POINTER(ChunkOpts), C.c_uint32, C.c_void_p, C.POINTER(ChunkReport)]),
     'moshii_last_launch_info': (C.c_int, [C.c_char_p, C.c_int32, _c_int_p, _c_int_p]),
 }
 
@@ -297,6 +315,47 @@ def chain_solve_host(model: Model, prior, opts_tuple, chains):
                                  BUFFERS_HOST, None))
     del keep
     return outs
+
+
+def plan_chunks(F, num_chunks, warmup, cap=1 << 20):
+    """moshii_plan_chunks -> (starts, launch_starts) int32 arrays (host arithmetic only; works without a GPU)."""
+    n = max(1, int(num_chunks))
+    starts = np.zeros(n, dtype=np.int32); launch = np.zeros(n, dtype=np.int32)
+    c = load().moshii_plan_chunks(int(F), n, int(warmup), int(cap), _ip(starts), _ip(launch))
+    if c < 0:
+        check(c)
+    return starts[:c].copy(), launch[:c].copy()
+
+
+def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, warmup=16, verify_tol=1e-6):
+    """moshii_sequence_solve on host buffers.  seqs: list of dict(attach, obs[F,M,3], vis[F,M]).
+    Returns (list of per-sequence output dicts as chain_solve_host, report dict)."""
+    lib = load()
+    opts, _keep = opts_tuple
+    n = len(seqs)
+    descs = (SequenceDesc * n)()
+    outs, keep = [], []
+    for i, sq in enumerate(seqs):
+        att = sq['attach']
+        obs = _f64(sq['obs']); vis = np.ascontiguousarray(sq['vis'], dtype=np.uint8)
+        F, M = vis.shape
+        assert obs.shape == (F, M, 3) and M == att.M
+        o = dict(pose=np.zeros((F, model.NP)), fullpose=np.zeros((F, model.P)), trans=np.zeros((F, 3)),
+                 markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, 4)), iters=np.zeros((F, 2), dtype=np.int32),
+                 status=np.zeros(F, dtype=np.int32))
+        d = descs[i]
+        d.attach = att.handle; d.F = F; d.obs = obs.ctypes.data; d.vis = vis.ctypes.data
+        keep += [obs, vis]
+        for key in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status'):
+            setattr(d, key, o[key].ctypes.data)
+        outs.append(o)
+    co = ChunkOpts(int(num_chunks), int(warmup), float(verify_tol))
+    rep = ChunkReport()
+    check(lib.moshii_sequence_solve(model.handle, prior.handle if prior is not None else None, C.byref(opts), n, descs,
+                                    C.byref(co), BUFFERS_HOST, None, C.byref(rep)))
+    del keep
+    report = {k: getattr(rep, k) for k, _ in ChunkReport._fields_}
+    return outs, report
 
 
 def last_launch_info():

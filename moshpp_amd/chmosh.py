@@ -101,16 +101,21 @@ class StageIISolver:
                                    maxiter=maxiter, num_train_markers=NUM_TRAIN_MARKERS)
         self.optimize_fingers = bool(optimize_fingers)
 
-    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=48):
-        """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0)."""
+    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=16, verify_tol=1e-6):
+        """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
+        chain_mode 'sequential': one chain, the reference's exact frame order (chmosh.py:584).
+        chain_mode 'chunked': moshii_sequence_solve -- concurrent chunks with warm-up overlap, verified and
+        repaired against the sequential chain to `verify_tol` (out['chunk_report'])."""
         F = obs.shape[0]
         if chain_mode == 'sequential' or F == 0:
             out = capi.chain_solve_host(self.dev, self.prior, self.opts,
                                         [dict(attach=self.attach, obs=obs, vis=vis, first=True)])[0]
             return out
         if chain_mode == 'chunked':
-            from .chunking import solve_chunked
-            return solve_chunked(self, obs, vis, num_chunks=num_chunks, warmup=chunk_warmup)
+            outs, report = capi.sequence_solve_host(self.dev, self.prior, self.opts, [dict(attach=self.attach, obs=obs, vis=vis)],
+                                                    num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol)
+            outs[0]['chunk_report'] = report
+            return outs[0]
         raise ValueError(f'unknown chain_mode {chain_mode}')
 
 
@@ -174,7 +179,8 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
 
     # 5. the frame loop (:584-724) on the GPU
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', 'sequential'),
-                       num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 48)))
+                       num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 16)),
+                       verify_tol=float(_get(ext, 'verify_tol', 1e-6)))
     for fi in np.flatnonzero(out['status'] == 1):
         logger.error(f'no available observed markers for frame {selected_frames[fi]}. skipping the frame.')
     if np.any(out['status'] < 0):

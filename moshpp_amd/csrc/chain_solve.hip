@@ -956,28 +956,41 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
     const AttachDev at = *chp->att;
     const Ctx cx = make_ctx(lds, ly);
 
-    const int NP = md.NP, M = at.M, F = chp->F;
+    const int NP = md.NP, M = at.M, F = chp->F, skip = chp->skip;
+    bool has_prev, first;
     {
+        const double* is = chp->init_state;
         const double* ip = chp->init_pose;
         const double* iv = chp->init_prev;
         const double* it = chp->init_trans;
         for (int i = tid; i < NP; i += MOSHII_TPB) {
-            cx.pose[i] = ip ? ip[i] : 0.0;
-            cx.pose_prev[i] = iv ? iv[i] : 0.0;
+            cx.pose[i] = is ? is[i] : (ip ? ip[i] : 0.0);
+            cx.pose_prev[i] = is ? is[NP + i] : (iv ? iv[i] : 0.0);
             cx.vtarget[i] = 0.0;
             cx.pid2prior[i] = -1;
         }
-        if (tid < 3) cx.trans[tid] = it ? it[tid] : 0.0;
+        if (tid < 3) cx.trans[tid] = is ? is[2 * NP + tid] : (it ? it[tid] : 0.0);
+        has_prev = is ? (is[2 * NP + 3] != 0.0) : (iv != nullptr);
+        first = is ? (is[2 * NP + 4] != 0.0) : (chp->first != 0);
     }
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
     __syncthreads();
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
-    bool has_prev = chp->init_prev != nullptr;
-    bool first = chp->first != 0;
     PROF_BEGIN();
 
-    for (int t = 0; t < F; ++t) {
+    for (int t = 0; t <= F; ++t) {
+        // chunk hand-off states: moshii_sequence_solve checks a chunk's entry state against its predecessor's final one
+        for (int which = 0; which < 2; ++which) {
+            double* so = (which == 0) ? ((t == skip) ? chp->entry_state : nullptr) : ((t == F) ? chp->final_state : nullptr);
+            if (so == nullptr) continue;
+            for (int i = tid; i < NP; i += MOSHII_TPB) { so[i] = cx.pose[i]; so[NP + i] = cx.pose_prev[i]; }
+            if (tid < 3) so[2 * NP + tid] = cx.trans[tid];
+            if (tid == 3) so[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+            if (tid == 4) so[2 * NP + 4] = first ? 1.0 : 0.0;
+        }
+        if (t == F) break;
+        const bool record = t >= skip;
         const uint8_t* visrow = chp->vis + (size_t)t * M;
         // visible-marker list (chmosh.py:591-594), kept in label order
         if (tid == 0) {
@@ -989,7 +1002,7 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
         const int nobs = (int)cx.scal[S_TMP1];
         if (nobs == 0) {   // chmosh.py:586-588
             int* st = chp->status;
-            if (tid == 0 && st) st[t] = 1;
+            if (tid == 0 && st && record) st[t] = 1;
             __syncthreads();
             continue;
         }
@@ -1026,7 +1039,7 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
                                   round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, n_iter, n_fev, fail);
         }
         first = false;
-        {   // record
+        if (record) {   // record
             double* o;
             if ((o = chp->pose) != nullptr) for (int i = tid; i < NP; i += MOSHII_TPB) o[(size_t)t * NP + i] = cx.pose[i];
             if ((o = chp->fullpose) != nullptr) for (int i = tid; i < md.P; i += MOSHII_TPB) o[(size_t)t * md.P + i] = cx.fullpose[i];

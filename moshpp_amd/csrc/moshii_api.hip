@@ -561,21 +561,34 @@ int moshii_attach_markers(moshii_attach_t a, int32_t F, const double* pose, cons
     return MOSHII_OK;
 }
 
-int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* o, int32_t n_chains,
-                       const moshii_chain_desc* chains, uint32_t flags, void* stream_) {
-    if (!m || !o || !chains || n_chains < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+}  // extern "C" (reopened below)
+
+// ---- shared launch preparation for moshii_chain_solve / moshii_sequence_solve -----------------------
+namespace {
+
+struct LaunchCfg {
+    int nblk = 0;
+    ChainLayout ly;
+    size_t lds_bytes = 0;
+    OptsDev od;
+    PriorDev pd;
+    ModelDev md;
+};
+
+// Validates the options, picks the J^T J register tiling and the LDS layout (marker-tile size Tm as large as the
+// per-workgroup LDS budget allows) and uploads the id lists.  `extra_bytes` of the model's control scratch are
+// reserved after the id lists; their device/host offsets come back through ctl_off.
+int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* o, int Mmax, int Nvmax, int NWmax,
+                   int n_workgroups, hipStream_t stream, size_t extra_bytes, LaunchCfg* cfg, size_t* ctl_off) {
     if (!m->betas_set) return fail(MOSHII_ERR_ARG, "moshii_model_set_betas has not been called");
     if (o->n_body > 0 && (!prior || prior->npose != o->n_body)) return fail(MOSHII_ERR_ARG, "prior npose must equal n_body");
     if (o->n_step1 < 0 || o->n_step2 < 0 || o->n_step1 > m->NP || o->n_step2 > m->NP) return fail(MOSHII_ERR_ARG, "bad free-variable lists");
-    hipStream_t stream = (hipStream_t)stream_;
-    const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
-    const int NP = m->NP, P = m->P;
+    const int NP = m->NP;
     const int nmax = 3 + std::max(o->n_step1, o->n_step2);
     int nblk = pick_nblk(nmax);
     if (nblk < 0) return fail(MOSHII_ERR_UNSUPPORTED, "more than 125 free pose variables per step");
     if (const char* e = getenv("MOSHII_FORCE_NBLK")) nblk = std::max(nblk, atoi(e));
-    // needed joints (superset over both steps)
-    auto count_kf = [&](const int32_t* ids, int n) {
+    auto count_kf = [&](const int32_t* ids, int n) {   // needed joints (superset over both steps)
         std::vector<char> need(m->K, 0);
         for (int i = 0; i < n; ++i) {
             if (ids[i] < 0 || ids[i] >= NP) return -1;
@@ -590,121 +603,347 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     if (o->n_finger > 0)
         for (int i = 1; i < o->n_finger; ++i)
             if (o->finger_ids[i] != o->finger_ids[i - 1] + 1) return fail(MOSHII_ERR_UNSUPPORTED, "finger ids must be contiguous");
-    int Mmax = 0, Nvmax = 0, NWmax = 1;
-    for (int c = 0; c < n_chains; ++c) {
-        const moshii_chain_desc& ch = chains[c];
-        if (!ch.attach || ch.attach->model != m || ch.F < 0 || !ch.obs || !ch.vis) return fail(MOSHII_ERR_ARG, "bad chain descriptor");
-        Mmax = std::max(Mmax, ch.attach->M); Nvmax = std::max(Nvmax, ch.attach->Nv); NWmax = std::max(NWmax, ch.attach->NW);
-    }
     const int G = prior ? prior->G : 0, npose = prior ? prior->npose : 0;
-    // marker-tile size: as large as fits the LDS budget
-    int budget = 64 * 1024;
+    // LDS budget per workgroup: a lone chain may take the whole CU (160 KiB); a grid that fills the chip leaves
+    // room for two workgroups per CU so that one chain's dependency stalls are covered by the other's work.
+    int n_cu = 256;
+    { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 1) n_cu = 256; }
+    int budget = (n_workgroups <= n_cu) ? 160 * 1024 : 80 * 1024;
     if (const char* e = getenv("MOSHII_LDS_BUDGET")) budget = atoi(e);
-    int Tm = 16;
+    int Tm = std::min(16, std::max(2, Mmax));
     if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(32, atoi(e)));
     ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk);
     while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk); }
     const size_t lds_bytes = (size_t)ly.total_doubles * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(MOSHII_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of a CU");
 
-    // ---- control data -> scratch
-    size_t need = sizeof(ChainDev) * n_chains + sizeof(int) * (o->n_step1 + o->n_step2 + o->n_body + o->n_finger + 8) +
-                  sizeof(double) * (size_t)n_chains * (2 * NP + 4) + 256;
+    const size_t nids = (size_t)o->n_step1 + o->n_step2 + o->n_body + o->n_finger;
+    const size_t need = sizeof(int) * (nids + 16) + 64 + extra_bytes;
     int rc = m->scratch.reserve(need);
     if (rc) return rc;
-    std::vector<char> hostbuf(need, 0);
-    size_t off = 0;
-    auto put = [&](const void* src, size_t bytes) { off = (off + 15) & ~size_t(15); size_t o2 = off; if (src) memcpy(hostbuf.data() + off, src, bytes); off += bytes; return o2; };
-    const size_t o_step1 = put(o->step1_ids, sizeof(int) * o->n_step1);
-    const size_t o_step2 = put(o->step2_ids, sizeof(int) * o->n_step2);
-    const size_t o_body = put(o->body_ids, sizeof(int) * o->n_body);
-    const size_t o_finger = put(o->finger_ids, sizeof(int) * o->n_finger);
-    std::vector<size_t> o_ip(n_chains, (size_t)-1), o_it(n_chains, (size_t)-1), o_iv(n_chains, (size_t)-1);
-    for (int c = 0; c < n_chains; ++c) {
-        if (chains[c].init_pose) o_ip[c] = put(chains[c].init_pose, sizeof(double) * NP);
-        if (chains[c].init_trans) o_it[c] = put(chains[c].init_trans, sizeof(double) * 3);
-        if (chains[c].init_pose_prev) o_iv[c] = put(chains[c].init_pose_prev, sizeof(double) * NP);
-    }
-    const size_t o_chains = put(nullptr, sizeof(ChainDev) * n_chains);
-    if (off > need) return fail(MOSHII_ERR_ARG, "internal: scratch overflow");
+    std::vector<int> ids;
+    ids.reserve(nids);
+    const size_t e1 = 0, e2 = e1 + o->n_step1, eb = e2 + o->n_step2, ef = eb + o->n_body;
+    ids.insert(ids.end(), o->step1_ids, o->step1_ids + o->n_step1);
+    ids.insert(ids.end(), o->step2_ids, o->step2_ids + o->n_step2);
+    ids.insert(ids.end(), o->body_ids, o->body_ids + o->n_body);
+    ids.insert(ids.end(), o->finger_ids, o->finger_ids + o->n_finger);
     char* dbase = m->scratch.ptr;
+    if (!ids.empty()) {
+        HIP_TRY(hipMemcpyAsync(dbase, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // `ids` is pageable and goes out of scope
+    }
+    m->scratch.used = true; m->scratch.last_stream = stream;
+    *ctl_off = (ids.size() * sizeof(int) + 63) & ~size_t(63);
 
-    struct Staged { double *obs, *pose, *fullpose, *trans, *msim, *errs; uint8_t* vis; int *iters, *status; };
+    OptsDev& od = cfg->od;
+    od.wt_data = o->wt_data; od.wt_velo = o->wt_velo; od.wt_poseB = o->wt_poseB; od.wt_poseH = o->wt_poseH;
+    od.wt_annealing = o->wt_annealing; od.num_train_markers = o->num_train_markers;
+    od.e3_first = o->e3_first; od.e3 = o->e3; od.delta0 = o->delta0; od.maxiter = o->maxiter;
+    od.n1 = o->n_step1; od.n2 = o->n_step2; od.nbody = o->n_body; od.nfinger = o->n_finger;
+    const int* dids = (const int*)dbase;
+    od.step1 = dids + e1; od.step2 = dids + e2; od.body = dids + eb; od.finger = dids + ef;
+    memset(&cfg->pd, 0, sizeof(cfg->pd));
+    if (prior) cfg->pd = prior->dev();
+    cfg->md = m->dev();
+    cfg->nblk = nblk; cfg->ly = ly; cfg->lds_bytes = lds_bytes;
+    return MOSHII_OK;
+}
+
+int launch_chains(const LaunchCfg& cfg, int n, const ChainDev* d_chains, hipStream_t stream) {
+    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly));
+    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + ">";
+    g_last.lds = (int)cfg.lds_bytes; g_last.threads = MOSHII_TPB;
+    return MOSHII_OK;
+}
+
+// host<->device staging of one sequence's per-frame buffers (MOSHII_BUFFERS_HOST callers)
+struct Staged {
+    double *obs = nullptr, *pose = nullptr, *fullpose = nullptr, *trans = nullptr, *msim = nullptr, *errs = nullptr;
+    uint8_t* vis = nullptr;
+    int *iters = nullptr, *status = nullptr;
+    void release() {
+        void* ptrs[] = {obs, vis, pose, fullpose, trans, msim, errs, iters, status};
+        for (void* q : ptrs) if (q) hipFree(q);
+        *this = Staged();
+    }
+};
+
+struct FrameBufs {   // the per-frame arrays shared by moshii_chain_desc and moshii_sequence_desc
+    int F, M;
+    const double* obs; const uint8_t* vis;
+    double *pose, *fullpose, *trans, *msim, *errs; int *iters, *status;
+};
+
+int stage_in(const FrameBufs& h, int NP, int P, hipStream_t stream, Staged* s) {
+    const size_t Fz = std::max(h.F, 1), M = h.M;
+    int rc;
+    if ((rc = dev_upload(h.obs, (size_t)h.F * M * 3, &s->obs))) return rc;
+    if ((rc = dev_upload(h.vis, (size_t)h.F * M, &s->vis))) return rc;
+    HIP_TRY(hipMalloc((void**)&s->pose, Fz * NP * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->fullpose, Fz * P * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->trans, Fz * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->msim, Fz * M * 3 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->errs, Fz * 4 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->iters, Fz * 2 * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&s->status, Fz * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(s->pose, 0, Fz * NP * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(s->fullpose, 0, Fz * P * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(s->trans, 0, Fz * 3 * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(s->msim, 0, Fz * M * 3 * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(s->errs, 0, Fz * 4 * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(s->iters, 0, Fz * 2 * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(s->status, 0, Fz * sizeof(int), stream));
+    return MOSHII_OK;
+}
+
+int stage_out(const FrameBufs& h, int NP, int P, Staged* s) {
+    const size_t F = h.F, M = h.M;
+    if (F) {
+        if (h.pose) HIP_TRY(hipMemcpy(h.pose, s->pose, F * NP * sizeof(double), hipMemcpyDeviceToHost));
+        if (h.fullpose) HIP_TRY(hipMemcpy(h.fullpose, s->fullpose, F * P * sizeof(double), hipMemcpyDeviceToHost));
+        if (h.trans) HIP_TRY(hipMemcpy(h.trans, s->trans, F * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (h.msim) HIP_TRY(hipMemcpy(h.msim, s->msim, F * M * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (h.errs) HIP_TRY(hipMemcpy(h.errs, s->errs, F * 4 * sizeof(double), hipMemcpyDeviceToHost));
+        if (h.iters) HIP_TRY(hipMemcpy(h.iters, s->iters, F * 2 * sizeof(int), hipMemcpyDeviceToHost));
+        if (h.status) HIP_TRY(hipMemcpy(h.status, s->status, F * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    s->release();
+    return MOSHII_OK;
+}
+
+// max |entry_c - final_pred(c)| per chunk (pose, trans, and pose_prev when the velocity term is live); a flag
+// mismatch (first-frame schedule pending / velocity term missing on one side) counts as infinite deviation.
+__global__ void k_verify_chunks(int n, int NP, const int* __restrict__ pred, const double* __restrict__ entry,
+                                const double* __restrict__ fin, double* __restrict__ dev) {
+    const int c = blockIdx.x;
+    if (c >= n) return;
+    const int p = pred[c];
+    __shared__ double red[64];
+    double d = 0.0;
+    if (p >= 0) {
+        const int S = 2 * NP + 5;
+        const double* a = entry + (size_t)c * S;
+        const double* b = fin + (size_t)p * S;
+        const bool flags_ok = (a[2 * NP + 3] == b[2 * NP + 3]) && (a[2 * NP + 4] == b[2 * NP + 4]);
+        const bool hp = a[2 * NP + 3] != 0.0;
+        for (int i = threadIdx.x; i < 2 * NP + 3; i += blockDim.x) {
+            if (i >= NP && i < 2 * NP && !hp) continue;
+            d = fmax(d, fabs(a[i] - b[i]));
+        }
+        if (!flags_ok || !(d == d)) d = 1e300;
+    }
+    red[threadIdx.x] = d;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) dev[c] = red[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* o, int32_t n_chains,
+                       const moshii_chain_desc* chains, uint32_t flags, void* stream_) {
+    if (!m || !o || !chains || n_chains < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
+    const int NP = m->NP, P = m->P;
+    int Mmax = 0, Nvmax = 0, NWmax = 1;
+    for (int c = 0; c < n_chains; ++c) {
+        const moshii_chain_desc& ch = chains[c];
+        if (!ch.attach || ch.attach->model != m || ch.F < 0 || !ch.obs || !ch.vis) return fail(MOSHII_ERR_ARG, "bad chain descriptor");
+        Mmax = std::max(Mmax, ch.attach->M); Nvmax = std::max(Nvmax, ch.attach->Nv); NWmax = std::max(NWmax, ch.attach->NW);
+    }
+    // control block after the id lists: [ChainDev x n][init vectors]
+    const size_t extra = sizeof(ChainDev) * n_chains + sizeof(double) * (size_t)n_chains * (2 * NP + 4) + 256;
+    LaunchCfg cfg;
+    size_t ctl = 0;
+    int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, n_chains, stream, extra, &cfg, &ctl);
+    if (rc) return rc;
+    char* dbase = m->scratch.ptr + ctl;
+    std::vector<char> hostbuf(extra, 0);
+    size_t off = sizeof(ChainDev) * n_chains;
+    auto put = [&](const void* src, size_t bytes) { off = (off + 15) & ~size_t(15); size_t o2 = off; memcpy(hostbuf.data() + off, src, bytes); off += bytes; return o2; };
     std::vector<Staged> st(dev ? 0 : n_chains);
     std::vector<ChainDev> cds(n_chains);
     for (int c = 0; c < n_chains; ++c) {
         const moshii_chain_desc& ch = chains[c];
         ChainDev& cd = cds[c];
-        const int M = ch.attach->M, F = ch.F;
-        cd.att = ch.attach->d_self; cd.F = F; cd.first = ch.first_frame_schedule;
-        cd.init_pose = (o_ip[c] == (size_t)-1) ? nullptr : (const double*)(dbase + o_ip[c]);
-        cd.init_trans = (o_it[c] == (size_t)-1) ? nullptr : (const double*)(dbase + o_it[c]);
-        cd.init_prev = (o_iv[c] == (size_t)-1) ? nullptr : (const double*)(dbase + o_iv[c]);
+        memset(&cd, 0, sizeof(cd));
+        cd.att = ch.attach->d_self; cd.F = ch.F; cd.first = ch.first_frame_schedule;
+        if (ch.init_pose) cd.init_pose = (const double*)(dbase + put(ch.init_pose, sizeof(double) * NP));
+        if (ch.init_trans) cd.init_trans = (const double*)(dbase + put(ch.init_trans, sizeof(double) * 3));
+        if (ch.init_pose_prev) cd.init_prev = (const double*)(dbase + put(ch.init_pose_prev, sizeof(double) * NP));
         if (dev) {
             cd.obs = ch.obs; cd.vis = ch.vis; cd.pose = ch.pose; cd.fullpose = ch.fullpose; cd.trans = ch.trans;
             cd.msim = ch.markers_sim; cd.errs = ch.errs; cd.iters = ch.iters; cd.status = ch.status;
         } else {
+            const FrameBufs fb{ch.F, ch.attach->M, ch.obs, ch.vis, ch.pose, ch.fullpose, ch.trans, ch.markers_sim, ch.errs, ch.iters, ch.status};
             Staged& s = st[c];
-            memset(&s, 0, sizeof(s));
-            const size_t Fz = std::max(F, 1);
-            if ((rc = dev_upload(ch.obs, (size_t)F * M * 3, &s.obs))) return rc;
-            if ((rc = dev_upload(ch.vis, (size_t)F * M, &s.vis))) return rc;
-            HIP_TRY(hipMalloc((void**)&s.pose, Fz * NP * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&s.fullpose, Fz * P * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&s.trans, Fz * 3 * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&s.msim, Fz * M * 3 * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&s.errs, Fz * 4 * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&s.iters, Fz * 2 * sizeof(int)));
-            HIP_TRY(hipMalloc((void**)&s.status, Fz * sizeof(int)));
-            HIP_TRY(hipMemsetAsync(s.pose, 0, Fz * NP * sizeof(double), stream));
-            HIP_TRY(hipMemsetAsync(s.fullpose, 0, Fz * P * sizeof(double), stream));
-            HIP_TRY(hipMemsetAsync(s.trans, 0, Fz * 3 * sizeof(double), stream));
-            HIP_TRY(hipMemsetAsync(s.msim, 0, Fz * M * 3 * sizeof(double), stream));
-            HIP_TRY(hipMemsetAsync(s.errs, 0, Fz * 4 * sizeof(double), stream));
-            HIP_TRY(hipMemsetAsync(s.iters, 0, Fz * 2 * sizeof(int), stream));
-            HIP_TRY(hipMemsetAsync(s.status, 0, Fz * sizeof(int), stream));
+            if ((rc = stage_in(fb, NP, P, stream, &s))) return rc;
             cd.obs = s.obs; cd.vis = s.vis; cd.pose = s.pose; cd.fullpose = s.fullpose; cd.trans = s.trans;
             cd.msim = s.msim; cd.errs = s.errs; cd.iters = s.iters; cd.status = s.status;
         }
     }
-    memcpy(hostbuf.data() + o_chains, cds.data(), sizeof(ChainDev) * n_chains);
+    if (off > extra) return fail(MOSHII_ERR_ARG, "internal: scratch overflow");
+    memcpy(hostbuf.data(), cds.data(), sizeof(ChainDev) * n_chains);
     HIP_TRY(hipMemcpyAsync(dbase, hostbuf.data(), off, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // hostbuf is pageable and goes out of scope
-    m->scratch.used = true; m->scratch.last_stream = stream;
-
-    OptsDev od;
-    od.wt_data = o->wt_data; od.wt_velo = o->wt_velo; od.wt_poseB = o->wt_poseB; od.wt_poseH = o->wt_poseH;
-    od.wt_annealing = o->wt_annealing; od.num_train_markers = o->num_train_markers;
-    od.e3_first = o->e3_first; od.e3 = o->e3; od.delta0 = o->delta0; od.maxiter = o->maxiter;
-    od.n1 = o->n_step1; od.n2 = o->n_step2; od.nbody = o->n_body; od.nfinger = o->n_finger;
-    od.step1 = (const int*)(dbase + o_step1); od.step2 = (const int*)(dbase + o_step2);
-    od.body = (const int*)(dbase + o_body); od.finger = (const int*)(dbase + o_finger);
-    PriorDev pd;
-    memset(&pd, 0, sizeof(pd));
-    if (prior) pd = prior->dev();
-    ModelDev md = m->dev();
-    HIP_TRY(moshii_launch_chain_solve(nblk, n_chains, lds_bytes, stream, (const ChainDev*)(dbase + o_chains), &md, &pd, &od, &ly));
-    g_last.name = "k_chain_solve<" + std::to_string(nblk) + ">";
-    g_last.lds = (int)lds_bytes; g_last.threads = MOSHII_TPB;
+    if ((rc = launch_chains(cfg, n_chains, (const ChainDev*)dbase, stream))) return rc;
     if (!dev) {
         HIP_TRY(hipStreamSynchronize(stream));
         for (int c = 0; c < n_chains; ++c) {
             const moshii_chain_desc& ch = chains[c];
-            Staged& s = st[c];
-            const size_t F = ch.F, M = ch.attach->M;
-            if (F) {
-                if (ch.pose) HIP_TRY(hipMemcpy(ch.pose, s.pose, F * NP * sizeof(double), hipMemcpyDeviceToHost));
-                if (ch.fullpose) HIP_TRY(hipMemcpy(ch.fullpose, s.fullpose, F * P * sizeof(double), hipMemcpyDeviceToHost));
-                if (ch.trans) HIP_TRY(hipMemcpy(ch.trans, s.trans, F * 3 * sizeof(double), hipMemcpyDeviceToHost));
-                if (ch.markers_sim) HIP_TRY(hipMemcpy(ch.markers_sim, s.msim, F * M * 3 * sizeof(double), hipMemcpyDeviceToHost));
-                if (ch.errs) HIP_TRY(hipMemcpy(ch.errs, s.errs, F * 4 * sizeof(double), hipMemcpyDeviceToHost));
-                if (ch.iters) HIP_TRY(hipMemcpy(ch.iters, s.iters, F * 2 * sizeof(int), hipMemcpyDeviceToHost));
-                if (ch.status) HIP_TRY(hipMemcpy(ch.status, s.status, F * sizeof(int), hipMemcpyDeviceToHost));
-            }
-            void* ptrs[] = {s.obs, s.vis, s.pose, s.fullpose, s.trans, s.msim, s.errs, s.iters, s.status};
-            for (void* q : ptrs) if (q) hipFree(q);
+            const FrameBufs fb{ch.F, ch.attach->M, ch.obs, ch.vis, ch.pose, ch.fullpose, ch.trans, ch.markers_sim, ch.errs, ch.iters, ch.status};
+            if ((rc = stage_out(fb, NP, P, &st[c]))) return rc;
         }
     }
+    return MOSHII_OK;
+}
+
+int moshii_plan_chunks(int32_t F, int32_t num_chunks, int32_t warmup, int32_t cap, int32_t* starts, int32_t* launch_starts) {
+    if (F < 0 || num_chunks < 1 || warmup < 0 || cap < 1 || !starts || !launch_starts) return fail(MOSHII_ERR_ARG, "bad argument");
+    int C = std::min<int64_t>(num_chunks, std::max(F, 1));
+    C = std::min(C, cap);
+    for (int c = 0; c < C; ++c) {
+        starts[c] = (int32_t)(((int64_t)F * c) / C);                 // balanced: lengths differ by at most one frame
+        launch_starts[c] = (c == 0) ? 0 : std::max(0, starts[c] - warmup);
+    }
+    return C;
+}
+
+int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* o, int32_t n_seq,
+                          const moshii_sequence_desc* seqs, const moshii_chunk_opts* co, uint32_t flags, void* stream_,
+                          moshii_chunk_report* report) {
+    if (!m || !o || !seqs || n_seq < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
+    const int NP = m->NP, P = m->P, S = 2 * NP + 5;
+    const int warmup = co ? std::max(0, co->warmup) : 16;
+    const double tol = (co && co->verify_tol > 0.0) ? co->verify_tol : 1e-6;
+    int Mmax = 0, Nvmax = 0, NWmax = 1;
+    int64_t Ftot = 0;
+    for (int q = 0; q < n_seq; ++q) {
+        const moshii_sequence_desc& sq = seqs[q];
+        if (!sq.attach || sq.attach->model != m || sq.F < 0 || !sq.obs || !sq.vis) return fail(MOSHII_ERR_ARG, "bad sequence descriptor");
+        Mmax = std::max(Mmax, sq.attach->M); Nvmax = std::max(Nvmax, sq.attach->Nv); NWmax = std::max(NWmax, sq.attach->NW);
+        Ftot += sq.F;
+    }
+    // ---- chunk plan
+    int n_cu = 256;
+    { int d = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d); if (n_cu < 1) n_cu = 256; }
+    int want_total = co ? co->num_chunks : 0;   // chunks per sequence when > 0
+    struct Chunk { int seq, s, e, a, pred; };
+    std::vector<Chunk> chunks;
+    {
+        const int min_len = std::max(4, warmup / 2);
+        const int64_t slots = 2 * (int64_t)n_cu;   // two workgroups per CU (prepare_launch's LDS budget for a full grid)
+        std::vector<int32_t> st, ls;
+        for (int q = 0; q < n_seq; ++q) {
+            const int F = seqs[q].F;
+            int C = want_total;
+            if (C <= 0) {   // auto: fill the chip once, but keep chunks at least min_len frames long
+                const int64_t share = std::max<int64_t>(1, (slots * F) / std::max<int64_t>(Ftot, 1));
+                C = (int)std::max<int64_t>(1, std::min<int64_t>(share, F / min_len));
+            }
+            st.assign(std::max(C, 1), 0); ls.assign(std::max(C, 1), 0);
+            C = moshii_plan_chunks(F, C, warmup, 1 << 20, st.data(), ls.data());
+            if (C < 0) return C;
+            for (int c = 0; c < C; ++c) {
+                Chunk ck; ck.seq = q; ck.s = st[c]; ck.e = (c + 1 < C) ? st[c + 1] : F; ck.a = ls[c];
+                ck.pred = (c == 0) ? -1 : (int)chunks.size() - 1;
+                chunks.push_back(ck);
+            }
+        }
+    }
+    const int NC = (int)chunks.size();
+    // ---- launch preparation + control block: [ChainDev x NC (pass 1)][ChainDev x NC (repairs)][pred x NC]
+    const size_t extra = 2 * sizeof(ChainDev) * NC + sizeof(int) * NC + 256;
+    LaunchCfg cfg;
+    size_t ctl = 0;
+    int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, NC, stream, extra, &cfg, &ctl);
+    if (rc) return rc;
+    char* dbase = m->scratch.ptr + ctl;
+    ChainDev* d_pass1 = (ChainDev*)dbase;
+    ChainDev* d_repair = d_pass1 + NC;
+    int* d_pred = (int*)(d_repair + NC);
+    double *d_entry = nullptr, *d_final = nullptr, *d_dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_entry, (size_t)NC * S * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&d_final, (size_t)NC * S * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&d_dev, (size_t)NC * sizeof(double)));
+    auto cleanup = [&]() { hipFree(d_entry); hipFree(d_final); hipFree(d_dev); };
+    std::vector<Staged> st(dev ? 0 : n_seq);
+    std::vector<FrameBufs> fbs(n_seq), dbs(n_seq);
+    for (int q = 0; q < n_seq; ++q) {
+        const moshii_sequence_desc& sq = seqs[q];
+        fbs[q] = FrameBufs{sq.F, sq.attach->M, sq.obs, sq.vis, sq.pose, sq.fullpose, sq.trans, sq.markers_sim, sq.errs, sq.iters, sq.status};
+        dbs[q] = fbs[q];
+        if (!dev) {
+            Staged& s = st[q];
+            if ((rc = stage_in(fbs[q], NP, P, stream, &s))) { cleanup(); return rc; }
+            dbs[q].obs = s.obs; dbs[q].vis = s.vis; dbs[q].pose = s.pose; dbs[q].fullpose = s.fullpose; dbs[q].trans = s.trans;
+            dbs[q].msim = s.msim; dbs[q].errs = s.errs; dbs[q].iters = s.iters; dbs[q].status = s.status;
+        }
+    }
+    auto make_chain = [&](const Chunk& ck, int from, int idx, bool repair) {
+        // a chain over frames [from, ck.e) of its sequence; rows are addressed relative to `from`
+        const FrameBufs& b = dbs[ck.seq];
+        const size_t M = b.M;
+        ChainDev cd;
+        memset(&cd, 0, sizeof(cd));
+        cd.att = seqs[ck.seq].attach->d_self;
+        cd.F = ck.e - from; cd.first = 1; cd.skip = ck.s - from;
+        cd.obs = b.obs + (size_t)from * M * 3; cd.vis = b.vis + (size_t)from * M;
+        cd.pose = b.pose ? b.pose + (size_t)from * NP : nullptr;
+        cd.fullpose = b.fullpose ? b.fullpose + (size_t)from * P : nullptr;
+        cd.trans = b.trans ? b.trans + (size_t)from * 3 : nullptr;
+        cd.msim = b.msim ? b.msim + (size_t)from * M * 3 : nullptr;
+        cd.errs = b.errs ? b.errs + (size_t)from * 4 : nullptr;
+        cd.iters = b.iters ? b.iters + (size_t)from * 2 : nullptr;
+        cd.status = b.status ? b.status + (size_t)from : nullptr;
+        cd.final_state = d_final + (size_t)idx * S;
+        if (repair) cd.init_state = d_final + (size_t)ck.pred * S;
+        else cd.entry_state = d_entry + (size_t)idx * S;
+        return cd;
+    };
+    std::vector<ChainDev> cds(NC);
+    std::vector<int> pred(NC);
+    for (int c = 0; c < NC; ++c) { cds[c] = make_chain(chunks[c], chunks[c].a, c, false); pred[c] = chunks[c].pred; }
+    HIP_TRY(hipMemcpyAsync(d_pass1, cds.data(), sizeof(ChainDev) * NC, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_pred, pred.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if ((rc = launch_chains(cfg, NC, d_pass1, stream))) { cleanup(); return rc; }
+    // ---- verify the hand-offs; re-solve (exactly, from the predecessor's final state) the chunks that fail
+    std::vector<double> hdev(NC, 0.0);
+    std::vector<char> exact(NC, 0);
+    int n_repaired = 0, rounds = 0;
+    double max_dev = 0.0;
+    while (true) {
+        hipLaunchKernelGGL(k_verify_chunks, dim3(NC), dim3(64), 0, stream, NC, NP, d_pred, d_entry, d_final, d_dev);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hdev.data(), d_dev, sizeof(double) * NC, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::vector<char> failing(NC, 0);
+        for (int c = 0; c < NC; ++c) failing[c] = !exact[c] && chunks[c].pred >= 0 && !(hdev[c] <= tol);
+        std::vector<int> todo;   // failing chunks whose predecessor's end state is already final
+        for (int c = 0; c < NC; ++c) if (failing[c] && !failing[chunks[c].pred]) todo.push_back(c);
+        if (todo.empty()) break;
+        std::vector<ChainDev> rep(todo.size());
+        for (size_t i = 0; i < todo.size(); ++i) { rep[i] = make_chain(chunks[todo[i]], chunks[todo[i]].s, todo[i], true); exact[todo[i]] = 1; }
+        HIP_TRY(hipMemcpyAsync(d_repair, rep.data(), sizeof(ChainDev) * rep.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if ((rc = launch_chains(cfg, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }
+        n_repaired += (int)rep.size();
+        ++rounds;
+    }
+    for (int c = 0; c < NC; ++c) if (!exact[c] && chunks[c].pred >= 0) max_dev = std::max(max_dev, hdev[c]);
+    if (report) { report->n_chunks = NC; report->n_repaired = n_repaired; report->repair_rounds = rounds; report->max_handoff_dev = max_dev;
+                  report->warmup = warmup; report->verify_tol = tol; }
+    if (!dev)
+        for (int q = 0; q < n_seq; ++q)
+            if ((rc = stage_out(fbs[q], NP, P, &st[q]))) { cleanup(); return rc; }
+    cleanup();
     return MOSHII_OK;
 }
 

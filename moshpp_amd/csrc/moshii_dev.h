@@ -60,6 +60,12 @@ struct ChainDev {
     double* errs;
     int* iters;
     int* status;
+    // chunked sequences (moshii_sequence_solve): the first `skip` frames are warm-up -- solved, not recorded.
+    // state vectors are [pose NP][pose_prev NP][trans 3][has_prev][first] = 2 NP + 5 doubles.
+    int skip;
+    const double* init_state;   // device; overrides init_pose/init_trans/init_prev/first when non-null
+    double* entry_state;        // device or null: state on entering frame `skip`
+    double* final_state;        // device or null: state after the last frame
 };
 
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).

@@ -43,3 +43,57 @@ def make_solver(job, maxiter=100):
     from .chmosh import StageIISolver
     return StageIISolver(job['sm'], job['betas'], job['markers_latent'], job['prior'], job['weights'],
                          surface_model_type=job['model_type'], optimize_fingers=job['optimize_fingers'], maxiter=maxiter)
+
+
+class DeviceSequence:
+    """One sequence with obs/vis and every output resident in HBM (torch tensors own the memory; libmoshii sees
+    raw device pointers).  Used by bench.py and tools/ to time the hot path without host staging."""
+
+    def __init__(self, job, solver, device):
+        import torch
+        from . import capi
+        sm = job['sm']
+        F, M = job['vis'].shape
+        self.F, self.M, self.solver, self.job = F, M, solver, job
+        self.obs = torch.from_numpy(np.ascontiguousarray(job['obs'])).to(device)
+        self.vis = torch.from_numpy(np.ascontiguousarray(job['vis'].astype(np.uint8))).to(device)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        self.pose = z((F, sm.NP), torch.float64); self.fullpose = z((F, 3 * sm.K), torch.float64)
+        self.trans = z((F, 3), torch.float64); self.msim = z((F, M, 3), torch.float64)
+        self.errs = z((F, 4), torch.float64); self.iters = z((F, 2), torch.int32); self.status = z((F,), torch.int32)
+        self.cdesc = (capi.ChainDesc * 1)()
+        self.sdesc = (capi.SequenceDesc * 1)()
+        for d in (self.cdesc[0], self.sdesc[0]):
+            d.attach = solver.attach.handle; d.F = F
+            d.obs = self.obs.data_ptr(); d.vis = self.vis.data_ptr()
+            d.pose = self.pose.data_ptr(); d.fullpose = self.fullpose.data_ptr(); d.trans = self.trans.data_ptr()
+            d.markers_sim = self.msim.data_ptr(); d.errs = self.errs.data_ptr(); d.iters = self.iters.data_ptr()
+            d.status = self.status.data_ptr()
+        self.cdesc[0].first_frame_schedule = 1
+        self.report = None
+
+    def _handles(self):
+        s = self.solver
+        return s.dev.handle, (s.prior.handle if s.prior is not None else None), s.opts[0]
+
+    def solve_sequential(self, stream):
+        import ctypes as C
+        from . import capi
+        mh, ph, opts = self._handles()
+        capi.check(capi.load().moshii_chain_solve(mh, ph, C.byref(opts), 1, self.cdesc, capi.BUFFERS_DEVICE, C.c_void_p(stream)))
+
+    def solve_chunked(self, stream, num_chunks=0, warmup=16, verify_tol=1e-6):
+        import ctypes as C
+        from . import capi
+        mh, ph, opts = self._handles()
+        co = capi.ChunkOpts(int(num_chunks), int(warmup), float(verify_tol))
+        rep = capi.ChunkReport()
+        capi.check(capi.load().moshii_sequence_solve(mh, ph, C.byref(opts), 1, self.sdesc, C.byref(co), capi.BUFFERS_DEVICE,
+                                                     C.c_void_p(stream), C.byref(rep)))
+        self.report = {k: getattr(rep, k) for k, _ in capi.ChunkReport._fields_}
+        return self.report
+
+    def results(self):
+        return dict(pose=self.pose.cpu().numpy(), fullpose=self.fullpose.cpu().numpy(), trans=self.trans.cpu().numpy(),
+                    markers_sim=self.msim.cpu().numpy(), errs=self.errs.cpu().numpy(), iters=self.iters.cpu().numpy(),
+                    status=self.status.cpu().numpy())

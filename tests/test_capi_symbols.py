@@ -61,3 +61,21 @@ def test_no_silent_cpu_fallback(lib):
     from moshpp_amd.chmosh import mosh_stageii
     with pytest.raises(capi.MoshiiError):
         mosh_stageii('x.npz', None, None, None, None, None)
+
+
+def test_plan_chunks_is_balanced_and_covers_every_frame():
+    """moshii_plan_chunks is host arithmetic (no device): chunk starts are balanced, warm-up is clipped at 0."""
+    import numpy as np
+    from moshpp_amd import capi
+    for F, C, W in [(4000, 256, 16), (4000, 512, 16), (10, 4, 16), (3, 8, 2), (1, 1, 0), (0, 4, 16), (97, 5, 0)]:
+        starts, launch = capi.plan_chunks(F, C, W)
+        n = len(starts)
+        assert 1 <= n <= max(1, min(C, max(F, 1)))
+        assert starts[0] == 0 and launch[0] == 0
+        ends = list(starts[1:]) + [F]
+        lens = np.array(ends) - starts
+        assert lens.sum() == F and (lens >= 0).all() and lens.max() - lens.min() <= 1
+        assert (launch <= starts).all() and (starts - launch <= W).all() and (launch >= 0).all()
+        assert all(launch[c] == max(0, starts[c] - W) for c in range(1, n))
+    s, l = capi.plan_chunks(100, 10, 4, cap=3)
+    assert len(s) == 3

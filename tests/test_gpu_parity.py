@@ -183,3 +183,78 @@ def test_mosh_stageii_end_to_end(gpu_lib, tmp_path):
     assert np.abs(out['trans'] - ref['trans']).max() < TIGHT
     for a, b, l, t in zip(dd['markers_sim'], ref['markers_sim'], dd['labels_obs'], ref['frame_ids']):
         assert np.abs(a - b).max() < TIGHT and l == [x for x, v in zip(s['latent_labels'], vis[t]) if v]
+
+
+# ---------------------------------------------------------------------------------------------------
+# chunked sequence solve (moshii_sequence_solve): concurrent chunks, verified + repaired hand-offs
+# ---------------------------------------------------------------------------------------------------
+def _sequential(dev, case):
+    from moshpp_amd import capi
+    return capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                 [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+
+
+def test_sequence_solve_matches_sequential_chain(gpu_lib):
+    """Chunks that start 16 frames early converge onto the sequential chain before their first recorded frame
+    (tools/chunk_deviation.py); the hand-off check accepts them at 1e-6 and the stitched result stays within the
+    north-star tolerance of both the GPU's own sequential chain and the oracle's."""
+    from moshpp_amd import capi
+    F = 96
+    case = oracle_case('smplh', F=F, M=53, seed=51, empty_frames=(40, 41, 63))
+    dev = device_case(case)
+    seq = _sequential(dev, case)
+    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                         [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                         num_chunks=4, warmup=16, verify_tol=1e-6)
+    out = outs[0]
+    print('chunk report', rep)
+    assert rep['n_chunks'] == 4
+    np.testing.assert_array_equal(out['status'], seq['status'])
+    solved = np.where(seq['status'] == 0)[0]
+    dp = np.abs(out['fullpose'][solved] - seq['fullpose'][solved]).max()
+    dm = np.abs(out['markers_sim'][solved] - seq['markers_sim'][solved]).max()
+    print(f'chunked vs sequential: max|dpose|={dp:.2e} rad, max|dmarker|={dm:.2e} m')
+    assert dp < POSE_TOL and dm < MARKER_TOL
+    assert dp < 1e-5, 'accepted hand-offs (<= 1e-6) must not grow'
+    np.testing.assert_array_equal(out['fullpose'][:24], seq['fullpose'][:24])   # chunk 0 IS the sequential chain
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplh')
+    assert np.abs(out['fullpose'][solved] - ref['fullpose']).max() < POSE_TOL
+    rm = np.sqrt(np.concatenate([((out['markers_sim'][t][case['vis'][t]] - ref['markers_sim'][i]) ** 2).sum(1)
+                                 for i, t in enumerate(solved)]).mean())
+    assert rm < MARKER_TOL
+
+
+def test_sequence_solve_repair_reproduces_chain_bitwise(gpu_lib):
+    """With no warm-up every hand-off fails verification; each chunk is then re-solved from its predecessor's
+    exact end state, which must reproduce the sequential chain bit for bit (all chunks, cascading rounds)."""
+    from moshpp_amd import capi
+    case = oracle_case('smplh', F=40, M=53, seed=52, empty_frames=(9, 10, 20))   # frame 10/20 are chunk starts
+    dev = device_case(case)
+    seq = _sequential(dev, case)
+    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                         [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                         num_chunks=4, warmup=0, verify_tol=1e-12)
+    print('chunk report', rep)
+    assert rep['n_chunks'] == 4 and rep['n_repaired'] == 3
+    for k in ('fullpose', 'trans', 'markers_sim', 'status', 'errs', 'pose'):
+        np.testing.assert_array_equal(outs[0][k], seq[k])
+    np.testing.assert_array_equal(outs[0]['iters'], seq['iters'])
+
+
+def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
+    """Several sequences, automatic chunk count: every sequence matches its own sequential chain."""
+    from moshpp_amd import capi
+    case = oracle_case('smpl', F=64, M=41, seed=53)
+    dev = device_case(case)
+    rng = np.random.default_rng(3)
+    seqs = []
+    for q in range(3):
+        F = (64, 50, 33)[q]
+        seqs.append(dict(attach=dev['attach'], obs=case['obs'][:F] + rng.normal(0, 0.001, (F, 41, 3)), vis=case['vis'][:F]))
+    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'], seqs, num_chunks=0, warmup=12)
+    print('chunk report', rep)
+    assert rep['n_chunks'] >= 3
+    for q, sq in enumerate(seqs):
+        alone = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], [dict(first=True, **sq)])[0]
+        assert np.abs(outs[q]['fullpose'] - alone['fullpose']).max() < 1e-5
+        np.testing.assert_array_equal(outs[q]['status'], alone['status'])
