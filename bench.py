@@ -3,15 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full Stage-II pass (moshii_chain_solve) over one synthetic sequence of BASELINE config[1]
-(4000-frame SMPL-H, 53 body markers, fixed betas, exact sequential-chain semantics of the reference), with
-observations already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
-every rank solves its own sequence of the same shape -- the path has no data-path collective -- and the
-job-level frames/s is reported ("scaling": "weak").
+A "step" = one full Stage-II pass over one synthetic sequence of BASELINE config[1] (4000-frame SMPL-H, 53 body
+markers, fixed betas) with observations and outputs resident in HBM: `moshii_sequence_solve` cuts the sequence into
+one chunk per CU, solves the chunks concurrently (each starts --chunk-warmup frames early), verifies every hand-off
+against its predecessor's end state on the device and re-solves the chunks that miss --verify-tol exactly -- all of
+that is inside the timed region.  `--mode sequential` times the reference's literal frame order instead (one chain =
+one workgroup).  With N > 1 (torch.distributed.run, one rank per GPU) every rank solves its own sequence of the same
+shape -- the path has no data-path collective -- and the job-level frames/s is reported ("scaling": "weak").
 
-Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, k_chain_solve), `roofline_lbs`
-(full-mesh LBS export kernel), `cpu_baseline` (the NumPy oracle on a bounded sample, host cores of this box),
-`parity` (GPU vs oracle on that sample).
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline           dominant kernel k_chain_solve against the f64 vector peak (it is latency/ALU-bound, not HBM-bound)
+  roofline_lbs       the full-mesh LBS export kernel against the HBM peak
+  cpu_baseline       the NumPy oracle ("port") on a bounded sample, host cores of this box
+  parity             GPU result of the timed mode vs the oracle's sequential chain on that sample
+  sequential_chain   the literal frame order on the GPU (one workgroup) and the timed mode's deviation from it over
+                     ALL frames
 """
 from __future__ import annotations
 
@@ -26,14 +32,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector/matrix FP64 (AMD spec sheet; half the 157.3 TF FP32 rate of MI355X_MICROARCH.md)
+F64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (AMD spec sheet; half the 157.3 TF FP32 rate of MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def solver_flops(K, Nv, n1, n2, NP, npose, nobs_mean, iters, fevals, first_frame_rounds=0):
-    """Algorithmic FLOPs of the solve per SURVEY.md 8(d) / DESIGN.md:
-    forward 2*3Nv*9(K-1) + 2*Nv*K*12 per residual evaluation; per Jacobian 3Nv*n*30 + normal equations
-    2*m*n^2/2 + Cholesky n^3/3, with m = 3*nobs + (npose+1) + NP rows."""
+def solver_flops(K, Nv, n1, n2, NP, npose, nobs_mean, iters, fevals):
+    """Algorithmic FLOPs of the solve (SURVEY.md 8(d) / DESIGN.md 5): forward 2*3Nv*9(K-1) + 2*Nv*K*12 per residual
+    evaluation; per Jacobian 3Nv*n*30 + normal equations 2*m*n^2/2 + factorisation n^3/3, m = 3*nobs + (npose+1) + NP."""
     fwd = 2.0 * 3 * Nv * 9 * (K - 1) + 2.0 * Nv * K * 12
     m = 3.0 * nobs_mean + (npose + 1 if npose else 0) + NP
     n = 3 + 0.5 * (n1 + n2)
@@ -44,12 +49,17 @@ def solver_flops(K, Nv, n1, n2, NP, npose, nobs_mean, iters, fevals, first_frame
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--frames', type=int, default=4000)
     ap.add_argument('--markers', type=int, default=53)
-    ap.add_argument('--cpu-sample', type=int, default=200, help='frames of the workload timed on the CPU oracle')
+    ap.add_argument('--mode', choices=('chunked', 'sequential'), default='chunked')
+    ap.add_argument('--chunks', type=int, default=0, help='chunks per sequence (0 = one per CU)')
+    ap.add_argument('--chunk-warmup', type=int, default=32)
+    ap.add_argument('--verify-tol', type=float, default=1e-9)
+    ap.add_argument('--cpu-sample', type=int, default=400, help='frames of the workload timed on the CPU oracle')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
     ap.add_argument('--lbs-frames', type=int, default=2000)
     args = ap.parse_args()
 
@@ -68,10 +78,8 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from moshpp_amd import capi, workload
-    capi.load()
-    check = capi.check
     lib = capi.load()
-    check(lib.moshii_set_device(local_rank))
+    capi.check(lib.moshii_set_device(local_rank))
 
     # ---- workload: BASELINE config[1]; each rank its own seeded sequence of the same shape
     job = workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=1000 + rank)
@@ -79,32 +87,15 @@ def main():
     sm = job['sm']
     F, M = job['vis'].shape
     dev = torch.device('cuda', local_rank)
-    obs_d = torch.from_numpy(np.ascontiguousarray(job['obs'])).to(dev)
-    vis_d = torch.from_numpy(np.ascontiguousarray(job['vis'].astype(np.uint8))).to(dev)
-    out_pose = torch.zeros((F, sm.NP), dtype=torch.float64, device=dev)
-    out_full = torch.zeros((F, 3 * sm.K), dtype=torch.float64, device=dev)
-    out_trans = torch.zeros((F, 3), dtype=torch.float64, device=dev)
-    out_msim = torch.zeros((F, M, 3), dtype=torch.float64, device=dev)
-    out_errs = torch.zeros((F, 4), dtype=torch.float64, device=dev)
-    out_iters = torch.zeros((F, 2), dtype=torch.int32, device=dev)
-    out_status = torch.zeros((F,), dtype=torch.int32, device=dev)
-    desc = (capi.ChainDesc * 1)()
-    d = desc[0]
-    d.attach = solver.attach.handle
-    d.F = F
-    d.first_frame_schedule = 1
-    d.obs = obs_d.data_ptr(); d.vis = vis_d.data_ptr()
-    d.pose = out_pose.data_ptr(); d.fullpose = out_full.data_ptr(); d.trans = out_trans.data_ptr()
-    d.markers_sim = out_msim.data_ptr(); d.errs = out_errs.data_ptr(); d.iters = out_iters.data_ptr()
-    d.status = out_status.data_ptr()
-    import ctypes as C
-    opts = solver.opts[0]
-    prior_h = solver.prior.handle if solver.prior is not None else None
+    ds = workload.DeviceSequence(job, solver, dev)
+    reports = []
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
-        check(lib.moshii_chain_solve(solver.dev.handle, prior_h, C.byref(opts), 1, desc, capi.BUFFERS_DEVICE,
-                                     C.c_void_p(stream)))
+        if args.mode == 'chunked':
+            reports.append(ds.solve_chunked(stream, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol))
+        else:
+            ds.solve_sequential(stream)
 
     def barrier():
         if dist is not None:
@@ -113,6 +104,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    reports.clear()
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -123,15 +115,16 @@ def main():
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     barrier()
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    step_ms = [a.elapsed_time(b) for a, b in ev]
     t_max = t_local
     if dist is not None:
         tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
-    status = out_status.cpu().numpy()
-    iters = out_iters.cpu().numpy()
-    solved = int((status != 1).sum())
+    out = ds.results()
+    status, iters = out['status'], out['iters']
+    solved_mask = status != 1
+    solved = int(solved_mask.sum())
     total_solved = solved
     if dist is not None:
         ts = torch.tensor([solved], dtype=torch.float64, device=dev)
@@ -140,35 +133,61 @@ def main():
     value = total_solved * args.steps / t_max
     ms_per_step = 1e3 * t_max / args.steps
 
+    name, lds, thr = capi.last_launch_info()
+    rep = reports[-1] if reports else None
+    how = (f'chunked: {rep["n_chunks"]} concurrent chunks (1 workgroup each), {rep["warmup"]}-frame warm-up overlap, hand-offs '
+           f'verified to {rep["verify_tol"]:g} and repaired exactly' if rep else 'exact sequential chain (1 chain = 1 workgroup)')
     result = {
         'metric': 'solved mocap frames/sec (Stage-II)', 'value': round(value, 2), 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'BASELINE config[1]: {F}-frame SMPL-H sequence, {M} body markers, fixed betas, '
-                               f'exact sequential chain (1 chain = 1 workgroup per GPU)',
-                   'frames_per_gpu': F, 'markers': M, 'free_vars_step1': 3 + len(solver.ids['step1']),
+        'config': {'workload': f'BASELINE config[1]: {F}-frame SMPL-H sequence, {M} body markers, fixed betas; {how}',
+                   'mode': args.mode, 'frames_per_gpu': F, 'markers': M, 'free_vars_step1': 3 + len(solver.ids['step1']),
                    'free_vars_step2': 3 + len(solver.ids['step2']), 'sequences_per_gpu': 1},
     }
+    if rep:
+        result['chunking'] = dict(rep, repaired_per_step=float(np.mean([r['n_repaired'] for r in reports])))
     if rank == 0:
-        name, lds, thr = capi.last_launch_info()
         nobs_mean = float(job['vis'].sum(1).mean())
         fl = solver_flops(sm.K, 3 * M, len(solver.ids['step1']), len(solver.ids['step2']), sm.NP,
-                          len(solver.ids['body']), nobs_mean, iters[:, 0].sum(), iters[:, 1].sum())
-        kt = float(np.mean(kern_ms)) * 1e-3
+                          len(solver.ids['body']), nobs_mean, iters[solved_mask, 0].sum(), iters[solved_mask, 1].sum())
+        kt = float(np.mean(step_ms)) * 1e-3
         ach = fl / kt / 1e12
         result['roofline'] = {
-            'kernel': name, 'bound': 'valu_f64 (dependency/latency-bound: ONE workgroup on 1 of 256 CUs)',
+            'kernel': name, 'bound': 'valu_f64 (dependency/latency-bound small dense solves; HBM traffic ~3 KB/frame)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
-            'frac_of_one_cu': round(ach / (F64_VALU_PEAK_TFLOPS / 256.0), 4),
-            'traffic': None, 'kernel_ms': round(kt * 1e3, 3), 'algorithmic_gflop_per_launch': round(fl / 1e9, 3),
-            'dogleg_iters_per_frame': round(float(iters[:, 0].sum()) / max(solved, 1), 3),
-            'residual_evals_per_frame': round(float(iters[:, 1].sum()) / max(solved, 1), 3), 'lds_bytes': lds,
+            'traffic': None, 'step_ms_hip_events': round(kt * 1e3, 3),
+            'algorithmic_gflop_per_step': round(fl / 1e9, 3),
+            'note': 'algorithmic = the sequential chain\'s work on the recorded frames; warm-up and repair work is overhead',
+            'dogleg_iters_per_frame': round(float(iters[solved_mask, 0].sum()) / max(solved, 1), 3),
+            'residual_evals_per_frame': round(float(iters[solved_mask, 1].sum()) / max(solved, 1), 3), 'lds_bytes': lds,
         }
+        # ---- the literal frame order on one workgroup, and the timed mode's deviation from it over all frames
+        if args.mode == 'chunked' and not args.no_sequential:
+            dsq = workload.DeviceSequence(job, solver, dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            dsq.solve_sequential(stream)
+            torch.cuda.synchronize()
+            tsq = time.perf_counter() - ts0
+            sq = dsq.results()
+            dp = np.abs(out['fullpose'] - sq['fullpose'])[solved_mask].max(1)
+            dm = out['markers_sim'][solved_mask] - sq['markers_sim'][solved_mask]
+            result['sequential_chain'] = {
+                'frames_per_s': round(solved / tsq, 1), 'ms': round(tsq * 1e3, 1), 'kernel': capi.last_launch_info()[0],
+                'timed_mode_vs_sequential': {'max_abs_pose_diff_rad': float(dp.max()), 'frames_over_1e-4_rad': int((dp > 1e-4).sum()),
+                                             'frames_over_1e-6_rad': int((dp > 1e-6).sum()),
+                                             'marker_rmse_m': float(np.sqrt((dm ** 2).sum(-1).mean())),
+                                             'status_identical': bool((status == sq['status']).all())}}
+            result['speedup_vs_sequential_chain'] = round(value / max(solved / tsq, 1e-9) / world, 2)
+            del dsq
         # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names)
         try:
-            Fl = args.lbs_frames
-            pose32 = out_pose[:Fl].to(torch.float32).contiguous()
-            trans32 = out_trans[:Fl].to(torch.float32).contiguous()
+            import ctypes as C
+            Fl = min(args.lbs_frames, F)
+            pose32 = ds.pose[:Fl].to(torch.float32).contiguous()
+            trans32 = ds.trans[:Fl].to(torch.float32).contiguous()
             verts = torch.empty((Fl, sm.V, 3), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream().cuda_stream
             for _ in range(2):
@@ -183,15 +202,17 @@ def main():
             torch.cuda.synchronize()
             lt = e0.elapsed_time(e1) * 1e-3 / reps
             Kj = sm.K
-            model_bytes = 12 * sm.V * (1 + 9 * (Kj - 1)) + 4 * sm.V * Kj
-            bytes_alg = Fl * (12 * sm.V + 4 * 3 * Kj + 12) + model_bytes
-            result['roofline_lbs'] = {'kernel': 'lbs_forward_f32', 'bound': 'hbm', 'achieved': round(bytes_alg / lt / 1e9, 1),
+            # algorithmic bytes: 12 V out + pose/trans in per frame, plus ONE read of the model in the precision the kernel
+            # consumes it (f16 posedirs, f32 rest vertices, sparse skinning weights as (joint, weight) pairs)
+            model_bytes = 2 * 3 * sm.V * 9 * (Kj - 1) + 12 * sm.V + 8 * 4 * sm.V
+            bytes_alg = Fl * (12 * sm.V + 4 * sm.NP + 12) + model_bytes
+            result['roofline_lbs'] = {'kernel': 'k_lbs_mfma (+ k_lbs_prep)', 'bound': 'hbm', 'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives', 'achieved': round(bytes_alg / lt / 1e9, 1),
                                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
                                       'traffic': None, 'frames': Fl, 'kernel_ms': round(lt * 1e3, 3),
                                       'frames_per_s': round(Fl / lt, 1)}
         except Exception as e:   # the LBS leg must never take the headline number down
             result['roofline_lbs'] = {'error': repr(e)}
-        # ---- CPU baseline: the NumPy oracle ("port") on a bounded sample of the same workload
+        # ---- CPU baseline: the NumPy oracle ("port") on a bounded sample of the same workload; parity on that sample
         if not args.no_cpu:
             from oracle import stageii_oracle as so
             S = min(args.cpu_sample, F)
@@ -216,13 +237,15 @@ def main():
                                       'kind': 'port', 'host_cores_visible': os.cpu_count(),
                                       'sample': f'first {S} frames of the same sequence, NumPy float64 oracle '
                                                 f'(lean marker-subset mode), single process, {tc:.1f} s'}
-            gp = out_full[:S].cpu().numpy()[status[:S] != 1]
-            gm = out_msim[:S].cpu().numpy()
-            sq = []
+            gp = out['fullpose'][:S][status[:S] != 1]
+            gm = out['markers_sim'][:S]
+            sqd = []
             for i, t in enumerate(ref['frame_ids']):
-                sq.append(((gm[t][job['vis'][t]] - ref['markers_sim'][i]) ** 2).sum(1))
-            result['parity'] = {'frames': int(n_ref), 'max_abs_pose_diff_rad': float(np.abs(gp - ref['fullpose']).max()),
-                                'marker_rmse_m': float(np.sqrt(np.concatenate(sq).mean())),
+                sqd.append(((gm[t][job['vis'][t]] - ref['markers_sim'][i]) ** 2).sum(1))
+            dpo = np.abs(gp - ref['fullpose']).max(1)
+            result['parity'] = {'against': 'oracle sequential chain', 'frames': int(n_ref),
+                                'max_abs_pose_diff_rad': float(dpo.max()), 'frames_over_1e-4_rad': int((dpo > 1e-4).sum()),
+                                'marker_rmse_m': float(np.sqrt(np.concatenate(sqd).mean())),
                                 'tolerance': {'pose_rad': 1e-4, 'marker_rmse_m': 1e-3}}
             result['speedup_vs_cpu_port'] = round(value / max(n_ref / tc, 1e-9), 1)
         print(json.dumps(result), flush=True)

@@ -166,7 +166,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL whe
  *   pass 1  chunk c > 0 starts `warmup` frames early with the first-frame schedule (:629-655); those frames
  *           are solved but not recorded.  The chain map is a contraction (data term 400 vs velocity 2.5,
  *           moshpp_conf.yaml:118-125): the influence of the start state decays ~2.5x per frame
- *           (tools/chunk_deviation.py: 16 frames -> <1e-7 rad).
+ *           (tools/chunk_deviation.py: 16 frames -> <1e-7 rad, 32 -> <1e-12).
  *   verify  the state (pose, pose_prev, trans) with which chunk c enters its first recorded frame is compared
  *           with the state its predecessor ended in; max|diff| <= verify_tol accepts the hand-off.
  *   repair  a chunk that fails is re-solved from its predecessor's exact end state (warm start + velocity
@@ -188,9 +188,9 @@ typedef struct moshii_sequence_desc {
 } moshii_sequence_desc;
 
 typedef struct moshii_chunk_opts {
-    int32_t num_chunks;             /* chunks per sequence; 0 = fill the GPU (2 workgroups per CU)  */
-    int32_t warmup;                 /* warm-up frames per chunk (default 16)                        */
-    double  verify_tol;             /* hand-off tolerance on pose [rad] / trans [m] (default 1e-6)  */
+    int32_t num_chunks;             /* chunks per sequence; 0 = fill the GPU (1 workgroup per CU)   */
+    int32_t warmup;                 /* warm-up frames per chunk (NULL opts: 32)                     */
+    double  verify_tol;             /* hand-off tolerance on pose [rad] / trans [m] (<= 0: 1e-9)    */
 } moshii_chunk_opts;
 
 typedef struct moshii_chunk_report {

@@ -27,15 +27,17 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, profile=False):
+    """profile=True builds libmoshii_prof.so with in-kernel clock64() phase laps (tools/prof_chain.py)."""
+    out = OUT.replace('libmoshii.so', 'libmoshii_prof.so') if profile else OUT
+    if not force and not profile and not needs_build():
         return OUT
     objs = []
     procs = []
     for s in SOURCES:
-        obj = os.path.join(CSRC, s.replace('.hip', '.o'))
+        obj = os.path.join(CSRC, s.replace('.hip', '_prof.o' if profile else '.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-value',
-               '-c', os.path.join(CSRC, s), '-o', obj]
+               '-c', os.path.join(CSRC, s), '-o', obj] + (['-DMOSHII_PROFILE'] if profile else [])
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -43,13 +45,12 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f'hipcc failed on {s}')
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(OUT)
+    print(build(force='--force' in sys.argv, profile='--profile' in sys.argv))

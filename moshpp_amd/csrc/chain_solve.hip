@@ -36,8 +36,9 @@ struct Ctx {
     double *g, *dsd, *dgn, *ddl, *y;
     double *red, *scal;
     unsigned long long* anc;
-    int *visidx, *colpid, *colprior, *pid2prior, *jointslot, *kfree;
-    double *big, *Jv, *Jrow, *Lm, *Trot, *xjs, *rest;
+    int *visidx, *colpid, *colprior, *pid2prior, *jointslot, *kfree, *colq;
+    double *big, *Jh, *Jrow, *Lm, *Trot, *xjs, *rest;
+    int* tjs;
 };
 
 struct FrameParams {
@@ -106,6 +107,27 @@ __device__ __forceinline__ void rodrigues_dev(const double* r, double* R, double
         R[e] = id + a * Km[e] + b * K2[e];
         Jl[e] = id + b * Km[e] + c * K2[e];
     }
+}
+
+// rotation only (same formulas / small-angle switch as rodrigues_dev)
+__device__ __forceinline__ void rodrigues_R(const double* r, double* R) {
+    const double x = r[0], y = r[1], z = r[2];
+    const double t2 = x * x + y * y + z * z;
+    double a, b;
+    if (t2 < 1e-6) {
+        a = 1.0 - t2 / 6.0 + t2 * t2 / 120.0;
+        b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0;
+    } else {
+        const double t = sqrt(t2);
+        double s, co;
+        sincos(t, &s, &co);
+        a = s / t;
+        b = (1.0 - co) / t2;
+    }
+    const double K2[9] = {x * x - t2, x * y, x * z, x * y, y * y - t2, y * z, x * z, y * z, z * z - t2};
+    const double Km[9] = {0.0, -z, y, z, 0.0, -x, -y, x, 0.0};
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0) + a * Km[e] + b * K2[e];
 }
 
 __device__ __forceinline__ void mat3_mul(const double* A, const double* Bm, double* C) {
@@ -187,35 +209,27 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         if (d < bd) v = pose[d];
         else {
             const int h = d - bd;
-            v = md.hands_mean[h];
-            for (int i = 0; i < hd; ++i)
-                if (h >= md.comp_lo[i] && h < md.comp_hi[i]) v += pose[bd + i] * md.comps[i * nhf + h];
+            const int lo = md.col_lo[h], hi = md.col_hi[h];   // components with a non-zero entry in column h
+            double v0 = md.hands_mean[h], v1 = 0.0;
+            int i = lo;
+            for (; i + 2 <= hi; i += 2) {
+                v0 += pose[bd + i] * md.comps[i * nhf + h];
+                v1 += pose[bd + i + 1] * md.comps[(i + 1) * nhf + h];
+            }
+            if (i < hi) v0 += pose[bd + i] * md.comps[i * nhf + h];
+            v = v0 + v1;
         }
         cx.fullpose[d] = v;
     }
     __syncthreads();
-    // F2: per joint Rodrigues, left-Jacobian columns, pose feature R - I, dR/dtheta_c = [a_c]x R
+    // F2: per joint rotation and pose feature R - I  (the Jacobian-only quantities are built in assemble())
     if (tid < K) {
-        double R[9], Jl[9];
-        rodrigues_dev(&cx.fullpose[3 * tid], R, Jl);
+        double R[9];
+        rodrigues_R(&cx.fullpose[3 * tid], R);
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
             cx.Rloc[tid * 9 + e] = R[e];
             cx.feat[tid * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double ax = Jl[0 * 3 + c], ay = Jl[1 * 3 + c], az = Jl[2 * 3 + c];
-            cx.acol[tid * 9 + c * 3 + 0] = ax;
-            cx.acol[tid * 9 + c * 3 + 1] = ay;
-            cx.acol[tid * 9 + c * 3 + 2] = az;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {   // column d of R
-                const double rx = R[0 * 3 + d], ry = R[1 * 3 + d], rz = R[2 * 3 + d];
-                cx.B[tid * 27 + c * 9 + 0 * 3 + d] = ay * rz - az * ry;
-                cx.B[tid * 27 + c * 9 + 1 * 3 + d] = az * rx - ax * rz;
-                cx.B[tid * 27 + c * 9 + 2 * 3 + d] = ax * ry - ay * rx;
-            }
         }
         if (tid == 0) {
 #pragma unroll
@@ -223,51 +237,59 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             cx.tw[0] = md.J[0]; cx.tw[1] = md.J[1]; cx.tw[2] = md.J[2];
         }
     }
-    // F3: kinematic chain, one tree level per barrier (G_j = G_par(j) . [R_j | J_j - J_par(j)])
-    for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
-        __syncthreads();
-        if (tid < K && md.depth[tid] == lvl) {
-            const int p = md.parents[tid];
-            double Rp[9], Rl[9], Ro[9];
+    __syncthreads();
+    PROF_LAP(0);
+    // F3 (wave 0 only): kinematic chain G_j = G_par(j) . [R_j | J_j - J_par(j)], one tree level per step.  All K <= 64
+    // joints live in one wavefront, whose LDS operations complete in order, so levels need no workgroup barrier;
+    // waves 1..3 are already streaming posedirs (which needs only the local rotations) meanwhile.
+    if (tid < 64) {
+        const int lvl_of = (tid < K) ? md.depth[tid] : -1;
+        const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
+        for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lvl_of == lvl) {
+                double Rp[9], Rl[9], Ro[9];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { Rp[e] = cx.Rw[p * 9 + e]; Rl[e] = cx.Rloc[tid * 9 + e]; }
-            mat3_mul(Rp, Rl, Ro);
+                for (int e = 0; e < 9; ++e) { Rp[e] = cx.Rw[p * 9 + e]; Rl[e] = cx.Rloc[tid * 9 + e]; }
+                mat3_mul(Rp, Rl, Ro);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) cx.Rw[tid * 9 + e] = Ro[e];
-            const double dx = md.J[tid * 3 + 0] - md.J[p * 3 + 0];
-            const double dy = md.J[tid * 3 + 1] - md.J[p * 3 + 1];
-            const double dz = md.J[tid * 3 + 2] - md.J[p * 3 + 2];
-            double ox, oy, oz;
-            mat3_vec(Rp, dx, dy, dz, ox, oy, oz);
-            cx.tw[tid * 3 + 0] = ox + cx.tw[p * 3 + 0];
-            cx.tw[tid * 3 + 1] = oy + cx.tw[p * 3 + 1];
-            cx.tw[tid * 3 + 2] = oz + cx.tw[p * 3 + 2];
+                for (int e = 0; e < 9; ++e) cx.Rw[tid * 9 + e] = Ro[e];
+                const double dx = md.J[tid * 3 + 0] - md.J[p * 3 + 0];
+                const double dy = md.J[tid * 3 + 1] - md.J[p * 3 + 1];
+                const double dz = md.J[tid * 3 + 2] - md.J[p * 3 + 2];
+                double ox, oy, oz;
+                mat3_vec(Rp, dx, dy, dz, ox, oy, oz);
+                cx.tw[tid * 3 + 0] = ox + cx.tw[p * 3 + 0];
+                cx.tw[tid * 3 + 1] = oy + cx.tw[p * 3 + 1];
+                cx.tw[tid * 3 + 2] = oz + cx.tw[p * 3 + 2];
+            }
         }
     }
-    __syncthreads();
-    // world rotation axes omega_{k,c} = Rw_par(k) . Jl_k[:,c]
-    if (tid < 3 * K) {
-        const int k = tid / 3, c = tid % 3;
-        const double ax = cx.acol[k * 9 + c * 3 + 0], ay = cx.acol[k * 9 + c * 3 + 1], az = cx.acol[k * 9 + c * 3 + 2];
-        double ox = ax, oy = ay, oz = az;
-        if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
-        cx.omega[k * 9 + c * 3 + 0] = ox; cx.omega[k * 9 + c * 3 + 1] = oy; cx.omega[k * 9 + c * 3 + 2] = oz;
-    }
-    PROF_LAP(0);
-    // F4: v_posed = v_shaped + posedirs . vec(R - I) for the attached vertices; item = (coordinate i, vertex a)
-    const int Nv = at.Nv, Nvp = at.Nvp;
-    for (int it = tid; it < 3 * Nv; it += MOSHII_TPB) {
-        const int i = it / Nv, a = it - i * Nv;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        const double* pp = at.Pt + (size_t)(i * 9) * Nvp + a;
+    // F4: v_posed = v_shaped + posedirs . vec(R - I) for the attached vertices.  item = (coordinate i, vertex pair):
+    // every lane streams 16-byte pairs of the vertex-fastest posedirs slice (fully coalesced rows of Nvp doubles).
+    const int Nv = at.Nv, Nvp = at.Nvp, Nvh = Nvp >> 1;
+    for (int it = tid; it < 3 * Nvh; it += MOSHII_TPB) {
+        const int i = it / Nvh, a2 = it - i * Nvh;
+        double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0, s2x = 0.0, s2y = 0.0;
+        const double2* pp = reinterpret_cast<const double2*>(at.Pt) + (size_t)(i * 9) * Nvh + a2;
+#pragma unroll 3
         for (int k = 1; k < K; ++k) {
             const double* f = &cx.feat[k * 9];
-            const double* pk = pp + (size_t)((k - 1) * 27) * Nvp;
-            s0 += pk[0 * Nvp] * f[0]; s1 += pk[1 * Nvp] * f[1]; s2 += pk[2 * Nvp] * f[2];
-            s0 += pk[3 * Nvp] * f[3]; s1 += pk[4 * Nvp] * f[4]; s2 += pk[5 * Nvp] * f[5];
-            s0 += pk[6 * Nvp] * f[6]; s1 += pk[7 * Nvp] * f[7]; s2 += pk[8 * Nvp] * f[8];
+            const double2* pk = pp + (size_t)((k - 1) * 27) * Nvh;
+            double2 q[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q[e] = pk[(size_t)e * Nvh];
+#pragma unroll
+            for (int e = 0; e < 9; e += 3) {
+                s0x += q[e].x * f[e]; s0y += q[e].y * f[e];
+                s1x += q[e + 1].x * f[e + 1]; s1y += q[e + 1].y * f[e + 1];
+                s2x += q[e + 2].x * f[e + 2]; s2y += q[e + 2].y * f[e + 2];
+            }
         }
-        cx.vposed[a * 3 + i] = at.vsh[a * 3 + i] + ((s0 + s1) + s2);
+        const int a = 2 * a2;
+        if (a < Nv) cx.vposed[a * 3 + i] = at.vsh[a * 3 + i] + ((s0x + s1x) + s2x);
+        if (a + 1 < Nv) cx.vposed[(a + 1) * 3 + i] = at.vsh[(a + 1) * 3 + i] + ((s0y + s1y) + s2y);
     }
     __syncthreads();
     PROF_LAP(1);
@@ -319,19 +341,30 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         for (int b = tid; b < np_; b += MOSHII_TPB) cx.xb[b] = pose[op.body[b]];
         __syncthreads();
         const int G = pr.G;
-        for (int it = tid; it < G * np_; it += MOSHII_TPB) {
-            const int gc = it / np_, a = it - gc * np_;
-            const double* Lg = pr.chols + (size_t)gc * np_ * np_;
-            const double* mu = pr.means + (size_t)gc * np_;
-            double s = 0.0;
-            for (int b = a; b < np_; ++b) s += (cx.xb[b] - mu[b]) * Lg[b * np_ + a];
-            cx.ell[it] = 0.70710678118654757 * s;
-        }
-        __syncthreads();
-        if (tid < G) {
-            double s = 0.0;
-            for (int a = 0; a < np_; ++a) { const double l = cx.ell[tid * np_ + a]; s += l * l; }
-            cx.score[tid] = s;
+        // one wavefront per mixture component; lane a accumulates column a (and a + 64) of L_g while b runs uniformly over
+        // the rows, so that every load is one contiguous run of row b -- and |l_g|^2 falls out of a wave reduction.
+        {
+            const int lane = tid & 63;
+            for (int gc = tid >> 6; gc < G; gc += MOSHII_TPB / 64) {
+                const double* Lg = pr.chols + (size_t)gc * np_ * np_;
+                const double* mu = pr.means + (size_t)gc * np_;
+                double s0 = 0.0, s1 = 0.0;
+                const int c0 = min(lane, np_ - 1), c1 = min(lane + 64, np_ - 1);   // clamped: every load is in bounds, no branch
+                const bool two = np_ > 64;
+#pragma unroll 8
+                for (int b = 0; b < np_; ++b) {
+                    const double dx = cx.xb[b] - mu[b];
+                    const double* row = Lg + (size_t)b * np_;
+                    const double v0 = row[c0];
+                    s0 += (lane <= b) ? dx * v0 : 0.0;                // lower triangle: rows b >= column
+                    if (two) { const double v1 = row[c1]; s1 += (lane + 64 <= b) ? dx * v1 : 0.0; }   // uniform branch
+                }
+                s0 *= 0.70710678118654757; s1 *= 0.70710678118654757;
+                if (lane < np_) cx.ell[gc * np_ + lane] = s0;
+                if (lane + 64 < np_) cx.ell[gc * np_ + lane + 64] = s1;
+                const double sq = wave_sum(s0 * s0 + s1 * s1);
+                if (lane == 0) cx.score[gc] = sq;
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -438,52 +471,122 @@ struct AReg {
     }
 };
 
-// Solve A d = g by Cholesky on the bordered packed matrix [A; g^T] in LDS: factoring the first n columns
-// turns the extra row into y = L^{-1} g; wave 0 then back-substitutes L^T d = y.  Returns false if A is not
-// numerically positive definite (the reference would fall back to lstsq; callers take the Cauchy step).
-__device__ bool chol_solve(double* Lp, const double* g, double* d, double* scal, int n) {
+__device__ __forceinline__ double readlane_f64(double v, int lane /* wave-uniform */) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Solve A d = g by a right-looking L D L^T elimination carried out in REGISTERS: every thread keeps a working copy
+// of its 16x16-interleaved entries of [A; g^T] (the right-hand side rides along as row n), and per column j
+//   owners of column j publish c_ij = l_ij d_j (their current entries) to the packed factor in LDS,
+//   one barrier, then every thread reads the <= 2 NBLK column entries it needs and updates its own registers
+//   with c_ij c_kj / d_j.
+// No thread ever reads an LDS word that is written in the same step (column j+1 has its own storage), so ONE
+// workgroup barrier per column suffices; no square roots.  Wave 0 then back-substitutes
+// x_j = (b_j - sum_{i>j} c_ij x_i) / d_j from the packed factor.  A itself is left untouched (the dogleg needs
+// d^T A d afterwards).  Returns false on a non-positive pivot (the reference would fall back to lstsq; callers
+// take the Cauchy step).
+template <int NBLK>
+__device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, double* d, double* pinv, int n) {
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     PROF_BEGIN(); PROF_COUNT(22);
-    for (int q = tid; q < n; q += MOSHII_TPB) Lp[n * (n + 1) / 2 + q] = g[q];
+    double w[AReg<NBLK>::NE];
+    {
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
+                w[e] = (q1 == n) ? ((q2 < n) ? g[q2] : 0.0) : A.a[e];
+                ++e;
+            }
+    }
+    // packed-row offsets of this thread's rows / columns (keeps integer multiplies out of the column loop)
+    int roff[NBLK], coff[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int q1 = b * 16 + ty, q2 = b * 16 + tx;
+        roff[b] = q1 * (q1 + 1) / 2;
+        coff[b] = q2 * (q2 + 1) / 2;
+    }
+    // The column loop is branch-free: a memory operation that does not apply to this lane is redirected to a spare
+    // word (stores -> `trash`, loads -> `zero`, which holds 0.0) instead of being skipped, so the compiler emits
+    // straight-line LDS traffic with a single wait instead of one exec-masked branch + wait per access.
+    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
+    if (tid == 0) Lp[zero] = 0.0;
     bool ok = true;
+    int jj = 0;   // packed index of the pivot (j, j)
     for (int j = 0; j < n; ++j) {
-        __syncthreads();
-        const double pj = Lp[j * (j + 1) / 2 + j];
-        if (!(pj > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS word
-        const double dj = sqrt(pj);
-        const double dinv = 1.0 / dj;
-        for (int i = j + 1 + tid; i <= n; i += MOSHII_TPB) Lp[i * (i + 1) / 2 + j] *= dinv;
-        __syncthreads();
-        if (tid == 0) Lp[j * (j + 1) / 2 + j] = dj;
-        for (int i = j + 1 + ty; i <= n; i += 16) {
-            const double lij = Lp[i * (i + 1) / 2 + j];
-            const int kend = (i < n) ? i : n - 1;     // the border row has no diagonal entry
-            for (int k = j + 1 + tx; k <= kend; k += 16) Lp[i * (i + 1) / 2 + k] -= lij * Lp[k * (k + 1) / 2 + j];
+        const int bj0 = j >> 4;
+        const bool owner = tx == (j & 15);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) {   // publish column j (rows j..n): entry (bi, bj0) of this thread
+            double v = 0.0;
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) v = (bj == bj0) ? w[bi * (bi + 1) / 2 + bj] : v;
+            const int q1 = bi * 16 + ty;
+            const bool valid = owner && bi >= bj0 && q1 >= j && q1 <= n;
+            Lp[valid ? roff[bi] + j : trash] = v;
         }
+        __syncthreads();
+        const double pj = Lp[jj];
+        double ci[NBLK], ck[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int q1 = b * 16 + ty, q2 = b * 16 + tx;
+            ci[b] = Lp[(q1 > j && q1 <= n) ? roff[b] + j : zero];
+            ck[b] = Lp[(q2 > j && q2 <= n) ? coff[b] + j : zero];
+        }
+        jj += j + 2;
+        if (!(pj > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS word
+        // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
+        double pin = __builtin_amdgcn_rcp(pj);
+        pin = fma(fma(-pj, pin, 1.0), pin, pin);
+        pin = fma(fma(-pj, pin, 1.0), pin, pin);
+        if (tid == 0) pinv[j] = pin;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) ck[b] *= pin;
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) { w[e] -= ci[bi] * ck[bj]; ++e; }
     }
     __syncthreads();
     PROF_LAP(9);
     if (!ok) return false;
-    // back substitution by wave 0: lane l owns rows l and l+64
+    // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
+    // Row j of the factor and 1/d_j are fetched one step ahead (off the readlane -> multiply -> fma chain); rows are
+    // read branch-free (lanes beyond the row read the zero word).
     if (tid < 64) {
         const int base = n * (n + 1) / 2;
-        double y0 = (tid < n) ? Lp[base + tid] : 0.0;
-        double y1 = (tid + 64 < n) ? Lp[base + tid + 64] : 0.0;
-        for (int j = n - 1; j >= 0; --j) {
-            const double ljj = Lp[j * (j + 1) / 2 + j];
-            const double yj = (j < 64) ? __shfl(y0, j, 64) : __shfl(y1, j - 64, 64);
-            const double dj = yj / ljj;
-            if (tid == (j & 63)) { if (j < 64) y0 = dj; else y1 = dj; }
-            if (tid < j) y0 -= Lp[j * (j + 1) / 2 + tid] * dj;
-            if (tid + 64 < j) y1 -= Lp[j * (j + 1) / 2 + tid + 64] * dj;
+        double y0 = Lp[(tid < n) ? base + tid : zero];
+        double y1 = Lp[(tid + 64 < n) ? base + tid + 64 : zero];
+        int rowj = (n - 1) * n / 2;
+        double l0 = Lp[(tid < n - 1) ? rowj + tid : zero];
+        double l1 = Lp[(tid + 64 < n - 1) ? rowj + tid + 64 : zero];
+        double pv = pinv[n - 1];
+        for (int jv = n - 1; jv >= 0; --jv) {
+            const int j = __builtin_amdgcn_readfirstlane(jv);
+            const int jn = (j > 0) ? j - 1 : 0;   // next row (row 0 is re-read harmlessly at the last step)
+            rowj -= j;                            // (j-1) j / 2
+            const double nl0 = Lp[(tid < jn) ? rowj + tid : zero];
+            const double nl1 = Lp[(tid + 64 < jn) ? rowj + tid + 64 : zero];
+            const double npv = pinv[jn];
+            const double yj = (j < 64) ? readlane_f64(y0, j) : readlane_f64(y1, j - 64);
+            const double dj = yj * pv;
+            y0 = (tid == j) ? dj : fma(-l0, dj, y0);        // l0 / l1 are zero on and beyond the diagonal
+            y1 = (tid + 64 == j) ? dj : fma(-l1, dj, y1);
+            l0 = nl0; l1 = nl1; pv = npv;
         }
         if (tid < n) d[tid] = y0;
         if (tid + 64 < n) d[tid + 64] = y1;
     }
     __syncthreads();
     PROF_LAP(10);
-    (void)scal;
     return true;
 }
 
@@ -493,14 +596,42 @@ __device__ bool chol_solve(double* Lp, const double* g, double* d, double* scal,
 template <int NBLK>
 __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at,
                          const PriorDev& pr, const OptsDev& op, const double* pose, const FrameParams& fp,
-                         int n, int nkf, AReg<NBLK>& A) {
+                         int n, int nkf, int nfree_hand, AReg<NBLK>& A) {
     const int tid = threadIdx.x;
     const int LDJ = ly.LDJ, Tm = ly.Tm, NW = at.NW, Nvp = at.Nvp, bd = md.body_dof, nhf = md.nhand_full;
     PROF_BEGIN(); PROF_COUNT(21);
     A.zero();
     for (int q = tid; q < n; q += MOSHII_TPB) cx.g[q] = 0.0;
     for (int e = tid; e < 3 * Tm * LDJ; e += MOSHII_TPB) cx.Jrow[e] = 0.0;
+    // Jacobian-only joint quantities at the current point (the forward state of the last evaluation is in LDS):
+    // left-Jacobian columns a_c of each joint rotation and dR/dtheta_c = [a_c]x R
+    if (tid < md.K) {
+        double R[9], Jl[9];
+        rodrigues_dev(&cx.fullpose[3 * tid], R, Jl);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double ax = Jl[0 * 3 + c], ay = Jl[1 * 3 + c], az = Jl[2 * 3 + c];
+            cx.acol[tid * 9 + c * 3 + 0] = ax;
+            cx.acol[tid * 9 + c * 3 + 1] = ay;
+            cx.acol[tid * 9 + c * 3 + 2] = az;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {   // column d of R
+                const double rx = R[0 * 3 + d], ry = R[1 * 3 + d], rz = R[2 * 3 + d];
+                cx.B[tid * 27 + c * 9 + 0 * 3 + d] = ay * rz - az * ry;
+                cx.B[tid * 27 + c * 9 + 1 * 3 + d] = az * rx - ax * rz;
+                cx.B[tid * 27 + c * 9 + 2 * 3 + d] = ax * ry - ay * rx;
+            }
+        }
+    }
     __syncthreads();
+    // world rotation axes omega_{k,c} = Rw_par(k) . a_{k,c}   (published by the barrier that ends T0)
+    if (tid < 3 * md.K) {
+        const int k = tid / 3, c = tid % 3;
+        const double ax = cx.acol[k * 9 + c * 3 + 0], ay = cx.acol[k * 9 + c * 3 + 1], az = cx.acol[k * 9 + c * 3 + 2];
+        double ox = ax, oy = ay, oz = az;
+        if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
+        cx.omega[k * 9 + c * 3 + 0] = ox; cx.omega[k * 9 + c * 3 + 1] = oy; cx.omega[k * 9 + c * 3 + 2] = oz;
+    }
     for (int tile0 = 0; tile0 < fp.nobs; tile0 += Tm) {
         const int cnt = min(Tm, fp.nobs - tile0);
         const int ntv = 3 * cnt;
@@ -517,9 +648,11 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const double w = at.ww[av * NW + s];
                 double ox, oy, oz;
                 mat3_vec(&cx.Rw[j * 9], px - md.J[j * 3 + 0], py - md.J[j * 3 + 1], pz - md.J[j * 3 + 2], ox, oy, oz);
-                cx.xjs[(tid * NW + s) * 3 + 0] = ox + cx.tw[j * 3 + 0];
-                cx.xjs[(tid * NW + s) * 3 + 1] = oy + cx.tw[j * 3 + 1];
-                cx.xjs[(tid * NW + s) * 3 + 2] = oz + cx.tw[j * 3 + 2];
+                cx.xjs[(tid * NW + s) * 4 + 0] = ox + cx.tw[j * 3 + 0];
+                cx.xjs[(tid * NW + s) * 4 + 1] = oy + cx.tw[j * 3 + 1];
+                cx.xjs[(tid * NW + s) * 4 + 2] = oz + cx.tw[j * 3 + 2];
+                cx.xjs[(tid * NW + s) * 4 + 3] = w;
+                cx.tjs[tid * NW + s] = j;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) Tr[e] += w * cx.Rw[j * 9 + e];
             }
@@ -538,100 +671,114 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         }
         __syncthreads();
         PROF_LAP(4);
-        // T1: vertex Jacobian columns of the needed joints: item = (tile vertex, joint)
-        for (int it = tid; it < ntv * nkf; it += MOSHII_TPB) {
-            const int kfi = it / ntv, al = it - kfi * ntv;
+        // T1: marker rows, fused over the marker's three vertices: item = (tile marker, needed joint), marker fastest so
+        // that the posedirs gathers of a wavefront fall into a few contiguous runs.  For each vertex
+        //   dv/dtheta_{k,c} = omega_{k,c} x sum_{j in subtree(k)} w_j (x_j - t_k)  +  Trot . (P_k . vec([a_c]x R_k))
+        // and the three columns are contracted at once with the marker's local 3x9 Jacobian L.
+        const int bj0 = bd / 3;   // first hand joint (its dofs are hand-PCA coefficients, not pose variables)
+        for (int it = tid; it < cnt * nkf; it += MOSHII_TPB) {
+            const int kfi = it / cnt, ml = it - kfi * cnt;
             const int k = cx.kfree[kfi];
-            const int m = cx.visidx[tile0 + al / 3];
-            const int av = 3 * m + al % 3;
+            const int m = cx.visidx[tile0 + ml];
             const unsigned long long mask = cx.anc[k];
             const double tkx = cx.tw[k * 3 + 0], tky = cx.tw[k * 3 + 1], tkz = cx.tw[k * 3 + 2];
-            double ax = 0.0, ay = 0.0, az = 0.0;
-            for (int s = 0; s < NW; ++s) {
-                const int j = at.wj[av * NW + s];
-                if ((mask >> j) & 1ull) {
-                    const double w = at.ww[av * NW + s];
-                    ax += w * (cx.xjs[(al * NW + s) * 3 + 0] - tkx);
-                    ay += w * (cx.xjs[(al * NW + s) * 3 + 1] - tky);
-                    az += w * (cx.xjs[(al * NW + s) * 3 + 2] - tkz);
+            const double* L = &cx.Lm[ml * 27];
+            double om[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) om[e] = cx.omega[k * 9 + e];
+            double r[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) r[e] = 0.0;
+#pragma unroll
+            for (int sv = 0; sv < 3; ++sv) {
+                const int al = 3 * ml + sv, av = 3 * m + sv;
+                double ax = 0.0, ay = 0.0, az = 0.0;
+                for (int s2 = 0; s2 < NW; ++s2) {   // joints of this vertex inside the subtree of k (branch-free: weight 0 otherwise)
+                    const int j = cx.tjs[al * NW + s2];
+                    const double* xw = &cx.xjs[(al * NW + s2) * 4];
+                    const double w = ((mask >> j) & 1ull) ? xw[3] : 0.0;
+                    ax += w * (xw[0] - tkx);
+                    ay += w * (xw[1] - tky);
+                    az += w * (xw[2] - tkz);
                 }
-            }
-            double col[9];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double ox = cx.omega[k * 9 + c * 3 + 0], oy = cx.omega[k * 9 + c * 3 + 1], oz = cx.omega[k * 9 + c * 3 + 2];
-                col[c * 3 + 0] = oy * az - oz * ay;
-                col[c * 3 + 1] = oz * ax - ox * az;
-                col[c * 3 + 2] = ox * ay - oy * ax;
-            }
-            if (k >= 1) {
-                double p[27];
-                const double* pp = at.Pt + (size_t)((k - 1) * 27) * Nvp + av;
-#pragma unroll
-                for (int q = 0; q < 27; ++q) p[q] = pp[(size_t)q * Nvp];
-                const double* Tr = &cx.Trot[al * 9];
+                double col[9];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const double* Bc = &cx.B[k * 27 + c * 9];
-                    double pd[3];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) s += p[i * 9 + e] * Bc[e];
-                        pd[i] = s;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) col[c * 3 + i] += Tr[i * 3 + 0] * pd[0] + Tr[i * 3 + 1] * pd[1] + Tr[i * 3 + 2] * pd[2];
+                    col[c * 3 + 0] = om[c * 3 + 1] * az - om[c * 3 + 2] * ay;
+                    col[c * 3 + 1] = om[c * 3 + 2] * ax - om[c * 3 + 0] * az;
+                    col[c * 3 + 2] = om[c * 3 + 0] * ay - om[c * 3 + 1] * ax;
                 }
-            }
-            double* out = &cx.Jv[(al * nkf + kfi) * 9];
+                {   // pose-corrective part; the root joint (k = 0) has none: it reads joint 1's record and scales by 0
+                    const double cs = (k >= 1) ? 1.0 : 0.0;
+                    const int kk = max(k, 1);
+                    double pv[28];   // one 224-byte record: 14 x 16-byte loads per lane
+                    const double2* pp = reinterpret_cast<const double2*>(at.Pj + ((size_t)(kk - 1) * Nvp + av) * 28);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) out[e] = col[e];
+                    for (int q = 0; q < 14; ++q) { const double2 t2 = pp[q]; pv[2 * q] = t2.x; pv[2 * q + 1] = t2.y; }
+                    const double* Tr = &cx.Trot[al * 9];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double* Bc = &cx.B[k * 27 + c * 9];
+                        double pd[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            double sacc = 0.0;
+#pragma unroll
+                            for (int e = 0; e < 9; ++e) sacc += pv[i * 9 + e] * Bc[e];
+                            pd[i] = cs * sacc;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) col[c * 3 + i] += Tr[i * 3 + 0] * pd[0] + Tr[i * 3 + 1] * pd[1] + Tr[i * 3 + 2] * pd[2];
+                    }
+                }
+#pragma unroll
+                for (int row = 0; row < 3; ++row)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        r[row * 3 + c] += L[row * 9 + sv * 3 + 0] * col[c * 3 + 0] + L[row * 9 + sv * 3 + 1] * col[c * 3 + 1] +
+                                          L[row * 9 + sv * 3 + 2] * col[c * 3 + 2];
+            }
+            if (k < bj0) {   // pose variables of a body joint: write the free ones straight into the Jacobian tile
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int q = cx.colq[3 * k + c];
+                    if (q >= 0) {
+                        cx.Jrow[(3 * ml + 0) * LDJ + q] = fp.wt_data * r[0 * 3 + c];
+                        cx.Jrow[(3 * ml + 1) * LDJ + q] = fp.wt_data * r[1 * 3 + c];
+                        cx.Jrow[(3 * ml + 2) * LDJ + q] = fp.wt_data * r[2 * 3 + c];
+                    }
+                }
+            } else {         // hand joint: park d marker / d fullpose for the PCA contraction below
+                double* jh = &cx.Jh[((size_t)ml * ly.nhj + (k - bj0)) * 9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) jh[e] = r[e];
+            }
+        }
+        // translation columns: d marker / d trans = I
+        for (int it = tid; it < cnt * 9; it += MOSHII_TPB) {
+            const int ml = it / 9, row = (it % 9) / 3, q = it % 3;
+            cx.Jrow[(3 * ml + row) * LDJ + q] = (row == q) ? fp.wt_data : 0.0;
         }
         __syncthreads();
         PROF_LAP(5);
-        // T2: marker rows: item = (tile marker, column)
-        for (int it = tid; it < cnt * n; it += MOSHII_TPB) {
-            const int ml = it / n, q = it - ml * n;
-            const double* L = &cx.Lm[ml * 27];
-            double r0, r1, r2;
-            if (q < 3) {
-                r0 = (q == 0) ? 1.0 : 0.0; r1 = (q == 1) ? 1.0 : 0.0; r2 = (q == 2) ? 1.0 : 0.0;
-            } else {
-                const int pid = cx.colpid[q];
-                double J9[9];
-                if (pid < bd) {
-                    const int k = pid / 3, c = pid - 3 * k;
-                    const int kfi = cx.jointslot[k];
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)
-#pragma unroll
-                        for (int x = 0; x < 3; ++x) J9[s * 3 + x] = cx.Jv[((3 * ml + s) * nkf + kfi) * 9 + c * 3 + x];
-                } else {
-                    const int i = pid - bd;
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) J9[e] = 0.0;
-                    for (int h = md.comp_lo[i]; h < md.comp_hi[i]; ++h) {
-                        const int d = bd + h;
-                        const int k = d / 3, c = d - 3 * k;
-                        const int kfi = cx.jointslot[k];
-                        const double cc = md.comps[i * nhf + h];
-#pragma unroll
-                        for (int s = 0; s < 3; ++s)
-#pragma unroll
-                            for (int x = 0; x < 3; ++x) J9[s * 3 + x] += cc * cx.Jv[((3 * ml + s) * nkf + kfi) * 9 + c * 3 + x];
-                    }
+        // T2: hand-PCA columns: d marker / d pose[bd + i] = sum_h comps[i][h] d marker / d fullpose[bd + h]
+        if (nfree_hand > 0) {
+            for (int it = tid; it < cnt * nfree_hand; it += MOSHII_TPB) {
+                const int ml = it / nfree_hand, q = n - nfree_hand + (it - ml * nfree_hand);   // hand columns are the tail
+                const int i = cx.colpid[q] - bd;
+                double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+                for (int h = md.comp_lo[i]; h < md.comp_hi[i]; ++h) {
+                    const int hj = h / 3, c = h - 3 * hj;
+                    const double cc = md.comps[i * nhf + h];
+                    const double* jh = &cx.Jh[((size_t)ml * ly.nhj + hj) * 9];
+                    r0 += cc * jh[0 * 3 + c]; r1 += cc * jh[1 * 3 + c]; r2 += cc * jh[2 * 3 + c];
                 }
-                r0 = 0.0; r1 = 0.0; r2 = 0.0;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) { r0 += L[e] * J9[e]; r1 += L[9 + e] * J9[e]; r2 += L[18 + e] * J9[e]; }
+                cx.Jrow[(3 * ml + 0) * LDJ + q] = fp.wt_data * r0;
+                cx.Jrow[(3 * ml + 1) * LDJ + q] = fp.wt_data * r1;
+                cx.Jrow[(3 * ml + 2) * LDJ + q] = fp.wt_data * r2;
             }
-            cx.Jrow[(3 * ml + 0) * LDJ + q] = fp.wt_data * r0;
-            cx.Jrow[(3 * ml + 1) * LDJ + q] = fp.wt_data * r1;
-            cx.Jrow[(3 * ml + 2) * LDJ + q] = fp.wt_data * r2;
+            __syncthreads();
         }
-        __syncthreads();
         PROF_LAP(6);
         // T3: A += Jt^T Jt ; g -= Jt^T r
         A.rank_update(cx.Jrow, ntv, LDJ);
@@ -653,12 +800,17 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             const int pid = cx.colpid[q];
             if (fp.has_velo) { const double w2 = fp.wt_velo * fp.wt_velo; dg += w2; gq -= w2 * (pose[pid] - cx.vtarget[pid]); }
             const int pb = cx.colprior[q];
-            if (pb >= 0) {
-                const double* Lrow = pr.chols + ((size_t)kb * np_ + pb) * np_;
-                const double* ell = &cx.ell[kb * np_];
-                double s = 0.0;
-                for (int a = 0; a <= pb; ++a) s += Lrow[a] * ell[a];
-                gq -= fp.wt_pose * fp.wt_pose * 0.70710678118654757 * s;
+            if (pb >= 0) {   // prior gradient w^2 (1/2 L L^T)(x - mu): column pb of the symmetric half-precision, b uniform
+                const double* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
+                const double* mu = pr.means + (size_t)kb * np_;
+                double s0 = 0.0, s1 = 0.0;
+                int b = 0;
+                for (; b + 2 <= np_; b += 2) {
+                    s0 += Hk[(size_t)b * np_] * (cx.xb[b] - mu[b]);
+                    s1 += Hk[(size_t)(b + 1) * np_] * (cx.xb[b + 1] - mu[b + 1]);
+                }
+                if (b < np_) s0 += Hk[(size_t)b * np_] * (cx.xb[b] - mu[b]);
+                gq -= fp.wt_pose * fp.wt_pose * (s0 + s1);
             }
             if (fp.use_fingers) {
                 // finger ids are a contiguous tail of the pose vector in every supported model
@@ -767,15 +919,18 @@ __device__ __noinline__ void rigid_init_serial(const Ctx& cx, const FrameParams&
 template <int NBLK>
 __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                          const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, double e3,
-                         bool rigid, bool eval_only, int& n_iter, int& n_fev, int& fail) {
+                         bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int& n_iter, int& n_fev, int& fail) {
     const int tid = threadIdx.x;
     const int n = 3 + nids;
-    int nkf = 0;
+    int nkf = 0, nfree_hand = 0;
     if (!eval_only) {   // column tables + needed-joint list
+        for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.colq[i] = -1;
+        __syncthreads();
         for (int q = tid; q < n; q += MOSHII_TPB) {
             const int pid = (q < 3) ? -1 : ids[q - 3];
             cx.colpid[q] = pid;
             cx.colprior[q] = (pid >= 0) ? cx.pid2prior[pid] : -1;
+            if (pid >= 0) cx.colq[pid] = q;
         }
         if (tid == 0) {
             for (int k = 0; k < md.K; ++k) cx.jointslot[k] = -1;
@@ -787,9 +942,13 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             int c = 0;
             for (int k = 0; k < md.K; ++k) if (cx.jointslot[k] == 0) { cx.jointslot[k] = c; cx.kfree[c] = k; ++c; }
             cx.scal[S_TMP0] = (double)c;
+            int nh = 0;   // ids are sorted, so the hand-PCA coefficients (pid >= body_dof) are the trailing columns
+            for (int i = 0; i < nids; ++i) nh += (ids[i] >= md.body_dof) ? 1 : 0;
+            cx.scal[S_TMP2] = (double)nh;
         }
         __syncthreads();
         nkf = (int)cx.scal[S_TMP0];
+        nfree_hand = (int)cx.scal[S_TMP2];
     }
     AReg<NBLK> A;
     A.zero();
@@ -800,8 +959,13 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     double sse = 0.0, delta = op.delta0, norm_sd = 0.0, norm_gn = 0.0, step = 0.0, p2 = 0.0, gd = 0.0;
     bool init = true, done = false, have_gn = false;
     int iteration = 0;
+    // `reuse`: the previous phase of this frame ended with the forward state of the CURRENT point in LDS and the same
+    // residual weights, so its evaluation (what ch.minimize recomputes on entry) is carried over instead of redone.
+    bool skip_eval = reuse && !rigid;
     while (true) {
-        last = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow);
+        if (skip_eval) { last = carried; skip_eval = false; }
+        else last = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow);
+        at_pose = true;   // cleared below when a trial point is rejected
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
             __syncthreads();
@@ -825,6 +989,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 rho = rho / (2.0 * gd - dAd);
             }
             improved = rho > 0.0;
+            at_pose = improved;
             if (improved) {
                 for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose[i] = cx.pose_t[i];
                 if (tid < 3) cx.trans[tid] = cx.trans_t[tid];
@@ -834,7 +999,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
         if (do_assemble) {
-            assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, A);
+            assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, nfree_hand, A);
             double gm = 0.0;
             for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
             if (block_max(gm, cx.red) < 1e-15) done = true;
@@ -875,9 +1040,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = sc * cx.dsd[q];
         } else {
             if (!have_gn) {
-                A.store_packed(cx.big, n);
-                __syncthreads();
-                if (!chol_solve(cx.big, cx.g, cx.dgn, cx.scal, n)) {
+                if (!ldl_solve<NBLK>(A, cx.big, cx.g, cx.dgn, cx.y, n)) {
                     fail = 1;
                     for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
                     __syncthreads();
@@ -922,6 +1085,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         __syncthreads();
     }
     n_iter += iteration;
+    carried = last;
     return last;
 }
 
@@ -940,15 +1104,20 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     int* ints = reinterpret_cast<int*>(lds + ly.o_ints);
     cx.visidx = ints + ly.i_visidx; cx.colpid = ints + ly.i_colpid; cx.colprior = ints + ly.i_colprior;
     cx.pid2prior = ints + ly.i_pid2prior; cx.jointslot = ints + ly.i_jointslot; cx.kfree = ints + ly.i_kfree;
+    cx.colq = ints + ly.i_colq;
     cx.big = lds + ly.o_big;
-    cx.Jv = cx.big + ly.t_Jv; cx.Jrow = cx.big + ly.t_Jrow; cx.Lm = cx.big + ly.t_Lm; cx.Trot = cx.big + ly.t_Trot;
+    cx.Jh = cx.big + ly.t_Jh; cx.Jrow = cx.big + ly.t_Jrow; cx.Lm = cx.big + ly.t_Lm; cx.Trot = cx.big + ly.t_Trot;
     cx.xjs = cx.big + ly.t_xjs; cx.rest = cx.big + ly.t_rest;
+    cx.tjs = reinterpret_cast<int*>(cx.big + ly.t_tjs);
 
     return cx;
 }
 
-template <int NBLK>
-__global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __restrict__ chains, ModelDev md, PriorDev pr,
+// MINW = 1: one workgroup per CU, the compiler may use the whole 512-entry register file (lowest latency per chain);
+// MINW = 2: registers capped at 256 so that two workgroups share a CU and cover each other's dependency stalls
+//           (highest throughput when there are more chains than CUs).
+template <int NBLK, int MINW>
+__global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev* __restrict__ chains, ModelDev md, PriorDev pr,
                                                              OptsDev op, ChainLayout ly) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -978,6 +1147,9 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
     PROF_BEGIN();
+#ifdef MOSHII_PROFILE
+    const long long _wall0 = wall_clock64();
+#endif
 
     for (int t = 0; t <= F; ++t) {
         // chunk hand-off states: moshii_sequence_solve checks a chunk's entry state against its predecessor's final one
@@ -1029,14 +1201,20 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
         int n_iter = 0, n_fev = 0, fail = 0;
         // phases: [rigid + annealed rounds x10 x5 x1 (first solved frame only, :629-655)] step 1 (:665-671),
         //         step 2 (:676-705), record (:712-724)
-        Sse fin;
+        Sse fin, carried;
+        bool at_pose = false;
+        double prev_wt_pose = -1.0;
+        int prev_fingers = -1;
         for (int kind = first ? 0 : 3; kind < 6; ++kind) {
             const bool round = kind < 3;
             const bool step2 = kind == 4;
             fp.wt_pose = round ? ((kind == 0) ? 10.0 : (kind == 1) ? 5.0 : 1.0) * wt_pose : wt_pose;
             fp.use_fingers = (kind >= 4 && op.nfinger > 0) ? 1 : 0;
+            const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_fingers == fp.use_fingers;
             fin = run_phase<NBLK>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
-                                  round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, n_iter, n_fev, fail);
+                                  round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose,
+                                  n_iter, n_fev, fail);
+            prev_wt_pose = fp.wt_pose; prev_fingers = fp.use_fingers;
         }
         first = false;
         if (record) {   // record
@@ -1055,13 +1233,20 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_chain_solve(const ChainDev* __re
         __syncthreads();
     }
     PROF_LAP(12);
+#ifdef MOSHII_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[30] += wall_clock64() - _wall0;   // constant 100 MHz counter
+#endif
 }
 
-template __global__ void k_chain_solve<2>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
-template __global__ void k_chain_solve<4>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
-template __global__ void k_chain_solve<5>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
-template __global__ void k_chain_solve<7>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
-template __global__ void k_chain_solve<8>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+#define MOSHII_INSTANTIATE(N) \
+    template __global__ void k_chain_solve<N, 1>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout); \
+    template __global__ void k_chain_solve<N, 2>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+MOSHII_INSTANTIATE(2)
+MOSHII_INSTANTIATE(4)
+MOSHII_INSTANTIATE(5)
+MOSHII_INSTANTIATE(7)
+MOSHII_INSTANTIATE(8)
+#undef MOSHII_INSTANTIATE
 
 
 // Simulated markers for explicit pose variables (TransformedLms.r), one frame per workgroup.
@@ -1089,17 +1274,22 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restr
 
 }  // namespace moshii
 
-extern "C" hipError_t moshii_launch_chain_solve(int nblk, int n_chains, size_t lds_bytes, hipStream_t stream,
+extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int n_chains, size_t lds_bytes, hipStream_t stream,
                                                 const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
                                                 const OptsDev* op, const ChainLayout* ly) {
     using namespace moshii;
     void (*kern)(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout) = nullptr;
-    switch (nblk) {
-        case 2: kern = k_chain_solve<2>; break;
-        case 4: kern = k_chain_solve<4>; break;
-        case 5: kern = k_chain_solve<5>; break;
-        case 7: kern = k_chain_solve<7>; break;
-        case 8: kern = k_chain_solve<8>; break;
+    switch (nblk * 2 + (two_per_cu ? 1 : 0)) {
+        case 4: kern = k_chain_solve<2, 1>; break;
+        case 5: kern = k_chain_solve<2, 2>; break;
+        case 8: kern = k_chain_solve<4, 1>; break;
+        case 9: kern = k_chain_solve<4, 2>; break;
+        case 10: kern = k_chain_solve<5, 1>; break;
+        case 11: kern = k_chain_solve<5, 2>; break;
+        case 14: kern = k_chain_solve<7, 1>; break;
+        case 15: kern = k_chain_solve<7, 2>; break;
+        case 16: kern = k_chain_solve<8, 1>; break;
+        case 17: kern = k_chain_solve<8, 2>; break;
         default: return hipErrorInvalidValue;
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

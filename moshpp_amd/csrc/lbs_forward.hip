@@ -1,21 +1,46 @@
-// Batched full-mesh LBS, float32: verts[F][V][3] for F frames of pose variables.
-// Replaces SmplModelLBS.r (src/moshpp/models/smpl_fast_derivatives.py:206-218,243-244 -> psbody
-// verts_decorated) evaluated for a whole solved sequence at once.
+// Batched full-mesh LBS, float32 out: verts[F][V][3] for F frames of pose variables.
+// Replaces SmplModelLBS.r (src/moshpp/models/smpl_fast_derivatives.py:206-218,243-244 -> psbody verts_decorated)
+// evaluated for a whole solved sequence at once (mesh export of a Stage-II result).
 //
-// v0 (correctness baseline): one workgroup = 256 vertices of one frame, posedirs stored vertex-fastest so
-// every load/store of a wave is one coalesced 256 B segment.  The MFMA version replaces this file's kernel.
+// Per (vertex, frame) the work is 2*3*9(K-1) flop of pose correctives (SMPL-H: 2754) against 12 bytes of output, i.e.
+// 230 flop/B: on the f32 pipes (157 TF) that is 19x above the HBM ridge, on the f16 matrix pipes (2.5 PF) it sits AT the
+// ridge.  So the corrective contraction  C[v,i,f] = sum_q posedirs[v,i,q] * (R - I)[f,q]  runs on
+// v_mfma_f32_32x32x16_f16 (f16 operands, scaled so posedirs stay in the normal range; f32 accumulate), and everything
+// else is fused behind it so that HBM sees the 12 V F output bytes once:
+//
+//   k_lbs_prep   one 64-thread workgroup per frame: hand-PCA -> fullpose, Rodrigues, kinematic chain;
+//                writes the skinning transforms A[j][f][12] (f32, translation folded with trans[f]) and the pose
+//                feature rows featT[f][KP] (f16).
+//   k_lbs_mfma   one workgroup (4 waves, one per SIMD) per 128 vertices x 128 frames:
+//                  * the 128 x KP feature panel is staged once in LDS (row pitch 16 x odd bytes: conflict-free b128 reads);
+//                  * each wave owns 32 vertices x 3 coordinates x 4 frame tiles = 12 accumulators (192 registers) and
+//                    streams its posedirs fragments from a fragment-major copy of the model (one contiguous 1 KiB
+//                    record per wave-load, prefetched two k-steps ahead): 3 global + 4 LDS fragment loads feed 12 MFMAs;
+//                  * epilogue on the accumulator layout itself (lane = frame, register = vertex): per 32-frame tile the
+//                    K joint transforms are staged in LDS ([joint][frame][12], 48-byte lane stride: conflict-free b128
+//                    reads) and every vertex gathers only its own <= 8 influences -- sparse skinning, no W x A GEMM:
+//                    SMPL-family weights have <= 4 influences per vertex, the dense contraction would be 13x the work;
+//                  * results are transposed through LDS and leave as contiguous 384-byte runs per (wave, frame).
+//                workgroup -> (vertex tile, frame tile) is XCD-aware: all frame tiles of one vertex tile run on the XCD
+//                whose L2 already holds that tile's 356 KB of posedirs fragments.
+//
+// Accuracy: f16 operands give |err| ~ 2^-11 |posedirs| |R - I| sqrt(9(K-1)) ~ 5e-6 m for millimetre-scale correctives
+// (tests bound it at 2e-5 m); moshii_lbs_forward_f64 is the reference-precision path.
 #include "../../include/moshii.h"
 #include "moshii_dev.h"
 
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
 #include <vector>
 
-struct Lbs32Model {
-    float* v_shaped;
-    float* posedirs_t;   // [9(K-1)][3][Vp]
-    float* weights;      // [K][Vp]
-    float* J;            // [K][3]
-    int Vp;
-};
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LBS_NWMAX 8          // skinning influences per vertex (else the launch falls back to the plain kernel)
+#define LBS_TV 128           // vertices per workgroup (32 per wave)
+#define LBS_TF 128           // frames per workgroup (4 MFMA column tiles)
 
 extern "C" {
 int moshii_internal_model_dims(moshii_model_t m, int* V, int* K);
@@ -23,6 +48,7 @@ const double* moshii_internal_vsh(moshii_model_t m);
 const double* moshii_internal_posedirs(moshii_model_t m);
 const double* moshii_internal_weights(moshii_model_t m);
 const double* moshii_internal_J(moshii_model_t m);
+const double* moshii_internal_weights_host(moshii_model_t m);
 void* moshii_internal_l32(moshii_model_t m);
 void moshii_internal_l32_set_valid(moshii_model_t m, int v);
 }
@@ -54,6 +80,36 @@ __global__ void k_cvt_weights(int V, int Vp, int K, const double* __restrict__ s
     }
 }
 
+// max |posedirs| (for the f16 scale)
+__global__ void k_absmax(size_t n, const double* __restrict__ src, double* __restrict__ out) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmax(m, fabs(src[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// fragment-major f16 posedirs: record (vg, i, ks) holds, for lane l, the 8 values posedirs[v = 32 vg + (l & 31)][i][16 ks + 8 (l >> 5) + e]
+__global__ void k_pack_pfrag(int V, int nfeat, int KS, int nvg, double pscale, const double* __restrict__ src, _Float16* __restrict__ dst) {
+    const size_t total = (size_t)nvg * 3 * KS * 64 * 8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        const int l = (int)((idx >> 3) & 63);
+        size_t r = idx >> 9;
+        const int ks = (int)(r % KS); r /= KS;
+        const int i = (int)(r % 3);
+        const int vg = (int)(r / 3);
+        const int v = vg * 32 + (l & 31);
+        const int q = ks * 16 + (l >> 5) * 8 + e;
+        double val = 0.0;
+        if (v < V && q < nfeat) val = src[((size_t)v * 3 + i) * nfeat + q] * pscale;
+        dst[idx] = (_Float16)val;
+    }
+}
+
+// ---- fallback kernel: one workgroup = 256 vertices of one frame (plain f32, dense weights) ----------------
 __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, const float* __restrict__ pose,
                                                      const float* __restrict__ trans, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
@@ -132,7 +188,290 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
     for (int i = 0; i < 3; ++i) o[i] = T[i * 4 + 0] * vp[0] + T[i * 4 + 1] * vp[1] + T[i * 4 + 2] * vp[2] + T[i * 4 + 3] + tr[i];
 }
 
+// ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
+__global__ __launch_bounds__(64) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KP,
+                                                  const float* __restrict__ pose, const float* __restrict__ trans,
+                                                  float* __restrict__ Atr, _Float16* __restrict__ featT) {
+    __shared__ float fullpose[3 * MOSHII_MAXK];
+    __shared__ float Rl[MOSHII_MAXK * 9], Rw[MOSHII_MAXK * 9], tw[MOSHII_MAXK * 3];
+    const int K = md.K, P = md.P, f = blockIdx.x, tid = threadIdx.x;
+    const float* ps = pose + (size_t)f * md.NP;
+    for (int d = tid; d < P; d += 64) {
+        float v;
+        if (d < md.body_dof) v = ps[d];
+        else {
+            const int h = d - md.body_dof;
+            double acc = md.hands_mean[h];
+            for (int i = md.col_lo[h]; i < md.col_hi[h]; ++i) acc += (double)ps[md.body_dof + i] * md.comps[i * md.nhand_full + h];
+            v = (float)acc;
+        }
+        fullpose[d] = v;
+    }
+    __syncthreads();
+    _Float16* frow = featT + (size_t)f * KP;
+    if (tid < K) {
+        const float x = fullpose[3 * tid], y = fullpose[3 * tid + 1], z = fullpose[3 * tid + 2];
+        const float t2 = x * x + y * y + z * z;
+        float a, b;
+        if (t2 < 1e-6f) { a = 1.0f - t2 / 6.0f; b = 0.5f - t2 / 24.0f; }
+        else { const float t = sqrtf(t2); a = sinf(t) / t; b = (1.0f - cosf(t)) / t2; }
+        const float K2[9] = {x * x - t2, x * y, x * z, x * y, y * y - t2, y * z, x * z, y * z, z * z - t2};
+        const float Km[9] = {0.0f, -z, y, z, 0.0f, -x, -y, x, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const float id = (e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f;
+            const float r = id + a * Km[e] + b * K2[e];
+            Rl[tid * 9 + e] = r;
+            if (tid >= 1) frow[(tid - 1) * 9 + e] = (_Float16)(r - id);   // computed as a K + b K^2: no cancellation
+        }
+    }
+    for (int q = 9 * (K - 1) + tid; q < KP; q += 64) frow[q] = (_Float16)0.0f;
+    __syncthreads();
+    // kinematic chain inside one wavefront (in-order LDS), one tree level per step
+    if (tid == 0) {
+        for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];
+        for (int i = 0; i < 3; ++i) tw[i] = Jf[i];
+    }
+    const int lvl_of = (tid < K) ? md.depth[tid] : -1;
+    const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
+    for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lvl_of == lvl) {
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j)
+                    Rw[tid * 9 + i * 3 + j] = Rw[p * 9 + i * 3 + 0] * Rl[tid * 9 + j] + Rw[p * 9 + i * 3 + 1] * Rl[tid * 9 + 3 + j] + Rw[p * 9 + i * 3 + 2] * Rl[tid * 9 + 6 + j];
+                tw[tid * 3 + i] = Rw[p * 9 + i * 3 + 0] * (Jf[tid * 3 + 0] - Jf[p * 3 + 0]) + Rw[p * 9 + i * 3 + 1] * (Jf[tid * 3 + 1] - Jf[p * 3 + 1]) +
+                                  Rw[p * 9 + i * 3 + 2] * (Jf[tid * 3 + 2] - Jf[p * 3 + 2]) + tw[p * 3 + i];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (tid < K) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint)
+        float* o = Atr + ((size_t)tid * F + f) * 12;
+        const float* tr = trans + (size_t)f * 3;
+        for (int i = 0; i < 3; ++i) {
+            const float r0 = Rw[tid * 9 + i * 3 + 0], r1 = Rw[tid * 9 + i * 3 + 1], r2 = Rw[tid * 9 + i * 3 + 2];
+            o[i * 4 + 0] = r0; o[i * 4 + 1] = r1; o[i * 4 + 2] = r2;
+            o[i * 4 + 3] = tw[tid * 3 + i] - (r0 * Jf[tid * 3 + 0] + r1 * Jf[tid * 3 + 1] + r2 * Jf[tid * 3 + 2]) + tr[i];
+        }
+    }
+}
+
+// ---- the MFMA kernel --------------------------------------------------------------------------------------
+#define LBS_PITCH(KP) ((KP) + 8)   // halves; (KP + 8) * 2 bytes = 16 (2 KS + 1): 16 x odd  (464 -> 944 = 16 * 59)
+#define LBS_FCH 8                  // frame tiles per L2 chunk: 1024 frames of transforms (K x 48 KB) stay L2-resident
+__host__ __device__ inline size_t lbs_region_bytes(int KP, int K) {
+    const size_t panel = (size_t)LBS_TF * LBS_PITCH(KP) * 2;
+    const size_t epi = ((size_t)K * 32 * 12 + 4 * 32 * 97) * 4;
+    return ((panel > epi ? panel : epi) + 15) & ~size_t(15);
+}
+
+// Blend + apply for one 32-frame tile, on the accumulator layout (lane = frame column, register = vertex row).
+// Tl: this frame tile's joint transforms [K][32][12]; sjw: the workgroup's per-vertex influences [128][NWT] as
+// {byte offset of the joint's [32][12] block, weight bits}.  Vertices are processed in pairs with every LDS load of
+// the pair issued before the first use (the influence -> transform address chain is the latency that matters here).
+template <int NWT>
+__device__ __forceinline__ void lbs_epilogue(const f32x16& ax, const f32x16& ay, const f32x16& az, float isc,
+                                             const char* Tl, const int2* sjw, const float* vl, float* tb,
+                                             int V, int F, int fbase, int v0, int wv, int lane, float* __restrict__ out) {
+    const int h = lane >> 5, fl = lane & 31;
+    const char* Tlane = Tl + fl * 48;
+#pragma unroll
+    for (int rg = 0; rg < 16; rg += 4) {
+        // influences of four vertices at once (uniform per half-wave: broadcast reads), then one vertex at a time:
+        // its NWT transforms (3 b128 reads each) are all in flight before the first multiply
+        int2 jw[4][NWT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = rg + t;
+            const int vloc = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int s2 = 0; s2 < NWT; ++s2) jw[t][s2] = sjw[vloc * NWT + s2];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = rg + t;
+            const int vw = (r & 3) + 8 * (r >> 2) + 4 * h;   // vertex inside the wave's 32-vertex group
+            const int vloc = wv * 32 + vw;
+            float4 A0[NWT], A1[NWT], A2[NWT];
+#pragma unroll
+            for (int s2 = 0; s2 < NWT; ++s2) {
+                const float4* tp = reinterpret_cast<const float4*>(Tlane + jw[t][s2].x);
+                A0[s2] = tp[0]; A1[s2] = tp[1]; A2[s2] = tp[2];
+            }
+            float4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
+#pragma unroll
+            for (int s2 = 0; s2 < NWT; ++s2) {
+                const float w = __int_as_float(jw[t][s2].y);
+                T0.x += w * A0[s2].x; T0.y += w * A0[s2].y; T0.z += w * A0[s2].z; T0.w += w * A0[s2].w;
+                T1.x += w * A1[s2].x; T1.y += w * A1[s2].y; T1.z += w * A1[s2].z; T1.w += w * A1[s2].w;
+                T2.x += w * A2[s2].x; T2.y += w * A2[s2].y; T2.z += w * A2[s2].z; T2.w += w * A2[s2].w;
+            }
+            const float px = vl[vloc * 3 + 0] + isc * ax[r];
+            const float py = vl[vloc * 3 + 1] + isc * ay[r];
+            const float pz = vl[vloc * 3 + 2] + isc * az[r];
+            // transpose through this wave's LDS buffer: row = frame, 96 contiguous floats = 32 vertices x 3 (+1 pad)
+            tb[fl * 97 + vw * 3 + 0] = T0.x * px + T0.y * py + T0.z * pz + T0.w;
+            tb[fl * 97 + vw * 3 + 1] = T1.x * px + T1.y * py + T1.z * pz + T1.w;
+            tb[fl * 97 + vw * 3 + 2] = T2.x * px + T2.y * py + T2.z * pz + T2.w;
+            __builtin_amdgcn_sched_barrier(0);   // one vertex at a time: bounds the live set (NWT x 12 transform registers)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int vbase = v0 + wv * 32;
+    const int nvalid = min(32, V - vbase) * 3;   // floats of this wave's run that exist in the output
+    const int nfr = min(32, F - fbase);
+    for (int fr0 = 0; fr0 < nfr; fr0 += 8) {   // 8 frame rows per batch: all LDS reads first, then the global stores
+        float lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo[k] = tb[(fr0 + k) * 97 + lane]; hi[k] = tb[(fr0 + k) * 97 + min(lane + 64, 95)]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (fr0 + k < nfr) {
+                float* orow = out + ((size_t)(fbase + fr0 + k) * V + vbase) * 3;
+                if (lane < nvalid) orow[lane] = lo[k];
+                if (lane + 64 < nvalid) orow[lane + 64] = hi[k];
+            }
+        }
+    }
+}
+
+template <int NWT>
+__global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F, int NVT, int NFT, int NVX,
+                                                      float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8; each XCD owns the vertex tiles {xcd, xcd + 8, ...} and walks
+    // (frame chunk, vertex tile, frame tile in chunk) with the frame tile fastest: the 356 KB of posedirs fragments of
+    // a vertex tile are fetched once per chunk and then hit that XCD's L2, and a chunk's K x 1024 x 48 B of joint
+    // transforms (2.5 MB for SMPL-H) stays L2-resident while every vertex tile of the XCD sweeps over it.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int fl_t = slot % LBS_FCH, rest = slot / LBS_FCH;
+    const int vt = xcd + 8 * (rest % NVX), ft = (rest / NVX) * LBS_FCH + fl_t;
+    if (vt >= NVT || ft >= NFT) return;
+    const int KP = lm.KP, KS = lm.KS, pitch = LBS_PITCH(KP);
+    // LDS: [ region R | sjw | vl ],  R = max(feature panel, transforms of one frame tile + 4 transpose buffers)
+    _Float16* Bp = reinterpret_cast<_Float16*>(lds_raw);                           // main loop: [128][pitch] f16
+    const int K = lm.K;
+    char* Tl = lds_raw;                                                            // epilogue: [K][32][12] f32
+    float* tball = reinterpret_cast<float*>(lds_raw) + (size_t)K * 32 * 12;        //           [4 waves][32][97] f32
+    const size_t regionR = lbs_region_bytes(KP, K);
+    int2* sjw = reinterpret_cast<int2*>(lds_raw + regionR);                        // [128][NWT]
+    float* vl = reinterpret_cast<float*>(sjw + LBS_TV * NWT);                      // [128][3]
+    const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
+    // stage the feature panel (rows beyond F are zero) and this tile's influences / rest vertices
+    {
+        const int chunks = KP / 8;   // 16-byte chunks per row (<= 64: one lane per chunk, one wave per row, no index division)
+        for (int r0 = wv; r0 < LBS_TF; r0 += 4 * 8) {   // 8 independent 16-byte loads in flight per lane, then the LDS writes
+            half8 v[8];
+            const int cc = min(lane, chunks - 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int fr = min(f0 + r0 + 4 * k, F - 1);
+                v[k] = *reinterpret_cast<const half8*>(lm.featT + (size_t)fr * KP + cc * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + 4 * k;
+                half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (lane < chunks) *reinterpret_cast<half8*>(Bp + (size_t)r * pitch + cc * 8) = (f0 + r < F) ? v[k] : z;
+            }
+        }
+        for (int c = tid; c < LBS_TV * NWT; c += 256) sjw[c] = lm.sjw[(size_t)v0 * NWT + c];
+        for (int c = tid; c < LBS_TV * 3; c += 256) vl[c] = lm.vsh_pad[(size_t)v0 * 3 + c];
+    }
+    __syncthreads();
+    // ---- main loop: acc[i][nt] (32 vertices x 32 frames) += Pfrag(i, ks) x featT(nt, ks)
+    f32x16 acc[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][nt][e] = 0.0f;
+    const int vg = vt * 4 + wv;   // this wave's 32-vertex group
+    const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)vg * 3 * KS) * 64 + lane;
+    const size_t astride = (size_t)KS * 64;   // coordinate stride in half8 units
+    const _Float16* bp = Bp + (size_t)(lane & 31) * pitch + (lane >> 5) * 8;
+    // Six rotating A-fragment sets (k-steps t .. t+5) and two B-fragment sets (t, t+1), addressed by NAME so that no register
+    // copy ever waits on a load: step t computes from (A[t%6], B[t%2]) while the global loads for A[(t+5)%6] (five
+    // k-steps = 1920 MFMA cycles ahead: covers an L2 miss with one wave per SIMD) and the LDS reads for B[(t+1)%2] fly.
+    half8 aS[6][3], bS[2][4];
+#define LBS_LOAD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int i = 0; i < 3; ++i) aS[SET][i] = ap[i * astride + (size_t)kk_ * 64]; }
+#define LBS_LOAD_B(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) bS[SET][nt] = *reinterpret_cast<const half8*>(bp + (size_t)nt * 32 * pitch + kk_ * 16); }
+    // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use and the
+    //  loop waits vmcnt(0) every k-step -- measured 89 cycles per MFMA instead of 32)
+#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int i = 0; i < 3; ++i) \
+        acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aS[ASET][i], bS[BSET][nt], acc[i][nt], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+    LBS_LOAD_A(0, 0) LBS_LOAD_A(1, 1) LBS_LOAD_A(2, 2) LBS_LOAD_A(3, 3) LBS_LOAD_A(4, 4) LBS_LOAD_B(0, 0)
+    int ks = 0;
+    for (; ks + 6 <= KS; ks += 6) {
+        LBS_LOAD_A(5, ks + 5) LBS_LOAD_B(1, ks + 1) LBS_MMA(0, 0)
+        LBS_LOAD_A(0, ks + 6) LBS_LOAD_B(0, ks + 2) LBS_MMA(1, 1)
+        LBS_LOAD_A(1, ks + 7) LBS_LOAD_B(1, ks + 3) LBS_MMA(2, 0)
+        LBS_LOAD_A(2, ks + 8) LBS_LOAD_B(0, ks + 4) LBS_MMA(3, 1)
+        LBS_LOAD_A(3, ks + 9) LBS_LOAD_B(1, ks + 5) LBS_MMA(4, 0)
+        LBS_LOAD_A(4, ks + 10) LBS_LOAD_B(0, ks + 6) LBS_MMA(5, 1)
+    }
+    // remainder (KS mod 6 steps): same rotation; the fragments are already in flight, only B needs fetching
+    if (ks < KS) { LBS_LOAD_B(1, ks + 1) LBS_MMA(0, 0) ++ks; }
+    if (ks < KS) { LBS_LOAD_B(0, ks + 1) LBS_MMA(1, 1) ++ks; }
+    if (ks < KS) { LBS_LOAD_B(1, ks + 1) LBS_MMA(2, 0) ++ks; }
+    if (ks < KS) { LBS_LOAD_B(0, ks + 1) LBS_MMA(3, 1) ++ks; }
+    if (ks < KS) { LBS_LOAD_B(1, ks + 1) LBS_MMA(4, 0) ++ks; }
+#undef LBS_LOAD_A
+#undef LBS_LOAD_B
+#undef LBS_MMA
+    // ---- epilogue, one 32-frame tile at a time.  The NEXT tile's joint transforms are pulled into registers (all of a
+    // lane's <= 24 16-byte loads in flight at once) before the current tile is blended, and dropped into LDS behind an
+    // LDS-only barrier -- a plain __syncthreads() would also wait for the tile's global stores to be acknowledged.
+    float* tb = tball + (size_t)wv * 32 * 97;
+    const float isc = lm.inv_pscale;
+    const int nchunk = K * 96;   // 16-byte chunks of one tile's transforms: [j][frame in tile][3]
+    float4 tl0, tl1, tl2, tl3, tl4, tl5, tl6, tl7, tl8, tl9, tl10, tl11, tl12, tl13, tl14, tl15, tl16, tl17, tl18, tl19, tl20, tl21, tl22, tl23;   // (named scalars: hipcc keeps an array of these in scratch)
+#define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define LBS_FETCH1(K_, FB) { const int c = min(tid + 256 * K_, nchunk - 1); const int j = c / 96, rem = c - j * 96, fl2 = rem / 3, q = rem - fl2 * 3; \
+        tl##K_ = reinterpret_cast<const float4*>(lm.Atr + ((size_t)j * F + min((FB) + fl2, F - 1)) * 12)[q]; }
+#define LBS_PUT1(K_) { const int c = tid + 256 * K_; if (c < nchunk) reinterpret_cast<float4*>(Tl)[c] = tl##K_; }
+#define LBS_FETCH_TL(FB) { LBS_FETCH1(0, FB) LBS_FETCH1(1, FB) LBS_FETCH1(2, FB) LBS_FETCH1(3, FB) LBS_FETCH1(4, FB) LBS_FETCH1(5, FB) LBS_FETCH1(6, FB) LBS_FETCH1(7, FB) LBS_FETCH1(8, FB) LBS_FETCH1(9, FB) LBS_FETCH1(10, FB) LBS_FETCH1(11, FB) LBS_FETCH1(12, FB) LBS_FETCH1(13, FB) LBS_FETCH1(14, FB) LBS_FETCH1(15, FB) LBS_FETCH1(16, FB) LBS_FETCH1(17, FB) LBS_FETCH1(18, FB) LBS_FETCH1(19, FB) LBS_FETCH1(20, FB) LBS_FETCH1(21, FB) LBS_FETCH1(22, FB) LBS_FETCH1(23, FB) }
+#define LBS_PUT_TL() { LBS_PUT1(0) LBS_PUT1(1) LBS_PUT1(2) LBS_PUT1(3) LBS_PUT1(4) LBS_PUT1(5) LBS_PUT1(6) LBS_PUT1(7) LBS_PUT1(8) LBS_PUT1(9) LBS_PUT1(10) LBS_PUT1(11) LBS_PUT1(12) LBS_PUT1(13) LBS_PUT1(14) LBS_PUT1(15) LBS_PUT1(16) LBS_PUT1(17) LBS_PUT1(18) LBS_PUT1(19) LBS_PUT1(20) LBS_PUT1(21) LBS_PUT1(22) LBS_PUT1(23) }
+    LBS_FETCH_TL(f0)
+    LBS_LDS_BARRIER();   // every wave is done with the feature panel
+    LBS_PUT_TL()
+    LBS_LDS_BARRIER();
+    // (one call per frame tile with a compile-time accumulator index: runtime indexing would push acc[][] to scratch)
+    LBS_FETCH_TL(f0 + 32)
+    lbs_epilogue<NWT>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, sjw, vl, tb, V, F, f0 + 0, v0, wv, lane, out);
+    LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+    LBS_FETCH_TL(f0 + 64)
+    lbs_epilogue<NWT>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, sjw, vl, tb, V, F, f0 + 32, v0, wv, lane, out);
+    LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+    LBS_FETCH_TL(f0 + 96)
+    lbs_epilogue<NWT>(acc[0][2], acc[1][2], acc[2][2], isc, Tl, sjw, vl, tb, V, F, f0 + 64, v0, wv, lane, out);
+    LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+    lbs_epilogue<NWT>(acc[0][3], acc[1][3], acc[2][3], isc, Tl, sjw, vl, tb, V, F, f0 + 96, v0, wv, lane, out);
+#undef LBS_FETCH_TL
+#undef LBS_PUT_TL
+#undef LBS_FETCH1
+#undef LBS_PUT1
+#undef LBS_LDS_BARRIER
+}
+
 }  // namespace
+
+static void free_ptr(void* p) { if (p) hipFree(p); }
+
+extern "C" void moshii_lbs32_free(void* l32) {
+    Lbs32Model* lm = (Lbs32Model*)l32;
+    free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
+    free_ptr(lm->Pfrag); free_ptr(lm->vsh_pad); free_ptr(lm->sjw);
+    free_ptr(lm->Atr); free_ptr(lm->featT);
+    memset(lm, 0, sizeof(*lm));
+}
 
 extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
     int V, K;
@@ -148,18 +487,101 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
         lm->Vp = Vp;
         hipLaunchKernelGGL(k_cvt_posedirs, dim3(2048), dim3(256), 0, 0, V, Vp, nfeat, moshii_internal_posedirs(m), lm->posedirs_t);
         hipLaunchKernelGGL(k_cvt_weights, dim3(512), dim3(256), 0, 0, V, Vp, K, moshii_internal_weights(m), lm->weights);
+        // ---- MFMA-path model copy
+        lm->mfma_ok = 0;
+        const int Vp128 = (V + LBS_TV - 1) / LBS_TV * LBS_TV;
+        const int KS = (nfeat + 15) / 16, KP = KS * 16;
+        const int nvg = Vp128 / 32;
+        lm->Vp128 = Vp128; lm->KS = KS; lm->KP = KP;
+        // per-vertex influence lists (host; once per model)
+        const double* wh = moshii_internal_weights_host(m);
+        int NW = 1;
+        for (int v = 0; v < V; ++v) {
+            int c = 0;
+            for (int j = 0; j < K; ++j) c += (wh[(size_t)v * K + j] != 0.0) ? 1 : 0;
+            NW = std::max(NW, c);
+        }
+        bool ok = nfeat > 0 && NW <= LBS_NWMAX;
+        lm->K = K; lm->NW = NW;
+        const int NWT = (NW <= 4) ? 4 : 8;   // influences padded to the kernel's compile-time width (joint 0, weight 0)
+        lm->NW = NWT;
+        std::vector<int> sjw(ok ? (size_t)Vp128 * NWT * 2 : 0, 0);   // {byte offset of the joint's [32][12] f32 block, weight bits}
+        for (int v = 0; v < V && ok; ++v) {
+            int c = 0;
+            for (int j = 0; j < K; ++j) {
+                const double w = wh[(size_t)v * K + j];
+                if (w != 0.0) {
+                    const float wf = (float)w;
+                    int bits; memcpy(&bits, &wf, 4);
+                    sjw[((size_t)v * NWT + c) * 2 + 0] = j * 32 * 48;
+                    sjw[((size_t)v * NWT + c) * 2 + 1] = bits;
+                    ++c;
+                }
+            }
+        }
+        if (ok) {
+            double* d_part = nullptr;
+            if (hipMalloc((void**)&d_part, 256 * sizeof(double)) != hipSuccess) return MOSHII_ERR_HIP;
+            hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, 0, (size_t)V * 3 * nfeat, moshii_internal_posedirs(m), d_part);
+            double part[256];
+            if (hipMemcpy(part, d_part, sizeof(part), hipMemcpyDeviceToHost) != hipSuccess) return MOSHII_ERR_HIP;
+            hipFree(d_part);
+            double amax = 0.0;
+            for (double p : part) amax = std::max(amax, p);
+            // power-of-two scale that lifts the largest corrective to ~2^13: small entries stay normal in f16
+            double pscale = 1.0;
+            if (amax > 0.0) pscale = std::ldexp(1.0, 13 - (int)std::ceil(std::log2(amax)));
+            lm->inv_pscale = (float)(1.0 / pscale);
+            if (hipMalloc((void**)&lm->Pfrag, (size_t)nvg * 3 * KS * 64 * 8 * sizeof(_Float16)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->vsh_pad, (size_t)Vp128 * 3 * sizeof(float)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->sjw, sjw.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
+            hipMemcpy(lm->sjw, sjw.data(), sjw.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_pack_pfrag, dim3(4096), dim3(256), 0, 0, V, nfeat, KS, nvg, pscale, moshii_internal_posedirs(m), lm->Pfrag);
+            lm->mfma_ok = 1;
+        }
     }
     hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->v_shaped);
     hipLaunchKernelGGL(k_cvt_vsh, dim3(1), dim3(256), 0, 0, K * 3, moshii_internal_J(m), lm->J);
+    if (lm->mfma_ok) {
+        hipMemset(lm->vsh_pad, 0, (size_t)lm->Vp128 * 3 * sizeof(float));
+        hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->vsh_pad);
+    }
     if (hipDeviceSynchronize() != hipSuccess) return MOSHII_ERR_HIP;
     moshii_internal_l32_set_valid(m, 1);
     return MOSHII_OK;
 }
 
 extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* md, int F, const float* pose,
-                                            const float* trans, float* verts, const void* lbs32) {
-    const Lbs32Model lm = *(const Lbs32Model*)lbs32;
-    const size_t lds = (size_t)(md->P + md->K * 30) * sizeof(float);
-    hipLaunchKernelGGL(k_lbs_f32_v0, dim3((md->V + 255) / 256, F), dim3(256), lds, stream, *md, lm, pose, trans, verts);
+                                            const float* trans, float* verts, void* lbs32) {
+    Lbs32Model* lmp = (Lbs32Model*)lbs32;
+    const bool force_v0 = getenv("MOSHII_LBS_PLAIN") != nullptr;
+    if (!lmp->mfma_ok || force_v0) {
+        const Lbs32Model lm = *lmp;
+        const size_t lds = (size_t)(md->P + md->K * 30) * sizeof(float);
+        hipLaunchKernelGGL(k_lbs_f32_v0, dim3((md->V + 255) / 256, F), dim3(256), lds, stream, *md, lm, pose, trans, verts);
+        return hipGetLastError();
+    }
+    if (F > lmp->Fcap) {   // per-call scratch grows to the largest F seen (not stream-ordered: sync first)
+        hipStreamSynchronize(stream);
+        free_ptr(lmp->Atr); free_ptr(lmp->featT);
+        lmp->Atr = nullptr; lmp->featT = nullptr; lmp->Fcap = 0;
+        hipError_t e = hipMalloc((void**)&lmp->Atr, (size_t)md->K * F * 12 * sizeof(float));
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&lmp->featT, (size_t)F * lmp->KP * sizeof(_Float16));
+        if (e != hipSuccess) return e;
+        lmp->Fcap = F;
+    }
+    const Lbs32Model lm = *lmp;
+    hipLaunchKernelGGL(k_lbs_prep, dim3(F), dim3(64), 0, stream, *md, lm.J, F, lm.KP, pose, trans, lm.Atr, lm.featT);
+    const int NVT = lm.Vp128 / LBS_TV, NFT = (F + LBS_TF - 1) / LBS_TF;
+    const int NVX = (NVT + 7) / 8;                         // vertex tiles per XCD
+    const int NCH = (NFT + LBS_FCH - 1) / LBS_FCH;         // frame chunks
+    const int grid = 8 * NCH * NVX * LBS_FCH;
+    const size_t lds = lbs_region_bytes(lm.KP, lm.K) + (size_t)LBS_TV * lm.NW * 8 + (size_t)LBS_TV * 3 * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = (lm.NW == 4) ? k_lbs_mfma<4> : k_lbs_mfma<8>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, lm, md->V, F, NVT, NFT, NVX, verts);
     return hipGetLastError();
 }

@@ -10,14 +10,14 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t moshii_launch_chain_solve(int nblk, int n_chains, size_t lds_bytes, hipStream_t stream,
+extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int n_chains, size_t lds_bytes, hipStream_t stream,
                                                 const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
                                                 const OptsDev* op, const ChainLayout* ly);
 extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t stream, const AttachDev* att,
                                             const ModelDev* md, const ChainLayout* ly, const double* pose,
                                             const double* trans, double* out);
 extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* md, int F, const float* pose,
-                                            const float* trans, float* verts, const void* lbs32);
+                                            const float* trans, float* verts, void* lbs32);
 
 namespace {
 
@@ -60,25 +60,16 @@ struct Scratch {   // growable device buffer reused across calls (small control 
 
 }  // namespace
 
-// single-precision copy of the model for the HBM-bound export kernel (lbs_forward.hip)
-struct Lbs32Model {
-    float* v_shaped = nullptr;     // [V][3]
-    float* posedirs_t = nullptr;   // [9(K-1)][3][Vp]  vertex fastest
-    float* weights = nullptr;      // [K][Vp] vertex fastest (dense)
-    float* J = nullptr;            // [K][3]
-    int Vp = 0;
-};
-
 struct moshii_model_s {
     int V = 0, K = 0, NB = 0, P = 0, NP = 0, body_dof = 0, hand_dof = 0, nhand_full = 0, maxdepth = 0;
     std::vector<int> parents, depth;
     std::vector<double> weights_host;   // [V][K] (attachment packing)
     double *d_vt = nullptr, *d_shapedirs = nullptr, *d_posedirs = nullptr, *d_weights = nullptr, *d_Jreg = nullptr;
     double *d_vsh = nullptr, *d_J = nullptr, *d_hands_mean = nullptr, *d_comps = nullptr;
-    int *d_parents = nullptr, *d_depth = nullptr, *d_comp_lo = nullptr, *d_comp_hi = nullptr;
+    int *d_parents = nullptr, *d_depth = nullptr, *d_comp_lo = nullptr, *d_comp_hi = nullptr, *d_col_lo = nullptr, *d_col_hi = nullptr;
     unsigned long long* d_anc = nullptr;
     bool betas_set = false;
-    Lbs32Model l32;
+    Lbs32Model l32 = {};
     bool l32_valid = false;
     Scratch scratch;
     ModelDev dev() const {
@@ -86,7 +77,7 @@ struct moshii_model_s {
         md.V = V; md.K = K; md.P = P; md.NP = NP; md.body_dof = body_dof; md.hand_dof = hand_dof;
         md.nhand_full = nhand_full; md.maxdepth = maxdepth;
         md.parents = d_parents; md.J = d_J; md.hands_mean = d_hands_mean; md.comps = d_comps;
-        md.comp_lo = d_comp_lo; md.comp_hi = d_comp_hi; md.anc = d_anc; md.depth = d_depth;
+        md.comp_lo = d_comp_lo; md.comp_hi = d_comp_hi; md.col_lo = d_col_lo; md.col_hi = d_col_hi; md.anc = d_anc; md.depth = d_depth;
         return md;
     }
 };
@@ -100,7 +91,7 @@ struct moshii_prior_s {
 struct moshii_attach_s {
     moshii_model_t model = nullptr;
     int M = 0, Nv = 0, Nvp = 0, NW = 0;
-    double *d_vsh = nullptr, *d_Pt = nullptr, *d_ww = nullptr, *d_coef = nullptr;
+    double *d_vsh = nullptr, *d_Pt = nullptr, *d_Pj = nullptr, *d_ww = nullptr, *d_coef = nullptr;
     int* d_wj = nullptr;
     int* d_vids = nullptr;
     AttachDev* d_self = nullptr;
@@ -138,18 +129,19 @@ __global__ void k_joints(int V, const double* __restrict__ Jreg, const double* _
 }
 
 __global__ void k_pack_attach(int Nv, int Nvp, int K, const int* __restrict__ vids, const double* __restrict__ posedirs,
-                              const double* __restrict__ vsh, double* __restrict__ Pt, double* __restrict__ vsh_out) {
+                              const double* __restrict__ vsh, double* __restrict__ Pt, double* __restrict__ Pj,
+                              double* __restrict__ vsh_out) {
     const int nfeat = 9 * (K - 1);
     const size_t total = (size_t)(K - 1) * 27 * Nvp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int a = (int)(idx % Nvp);
         const int r = (int)(idx / Nvp);           // (k-1)*27 + i*9 + e
+        const int km1 = r / 27, q = r % 27;
         double v = 0.0;
-        if (a < Nv) {
-            const int km1 = r / 27, i = (r % 27) / 9, e = r % 9;
-            v = posedirs[((size_t)vids[a] * 3 + i) * nfeat + 9 * km1 + e];
-        }
+        if (a < Nv) v = posedirs[((size_t)vids[a] * 3 + q / 9) * nfeat + 9 * km1 + q % 9];
         Pt[idx] = v;
+        Pj[((size_t)km1 * Nvp + a) * 28 + q] = v;
+        if (q == 26) Pj[((size_t)km1 * Nvp + a) * 28 + 27] = 0.0;
     }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < Nv * 3) vsh_out[t] = vsh[(size_t)vids[t / 3] * 3 + t % 3];
@@ -236,17 +228,17 @@ __global__ void k_lbs_f64(ModelDev md, const double* __restrict__ vsh, const dou
 // ---- LDS layout of the chain kernel ------------------------------------------------------------
 int pick_nblk(int n) {
     const int opts[5] = {2, 4, 5, 7, 8};
-    for (int o : opts) if (o * 16 >= n) return o;
+    for (int o : opts) if (o * 16 >= n + 1) return o;   // +1: the right-hand side rides along as row n (ldl_solve)
     return -1;
 }
 
-ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm, int nblk = 0) {
+ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm, int nblk = 0, int nhj = 0) {
     ChainLayout ly;
     memset(&ly, 0, sizeof(ly));
     const int K = m->K, NP = m->NP, P = m->P;
     if (nblk <= 0) nblk = pick_nblk(nmax);
     const int LDJ = nblk * 16;
-    ly.Mmax = Mmax; ly.Nvmax = Nvmax; ly.NWmax = NWmax; ly.nmax = nmax; ly.Tm = Tm; ly.nkfmax = nkfmax; ly.LDJ = LDJ;
+    ly.Mmax = Mmax; ly.Nvmax = Nvmax; ly.NWmax = NWmax; ly.nmax = nmax; ly.Tm = Tm; ly.nkfmax = nkfmax; ly.LDJ = LDJ; ly.nhj = nhj;
     int off = 0;
     auto take = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
     ly.o_pose = take(NP); ly.o_trans = take(4); ly.o_pose_t = take(NP); ly.o_trans_t = take(4);
@@ -261,14 +253,15 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     int io = 0;
     auto itake = [&](int ni) { int o = io; io += ni; return o; };
     ly.i_visidx = itake(Mmax); ly.i_colpid = itake(LDJ); ly.i_colprior = itake(LDJ); ly.i_pid2prior = itake(NP);
-    ly.i_jointslot = itake(K); ly.i_kfree = itake(K);
+    ly.i_jointslot = itake(K); ly.i_kfree = itake(K); ly.i_colq = itake(NP);
     ly.i_total = io;
     ly.o_ints = take((io + 1) / 2);
     int t = 0;
     auto ttake = [&](int nd) { int o = t; t += (nd + 1) & ~1; return o; };
-    ly.t_Jv = ttake(3 * Tm * nkfmax * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 27);
-    ly.t_Trot = ttake(3 * Tm * 9); ly.t_xjs = ttake(3 * Tm * NWmax * 3); ly.t_rest = ttake(3 * Tm);
-    const int chol = (nmax + 1) * (nmax + 2) / 2;
+    ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 27);
+    ly.t_Trot = ttake(3 * Tm * 9); ly.t_xjs = ttake(3 * Tm * NWmax * 4); ly.t_rest = ttake(3 * Tm);
+    ly.t_tjs = ttake((3 * Tm * NWmax + 1) / 2);
+    const int chol = (nmax + 1) * (nmax + 2) / 2 + 2;   // + the trash / zero words of ldl_solve
     ly.big_doubles = std::max(t, chol);
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
@@ -343,6 +336,16 @@ int moshii_model_create(const moshii_model_desc* d, moshii_model_t* out) {
         if ((rc = dev_upload(d->selected_components, (size_t)d->hand_dof * nhf, &m->d_comps))) return rc;
         if ((rc = dev_upload(lo.data(), lo.size(), &m->d_comp_lo))) return rc;
         if ((rc = dev_upload(hi.data(), hi.size(), &m->d_comp_hi))) return rc;
+        std::vector<int> clo(nhf), chi(nhf);
+        for (int c = 0; c < nhf; ++c) {
+            int l = d->hand_dof, h = 0;
+            for (int i = 0; i < d->hand_dof; ++i)
+                if (d->selected_components[(size_t)i * nhf + c] != 0.0) { l = std::min(l, i); h = std::max(h, i + 1); }
+            if (l > h) { l = 0; h = 0; }
+            clo[c] = l; chi[c] = h;
+        }
+        if ((rc = dev_upload(clo.data(), clo.size(), &m->d_col_lo))) return rc;
+        if ((rc = dev_upload(chi.data(), chi.size(), &m->d_col_hi))) return rc;
     }
     HIP_TRY(hipMalloc((void**)&m->d_vsh, V * 3 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&m->d_J, K * 3 * sizeof(double)));
@@ -351,12 +354,9 @@ int moshii_model_create(const moshii_model_desc* d, moshii_model_t* out) {
     return moshii_model_set_betas(m, zero.data(), d->NB);
 }
 
+extern "C" void moshii_lbs32_free(void* l32);   // lbs_forward.hip
 static void free_l32(moshii_model_s* m) {
-    if (m->l32.v_shaped) hipFree(m->l32.v_shaped);
-    if (m->l32.posedirs_t) hipFree(m->l32.posedirs_t);
-    if (m->l32.weights) hipFree(m->l32.weights);
-    if (m->l32.J) hipFree(m->l32.J);
-    m->l32 = Lbs32Model();
+    moshii_lbs32_free(&m->l32);
     m->l32_valid = false;
 }
 
@@ -364,7 +364,7 @@ int moshii_model_destroy(moshii_model_t m) {
     if (!m) return MOSHII_OK;
     hipDeviceSynchronize();
     void* ptrs[] = {m->d_vt, m->d_shapedirs, m->d_posedirs, m->d_weights, m->d_Jreg, m->d_vsh, m->d_J, m->d_hands_mean,
-                    m->d_comps, m->d_parents, m->d_depth, m->d_comp_lo, m->d_comp_hi, m->d_anc};
+                    m->d_comps, m->d_parents, m->d_depth, m->d_comp_lo, m->d_comp_hi, m->d_col_lo, m->d_col_hi, m->d_anc};
     for (void* p : ptrs) if (p) hipFree(p);
     free_l32(m);
     delete m;
@@ -521,14 +521,15 @@ int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, co
     HIP_TRY(hipMalloc((void**)&a->d_vsh, (size_t)a->Nv * 3 * sizeof(double)));
     const size_t npt = (size_t)(m->K - 1) * 27 * a->Nvp;
     HIP_TRY(hipMalloc((void**)&a->d_Pt, std::max<size_t>(npt, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&a->d_Pj, std::max<size_t>((size_t)(m->K - 1) * a->Nvp * 28, 1) * sizeof(double)));
     const int blocks = (int)std::min<size_t>(4096, std::max<size_t>((npt + 255) / 256, (size_t)(a->Nv * 3 + 255) / 256));
     hipLaunchKernelGGL(k_pack_attach, dim3(std::max(blocks, 1)), dim3(256), 0, 0, a->Nv, a->Nvp, m->K, a->d_vids, m->d_posedirs,
-                       m->d_vsh, a->d_Pt, a->d_vsh);
+                       m->d_vsh, a->d_Pt, a->d_Pj, a->d_vsh);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     AttachDev& av = a->host_view;
     av.M = M; av.Nv = a->Nv; av.Nvp = a->Nvp; av.NW = NW;
-    av.vsh = a->d_vsh; av.Pt = a->d_Pt; av.wj = a->d_wj; av.ww = a->d_ww; av.coef = a->d_coef;
+    av.vsh = a->d_vsh; av.Pt = a->d_Pt; av.Pj = a->d_Pj; av.wj = a->d_wj; av.ww = a->d_ww; av.coef = a->d_coef;
     if ((rc = dev_upload(&av, 1, &a->d_self))) return rc;
     *out = a;
     return MOSHII_OK;
@@ -537,7 +538,7 @@ int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, co
 int moshii_attach_destroy(moshii_attach_t a) {
     if (!a) return MOSHII_OK;
     hipDeviceSynchronize();
-    void* ptrs[] = {a->d_vsh, a->d_Pt, a->d_ww, a->d_coef, a->d_wj, a->d_vids, a->d_self};
+    void* ptrs[] = {a->d_vsh, a->d_Pt, a->d_Pj, a->d_ww, a->d_coef, a->d_wj, a->d_vids, a->d_self};
     for (void* q : ptrs) if (q) hipFree(q);
     delete a;
     return MOSHII_OK;
@@ -568,6 +569,7 @@ namespace {
 
 struct LaunchCfg {
     int nblk = 0;
+    int two_per_cu = 0;
     ChainLayout ly;
     size_t lds_bytes = 0;
     OptsDev od;
@@ -608,12 +610,27 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     // room for two workgroups per CU so that one chain's dependency stalls are covered by the other's work.
     int n_cu = 256;
     { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 1) n_cu = 256; }
-    int budget = (n_workgroups <= n_cu) ? 160 * 1024 : 80 * 1024;
+    // One workgroup per CU by default: the 256-register variant (two per CU) spills and was measured slower per chain
+    // by 1.9x for +6 % aggregate throughput (tools/gpu_occupancy.py); MOSHII_TWO_PER_CU=1 selects it for experiments.
+    int two_per_cu = 0;
+    (void)n_workgroups;
+    if (const char* e = getenv("MOSHII_TWO_PER_CU")) two_per_cu = atoi(e) != 0;
+    int budget = two_per_cu ? 80 * 1024 : 160 * 1024;
     if (const char* e = getenv("MOSHII_LDS_BUDGET")) budget = atoi(e);
-    int Tm = std::min(16, std::max(2, Mmax));
-    if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(32, atoi(e)));
-    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk);
-    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk); }
+    // hand joints whose d marker / d fullpose must be parked for the PCA contraction (only when hand coefficients are free)
+    bool hand_free = false;
+    for (int i = 0; i < o->n_step1; ++i) hand_free |= o->step1_ids[i] >= m->body_dof;
+    for (int i = 0; i < o->n_step2; ++i) hand_free |= o->step2_ids[i] >= m->body_dof;
+    const int nhj = hand_free ? (m->K - m->body_dof / 3) : 0;
+    int Tm = std::min(40, std::max(2, Mmax));   // T0 maps tile vertices to threads 0..127: 3 Tm <= 120
+    if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(40, atoi(e)));
+    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj);
+    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj); }
+    if (!getenv("MOSHII_TM") && Tm < Mmax) {   // balance the tiles: same tile count, equal sizes
+        const int ntiles = (Mmax + Tm - 1) / Tm;
+        Tm = (Mmax + ntiles - 1) / ntiles;
+        ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj);
+    }
     const size_t lds_bytes = (size_t)ly.total_doubles * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(MOSHII_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of a CU");
 
@@ -646,13 +663,13 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     memset(&cfg->pd, 0, sizeof(cfg->pd));
     if (prior) cfg->pd = prior->dev();
     cfg->md = m->dev();
-    cfg->nblk = nblk; cfg->ly = ly; cfg->lds_bytes = lds_bytes;
+    cfg->nblk = nblk; cfg->two_per_cu = two_per_cu; cfg->ly = ly; cfg->lds_bytes = lds_bytes;
     return MOSHII_OK;
 }
 
 int launch_chains(const LaunchCfg& cfg, int n, const ChainDev* d_chains, hipStream_t stream) {
-    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly));
-    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + ">";
+    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, cfg.two_per_cu, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly));
+    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + "," + std::to_string(cfg.two_per_cu ? 2 : 1) + ">";
     g_last.lds = (int)cfg.lds_bytes; g_last.threads = MOSHII_TPB;
     return MOSHII_OK;
 }
@@ -820,8 +837,8 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     hipStream_t stream = (hipStream_t)stream_;
     const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
     const int NP = m->NP, P = m->P, S = 2 * NP + 5;
-    const int warmup = co ? std::max(0, co->warmup) : 16;
-    const double tol = (co && co->verify_tol > 0.0) ? co->verify_tol : 1e-6;
+    const int warmup = co ? std::max(0, co->warmup) : 32;
+    const double tol = (co && co->verify_tol > 0.0) ? co->verify_tol : 1e-9;
     int Mmax = 0, Nvmax = 0, NWmax = 1;
     int64_t Ftot = 0;
     for (int q = 0; q < n_seq; ++q) {
@@ -838,7 +855,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     std::vector<Chunk> chunks;
     {
         const int min_len = std::max(4, warmup / 2);
-        const int64_t slots = 2 * (int64_t)n_cu;   // two workgroups per CU (prepare_launch's LDS budget for a full grid)
+        const int64_t slots = n_cu;   // one workgroup per CU (see prepare_launch)
         std::vector<int32_t> st, ls;
         for (int q = 0; q < n_seq; ++q) {
             const int F = seqs[q].F;
@@ -963,6 +980,7 @@ const double* moshii_internal_vsh(moshii_model_t m) { return m->d_vsh; }
 const double* moshii_internal_posedirs(moshii_model_t m) { return m->d_posedirs; }
 const double* moshii_internal_weights(moshii_model_t m) { return m->d_weights; }
 const double* moshii_internal_J(moshii_model_t m) { return m->d_J; }
+const double* moshii_internal_weights_host(moshii_model_t m) { return m->weights_host.data(); }
 void* moshii_internal_l32(moshii_model_t m) { return &m->l32; }
 void moshii_internal_l32_set_valid(moshii_model_t m, int v) { m->l32_valid = v != 0; }
 }

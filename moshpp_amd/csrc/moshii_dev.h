@@ -14,6 +14,8 @@ struct ModelDev {
     const double* comps;             // [hand_dof][nhand_full]
     const int* comp_lo;              // [hand_dof] first non-zero column of each component row
     const int* comp_hi;              // [hand_dof] one past the last non-zero column
+    const int* col_lo;               // [nhand_full] first component with a non-zero entry in this column
+    const int* col_hi;               // [nhand_full] one past the last such component
     const unsigned long long* anc;   // [K] bit j set iff k is j or an ancestor of j
     const int* depth;                // [K]
 };
@@ -21,7 +23,8 @@ struct ModelDev {
 struct AttachDev {
     int M, Nv, Nvp, NW;
     const double* vsh;     // [Nv][3] v_shaped rows of the attached vertices (a = 3*m + s)
-    const double* Pt;      // [(K-1)*27][Nvp] posedirs slice, vertex index fastest
+    const double* Pt;      // [(K-1)*27][Nvp] posedirs slice, vertex index fastest (forward pass: coalesced rows)
+    const double* Pj;      // [(K-1)][Nvp][28] the same slice, one 224-byte record per (joint, vertex) (Jacobian pass)
     const int* wj;         // [Nv][NW] joints with non-zero skinning weight (padded: joint 0, weight 0)
     const double* ww;      // [Nv][NW]
     const double* coef;    // [M][3]
@@ -70,7 +73,7 @@ struct ChainDev {
 
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).
 struct ChainLayout {
-    int Mmax, Nvmax, NWmax, nmax, Tm, nkfmax, LDJ;
+    int Mmax, Nvmax, NWmax, nmax, Tm, nkfmax, LDJ, nhj;
     int o_pose, o_trans, o_pose_t, o_trans_t, o_pose_prev, o_vtarget, o_fullpose;
     int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol;
     int o_vposed, o_vpos, o_msim, o_res;
@@ -83,7 +86,29 @@ struct ChainLayout {
     int big_doubles;
     int total_doubles;
     // int region sub-offsets (in ints)
-    int i_visidx, i_colpid, i_colprior, i_pid2prior, i_jointslot, i_kfree, i_total;
+    int i_visidx, i_colpid, i_colprior, i_pid2prior, i_jointslot, i_kfree, i_colq, i_total;
     // tile sub-offsets inside big (in doubles)
-    int t_Jv, t_Jrow, t_Lm, t_Trot, t_xjs, t_rest;
+    int t_Jh, t_Jrow, t_Lm, t_Trot, t_xjs, t_rest, t_tjs;
+};
+
+// single-precision / half-precision copies of the model for the full-mesh export kernels (lbs_forward.hip)
+struct Lbs32Model {
+    // plain f32 copy (fallback kernel)
+    float* v_shaped;       // [V][3]
+    float* posedirs_t;     // [9(K-1)][3][Vp64]  vertex fastest
+    float* weights;        // [K][Vp64]
+    float* J;              // [K][3]
+    int Vp;                // V padded to 64
+    // MFMA path
+    _Float16* Pfrag;       // [Vp128/32][3][KS][64 lanes][8]  posedirs * pscale, fragment-major
+    float* vsh_pad;        // [Vp128][3]
+    int2* sjw;             // [Vp128][NW]  skinning influences per vertex: {byte offset of the joint's transform block, weight bits}
+    int K, NW;
+    float inv_pscale;
+    int Vp128, KP, KS;
+    int mfma_ok;
+    // per-call scratch
+    float* Atr;            // [K][Fcap][12]
+    _Float16* featT;       // [Fcap][KP]
+    int Fcap;
 };

@@ -1,0 +1,32 @@
+"""Time the full-mesh LBS export kernels alone (for rocprofv3): python tools/lbs_bench.py [F] [reps] [model]"""
+import ctypes as C, sys, time
+import numpy as np
+sys.path.insert(0, '.')
+import torch
+from moshpp_amd import capi, workload
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+mt = sys.argv[3] if len(sys.argv) > 3 else 'smplh'
+M = {'smplh': 53, 'smpl': 41, 'smplx': 89, 'mano': 33}[mt]
+job = workload.make_job(mt, 8, M, seed=1000, optimize_fingers=(mt == 'mano'))
+solver = workload.make_solver(job)
+sm = job['sm']
+dev = torch.device('cuda', 0)
+rng = np.random.default_rng(0)
+pose = torch.from_numpy(rng.normal(0, 0.3, (F, sm.NP)).astype(np.float32)).to(dev)
+trans = torch.from_numpy(rng.normal(0, 1, (F, 3)).astype(np.float32)).to(dev)
+verts = torch.empty((F, sm.V, 3), dtype=torch.float32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+run = lambda: solver.dev.lbs_forward_device(F, pose.data_ptr(), trans.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    run()
+e1.record()
+torch.cuda.synchronize()
+t = e0.elapsed_time(e1) * 1e-3 / reps
+out_bytes = F * sm.V * 12
+print(f'{mt} F={F}: {t*1e6:.1f} us per call, output {out_bytes/1e6:.1f} MB -> {out_bytes/t/1e9:.0f} GB/s ({out_bytes/t/8e12*100:.1f}% of 8 TB/s), {F/t:.0f} frames/s')

@@ -30,4 +30,5 @@ for k, nm in names.items():
     acc += p[k]
     print(f'  {nm:34s} {p[k]/tot*100:6.2f}%  {p[k]*us_per_tick/F:8.1f} us/frame')
 print(f'  {"other (dogleg control, copies)":34s} {(tot-acc)/tot*100:6.2f}%  {(tot-acc)*us_per_tick/F:8.1f} us/frame')
+print(f'shader clock during the kernel: {p[12] / (p[30] / 100e6) / 1e6:.0f} MHz (s_memtime ticks / s_memrealtime @100 MHz)')
 print('iters/frame', out['iters'][:,0].mean(), 'status', np.unique(out['status'], return_counts=True))
