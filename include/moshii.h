@@ -190,7 +190,7 @@ typedef struct moshii_sequence_desc {
 typedef struct moshii_chunk_opts {
     int32_t num_chunks;             /* chunks per sequence; 0 = fill the GPU (1 workgroup per CU)   */
     int32_t warmup;                 /* warm-up frames per chunk (NULL opts: 32)                     */
-    double  verify_tol;             /* hand-off tolerance on pose [rad] / trans [m] (<= 0: 1e-9)    */
+    double  verify_tol;             /* hand-off tolerance on pose [rad] / trans [m] (<= 0: 1e-11)   */
 } moshii_chunk_opts;
 
 typedef struct moshii_chunk_report {

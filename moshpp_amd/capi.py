@@ -327,7 +327,7 @@ def plan_chunks(F, num_chunks, warmup, cap=1 << 20):
     return starts[:c].copy(), launch[:c].copy()
 
 
-def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, warmup=32, verify_tol=1e-9):
+def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, warmup=32, verify_tol=1e-11):
     """moshii_sequence_solve on host buffers.  seqs: list of dict(attach, obs[F,M,3], vis[F,M]).
     Returns (list of per-sequence output dicts as chain_solve_host, report dict)."""
     lib = load()

@@ -101,7 +101,7 @@ class StageIISolver:
                                    maxiter=maxiter, num_train_markers=NUM_TRAIN_MARKERS)
         self.optimize_fingers = bool(optimize_fingers)
 
-    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-9):
+    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11):
         """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
         chain_mode 'sequential': one chain, the reference's exact frame order (chmosh.py:584).
         chain_mode 'chunked': moshii_sequence_solve -- concurrent chunks with warm-up overlap, verified and
@@ -180,7 +180,7 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     # 5. the frame loop (:584-724) on the GPU
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', 'sequential'),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
-                       verify_tol=float(_get(ext, 'verify_tol', 1e-9)))
+                       verify_tol=float(_get(ext, 'verify_tol', 1e-11)))
     for fi in np.flatnonzero(out['status'] == 1):
         logger.error(f'no available observed markers for frame {selected_frames[fi]}. skipping the frame.')
     if np.any(out['status'] < 0):

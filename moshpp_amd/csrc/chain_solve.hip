@@ -31,12 +31,12 @@ enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 =
 struct Ctx {
     double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
     double *feat, *B, *omega, *Rw, *tw, *Rloc, *acol;
-    double *vposed, *vpos, *msim, *res;
+    double *vposed, *vpos, *msim, *res, *vconst;
     double *xb, *ell, *score;
     double *g, *dsd, *dgn, *ddl, *y;
     double *red, *scal;
     unsigned long long* anc;
-    int *visidx, *colpid, *colprior, *pid2prior, *jointslot, *kfree, *colq;
+    int *visidx, *colpid, *colprior, *pid2prior, *jointslot, *kfree, *colq, *ksum, *kconst;
     double *big, *Jh, *Jrow, *Lm, *Trot, *xjs, *rest;
     int* tjs;
 };
@@ -193,34 +193,70 @@ __device__ __forceinline__ void marker_eval(const double* c, const double* v0, c
         }
 }
 
+// fullpose[d] = pose[d] for the leading body dofs, hands_mean + pose_hand . selected_components beyond
+// (smpl_fast_derivatives.py:194-204); the two-accumulator order is part of the kernel's numerics
+__device__ __forceinline__ double fullpose_entry(const ModelDev& md, const double* pose, int d) {
+    const int bd = md.body_dof, nhf = md.nhand_full;
+    if (d < bd) return pose[d];
+    const int h = d - bd;
+    const int lo = md.col_lo[h], hi = md.col_hi[h];   // components with a non-zero entry in column h
+    double v0 = md.hands_mean[h], v1 = 0.0;
+    int i = lo;
+    for (; i + 2 <= hi; i += 2) {
+        v0 += pose[bd + i] * md.comps[i * nhf + h];
+        v1 += pose[bd + i + 1] * md.comps[(i + 1) * nhf + h];
+    }
+    if (i < hi) v0 += pose[bd + i] * md.comps[i * nhf + h];
+    return v0 + v1;
+}
+
+// dst[a][i] = base[a][i] + sum_{k in klist} posedirs[a][i][9(k-1) .. 9k) . (R_k - I)   (cx.feat holds R - I of every joint).
+// item = (coordinate i, vertex pair): every lane streams 16-byte pairs of the vertex-fastest posedirs slice (fully
+// coalesced rows of Nvp doubles).  Only the joints that are FREE in the running solve change between evaluations, so the
+// chain keeps the other joints' contribution in cx.vconst and each evaluation streams |klist| / (K-1) of the slice.
+__device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev& at, const int* klist, int nk,
+                                                 const double* base, double* dst) {
+    const int tid = threadIdx.x;
+    const int Nv = at.Nv, Nvp = at.Nvp, Nvh = Nvp >> 1;
+    for (int it = tid; it < 3 * Nvh; it += MOSHII_TPB) {
+        const int i = it / Nvh, a2 = it - i * Nvh;
+        double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0, s2x = 0.0, s2y = 0.0;
+        const double2* pp = reinterpret_cast<const double2*>(at.Pt) + (size_t)(i * 9) * Nvh + a2;
+#pragma unroll 3
+        for (int idx = 0; idx < nk; ++idx) {
+            const int k = klist[idx];
+            const double* f = &cx.feat[k * 9];
+            const double2* pk = pp + (size_t)((k - 1) * 27) * Nvh;
+            double2 q[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) q[e] = pk[(size_t)e * Nvh];
+#pragma unroll
+            for (int e = 0; e < 9; e += 3) {
+                s0x += q[e].x * f[e]; s0y += q[e].y * f[e];
+                s1x += q[e + 1].x * f[e + 1]; s1y += q[e + 1].y * f[e + 1];
+                s2x += q[e + 2].x * f[e + 2]; s2y += q[e + 2].y * f[e + 2];
+            }
+        }
+        const int a = 2 * a2;
+        if (a < Nv) dst[a * 3 + i] = base[a * 3 + i] + ((s0x + s1x) + s2x);
+        if (a + 1 < Nv) dst[(a + 1) * 3 + i] = base[(a + 1) * 3 + i] + ((s0y + s1y) + s2y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward evaluation of every residual block at (pose, trans): leaves joint transforms, posed
 // attached vertices, simulated markers, weighted data residuals and the prior's l-vectors in LDS.
 // ------------------------------------------------------------------------------------------------
+// klist/nk: the joints whose pose-corrective contribution is summed here; vbase = rest vertices + the contribution of
+// every other joint (cx.vconst, see posedirs_partial) -- or klist = all joints and vbase = v_shaped.
 __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                             const OptsDev& op, const double* pose, const double* trans, const FrameParams& fp,
-                            const uint8_t* visrow) {
+                            const uint8_t* visrow, const int* klist, int nk, const double* vbase) {
     const int tid = threadIdx.x;
     const int K = md.K, P = md.P, bd = md.body_dof, hd = md.hand_dof, nhf = md.nhand_full;
     PROF_BEGIN(); PROF_COUNT(20);
     // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
-    for (int d = tid; d < P; d += MOSHII_TPB) {
-        double v;
-        if (d < bd) v = pose[d];
-        else {
-            const int h = d - bd;
-            const int lo = md.col_lo[h], hi = md.col_hi[h];   // components with a non-zero entry in column h
-            double v0 = md.hands_mean[h], v1 = 0.0;
-            int i = lo;
-            for (; i + 2 <= hi; i += 2) {
-                v0 += pose[bd + i] * md.comps[i * nhf + h];
-                v1 += pose[bd + i + 1] * md.comps[(i + 1) * nhf + h];
-            }
-            if (i < hi) v0 += pose[bd + i] * md.comps[i * nhf + h];
-            v = v0 + v1;
-        }
-        cx.fullpose[d] = v;
-    }
+    for (int d = tid; d < P; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, pose, d);
     __syncthreads();
     // F2: per joint rotation and pose feature R - I  (the Jacobian-only quantities are built in assemble())
     if (tid < K) {
@@ -266,35 +302,12 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             }
         }
     }
-    // F4: v_posed = v_shaped + posedirs . vec(R - I) for the attached vertices.  item = (coordinate i, vertex pair):
-    // every lane streams 16-byte pairs of the vertex-fastest posedirs slice (fully coalesced rows of Nvp doubles).
-    const int Nv = at.Nv, Nvp = at.Nvp, Nvh = Nvp >> 1;
-    for (int it = tid; it < 3 * Nvh; it += MOSHII_TPB) {
-        const int i = it / Nvh, a2 = it - i * Nvh;
-        double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0, s2x = 0.0, s2y = 0.0;
-        const double2* pp = reinterpret_cast<const double2*>(at.Pt) + (size_t)(i * 9) * Nvh + a2;
-#pragma unroll 3
-        for (int k = 1; k < K; ++k) {
-            const double* f = &cx.feat[k * 9];
-            const double2* pk = pp + (size_t)((k - 1) * 27) * Nvh;
-            double2 q[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) q[e] = pk[(size_t)e * Nvh];
-#pragma unroll
-            for (int e = 0; e < 9; e += 3) {
-                s0x += q[e].x * f[e]; s0y += q[e].y * f[e];
-                s1x += q[e + 1].x * f[e + 1]; s1y += q[e + 1].y * f[e + 1];
-                s2x += q[e + 2].x * f[e + 2]; s2y += q[e + 2].y * f[e + 2];
-            }
-        }
-        const int a = 2 * a2;
-        if (a < Nv) cx.vposed[a * 3 + i] = at.vsh[a * 3 + i] + ((s0x + s1x) + s2x);
-        if (a + 1 < Nv) cx.vposed[(a + 1) * 3 + i] = at.vsh[(a + 1) * 3 + i] + ((s0y + s1y) + s2y);
-    }
+    // F4: v_posed = vbase + sum_{k in klist} posedirs_k . vec(R_k - I) for the attached vertices.
+    posedirs_partial(cx, at, klist, nk, vbase, cx.vposed);
     __syncthreads();
     PROF_LAP(1);
     // F5: skinning  v = sum_j w_j (Rw_j (v_posed - J_j) + tw_j) + trans
-    const int NW = at.NW;
+    const int NW = at.NW, Nv = at.Nv;
     for (int a = tid; a < Nv; a += MOSHII_TPB) {
         const double px = cx.vposed[a * 3 + 0], py = cx.vposed[a * 3 + 1], pz = cx.vposed[a * 3 + 2];
         double ax = 0.0, ay = 0.0, az = 0.0;
@@ -342,24 +355,36 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         __syncthreads();
         const int G = pr.G;
         // one wavefront per mixture component; lane a accumulates column a (and a + 64) of L_g while b runs uniformly over
-        // the rows, so that every load is one contiguous run of row b -- and |l_g|^2 falls out of a wave reduction.
+        // the rows, so that every load is one contiguous run of row b -- eight rows in flight per lane -- and |l_g|^2 falls
+        // out of a wave reduction.  x - mu_g is parked in this component's slice of cx.ell first (the wavefront's LDS
+        // operations complete in order, so its own later overwrite with l_g is safe).
         {
             const int lane = tid & 63;
+            const int c0 = min(lane, np_ - 1), c1 = min(lane + 64, np_ - 1);   // clamped: every load is in bounds, no branch
             for (int gc = tid >> 6; gc < G; gc += MOSHII_TPB / 64) {
                 const double* Lg = pr.chols + (size_t)gc * np_ * np_;
                 const double* mu = pr.means + (size_t)gc * np_;
+                double* dxg = &cx.ell[gc * np_];
+                for (int b = lane; b < np_; b += 64) dxg[b] = cx.xb[b] - mu[b];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 double s0 = 0.0, s1 = 0.0;
-                const int c0 = min(lane, np_ - 1), c1 = min(lane + 64, np_ - 1);   // clamped: every load is in bounds, no branch
-                const bool two = np_ > 64;
-#pragma unroll 8
-                for (int b = 0; b < np_; ++b) {
-                    const double dx = cx.xb[b] - mu[b];
-                    const double* row = Lg + (size_t)b * np_;
-                    const double v0 = row[c0];
-                    s0 += (lane <= b) ? dx * v0 : 0.0;                // lower triangle: rows b >= column
-                    if (two) { const double v1 = row[c1]; s1 += (lane + 64 <= b) ? dx * v1 : 0.0; }   // uniform branch
+                for (int b0 = 0; b0 < np_; b0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = Lg[(size_t)min(b0 + k, np_ - 1) * np_ + c0];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int b = b0 + k;
+                        const double dx = dxg[min(b, np_ - 1)];
+                        s0 += (b < np_ && lane <= b) ? dx * v[k] : 0.0;   // lower triangle: rows b >= column
+                    }
                 }
+                if (np_ > 64)   // columns 64.. (SMPL's 69-dof prior): rows b >= 64 only
+                    for (int b = 64; b < np_; ++b) { const double v1 = Lg[(size_t)b * np_ + c1]; s1 += (lane + 64 <= b) ? dxg[b] * v1 : 0.0; }
                 s0 *= 0.70710678118654757; s1 *= 0.70710678118654757;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 if (lane < np_) cx.ell[gc * np_ + lane] = s0;
                 if (lane + 64 < np_) cx.ell[gc * np_ + lane + 64] = s1;
                 const double sq = wave_sum(s0 * s0 + s1 * s1);
@@ -441,19 +466,28 @@ struct AReg {
                 ++e;
             }
     }
-    // sum_{q1,q2} A[q1][q2] x[q1] x[q2] over the full symmetric matrix (block partial; reduce outside)
+    // sum_{q1,q2} A[q1][q2] x[q1] x[q2] over the full symmetric matrix (block partial; reduce outside).  Branch-free: the
+    // 2 NBLK vector entries are fetched up front (zero beyond n), off-diagonal blocks count twice, diagonal blocks by ty/tx.
     __device__ __forceinline__ double quad_partial(const double* x, int n) const {
         const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        double xr[NBLK], xc[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int q1 = b * 16 + ty, q2 = b * 16 + tx;
+            const double v1 = x[min(q1, n - 1)], v2 = x[min(q2, n - 1)];
+            xr[b] = (q1 < n) ? v1 : 0.0;
+            xc[b] = (q2 < n) ? v2 : 0.0;
+        }
+        const double cd = (tx < ty) ? 2.0 : ((tx == ty) ? 1.0 : 0.0);
         double s = 0.0;
         int e = 0;
 #pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi)
+        for (int bi = 0; bi < NBLK; ++bi) {
+            double r = 0.0;
 #pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) {
-                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
-                if (q1 < n && q2 <= q1) s += ((q1 == q2) ? 1.0 : 2.0) * a[e] * x[q1] * x[q2];
-                ++e;
-            }
+            for (int bj = 0; bj <= bi; ++bj) { r += ((bj == bi) ? cd : 2.0) * a[e] * xc[bj]; ++e; }
+            s += xr[bi] * r;
+        }
         return s;
     }
     // packed lower triangle: idx(i,j) = i(i+1)/2 + j; row n holds the right-hand side (bordered form)
@@ -504,56 +538,58 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
                 ++e;
             }
     }
-    // packed-row offsets of this thread's rows / columns (keeps integer multiplies out of the column loop)
-    int roff[NBLK], coff[NBLK];
+    // Per-thread LDS addresses, resolved once: rows beyond the border row n (and columns beyond n-1) point at the spare
+    // words, so the column loop needs one comparison per access.  Stores that do not apply go to `trash`, loads that do
+    // not apply read `zero` (= 0.0): the loop is straight-line LDS traffic with a single barrier per column.
+    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
+    int rS[NBLK], rL[NBLK], cL[NBLK];   // packed offset of row q1 (store / load view) and of row q2 = this thread's column
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int q1 = b * 16 + ty, q2 = b * 16 + tx;
-        roff[b] = q1 * (q1 + 1) / 2;
-        coff[b] = q2 * (q2 + 1) / 2;
+        rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
+        rL[b] = rS[b];
+        cL[b] = (q2 <= n) ? q2 * (q2 + 1) / 2 : -1;
     }
-    // The column loop is branch-free: a memory operation that does not apply to this lane is redirected to a spare
-    // word (stores -> `trash`, loads -> `zero`, which holds 0.0) instead of being skipped, so the compiler emits
-    // straight-line LDS traffic with a single wait instead of one exec-masked branch + wait per access.
-    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
     if (tid == 0) Lp[zero] = 0.0;
     bool ok = true;
     int jj = 0;   // packed index of the pivot (j, j)
-    for (int j = 0; j < n; ++j) {
-        const int bj0 = j >> 4;
-        const bool owner = tx == (j & 15);
+    // outer loop over 16-column blocks is unrolled, so every register index below is a compile-time constant
 #pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi) {   // publish column j (rows j..n): entry (bi, bj0) of this thread
-            double v = 0.0;
+    for (int bj0 = 0; bj0 < NBLK; ++bj0) {
+        if (!ok) break;
+        for (int jl = 0; jl < 16; ++jl) {
+            const int j = bj0 * 16 + jl;
+            if (j >= n) break;
+            const bool owner = tx == jl;
 #pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) v = (bj == bj0) ? w[bi * (bi + 1) / 2 + bj] : v;
-            const int q1 = bi * 16 + ty;
-            const bool valid = owner && bi >= bj0 && q1 >= j && q1 <= n;
-            Lp[valid ? roff[bi] + j : trash] = v;
+            for (int bi = bj0; bi < NBLK; ++bi) {   // publish column j (rows j..n): entry (bi, bj0) of this thread
+                const int q1 = bi * 16 + ty;
+                const bool valid = owner && q1 >= j && rS[bi] >= 0;
+                Lp[valid ? rS[bi] + j : trash] = w[bi * (bi + 1) / 2 + bj0];
+            }
+            __syncthreads();
+            const double pj = Lp[jj];
+            double ci[NBLK], ck[NBLK];
+#pragma unroll
+            for (int b = bj0; b < NBLK; ++b) {
+                const int q1 = b * 16 + ty, q2 = b * 16 + tx;
+                ci[b] = Lp[(q1 > j && rL[b] >= 0) ? rL[b] + j : zero];
+                ck[b] = Lp[(q2 > j && cL[b] >= 0) ? cL[b] + j : zero];
+            }
+            jj += j + 2;
+            if (!(pj > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS word
+            // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
+            double pin = __builtin_amdgcn_rcp(pj);
+            pin = fma(fma(-pj, pin, 1.0), pin, pin);
+            pin = fma(fma(-pj, pin, 1.0), pin, pin);
+            if (tid == 0) pinv[j] = pin;
+#pragma unroll
+            for (int b = bj0; b < NBLK; ++b) ck[b] *= pin;
+#pragma unroll
+            for (int bi = bj0; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = bj0; bj <= bi; ++bj) w[bi * (bi + 1) / 2 + bj] -= ci[bi] * ck[bj];
         }
-        __syncthreads();
-        const double pj = Lp[jj];
-        double ci[NBLK], ck[NBLK];
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            const int q1 = b * 16 + ty, q2 = b * 16 + tx;
-            ci[b] = Lp[(q1 > j && q1 <= n) ? roff[b] + j : zero];
-            ck[b] = Lp[(q2 > j && q2 <= n) ? coff[b] + j : zero];
-        }
-        jj += j + 2;
-        if (!(pj > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS word
-        // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
-        double pin = __builtin_amdgcn_rcp(pj);
-        pin = fma(fma(-pj, pin, 1.0), pin, pin);
-        pin = fma(fma(-pj, pin, 1.0), pin, pin);
-        if (tid == 0) pinv[j] = pin;
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) ck[b] *= pin;
-        int e = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi)
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) { w[e] -= ci[bi] * ck[bj]; ++e; }
     }
     __syncthreads();
     PROF_LAP(9);
@@ -919,11 +955,14 @@ __device__ __noinline__ void rigid_init_serial(const Ctx& cx, const FrameParams&
 template <int NBLK>
 __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                          const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, double e3,
-                         bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int& n_iter, int& n_fev, int& fail) {
+                         bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int set_id, int& vc_key,
+                         int& tab_key, int& n_iter, int& n_fev, int& fail) {
     const int tid = threadIdx.x;
     const int n = 3 + nids;
-    int nkf = 0, nfree_hand = 0;
-    if (!eval_only) {   // column tables + needed-joint list
+    // column tables + needed-joint lists of this free set; they stay in LDS until a solve with another set replaces them
+    // (body-only Stage-II uses one set throughout: built once per chain)
+    if (!eval_only && tab_key != set_id) {
+        tab_key = set_id;
         for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.colq[i] = -1;
         __syncthreads();
         for (int q = tid; q < n; q += MOSHII_TPB) {
@@ -945,10 +984,32 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             int nh = 0;   // ids are sorted, so the hand-PCA coefficients (pid >= body_dof) are the trailing columns
             for (int i = 0; i < nids; ++i) nh += (ids[i] >= md.body_dof) ? 1 : 0;
             cx.scal[S_TMP2] = (double)nh;
+            // joints whose rotation moves during this solve (their pose correctives are re-summed at every evaluation)
+            // and the rest (summed once into cx.vconst); the root has no correctives
+            int ns = 0, nc = 0;
+            for (int k = 1; k < md.K; ++k) { if (cx.jointslot[k] >= 0) cx.ksum[ns++] = k; else cx.kconst[nc++] = k; }
+            cx.scal[S_TMP3] = (double)ns;
         }
         __syncthreads();
-        nkf = (int)cx.scal[S_TMP0];
-        nfree_hand = (int)cx.scal[S_TMP2];
+    }
+    const int nkf = (int)cx.scal[S_TMP0], nfree_hand = (int)cx.scal[S_TMP2];
+    const int nks = (int)cx.scal[S_TMP3];   // (eval-only phases reuse the lists of the solve that preceded them)
+    const int nkc = md.K - 1 - nks;
+    if (vc_key != set_id) {
+        // cx.vconst = v_shaped + correctives of the joints that stay fixed in this solve, at the current pose.  It stays
+        // valid until a solve with a different free set runs (body-only Stage-II: computed once per chain).
+        for (int d = tid; d < md.P; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, cx.pose, d);
+        __syncthreads();
+        if (tid < md.K) {
+            double R[9];
+            rodrigues_R(&cx.fullpose[3 * tid], R);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) cx.feat[tid * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        posedirs_partial(cx, at, cx.kconst, nkc, at.vsh, cx.vconst);
+        __syncthreads();
+        vc_key = set_id;
     }
     AReg<NBLK> A;
     A.zero();
@@ -964,7 +1025,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     bool skip_eval = reuse && !rigid;
     while (true) {
         if (skip_eval) { last = carried; skip_eval = false; }
-        else last = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow);
+        else last = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow, cx.ksum, nks, cx.vconst);
         at_pose = true;   // cleared below when a trial point is rejected
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
@@ -1096,7 +1157,7 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     cx.pose_prev = lds + ly.o_pose_prev; cx.vtarget = lds + ly.o_vtarget; cx.fullpose = lds + ly.o_fullpose;
     cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
     cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
-    cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
+    cx.vconst = lds + ly.o_vconst; cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
     cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
     cx.g = lds + ly.o_g; cx.dsd = lds + ly.o_dsd; cx.dgn = lds + ly.o_dgn; cx.ddl = lds + ly.o_ddl; cx.y = lds + ly.o_y;
     cx.red = lds + ly.o_red; cx.scal = lds + ly.o_scal;
@@ -1104,7 +1165,7 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     int* ints = reinterpret_cast<int*>(lds + ly.o_ints);
     cx.visidx = ints + ly.i_visidx; cx.colpid = ints + ly.i_colpid; cx.colprior = ints + ly.i_colprior;
     cx.pid2prior = ints + ly.i_pid2prior; cx.jointslot = ints + ly.i_jointslot; cx.kfree = ints + ly.i_kfree;
-    cx.colq = ints + ly.i_colq;
+    cx.colq = ints + ly.i_colq; cx.ksum = ints + ly.i_ksum; cx.kconst = ints + ly.i_kconst;
     cx.big = lds + ly.o_big;
     cx.Jh = cx.big + ly.t_Jh; cx.Jrow = cx.big + ly.t_Jrow; cx.Lm = cx.big + ly.t_Lm; cx.Trot = cx.big + ly.t_Trot;
     cx.xjs = cx.big + ly.t_xjs; cx.rest = cx.big + ly.t_rest;
@@ -1146,6 +1207,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     __syncthreads();
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
+    int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)
     PROF_BEGIN();
 #ifdef MOSHII_PROFILE
     const long long _wall0 = wall_clock64();
@@ -1203,6 +1265,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         //         step 2 (:676-705), record (:712-724)
         Sse fin, carried;
         bool at_pose = false;
+        const bool same_sets = op.same_sets != 0;
         double prev_wt_pose = -1.0;
         int prev_fingers = -1;
         for (int kind = first ? 0 : 3; kind < 6; ++kind) {
@@ -1213,7 +1276,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_fingers == fp.use_fingers;
             fin = run_phase<NBLK>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
                                   round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose,
-                                  n_iter, n_fev, fail);
+                                  /*set_id=*/(kind >= 4 && !same_sets) ? 2 : 1, vc_key, tab_key, n_iter, n_fev, fail);
             prev_wt_pose = fp.wt_pose; prev_fingers = fp.use_fingers;
         }
         first = false;
@@ -1268,7 +1331,9 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restr
     OptsDev op;
     op.nbody = 0; op.nfinger = 0; op.n1 = 0; op.n2 = 0; op.maxiter = 0;
     op.step1 = nullptr; op.step2 = nullptr; op.body = nullptr; op.finger = nullptr;
-    eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr);
+    for (int k = 1 + tid; k < md.K; k += MOSHII_TPB) cx.ksum[k - 1] = k;   // every joint's correctives, on top of v_shaped
+    __syncthreads();
+    eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh);
     for (int i = tid; i < 3 * at.M; i += MOSHII_TPB) out[(size_t)f * 3 * at.M + i] = cx.msim[i];
 }
 

@@ -41,7 +41,7 @@ struct PriorDev {
 struct OptsDev {
     double wt_data, wt_velo, wt_poseB, wt_poseH, wt_annealing, num_train_markers;
     double e3_first, e3, delta0;
-    int maxiter, n1, n2, nbody, nfinger;
+    int maxiter, n1, n2, nbody, nfinger, same_sets;
     const int* step1;
     const int* step2;
     const int* body;
@@ -76,7 +76,7 @@ struct ChainLayout {
     int Mmax, Nvmax, NWmax, nmax, Tm, nkfmax, LDJ, nhj;
     int o_pose, o_trans, o_pose_t, o_trans_t, o_pose_prev, o_vtarget, o_fullpose;
     int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol;
-    int o_vposed, o_vpos, o_msim, o_res;
+    int o_vposed, o_vpos, o_msim, o_res, o_vconst;
     int o_xb, o_ell, o_score;
     int o_g, o_dsd, o_dgn, o_ddl, o_y;
     int o_red, o_scal;
@@ -86,7 +86,7 @@ struct ChainLayout {
     int big_doubles;
     int total_doubles;
     // int region sub-offsets (in ints)
-    int i_visidx, i_colpid, i_colprior, i_pid2prior, i_jointslot, i_kfree, i_colq, i_total;
+    int i_visidx, i_colpid, i_colprior, i_pid2prior, i_jointslot, i_kfree, i_colq, i_ksum, i_kconst, i_total;
     // tile sub-offsets inside big (in doubles)
     int t_Jh, t_Jrow, t_Lm, t_Trot, t_xjs, t_rest, t_tjs;
 };

@@ -82,7 +82,7 @@ class DeviceSequence:
         mh, ph, opts = self._handles()
         capi.check(capi.load().moshii_chain_solve(mh, ph, C.byref(opts), 1, self.cdesc, capi.BUFFERS_DEVICE, C.c_void_p(stream)))
 
-    def solve_chunked(self, stream, num_chunks=0, warmup=32, verify_tol=1e-9):
+    def solve_chunked(self, stream, num_chunks=0, warmup=32, verify_tol=1e-11):
         import ctypes as C
         from . import capi
         mh, ph, opts = self._handles()

@@ -286,3 +286,24 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     # linearity in trans (size-independent property): shifting trans shifts every vertex by the same amount
     got2 = dev['model'].lbs_forward(pose, trans + 0.25, dtype=np.float32)
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
+
+
+def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib):
+    """Short warm-up + tight tolerance makes most hand-offs fail, in runs: chunks repaired early must be repaired AGAIN
+    when their predecessor is re-solved in a later round (regression: a chunk once repaired used to be trusted for good,
+    leaving it stitched to a stale predecessor state).  The stitched result must agree with the sequential chain on
+    every frame to well below the north-star tolerance."""
+    from moshpp_amd import capi
+    F = 480
+    case = oracle_case('smplh', F=F, M=53, seed=71)
+    dev = device_case(case)
+    seq = _sequential(dev, case)
+    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                         [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                         num_chunks=40, warmup=6, verify_tol=1e-12)
+    print('chunk report', rep)
+    assert rep['n_repaired'] >= 10 and rep['repair_rounds'] >= 2
+    solved = seq['status'] == 0
+    dp = np.abs(outs[0]['fullpose'] - seq['fullpose'])[solved].max(1)
+    print(f'max dev {dp.max():.2e}, frames > 1e-9: {(dp > 1e-9).sum()}')
+    assert dp.max() < 1e-7
