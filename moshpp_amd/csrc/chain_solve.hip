@@ -1208,6 +1208,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
     int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)
+    int rejoin_run = 0;            // consecutive frames that reproduced the stored trajectory (repair chains)
     PROF_BEGIN();
 #ifdef MOSHII_PROFILE
     const long long _wall0 = wall_clock64();
@@ -1280,6 +1281,15 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             prev_wt_pose = fp.wt_pose; prev_fingers = fp.use_fingers;
         }
         first = false;
+        if (record && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
+            // repair chains: has this chain re-joined the trajectory already stored for this chunk?
+            double dv = 0.0;
+            const double* po = chp->pose + (size_t)t * NP;
+            for (int i = tid; i < NP; i += MOSHII_TPB) dv = fmax(dv, fabs(cx.pose[i] - po[i]));
+            if (tid < 3) dv = fmax(dv, fabs(cx.trans[tid] - chp->trans[t * 3 + tid]));
+            dv = block_max(dv, cx.red);
+            rejoin_run = (dv <= chp->rejoin_tol) ? rejoin_run + 1 : 0;   // (NaN compares false)
+        }
         if (record) {   // record
             double* o;
             if ((o = chp->pose) != nullptr) for (int i = tid; i < NP; i += MOSHII_TPB) o[(size_t)t * NP + i] = cx.pose[i];
@@ -1294,6 +1304,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
         }
         __syncthreads();
+        if (rejoin_run >= 2 && t + 1 < F) break;   // pose and pose_prev both match: the stored rows (and final state) stand
     }
     PROF_LAP(12);
 #ifdef MOSHII_PROFILE

@@ -840,6 +840,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     const int NP = m->NP, P = m->P, S = 2 * NP + 5;
     const int warmup = co ? std::max(0, co->warmup) : 32;
     const double tol = (co && co->verify_tol > 0.0) ? co->verify_tol : 1e-11;
+    const bool rejoin = getenv("MOSHII_NO_REJOIN") == nullptr;   // repair chains stop where they re-join the stored trajectory
     int Mmax = 0, Nvmax = 0, NWmax = 1;
     int64_t Ftot = 0;
     for (int q = 0; q < n_seq; ++q) {
@@ -925,7 +926,10 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         // predecessor's end state it was started from, so if that predecessor is itself re-solved later the
         // mismatch shows up in the next verification and this chunk is repaired again
         cd.entry_state = d_entry + (size_t)idx * S;
-        if (repair) cd.init_state = d_final + (size_t)ck.pred * S;
+        if (repair) {
+            cd.init_state = d_final + (size_t)ck.pred * S;
+            cd.rejoin_tol = rejoin ? tol : 0.0;
+        }
         return cd;
     };
     std::vector<ChainDev> cds(NC);

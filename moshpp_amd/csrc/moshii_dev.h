@@ -69,6 +69,8 @@ struct ChainDev {
     const double* init_state;   // device; overrides init_pose/init_trans/init_prev/first when non-null
     double* entry_state;        // device or null: state on entering frame `skip`
     double* final_state;        // device or null: state after the last frame
+    double rejoin_tol;          // > 0 (repair chains): stop once two consecutive solved frames reproduce the rows already in
+                                // `pose`/`trans` to this tolerance -- the rest of the chunk is then the continuation within tol
 };
 
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).
