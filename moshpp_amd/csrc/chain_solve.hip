@@ -369,12 +369,12 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 double s0 = 0.0, s1 = 0.0;
-                for (int b0 = 0; b0 < np_; b0 += 8) {
-                    double v[8];
+                for (int b0 = 0; b0 < np_; b0 += 16) {   // 16 coalesced row loads in flight per lane
+                    double v[16];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = Lg[(size_t)min(b0 + k, np_ - 1) * np_ + c0];
+                    for (int k = 0; k < 16; ++k) v[k] = Lg[(size_t)min(b0 + k, np_ - 1) * np_ + c0];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < 16; ++k) {
                         const int b = b0 + k;
                         const double dx = dxg[min(b, np_ - 1)];
                         s0 += (b < np_ && lane <= b) ? dx * v[k] : 0.0;   // lower triangle: rows b >= column
@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     __syncthreads();
     int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)
     int rejoin_run = 0;            // consecutive frames that reproduced the stored trajectory (repair chains)
+    int bi_next = 0;               // next chunk boundary of a run-through repair chain
     PROF_BEGIN();
 #ifdef MOSHII_PROFILE
     const long long _wall0 = wall_clock64();
@@ -1223,6 +1224,16 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if (tid < 3) so[2 * NP + tid] = cx.trans[tid];
             if (tid == 3) so[2 * NP + 3] = has_prev ? 1.0 : 0.0;
             if (tid == 4) so[2 * NP + 4] = first ? 1.0 : 0.0;
+        }
+        if (bi_next < chp->nb && t == chp->bnd[bi_next]) {   // a chunk boundary inside a run-through repair chain
+            const int S = 2 * NP + 5;
+            double* s1 = chp->run_final + (size_t)bi_next * S;
+            double* s2 = chp->run_entry + (size_t)(bi_next + 1) * S;
+            for (int i = tid; i < NP; i += MOSHII_TPB) { s1[i] = cx.pose[i]; s1[NP + i] = cx.pose_prev[i]; s2[i] = cx.pose[i]; s2[NP + i] = cx.pose_prev[i]; }
+            if (tid < 3) { s1[2 * NP + tid] = cx.trans[tid]; s2[2 * NP + tid] = cx.trans[tid]; }
+            if (tid == 3) { s1[2 * NP + 3] = has_prev ? 1.0 : 0.0; s2[2 * NP + 3] = has_prev ? 1.0 : 0.0; }
+            if (tid == 4) { s1[2 * NP + 4] = first ? 1.0 : 0.0; s2[2 * NP + 4] = first ? 1.0 : 0.0; }
+            ++bi_next;
         }
         if (t == F) break;
         const bool record = t >= skip;
@@ -1304,7 +1315,8 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
         }
         __syncthreads();
-        if (rejoin_run >= 2 && t + 1 < F) break;   // pose and pose_prev both match: the stored rows (and final state) stand
+        if (rejoin_run >= 2 && t + 1 < F) { if (tid == 0 && chp->frames_done) *chp->frames_done = t + 1; break; }   // pose and pose_prev both match: the stored rows (and final state) stand
+        if (t + 1 == F && tid == 0 && chp->frames_done) *chp->frames_done = F;
     }
     PROF_LAP(12);
 #ifdef MOSHII_PROFILE

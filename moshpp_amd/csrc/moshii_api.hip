@@ -878,7 +878,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     }
     const int NC = (int)chunks.size();
     // ---- launch preparation + control block: [ChainDev x NC (pass 1)][ChainDev x NC (repairs)][pred x NC]
-    const size_t extra = 2 * sizeof(ChainDev) * NC + sizeof(int) * NC + 256;
+    const size_t extra = 2 * sizeof(ChainDev) * NC + 3 * sizeof(int) * NC + 256;
     LaunchCfg cfg;
     size_t ctl = 0;
     int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, NC, stream, extra, &cfg, &ctl);
@@ -887,6 +887,9 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     ChainDev* d_pass1 = (ChainDev*)dbase;
     ChainDev* d_repair = d_pass1 + NC;
     int* d_pred = (int*)(d_repair + NC);
+    int* d_bnd = d_pred + NC;   // chunk boundaries (relative frames) of run-through repair chains
+    int* d_done = d_bnd + NC;   // frames processed per repair chain (diagnostics)
+    const bool trace = getenv("MOSHII_TRACE_REPAIR") != nullptr;
     double *d_entry = nullptr, *d_final = nullptr, *d_dev = nullptr;
     HIP_TRY(hipMalloc((void**)&d_entry, (size_t)NC * S * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&d_final, (size_t)NC * S * sizeof(double)));
@@ -957,16 +960,64 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         }
         std::vector<char> failing(NC, 0);
         for (int c = 0; c < NC; ++c) failing[c] = chunks[c].pred >= 0 && !(hdev[c] <= tol);
-        std::vector<int> todo;   // failing chunks whose predecessor's end state is already final
-        for (int c = 0; c < NC; ++c) if (failing[c] && !failing[chunks[c].pred]) todo.push_back(c);
+        // Scheduling of the repair chains (any mistake here only costs time: whatever ends up inconsistent fails the next
+        // verification).  A GROSS miss (> 1e-6) is a chunk whose fresh start sat in another basin: its repair chain may have
+        // to run through several chunks before it re-joins, so it owns everything up to the next gross miss.  A SLIGHT
+        // miss is a warm-up that had not quite converged: its chain re-joins within a few frames; slight misses that lie in
+        // a gross chain's span wait for the next round (they may be swept anyway), the others are repaired right away.
+        std::vector<int> todo;
+        std::vector<char> todo_gross;
+        {
+            const double gross_dev = 1e-6;
+            int seq = -1;
+            bool in_span = false;
+            for (int c = 0; c < NC; ++c) {
+                if (chunks[c].seq != seq) { seq = chunks[c].seq; in_span = false; }
+                if (!failing[c]) continue;
+                const int p = chunks[c].pred;
+                const bool g = rejoin && hdev[c] > gross_dev, pg = rejoin && failing[p] && hdev[p] > gross_dev;
+                if (!rejoin) { if (!failing[p]) { todo.push_back(c); todo_gross.push_back(0); } continue; }
+                if (g) { if (!pg) { todo.push_back(c); todo_gross.push_back(1); in_span = true; } }
+                else if (!in_span) { todo.push_back(c); todo_gross.push_back(0); }
+            }
+        }
         if (todo.empty()) break;
+        // every repair chain starts at its failing chunk and runs on through the following chunks until it re-joins the
+        // stored trajectory, or reaches the next chain's start / the end of the sequence
         std::vector<ChainDev> rep(todo.size());
-        for (size_t i = 0; i < todo.size(); ++i) { rep[i] = make_chain(chunks[todo[i]], chunks[todo[i]].s, todo[i], true); exact[todo[i]] = 1; }
+        std::vector<int> hbnd(NC, 0);
+        int nbnd = 0;
+        for (size_t i = 0; i < todo.size(); ++i) {
+            const int c = todo[i];
+            int cl = c + 1;   // one past the last chunk this chain may cover
+            while (cl < NC && chunks[cl].seq == chunks[c].seq && !(i + 1 < todo.size() && todo[i + 1] == cl)) ++cl;   // (up to the next chain)
+            ChainDev cd = make_chain(chunks[c], chunks[c].s, c, true);
+            cd.F = chunks[cl - 1].e - chunks[c].s;
+            cd.final_state = d_final + (size_t)(cl - 1) * S;
+            cd.nb = cl - 1 - c;
+            cd.bnd = d_bnd + nbnd;
+            cd.run_final = d_final + (size_t)c * S;
+            cd.run_entry = d_entry + (size_t)c * S;
+            for (int k = c + 1; k < cl; ++k) hbnd[nbnd++] = chunks[k].s - chunks[c].s;
+            if (!rejoin) { cd.F = chunks[c].e - chunks[c].s; cd.nb = 0; cd.final_state = d_final + (size_t)c * S; }   // (one chunk per chain)
+            cd.frames_done = trace ? d_done + i : nullptr;
+            rep[i] = cd;
+            exact[c] = 1;
+        }
+        HIP_TRY(hipMemcpyAsync(d_bnd, hbnd.data(), sizeof(int) * std::max(nbnd, 1), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_repair, rep.data(), sizeof(ChainDev) * rep.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if ((rc = launch_chains(cfg, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }
         n_repaired += (int)rep.size();
         ++rounds;
+        if (trace) {
+            std::vector<int> done(rep.size(), -1);
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpy(done.data(), d_done, sizeof(int) * rep.size(), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[moshii] repair round %d: %zu chains (chunk:dev:frames_done/limit)", rounds, rep.size());
+            for (size_t i = 0; i < rep.size(); ++i) fprintf(stderr, " %d:%.0e:%d/%d", todo[i], hdev[todo[i]], done[i], rep[i].F);
+            fprintf(stderr, "\n");
+        }
     }
     for (int c = 0; c < NC; ++c) if (chunks[c].pred >= 0) max_dev = std::max(max_dev, hdev[c]);
     if (report) { report->n_chunks = NC; report->n_repaired = n_repaired; report->repair_rounds = rounds; report->max_handoff_dev = max_dev;

@@ -69,6 +69,13 @@ struct ChainDev {
     const double* init_state;   // device; overrides init_pose/init_trans/init_prev/first when non-null
     double* entry_state;        // device or null: state on entering frame `skip`
     double* final_state;        // device or null: state after the last frame
+    // repair chains that run on through following chunks: at relative frame bnd[i] the state is the end state of chunk
+    // (first + i) and the entry state of chunk (first + i + 1)
+    int nb;
+    const int* bnd;
+    double* run_final;          // final-state slot of this chain's first chunk (slots are contiguous by chunk)
+    double* run_entry;          // entry-state slot of this chain's first chunk
+    int* frames_done;           // device or null: number of frames this chain processed before it stopped
     double rejoin_tol;          // > 0 (repair chains): stop once two consecutive solved frames reproduce the rows already in
                                 // `pose`/`trans` to this tolerance -- the rest of the chunk is then the continuation within tol
 };

@@ -235,7 +235,7 @@ def test_sequence_solve_repair_reproduces_chain_bitwise(gpu_lib):
                                          [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
                                          num_chunks=4, warmup=0, verify_tol=1e-12)
     print('chunk report', rep)
-    assert rep['n_chunks'] == 4 and rep['n_repaired'] == 3
+    assert rep['n_chunks'] == 4 and 1 <= rep['n_repaired'] <= 3   # one run-through chain (or one per chunk) re-solves chunks 1..3
     for k in ('fullpose', 'trans', 'markers_sim', 'status', 'errs', 'pose'):
         np.testing.assert_array_equal(outs[0][k], seq[k])
     np.testing.assert_array_equal(outs[0]['iters'], seq['iters'])
@@ -288,21 +288,30 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
 
 
-def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib):
-    """Short warm-up + tight tolerance makes most hand-offs fail, in runs: chunks repaired early must be repaired AGAIN
-    when their predecessor is re-solved in a later round (regression: a chunk once repaired used to be trusted for good,
-    leaving it stitched to a stale predecessor state).  The stitched result must agree with the sequential chain on
-    every frame to well below the north-star tolerance."""
+@pytest.mark.parametrize('rejoin', [True, False])
+def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib, rejoin):
+    """Short warm-up + tight tolerance makes most hand-offs fail, in runs.  Two repair strategies must both end on the
+    sequential chain: run-through chains that stop where they re-join the stored rows (default), and one chain per chunk
+    over many rounds (MOSHII_NO_REJOIN=1) -- there a chunk repaired early must be repaired AGAIN when its predecessor is
+    re-solved in a later round (regression: a chunk once repaired used to be trusted for good, leaving it stitched to a
+    stale predecessor state)."""
     from moshpp_amd import capi
     F = 480
     case = oracle_case('smplh', F=F, M=53, seed=71)
     dev = device_case(case)
     seq = _sequential(dev, case)
-    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
-                                         [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
-                                         num_chunks=40, warmup=6, verify_tol=1e-12)
+    if not rejoin:
+        os.environ['MOSHII_NO_REJOIN'] = '1'
+    try:
+        outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                             [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                             num_chunks=40, warmup=6, verify_tol=1e-12)
+    finally:
+        os.environ.pop('MOSHII_NO_REJOIN', None)
     print('chunk report', rep)
-    assert rep['n_repaired'] >= 10 and rep['repair_rounds'] >= 2
+    assert rep['n_repaired'] >= 1 and rep['repair_rounds'] >= 1
+    if not rejoin:
+        assert rep['n_repaired'] >= 10 and rep['repair_rounds'] >= 2
     solved = seq['status'] == 0
     dp = np.abs(outs[0]['fullpose'] - seq['fullpose'])[solved].max(1)
     print(f'max dev {dp.max():.2e}, frames > 1e-9: {(dp > 1e-9).sum()}')
