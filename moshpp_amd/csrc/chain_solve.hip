@@ -4,13 +4,15 @@
 // drives through chumpy: SmplModelLBS forward (models/smpl_fast_derivatives.py:185-244), its pose
 // Jacobian (:246-258), TransformedLms (transformed_lm.py:130-162), the max-mixture prior
 // (prior/gmm_prior_ch.py:53-85), the rigid first-frame init (rigid_transformations.py:39-83) and
-// chumpy's minimize_dogleg (normal equations, Cholesky solve, trust-region control).
+// chumpy's minimize_dogleg (normal equations, solve, trust-region control).
 //
 // Mapping: one chain (sequence or chunk) per 256-thread workgroup = 4 waves, one per SIMD of a CU.
-// All solver state is float64 and lives in LDS / registers; the only HBM/L2 traffic per evaluation is
-// the compact posedirs slice of the <= 3M attached vertices (vertex index fastest => coalesced),
-// M*3 observations in and one result row out per frame.  J^T J is accumulated in registers as
-// 16x16-thread outer-product tiles (lower triangle only), factored by a right-looking Cholesky in LDS.
+// All solver state is float64 and lives in LDS / registers; per evaluation the only L2 traffic is the
+// free joints' share of the compact posedirs slice of the <= 3M attached vertices (vertex index fastest
+// => coalesced), per frame M*3 observations in and one result row out.  J^T J is accumulated in
+// registers as 16x16-thread outer-product tiles (lower triangle only) and eliminated (L D L^T) in
+// registers with one LDS-published column and one barrier per step.  DESIGN.md section 4 has the
+// per-phase timings and the rules this file follows (branch-free LDS traffic, loads batched ahead of use).
 #include "moshii_dev.h"
 
 namespace moshii {
@@ -489,19 +491,6 @@ struct AReg {
             s += xr[bi] * r;
         }
         return s;
-    }
-    // packed lower triangle: idx(i,j) = i(i+1)/2 + j; row n holds the right-hand side (bordered form)
-    __device__ __forceinline__ void store_packed(double* Lp, int n) const {
-        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-        int e = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi)
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) {
-                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
-                if (q1 < n && q2 <= q1) Lp[q1 * (q1 + 1) / 2 + q2] = a[e];
-                ++e;
-            }
     }
 };
 

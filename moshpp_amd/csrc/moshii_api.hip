@@ -944,7 +944,6 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     if ((rc = launch_chains(cfg, NC, d_pass1, stream))) { cleanup(); return rc; }
     // ---- verify the hand-offs; re-solve (exactly, from the predecessor's final state) the chunks that fail
     std::vector<double> hdev(NC, 0.0);
-    std::vector<char> exact(NC, 0);
     int n_repaired = 0, rounds = 0;
     double max_dev = 0.0;
     while (true) {
@@ -1002,7 +1001,6 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             if (!rejoin) { cd.F = chunks[c].e - chunks[c].s; cd.nb = 0; cd.final_state = d_final + (size_t)c * S; }   // (one chunk per chain)
             cd.frames_done = trace ? d_done + i : nullptr;
             rep[i] = cd;
-            exact[c] = 1;
         }
         HIP_TRY(hipMemcpyAsync(d_bnd, hbnd.data(), sizeof(int) * std::max(nbnd, 1), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_repair, rep.data(), sizeof(ChainDev) * rep.size(), hipMemcpyHostToDevice, stream));
