@@ -371,12 +371,12 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 double s0 = 0.0, s1 = 0.0;
-                for (int b0 = 0; b0 < np_; b0 += 16) {   // 16 coalesced row loads in flight per lane
-                    double v[16];
+                for (int b0 = 0; b0 < np_; b0 += 32) {   // 32 coalesced row loads in flight per lane
+                    double v[32];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] = Lg[(size_t)min(b0 + k, np_ - 1) * np_ + c0];
+                    for (int k = 0; k < 32; ++k) v[k] = Lg[(size_t)min(b0 + k, np_ - 1) * np_ + c0];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
+                    for (int k = 0; k < 32; ++k) {
                         const int b = b0 + k;
                         const double dx = dxg[min(b, np_ - 1)];
                         s0 += (b < np_ && lane <= b) ? dx * v[k] : 0.0;   // lower triangle: rows b >= column
@@ -428,16 +428,26 @@ struct AReg {
     // A += rows^T rows  (rows: nr x LDJ in LDS, columns >= n are zero)
     __device__ __forceinline__ void rank_update(const double* rows, int nr, int LDJ) {
         const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-        for (int r = 0; r < nr; ++r) {
-            const double* row = rows + r * LDJ;
-            double av[NBLK], bv[NBLK];
+        constexpr int RB = (NBLK <= 5) ? 4 : 2;   // rows per batch: all 2 NBLK RB LDS reads are issued before the first multiply
+        for (int r0 = 0; r0 < nr; r0 += RB) {
+            double av[RB][NBLK], bv[RB][NBLK];
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) { av[b] = row[b * 16 + ty]; bv[b] = row[b * 16 + tx]; }
-            int e = 0;
+            for (int k = 0; k < RB; ++k) {
+                const double* row = rows + min(r0 + k, nr - 1) * LDJ;
 #pragma unroll
-            for (int bi = 0; bi < NBLK; ++bi)
+                for (int b = 0; b < NBLK; ++b) { av[k][b] = row[b * 16 + ty]; bv[k][b] = row[b * 16 + tx]; }
+            }
 #pragma unroll
-                for (int bj = 0; bj <= bi; ++bj) { a[e] += av[bi] * bv[bj]; ++e; }
+            for (int k = 0; k < RB; ++k) {
+                const double live = (r0 + k < nr) ? 1.0 : 0.0;   // the clamped re-read of the last row counts once
+                int e = 0;
+#pragma unroll
+                for (int bi = 0; bi < NBLK; ++bi) {
+                    const double al = live * av[k][bi];
+#pragma unroll
+                    for (int bj = 0; bj <= bi; ++bj) { a[e] += al * bv[k][bj]; ++e; }
+                }
+            }
         }
     }
     __device__ __forceinline__ void add_diag(const double* dvec /* LDS [n] */, int n) {
@@ -527,57 +537,82 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
                 ++e;
             }
     }
-    // Per-thread LDS addresses, resolved once: rows beyond the border row n (and columns beyond n-1) point at the spare
-    // words, so the column loop needs one comparison per access.  Stores that do not apply go to `trash`, loads that do
-    // not apply read `zero` (= 0.0): the loop is straight-line LDS traffic with a single barrier per column.
+    // LDS views.  Lp: the packed factor (what the back-substitution reads); entry (i, j), i > j, is written once, by its
+    // owner, and never read inside the elimination loop.  Cv: the column broadcast buffer [2 parities][2 columns][rows],
+    // rewritten every step -- parity double-buffering makes one barrier per step sufficient (a thread can only be two
+    // steps ahead of another after both passed the barrier in between).  Two columns are eliminated per step: one
+    // barrier and one LDS round trip per PAIR; the second column's entries are corrected by the first on the fly,
+    //   c'_{i,j+1} = c_{i,j+1} - c_{ij} a / d_j ,   d'_{j+1} = d_{j+1} - a^2 / d_j ,   a = A[j+1][j].
+    // Stores that do not apply go to `trash`, loads that do not apply read `zero` (= 0.0): straight-line LDS traffic.
     const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
-    int rS[NBLK], rL[NBLK], cL[NBLK];   // packed offset of row q1 (store / load view) and of row q2 = this thread's column
+    constexpr int CVR = NBLK * 16;                 // rows of one broadcast column
+    double* Cv = Lp + zero + 1;                    // [2][2][CVR]
+    int rS[NBLK];                                  // packed offset of this thread's row q1 (or -1 beyond the border row)
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
-        const int q1 = b * 16 + ty, q2 = b * 16 + tx;
+        const int q1 = b * 16 + ty;
         rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
-        rL[b] = rS[b];
-        cL[b] = (q2 <= n) ? q2 * (q2 + 1) / 2 : -1;
     }
     if (tid == 0) Lp[zero] = 0.0;
     bool ok = true;
-    int jj = 0;   // packed index of the pivot (j, j)
+    int step = 0;
     // outer loop over 16-column blocks is unrolled, so every register index below is a compile-time constant
 #pragma unroll
     for (int bj0 = 0; bj0 < NBLK; ++bj0) {
         if (!ok) break;
-        for (int jl = 0; jl < 16; ++jl) {
+        for (int jl = 0; jl < 16; jl += 2) {
             const int j = bj0 * 16 + jl;
             if (j >= n) break;
-            const bool owner = tx == jl;
+            const bool pair = j + 1 < n;   // (n odd: the last column goes alone)
+            double* cv = Cv + (step & 1) * 2 * CVR;
+            ++step;
+            const bool ownA = tx == jl, ownB = tx == jl + 1;
 #pragma unroll
-            for (int bi = bj0; bi < NBLK; ++bi) {   // publish column j (rows j..n): entry (bi, bj0) of this thread
+            for (int bi = bj0; bi < NBLK; ++bi) {   // publish columns j, j+1 as they stand (rows of this thread), and column j's final entries
                 const int q1 = bi * 16 + ty;
-                const bool valid = owner && q1 >= j && rS[bi] >= 0;
-                Lp[valid ? rS[bi] + j : trash] = w[bi * (bi + 1) / 2 + bj0];
+                const double v = w[bi * (bi + 1) / 2 + bj0];
+                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Lp + trash;
+                *dst = v;
+                Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;
             }
             __syncthreads();
-            const double pj = Lp[jj];
-            double ci[NBLK], ck[NBLK];
+            const double p0 = cv[j], a10 = cv[j + 1], p1r = cv[CVR + j + 1];
+            double ci0[NBLK], ci1[NBLK], ck0[NBLK], ck1[NBLK];
 #pragma unroll
             for (int b = bj0; b < NBLK; ++b) {
                 const int q1 = b * 16 + ty, q2 = b * 16 + tx;
-                ci[b] = Lp[(q1 > j && rL[b] >= 0) ? rL[b] + j : zero];
-                ck[b] = Lp[(q2 > j && cL[b] >= 0) ? cL[b] + j : zero];
+                const bool vr = q1 > j + 1 && q1 <= n, vc = q2 > j + 1 && q2 <= n;
+                ci0[b] = vr ? cv[q1] : 0.0; ci1[b] = vr ? cv[CVR + q1] : 0.0;
+                ck0[b] = vc ? cv[q2] : 0.0; ck1[b] = vc ? cv[CVR + q2] : 0.0;
             }
-            jj += j + 2;
-            if (!(pj > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS word
+            if (!(p0 > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS words
             // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
-            double pin = __builtin_amdgcn_rcp(pj);
-            pin = fma(fma(-pj, pin, 1.0), pin, pin);
-            pin = fma(fma(-pj, pin, 1.0), pin, pin);
-            if (tid == 0) pinv[j] = pin;
+            double pin0 = __builtin_amdgcn_rcp(p0);
+            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
+            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
+            const double l10 = a10 * pin0;
+            const double p1 = pair ? fma(-a10, l10, p1r) : 1.0;
+            if (!(p1 > 0.0)) { ok = false; break; }
+            double pin1 = __builtin_amdgcn_rcp(p1);
+            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
+            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
+            if (!pair) pin1 = 0.0;
+            if (tid == 0) { pinv[j] = pin0; if (pair) pinv[j + 1] = pin1; }
 #pragma unroll
-            for (int b = bj0; b < NBLK; ++b) ck[b] *= pin;
+            for (int b = bj0; b < NBLK; ++b) {
+                ci1[b] = fma(-ci0[b], l10, ci1[b]);          // column j+1 corrected by column j
+                ck1[b] = fma(-ck0[b], l10, ck1[b]);
+                const int q1 = b * 16 + ty;
+                Lp[(ownB && pair && q1 > j + 1 && rS[b] >= 0) ? rS[b] + j + 1 : trash] = ci1[b];   // ... and stored, final
+                ck0[b] *= pin0; ck1[b] *= pin1;
+            }
 #pragma unroll
             for (int bi = bj0; bi < NBLK; ++bi)
 #pragma unroll
-                for (int bj = bj0; bj <= bi; ++bj) w[bi * (bi + 1) / 2 + bj] -= ci[bi] * ck[bj];
+                for (int bj = bj0; bj <= bi; ++bj) {
+                    const int e = bi * (bi + 1) / 2 + bj;
+                    w[e] = fma(-ci1[bi], ck1[bj], fma(-ci0[bi], ck0[bj], w[e]));
+                }
         }
     }
     __syncthreads();
@@ -808,9 +843,16 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         // T3: A += Jt^T Jt ; g -= Jt^T r
         A.rank_update(cx.Jrow, ntv, LDJ);
         for (int q = tid; q < n; q += MOSHII_TPB) {
-            double s = 0.0;
-            for (int r = 0; r < ntv; ++r) s += cx.Jrow[r * LDJ + q] * cx.rest[r];
-            cx.g[q] -= s;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int r = 0;
+            for (; r + 4 <= ntv; r += 4) {
+                s0 += cx.Jrow[r * LDJ + q] * cx.rest[r];
+                s1 += cx.Jrow[(r + 1) * LDJ + q] * cx.rest[r + 1];
+                s2 += cx.Jrow[(r + 2) * LDJ + q] * cx.rest[r + 2];
+                s3 += cx.Jrow[(r + 3) * LDJ + q] * cx.rest[r + 3];
+            }
+            for (; r < ntv; ++r) s0 += cx.Jrow[r * LDJ + q] * cx.rest[r];
+            cx.g[q] -= (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
         PROF_LAP(7);

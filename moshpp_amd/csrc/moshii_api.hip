@@ -261,7 +261,7 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 27);
     ly.t_Trot = ttake(3 * Tm * 9); ly.t_xjs = ttake(3 * Tm * NWmax * 4); ly.t_rest = ttake(3 * Tm);
     ly.t_tjs = ttake((3 * Tm * NWmax + 1) / 2);
-    const int chol = (nmax + 1) * (nmax + 2) / 2 + 2;   // + the trash / zero words of ldl_solve
+    const int chol = (nmax + 1) * (nmax + 2) / 2 + 2 + 4 * LDJ + 4;   // + trash / zero words + the column broadcast buffer of ldl_solve
     ly.big_doubles = std::max(t, chol);
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
