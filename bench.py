@@ -81,8 +81,9 @@ def main():
     lib = capi.load()
     capi.check(lib.moshii_set_device(local_rank))
 
-    # ---- workload: BASELINE config[1]; each rank its own seeded sequence of the same shape
-    job = workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=1000 + rank)
+    # ---- workload: BASELINE config[1]; every rank solves its own copy of the same seeded sequence (identical work per
+    # GPU: the chunk-repair pattern depends on the motion, so different seeds would blur the weak-scaling figure)
+    job = workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=1000)
     solver = workload.make_solver(job)
     sm = job['sm']
     F, M = job['vis'].shape

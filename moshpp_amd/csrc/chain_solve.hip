@@ -32,7 +32,7 @@ enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 =
 
 struct Ctx {
     double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
-    double *feat, *B, *omega, *Rw, *tw, *Rloc, *acol;
+    double *feat, *B, *omega, *Rw, *tw, *Rloc, *acol, *Jl;
     double *vposed, *vpos, *msim, *res, *vconst;
     double *xb, *ell, *score;
     double *g, *dsd, *dgn, *ddl, *y;
@@ -272,7 +272,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         if (tid == 0) {
 #pragma unroll
             for (int e = 0; e < 9; ++e) cx.Rw[e] = R[e];
-            cx.tw[0] = md.J[0]; cx.tw[1] = md.J[1]; cx.tw[2] = md.J[2];
+            cx.tw[0] = cx.Jl[0]; cx.tw[1] = cx.Jl[1]; cx.tw[2] = cx.Jl[2];
         }
     }
     __syncthreads();
@@ -293,9 +293,9 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                 mat3_mul(Rp, Rl, Ro);
 #pragma unroll
                 for (int e = 0; e < 9; ++e) cx.Rw[tid * 9 + e] = Ro[e];
-                const double dx = md.J[tid * 3 + 0] - md.J[p * 3 + 0];
-                const double dy = md.J[tid * 3 + 1] - md.J[p * 3 + 1];
-                const double dz = md.J[tid * 3 + 2] - md.J[p * 3 + 2];
+                const double dx = cx.Jl[tid * 3 + 0] - cx.Jl[p * 3 + 0];
+                const double dy = cx.Jl[tid * 3 + 1] - cx.Jl[p * 3 + 1];
+                const double dz = cx.Jl[tid * 3 + 2] - cx.Jl[p * 3 + 2];
                 double ox, oy, oz;
                 mat3_vec(Rp, dx, dy, dz, ox, oy, oz);
                 cx.tw[tid * 3 + 0] = ox + cx.tw[p * 3 + 0];
@@ -317,7 +317,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             const int j = at.wj[a * NW + s];
             const double w = at.ww[a * NW + s];
             double ox, oy, oz;
-            mat3_vec(&cx.Rw[j * 9], px - md.J[j * 3 + 0], py - md.J[j * 3 + 1], pz - md.J[j * 3 + 2], ox, oy, oz);
+            mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
             ax += w * (ox + cx.tw[j * 3 + 0]);
             ay += w * (oy + cx.tw[j * 3 + 1]);
             az += w * (oz + cx.tw[j * 3 + 2]);
@@ -379,11 +379,15 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                     for (int k = 0; k < 32; ++k) {
                         const int b = b0 + k;
                         const double dx = dxg[min(b, np_ - 1)];
-                        s0 += (b < np_ && lane <= b) ? dx * v[k] : 0.0;   // lower triangle: rows b >= column
+                        // lower triangle: rows b >= column.  The 0/1 factor (instead of a conditional expression) keeps the
+                        // LDS read above unconditional: hipcc otherwise sinks it into an exec-masked branch with its own
+                        // lgkmcnt(0) wait -- 63 serialized LDS round trips per component.
+                        const double m = (b < np_ && lane <= b) ? 1.0 : 0.0;
+                        s0 = fma(dx * m, v[k], s0);
                     }
                 }
                 if (np_ > 64)   // columns 64.. (SMPL's 69-dof prior): rows b >= 64 only
-                    for (int b = 64; b < np_; ++b) { const double v1 = Lg[(size_t)b * np_ + c1]; s1 += (lane + 64 <= b) ? dxg[b] * v1 : 0.0; }
+                    for (int b = 64; b < np_; ++b) { const double v1 = Lg[(size_t)b * np_ + c1]; const double m = (lane + 64 <= b) ? 1.0 : 0.0; s1 = fma(dxg[b] * m, v1, s1); }
                 s0 *= 0.70710678118654757; s1 *= 0.70710678118654757;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -462,21 +466,28 @@ struct AReg {
                 ++e;
             }
     }
-    // A[q1][q2] += scale * Pk[colprior[q1]][colprior[q2]]
+    // A[q1][q2] += scale * Pk[colprior[q1]][colprior[q2]]   (branch-free: clamped gathers, 0/1 factor)
     __device__ __forceinline__ void add_prior(double scale, const double* Pk, int np_, const int* colprior, int n) {
         const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+        int pr_[NBLK], pc_[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int q1 = b * 16 + ty, q2 = b * 16 + tx;
+            const int p1 = colprior[min(q1, n - 1)], p2 = colprior[min(q2, n - 1)];
+            pr_[b] = (q1 < n) ? p1 : -1;
+            pc_[b] = (q2 < n) ? p2 : -1;
+        }
+        double v[NE];
         int e = 0;
 #pragma unroll
         for (int bi = 0; bi < NBLK; ++bi)
 #pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) {
-                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
-                if (q1 < n && q2 < n) {
-                    const int p1 = colprior[q1], p2 = colprior[q2];
-                    if (p1 >= 0 && p2 >= 0) a[e] += scale * Pk[p1 * np_ + p2];
-                }
-                ++e;
-            }
+            for (int bj = 0; bj <= bi; ++bj) { v[e] = Pk[max(pr_[bi], 0) * np_ + max(pc_[bj], 0)]; ++e; }
+        e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) { a[e] = fma(scale * ((pr_[bi] >= 0 && pc_[bj] >= 0) ? 1.0 : 0.0), v[e], a[e]); ++e; }
     }
     // sum_{q1,q2} A[q1][q2] x[q1] x[q2] over the full symmetric matrix (block partial; reduce outside).  Branch-free: the
     // 2 NBLK vector entries are fetched up front (zero beyond n), off-diagonal blocks count twice, diagonal blocks by ty/tx.
@@ -487,8 +498,8 @@ struct AReg {
         for (int b = 0; b < NBLK; ++b) {
             const int q1 = b * 16 + ty, q2 = b * 16 + tx;
             const double v1 = x[min(q1, n - 1)], v2 = x[min(q2, n - 1)];
-            xr[b] = (q1 < n) ? v1 : 0.0;
-            xc[b] = (q2 < n) ? v2 : 0.0;
+            xr[b] = v1 * ((q1 < n) ? 1.0 : 0.0);   // (0/1 factors keep the reads unconditional)
+            xc[b] = v2 * ((q2 < n) ? 1.0 : 0.0);
         }
         const double cd = (tx < ty) ? 2.0 : ((tx == ty) ? 1.0 : 0.0);
         double s = 0.0;
@@ -533,7 +544,8 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj) {
                 const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
-                w[e] = (q1 == n) ? ((q2 < n) ? g[q2] : 0.0) : A.a[e];
+                const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);   // (unconditional read)
+                w[e] = (q1 == n) ? gq : A.a[e];
                 ++e;
             }
     }
@@ -582,8 +594,10 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
             for (int b = bj0; b < NBLK; ++b) {
                 const int q1 = b * 16 + ty, q2 = b * 16 + tx;
                 const bool vr = q1 > j + 1 && q1 <= n, vc = q2 > j + 1 && q2 <= n;
-                ci0[b] = vr ? cv[q1] : 0.0; ci1[b] = vr ? cv[CVR + q1] : 0.0;
-                ck0[b] = vc ? cv[q2] : 0.0; ck1[b] = vc ? cv[CVR + q2] : 0.0;
+                const double* zr = Lp + zero;   // (address select, not value select: the loads stay unconditional)
+                const double* r0 = vr ? cv + q1 : zr; const double* r1 = vr ? cv + CVR + q1 : zr;
+                const double* c0p = vc ? cv + q2 : zr; const double* c1p = vc ? cv + CVR + q2 : zr;
+                ci0[b] = *r0; ci1[b] = *r1; ck0[b] = *c0p; ck1[b] = *c1p;
             }
             if (!(p0 > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS words
             // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
@@ -677,9 +691,9 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 #pragma unroll
             for (int d = 0; d < 3; ++d) {   // column d of R
                 const double rx = R[0 * 3 + d], ry = R[1 * 3 + d], rz = R[2 * 3 + d];
-                cx.B[tid * 27 + c * 9 + 0 * 3 + d] = ay * rz - az * ry;
-                cx.B[tid * 27 + c * 9 + 1 * 3 + d] = az * rx - ax * rz;
-                cx.B[tid * 27 + c * 9 + 2 * 3 + d] = ax * ry - ay * rx;
+                cx.B[tid * 28 + c * 9 + 0 * 3 + d] = ay * rz - az * ry;
+                cx.B[tid * 28 + c * 9 + 1 * 3 + d] = az * rx - ax * rz;
+                cx.B[tid * 28 + c * 9 + 2 * 3 + d] = ax * ry - ay * rx;
             }
         }
     }
@@ -690,7 +704,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         const double ax = cx.acol[k * 9 + c * 3 + 0], ay = cx.acol[k * 9 + c * 3 + 1], az = cx.acol[k * 9 + c * 3 + 2];
         double ox = ax, oy = ay, oz = az;
         if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
-        cx.omega[k * 9 + c * 3 + 0] = ox; cx.omega[k * 9 + c * 3 + 1] = oy; cx.omega[k * 9 + c * 3 + 2] = oz;
+        cx.omega[k * 10 + c * 3 + 0] = ox; cx.omega[k * 10 + c * 3 + 1] = oy; cx.omega[k * 10 + c * 3 + 2] = oz;
     }
     for (int tile0 = 0; tile0 < fp.nobs; tile0 += Tm) {
         const int cnt = min(Tm, fp.nobs - tile0);
@@ -707,7 +721,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const int j = at.wj[av * NW + s];
                 const double w = at.ww[av * NW + s];
                 double ox, oy, oz;
-                mat3_vec(&cx.Rw[j * 9], px - md.J[j * 3 + 0], py - md.J[j * 3 + 1], pz - md.J[j * 3 + 2], ox, oy, oz);
+                mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
                 cx.xjs[(tid * NW + s) * 4 + 0] = ox + cx.tw[j * 3 + 0];
                 cx.xjs[(tid * NW + s) * 4 + 1] = oy + cx.tw[j * 3 + 1];
                 cx.xjs[(tid * NW + s) * 4 + 2] = oz + cx.tw[j * 3 + 2];
@@ -717,7 +731,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 for (int e = 0; e < 9; ++e) Tr[e] += w * cx.Rw[j * 9 + e];
             }
 #pragma unroll
-            for (int e = 0; e < 9; ++e) cx.Trot[tid * 9 + e] = Tr[e];
+            for (int e = 0; e < 9; ++e) cx.Trot[tid * 10 + e] = Tr[e];
         } else if (tid >= 128 && tid < 128 + cnt) {
             const int ml = tid - 128;
             const int m = cx.visidx[tile0 + ml];
@@ -725,7 +739,11 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             double mk[3], L[27];
             marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, L);
 #pragma unroll
-            for (int e = 0; e < 27; ++e) cx.Lm[ml * 27 + e] = L[e];
+            for (int sv = 0; sv < 3; ++sv)   // stored per vertex: [ml][sv][row*3 + x] in rows of 10 doubles (16-byte reads in T1)
+#pragma unroll
+                for (int row = 0; row < 3; ++row)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) cx.Lm[(ml * 3 + sv) * 10 + row * 3 + x] = L[row * 9 + sv * 3 + x];
 #pragma unroll
             for (int i = 0; i < 3; ++i) cx.rest[ml * 3 + i] = cx.res[m * 3 + i];
         }
@@ -742,24 +760,33 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             const int m = cx.visidx[tile0 + ml];
             const unsigned long long mask = cx.anc[k];
             const double tkx = cx.tw[k * 3 + 0], tky = cx.tw[k * 3 + 1], tkz = cx.tw[k * 3 + 2];
-            const double* L = &cx.Lm[ml * 27];
-            double om[9];
+            double om[10];   // (rows of 10 doubles: five 16-byte LDS reads)
+            {
+                const double2* o2 = reinterpret_cast<const double2*>(&cx.omega[k * 10]);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) om[e] = cx.omega[k * 9 + e];
+                for (int q = 0; q < 5; ++q) { const double2 t2 = o2[q]; om[2 * q] = t2.x; om[2 * q + 1] = t2.y; }
+            }
             double r[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) r[e] = 0.0;
+            double Bk[28];   // dR_k/dtheta_c, c = 0..2: the same for the marker's three vertices (14 16-byte LDS reads, once per item)
+            {
+                const double2* bp2 = reinterpret_cast<const double2*>(&cx.B[k * 28]);
+#pragma unroll
+                for (int q = 0; q < 14; ++q) { const double2 t2 = bp2[q]; Bk[2 * q] = t2.x; Bk[2 * q + 1] = t2.y; }
+            }
 #pragma unroll
             for (int sv = 0; sv < 3; ++sv) {
                 const int al = 3 * ml + sv, av = 3 * m + sv;
                 double ax = 0.0, ay = 0.0, az = 0.0;
                 for (int s2 = 0; s2 < NW; ++s2) {   // joints of this vertex inside the subtree of k (branch-free: weight 0 otherwise)
                     const int j = cx.tjs[al * NW + s2];
-                    const double* xw = &cx.xjs[(al * NW + s2) * 4];
-                    const double w = ((mask >> j) & 1ull) ? xw[3] : 0.0;
-                    ax += w * (xw[0] - tkx);
-                    ay += w * (xw[1] - tky);
-                    az += w * (xw[2] - tkz);
+                    const double2* xw = reinterpret_cast<const double2*>(&cx.xjs[(al * NW + s2) * 4]);
+                    const double2 xy = xw[0], zw = xw[1];   // two 16-byte reads; the weight rides with z, so it cannot be sunk into a branch
+                    const double w = ((mask >> j) & 1ull) ? zw.y : 0.0;
+                    ax += w * (xy.x - tkx);
+                    ay += w * (xy.y - tky);
+                    az += w * (zw.x - tkz);
                 }
                 double col[9];
 #pragma unroll
@@ -775,10 +802,15 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                     const double2* pp = reinterpret_cast<const double2*>(at.Pj + ((size_t)(kk - 1) * Nvp + av) * 28);
 #pragma unroll
                     for (int q = 0; q < 14; ++q) { const double2 t2 = pp[q]; pv[2 * q] = t2.x; pv[2 * q + 1] = t2.y; }
-                    const double* Tr = &cx.Trot[al * 9];
+                    double Tr[10];
+                    {
+                        const double2* t2p = reinterpret_cast<const double2*>(&cx.Trot[al * 10]);
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) { const double2 t2 = t2p[q]; Tr[2 * q] = t2.x; Tr[2 * q + 1] = t2.y; }
+                    }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const double* Bc = &cx.B[k * 27 + c * 9];
+                        const double* Bc = &Bk[c * 9];
                         double pd[3];
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
@@ -791,12 +823,17 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                         for (int i = 0; i < 3; ++i) col[c * 3 + i] += Tr[i * 3 + 0] * pd[0] + Tr[i * 3 + 1] * pd[1] + Tr[i * 3 + 2] * pd[2];
                     }
                 }
+                double Ls[10];
+                {
+                    const double2* l2 = reinterpret_cast<const double2*>(&cx.Lm[(ml * 3 + sv) * 10]);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { const double2 t2 = l2[q]; Ls[2 * q] = t2.x; Ls[2 * q + 1] = t2.y; }
+                }
 #pragma unroll
                 for (int row = 0; row < 3; ++row)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        r[row * 3 + c] += L[row * 9 + sv * 3 + 0] * col[c * 3 + 0] + L[row * 9 + sv * 3 + 1] * col[c * 3 + 1] +
-                                          L[row * 9 + sv * 3 + 2] * col[c * 3 + 2];
+                        r[row * 3 + c] += Ls[row * 3 + 0] * col[c * 3 + 0] + Ls[row * 3 + 1] * col[c * 3 + 1] + Ls[row * 3 + 2] * col[c * 3 + 2];
             }
             if (k < bj0) {   // pose variables of a body joint: write the free ones straight into the Jacobian tile
 #pragma unroll
@@ -871,12 +908,17 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const double* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
                 const double* mu = pr.means + (size_t)kb * np_;
                 double s0 = 0.0, s1 = 0.0;
-                int b = 0;
-                for (; b + 2 <= np_; b += 2) {
-                    s0 += Hk[(size_t)b * np_] * (cx.xb[b] - mu[b]);
-                    s1 += Hk[(size_t)(b + 1) * np_] * (cx.xb[b + 1] - mu[b + 1]);
+                for (int b0 = 0; b0 < np_; b0 += 8) {   // 8 column entries + 8 means in flight per lane
+                    double h[8], m8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int b = min(b0 + k, np_ - 1); h[k] = Hk[b * np_]; m8[k] = mu[b]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const int b = b0 + k;
+                        s0 = fma(h[k] * ((b < np_) ? 1.0 : 0.0), cx.xb[min(b, np_ - 1)] - m8[k], s0);
+                        s1 = fma(h[k + 1] * ((b + 1 < np_) ? 1.0 : 0.0), cx.xb[min(b + 1, np_ - 1)] - m8[k + 1], s1);
+                    }
                 }
-                if (b < np_) s0 += Hk[(size_t)b * np_] * (cx.xb[b] - mu[b]);
                 gq -= fp.wt_pose * fp.wt_pose * (s0 + s1);
             }
             if (fp.use_fingers) {
@@ -1186,7 +1228,7 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     Ctx cx;
     cx.pose = lds + ly.o_pose; cx.trans = lds + ly.o_trans; cx.pose_t = lds + ly.o_pose_t; cx.trans_t = lds + ly.o_trans_t;
     cx.pose_prev = lds + ly.o_pose_prev; cx.vtarget = lds + ly.o_vtarget; cx.fullpose = lds + ly.o_fullpose;
-    cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
+    cx.Jl = lds + ly.o_Jl; cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
     cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
     cx.vconst = lds + ly.o_vconst; cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
     cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
@@ -1235,6 +1277,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         first = is ? (is[2 * NP + 4] != 0.0) : (chp->first != 0);
     }
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
+    for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];   // regressed joints: read in every phase, keep them in LDS
     __syncthreads();
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
@@ -1386,6 +1429,7 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restr
     op.nbody = 0; op.nfinger = 0; op.n1 = 0; op.n2 = 0; op.maxiter = 0;
     op.step1 = nullptr; op.step2 = nullptr; op.body = nullptr; op.finger = nullptr;
     for (int k = 1 + tid; k < md.K; k += MOSHII_TPB) cx.ksum[k - 1] = k;   // every joint's correctives, on top of v_shaped
+    for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];
     __syncthreads();
     eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh);
     for (int i = tid; i < 3 * at.M; i += MOSHII_TPB) out[(size_t)f * 3 * at.M + i] = cx.msim[i];

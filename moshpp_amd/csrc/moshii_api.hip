@@ -243,7 +243,7 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     auto take = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
     ly.o_pose = take(NP); ly.o_trans = take(4); ly.o_pose_t = take(NP); ly.o_trans_t = take(4);
     ly.o_pose_prev = take(NP); ly.o_vtarget = take(NP); ly.o_fullpose = take(P);
-    ly.o_feat = take(K * 9); ly.o_B = take(K * 27); ly.o_omega = take(K * 9); ly.o_Rw = take(K * 9); ly.o_tw = take(K * 3);
+    ly.o_feat = take(K * 9); ly.o_B = take(K * 28); ly.o_omega = take(K * 10); ly.o_Jl = take(K * 3); ly.o_Rw = take(K * 9); ly.o_tw = take(K * 3);
     ly.o_Rloc = take(K * 9); ly.o_acol = take(K * 9);
     ly.o_vconst = take(Nvmax * 3); ly.o_vposed = take(Nvmax * 3); ly.o_vpos = take(Nvmax * 3); ly.o_msim = take(Mmax * 3); ly.o_res = take(Mmax * 3);
     ly.o_xb = take(std::max(npose, 1)); ly.o_ell = take(std::max(G * npose, 1)); ly.o_score = take(std::max(G, 1));
@@ -258,8 +258,8 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.o_ints = take((io + 1) / 2);
     int t = 0;
     auto ttake = [&](int nd) { int o = t; t += (nd + 1) & ~1; return o; };
-    ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 27);
-    ly.t_Trot = ttake(3 * Tm * 9); ly.t_xjs = ttake(3 * Tm * NWmax * 4); ly.t_rest = ttake(3 * Tm);
+    ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 30);
+    ly.t_Trot = ttake(3 * Tm * 10); ly.t_xjs = ttake(3 * Tm * NWmax * 4); ly.t_rest = ttake(3 * Tm);
     ly.t_tjs = ttake((3 * Tm * NWmax + 1) / 2);
     const int chol = (nmax + 1) * (nmax + 2) / 2 + 2 + 4 * LDJ + 4;   // + trash / zero words + the column broadcast buffer of ldl_solve
     ly.big_doubles = std::max(t, chol);

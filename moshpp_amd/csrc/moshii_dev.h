@@ -84,7 +84,7 @@ struct ChainDev {
 struct ChainLayout {
     int Mmax, Nvmax, NWmax, nmax, Tm, nkfmax, LDJ, nhj;
     int o_pose, o_trans, o_pose_t, o_trans_t, o_pose_prev, o_vtarget, o_fullpose;
-    int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol;
+    int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol, o_Jl;
     int o_vposed, o_vpos, o_msim, o_res, o_vconst;
     int o_xb, o_ell, o_score;
     int o_g, o_dsd, o_dgn, o_ddl, o_y;
