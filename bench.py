@@ -18,6 +18,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   parity             GPU result of the timed mode vs the oracle's sequential chain on that sample
   sequential_chain   the literal frame order on the GPU (one workgroup) and the timed mode's deviation from it over
                      ALL frames
+  many_sequences     32 copies of the sequence in one call: the dominant kernel with every CU busy
 """
 from __future__ import annotations
 
@@ -61,6 +62,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
     ap.add_argument('--lbs-frames', type=int, default=2000)
+    ap.add_argument('--many', type=int, default=32, help='extra leg: this many copies of the sequence in one call (0: skip)')
     args = ap.parse_args()
 
     import torch
@@ -183,6 +185,31 @@ def main():
                                              'status_identical': bool((status == sq['status']).all())}}
             result['speedup_vs_sequential_chain'] = round(value / max(solved / tsq, 1e-9) / world, 2)
             del dsq
+        # ---- the same kernel with the chip full: 32 copies of the sequence in one call (BASELINE config[2] shape: many
+        # sequences per GPU).  8 chunks per sequence, so warm-up is 7 % of the work and every CU carries a chain.
+        if args.many > 0:
+            try:
+                copies = [workload.DeviceSequence(job, solver, dev) for _ in range(args.many)]
+                stream = torch.cuda.current_stream().cuda_stream
+                workload.solve_many_chunked(copies, stream)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                mrep = workload.solve_many_chunked(copies, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                mt = e0.elapsed_time(e1) * 1e-3
+                mout = copies[-1].results()
+                dpm = np.abs(mout['fullpose'] - out['fullpose'])[solved_mask].max()
+                mach = fl * args.many / mt / 1e12
+                result['many_sequences'] = {
+                    'sequences': args.many, 'frames': args.many * F, 'frames_per_s': round(args.many * solved / mt, 1), 'ms': round(mt * 1e3, 2),
+                    'chunking': mrep, 'max_abs_pose_diff_vs_single_run_rad': float(dpm),
+                    'roofline': {'kernel': name, 'bound': 'valu_f64', 'achieved': round(mach, 4), 'peak': F64_VALU_PEAK_TFLOPS,
+                                 'unit': 'TFLOP/s', 'frac': round(mach / F64_VALU_PEAK_TFLOPS, 5)}}
+                del copies
+            except Exception as e:
+                result['many_sequences'] = {'error': repr(e)}
         # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names)
         try:
             import ctypes as C

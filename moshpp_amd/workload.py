@@ -97,3 +97,19 @@ class DeviceSequence:
         return dict(pose=self.pose.cpu().numpy(), fullpose=self.fullpose.cpu().numpy(), trans=self.trans.cpu().numpy(),
                     markers_sim=self.msim.cpu().numpy(), errs=self.errs.cpu().numpy(), iters=self.iters.cpu().numpy(),
                     status=self.status.cpu().numpy())
+
+
+def solve_many_chunked(seqs, stream, num_chunks=0, warmup=32, verify_tol=1e-11):
+    """moshii_sequence_solve over several DeviceSequence objects of the same solver in ONE call (one launch for all
+    their chunks).  Returns the chunk report."""
+    import ctypes as C
+    from . import capi
+    mh, ph, opts = seqs[0]._handles()
+    descs = (capi.SequenceDesc * len(seqs))()
+    for i, sq in enumerate(seqs):
+        C.memmove(C.byref(descs[i]), C.byref(sq.sdesc[0]), C.sizeof(capi.SequenceDesc))
+    co = capi.ChunkOpts(int(num_chunks), int(warmup), float(verify_tol))
+    rep = capi.ChunkReport()
+    capi.check(capi.load().moshii_sequence_solve(mh, ph, C.byref(opts), len(seqs), descs, C.byref(co), capi.BUFFERS_DEVICE,
+                                                 C.c_void_p(stream), C.byref(rep)))
+    return {k: getattr(rep, k) for k, _ in capi.ChunkReport._fields_}
