@@ -189,25 +189,39 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 }
 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
-__global__ __launch_bounds__(64) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KP,
-                                                  const float* __restrict__ pose, const float* __restrict__ trans,
-                                                  float* __restrict__ Atr, _Float16* __restrict__ featT) {
-    __shared__ float fullpose[3 * MOSHII_MAXK];
-    __shared__ float Rl[MOSHII_MAXK * 9], Rw[MOSHII_MAXK * 9], tw[MOSHII_MAXK * 3];
-    const int K = md.K, P = md.P, f = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KP,
+                                                   const float* __restrict__ pose, const float* __restrict__ trans,
+                                                   float* __restrict__ Atr, _Float16* __restrict__ featT) {
+    // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own
+    __shared__ float s_fullpose[4][3 * MOSHII_MAXK];
+    __shared__ float s_Rl[4][MOSHII_MAXK * 9], s_Rw[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];
+    const int K = md.K, P = md.P, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + wv;
+    if (f >= F) return;   // (whole wavefront; no workgroup barrier below)
+    float* fullpose = s_fullpose[wv]; float* Rl = s_Rl[wv]; float* Rw = s_Rw[wv]; float* tw = s_tw[wv];
     const float* ps = pose + (size_t)f * md.NP;
+    const int bd = md.body_dof, nhf = md.nhand_full;
     for (int d = tid; d < P; d += 64) {
         float v;
-        if (d < md.body_dof) v = ps[d];
+        if (d < bd) v = ps[d];
         else {
-            const int h = d - md.body_dof;
-            double acc = md.hands_mean[h];
-            for (int i = md.col_lo[h]; i < md.col_hi[h]; ++i) acc += (double)ps[md.body_dof + i] * md.comps[i * md.nhand_full + h];
-            v = (float)acc;
+            const int h = d - bd;
+            const int lo = md.col_lo[h], hi = md.col_hi[h];
+            float a0 = md.hands_mean[h], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // four independent chains: the loads overlap
+            int i = lo;
+            for (; i + 4 <= hi; i += 4) {
+                a0 += ps[bd + i] * (float)md.comps[i * nhf + h];
+                a1 += ps[bd + i + 1] * (float)md.comps[(i + 1) * nhf + h];
+                a2 += ps[bd + i + 2] * (float)md.comps[(i + 2) * nhf + h];
+                a3 += ps[bd + i + 3] * (float)md.comps[(i + 3) * nhf + h];
+            }
+            for (; i < hi; ++i) a0 += ps[bd + i] * (float)md.comps[i * nhf + h];
+            v = (a0 + a1) + (a2 + a3);
         }
         fullpose[d] = v;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     _Float16* frow = featT + (size_t)f * KP;
     if (tid < K) {
         const float x = fullpose[3 * tid], y = fullpose[3 * tid + 1], z = fullpose[3 * tid + 2];
@@ -222,39 +236,41 @@ __global__ __launch_bounds__(64) void k_lbs_prep(ModelDev md, const float* __res
             const float id = (e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f;
             const float r = id + a * Km[e] + b * K2[e];
             Rl[tid * 9 + e] = r;
-            if (tid >= 1) frow[(tid - 1) * 9 + e] = (_Float16)(r - id);   // computed as a K + b K^2: no cancellation
+            if (tid >= 1) frow[(tid - 1) * 9 + e] = (_Float16)(a * Km[e] + b * K2[e]);   // R - I without the cancellation
         }
     }
     for (int q = 9 * (K - 1) + tid; q < KP; q += 64) frow[q] = (_Float16)0.0f;
-    __syncthreads();
-    // kinematic chain inside one wavefront (in-order LDS), one tree level per step
+    // kinematic chain inside the wavefront (in-order LDS), one tree level per step
     if (tid == 0) {
         for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];
         for (int i = 0; i < 3; ++i) tw[i] = Jf[i];
     }
     const int lvl_of = (tid < K) ? md.depth[tid] : -1;
     const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
+    float Jd[3] = {0.0f, 0.0f, 0.0f}, Jme[3] = {0.0f, 0.0f, 0.0f};
+    if (tid < K) for (int i = 0; i < 3; ++i) { Jme[i] = Jf[tid * 3 + i]; Jd[i] = Jme[i] - Jf[p * 3 + i]; }
     for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lvl_of == lvl) {
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j)
-                    Rw[tid * 9 + i * 3 + j] = Rw[p * 9 + i * 3 + 0] * Rl[tid * 9 + j] + Rw[p * 9 + i * 3 + 1] * Rl[tid * 9 + 3 + j] + Rw[p * 9 + i * 3 + 2] * Rl[tid * 9 + 6 + j];
-                tw[tid * 3 + i] = Rw[p * 9 + i * 3 + 0] * (Jf[tid * 3 + 0] - Jf[p * 3 + 0]) + Rw[p * 9 + i * 3 + 1] * (Jf[tid * 3 + 1] - Jf[p * 3 + 1]) +
-                                  Rw[p * 9 + i * 3 + 2] * (Jf[tid * 3 + 2] - Jf[p * 3 + 2]) + tw[p * 3 + i];
+                const float p0 = Rw[p * 9 + i * 3 + 0], p1 = Rw[p * 9 + i * 3 + 1], p2 = Rw[p * 9 + i * 3 + 2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Rw[tid * 9 + i * 3 + j] = p0 * Rl[tid * 9 + j] + p1 * Rl[tid * 9 + 3 + j] + p2 * Rl[tid * 9 + 6 + j];
+                tw[tid * 3 + i] = p0 * Jd[0] + p1 * Jd[1] + p2 * Jd[2] + tw[p * 3 + i];
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (tid < K) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint)
-        float* o = Atr + ((size_t)tid * F + f) * 12;
+        float4* o = reinterpret_cast<float4*>(Atr + ((size_t)tid * F + f) * 12);
         const float* tr = trans + (size_t)f * 3;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float r0 = Rw[tid * 9 + i * 3 + 0], r1 = Rw[tid * 9 + i * 3 + 1], r2 = Rw[tid * 9 + i * 3 + 2];
-            o[i * 4 + 0] = r0; o[i * 4 + 1] = r1; o[i * 4 + 2] = r2;
-            o[i * 4 + 3] = tw[tid * 3 + i] - (r0 * Jf[tid * 3 + 0] + r1 * Jf[tid * 3 + 1] + r2 * Jf[tid * 3 + 2]) + tr[i];
+            o[i] = make_float4(r0, r1, r2, tw[tid * 3 + i] - (r0 * Jme[0] + r1 * Jme[1] + r2 * Jme[2]) + tr[i]);
         }
     }
 }
@@ -572,7 +588,7 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
         lmp->Fcap = F;
     }
     const Lbs32Model lm = *lmp;
-    hipLaunchKernelGGL(k_lbs_prep, dim3(F), dim3(64), 0, stream, *md, lm.J, F, lm.KP, pose, trans, lm.Atr, lm.featT);
+    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KP, pose, trans, lm.Atr, lm.featT);
     const int NVT = lm.Vp128 / LBS_TV, NFT = (F + LBS_TF - 1) / LBS_TF;
     const int NVX = (NVT + 7) / 8;                         // vertex tiles per XCD
     const int NCH = (NFT + LBS_FCH - 1) / LBS_FCH;         // frame chunks
