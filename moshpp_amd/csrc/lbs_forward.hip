@@ -16,11 +16,14 @@
 //                  * each wave owns 32 vertices x 3 coordinates x 4 frame tiles = 12 accumulators (192 registers) and
 //                    streams its posedirs fragments from a fragment-major copy of the model (one contiguous 1 KiB
 //                    record per wave-load, prefetched two k-steps ahead): 3 global + 4 LDS fragment loads feed 12 MFMAs;
-//                  * epilogue on the accumulator layout itself (lane = frame, register = vertex): per 32-frame tile the
-//                    K joint transforms are staged in LDS ([joint][frame][12], 48-byte lane stride: conflict-free b128
-//                    reads) and every vertex gathers only its own <= 8 influences -- sparse skinning, no W x A GEMM:
-//                    SMPL-family weights have <= 4 influences per vertex, the dense contraction would be 13x the work;
-//                  * results are transposed through LDS and leave as contiguous 384-byte runs per (wave, frame).
+//                  * the MFMA runs "features x posedirs": accumulator column (lane) = vertex, accumulator register = frame.
+//                    Epilogue on that layout: a lane keeps ITS vertex's <= 8 skinning influences and rest position in
+//                    registers for the whole tile; per 32-frame tile the K joint transforms are staged in LDS
+//                    ([joint][frame][12], joint blocks 1552 B apart so that different joints fall on different banks, equal
+//                    joints broadcast) and each (lane, frame) gathers only its own influences -- sparse skinning, no
+//                    W x A GEMM: SMPL-family weights have <= 4 influences per vertex, the dense contraction is 13x the work;
+//                  * for a fixed frame the 32 lanes of a half-wave hold 32 consecutive vertices: results leave straight
+//                    from registers as 12-byte stores that tile contiguous 384-byte runs (no LDS transposition).
 //                workgroup -> (vertex tile, frame tile) is XCD-aware: all frame tiles of one vertex tile run on the XCD
 //                whose L2 already holds that tile's 356 KB of posedirs fragments.
 //
@@ -37,6 +40,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));   // 12-byte, dword-aligned store unit
 
 #define LBS_NWMAX 8          // skinning influences per vertex (else the launch falls back to the plain kernel)
 #define LBS_TV 128           // vertices per workgroup (32 per wave)
@@ -280,84 +284,53 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 #define LBS_FCH 8                  // frame tiles per L2 chunk: 1024 frames of transforms (K x 48 KB) stay L2-resident
 __host__ __device__ inline size_t lbs_region_bytes(int KP, int K) {
     const size_t panel = (size_t)LBS_TF * LBS_PITCH(KP) * 2;
-    const size_t epi = ((size_t)K * 32 * 12 + 4 * 32 * 97) * 4;
+    const size_t epi = (size_t)K * 1552;   // (LBS_JSTRIDE)
     return ((panel > epi ? panel : epi) + 15) & ~size_t(15);
 }
 
-// Blend + apply for one 32-frame tile, on the accumulator layout (lane = frame column, register = vertex row).
-// Tl: this frame tile's joint transforms [K][32][12]; sjw: the workgroup's per-vertex influences [128][NWT] as
-// {byte offset of the joint's [32][12] block, weight bits}.  Vertices are processed in pairs with every LDS load of
-// the pair issued before the first use (the influence -> transform address chain is the latency that matters here).
+#define LBS_JSTRIDE 1552   // bytes between the LDS transform blocks of consecutive joints: 32 frames x 48 B + 16 (bank shift)
+
+// Blend + apply + store for one 32-frame tile, on the accumulator layout (lane = vertex column, register = frame row).
+// Tl: this frame tile's joint transforms [K][LBS_JSTRIDE]; jw: this lane's influences {byte offset of the joint block, weight bits}.
 template <int NWT>
 __device__ __forceinline__ void lbs_epilogue(const f32x16& ax, const f32x16& ay, const f32x16& az, float isc,
-                                             const char* Tl, const int2* sjw, const float* vl, float* tb,
-                                             int V, int F, int fbase, int v0, int wv, int lane, float* __restrict__ out) {
-    const int h = lane >> 5, fl = lane & 31;
-    const char* Tlane = Tl + fl * 48;
+                                             const char* Tl, const int2 (&jw)[NWT], float vx, float vy, float vz,
+                                             int V, int F, int fbase, int v, int lane, float* __restrict__ out, int dbg) {
+    const int h = lane >> 5;
 #pragma unroll
-    for (int rg = 0; rg < 16; rg += 4) {
-        // influences of four vertices at once (uniform per half-wave: broadcast reads), then one vertex at a time:
-        // its NWT transforms (3 b128 reads each) are all in flight before the first multiply
-        int2 jw[4][NWT];
+    for (int r = 0; r < 16; ++r) {
+        const int fr = (r & 3) + 8 * (r >> 2) + 4 * h;   // frame inside the tile
+        const char* Tf = Tl + fr * 48;
+        float4 A0[NWT], A1[NWT], A2[NWT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = rg + t;
-            const int vloc = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-            for (int s2 = 0; s2 < NWT; ++s2) jw[t][s2] = sjw[vloc * NWT + s2];
+        for (int s2 = 0; s2 < NWT; ++s2) {
+            const float4* tp = reinterpret_cast<const float4*>(Tf + jw[s2].x);
+            A0[s2] = tp[0]; A1[s2] = tp[1]; A2[s2] = tp[2];
         }
+        float4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = rg + t;
-            const int vw = (r & 3) + 8 * (r >> 2) + 4 * h;   // vertex inside the wave's 32-vertex group
-            const int vloc = wv * 32 + vw;
-            float4 A0[NWT], A1[NWT], A2[NWT];
-#pragma unroll
-            for (int s2 = 0; s2 < NWT; ++s2) {
-                const float4* tp = reinterpret_cast<const float4*>(Tlane + jw[t][s2].x);
-                A0[s2] = tp[0]; A1[s2] = tp[1]; A2[s2] = tp[2];
-            }
-            float4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
-#pragma unroll
-            for (int s2 = 0; s2 < NWT; ++s2) {
-                const float w = __int_as_float(jw[t][s2].y);
-                T0.x += w * A0[s2].x; T0.y += w * A0[s2].y; T0.z += w * A0[s2].z; T0.w += w * A0[s2].w;
-                T1.x += w * A1[s2].x; T1.y += w * A1[s2].y; T1.z += w * A1[s2].z; T1.w += w * A1[s2].w;
-                T2.x += w * A2[s2].x; T2.y += w * A2[s2].y; T2.z += w * A2[s2].z; T2.w += w * A2[s2].w;
-            }
-            const float px = vl[vloc * 3 + 0] + isc * ax[r];
-            const float py = vl[vloc * 3 + 1] + isc * ay[r];
-            const float pz = vl[vloc * 3 + 2] + isc * az[r];
-            // transpose through this wave's LDS buffer: row = frame, 96 contiguous floats = 32 vertices x 3 (+1 pad)
-            tb[fl * 97 + vw * 3 + 0] = T0.x * px + T0.y * py + T0.z * pz + T0.w;
-            tb[fl * 97 + vw * 3 + 1] = T1.x * px + T1.y * py + T1.z * pz + T1.w;
-            tb[fl * 97 + vw * 3 + 2] = T2.x * px + T2.y * py + T2.z * pz + T2.w;
-            __builtin_amdgcn_sched_barrier(0);   // one vertex at a time: bounds the live set (NWT x 12 transform registers)
+        for (int s2 = 0; s2 < NWT; ++s2) {
+            const float w = __int_as_float(jw[s2].y);
+            T0.x += w * A0[s2].x; T0.y += w * A0[s2].y; T0.z += w * A0[s2].z; T0.w += w * A0[s2].w;
+            T1.x += w * A1[s2].x; T1.y += w * A1[s2].y; T1.z += w * A1[s2].z; T1.w += w * A1[s2].w;
+            T2.x += w * A2[s2].x; T2.y += w * A2[s2].y; T2.z += w * A2[s2].z; T2.w += w * A2[s2].w;
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int vbase = v0 + wv * 32;
-    const int nvalid = min(32, V - vbase) * 3;   // floats of this wave's run that exist in the output
-    const int nfr = min(32, F - fbase);
-    for (int fr0 = 0; fr0 < nfr; fr0 += 8) {   // 8 frame rows per batch: all LDS reads first, then the global stores
-        float lo[8], hi[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { lo[k] = tb[(fr0 + k) * 97 + lane]; hi[k] = tb[(fr0 + k) * 97 + min(lane + 64, 95)]; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (fr0 + k < nfr) {
-                float* orow = out + ((size_t)(fbase + fr0 + k) * V + vbase) * 3;
-                if (lane < nvalid) orow[lane] = lo[k];
-                if (lane + 64 < nvalid) orow[lane + 64] = hi[k];
-            }
+        const float px = vx + isc * ax[r], py = vy + isc * ay[r], pz = vz + isc * az[r];
+        const int f = fbase + fr;
+        if (f < F && v < V && !(dbg & 16)) {
+            // one 12-byte store per lane; 32 consecutive lanes = 32 consecutive vertices = one contiguous 384-byte run
+            // (streaming: the 165 MB of output must not evict the posedirs fragments the k-loop re-reads from L2)
+            f32x3u val = {T0.x * px + T0.y * py + T0.z * pz + T0.w, T1.x * px + T1.y * py + T1.z * pz + T1.w,
+                          T2.x * px + T2.y * py + T2.z * pz + T2.w};
+            __builtin_nontemporal_store(val, reinterpret_cast<f32x3u*>(out + ((size_t)f * V + v) * 3));
         }
+        if (r & 1) __builtin_amdgcn_sched_barrier(0);   // two frames at a time: their gathers overlap, the live set stays bounded
     }
 }
 
 template <int NWT>
 __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F, int NVT, int NFT, int NVX,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, int dbg_stop) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8; each XCD owns the vertex tiles {xcd, xcd + 8, ...} and walks
@@ -370,14 +343,10 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     const int vt = xcd + 8 * (rest % NVX), ft = (rest / NVX) * LBS_FCH + fl_t;
     if (vt >= NVT || ft >= NFT) return;
     const int KP = lm.KP, KS = lm.KS, pitch = LBS_PITCH(KP);
-    // LDS: [ region R | sjw | vl ],  R = max(feature panel, transforms of one frame tile + 4 transpose buffers)
+    // LDS: one region R = max(feature panel [main loop], joint transforms of one frame tile [epilogue])
     _Float16* Bp = reinterpret_cast<_Float16*>(lds_raw);                           // main loop: [128][pitch] f16
     const int K = lm.K;
-    char* Tl = lds_raw;                                                            // epilogue: [K][32][12] f32
-    float* tball = reinterpret_cast<float*>(lds_raw) + (size_t)K * 32 * 12;        //           [4 waves][32][97] f32
-    const size_t regionR = lbs_region_bytes(KP, K);
-    int2* sjw = reinterpret_cast<int2*>(lds_raw + regionR);                        // [128][NWT]
-    float* vl = reinterpret_cast<float*>(sjw + LBS_TV * NWT);                      // [128][3]
+    char* Tl = lds_raw;                                                            // epilogue: [K][LBS_JSTRIDE]
     const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
     // stage the feature panel (rows beyond F are zero) and this tile's influences / rest vertices
     {
@@ -397,11 +366,15 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
                 if (lane < chunks) *reinterpret_cast<half8*>(Bp + (size_t)r * pitch + cc * 8) = (f0 + r < F) ? v[k] : z;
             }
         }
-        for (int c = tid; c < LBS_TV * NWT; c += 256) sjw[c] = lm.sjw[(size_t)v0 * NWT + c];
-        for (int c = tid; c < LBS_TV * 3; c += 256) vl[c] = lm.vsh_pad[(size_t)v0 * 3 + c];
     }
+    // this lane's vertex (accumulator column): influences and rest position stay in registers for the whole tile
+    const int vme = v0 + wv * 32 + (lane & 31);
+    int2 jw[NWT];
+#pragma unroll
+    for (int s2 = 0; s2 < NWT; ++s2) jw[s2] = lm.sjw[(size_t)vme * NWT + s2];
+    const float vx = lm.vsh_pad[(size_t)vme * 3 + 0], vy = lm.vsh_pad[(size_t)vme * 3 + 1], vz = lm.vsh_pad[(size_t)vme * 3 + 2];
     __syncthreads();
-    // ---- main loop: acc[i][nt] (32 vertices x 32 frames) += Pfrag(i, ks) x featT(nt, ks)
+    // ---- main loop: acc[i][nt] (32 frames x 32 vertices) += featT(nt, ks) x Pfrag(i, ks)^T
     f32x16 acc[3][4];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -422,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use and the
     //  loop waits vmcnt(0) every k-step -- measured 89 cycles per MFMA instead of 32)
 #define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int i = 0; i < 3; ++i) \
-        acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aS[ASET][i], bS[BSET][nt], acc[i][nt], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+        acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bS[BSET][nt], aS[ASET][i], acc[i][nt], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
     LBS_LOAD_A(0, 0) LBS_LOAD_A(1, 1) LBS_LOAD_A(2, 2) LBS_LOAD_A(3, 3) LBS_LOAD_A(4, 4) LBS_LOAD_B(0, 0)
     int ks = 0;
     for (; ks + 6 <= KS; ks += 6) {
@@ -442,17 +415,20 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
 #undef LBS_LOAD_A
 #undef LBS_LOAD_B
 #undef LBS_MMA
+    // (MOSHII_LBS_STOP=2|4|16|32: phase timing by truncation / ablation -- 2: stop after the k-loop, 4: after the first
+    //  frame tile, 16: no stores, 32: every gather reads joint 0)
+    if (dbg_stop == 2) { if (acc[0][0][0] + acc[1][1][3] + acc[2][2][7] + acc[0][3][9] + acc[1][2][5] + acc[2][3][1] == 123.456f) out[0] = 1.0f; return; }
+    if (dbg_stop & 32) for (int s2 = 0; s2 < NWT; ++s2) jw[s2].x = 0;
     // ---- epilogue, one 32-frame tile at a time.  The NEXT tile's joint transforms are pulled into registers (all of a
     // lane's <= 24 16-byte loads in flight at once) before the current tile is blended, and dropped into LDS behind an
     // LDS-only barrier -- a plain __syncthreads() would also wait for the tile's global stores to be acknowledged.
-    float* tb = tball + (size_t)wv * 32 * 97;
     const float isc = lm.inv_pscale;
     const int nchunk = K * 96;   // 16-byte chunks of one tile's transforms: [j][frame in tile][3]
     float4 tl0, tl1, tl2, tl3, tl4, tl5, tl6, tl7, tl8, tl9, tl10, tl11, tl12, tl13, tl14, tl15, tl16, tl17, tl18, tl19, tl20, tl21, tl22, tl23;   // (named scalars: hipcc keeps an array of these in scratch)
 #define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define LBS_FETCH1(K_, FB) { const int c = min(tid + 256 * K_, nchunk - 1); const int j = c / 96, rem = c - j * 96, fl2 = rem / 3, q = rem - fl2 * 3; \
         tl##K_ = reinterpret_cast<const float4*>(lm.Atr + ((size_t)j * F + min((FB) + fl2, F - 1)) * 12)[q]; }
-#define LBS_PUT1(K_) { const int c = tid + 256 * K_; if (c < nchunk) reinterpret_cast<float4*>(Tl)[c] = tl##K_; }
+#define LBS_PUT1(K_) { const int c = tid + 256 * K_; const int j = c / 96, rem = c - j * 96; if (c < nchunk) *reinterpret_cast<float4*>(Tl + j * LBS_JSTRIDE + rem * 16) = tl##K_; }
 #define LBS_FETCH_TL(FB) { LBS_FETCH1(0, FB) LBS_FETCH1(1, FB) LBS_FETCH1(2, FB) LBS_FETCH1(3, FB) LBS_FETCH1(4, FB) LBS_FETCH1(5, FB) LBS_FETCH1(6, FB) LBS_FETCH1(7, FB) LBS_FETCH1(8, FB) LBS_FETCH1(9, FB) LBS_FETCH1(10, FB) LBS_FETCH1(11, FB) LBS_FETCH1(12, FB) LBS_FETCH1(13, FB) LBS_FETCH1(14, FB) LBS_FETCH1(15, FB) LBS_FETCH1(16, FB) LBS_FETCH1(17, FB) LBS_FETCH1(18, FB) LBS_FETCH1(19, FB) LBS_FETCH1(20, FB) LBS_FETCH1(21, FB) LBS_FETCH1(22, FB) LBS_FETCH1(23, FB) }
 #define LBS_PUT_TL() { LBS_PUT1(0) LBS_PUT1(1) LBS_PUT1(2) LBS_PUT1(3) LBS_PUT1(4) LBS_PUT1(5) LBS_PUT1(6) LBS_PUT1(7) LBS_PUT1(8) LBS_PUT1(9) LBS_PUT1(10) LBS_PUT1(11) LBS_PUT1(12) LBS_PUT1(13) LBS_PUT1(14) LBS_PUT1(15) LBS_PUT1(16) LBS_PUT1(17) LBS_PUT1(18) LBS_PUT1(19) LBS_PUT1(20) LBS_PUT1(21) LBS_PUT1(22) LBS_PUT1(23) }
     LBS_FETCH_TL(f0)
@@ -461,15 +437,16 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     LBS_LDS_BARRIER();
     // (one call per frame tile with a compile-time accumulator index: runtime indexing would push acc[][] to scratch)
     LBS_FETCH_TL(f0 + 32)
-    lbs_epilogue<NWT>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, sjw, vl, tb, V, F, f0 + 0, v0, wv, lane, out);
+    lbs_epilogue<NWT>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, V, F, f0 + 0, vme, lane, out, dbg_stop);
+    if (dbg_stop == 4) { if (acc[1][1][3] + acc[2][2][7] + acc[0][3][9] + acc[0][1][0] + acc[2][1][1] == 123.456f) out[0] = 1.0f; return; }
     LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
     LBS_FETCH_TL(f0 + 64)
-    lbs_epilogue<NWT>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, sjw, vl, tb, V, F, f0 + 32, v0, wv, lane, out);
+    lbs_epilogue<NWT>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, V, F, f0 + 32, vme, lane, out, dbg_stop);
     LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
     LBS_FETCH_TL(f0 + 96)
-    lbs_epilogue<NWT>(acc[0][2], acc[1][2], acc[2][2], isc, Tl, sjw, vl, tb, V, F, f0 + 64, v0, wv, lane, out);
+    lbs_epilogue<NWT>(acc[0][2], acc[1][2], acc[2][2], isc, Tl, jw, vx, vy, vz, V, F, f0 + 64, vme, lane, out, dbg_stop);
     LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
-    lbs_epilogue<NWT>(acc[0][3], acc[1][3], acc[2][3], isc, Tl, sjw, vl, tb, V, F, f0 + 96, v0, wv, lane, out);
+    lbs_epilogue<NWT>(acc[0][3], acc[1][3], acc[2][3], isc, Tl, jw, vx, vy, vz, V, F, f0 + 96, vme, lane, out, dbg_stop);
 #undef LBS_FETCH_TL
 #undef LBS_PUT_TL
 #undef LBS_FETCH1
@@ -529,7 +506,7 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
                 if (w != 0.0) {
                     const float wf = (float)w;
                     int bits; memcpy(&bits, &wf, 4);
-                    sjw[((size_t)v * NWT + c) * 2 + 0] = j * 32 * 48;
+                    sjw[((size_t)v * NWT + c) * 2 + 0] = j * 1552;   // LBS_JSTRIDE
                     sjw[((size_t)v * NWT + c) * 2 + 1] = bits;
                     ++c;
                 }
@@ -593,11 +570,13 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     const int NVX = (NVT + 7) / 8;                         // vertex tiles per XCD
     const int NCH = (NFT + LBS_FCH - 1) / LBS_FCH;         // frame chunks
     const int grid = 8 * NCH * NVX * LBS_FCH;
-    const size_t lds = lbs_region_bytes(lm.KP, lm.K) + (size_t)LBS_TV * lm.NW * 8 + (size_t)LBS_TV * 3 * 4;
+    const size_t lds = lbs_region_bytes(lm.KP, lm.K);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = (lm.NW == 4) ? k_lbs_mfma<4> : k_lbs_mfma<8>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, lm, md->V, F, NVT, NFT, NVX, verts);
+    int dbg_stop = 0;
+    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg_stop = atoi(es);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, lm, md->V, F, NVT, NFT, NVX, verts, dbg_stop);
     return hipGetLastError();
 }
