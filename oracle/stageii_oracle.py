@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- float64 NumPy restatement of MoSh++ Stage-II.
 
-*** PARITY UNPINNED ***  The reference (nghorbani/moshpp v3.0) delegates all
+*** PARITY PARTLY PINNED ***  The reference (nghorbani/moshpp v3.0) delegates the
 arithmetic of this path to third-party packages that are neither vendored in
 /root/reference nor installable in this environment (no network):
 
@@ -9,11 +9,19 @@ arithmetic of this path to third-party packages that are neither vendored in
   * cv2.Rodrigues, sklearn KD-tree
 
 and the reference has no tests, golden vectors or fixtures.
-This file restates the *published* algorithms of those packages (SMPL's public
-`lbs.py`/`posemapper.py`/`verts.py`, chumpy's `optimization_internal.py`) and
-anchors them on the reference's own call sites.  It is validated by internal
-self-checks only (finite differences, scipy least-squares minimum, ground-truth
-recovery) -- see tests/test_oracle_*.py.
+
+PINNED to the reference's own code, executed in the build container (fixtures + generating
+scripts under tests/golden/, checked by tests/test_ref_golden.py and tests/test_host_logic.py):
+  * transformed_coeffs / markers_from_verts  <- TransformedCoeffs / TransformedLms values (transformed_lm.py:45-162,
+    incl. the sklearn kd-tree 8-NN and the SMPL-X eyeball exclusion)
+  * prepare_gmm_prior / gmm_prior_eval       <- create_gmm_body_prior + MaxMixtureComplete values (gmm_prior_ch.py:42-134)
+  * rigid_landmark_transform                 <- rigid_transformations.py:39-69
+  * (host package) C3D reader                <- the reference's vendored py-c3d writer (tools/c3d.py)
+UNPINNED (third-party code absent): the SMPL forward + its pose Jacobian, the node Jacobians, and
+`minimize_dogleg`.  These restate the *published* algorithms (SMPL's public `lbs.py`/`posemapper.py`/
+`verts.py`, chumpy's `optimization_internal.py`), anchored on the reference's call sites and validated by
+internal self-checks only (finite differences, scipy least-squares minimum, ground-truth recovery) --
+see tests/test_oracle.py.
 
 Reference anchors (all relative to /root/reference/src/moshpp):
   chmosh.py:458-741                    Stage-II schedule, weights, free variables, outputs

@@ -1,0 +1,74 @@
+"""Seeded inputs shared by tests/golden/make_ref_golden.py (which feeds them to the reference's own classes)
+and tests/test_ref_golden.py (which feeds them to the oracle and to the host package).  No dependency on
+/root/reference.  Everything that is cheap to store is kept in ref_inputs.npz so that the fixture does not
+depend on a random stream; the canonical bodies are the deterministic synthetic templates."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_SMALL = os.path.join(HERE, 'ref_inputs.npz')
+
+
+def _make_small():
+    from moshpp_amd import synth
+    rng = np.random.default_rng(20260926)
+    out = {}
+    for tag, M in (('smplh', 53), ('smplx', 89)):
+        dd = synth.synth_model(tag, seed=0)
+        v = dd['v_template']
+        vids = synth.pick_marker_vids(dd, M, seed=3, body_only=False)
+        if tag == 'smplx':
+            vids[:6] = [9383, 9500, 9929, 10000, 10200, 10474]      # eyeball vertices: must be skipped by the kNN
+        d = rng.normal(0, 1, (M, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        out[f'{tag}_markers_latent'] = v[vids] + 0.0095 * d
+    G = 4
+    gmm = synth.synth_gmm_prior(seed=5, n_gaussians=G)
+    out['gmm_means'], out['gmm_covars'], out['gmm_weights'] = gmm['means'], gmm['covars'], gmm['weights']
+    xs = rng.normal(0, 0.25, (8, 69))
+    xs[:G] = gmm['means'] + rng.normal(0, 0.05, (G, 69))           # one sample near every component
+    out['prior_xs'] = xs
+    a = rng.normal(0, 0.4, (5, 3, 41))
+    b = np.empty_like(a)
+    for i in range(5):
+        q, _ = np.linalg.qr(rng.normal(0, 1, (3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        b[i] = q.dot(a[i]) + rng.normal(0, 1, (3, 1)) + rng.normal(0, 0.002, (3, 41))
+    b[1][:, [2, 7, 30]] = np.nan                                     # occluded markers: NaN -> copied from a (:53)
+    a[4] = a[4] * np.array([[1.0], [1.0], [1e-9]])                   # near-planar set: exercises the det<0 branch
+    b[4] = -a[4][:, ::-1] + 0.3
+    out['rigid_a'], out['rigid_b'] = a, b
+    np.savez_compressed(_SMALL, **out)
+    return out
+
+
+def _small():
+    if not os.path.exists(_SMALL):
+        _make_small()
+    return np.load(_SMALL)
+
+
+def posed_body_of(can_body):
+    """A deterministic non-rigid deformation of the canonical body (elementwise arithmetic only)."""
+    c, s = np.cos(0.7), np.sin(0.7)
+    R = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]).dot(np.array([[1.0, 0, 0], [0, 0.8, -0.6], [0, 0.6, 0.8]]))
+    warp = 0.03 * np.sin(7.0 * can_body[:, [1, 2, 0]]) + 0.02 * np.cos(5.0 * can_body[:, [2, 0, 1]])
+    return (can_body + warp).dot(R.T) + np.array([0.3, -1.1, 0.45])
+
+
+def attach_inputs(tag):
+    from moshpp_amd import synth
+    can_body = np.ascontiguousarray(synth.synth_model(tag, seed=0)['v_template'], dtype=np.float64)
+    return can_body, posed_body_of(can_body), _small()[f'{tag}_markers_latent']
+
+
+def prior_inputs():
+    z = _small()
+    return dict(means=z['gmm_means'], covars=z['gmm_covars'], weights=z['gmm_weights']), z['prior_xs']
+
+
+def rigid_inputs():
+    z = _small()
+    return list(zip(z['rigid_a'], z['rigid_b']))

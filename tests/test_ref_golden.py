@@ -1,0 +1,74 @@
+"""Pins the oracle and the host package to outputs of the REFERENCE'S OWN classes, executed in the build
+container by tests/golden/make_ref_golden.py (see its header for what was run and how):
+TransformedCoeffs / TransformedLms (transformed_lm.py:45-162), create_gmm_body_prior + MaxMixtureComplete
+(prior/gmm_prior_ch.py:42-134), rigid_landmark_transform (rigid_transformations.py:39-69).
+The fixtures are values only; Jacobians of these nodes are checked by finite differences in test_oracle.py."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import stageii_oracle as so
+from tests.golden import ref_inputs
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_nodes.npz'))
+EYEBALLS = np.arange(9383, 10475)
+
+
+@pytest.mark.parametrize('tag', ['smplh', 'smplx'])
+def test_oracle_attachment_matches_reference_classes(tag):
+    can_body, posed, latent = ref_inputs.attach_inputs(tag)
+    closest, coef = so.transformed_coeffs(can_body, latent, exclude_vids=EYEBALLS if tag == 'smplx' else None)
+    assert np.array_equal(closest, G[f'{tag}_closest'])            # integer work: exact
+    assert np.abs(coef - G[f'{tag}_coefs']).max() < 1e-14
+    if tag == 'smplx':
+        assert closest.max() < 9383                                # no marker is attached to an eyeball vertex
+    mk = so.markers_from_verts(coef, posed[closest[:, 0]], posed[closest[:, 1]], posed[closest[:, 2]])
+    assert np.abs(mk - G[f'{tag}_markers']).max() < 1e-13
+
+
+@pytest.mark.parametrize('tag', ['smplh', 'smplx'])
+def test_host_attachment_matches_reference_classes(tag):
+    from moshpp_amd.transformed_lm import TransformedCoeffs
+    can_body, _, latent = ref_inputs.attach_inputs(tag)
+    tc = TransformedCoeffs(can_body, latent)
+    assert np.array_equal(tc.closest, G[f'{tag}_closest'])
+    assert np.abs(tc.coef - G[f'{tag}_coefs']).max() < 1e-14
+
+
+@pytest.mark.parametrize('npose', [63, 69])
+def test_oracle_prior_matches_reference_classes(npose):
+    gmm, xs = ref_inputs.prior_inputs()
+    p = so.prepare_gmm_prior(gmm, npose)
+    assert np.abs(p['chols'] - G[f'prior{npose}_chols']).max() < 1e-9 * np.abs(G[f'prior{npose}_chols']).max()
+    assert np.allclose(p['weights'], G[f'prior{npose}_weights'], rtol=1e-12, atol=0)
+    assert np.array_equal(p['means'], G[f'prior{npose}_means'])
+    for x, k_ref, r_ref in zip(xs, G[f'prior{npose}_k'], G[f'prior{npose}_r']):
+        r, k = so.gmm_prior_eval(p, x[:npose])
+        assert k == k_ref
+        assert r.shape == (npose + 1,)
+        assert np.abs(r - r_ref).max() < 1e-9 * max(1.0, np.abs(r_ref).max())
+    assert len(set(G[f'prior{npose}_k'].tolist())) > 1              # the max-mixture switch is exercised
+
+
+@pytest.mark.parametrize('exclude_hands,npose', [(True, 63), (False, 69)])
+def test_host_prior_loader_matches_reference_classes(tmp_path, exclude_hands, npose):
+    from moshpp_amd.prior import create_gmm_body_prior
+    gmm, _ = ref_inputs.prior_inputs()
+    fname = tmp_path / 'pose_body_prior.pkl'
+    with open(fname, 'wb') as fh:
+        pickle.dump(gmm, fh, protocol=2)
+    p = create_gmm_body_prior(str(fname), exclude_hands=exclude_hands)
+    chols = np.asarray(p['chols'] if isinstance(p, dict) else p.chols)
+    weights = np.asarray(p['weights'] if isinstance(p, dict) else p.weights)
+    assert np.abs(chols - G[f'prior{npose}_chols']).max() < 1e-9 * np.abs(G[f'prior{npose}_chols']).max()
+    assert np.allclose(weights, G[f'prior{npose}_weights'], rtol=1e-12, atol=0)
+
+
+def test_oracle_rigid_transform_matches_reference_function():
+    for (a, b), R_ref, T_ref in zip(ref_inputs.rigid_inputs(), G['rigid_R'], G['rigid_T']):
+        R, T = so.rigid_landmark_transform(a, b)
+        assert np.abs(R - R_ref).max() < 1e-12
+        assert np.abs(T.ravel() - T_ref).max() < 1e-12
+        assert abs(np.linalg.det(R) - 1.0) < 1e-12
