@@ -1,0 +1,170 @@
+"""What the reference does with the Stage-II result: merge it with the Stage-I data, pickle it, export it in the
+AMASS npz layout SOMA reads.
+
+Mirrors, for the Stage-II side only:
+  * `MoSh.mosh_stageii`            reference src/moshpp/mosh_head.py:268-301
+  * `MoSh.load_as_amass_npz`       reference src/moshpp/mosh_head.py:444-541
+  * `turn_fullpose_into_parts`     reference src/moshpp/tools/run_tools.py:70-85
+
+Stage-I (marker-layout optimisation, `MoSh.mosh_stagei`, :200-266) is not part of this package: its result
+(`*_stagei.pkl`, keys `markers_latent`, `latent_labels`, `betas`, `marker_meta`, `markers_latent_vids`,
+`stagei_debug_details`, optional `v_template_fname`) is an input here, as a file or a dict.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import os.path as osp
+import pickle
+import time
+from datetime import timedelta
+
+import numpy as np
+
+logger = logging.getLogger('moshpp_amd')
+
+
+def _cfg_container(cfg):
+    """cfg -> plain nested dict (`OmegaConf.to_container(cfg, resolve=True, enum_to_str=True)`, mosh_head.py:292-293)."""
+    if hasattr(cfg, 'to_container'):
+        return cfg.to_container()
+    try:
+        from omegaconf import OmegaConf
+        return OmegaConf.to_container(cfg, resolve=True, enum_to_str=True)
+    except ImportError:
+        return {k: (_cfg_container(v) if hasattr(v, 'items') else v) for k, v in cfg.items()}
+
+
+def _makepath(fname):
+    d = osp.dirname(fname)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    return fname
+
+
+def turn_fullpose_into_parts(fullpose, surface_model_type):
+    """fullpose[T, 3K] -> {'root_orient', 'pose_body', 'pose_hand', 'pose_jaw', 'pose_eye'} as the AMASS npz names
+    them (run_tools.py:70-85): SMPL* body = 3:66; SMPL-H hands = 66:; SMPL-X jaw 66:69, eyes 69:75, hands 75:;
+    MANO hand = 3:; animal/object models keep everything after the root in 'pose_body'."""
+    res = {'root_orient': fullpose[:, :3]}
+    if 'smpl' in surface_model_type:
+        res['pose_body'] = fullpose[:, 3:66]
+    elif any(text in surface_model_type for text in ('animal', 'object')):
+        res['pose_body'] = fullpose[:, 3:]
+    if 'smplh' in surface_model_type:
+        res['pose_hand'] = fullpose[:, 66:]
+    elif 'smplx' in surface_model_type:
+        res['pose_hand'] = fullpose[:, 75:]
+        res['pose_jaw'] = fullpose[:, 66:69]
+        res['pose_eye'] = fullpose[:, 69:75]
+    elif 'mano' in surface_model_type:
+        res['pose_hand'] = fullpose[:, 3:]
+    return res
+
+
+def run_stageii(stagei_data_or_fname, cfg, stageii_fname=None, mosh_stageii_func=None):
+    """`MoSh.mosh_stageii` (mosh_head.py:268-301) without the class around it.
+
+    Loads `stageii_fname` if it already exists (:272-274); otherwise calls `mosh_stageii_func` (default: the
+    libmoshii drop-in) with exactly the keyword arguments the reference passes (:280-286), merges the Stage-I
+    dict into the result (:289), records `stageii_elapsed_time` and the resolved cfg (:291-293) and pickles it.
+    Returns the stageii dict."""
+    if isinstance(stagei_data_or_fname, dict):
+        stagei_data = stagei_data_or_fname
+    else:
+        if not osp.exists(stagei_data_or_fname):
+            raise ValueError(f'stagei_fname results could not be found: {stagei_data_or_fname}. '
+                             f'please run stagei first.')
+        with open(stagei_data_or_fname, 'rb') as fh:
+            stagei_data = pickle.load(fh)
+    if stageii_fname and osp.exists(stageii_fname):
+        logger.info(f'loading mosh stageii results from {stageii_fname}')
+        with open(stageii_fname, 'rb') as fh:
+            return pickle.load(fh)
+    if mosh_stageii_func is None:
+        from .chmosh import mosh_stageii as mosh_stageii_func
+    logger.info(f'attempting mosh stageii to create {stageii_fname}')
+    tm = time.time()
+    stageii_data = mosh_stageii_func(mocap_fname=cfg.mocap.fname,
+                                     cfg=cfg,
+                                     markers_latent=stagei_data['markers_latent'],
+                                     latent_labels=stagei_data['latent_labels'],
+                                     betas=stagei_data['betas'],
+                                     marker_meta=stagei_data['marker_meta'],
+                                     v_template_fname=stagei_data.get('v_template_fname'))
+    stageii_elapsed_time = time.time() - tm
+    stageii_data.update(stagei_data)
+    stageii_data['stageii_debug_details']['stageii_elapsed_time'] = stageii_elapsed_time
+    stageii_data['stageii_debug_details']['cfg'] = _cfg_container(cfg)
+    if stageii_fname:
+        with open(_makepath(stageii_fname), 'wb') as fh:
+            pickle.dump(stageii_data, fh)
+        logger.debug(f'created stageii_fname: {stageii_fname}')
+    logger.debug(f'finished mosh stageii in {timedelta(seconds=stageii_elapsed_time)}')
+    return stageii_data
+
+
+_STAGEI_NPZ_KEYS = ('gender', 'surface_model_type', 'markers_latent', 'latent_labels', 'markers_latent_vids', 'betas',
+                    'v_template')
+
+
+def load_as_amass_npz(stageii_pkl_data_or_fname, stageii_npz_fname=None, stagei_npz_fname=None,
+                      include_markers=False, include_extra_details=False) -> dict:
+    """`MoSh.load_as_amass_npz` (mosh_head.py:444-541): same keys, same conditions, same side files.
+
+    Existing npz files are not overwritten (:521, 528).  The pre-2021 pickle format handled by
+    `load_as_amass_npz_legacy` (:342-442) is not supported (raises)."""
+    if isinstance(stageii_pkl_data_or_fname, dict):
+        pkl = stageii_pkl_data_or_fname
+    else:
+        try:
+            with open(stageii_pkl_data_or_fname, 'rb') as fh:
+                pkl = pickle.load(fh)
+        except UnicodeDecodeError as e:
+            raise NotImplementedError('legacy (python-2 era) stageii pickles are not supported') from e
+    dbg = pkl['stageii_debug_details']
+    cfg = dbg['cfg']
+    sm, mp = cfg['surface_model'], cfg['moshpp']
+    out = {
+        'gender': sm['gender'],
+        'surface_model_type': sm['type'],
+        'mocap_frame_rate': dbg['mocap_frame_rate'],
+        'mocap_time_length': dbg['mocap_time_length'],
+        'markers_latent': pkl['markers_latent'],
+        'latent_labels': pkl['latent_labels'],
+        'markers_latent_vids': pkl['markers_latent_vids'],
+        'trans': pkl['trans'],
+        'poses': pkl['fullpose'],
+    }
+    if include_extra_details:
+        out['surface_model_fname'] = sm['fname']
+    if 'v_template' in pkl['stagei_debug_details']:
+        out['v_template'] = pkl['stagei_debug_details']['v_template']
+    if mp['optimize_betas']:
+        out['betas'] = pkl['betas'][:sm['num_betas']]
+        out['num_betas'] = sm['num_betas']
+    if mp['optimize_dynamics']:
+        out['dmpls'] = pkl['dmpls'][:sm['num_dmpls']]        # (sic) the reference slices the frame axis here (:487)
+        out['num_dmpls'] = sm['num_dmpls']
+    if mp['optimize_face']:
+        out['expression'] = pkl['expression'][:, :sm['num_expressions']]
+        out['num_expressions'] = sm['num_expressions']
+    out.update(turn_fullpose_into_parts(pkl['fullpose'], sm['type']))
+    if include_markers:
+        out['markers'] = dbg['markers_orig']
+        out['labels'] = dbg['labels_orig']
+        out['markers_obs'] = dbg['markers_obs']
+        out['labels_obs'] = dbg['labels_obs']
+        out['markers_sim'] = dbg['markers_sim']
+        out['marker_meta'] = pkl['marker_meta']
+        out['num_markers'] = out['markers'].shape[1]
+    if stageii_npz_fname:
+        if not osp.exists(stageii_npz_fname):
+            np.savez(_makepath(str(stageii_npz_fname)), **out)
+            logger.info(f'created amass_stageii_npz_fname: {stageii_npz_fname}')
+        if stagei_npz_fname is None:
+            stagei_npz_fname = osp.join(osp.dirname(str(stageii_npz_fname)), f"{sm['gender']}_stagei.npz")
+        if not osp.exists(stagei_npz_fname):
+            np.savez(_makepath(str(stagei_npz_fname)), **{k: v for k, v in out.items() if k in _STAGEI_NPZ_KEYS})
+            logger.info(f'created amass_stagei_npz_fname: {stagei_npz_fname}')
+    return out

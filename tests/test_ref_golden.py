@@ -72,3 +72,15 @@ def test_oracle_rigid_transform_matches_reference_function():
         assert np.abs(R - R_ref).max() < 1e-12
         assert np.abs(T.ravel() - T_ref).max() < 1e-12
         assert abs(np.linalg.det(R) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize('mt,P', [('smpl', 72), ('smplh', 156), ('smplx', 165), ('mano', 48), ('animal_horse', 105),
+                                  ('object', 6)])
+def test_amass_part_split_matches_reference_function(mt, P):
+    from moshpp_amd.mosh_head import turn_fullpose_into_parts
+    parts = turn_fullpose_into_parts(np.arange(P, dtype=np.float64)[None].repeat(3, 0), mt)
+    ref_keys = sorted(k[len(f'parts_{mt}_'):] for k in G.files if k.startswith(f'parts_{mt}_'))
+    assert sorted(parts) == ref_keys
+    for k, v in parts.items():
+        assert v.shape[0] == 3
+        assert np.array_equal(v[0].astype(np.int64), G[f'parts_{mt}_{k}'])
