@@ -156,6 +156,18 @@ def prepare_model(model, betas=None):
     return m
 
 
+def set_free_shape(m, start, count):
+    """Declare shapedirs columns [start, start+count) as per-frame free variables of Stage-II Step 2: the
+    expression coefficients `opt_model.betas[exp_start:exp_start+num_expressions]` (chmosh.py:565-567, 687-688) or the
+    DMPL coefficients `opt_model.betas[num_betas:num_betas+num_dmpls]` (:513-514, 698-699).  The coefficients act as an
+    OFFSET on top of the betas frozen by prepare_model.  Both v_shaped and the regressed joints move with them
+    (smpl_fast_derivatives.py:186-191): S_free[V,3,E] and JS = J_regressor . S_free [K,3,E]."""
+    m['shape_start'], m['E'] = int(start), int(count)
+    m['S_free'] = np.ascontiguousarray(m['shapedirs'][:, :, start:start + count])
+    m['JS'] = np.einsum('kv,vie->kie', m['J_regressor'], m['S_free'])
+    return m
+
+
 def fullpose_from_pose(m, pose):
     """smpl_fast_derivatives.py:194-204: fullpose = [pose[:body_dof], hands_mean + pose_hand . comps]."""
     pose = np.asarray(pose, dtype=np.float64)
@@ -176,10 +188,11 @@ def pose_map_matrix(m):
     return mm
 
 
-def joint_transforms(m, fullpose):
+def joint_transforms(m, fullpose, J=None):
     """global_rigid_transformation (Appendix A.1): world rotations Rw[K,3,3], joint world
-    positions tw[K,3] (excluding trans); also local R, left Jacobians Jl."""
-    K, parents, J = m['K'], m['parents'], m['J']
+    positions tw[K,3] (excluding trans); also local R, left Jacobians Jl.  `J` overrides the frozen joints."""
+    K, parents = m['K'], m['parents']
+    J = m['J'] if J is None else J
     R, Jl = rodrigues(fullpose.reshape(K, 3))
     Rw = np.zeros((K, 3, 3))
     tw = np.zeros((K, 3))
@@ -192,36 +205,51 @@ def joint_transforms(m, fullpose):
     return R, Jl, Rw, tw
 
 
-def verts_forward(m, fullpose, trans, vids=None):
+def _shaped(m, sl, shp):
+    """v_shaped rows and regressed joints at the free shape coefficients `shp` (None: the frozen ones)."""
+    if shp is None:
+        return m['v_shaped'][sl], m['J']
+    shp = np.asarray(shp, dtype=np.float64)
+    return m['v_shaped'][sl] + m['S_free'][sl].dot(shp), m['J'] + m['JS'].dot(shp)
+
+
+def verts_forward(m, fullpose, trans, vids=None, shp=None):
     """LBS forward for the vertex subset `vids` (all if None):
     v = sum_j w_vj (Rw_j (v_posed - J_j) + tw_j) + trans, v_posed = v_shaped + posedirs.vec(R_j - I)."""
-    R, Jl, Rw, tw = joint_transforms(m, fullpose)
-    feat = (R[1:] - np.eye(3)).reshape(-1)
     sl = slice(None) if vids is None else vids
-    v_posed = m['v_shaped'][sl] + m['posedirs'][sl].dot(feat)
+    v_shaped, J = _shaped(m, sl, shp)
+    R, Jl, Rw, tw = joint_transforms(m, fullpose, J)
+    feat = (R[1:] - np.eye(3)).reshape(-1)
+    v_posed = v_shaped + m['posedirs'][sl].dot(feat)
     w = m['weights'][sl]
     # T = sum_j w_j A_j, A_j = [Rw_j | tw_j - Rw_j J_j]
     Arot = Rw
-    Atr = tw - np.einsum('kab,kb->ka', Rw, m['J'])
+    Atr = tw - np.einsum('kab,kb->ka', Rw, J)
     Trot = np.einsum('nk,kab->nab', w, Arot)
     Ttr = w.dot(Atr)
     v = np.einsum('nab,nb->na', Trot, v_posed) + Ttr + np.asarray(trans, dtype=np.float64)
     return v
 
 
-def verts_jacobian(m, fullpose, trans, vids):
-    """Value and analytic Jacobian of the vertex subset wrt every fullpose dof.
+def verts_jacobian(m, fullpose, trans, vids, shp=None, want_shape=False):
+    """Value and analytic Jacobian of the vertex subset wrt every fullpose dof (and, with want_shape, wrt the
+    free shape coefficients: psbody's `lbs_derivatives_wrt_shape`, smpl_fast_derivatives.py:260-261, restated).
 
     Returns v[n,3], dv[n,3,P].  For dof (k,c):
       dv = omega_kc x (S_k - W_k tw_k)  +  Trot . (posedirs[v,:,9(k-1):9k] . vec(dR_k/dtheta_c))   (k>=1 for 2nd term)
     with omega_kc = Rw_par(k) Jl_k[:,c], S_k = sum_{j in subtree(k)} w_j x_j, x_j = Rw_j (v_posed-J_j)+tw_j,
-    W_k = sum_{j in subtree(k)} w_j.  d/dtrans = I (not returned)."""
-    K, parents, J = m['K'], m['parents'], m['J']
-    R, Jl, Rw, tw = joint_transforms(m, fullpose)
+    W_k = sum_{j in subtree(k)} w_j.  d/dtrans = I (not returned).
+
+    Shape: with s the coefficients, dv_posed/ds_e = S_e(v), dJ_j/ds_e = JS_je, and the joint world positions obey
+    dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par); hence
+      dv/ds_e = Trot . S_e(v) + sum_j w_j q_je,   q_je = dt_je - Rw_j JS_je."""
+    K, parents = m['K'], m['parents']
+    v_shaped, J = _shaped(m, vids, shp)
+    R, Jl, Rw, tw = joint_transforms(m, fullpose, J)
     feat = (R[1:] - np.eye(3)).reshape(-1)
     Pd = m['posedirs'][vids]  # n,3,9(K-1)
     n = Pd.shape[0]
-    v_posed = m['v_shaped'][vids] + Pd.dot(feat)
+    v_posed = v_shaped + Pd.dot(feat)
     w = m['weights'][vids]
     x = np.einsum('kab,nkb->nka', Rw, v_posed[:, None, :] - J[None]) + tw[None]  # n,K,3
     v = np.einsum('nk,nka->na', w, x) + np.asarray(trans, dtype=np.float64)
@@ -245,7 +273,17 @@ def verts_jacobian(m, fullpose, trans, vids):
     dv = dv_art
     dv[:, 1:] += dv_cor
     dv = np.transpose(dv, (0, 3, 1, 2)).reshape(n, 3, 3 * K)
-    return v, dv
+    if not want_shape:
+        return v, dv
+    JS = m['JS']  # K,3,E
+    dt = np.zeros_like(JS)
+    dt[0] = JS[0]
+    for j in range(1, K):
+        p = parents[j]
+        dt[j] = dt[p] + Rw[p].dot(JS[j] - JS[p])
+    q = dt - np.einsum('kab,kbe->kae', Rw, JS)
+    dv_shape = np.einsum('nab,nbe->nae', Trot, m['S_free'][vids]) + np.einsum('nk,kae->nae', w, q)
+    return v, dv, dv_shape
 
 
 def verts_jacobian_reference_cost(m, fullpose, trans, vids):
@@ -493,7 +531,12 @@ def stageii_weights_default():
                 stageii_wt_poseB=1.6, stageii_wt_poseH=1.0, stageii_wt_poseF=1.0, stageii_wt_annealing=2.5)
 
 
-def pose_id_sets(model_type, NP, optimize_fingers=False, optimize_toes=False):
+def face_pose_ids(model_type, optimize_face):
+    """pose_face_ids (chmosh.py:560-563): the jaw, pose ids 66:69 of SMPL-X, when optimize_face."""
+    return list(range(66, 69)) if (model_type == 'smplx' and optimize_face) else []
+
+
+def pose_id_sets(model_type, NP, optimize_fingers=False, optimize_toes=False, optimize_face=False):
     """chmosh.py:546-579, 645-647, 665-667, 676-692.  Returns (root, body, finger, step1_ids, step2_ids)."""
     allp = list(range(NP))
     root = allp[:3]
@@ -518,13 +561,15 @@ def pose_id_sets(model_type, NP, optimize_fingers=False, optimize_toes=False):
     step2 = list(step1)
     if optimize_fingers:
         step2 = step2 + finger
+    step2 = step2 + face_pose_ids(model_type, optimize_face)   # :685-689
     step2 = sorted(set(step2))
     return root, body, finger, step1, step2
 
 
 class StageIIObjective:
-    """One frame's residual dict (chmosh.py:612-626, 681-683) over x = [trans, pose[free_ids]]
-    (the ChInputsStacked view: chmosh.py:649, 668, 692)."""
+    """One frame's residual dict (chmosh.py:612-626, 681-699) over x = [trans, pose[free_ids], shape (if free)]
+    (the ChInputsStacked view: chmosh.py:649, 668, 692; the reference stacks [trans, v_face_exp, pose[ids]] -- the
+    column order only permutes the normal equations)."""
 
     def __init__(self, m, closest, coef, prior, body_ids, reference_cost=False):
         self.m = m
@@ -546,33 +591,52 @@ class StageIIObjective:
         self.finger_ids = None
         self.wt_poseH = 0.0
         self.free_ids = None
+        # Step-2 extras: jaw pose term, free shape coefficients (expression or DMPL) with their regulariser and the
+        # "stay" term (chmosh.py:685-699)
+        self.face_ids = None
+        self.wt_poseF = 0.0
+        self.shp = np.zeros(m['E']) if 'E' in m else None
+        self.shape_free = False
+        self.wt_shape = 0.0
+        self.shp_anchor = None
+        self.wt_stay = 0.0
 
     # -- state ----------------------------------------------------------------------------
     def x(self):
-        return np.concatenate([self.trans, self.pose[self.free_ids]])
+        parts = [self.trans, self.pose[self.free_ids]]
+        if self.shape_free:
+            parts.append(self.shp)
+        return np.concatenate(parts)
 
     def set_x(self, x):
+        nf = len(self.free_ids)
         self.trans = np.array(x[:3])
-        self.pose[self.free_ids] = x[3:]
+        self.pose[self.free_ids] = x[3:3 + nf]
+        if self.shape_free:
+            self.shp = np.array(x[3 + nf:])
 
     def _unpack(self, x):
+        nf = len(self.free_ids)
         pose = self.pose.copy()
-        pose[self.free_ids] = x[3:]
+        pose[self.free_ids] = x[3:3 + nf]
+        self._shp_eval = np.asarray(x[3 + nf:]) if self.shape_free else self.shp
         return pose, np.asarray(x[:3])
 
     # -- pieces ---------------------------------------------------------------------------
-    def markers_sim(self, pose=None, trans=None):
+    def markers_sim(self, pose=None, trans=None, shp=None):
         pose = self.pose if pose is None else pose
         trans = self.trans if trans is None else trans
+        shp = self.shp if shp is None else shp
         fp = fullpose_from_pose(self.m, pose)
         vids = self.closest.reshape(-1)
-        v = verts_forward(self.m, fp, trans, vids).reshape(-1, 3, 3)
+        v = verts_forward(self.m, fp, trans, vids, shp=shp).reshape(-1, 3, 3)
         return markers_from_verts(self.coef, v[:, 0], v[:, 1], v[:, 2])
 
-    def terms(self, pose, trans):
-        """Ordered dict of residual blocks at (pose, trans)."""
+    def terms(self, pose, trans, shp=None):
+        """Ordered dict of residual blocks at (pose, trans, shape)."""
         out = {}
-        sim = self.markers_sim(pose, trans)
+        shp = self.shp if shp is None else shp
+        sim = self.markers_sim(pose, trans, shp)
         out['data'] = ((sim[self.vis] - self.obs[self.vis]) * self.wt_data).ravel()
         if len(self.body_ids):
             fp = fullpose_from_pose(self.m, pose)  # pose[body ids] are identity-mapped dofs
@@ -583,11 +647,17 @@ class StageIIObjective:
             out['velo'] = (pose - self.velo_target) * self.wt_velo
         if self.finger_ids is not None:
             out['poseH'] = pose[self.finger_ids] * self.wt_poseH
+        if self.face_ids is not None:
+            out['poseF'] = pose[self.face_ids] * self.wt_poseF
+        if self.shape_free:
+            if self.shp_anchor is not None and self.wt_stay != 0.0:
+                out['shape_stay'] = (shp - self.shp_anchor) * self.wt_stay
+            out['shape'] = shp * self.wt_shape
         return out
 
     def r(self, x):
         pose, trans = self._unpack(x)
-        return np.concatenate(list(self.terms(pose, trans).values()))
+        return np.concatenate(list(self.terms(pose, trans, self._shp_eval).values()))
 
     def J(self, x):
         pose, trans = self._unpack(x)
@@ -596,11 +666,17 @@ class StageIIObjective:
         free = np.asarray(self.free_ids, dtype=np.int64)
         fp = fullpose_from_pose(m, pose)
         vids = self.closest.reshape(-1)
+        shp = self._shp_eval
+        E = len(shp) if self.shape_free else 0
+        dv_shape = None
         if self.reference_cost:
             v, dv = verts_jacobian_reference_cost(m, fp, trans, vids)
             dv_pose = np.matmul(dv.reshape(-1, m['P']), self.mm).reshape(len(vids), 3, NP)
+        elif E:
+            v, dv, dv_shape = verts_jacobian(m, fp, trans, vids, shp=shp, want_shape=True)
+            dv_pose = dv.dot(self.mm)
         else:
-            v, dv = verts_jacobian(m, fp, trans, vids)
+            v, dv = verts_jacobian(m, fp, trans, vids, shp=shp)
             dv_pose = dv.dot(self.mm)  # n,3,NP
         M = self.closest.shape[0]
         v = v.reshape(M, 3, 3)
@@ -610,44 +686,72 @@ class StageIIObjective:
         vis = self.vis
         nobs = int(vis.sum())
         blocks = []
-        Jd = np.zeros((3 * nobs, 3 + len(free)))
+        nf = len(free)
+        Jd = np.zeros((3 * nobs, 3 + nf + E))
         Jd[:, 0:3] = np.tile(np.eye(3), (nobs, 1))
-        Jd[:, 3:] = dm_pose[vis][:, :, free].reshape(3 * nobs, len(free))
+        Jd[:, 3:3 + nf] = dm_pose[vis][:, :, free].reshape(3 * nobs, nf)
+        if E:
+            dm_shape = np.einsum('mab,mbe->mae', L, dv_shape.reshape(M, 9, E))
+            Jd[:, 3 + nf:] = dm_shape[vis].reshape(3 * nobs, E)
         blocks.append(Jd * self.wt_data)
         if len(self.body_ids):
             _, _, Jp = gmm_prior_eval(self.prior, pose[self.body_ids], want_jac=True)
-            Jb = np.zeros((Jp.shape[0], 3 + len(free)))
+            Jb = np.zeros((Jp.shape[0], 3 + nf + E))
             pos = {int(pid): i for i, pid in enumerate(free)}
             for bi, pid in enumerate(self.body_ids):
                 if int(pid) in pos:
                     Jb[:, 3 + pos[int(pid)]] = Jp[:, bi]
             blocks.append(Jb * self.wt_pose)
         if self.velo_target is not None:
-            Jv = np.zeros((NP, 3 + len(free)))
+            Jv = np.zeros((NP, 3 + nf + E))
             Jv[free, 3 + np.arange(len(free))] = 1.0
             blocks.append(Jv * self.wt_velo)
         if self.finger_ids is not None:
-            Jh = np.zeros((len(self.finger_ids), 3 + len(free)))
+            Jh = np.zeros((len(self.finger_ids), 3 + nf + E))
             pos = {int(pid): i for i, pid in enumerate(free)}
             for hi, pid in enumerate(self.finger_ids):
                 if int(pid) in pos:
                     Jh[hi, 3 + pos[int(pid)]] = 1.0
             blocks.append(Jh * self.wt_poseH)
+        if self.face_ids is not None:
+            Jf = np.zeros((len(self.face_ids), 3 + nf + E))
+            pos = {int(pid): i for i, pid in enumerate(free)}
+            for hi, pid in enumerate(self.face_ids):
+                if int(pid) in pos:
+                    Jf[hi, 3 + pos[int(pid)]] = 1.0
+            blocks.append(Jf * self.wt_poseF)
+        if self.shape_free:
+            Je = np.zeros((E, 3 + nf + E))
+            Je[np.arange(E), 3 + nf + np.arange(E)] = 1.0
+            if self.shp_anchor is not None and self.wt_stay != 0.0:
+                blocks.append(Je * self.wt_stay)
+            blocks.append(Je * self.wt_shape)
         return np.vstack(blocks)
 
 
 def stageii_chain(m, prior, closest, coef, obs, vis, model_type, weights=None, optimize_fingers=False,
                   optimize_toes=False, maxiter=100, reference_cost=False, init=None, num_train_markers=46,
-                  collect_stats=False):
+                  collect_stats=False, optimize_face=False, free_shape=None):
     """The Stage-II frame loop, chmosh.py:584-724, on array inputs:
     obs[F,M,3] (metres), vis[F,M] bool (marker of latent label i observed in frame t).
     `init` = None -> first-frame schedule (rigid init + 3 annealed rounds, chmosh.py:629-655);
     or dict(pose, trans, pose_prev|None) to continue a chain (used for chunk tests).
-    Returns dict(fullpose[F',P], trans[F',3], markers_sim[list], frame_ids[F'], errs{term: array}, pose[F',NP])."""
+    `optimize_face` adds the jaw pose ids + the `poseF` term to Step 2 (:685-686); `free_shape` = 'expr' | 'dmpl' frees
+    the shape block declared with set_free_shape(m, ...) in Step 2: 'expr' -> regulariser stageii_wt_expr (:687-688);
+    'dmpl' -> regulariser stageii_wt_dmpl plus `extrap_dmpl` (:693-699).  As written in the reference, `dmpl_prev` is
+    refreshed (:658-659) BEFORE the term is built, so (dmpl - (dmpl.r + (dmpl.r - dmpl_prev))) * 6 evaluates to
+    (dmpl - value at frame start) * 6, from the second solved frame on.
+    Returns dict(fullpose[F',P], trans[F',3], markers_sim[list], frame_ids[F'], errs{term: array}, pose[F',NP],
+    shape[F',E])."""
     W = stageii_weights_default() if weights is None else dict(weights)
     NP = m['NP']
-    root, body, finger, step1, step2 = pose_id_sets(model_type, NP, optimize_fingers, optimize_toes)
+    root, body, finger, step1, step2 = pose_id_sets(model_type, NP, optimize_fingers, optimize_toes, optimize_face)
+    face = face_pose_ids(model_type, optimize_face)
     objf = StageIIObjective(m, closest, coef, prior, body, reference_cost=reference_cost)
+    assert free_shape in (None, 'expr', 'dmpl')
+    if free_shape is not None:
+        assert 'E' in m, 'call set_free_shape(m, start, count) first'
+    dmpl_prev_set = False
     M = closest.shape[0]
     F = obs.shape[0]
     pose_prev = None
@@ -679,6 +783,9 @@ def stageii_chain(m, prior, closest, coef, obs, vis, model_type, weights=None, o
         objf.wt_poseH = W['stageii_wt_poseH'] * anneal
         objf.wt_velo = W['stageii_wt_velo']
         objf.finger_ids = None
+        objf.face_ids = None
+        objf.shape_free = False
+        objf.shp_anchor = None
         objf.velo_target = None
         if pose_prev is not None:
             objf.velo_target = objf.pose + (objf.pose - pose_prev)  # chmosh.py:624-626
@@ -696,18 +803,30 @@ def stageii_chain(m, prior, closest, coef, obs, vis, model_type, weights=None, o
             first = False
         else:
             pose_prev = objf.pose.copy()
+            dmpl_prev_set = True   # :658-659
         objf.wt_pose = wt_pose
         objf.free_ids = step1
         x = minimize_dogleg(objf, objf.x(), e_3=1e-2, delta_0=.5, maxiter=maxiter, stats=st)
         objf.set_x(x)
         if optimize_fingers:
             objf.finger_ids = np.asarray(finger, dtype=np.int64)
+        if len(face):
+            objf.face_ids = np.asarray(face, dtype=np.int64)
+            objf.wt_poseF = W['stageii_wt_poseF'] * anneal
+        if free_shape is not None:
+            objf.shape_free = True
+            objf.wt_shape = W['stageii_wt_expr'] if free_shape == 'expr' else W['stageii_wt_dmpl']
+            if free_shape == 'dmpl' and dmpl_prev_set:
+                objf.shp_anchor = objf.shp.copy()
+                objf.wt_stay = 6.0
         objf.free_ids = step2
         x = minimize_dogleg(objf, objf.x(), e_3=1e-2, delta_0=.5, maxiter=maxiter, stats=st)
         objf.set_x(x)
         # record (chmosh.py:712-724)
         for k, v in objf.terms(objf.pose, objf.trans).items():
             out['errs'].setdefault(k, []).append(float(np.sum(v ** 2)))
+        if objf.shp is not None:
+            out.setdefault('shape', []).append(objf.shp.copy())
         out['markers_sim'].append(objf.markers_sim()[vmask].copy())
         out['fullpose'].append(fullpose_from_pose(m, objf.pose))
         out['trans'].append(objf.trans.copy())
@@ -717,6 +836,7 @@ def stageii_chain(m, prior, closest, coef, obs, vis, model_type, weights=None, o
     res = dict(fullpose=np.array(out['fullpose']), trans=np.array(out['trans']), pose=np.array(out['pose']),
                markers_sim=out['markers_sim'], frame_ids=np.array(out['frame_ids'], dtype=np.int64),
                errs={k: np.array(v) for k, v in out['errs'].items()}, iters=np.array(out['iters']),
+               shape=np.array(out['shape']) if 'shape' in out else None,
                final=dict(pose=objf.pose.copy(), trans=objf.trans.copy(),
                           pose_prev=None if pose_prev is None else pose_prev.copy()))
     return res

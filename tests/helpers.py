@@ -60,3 +60,47 @@ def device_case(case, optimize_fingers=False, optimize_toes=False, maxiter=100, 
     W = so.stageii_weights_default() if weights is None else weights
     opts = capi.make_opts(W, st1, st2, body, finger if optimize_fingers else [], maxiter=maxiter)
     return dict(model=dev, attach=att, prior=pr, opts=opts)
+
+
+def shape_case(model_type='smplx', F=6, M=40, E=6, seed=0, kind='expr', boost=6.0):
+    """A case whose observations carry time-varying FREE shape coefficients (expression: `kind='expr'`, with jaw motion;
+    DMPL: `kind='dmpl'`): shapedirs gets E extra columns [16, 16+E) that Stage-II may move per frame
+    (chmosh.py:507-514, 562-567, 685-699).  Returns an oracle_case-like dict (+ shp_gt, E, start)."""
+    NB = 16 + E
+    dd = dict(synth.synth_model(model_type, seed=seed, num_betas=NB))
+    sd = np.array(dd['shapedirs'], dtype=np.float64)
+    sd[:, :, 16:] *= boost / np.maximum(np.abs(sd[:, :, 16:]).max(axis=(0, 1), keepdims=True) / 0.005, 1e-12)
+    dd['shapedirs'] = sd
+    s = synth.make_sequence(model_type, F, M, seed=seed, num_betas=NB, dd=dd, body_only_markers=False, dropout=0.0,
+                            n_gaps=0)
+    s['betas'] = s['betas'].copy()
+    s['betas'][16:] = 0.0
+    bd, hd, hm, comps = pose_layout(s)
+    model = dict(v_template=dd['v_template'], shapedirs=sd, posedirs=dd['posedirs'], weights=dd['weights'],
+                 J_regressor=dd['J_regressor'], parents=synth.kintree_parents(model_type), body_dof=bd, hand_dof=hd,
+                 hands_mean=hm, selected_components=comps)
+    m = so.prepare_model(model, s['betas'])
+    so.set_free_shape(m, 16, E)
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
+    closest, coef = so.transformed_coeffs(can, s['markers_latent'],
+                                          exclude_vids=np.arange(9383, 10475) if model_type == 'smplx' else None)
+    rng = np.random.default_rng(seed + 77)
+    tt = np.arange(F)[:, None] / 30.0
+    shp_gt = 1.2 * np.sin(2 * np.pi * (0.7 + 0.3 * rng.random(E))[None] * tt + rng.random(E)[None] * 6.0)
+    pose_gt = s['pose_gt'].copy()
+    pose_gt[:, bd:] = 0.0
+    if kind == 'expr' and model_type == 'smplx':
+        pose_gt[:, 66:69] = 0.15 * np.sin(2 * np.pi * 1.1 * tt + np.array([0.0, 1.0, 2.0]))   # jaw
+    obs = np.zeros((F, M, 3))
+    flat = closest.reshape(-1)
+    for f in range(F):
+        v = so.verts_forward(m, so.fullpose_from_pose(m, pose_gt[f]), s['trans_gt'][f], flat, shp=shp_gt[f])
+        v = v.reshape(M, 3, 3)
+        obs[f] = so.markers_from_verts(coef, v[:, 0], v[:, 1], v[:, 2])
+    obs += rng.normal(0, 0.0003, obs.shape)
+    vis = np.ones((F, M), dtype=bool)
+    vis[1:, 3] = False                      # one missing marker: annealing factor != 1
+    npose = 63 if model_type in ('smplh', 'smplx') else 69
+    prior = so.prepare_gmm_prior(s['gmm'], npose)
+    return dict(s=s, m=m, model=model, can=can, closest=closest, coef=coef, prior=prior, obs=obs, vis=vis,
+                model_type=model_type, shp_gt=shp_gt, pose_gt=pose_gt, E=E, start=16, kind=kind)

@@ -124,3 +124,55 @@ def test_reference_cost_mode_is_the_same_arithmetic(smplh_case):
     b = so.stageii_chain(c['m'], c['prior'], c['closest'], c['coef'], c['obs'][:2], c['vis'][:2], 'smplh',
                          reference_cost=True)
     assert np.abs(a['fullpose'] - b['fullpose']).max() < 1e-10
+
+
+@pytest.mark.parametrize('model_type,kind', [('smplx', 'expr'), ('smplh', 'dmpl')])
+def test_free_shape_block_jacobian_and_chain(model_type, kind):
+    """Expression / DMPL coefficients as Step-2 free variables (chmosh.py:685-699): analytic Jacobian of the full
+    objective incl. the shape columns (the restated `lbs_derivatives_wrt_shape`) vs central differences, and the chain
+    recovers the time-varying coefficients it was generated with."""
+    from tests.helpers import shape_case
+    c = shape_case(model_type, F=5, M=36, E=5, seed=2, kind=kind)
+    m = c['m']
+    face = kind == 'expr'
+    root, body, finger, st1, st2 = so.pose_id_sets(model_type, m['NP'], False, False, optimize_face=face)
+    o = so.StageIIObjective(m, c['closest'], c['coef'], c['prior'], body)
+    rng = np.random.default_rng(4)
+    o.pose = c['pose_gt'][2] + rng.normal(0, 0.02, m['NP'])
+    o.trans = c['s']['trans_gt'][2].copy()
+    o.shp = rng.normal(0, 0.5, c['E'])
+    o.vis, o.obs = c['vis'][2], c['obs'][2]
+    o.wt_data, o.wt_pose, o.wt_velo = 400 * 46 / o.vis.sum(), 1.6, 2.5
+    o.velo_target = o.pose + rng.normal(0, 0.01, m['NP'])
+    o.free_ids = st2
+    if face:
+        assert st2[-3:] == [66, 67, 68] or set([66, 67, 68]) <= set(st2)
+        o.face_ids, o.wt_poseF = np.array([66, 67, 68]), 1.3
+    o.shape_free, o.wt_shape = True, 0.9
+    o.shp_anchor, o.wt_stay = o.shp + 0.1, (6.0 if kind == 'dmpl' else 0.0)
+    x = o.x()
+    assert len(x) == 3 + len(st2) + c['E']
+    J = o.J(x)
+    r0 = o.r(x)
+    assert J.shape == (len(r0), len(x))
+    num = np.zeros_like(J)
+    for q in range(len(x)):
+        h = 1e-6
+        a, b = x.copy(), x.copy()
+        a[q] += h
+        b[q] -= h
+        num[:, q] = (o.r(a) - o.r(b)) / (2 * h)
+    assert np.abs(num - J).max() < 2e-5 * max(1.0, np.abs(J).max())
+    assert np.abs(J[:, -c['E']:]).max() > 1.0           # the shape columns are live
+    res = so.stageii_chain(m, c['prior'], c['closest'], c['coef'], c['obs'], c['vis'], model_type,
+                           optimize_face=face, free_shape=kind)
+    assert res['shape'].shape == (5, c['E'])
+    err = np.abs(res['shape'] - c['shp_gt'])
+    assert err[1:].max() < 0.35, err.max()             # regularised (wt 1.0) -> biased towards 0, but tracks
+    rm = np.sqrt(np.mean([np.mean((a - c['obs'][t][c['vis'][t]]) ** 2) for t, a in enumerate(res['markers_sim'])]))
+    assert rm < 1.5e-3
+    assert ('shape_stay' in res['errs']) == (kind == 'dmpl')
+    if kind == 'dmpl':
+        assert len(res['errs']['shape_stay']) == 4      # from the second solved frame on
+    if face:
+        assert np.abs(res['pose'][:, 66:69]).max() > 1e-3   # the jaw is free (weakly observed by this layout)
