@@ -74,6 +74,14 @@ int moshii_model_destroy(moshii_model_t m);
  * Stage-II, so this runs once per subject. */
 int moshii_model_set_betas(moshii_model_t m, const double* betas, int32_t nb);
 
+/* Declares shapedirs columns [start, start+count) as per-frame FREE variables of Stage-II Step 2: the expression
+ * coefficients opt_model.betas[exp_start : exp_start+num_expressions] (chmosh.py:565-567, 687-688) or the DMPL
+ * coefficients opt_model.betas[num_betas : num_betas+num_dmpls] (:513-514, 698-699).  Precomputes
+ * JS = J_regressor . shapedirs[:,:,block] (the joints move with them, smpl_fast_derivatives.py:187-191); the solver
+ * treats the coefficients as an OFFSET on the betas frozen by moshii_model_set_betas.  count = 0 clears it.
+ * Call before moshii_attach_create (attachments gather their rows of the block). */
+int moshii_model_set_free_shape(moshii_model_t m, int32_t start, int32_t count);
+
 /* Regressed joints J[K][3] for the current betas (host buffer). */
 int moshii_model_get_joints(moshii_model_t m, double* J_out);
 
@@ -133,7 +141,18 @@ typedef struct moshii_solve_opts {
     const int32_t* body_ids;
     int32_t n_finger;               /* pose_finger_ids when optimize_fingers (:681-683), else 0  */
     const int32_t* finger_ids;
+    /* Step-2 extras, all optional (0 / NULL = absent) */
+    int32_t n_face;                 /* pose_face_ids when optimize_face (:560-563, 685-686): contiguous, also in step2_ids */
+    const int32_t* face_ids;
+    double  wt_poseF;               /* stageii_wt_poseF (annealed like poseB/H, :606)             */
+    int32_t n_shape;                /* > 0: the block of moshii_model_set_free_shape is free in Step 2 (count must match) */
+    double  wt_shape;               /* stageii_wt_expr (:687) or stageii_wt_dmpl (:698)           */
+    double  wt_shape_stay;          /* DMPL: 6.0 = "extrap_dmpl" (:693-697).  dmpl_prev is refreshed (:658-659) before the
+                                     * term is built, so it evaluates to (dmpl - dmpl at frame start) * 6 from the second
+                                     * solved frame on.  0: no such term (expression).           */
 } moshii_solve_opts;
+
+#define MOSHII_NERR 8               /* per-frame SSE columns: data, poseB, velo, poseH, poseF, shape, shape_stay, 0 */
 
 typedef struct moshii_chain_desc {
     moshii_attach_t attach;
@@ -144,15 +163,17 @@ typedef struct moshii_chain_desc {
     const double*  init_pose;       /* host [NP] or NULL (zeros)                                  */
     const double*  init_trans;      /* host [3]  or NULL (zeros)                                  */
     const double*  init_pose_prev;  /* host [NP] or NULL (no velocity term on the next frame)     */
+    const double*  init_shape;      /* host [n_shape] or NULL (zeros): free shape coefficients     */
     /* outputs, one row per input frame; rows of frames without visible markers are left untouched
      * and flagged status = 1 (the reference skips them, :586-588) */
     double*  pose;                  /* [F][NP] pose variables                     (may be NULL)   */
     double*  fullpose;              /* [F][3K]  opt_model.fullpose (:720)                          */
     double*  trans;                 /* [F][3]                                                      */
     double*  markers_sim;           /* [F][M][3] simulated markers (all M; caller selects visible) */
-    double*  errs;                  /* [F][4] SSE of data, poseB, velo, poseH (:712-714)           */
+    double*  errs;                  /* [F][MOSHII_NERR] SSE of every residual block (:712-714)     */
     int32_t* iters;                 /* [F][2] dogleg outer iterations, residual evaluations        */
     int32_t* status;                /* [F] 0 solved, 1 skipped (no markers), <0 numerical failure  */
+    double*  shape;                 /* [F][n_shape] free shape coefficients: `expression` (:723-724) / `dmpls` (:721-722); may be NULL */
 } moshii_chain_desc;
 
 int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL when n_body == 0 */,
@@ -172,6 +193,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL whe
  *   repair  a chunk that fails is re-solved from its predecessor's exact end state (warm start + velocity
  *           term exactly as :624-626, 656-657), and its successor is re-verified; repeated until clean.
  * The call synchronises `stream` (the verification result is read on the host).
+ * Free shape coefficients (n_shape > 0) are not supported here (MOSHII_ERR_UNSUPPORTED): use moshii_chain_solve.
  * ------------------------------------------------------------------------------------------- */
 typedef struct moshii_sequence_desc {
     moshii_attach_t attach;

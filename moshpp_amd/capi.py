@@ -34,15 +34,20 @@ class SolveOpts(C.Structure):
                 ('wt_poseH', C.c_double), ('wt_annealing', C.c_double), ('num_train_markers', C.c_double),
                 ('e3_first', C.c_double), ('e3', C.c_double), ('delta0', C.c_double), ('maxiter', C.c_int32),
                 ('n_step1', C.c_int32), ('step1_ids', _c_int_p), ('n_step2', C.c_int32), ('step2_ids', _c_int_p),
-                ('n_body', C.c_int32), ('body_ids', _c_int_p), ('n_finger', C.c_int32), ('finger_ids', _c_int_p)]
+                ('n_body', C.c_int32), ('body_ids', _c_int_p), ('n_finger', C.c_int32), ('finger_ids', _c_int_p),
+                ('n_face', C.c_int32), ('face_ids', _c_int_p), ('wt_poseF', C.c_double), ('n_shape', C.c_int32),
+                ('wt_shape', C.c_double), ('wt_shape_stay', C.c_double)]
+
+
+NERR = 8   # MOSHII_NERR: data, poseB, velo, poseH, poseF, shape, shape_stay, 0
 
 
 class ChainDesc(C.Structure):
     _fields_ = [('attach', C.c_void_p), ('F', C.c_int32), ('first_frame_schedule', C.c_int32),
                 ('obs', C.c_void_p), ('vis', C.c_void_p), ('init_pose', _c_double_p), ('init_trans', _c_double_p),
-                ('init_pose_prev', _c_double_p), ('pose', C.c_void_p), ('fullpose', C.c_void_p),
-                ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p),
-                ('status', C.c_void_p)]
+                ('init_pose_prev', _c_double_p), ('init_shape', _c_double_p), ('pose', C.c_void_p),
+                ('fullpose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('errs', C.c_void_p),
+                ('iters', C.c_void_p), ('status', C.c_void_p), ('shape', C.c_void_p)]
 
 
 class SequenceDesc(C.Structure):
@@ -69,6 +74,7 @@ EXPORTS = {
     'moshii_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     'moshii_model_destroy': (C.c_int, [C.c_void_p]),
     'moshii_model_set_betas': (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
+    'moshii_model_set_free_shape': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'moshii_model_get_joints': (C.c_int, [C.c_void_p, _c_double_p]),
     'moshii_lbs_forward_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     'moshii_lbs_forward_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -178,6 +184,12 @@ class Model:
         b = _f64(np.ravel(betas))
         check(load().moshii_model_set_betas(self.handle, _dp(b), b.shape[0]))
 
+    def set_free_shape(self, start, count):
+        """Shapedirs columns [start, start+count) become Step-2 free variables (expression / DMPL); call before
+        creating attachments."""
+        check(load().moshii_model_set_free_shape(self.handle, int(start), int(count)))
+        self.n_free_shape = int(count)
+
     def joints(self):
         out = np.zeros((self.K, 3))
         check(load().moshii_model_get_joints(self.handle, _dp(out)))
@@ -266,24 +278,32 @@ class Attachment:
 
 
 def make_opts(weights, step1_ids, step2_ids, body_ids, finger_ids, maxiter=100, e3_first=1e-3, e3=1e-2,
-              delta0=0.5, num_train_markers=46.0):
-    """SolveOpts + the arrays it points to (keep the returned tuple alive during the call)."""
+              delta0=0.5, num_train_markers=46.0, face_ids=(), n_shape=0, shape_kind=None):
+    """SolveOpts + the arrays it points to (keep the returned tuple alive during the call).
+    face_ids: jaw pose ids of optimize_face (also part of step2_ids); n_shape / shape_kind ('expr' | 'dmpl'): the free
+    shape block declared with Model.set_free_shape."""
     o = SolveOpts()
     o.wt_data = float(weights['stageii_wt_data']); o.wt_velo = float(weights['stageii_wt_velo'])
     o.wt_poseB = float(weights['stageii_wt_poseB']); o.wt_poseH = float(weights['stageii_wt_poseH'])
     o.wt_annealing = float(weights['stageii_wt_annealing'])
     o.num_train_markers = float(num_train_markers)
     o.e3_first, o.e3, o.delta0, o.maxiter = float(e3_first), float(e3), float(delta0), int(maxiter)
-    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (step1_ids, step2_ids, body_ids, finger_ids)]
-    o.n_step1, o.n_step2, o.n_body, o.n_finger = (len(a) for a in arrs)
-    o.step1_ids, o.step2_ids, o.body_ids, o.finger_ids = (_ip(a) for a in arrs)
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (step1_ids, step2_ids, body_ids, finger_ids, face_ids)]
+    o.n_step1, o.n_step2, o.n_body, o.n_finger, o.n_face = (len(a) for a in arrs)
+    o.step1_ids, o.step2_ids, o.body_ids, o.finger_ids, o.face_ids = (_ip(a) for a in arrs)
+    o.wt_poseF = float(weights.get('stageii_wt_poseF', 1.0))
+    o.n_shape = int(n_shape)
+    if o.n_shape:
+        assert shape_kind in ('expr', 'dmpl')
+        o.wt_shape = float(weights['stageii_wt_expr' if shape_kind == 'expr' else 'stageii_wt_dmpl'])
+        o.wt_shape_stay = 6.0 if shape_kind == 'dmpl' else 0.0     # chmosh.py:697
     return o, arrs
 
 
 def chain_solve_host(model: Model, prior, opts_tuple, chains):
     """Run moshii_chain_solve on host buffers.
-    chains: list of dict(attach, obs[F,M,3], vis[F,M], first=True, init_pose=None, init_trans=None, init_pose_prev=None).
-    Returns list of dict(pose, fullpose, trans, markers_sim, errs, iters, status)."""
+    chains: list of dict(attach, obs[F,M,3], vis[F,M], first=True, init_pose=None, init_trans=None, init_pose_prev=None,
+    init_shape=None).  Returns list of dict(pose, fullpose, trans, markers_sim, errs[F,NERR], iters, status, shape[F,n_shape])."""
     lib = load()
     opts, _keep = opts_tuple
     n = len(chains)
@@ -295,8 +315,8 @@ def chain_solve_host(model: Model, prior, opts_tuple, chains):
         F, M = vis.shape
         assert obs.shape == (F, M, 3) and M == att.M
         o = dict(pose=np.zeros((F, model.NP)), fullpose=np.zeros((F, model.P)), trans=np.zeros((F, 3)),
-                 markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, 4)), iters=np.zeros((F, 2), dtype=np.int32),
-                 status=np.zeros(F, dtype=np.int32))
+                 markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, NERR)), iters=np.zeros((F, 2), dtype=np.int32),
+                 status=np.zeros(F, dtype=np.int32), shape=np.zeros((F, int(opts.n_shape))))
         d = descs[i]
         d.attach = att.handle
         d.F = F
@@ -304,12 +324,15 @@ def chain_solve_host(model: Model, prior, opts_tuple, chains):
         d.obs = obs.ctypes.data
         d.vis = vis.ctypes.data
         keep += [obs, vis]
-        for key, fld in (('init_pose', 'init_pose'), ('init_trans', 'init_trans'), ('init_pose_prev', 'init_pose_prev')):
+        for key, fld in (('init_pose', 'init_pose'), ('init_trans', 'init_trans'), ('init_pose_prev', 'init_pose_prev'),
+                         ('init_shape', 'init_shape')):
             if ch.get(key) is not None:
                 a = _f64(ch[key]); keep.append(a)
                 setattr(d, fld, _dp(a))
         for key in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status'):
             setattr(d, key, o[key].ctypes.data)
+        if opts.n_shape:
+            d.shape = o['shape'].ctypes.data
         outs.append(o)
     check(lib.moshii_chain_solve(model.handle, prior.handle if prior is not None else None, C.byref(opts), n, descs,
                                  BUFFERS_HOST, None))
@@ -341,7 +364,7 @@ def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, war
         F, M = vis.shape
         assert obs.shape == (F, M, 3) and M == att.M
         o = dict(pose=np.zeros((F, model.NP)), fullpose=np.zeros((F, model.P)), trans=np.zeros((F, 3)),
-                 markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, 4)), iters=np.zeros((F, 2), dtype=np.int32),
+                 markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, NERR)), iters=np.zeros((F, 2), dtype=np.int32),
                  status=np.zeros(F, dtype=np.int32))
         d = descs[i]
         d.attach = att.handle; d.F = F; d.obs = obs.ctypes.data; d.vis = vis.ctypes.data

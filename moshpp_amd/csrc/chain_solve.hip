@@ -33,7 +33,7 @@ enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 =
 struct Ctx {
     double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
     double *feat, *B, *omega, *Rw, *tw, *Rloc, *acol, *Jl;
-    double *vposed, *vpos, *msim, *res, *vconst;
+    double *vposed, *vpos, *msim, *res, *vconst, *vshp, *shp0;
     double *xb, *ell, *score;
     double *g, *dsd, *dgn, *ddl, *y;
     double *red, *scal;
@@ -47,9 +47,12 @@ struct FrameParams {
     const double* obs;      // [M][3] of this frame
     double wt_data, wt_pose, wt_poseH, wt_velo;
     int has_velo, use_fingers, nobs;
+    // extended variant (XT): jaw term, free shape block and its "stay" term are live in this phase
+    double wt_poseF;
+    int use_face, use_shape, has_stay;
 };
 
-struct Sse { double data, prior, velo, hand, total; };
+struct Sse { double data, prior, velo, hand, total, face, shape, stay; };
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -251,6 +254,9 @@ __device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev&
 // ------------------------------------------------------------------------------------------------
 // klist/nk: the joints whose pose-corrective contribution is summed here; vbase = rest vertices + the contribution of
 // every other joint (cx.vconst, see posedirs_partial) -- or klist = all joints and vbase = v_shaped.
+// XT (extended variant): the free shape coefficients s ride behind the pose variables (pose[NP .. NP + nshape)); the rest
+// vertices and the regressed joints are re-shaped with them at every evaluation (smpl_fast_derivatives.py:186-191).
+template <bool XT>
 __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                             const OptsDev& op, const double* pose, const double* trans, const FrameParams& fp,
                             const uint8_t* visrow, const int* klist, int nk, const double* vbase) {
@@ -259,6 +265,31 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     PROF_BEGIN(); PROF_COUNT(20);
     // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
     for (int d = tid; d < P; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, pose, d);
+    if constexpr (XT) {
+        if (op.nshape > 0) {
+            const int E = op.nshape, Nvp = at.Nvp;
+            const double* shp = pose + md.NP;
+            for (int i = tid; i < 3 * K; i += MOSHII_TPB) {   // J = J0 + JS . s
+                const double* js = md.JS + (size_t)(i / 3) * E * 3 + (i % 3);
+                double s0 = md.J[i], s1 = 0.0;
+                int e = 0;
+                for (; e + 2 <= E; e += 2) { s0 += js[e * 3] * shp[e]; s1 += js[(e + 1) * 3] * shp[e + 1]; }
+                if (e < E) s0 += js[e * 3] * shp[e];
+                cx.Jl[i] = s0 + s1;
+            }
+            for (int it = tid; it < 3 * Nvp; it += MOSHII_TPB) {   // rest vertices: vbase + S . s (vertex fastest: coalesced rows)
+                const int i = it / Nvp, a = it - i * Nvp;
+                const double* sp = at.Ssh + (size_t)i * Nvp + a;
+                const size_t st = (size_t)3 * Nvp;
+                double s0 = 0.0, s1 = 0.0;
+                int e = 0;
+                for (; e + 2 <= E; e += 2) { s0 += sp[e * st] * shp[e]; s1 += sp[(e + 1) * st] * shp[e + 1]; }
+                if (e < E) s0 += sp[e * st] * shp[e];
+                if (a < at.Nv) cx.vshp[a * 3 + i] = vbase[a * 3 + i] + (s0 + s1);
+            }
+            vbase = cx.vshp;
+        }
+    }
     __syncthreads();
     // F2: per joint rotation and pose feature R - I  (the Jacobian-only quantities are built in assemble())
     if (tid < K) {
@@ -350,6 +381,18 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         for (int i = tid; i < md.NP; i += MOSHII_TPB) { const double d = (pose[i] - cx.vtarget[i]) * fp.wt_velo; sv += d * d; }
     if (fp.use_fingers)
         for (int f = tid; f < op.nfinger; f += MOSHII_TPB) { const double d = pose[op.finger[f]] * fp.wt_poseH; sh += d * d; }
+    double sf = 0.0, ss = 0.0, sy = 0.0;   // jaw term, shape regulariser, shape "stay" term (chmosh.py:685-699)
+    if constexpr (XT) {
+        if (fp.use_face)
+            for (int f = tid; f < op.nface; f += MOSHII_TPB) { const double d = pose[op.face[f]] * fp.wt_poseF; sf += d * d; }
+        if (fp.use_shape)
+            for (int e = tid; e < op.nshape; e += MOSHII_TPB) {
+                const double sv_ = pose[md.NP + e];
+                const double d = sv_ * op.wt_shape;
+                ss += d * d;
+                if (fp.has_stay) { const double d2 = (sv_ - cx.shp0[e]) * op.wt_shape_stay; sy += d2 * d2; }
+            }
+    }
     // F7: prior: l_g = sqrt(.5) (x - mu_g) . L_g for every component, argmin of |l_g|^2 - log w_g
     const int np_ = op.nbody;
     if (np_ > 0) {
@@ -410,11 +453,14 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         }
     }
     block_sum3(sd, sv, sh, cx.red);   // (contains the barriers that publish scal[])
+    if constexpr (XT) block_sum3(sf, ss, sy, cx.red);
     PROF_LAP(3);
     Sse out;
     out.data = sd; out.velo = sv; out.hand = sh;
+    out.face = sf; out.shape = ss; out.stay = sy;
     out.prior = (np_ > 0) ? fp.wt_pose * fp.wt_pose * cx.scal[S_PRIOR_SS] : 0.0;
     out.total = ((out.data + out.prior) + out.velo) + out.hand;
+    if constexpr (XT) out.total += (sf + ss) + sy;
     return out;
 }
 
@@ -531,8 +577,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane /* wave-unifor
 // x_j = (b_j - sum_{i>j} c_ij x_i) / d_j from the packed factor.  A itself is left untouched (the dogleg needs
 // d^T A d afterwards).  Returns false on a non-positive pivot (the reference would fall back to lstsq; callers
 // take the Cauchy step).
-template <int NBLK>
-__device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, double* d, double* pinv, int n) {
+// BIG (NBLK > 8, extended variant only): the packed factor does not fit the LDS next to the solver state, so it is written
+// to this chain's global scratch (`Lp`, L2-resident) while the small broadcast area stays in LDS (`Sl_big`: trash word,
+// zero word, Cv, then a 16-row panel); the back-substitution then streams the factor through that panel, 16 rows per
+// barrier pair, and every lane of wave 0 owns up to four unknowns.
+template <int NBLK, bool BIG>
+__device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, double* Sl_big, const double* g, double* d, double* pinv, int n) {
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     PROF_BEGIN(); PROF_COUNT(22);
@@ -558,14 +608,15 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
     // Stores that do not apply go to `trash`, loads that do not apply read `zero` (= 0.0): straight-line LDS traffic.
     const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
     constexpr int CVR = NBLK * 16;                 // rows of one broadcast column
-    double* Cv = Lp + zero + 1;                    // [2][2][CVR]
+    double* const Sl = BIG ? Sl_big : Lp + trash;  // LDS: [0] trash word, [1] zero word, [2..] Cv
+    double* Cv = Sl + 2;                           // [2][2][CVR]
     int rS[NBLK];                                  // packed offset of this thread's row q1 (or -1 beyond the border row)
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int q1 = b * 16 + ty;
         rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
     }
-    if (tid == 0) Lp[zero] = 0.0;
+    if (tid == 0) Sl[1] = 0.0;
     bool ok = true;
     int step = 0;
     // outer loop over 16-column blocks is unrolled, so every register index below is a compile-time constant
@@ -583,7 +634,7 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
             for (int bi = bj0; bi < NBLK; ++bi) {   // publish columns j, j+1 as they stand (rows of this thread), and column j's final entries
                 const int q1 = bi * 16 + ty;
                 const double v = w[bi * (bi + 1) / 2 + bj0];
-                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Lp + trash;
+                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl;
                 *dst = v;
                 Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;
             }
@@ -594,7 +645,7 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
             for (int b = bj0; b < NBLK; ++b) {
                 const int q1 = b * 16 + ty, q2 = b * 16 + tx;
                 const bool vr = q1 > j + 1 && q1 <= n, vc = q2 > j + 1 && q2 <= n;
-                const double* zr = Lp + zero;   // (address select, not value select: the loads stay unconditional)
+                const double* zr = Sl + 1;   // (address select, not value select: the loads stay unconditional)
                 const double* r0 = vr ? cv + q1 : zr; const double* r1 = vr ? cv + CVR + q1 : zr;
                 const double* c0p = vc ? cv + q2 : zr; const double* c1p = vc ? cv + CVR + q2 : zr;
                 ci0[b] = *r0; ci1[b] = *r1; ck0[b] = *c0p; ck1[b] = *c1p;
@@ -632,6 +683,45 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
     __syncthreads();
     PROF_LAP(9);
     if (!ok) return false;
+    if constexpr (BIG) {
+        constexpr int NY = (CVR + 63) / 64;   // unknowns per lane of wave 0
+        constexpr int PR = 16;                // panel rows
+        double* pan = Sl + 2 + 4 * CVR;       // [PR][CVR]
+        const int base = n * (n + 1) / 2;
+        double y[NY];
+#pragma unroll
+        for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k < n) ? Lp[base + tid + 64 * k] : 0.0;
+        for (int jhi = n - 1; jhi >= 0; jhi -= PR) {
+            const int jlo = max(jhi - PR + 1, 0), rows = jhi - jlo + 1;
+            for (int it = tid; it < rows * CVR; it += MOSHII_TPB) {   // row j of the factor: entries (j, 0 .. j-1), zero beyond
+                const int r = it / CVR, i = it - r * CVR, j = jlo + r;
+                pan[it] = (i < j) ? Lp[j * (j + 1) / 2 + i] : 0.0;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                for (int jv = jhi; jv >= jlo; --jv) {
+                    const int j = __builtin_amdgcn_readfirstlane(jv);
+                    double l[NY];
+#pragma unroll
+                    for (int k = 0; k < NY; ++k) l[k] = pan[(j - jlo) * CVR + tid + 64 * k];
+                    double yj = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NY; ++k) if ((j >> 6) == k) yj = readlane_f64(y[k], j & 63);
+                    const double dj = yj * pinv[j];
+#pragma unroll
+                    for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k == j) ? dj : fma(-l[k], dj, y[k]);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < 64) {
+#pragma unroll
+            for (int k = 0; k < NY; ++k) if (tid + 64 * k < n) d[tid + 64 * k] = y[k];
+        }
+        __syncthreads();
+        PROF_LAP(10);
+        return true;
+    }
     // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
     // Row j of the factor and 1/d_j are fetched one step ahead (off the readlane -> multiply -> fma chain); rows are
     // read branch-free (lanes beyond the row read the zero word).
@@ -667,12 +757,14 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
 // ------------------------------------------------------------------------------------------------
 // Normal equations at the point whose forward state is in LDS:  A = J^T J (registers), g = -J^T r (LDS).
 // ------------------------------------------------------------------------------------------------
-template <int NBLK>
+// Columns: [trans 3][free pose variables][free shape coefficients]; ncp = 3 + #pose columns, n - ncp = #shape columns (XT only).
+template <int NBLK, bool XT>
 __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at,
                          const PriorDev& pr, const OptsDev& op, const double* pose, const FrameParams& fp,
-                         int n, int nkf, int nfree_hand, AReg<NBLK>& A) {
+                         int n, int ncp, int nkf, int nfree_hand, double* qs, AReg<NBLK>& A) {
     const int tid = threadIdx.x;
     const int LDJ = ly.LDJ, Tm = ly.Tm, NW = at.NW, Nvp = at.Nvp, bd = md.body_dof, nhf = md.nhand_full;
+    const int nshp = XT ? n - ncp : 0;
     PROF_BEGIN(); PROF_COUNT(21);
     A.zero();
     for (int q = tid; q < n; q += MOSHII_TPB) cx.g[q] = 0.0;
@@ -705,6 +797,40 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         double ox = ax, oy = ay, oz = az;
         if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
         cx.omega[k * 10 + c * 3 + 0] = ox; cx.omega[k * 10 + c * 3 + 1] = oy; cx.omega[k * 10 + c * 3 + 2] = oz;
+    }
+    if constexpr (XT) {
+        if (nshp > 0) {
+            // shape derivative of the joint transforms at the current point (the restated lbs_derivatives_wrt_shape):
+            //   dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par)   (joint world positions, one tree level per step)
+            //   q_j  = dt_j - Rw_j JS_j                               (so that dv/ds = Trot . S(v) + sum_j w_j q_j)
+            // K x nshape x 3 doubles each: too large for LDS next to the Jacobian tiles, so they live in this chain's
+            // global scratch (L2-resident; written here, read by the T1s items below).
+            const int E = nshp, KE = md.K * E;
+            double* dtv = qs;
+            double* qv = qs + (size_t)KE * 3;
+            for (int lvl = 0; lvl <= md.maxdepth; ++lvl) {
+                for (int it = tid; it < KE; it += MOSHII_TPB) {
+                    const int j = it / E, e = it - j * E;
+                    if (md.depth[j] != lvl) continue;
+                    const double* js = md.JS + (size_t)it * 3;
+                    const double jx = js[0], jy = js[1], jz = js[2];
+                    double dx = jx, dy = jy, dz = jz;
+                    if (j > 0) {
+                        const int p = md.parents[j];
+                        const double* jp = md.JS + ((size_t)p * E + e) * 3;
+                        const double* dp = dtv + ((size_t)p * E + e) * 3;
+                        double ox, oy, oz;
+                        mat3_vec(&cx.Rw[p * 9], jx - jp[0], jy - jp[1], jz - jp[2], ox, oy, oz);
+                        dx = dp[0] + ox; dy = dp[1] + oy; dz = dp[2] + oz;
+                    }
+                    dtv[(size_t)it * 3 + 0] = dx; dtv[(size_t)it * 3 + 1] = dy; dtv[(size_t)it * 3 + 2] = dz;
+                    double rx, ry, rz;
+                    mat3_vec(&cx.Rw[j * 9], jx, jy, jz, rx, ry, rz);
+                    qv[(size_t)it * 3 + 0] = dx - rx; qv[(size_t)it * 3 + 1] = dy - ry; qv[(size_t)it * 3 + 2] = dz - rz;
+                }
+                __syncthreads();
+            }
+        }
     }
     for (int tile0 = 0; tile0 < fp.nobs; tile0 += Tm) {
         const int cnt = min(Tm, fp.nobs - tile0);
@@ -851,6 +977,41 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 for (int e = 0; e < 9; ++e) jh[e] = r[e];
             }
         }
+        if constexpr (XT) {
+            // T1s: shape columns.  item = (tile marker, coefficient): dv/ds_e = Trot . S_e(v) + sum_s w_s q_{j_s, e} for the
+            // marker's three vertices, contracted with the marker's local 3x9 Jacobian.
+            if (nshp > 0) {
+                const double* qv = qs + (size_t)md.K * nshp * 3;
+                for (int it = tid; it < cnt * nshp; it += MOSHII_TPB) {
+                    const int e = it / cnt, ml = it - e * cnt;
+                    const int m = cx.visidx[tile0 + ml];
+                    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+#pragma unroll
+                    for (int sv = 0; sv < 3; ++sv) {
+                        const int al = 3 * ml + sv, av = 3 * m + sv;
+                        const double* sp = at.Ssh + (size_t)e * 3 * Nvp + av;
+                        const double sx = sp[0], sy = sp[Nvp], sz = sp[2 * Nvp];
+                        const double* Tr = &cx.Trot[al * 10];
+                        double dx = Tr[0] * sx + Tr[1] * sy + Tr[2] * sz;
+                        double dy = Tr[3] * sx + Tr[4] * sy + Tr[5] * sz;
+                        double dz = Tr[6] * sx + Tr[7] * sy + Tr[8] * sz;
+                        for (int s2 = 0; s2 < NW; ++s2) {
+                            const int j = cx.tjs[al * NW + s2];
+                            const double w = cx.xjs[(al * NW + s2) * 4 + 3];
+                            const double* qq = qv + ((size_t)j * nshp + e) * 3;
+                            dx += w * qq[0]; dy += w * qq[1]; dz += w * qq[2];
+                        }
+                        const double* Ls = &cx.Lm[(ml * 3 + sv) * 10];
+                        r0 += Ls[0] * dx + Ls[1] * dy + Ls[2] * dz;
+                        r1 += Ls[3] * dx + Ls[4] * dy + Ls[5] * dz;
+                        r2 += Ls[6] * dx + Ls[7] * dy + Ls[8] * dz;
+                    }
+                    cx.Jrow[(3 * ml + 0) * LDJ + ncp + e] = fp.wt_data * r0;
+                    cx.Jrow[(3 * ml + 1) * LDJ + ncp + e] = fp.wt_data * r1;
+                    cx.Jrow[(3 * ml + 2) * LDJ + ncp + e] = fp.wt_data * r2;
+                }
+            }
+        }
         // translation columns: d marker / d trans = I
         for (int it = tid; it < cnt * 9; it += MOSHII_TPB) {
             const int ml = it / 9, row = (it % 9) / 3, q = it % 3;
@@ -861,7 +1022,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         // T2: hand-PCA columns: d marker / d pose[bd + i] = sum_h comps[i][h] d marker / d fullpose[bd + h]
         if (nfree_hand > 0) {
             for (int it = tid; it < cnt * nfree_hand; it += MOSHII_TPB) {
-                const int ml = it / nfree_hand, q = n - nfree_hand + (it - ml * nfree_hand);   // hand columns are the tail
+                const int ml = it / nfree_hand, q = ncp - nfree_hand + (it - ml * nfree_hand);   // hand columns are the tail of the pose columns
                 const int i = cx.colpid[q] - bd;
                 double r0 = 0.0, r1 = 0.0, r2 = 0.0;
                 for (int h = md.comp_lo[i]; h < md.comp_hi[i]; ++h) {
@@ -900,7 +1061,13 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     const int kb = (np_ > 0) ? (int)cx.scal[S_KBEST] : 0;
     for (int q = tid; q < n; q += MOSHII_TPB) {
         double dg = 0.0, gq = 0.0;
-        if (q >= 3) {
+        if (XT && q >= ncp) {   // shape column: regulariser (+ "stay" term), both diagonal
+            const int e = q - ncp;
+            const double sv_ = pose[md.NP + e];
+            const double w2 = op.wt_shape * op.wt_shape;
+            dg += w2; gq -= w2 * sv_;
+            if (fp.has_stay) { const double y2 = op.wt_shape_stay * op.wt_shape_stay; dg += y2; gq -= y2 * (sv_ - cx.shp0[e]); }
+        } else if (q >= 3) {
             const int pid = cx.colpid[q];
             if (fp.has_velo) { const double w2 = fp.wt_velo * fp.wt_velo; dg += w2; gq -= w2 * (pose[pid] - cx.vtarget[pid]); }
             const int pb = cx.colprior[q];
@@ -925,6 +1092,11 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 // finger ids are a contiguous tail of the pose vector in every supported model
                 if (op.nfinger > 0 && pid >= op.finger[0] && pid <= op.finger[op.nfinger - 1]) {
                     const double w2 = fp.wt_poseH * fp.wt_poseH; dg += w2; gq -= w2 * pose[pid];
+                }
+            }
+            if constexpr (XT) {
+                if (fp.use_face && op.nface > 0 && pid >= op.face[0] && pid <= op.face[op.nface - 1]) {   // contiguous ids
+                    const double w2 = fp.wt_poseF * fp.wt_poseF; dg += w2; gq -= w2 * pose[pid];
                 }
             }
         }
@@ -1025,13 +1197,18 @@ __device__ __noinline__ void rigid_init_serial(const Ctx& cx, const FrameParams&
 //   rigid     : before the solve, evaluate the markers at the current state and apply the Procrustes init
 //   eval_only : no solve; just evaluate every term at the current state (per-frame record)
 // ------------------------------------------------------------------------------------------------
-template <int NBLK>
+// XT: the unknowns are x = [trans, pose[ids], shape coefficients (nshp of them, Step 2 only)]; the shape block is stored
+// behind the pose variables (cx.pose[NP ..]), so a shape column q has colpid[q] = NP + e and moves with the same code.
+template <int NBLK, bool XT>
 __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
-                         const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, double e3,
+                         const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, int nshp,
+                         double* qs, double e3,
                          bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int set_id, int& vc_key,
                          int& tab_key, int& n_iter, int& n_fev, int& fail) {
     const int tid = threadIdx.x;
-    const int n = 3 + nids;
+    const int ncp = 3 + nids;
+    const int n = ncp + (XT ? nshp : 0);
+    const int NPX = XT ? ly.NPX : md.NP;
     // column tables + needed-joint lists of this free set; they stay in LDS until a solve with another set replaces them
     // (body-only Stage-II uses one set throughout: built once per chain)
     if (!eval_only && tab_key != set_id) {
@@ -1039,10 +1216,10 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.colq[i] = -1;
         __syncthreads();
         for (int q = tid; q < n; q += MOSHII_TPB) {
-            const int pid = (q < 3) ? -1 : ids[q - 3];
+            const int pid = (q < 3) ? -1 : ((q < ncp) ? ids[q - 3] : md.NP + (q - ncp));
             cx.colpid[q] = pid;
-            cx.colprior[q] = (pid >= 0) ? cx.pid2prior[pid] : -1;
-            if (pid >= 0) cx.colq[pid] = q;
+            cx.colprior[q] = (pid >= 0 && pid < md.NP) ? cx.pid2prior[pid] : -1;
+            if (pid >= 0 && pid < md.NP) cx.colq[pid] = q;
         }
         if (tid == 0) {
             for (int k = 0; k < md.K; ++k) cx.jointslot[k] = -1;
@@ -1086,7 +1263,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     }
     AReg<NBLK> A;
     A.zero();
-    for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+    for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
     if (tid < 3) cx.trans_t[tid] = cx.trans[tid];
     __syncthreads();
     Sse last;
@@ -1098,12 +1275,12 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     bool skip_eval = reuse && !rigid;
     while (true) {
         if (skip_eval) { last = carried; skip_eval = false; }
-        else last = eval_forward(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow, cx.ksum, nks, cx.vconst);
+        else last = eval_forward<XT>(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow, cx.ksum, nks, cx.vconst);
         at_pose = true;   // cleared below when a trial point is rejected
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
             __syncthreads();
-            for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+            for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
             if (tid < 3) cx.trans_t[tid] = cx.trans[tid];
             __syncthreads();
             rigid = false;
@@ -1125,7 +1302,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             improved = rho > 0.0;
             at_pose = improved;
             if (improved) {
-                for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose[i] = cx.pose_t[i];
+                for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose[i] = cx.pose_t[i];
                 if (tid < 3) cx.trans[tid] = cx.trans_t[tid];
                 __syncthreads();
                 if (e3 > 0.0 && (sse - last.total) / sse < e3) done = true;
@@ -1133,7 +1310,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
         if (do_assemble) {
-            assemble<NBLK>(cx, ly, md, at, pr, op, cx.pose, fp, n, nkf, nfree_hand, A);
+            assemble<NBLK, XT>(cx, ly, md, at, pr, op, cx.pose, fp, n, ncp, nkf, nfree_hand, qs, A);
             double gm = 0.0;
             for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
             if (block_max(gm, cx.red) < 1e-15) done = true;
@@ -1174,7 +1351,9 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = sc * cx.dsd[q];
         } else {
             if (!have_gn) {
-                if (!ldl_solve<NBLK>(A, cx.big, cx.g, cx.dgn, cx.y, n)) {
+                // (BIG: factor in the chain's global scratch behind the shape-derivative arrays, LDS part at the head of `big`)
+                constexpr bool BIG = XT && NBLK > 8;
+                if (!ldl_solve<NBLK, BIG>(A, BIG ? qs + (size_t)6 * md.K * op.nshape : cx.big, cx.big, cx.g, cx.dgn, cx.y, n)) {
                     fail = 1;
                     for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
                     __syncthreads();
@@ -1212,7 +1391,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         block_sum3(s2, p2, gd, cx.red);
         step = sqrt(s2);
         if (step <= 1e-15 * sqrt(p2)) break;   // "small step size" stop
-        for (int i = tid; i < md.NP; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
+        for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
         if (tid < 3) cx.trans_t[tid] = cx.trans[tid] + cx.ddl[tid];
         __syncthreads();
         for (int q = 3 + tid; q < n; q += MOSHII_TPB) cx.pose_t[cx.colpid[q]] += cx.ddl[q];
@@ -1230,6 +1409,7 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     cx.pose_prev = lds + ly.o_pose_prev; cx.vtarget = lds + ly.o_vtarget; cx.fullpose = lds + ly.o_fullpose;
     cx.Jl = lds + ly.o_Jl; cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
     cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
+    cx.vshp = lds + ly.o_vshp; cx.shp0 = lds + ly.o_shp0;
     cx.vconst = lds + ly.o_vconst; cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
     cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
     cx.g = lds + ly.o_g; cx.dsd = lds + ly.o_dsd; cx.dgn = lds + ly.o_dgn; cx.ddl = lds + ly.o_ddl; cx.y = lds + ly.o_y;
@@ -1250,7 +1430,9 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
 // MINW = 1: one workgroup per CU, the compiler may use the whole 512-entry register file (lowest latency per chain);
 // MINW = 2: registers capped at 256 so that two workgroups share a CU and cover each other's dependency stalls
 //           (highest throughput when there are more chains than CUs).
-template <int NBLK, int MINW>
+// XT = true: the extended variant with the Step-2 extras of chmosh.py:685-699 (jaw term, free shape block); kept out of
+//           the plain instantiations so that their register allocation and timings are untouched.
+template <int NBLK, int MINW, bool XT>
 __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev* __restrict__ chains, ModelDev md, PriorDev pr,
                                                              OptsDev op, ChainLayout ly) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1273,6 +1455,10 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             cx.pid2prior[i] = -1;
         }
         if (tid < 3) cx.trans[tid] = is ? is[2 * NP + tid] : (it ? it[tid] : 0.0);
+        if constexpr (XT) {
+            const double* ish = chp->init_shape;
+            for (int e = tid; e < op.nshape; e += MOSHII_TPB) { cx.pose[NP + e] = ish ? ish[e] : 0.0; cx.shp0[e] = 0.0; }
+        }
         has_prev = is ? (is[2 * NP + 3] != 0.0) : (iv != nullptr);
         first = is ? (is[2 * NP + 4] != 0.0) : (chp->first != 0);
     }
@@ -1338,6 +1524,14 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         fp.wt_poseH = op.wt_poseH * anneal;
         fp.wt_velo = op.wt_velo;
         fp.use_fingers = 0;
+        fp.wt_poseF = 0.0; fp.use_face = 0; fp.use_shape = 0; fp.has_stay = 0;
+        if constexpr (XT) {
+            fp.wt_poseF = op.wt_poseF * anneal;                                          // :606
+            // "extrap_dmpl" (:693-697): dmpl_prev was refreshed at :658-659, so the term pulls towards the value the
+            // coefficients have on entering this frame -- from the second solved frame on
+            fp.has_stay = (!first && op.wt_shape_stay != 0.0) ? 1 : 0;
+            for (int e = tid; e < op.nshape; e += MOSHII_TPB) cx.shp0[e] = cx.pose[NP + e];
+        }
         fp.has_velo = has_prev ? 1 : 0;
         if (has_prev)   // :624-626  target = pose.r + (pose.r - pose_prev)
             for (int i = tid; i < NP; i += MOSHII_TPB) cx.vtarget[i] = cx.pose[i] + (cx.pose[i] - cx.pose_prev[i]);
@@ -1353,17 +1547,23 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         bool at_pose = false;
         const bool same_sets = op.same_sets != 0;
         double prev_wt_pose = -1.0;
-        int prev_fingers = -1;
+        int prev_terms = -1;
         for (int kind = first ? 0 : 3; kind < 6; ++kind) {
             const bool round = kind < 3;
             const bool step2 = kind == 4;
             fp.wt_pose = round ? ((kind == 0) ? 10.0 : (kind == 1) ? 5.0 : 1.0) * wt_pose : wt_pose;
             fp.use_fingers = (kind >= 4 && op.nfinger > 0) ? 1 : 0;
-            const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_fingers == fp.use_fingers;
-            fin = run_phase<NBLK>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
+            if constexpr (XT) {
+                fp.use_face = (kind >= 4 && op.nface > 0) ? 1 : 0;
+                fp.use_shape = (kind >= 4 && op.nshape > 0) ? 1 : 0;
+            }
+            const int terms = fp.use_fingers | (fp.use_face << 1) | (fp.use_shape << 2);   // the Step-2-only residual blocks
+            const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_terms == terms;
+            fin = run_phase<NBLK, XT>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
+                                  (XT && step2) ? op.nshape : 0, XT ? chp->qscratch : nullptr,
                                   round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose,
                                   /*set_id=*/(kind >= 4 && !same_sets) ? 2 : 1, vc_key, tab_key, n_iter, n_fev, fail);
-            prev_wt_pose = fp.wt_pose; prev_fingers = fp.use_fingers;
+            prev_wt_pose = fp.wt_pose; prev_terms = terms;
         }
         first = false;
         if (record && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
@@ -1380,9 +1580,14 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if ((o = chp->pose) != nullptr) for (int i = tid; i < NP; i += MOSHII_TPB) o[(size_t)t * NP + i] = cx.pose[i];
             if ((o = chp->fullpose) != nullptr) for (int i = tid; i < md.P; i += MOSHII_TPB) o[(size_t)t * md.P + i] = cx.fullpose[i];
             if ((o = chp->msim) != nullptr) for (int i = tid; i < 3 * M; i += MOSHII_TPB) o[(size_t)t * 3 * M + i] = cx.msim[i];
+            if constexpr (XT)
+                if ((o = chp->shape) != nullptr) for (int e = tid; e < op.nshape; e += MOSHII_TPB) o[(size_t)t * op.nshape + e] = cx.pose[NP + e];
             if (tid == 0) {
                 if ((o = chp->trans) != nullptr) { o[t * 3 + 0] = cx.trans[0]; o[t * 3 + 1] = cx.trans[1]; o[t * 3 + 2] = cx.trans[2]; }
-                if ((o = chp->errs) != nullptr) { o[t * 4 + 0] = fin.data; o[t * 4 + 1] = fin.prior; o[t * 4 + 2] = fin.velo; o[t * 4 + 3] = fin.hand; }
+                if ((o = chp->errs) != nullptr) {
+                    o[t * 8 + 0] = fin.data; o[t * 8 + 1] = fin.prior; o[t * 8 + 2] = fin.velo; o[t * 8 + 3] = fin.hand;
+                    o[t * 8 + 4] = XT ? fin.face : 0.0; o[t * 8 + 5] = XT ? fin.shape : 0.0; o[t * 8 + 6] = XT ? fin.stay : 0.0; o[t * 8 + 7] = 0.0;
+                }
                 int* oi;
                 if ((oi = chp->iters) != nullptr) { oi[t * 2 + 0] = n_iter; oi[t * 2 + 1] = n_fev; }
                 if ((oi = chp->status) != nullptr) oi[t] = fail ? -1 : 0;
@@ -1399,14 +1604,22 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
 }
 
 #define MOSHII_INSTANTIATE(N) \
-    template __global__ void k_chain_solve<N, 1>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout); \
-    template __global__ void k_chain_solve<N, 2>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+    template __global__ void k_chain_solve<N, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout); \
+    template __global__ void k_chain_solve<N, 2, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
 MOSHII_INSTANTIATE(2)
 MOSHII_INSTANTIATE(4)
 MOSHII_INSTANTIATE(5)
 MOSHII_INSTANTIATE(7)
 MOSHII_INSTANTIATE(8)
 #undef MOSHII_INSTANTIATE
+// extended variant: up to 3 + 111 pose + 80 expression unknowns (SMPL-X with fingers and face: NBLK = 13)
+#define MOSHII_INSTANTIATE_XT(N) \
+    template __global__ void k_chain_solve<N, 1, true>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+MOSHII_INSTANTIATE_XT(5)
+MOSHII_INSTANTIATE_XT(8)
+MOSHII_INSTANTIATE_XT(10)
+MOSHII_INSTANTIATE_XT(13)
+#undef MOSHII_INSTANTIATE_XT
 
 
 // Simulated markers for explicit pose variables (TransformedLms.r), one frame per workgroup.
@@ -1424,35 +1637,45 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restr
     FrameParams fp;
     fp.obs = nullptr; fp.wt_data = 0.0; fp.wt_pose = 0.0; fp.wt_poseH = 0.0; fp.wt_velo = 0.0;
     fp.has_velo = 0; fp.use_fingers = 0; fp.nobs = 0;
+    fp.wt_poseF = 0.0; fp.use_face = 0; fp.use_shape = 0; fp.has_stay = 0;
     PriorDev pr; pr.G = 0; pr.npose = 0; pr.means = nullptr; pr.chols = nullptr; pr.halfprec = nullptr; pr.neglogw = nullptr;
     OptsDev op;
     op.nbody = 0; op.nfinger = 0; op.n1 = 0; op.n2 = 0; op.maxiter = 0;
     op.step1 = nullptr; op.step2 = nullptr; op.body = nullptr; op.finger = nullptr;
+    op.nface = 0; op.nshape = 0; op.face = nullptr;
     for (int k = 1 + tid; k < md.K; k += MOSHII_TPB) cx.ksum[k - 1] = k;   // every joint's correctives, on top of v_shaped
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];
     __syncthreads();
-    eval_forward(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh);
+    eval_forward<false>(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh);
     for (int i = tid; i < 3 * at.M; i += MOSHII_TPB) out[(size_t)f * 3 * at.M + i] = cx.msim[i];
 }
 
 }  // namespace moshii
 
-extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int n_chains, size_t lds_bytes, hipStream_t stream,
+extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt, int n_chains, size_t lds_bytes, hipStream_t stream,
                                                 const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
                                                 const OptsDev* op, const ChainLayout* ly) {
     using namespace moshii;
     void (*kern)(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout) = nullptr;
-    switch (nblk * 2 + (two_per_cu ? 1 : 0)) {
-        case 4: kern = k_chain_solve<2, 1>; break;
-        case 5: kern = k_chain_solve<2, 2>; break;
-        case 8: kern = k_chain_solve<4, 1>; break;
-        case 9: kern = k_chain_solve<4, 2>; break;
-        case 10: kern = k_chain_solve<5, 1>; break;
-        case 11: kern = k_chain_solve<5, 2>; break;
-        case 14: kern = k_chain_solve<7, 1>; break;
-        case 15: kern = k_chain_solve<7, 2>; break;
-        case 16: kern = k_chain_solve<8, 1>; break;
-        case 17: kern = k_chain_solve<8, 2>; break;
+    if (xt) {
+        switch (nblk) {
+            case 5: kern = k_chain_solve<5, 1, true>; break;
+            case 8: kern = k_chain_solve<8, 1, true>; break;
+            case 10: kern = k_chain_solve<10, 1, true>; break;
+            case 13: kern = k_chain_solve<13, 1, true>; break;
+            default: return hipErrorInvalidValue;
+        }
+    } else switch (nblk * 2 + (two_per_cu ? 1 : 0)) {
+        case 4: kern = k_chain_solve<2, 1, false>; break;
+        case 5: kern = k_chain_solve<2, 2, false>; break;
+        case 8: kern = k_chain_solve<4, 1, false>; break;
+        case 9: kern = k_chain_solve<4, 2, false>; break;
+        case 10: kern = k_chain_solve<5, 1, false>; break;
+        case 11: kern = k_chain_solve<5, 2, false>; break;
+        case 14: kern = k_chain_solve<7, 1, false>; break;
+        case 15: kern = k_chain_solve<7, 2, false>; break;
+        case 16: kern = k_chain_solve<8, 1, false>; break;
+        case 17: kern = k_chain_solve<8, 2, false>; break;
         default: return hipErrorInvalidValue;
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int n_chains, size_t lds_bytes, hipStream_t stream,
+extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt, int n_chains, size_t lds_bytes, hipStream_t stream,
                                                 const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
                                                 const OptsDev* op, const ChainLayout* ly);
 extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t stream, const AttachDev* att,
@@ -66,6 +66,9 @@ struct moshii_model_s {
     std::vector<double> weights_host;   // [V][K] (attachment packing)
     double *d_vt = nullptr, *d_shapedirs = nullptr, *d_posedirs = nullptr, *d_weights = nullptr, *d_Jreg = nullptr;
     double *d_vsh = nullptr, *d_J = nullptr, *d_hands_mean = nullptr, *d_comps = nullptr;
+    double* d_JS = nullptr;             // [K][nshape][3] (moshii_model_set_free_shape)
+    int shape_start = 0, nshape = 0;
+    Scratch qscratch;                   // per-chain shape-derivative scratch of the extended chain kernel
     int *d_parents = nullptr, *d_depth = nullptr, *d_comp_lo = nullptr, *d_comp_hi = nullptr, *d_col_lo = nullptr, *d_col_hi = nullptr;
     unsigned long long* d_anc = nullptr;
     bool betas_set = false;
@@ -78,6 +81,7 @@ struct moshii_model_s {
         md.nhand_full = nhand_full; md.maxdepth = maxdepth;
         md.parents = d_parents; md.J = d_J; md.hands_mean = d_hands_mean; md.comps = d_comps;
         md.comp_lo = d_comp_lo; md.comp_hi = d_comp_hi; md.col_lo = d_col_lo; md.col_hi = d_col_hi; md.anc = d_anc; md.depth = d_depth;
+        md.nshape = nshape; md.JS = d_JS;
         return md;
     }
 };
@@ -91,7 +95,8 @@ struct moshii_prior_s {
 struct moshii_attach_s {
     moshii_model_t model = nullptr;
     int M = 0, Nv = 0, Nvp = 0, NW = 0;
-    double *d_vsh = nullptr, *d_Pt = nullptr, *d_Pj = nullptr, *d_ww = nullptr, *d_coef = nullptr;
+    double *d_vsh = nullptr, *d_Pt = nullptr, *d_Pj = nullptr, *d_ww = nullptr, *d_coef = nullptr, *d_Ssh = nullptr;
+    int nshape = 0;                     // free shape block gathered at creation (0: none)
     int* d_wj = nullptr;
     int* d_vids = nullptr;
     AttachDev* d_self = nullptr;
@@ -145,6 +150,37 @@ __global__ void k_pack_attach(int Nv, int Nvp, int K, const int* __restrict__ vi
     }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < Nv * 3) vsh_out[t] = vsh[(size_t)vids[t / 3] * 3 + t % 3];
+}
+
+// JS[k][e][i] = sum_v Jreg[k][v] shapedirs[v][i][start + e]: the regressed joints' derivative wrt the free shape block.
+__global__ void k_shape_joints(int V, int NB, int start, int E, const double* __restrict__ Jreg, const double* __restrict__ sd,
+                               double* __restrict__ JS) {
+    const int k = blockIdx.x / E, e = blockIdx.x % E;
+    __shared__ double red[3][256];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const double w = Jreg[(size_t)k * V + v];
+        if (w != 0.0)
+            for (int i = 0; i < 3; ++i) s[i] += w * sd[((size_t)v * 3 + i) * NB + start + e];
+    }
+    for (int i = 0; i < 3; ++i) red[i][threadIdx.x] = s[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) for (int i = 0; i < 3; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) JS[((size_t)k * E + e) * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// Ssh[e][i][a] = shapedirs[vids[a]][i][start + e]  (vertex index fastest; zero in the padding)
+__global__ void k_pack_shape(int Nv, int Nvp, int NB, int start, int E, const int* __restrict__ vids,
+                             const double* __restrict__ sd, double* __restrict__ Ssh) {
+    const size_t total = (size_t)E * 3 * Nvp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int a = (int)(idx % Nvp);
+        const int r = (int)(idx / Nvp);   // e*3 + i
+        Ssh[idx] = (a < Nv) ? sd[((size_t)vids[a] * 3 + r % 3) * NB + start + r / 3] : 0.0;
+    }
 }
 
 // Reference-precision full-mesh LBS: one block = 256 vertices of one frame.
@@ -226,13 +262,16 @@ __global__ void k_lbs_f64(ModelDev md, const double* __restrict__ vsh, const dou
 }
 
 // ---- LDS layout of the chain kernel ------------------------------------------------------------
-int pick_nblk(int n) {
+int pick_nblk(int n, bool xt = false) {
     const int opts[5] = {2, 4, 5, 7, 8};
+    const int opts_xt[4] = {5, 8, 10, 13};   // instantiations of the extended variant (chain_solve.hip)
+    if (xt) { for (int o : opts_xt) if (o * 16 >= n + 1) return o; return -1; }
     for (int o : opts) if (o * 16 >= n + 1) return o;   // +1: the right-hand side rides along as row n (ldl_solve)
     return -1;
 }
 
-ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm, int nblk = 0, int nhj = 0) {
+ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax, int npose, int G, int nmax, int nkfmax, int Tm, int nblk = 0, int nhj = 0,
+                        int nshape = 0) {
     ChainLayout ly;
     memset(&ly, 0, sizeof(ly));
     const int K = m->K, NP = m->NP, P = m->P;
@@ -241,7 +280,10 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.Mmax = Mmax; ly.Nvmax = Nvmax; ly.NWmax = NWmax; ly.nmax = nmax; ly.Tm = Tm; ly.nkfmax = nkfmax; ly.LDJ = LDJ; ly.nhj = nhj;
     int off = 0;
     auto take = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
-    ly.o_pose = take(NP); ly.o_trans = take(4); ly.o_pose_t = take(NP); ly.o_trans_t = take(4);
+    const int NPX = NP + nshape;   // free shape coefficients ride behind the pose variables
+    ly.NPX = NPX;
+    ly.o_pose = take(NPX); ly.o_trans = take(4); ly.o_pose_t = take(NPX); ly.o_trans_t = take(4);
+    ly.o_vshp = take(nshape > 0 ? Nvmax * 3 : 0); ly.o_shp0 = take(nshape);
     ly.o_pose_prev = take(NP); ly.o_vtarget = take(NP); ly.o_fullpose = take(P);
     ly.o_feat = take(K * 9); ly.o_B = take(K * 28); ly.o_omega = take(K * 10); ly.o_Jl = take(K * 3); ly.o_Rw = take(K * 9); ly.o_tw = take(K * 3);
     ly.o_Rloc = take(K * 9); ly.o_acol = take(K * 9);
@@ -261,7 +303,9 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 30);
     ly.t_Trot = ttake(3 * Tm * 10); ly.t_xjs = ttake(3 * Tm * NWmax * 4); ly.t_rest = ttake(3 * Tm);
     ly.t_tjs = ttake((3 * Tm * NWmax + 1) / 2);
-    const int chol = (nmax + 1) * (nmax + 2) / 2 + 2 + 4 * LDJ + 4;   // + trash / zero words + the column broadcast buffer of ldl_solve
+    // packed factor + trash / zero words + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
+    // the factor lives in global scratch and LDS keeps the broadcast buffer plus a 16-row panel
+    const int chol = (nblk > 8) ? 2 + 4 * LDJ + 16 * LDJ + 4 : (nmax + 1) * (nmax + 2) / 2 + 2 + 4 * LDJ + 4;
     ly.big_doubles = std::max(t, chol);
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
@@ -364,7 +408,7 @@ int moshii_model_destroy(moshii_model_t m) {
     if (!m) return MOSHII_OK;
     hipDeviceSynchronize();
     void* ptrs[] = {m->d_vt, m->d_shapedirs, m->d_posedirs, m->d_weights, m->d_Jreg, m->d_vsh, m->d_J, m->d_hands_mean,
-                    m->d_comps, m->d_parents, m->d_depth, m->d_comp_lo, m->d_comp_hi, m->d_col_lo, m->d_col_hi, m->d_anc};
+                    m->d_comps, m->d_parents, m->d_depth, m->d_comp_lo, m->d_comp_hi, m->d_col_lo, m->d_col_hi, m->d_anc, m->d_JS};
     for (void* p : ptrs) if (p) hipFree(p);
     free_l32(m);
     delete m;
@@ -385,6 +429,20 @@ int moshii_model_set_betas(moshii_model_t m, const double* betas, int32_t nb) {
     if (d_b) hipFree(d_b);
     m->betas_set = true;
     m->l32_valid = false;
+    return MOSHII_OK;
+}
+
+int moshii_model_set_free_shape(moshii_model_t m, int32_t start, int32_t count) {
+    if (!m || start < 0 || count < 0 || start + count > m->NB) return fail(MOSHII_ERR_ARG, "free shape block outside shapedirs");
+    if (count > 125) return fail(MOSHII_ERR_UNSUPPORTED, "at most 125 free shape coefficients");
+    HIP_TRY(hipDeviceSynchronize());
+    if (m->d_JS) { hipFree(m->d_JS); m->d_JS = nullptr; }
+    m->shape_start = start; m->nshape = count;
+    if (count == 0) return MOSHII_OK;
+    HIP_TRY(hipMalloc((void**)&m->d_JS, (size_t)m->K * count * 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_shape_joints, dim3(m->K * count), dim3(256), 0, 0, m->V, m->NB, start, count, m->d_Jreg, m->d_shapedirs, m->d_JS);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     return MOSHII_OK;
 }
 
@@ -526,10 +584,19 @@ int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, co
     hipLaunchKernelGGL(k_pack_attach, dim3(std::max(blocks, 1)), dim3(256), 0, 0, a->Nv, a->Nvp, m->K, a->d_vids, m->d_posedirs,
                        m->d_vsh, a->d_Pt, a->d_Pj, a->d_vsh);
     HIP_TRY(hipGetLastError());
+    if (m->nshape > 0) {   // rows of the free shape block (moshii_model_set_free_shape)
+        a->nshape = m->nshape;
+        const size_t ns = (size_t)m->nshape * 3 * a->Nvp;
+        HIP_TRY(hipMalloc((void**)&a->d_Ssh, ns * sizeof(double)));
+        hipLaunchKernelGGL(k_pack_shape, dim3((unsigned)std::min<size_t>(4096, (ns + 255) / 256)), dim3(256), 0, 0, a->Nv, a->Nvp, m->NB,
+                           m->shape_start, m->nshape, a->d_vids, m->d_shapedirs, a->d_Ssh);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipDeviceSynchronize());
     AttachDev& av = a->host_view;
     av.M = M; av.Nv = a->Nv; av.Nvp = a->Nvp; av.NW = NW;
     av.vsh = a->d_vsh; av.Pt = a->d_Pt; av.Pj = a->d_Pj; av.wj = a->d_wj; av.ww = a->d_ww; av.coef = a->d_coef;
+    av.Ssh = a->d_Ssh;
     if ((rc = dev_upload(&av, 1, &a->d_self))) return rc;
     *out = a;
     return MOSHII_OK;
@@ -538,7 +605,7 @@ int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, co
 int moshii_attach_destroy(moshii_attach_t a) {
     if (!a) return MOSHII_OK;
     hipDeviceSynchronize();
-    void* ptrs[] = {a->d_vsh, a->d_Pt, a->d_Pj, a->d_ww, a->d_coef, a->d_wj, a->d_vids, a->d_self};
+    void* ptrs[] = {a->d_vsh, a->d_Pt, a->d_Pj, a->d_ww, a->d_coef, a->d_wj, a->d_vids, a->d_self, a->d_Ssh};
     for (void* q : ptrs) if (q) hipFree(q);
     delete a;
     return MOSHII_OK;
@@ -570,6 +637,7 @@ namespace {
 struct LaunchCfg {
     int nblk = 0;
     int two_per_cu = 0;
+    int xt = 0;                 // extended kernel variant (jaw term / free shape block)
     ChainLayout ly;
     size_t lds_bytes = 0;
     OptsDev od;
@@ -586,9 +654,16 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     if (o->n_body > 0 && (!prior || prior->npose != o->n_body)) return fail(MOSHII_ERR_ARG, "prior npose must equal n_body");
     if (o->n_step1 < 0 || o->n_step2 < 0 || o->n_step1 > m->NP || o->n_step2 > m->NP) return fail(MOSHII_ERR_ARG, "bad free-variable lists");
     const int NP = m->NP;
-    const int nmax = 3 + std::max(o->n_step1, o->n_step2);
-    int nblk = pick_nblk(nmax);
-    if (nblk < 0) return fail(MOSHII_ERR_UNSUPPORTED, "more than 125 free pose variables per step");
+    const int nshape = o->n_shape;
+    if (nshape < 0 || o->n_face < 0) return fail(MOSHII_ERR_ARG, "bad Step-2 extras");
+    if (nshape > 0 && nshape != m->nshape) return fail(MOSHII_ERR_ARG, "n_shape must equal the block of moshii_model_set_free_shape");
+    if (o->n_face > 0 && !o->face_ids) return fail(MOSHII_ERR_ARG, "face_ids missing");
+    for (int i = 1; i < o->n_face; ++i)
+        if (o->face_ids[i] != o->face_ids[i - 1] + 1) return fail(MOSHII_ERR_UNSUPPORTED, "face ids must be contiguous");
+    const int xt = (nshape > 0 || o->n_face > 0) ? 1 : 0;
+    const int nmax = 3 + std::max(o->n_step1, o->n_step2 + nshape);
+    int nblk = pick_nblk(nmax, xt != 0);
+    if (nblk < 0) return fail(MOSHII_ERR_UNSUPPORTED, xt ? "more than 207 unknowns per step" : "more than 125 free pose variables per step");
     if (const char* e = getenv("MOSHII_FORCE_NBLK")) nblk = std::max(nblk, atoi(e));
     auto count_kf = [&](const int32_t* ids, int n) {   // needed joints (superset over both steps)
         std::vector<char> need(m->K, 0);
@@ -624,17 +699,17 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     const int nhj = hand_free ? (m->K - m->body_dof / 3) : 0;
     int Tm = std::min(40, std::max(2, Mmax));   // T0 maps tile vertices to threads 0..127: 3 Tm <= 120
     if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(40, atoi(e)));
-    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj);
-    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj); }
+    ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
+    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape); }
     if (!getenv("MOSHII_TM") && Tm < Mmax) {   // balance the tiles: same tile count, equal sizes
         const int ntiles = (Mmax + Tm - 1) / Tm;
         Tm = (Mmax + ntiles - 1) / ntiles;
-        ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj);
+        ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
     }
     const size_t lds_bytes = (size_t)ly.total_doubles * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(MOSHII_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of a CU");
 
-    const size_t nids = (size_t)o->n_step1 + o->n_step2 + o->n_body + o->n_finger;
+    const size_t nids = (size_t)o->n_step1 + o->n_step2 + o->n_body + o->n_finger + o->n_face;
     const size_t need = sizeof(int) * (nids + 16) + 64 + extra_bytes;
     int rc = m->scratch.reserve(need);
     if (rc) return rc;
@@ -645,6 +720,8 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     ids.insert(ids.end(), o->step2_ids, o->step2_ids + o->n_step2);
     ids.insert(ids.end(), o->body_ids, o->body_ids + o->n_body);
     ids.insert(ids.end(), o->finger_ids, o->finger_ids + o->n_finger);
+    const size_t efc = ids.size();
+    ids.insert(ids.end(), o->face_ids, o->face_ids + o->n_face);
     char* dbase = m->scratch.ptr;
     if (!ids.empty()) {
         HIP_TRY(hipMemcpyAsync(dbase, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -658,19 +735,21 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     od.wt_annealing = o->wt_annealing; od.num_train_markers = o->num_train_markers;
     od.e3_first = o->e3_first; od.e3 = o->e3; od.delta0 = o->delta0; od.maxiter = o->maxiter;
     od.n1 = o->n_step1; od.n2 = o->n_step2; od.nbody = o->n_body; od.nfinger = o->n_finger;
-    od.same_sets = (o->n_step1 == o->n_step2 && std::equal(o->step1_ids, o->step1_ids + o->n_step1, o->step2_ids)) ? 1 : 0;
+    od.same_sets = (nshape == 0 && o->n_step1 == o->n_step2 && std::equal(o->step1_ids, o->step1_ids + o->n_step1, o->step2_ids)) ? 1 : 0;
+    od.wt_poseF = o->wt_poseF; od.wt_shape = o->wt_shape; od.wt_shape_stay = o->wt_shape_stay;
+    od.nface = o->n_face; od.nshape = nshape;
     const int* dids = (const int*)dbase;
-    od.step1 = dids + e1; od.step2 = dids + e2; od.body = dids + eb; od.finger = dids + ef;
+    od.step1 = dids + e1; od.step2 = dids + e2; od.body = dids + eb; od.finger = dids + ef; od.face = dids + efc;
     memset(&cfg->pd, 0, sizeof(cfg->pd));
     if (prior) cfg->pd = prior->dev();
     cfg->md = m->dev();
-    cfg->nblk = nblk; cfg->two_per_cu = two_per_cu; cfg->ly = ly; cfg->lds_bytes = lds_bytes;
+    cfg->nblk = nblk; cfg->two_per_cu = xt ? 0 : two_per_cu; cfg->xt = xt; cfg->ly = ly; cfg->lds_bytes = lds_bytes;
     return MOSHII_OK;
 }
 
 int launch_chains(const LaunchCfg& cfg, int n, const ChainDev* d_chains, hipStream_t stream) {
-    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, cfg.two_per_cu, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly));
-    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + "," + std::to_string(cfg.two_per_cu ? 2 : 1) + ">";
+    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, cfg.two_per_cu, cfg.xt, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly));
+    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + "," + std::to_string(cfg.two_per_cu ? 2 : 1) + (cfg.xt ? ",xt>" : ">");
     g_last.lds = (int)cfg.lds_bytes; g_last.threads = MOSHII_TPB;
     return MOSHII_OK;
 }
@@ -702,14 +781,14 @@ int stage_in(const FrameBufs& h, int NP, int P, hipStream_t stream, Staged* s) {
     HIP_TRY(hipMalloc((void**)&s->fullpose, Fz * P * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&s->trans, Fz * 3 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&s->msim, Fz * M * 3 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&s->errs, Fz * 4 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->errs, Fz * MOSHII_NERR * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&s->iters, Fz * 2 * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&s->status, Fz * sizeof(int)));
     HIP_TRY(hipMemsetAsync(s->pose, 0, Fz * NP * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(s->fullpose, 0, Fz * P * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(s->trans, 0, Fz * 3 * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(s->msim, 0, Fz * M * 3 * sizeof(double), stream));
-    HIP_TRY(hipMemsetAsync(s->errs, 0, Fz * 4 * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(s->errs, 0, Fz * MOSHII_NERR * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(s->iters, 0, Fz * 2 * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(s->status, 0, Fz * sizeof(int), stream));
     return MOSHII_OK;
@@ -722,7 +801,7 @@ int stage_out(const FrameBufs& h, int NP, int P, Staged* s) {
         if (h.fullpose) HIP_TRY(hipMemcpy(h.fullpose, s->fullpose, F * P * sizeof(double), hipMemcpyDeviceToHost));
         if (h.trans) HIP_TRY(hipMemcpy(h.trans, s->trans, F * 3 * sizeof(double), hipMemcpyDeviceToHost));
         if (h.msim) HIP_TRY(hipMemcpy(h.msim, s->msim, F * M * 3 * sizeof(double), hipMemcpyDeviceToHost));
-        if (h.errs) HIP_TRY(hipMemcpy(h.errs, s->errs, F * 4 * sizeof(double), hipMemcpyDeviceToHost));
+        if (h.errs) HIP_TRY(hipMemcpy(h.errs, s->errs, F * MOSHII_NERR * sizeof(double), hipMemcpyDeviceToHost));
         if (h.iters) HIP_TRY(hipMemcpy(h.iters, s->iters, F * 2 * sizeof(int), hipMemcpyDeviceToHost));
         if (h.status) HIP_TRY(hipMemcpy(h.status, s->status, F * sizeof(int), hipMemcpyDeviceToHost));
     }
@@ -774,12 +853,21 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         Mmax = std::max(Mmax, ch.attach->M); Nvmax = std::max(Nvmax, ch.attach->Nv); NWmax = std::max(NWmax, ch.attach->NW);
     }
     // control block after the id lists: [ChainDev x n][init vectors]
-    const size_t extra = sizeof(ChainDev) * n_chains + sizeof(double) * (size_t)n_chains * (2 * NP + 4) + 256;
+    const int E = o->n_shape > 0 ? o->n_shape : 0;
+    const size_t extra = sizeof(ChainDev) * n_chains + sizeof(double) * (size_t)n_chains * (2 * NP + 4 + E + 2) + 256;
     LaunchCfg cfg;
     size_t ctl = 0;
     int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, n_chains, stream, extra, &cfg, &ctl);
     if (rc) return rc;
     char* dbase = m->scratch.ptr + ctl;
+    // extended variant: per-chain scratch for the shape derivatives of the joint transforms ([2][K][E][3] doubles)
+    const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 4 : 0;   // global packed factor (ldl_solve BIG)
+    const size_t qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
+    if (E > 0) {
+        if ((rc = m->qscratch.reserve(qbytes * n_chains))) return rc;
+        m->qscratch.used = true; m->qscratch.last_stream = stream;
+    }
+    std::vector<double*> d_shape(n_chains, nullptr);
     std::vector<char> hostbuf(extra, 0);
     size_t off = sizeof(ChainDev) * n_chains;
     auto put = [&](const void* src, size_t bytes) { off = (off + 15) & ~size_t(15); size_t o2 = off; memcpy(hostbuf.data() + off, src, bytes); off += bytes; return o2; };
@@ -793,10 +881,20 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         if (ch.init_pose) cd.init_pose = (const double*)(dbase + put(ch.init_pose, sizeof(double) * NP));
         if (ch.init_trans) cd.init_trans = (const double*)(dbase + put(ch.init_trans, sizeof(double) * 3));
         if (ch.init_pose_prev) cd.init_prev = (const double*)(dbase + put(ch.init_pose_prev, sizeof(double) * NP));
+        if (E > 0) {
+            if (ch.init_shape) cd.init_shape = (const double*)(dbase + put(ch.init_shape, sizeof(double) * E));
+            cd.qscratch = (double*)(m->qscratch.ptr + qbytes * c);
+        }
         if (dev) {
             cd.obs = ch.obs; cd.vis = ch.vis; cd.pose = ch.pose; cd.fullpose = ch.fullpose; cd.trans = ch.trans;
             cd.msim = ch.markers_sim; cd.errs = ch.errs; cd.iters = ch.iters; cd.status = ch.status;
+            cd.shape = E > 0 ? ch.shape : nullptr;
         } else {
+            if (E > 0 && ch.shape && ch.F > 0) {
+                HIP_TRY(hipMalloc((void**)&d_shape[c], (size_t)ch.F * E * sizeof(double)));
+                HIP_TRY(hipMemsetAsync(d_shape[c], 0, (size_t)ch.F * E * sizeof(double), stream));
+                cd.shape = d_shape[c];
+            }
             const FrameBufs fb{ch.F, ch.attach->M, ch.obs, ch.vis, ch.pose, ch.fullpose, ch.trans, ch.markers_sim, ch.errs, ch.iters, ch.status};
             Staged& s = st[c];
             if ((rc = stage_in(fb, NP, P, stream, &s))) return rc;
@@ -815,6 +913,10 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
             const moshii_chain_desc& ch = chains[c];
             const FrameBufs fb{ch.F, ch.attach->M, ch.obs, ch.vis, ch.pose, ch.fullpose, ch.trans, ch.markers_sim, ch.errs, ch.iters, ch.status};
             if ((rc = stage_out(fb, NP, P, &st[c]))) return rc;
+            if (d_shape[c]) {
+                HIP_TRY(hipMemcpy(ch.shape, d_shape[c], (size_t)ch.F * E * sizeof(double), hipMemcpyDeviceToHost));
+                hipFree(d_shape[c]);
+            }
         }
     }
     return MOSHII_OK;
@@ -835,6 +937,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                           const moshii_sequence_desc* seqs, const moshii_chunk_opts* co, uint32_t flags, void* stream_,
                           moshii_chunk_report* report) {
     if (!m || !o || !seqs || n_seq < 1) return fail(MOSHII_ERR_ARG, "bad argument");
+    if (o->n_shape > 0) return fail(MOSHII_ERR_UNSUPPORTED, "free shape coefficients: the chunk hand-off state does not carry them; use moshii_chain_solve");
     hipStream_t stream = (hipStream_t)stream_;
     const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
     const int NP = m->NP, P = m->P, S = 2 * NP + 5;
@@ -921,7 +1024,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         cd.fullpose = b.fullpose ? b.fullpose + (size_t)from * P : nullptr;
         cd.trans = b.trans ? b.trans + (size_t)from * 3 : nullptr;
         cd.msim = b.msim ? b.msim + (size_t)from * M * 3 : nullptr;
-        cd.errs = b.errs ? b.errs + (size_t)from * 4 : nullptr;
+        cd.errs = b.errs ? b.errs + (size_t)from * MOSHII_NERR : nullptr;
         cd.iters = b.iters ? b.iters + (size_t)from * 2 : nullptr;
         cd.status = b.status ? b.status + (size_t)from : nullptr;
         cd.final_state = d_final + (size_t)idx * S;

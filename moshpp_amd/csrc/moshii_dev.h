@@ -18,6 +18,9 @@ struct ModelDev {
     const int* col_hi;               // [nhand_full] one past the last such component
     const unsigned long long* anc;   // [K] bit j set iff k is j or an ancestor of j
     const int* depth;                // [K]
+    // free shape block (moshii_model_set_free_shape): dJ/ds, joint-major so that (joint, coefficient) items are contiguous
+    int nshape;
+    const double* JS;                // [K][nshape][3]
 };
 
 struct AttachDev {
@@ -28,6 +31,7 @@ struct AttachDev {
     const int* wj;         // [Nv][NW] joints with non-zero skinning weight (padded: joint 0, weight 0)
     const double* ww;      // [Nv][NW]
     const double* coef;    // [M][3]
+    const double* Ssh;     // [nshape][3][Nvp] rows of the free shape block, vertex index fastest (null when nshape == 0)
 };
 
 struct PriorDev {
@@ -46,6 +50,10 @@ struct OptsDev {
     const int* step2;
     const int* body;
     const int* finger;
+    // Step-2 extras (extended kernel variant only)
+    double wt_poseF, wt_shape, wt_shape_stay;
+    int nface, nshape;
+    const int* face;
 };
 
 struct ChainDev {
@@ -76,6 +84,10 @@ struct ChainDev {
     double* run_final;          // final-state slot of this chain's first chunk (slots are contiguous by chunk)
     double* run_entry;          // entry-state slot of this chain's first chunk
     int* frames_done;           // device or null: number of frames this chain processed before it stopped
+    // free shape coefficients (extended kernel variant)
+    const double* init_shape;   // device [nshape] or null
+    double* shape;              // device [F][nshape] or null
+    double* qscratch;           // device [2][K][nshape][3]: d(joint world position)/ds and q = dt - Rw . dJ/ds of the current point
     double rejoin_tol;          // > 0 (repair chains): stop once two consecutive solved frames reproduce the rows already in
                                 // `pose`/`trans` to this tolerance -- the rest of the chunk is then the continuation within tol
 };
@@ -83,6 +95,8 @@ struct ChainDev {
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).
 struct ChainLayout {
     int Mmax, Nvmax, NWmax, nmax, Tm, nkfmax, LDJ, nhj;
+    int NPX;                   // pose variables + free shape coefficients (the shape block rides behind the pose in LDS)
+    int o_vshp, o_shp0;        // shaped rest vertices of the current evaluation; shape coefficients at frame start
     int o_pose, o_trans, o_pose_t, o_trans_t, o_pose_prev, o_vtarget, o_fullpose;
     int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol, o_Jl;
     int o_vposed, o_vpos, o_msim, o_res, o_vconst;

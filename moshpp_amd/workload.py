@@ -60,7 +60,7 @@ class DeviceSequence:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
         self.pose = z((F, sm.NP), torch.float64); self.fullpose = z((F, 3 * sm.K), torch.float64)
         self.trans = z((F, 3), torch.float64); self.msim = z((F, M, 3), torch.float64)
-        self.errs = z((F, 4), torch.float64); self.iters = z((F, 2), torch.int32); self.status = z((F,), torch.int32)
+        self.errs = z((F, capi.NERR), torch.float64); self.iters = z((F, 2), torch.int32); self.status = z((F,), torch.int32)
         self.cdesc = (capi.ChainDesc * 1)()
         self.sdesc = (capi.SequenceDesc * 1)()
         for d in (self.cdesc[0], self.sdesc[0]):

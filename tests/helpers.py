@@ -44,21 +44,27 @@ def oracle_case(model_type='smplh', F=12, M=53, seed=0, **kw):
                 model_type=model_type)
 
 
-def device_case(case, optimize_fingers=False, optimize_toes=False, maxiter=100, weights=None):
-    """libmoshii handles + options for an oracle_case (same arrays, same ids)."""
+def device_case(case, optimize_fingers=False, optimize_toes=False, maxiter=100, weights=None, optimize_face=False,
+                shape_kind=None):
+    """libmoshii handles + options for an oracle_case / shape_case (same arrays, same ids)."""
     from moshpp_amd import capi
     mdl = case['model']
     m = case['m']
     dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'],
                      mdl['parents'], mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
     dev.set_betas(case['s']['betas'])
+    if shape_kind is not None:
+        dev.set_free_shape(case['start'], case['E'])          # before the attachment: it gathers its rows of the block
     att = capi.Attachment(dev, case['closest'], case['coef'])
     pr = None
     if case['prior'] is not None:
         pr = capi.Prior(case['prior']['means'], case['prior']['chols'], case['prior']['weights'])
-    root, body, finger, st1, st2 = so.pose_id_sets(case['model_type'], m['NP'], optimize_fingers, optimize_toes)
+    root, body, finger, st1, st2 = so.pose_id_sets(case['model_type'], m['NP'], optimize_fingers, optimize_toes,
+                                                   optimize_face=optimize_face)
     W = so.stageii_weights_default() if weights is None else weights
-    opts = capi.make_opts(W, st1, st2, body, finger if optimize_fingers else [], maxiter=maxiter)
+    opts = capi.make_opts(W, st1, st2, body, finger if optimize_fingers else [], maxiter=maxiter,
+                          face_ids=so.face_pose_ids(case['model_type'], optimize_face),
+                          n_shape=case['E'] if shape_kind is not None else 0, shape_kind=shape_kind)
     return dict(model=dev, attach=att, prior=pr, opts=opts)
 
 

@@ -316,3 +316,44 @@ def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib, rejoin):
     dp = np.abs(outs[0]['fullpose'] - seq['fullpose'])[solved].max(1)
     print(f'max dev {dp.max():.2e}, frames > 1e-9: {(dp > 1e-9).sum()}')
     assert dp.max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_type,kind,E,fingers,F', [
+    ('smplx', 'expr', 5, False, 8),        # jaw + 5 expression coefficients: 3 + 63 + 5 = 71 unknowns (NBLK 5, extended)
+    ('smplh', 'dmpl', 4, False, 8),        # DMPL block incl. the "stay" term (chmosh.py:693-699)
+    ('smplx', 'expr', 80, True, 4),        # the yaml default: 3 + 111 + 80 = 194 unknowns (NBLK 13)
+])
+def test_free_shape_block_matches_oracle(gpu_lib, model_type, kind, E, fingers, F):
+    """optimize_face / optimize_dynamics (chmosh.py:507-514, 562-567, 685-699): expression or DMPL coefficients and the
+    jaw as Step-2 free variables, through the extended chain kernel, against the oracle chain."""
+    from moshpp_amd import capi
+    from tests.helpers import shape_case
+    case = shape_case(model_type, F=F, M=40, E=E, seed=3, kind=kind)
+    face = kind == 'expr'
+    dev = device_case(case, optimize_fingers=fingers, optimize_face=face, shape_kind=kind)
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'],
+                           model_type, optimize_fingers=fingers, optimize_face=face, free_shape=kind)
+    out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+    assert capi.last_launch_info()[0].endswith(',xt>')
+    assert np.all(out['status'] == 0)
+    dp = np.abs(out['fullpose'] - ref['fullpose']).max()
+    dt = np.abs(out['trans'] - ref['trans']).max()
+    ds = np.abs(out['shape'] - ref['shape']).max()
+    rmse = np.sqrt(np.mean([((out['markers_sim'][t][case['vis'][t]] - ref['markers_sim'][t]) ** 2).sum(1).mean()
+                            for t in range(F)]))
+    print(f'{model_type}/{kind} E={E}: max|dpose|={dp:.3e} rad max|dtrans|={dt:.3e} m max|dshape|={ds:.3e} '
+          f'marker rmse={rmse:.3e} m iters gpu={out["iters"][:, 0].sum()} oracle={ref["iters"].sum()} '
+          f'kernel={capi.last_launch_info()[0]}')
+    assert np.abs(ref['shape']).max() > 0.2                      # the block really moves in this case
+    assert dp < POSE_TOL and rmse < MARKER_TOL and dt < 1e-4 and ds < 1e-3
+    assert dp < 1e-6 and ds < 1e-5 and rmse < TIGHT
+    np.testing.assert_array_equal(out['iters'][:, 0], ref['iters'])
+    np.testing.assert_allclose(out['errs'][:, 0], ref['errs']['data'], rtol=1e-5)
+    np.testing.assert_allclose(out['errs'][:, 5], ref['errs']['shape'], rtol=1e-5)
+    if face:
+        np.testing.assert_allclose(out['errs'][:, 4], ref['errs']['poseF'], rtol=1e-5, atol=1e-14)
+    if kind == 'dmpl':
+        np.testing.assert_allclose(out['errs'][1:, 6], ref['errs']['shape_stay'], rtol=1e-5, atol=1e-14)
+        assert out['errs'][0, 6] == 0.0
