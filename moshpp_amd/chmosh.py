@@ -40,10 +40,22 @@ def _get(node, key, default=None):
     return default if v is None else v
 
 
-def stageii_pose_ids(surface_model_type, pose_size, optimize_fingers, optimize_toes):
+def read_dmpl_pcs(dmpl_fname):
+    """`pickle.load(f)['eigvec']` of bodymodel_loader.load_dmpl / chmosh.py:511 -> [V, 3, n_dmpl]."""
+    import pickle
+    if isinstance(dmpl_fname, dict):
+        return np.asarray(dmpl_fname['eigvec'], dtype=np.float64)
+    if str(dmpl_fname).endswith('.npz'):
+        with np.load(dmpl_fname) as z:
+            return np.asarray(z['eigvec'], dtype=np.float64)
+    with open(dmpl_fname, 'rb') as f:
+        return np.asarray(pickle.load(f, encoding='latin-1')['eigvec'], dtype=np.float64)
+
+
+def stageii_pose_ids(surface_model_type, pose_size, optimize_fingers, optimize_toes, optimize_face=False):
     """Free-variable index sets of chmosh.py:546-579 (sets), :645-647 / :665-667 (Step 1), :676-692 (Step 2)."""
     all_pose_ids = list(range(pose_size))
-    pose_body_ids, pose_finger_ids = [], []
+    pose_body_ids, pose_finger_ids, pose_face_ids = [], [], []
     pose_root_ids = all_pose_ids[:3]
     if surface_model_type == 'smpl':
         pose_body_ids = all_pose_ids[3:]
@@ -53,6 +65,8 @@ def stageii_pose_ids(surface_model_type, pose_size, optimize_fingers, optimize_t
             pose_finger_ids = all_pose_ids[66:]
     elif surface_model_type == 'smplx':   # orient:3, body:63, jaw:3, eyel:3, eyer:3, handl, handr
         pose_body_ids = all_pose_ids[3:66]
+        if optimize_face:
+            pose_face_ids = all_pose_ids[66:69]             # the jaw (:562-563)
         if optimize_fingers:
             pose_finger_ids = all_pose_ids[75:]
     elif surface_model_type == 'mano':
@@ -65,9 +79,10 @@ def stageii_pose_ids(surface_model_type, pose_size, optimize_fingers, optimize_t
     step2 = list(step1)
     if optimize_fingers:
         step2 += pose_finger_ids
+    step2 += pose_face_ids                                  # :685-689
     step2 = sorted(set(step2))
     return dict(root=pose_root_ids, body=pose_body_ids, finger=pose_finger_ids if optimize_fingers else [],
-                step1=list(step1), step2=step2)
+                face=pose_face_ids, step1=list(step1), step2=step2)
 
 
 class StageIISolver:
@@ -75,9 +90,35 @@ class StageIISolver:
     Reusable across sequences of the same subject (the reference rebuilds all of this per call)."""
 
     def __init__(self, surface_model, betas, markers_latent, prior, weights, surface_model_type=None,
-                 num_betas=None, optimize_fingers=False, optimize_toes=False, maxiter=100):
-        self.sm = surface_model
+                 num_betas=None, optimize_fingers=False, optimize_toes=False, maxiter=100,
+                 optimize_face=False, betas_expr_start_id=300, num_expressions=80,
+                 optimize_dynamics=False, num_dmpls=8, dmpl_pcs=None):
+        """optimize_face (SMPL-X): jaw + `num_expressions` expression coefficients betas[expr_start:] become Step-2 free
+        variables (chmosh.py:562-567, 685-689).  optimize_dynamics (SMPL / SMPL-H): `dmpl_pcs[V,3,>=num_dmpls]` replaces
+        shapedirs[:, :, num_betas:num_betas+num_dmpls] and those coefficients become free (:507-514, 693-699)."""
         self.model_type = surface_model_type or surface_model.model_type
+        self.shape_kind, self.shape_start, self.n_shape = None, 0, 0
+        if optimize_dynamics:
+            assert self.model_type in ['smpl', 'smplh'], \
+                NotImplementedError('DMPLs are currently only supported by smpl and smplh models')   # :508-509
+            if optimize_face:
+                raise ValueError('optimize_face and optimize_dynamics are mutually exclusive (smplx vs smpl/smplh)')
+            nb0 = int(num_betas)
+            sd = np.array(surface_model.shapedirs, dtype=np.float64)
+            if sd.shape[2] < nb0 + num_dmpls:
+                sd = np.concatenate([sd, np.zeros(sd.shape[:2] + (nb0 + num_dmpls - sd.shape[2],))], axis=2)
+            sd[:, :, nb0:nb0 + num_dmpls] = np.asarray(dmpl_pcs, dtype=np.float64)[:, :, :num_dmpls]   # :512-513
+            import dataclasses
+            surface_model = dataclasses.replace(surface_model, shapedirs=sd, _device=None)
+            self.shape_kind, self.shape_start, self.n_shape = 'dmpl', nb0, int(num_dmpls)
+        elif optimize_face:
+            if self.model_type != 'smplx':
+                raise ValueError('optimize_face needs an smplx model (chmosh.py:560-567)')
+            self.shape_kind, self.shape_start, self.n_shape = 'expr', int(betas_expr_start_id), int(num_expressions)
+            if self.shape_start + self.n_shape > surface_model.num_total_betas:
+                raise ValueError(f'expression block [{self.shape_start}, {self.shape_start + self.n_shape}) exceeds the '
+                                 f'{surface_model.num_total_betas} shape coefficients of the model')
+        self.sm = surface_model
         self.dev = surface_model.device()
         betas = np.asarray(betas, dtype=np.float64).ravel()
         nb = len(betas) if num_betas is None else int(num_betas)
@@ -85,11 +126,12 @@ class StageIISolver:
         b[:nb] = betas[:nb]                               # chmosh.py:499-500
         self.betas = b
         self.dev.set_betas(b)
+        self.dev.set_free_shape(self.shape_start, self.n_shape)    # (0, 0) clears a block left by an earlier solver
         can_body = self.dev.lbs_forward(np.zeros((1, surface_model.NP)), np.zeros((1, 3)))[0]   # can_model.r (:502)
         self.can_body = can_body
         self.tc = TransformedCoeffs(can_body, markers_latent)
         self.attach = capi.Attachment(self.dev, self.tc.closest, self.tc.coef)
-        self.ids = stageii_pose_ids(self.model_type, surface_model.NP, optimize_fingers, optimize_toes)
+        self.ids = stageii_pose_ids(self.model_type, surface_model.NP, optimize_fingers, optimize_toes, optimize_face)
         self.prior = None
         if len(self.ids['body']):
             if prior is None:
@@ -98,8 +140,11 @@ class StageIISolver:
                 raise ValueError(f"prior npose {prior['npose']} != len(pose_body_ids) {len(self.ids['body'])}")
             self.prior = capi.Prior(prior['means'], prior['chols'], prior['weights'])
         self.opts = capi.make_opts(weights, self.ids['step1'], self.ids['step2'], self.ids['body'], self.ids['finger'],
-                                   maxiter=maxiter, num_train_markers=NUM_TRAIN_MARKERS)
+                                   maxiter=maxiter, num_train_markers=NUM_TRAIN_MARKERS, face_ids=self.ids['face'],
+                                   n_shape=self.n_shape, shape_kind=self.shape_kind)
         self.optimize_fingers = bool(optimize_fingers)
+        self.optimize_face = bool(optimize_face)
+        self.optimize_dynamics = bool(optimize_dynamics)
 
     def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11):
         """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
@@ -112,6 +157,9 @@ class StageIISolver:
                                         [dict(attach=self.attach, obs=obs, vis=vis, first=True)])[0]
             return out
         if chain_mode == 'chunked':
+            if self.n_shape:
+                raise NotImplementedError('chunked mode does not carry free shape coefficients across chunk hand-offs; '
+                                          "use chain_mode='sequential' with optimize_face / optimize_dynamics")
             outs, report = capi.sequence_solve_host(self.dev, self.prior, self.opts, [dict(attach=self.attach, obs=obs, vis=vis)],
                                                     num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol)
             outs[0]['chunk_report'] = report
@@ -145,12 +193,6 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
             cfg.moshpp[f'{cfg_key}'] = False
             logger.warning(f'{cfg_key} was activated but no {body_part} marker type detected in the mocaps: '
                            f'{cfg_key} = {cfg.moshpp[f"{cfg_key}"]}.')
-    if cfg.moshpp.optimize_face:
-        raise NotImplementedError('moshpp_amd: expression / jaw free variables (chmosh.py:685-689) are the next '
-                                  'scope row (SURVEY.md 8f #2); run with moshpp.optimize_face=False')
-    if cfg.moshpp.optimize_dynamics:
-        raise NotImplementedError('moshpp_amd: DMPL free variables (chmosh.py:507-514, 694-699) are out of the '
-                                  'current scope; run with moshpp.optimize_dynamics=False')
 
     # 3. model, prior, attachment (:488-503)
     sm = load_surface_model(surface_model_fname=cfg.surface_model.fname,
@@ -166,9 +208,19 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
                                       exclude_hands=sm.model_type in ['smplh', 'smplx'])
     stageii_wts = cfg.opt_settings.weights
     ext = _get(cfg, 'moshpp_amd', {}) or {}
+    dmpl_pcs = None
+    if cfg.moshpp.optimize_dynamics:   # :507-514 (the reference opens the pickle in text mode, a python-2 leftover)
+        assert cfg.surface_model.type in ['smpl', 'smplh'], \
+            NotImplementedError('DMPLs are currently only supported by smpl and smplh models')
+        dmpl_pcs = read_dmpl_pcs(cfg.surface_model.dmpl_fname)
     solver = StageIISolver(sm, betas, markers_latent, prior, stageii_wts, surface_model_type=cfg.surface_model.type,
                            num_betas=cfg.surface_model.num_betas, optimize_fingers=cfg.moshpp.optimize_fingers,
-                           optimize_toes=cfg.moshpp.optimize_toes, maxiter=cfg.opt_settings.maxiter)
+                           optimize_toes=cfg.moshpp.optimize_toes, maxiter=cfg.opt_settings.maxiter,
+                           optimize_face=cfg.moshpp.optimize_face,
+                           betas_expr_start_id=_get(cfg.surface_model, 'betas_expr_start_id', 300),
+                           num_expressions=_get(cfg.surface_model, 'num_expressions', 80),
+                           optimize_dynamics=cfg.moshpp.optimize_dynamics,
+                           num_dmpls=_get(cfg.surface_model, 'num_dmpls', 8), dmpl_pcs=dmpl_pcs)
     logger.debug(f'#observed, #simulated markers: {len(mocap.labels)}, {len(markers_latent)}')
 
     # 4. frames (:539-540) and the per-frame visible-label selection (:582-594) as arrays
@@ -203,6 +255,13 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
         errs['velo'] = out['errs'][solved[2:], 2]   # the velocity term exists from the third solved frame on
     if solver.optimize_fingers:
         errs['poseH'] = out['errs'][solved, 3]
+    if solver.optimize_face:
+        errs['poseF'] = out['errs'][solved, 4]
+        errs['expr'] = out['errs'][solved, 5]
+    if solver.optimize_dynamics:
+        if len(solved) > 1:
+            errs['extrap_dmpl'] = out['errs'][solved[1:], 6]   # exists from the second solved frame on (:695)
+        errs['dmpl'] = out['errs'][solved, 5]
     stageii_debug_details = {
         'stageii_errs': {k: np.array(v) for k, v in errs.items()},
         'markers_sim': perframe['markers_sim'],
@@ -218,4 +277,12 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     }
     stageii_data = {'fullpose': out['fullpose'][solved].copy(), 'trans': out['trans'][solved].copy(),
                     'stageii_debug_details': stageii_debug_details}
+    if solver.n_shape:
+        # per-frame opt_model.betas: the frozen Stage-I betas with the free block's values added in
+        betas_t = np.tile(solver.betas, (len(solved), 1))
+        betas_t[:, solver.shape_start:solver.shape_start + solver.n_shape] += out['shape'][solved]
+        if solver.optimize_dynamics:   # :721-722  betas[num_betas:total_num_betas]
+            stageii_data['dmpls'] = betas_t[:, solver.shape_start:solver.shape_start + solver.n_shape].copy()
+        if solver.optimize_face:       # :723-724  betas[exp_start_id:] -- the whole tail, as the reference stores it
+            stageii_data['expression'] = betas_t[:, solver.shape_start:].copy()
     return stageii_data

@@ -357,3 +357,63 @@ def test_free_shape_block_matches_oracle(gpu_lib, model_type, kind, E, fingers, 
     if kind == 'dmpl':
         np.testing.assert_allclose(out['errs'][1:, 6], ref['errs']['shape_stay'], rtol=1e-5, atol=1e-14)
         assert out['errs'][0, 6] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_type,kind', [('smplx', 'expr'), ('smplh', 'dmpl')])
+def test_mosh_stageii_face_and_dynamics_end_to_end(gpu_lib, tmp_path, model_type, kind):
+    """cfg.moshpp.optimize_face / optimize_dynamics through the drop-in entry point on files: the extra free variables,
+    residual blocks and output keys of chmosh.py:507-514, 562-567, 685-699, 721-724 against the oracle chain."""
+    import pickle
+    from moshpp_amd.cfg import make_cfg
+    from moshpp_amd.chmosh import mosh_stageii
+    from moshpp_amd.mocap_interface import write_mocap_c3d
+    from tests.helpers import shape_case
+    F, M, E = 7, 40, 6
+    case = shape_case(model_type, F=F, M=M, E=E, seed=9, kind=kind)
+    s = case['s']
+    raw = {k: v for k, v in s['model'].items() if not k.startswith('_')}
+    raw['shapedirs'] = case['model']['shapedirs'] if kind == 'expr' else case['model']['shapedirs'][:, :, :16]
+    with open(tmp_path / 'model.pkl', 'wb') as f:
+        pickle.dump(raw, f)
+    with open(tmp_path / 'pose_body_prior.pkl', 'wb') as f:
+        pickle.dump(s['gmm'], f)
+    np.savez(tmp_path / 'pose_hand_prior.npz', **s['hand_prior'])
+    with open(tmp_path / 'dmpl.pkl', 'wb') as f:
+        pickle.dump({'eigvec': case['model']['shapedirs'][:, :, 16:16 + E + 2][:, :, :E]}, f, protocol=2)
+    obs = case['obs'].copy()
+    obs[~case['vis']] = np.nan
+    c3d = str(tmp_path / 'ds' / 'subj' / 'talk.c3d')
+    os.makedirs(os.path.dirname(c3d))
+    write_mocap_c3d(obs, s['labels'], c3d, frame_rate=120)
+    meta = dict(s['marker_meta'])
+    if kind == 'expr':   # the layout must declare face markers, otherwise optimize_face is switched off (:475-486)
+        meta['marker_type'] = {l: ('face' if i % 4 == 0 else 'body') for i, l in enumerate(s['labels'])}
+        meta['marker_type_mask'] = {'body': np.ones(M, dtype=bool), 'face': np.arange(M) % 4 == 0}
+    cfg = make_cfg(**{'mocap.fname': c3d, 'surface_model.type': model_type, 'surface_model.fname': str(tmp_path / 'model.pkl'),
+                      'surface_model.dmpl_fname': str(tmp_path / 'dmpl.pkl'), 'surface_model.num_dmpls': E,
+                      'surface_model.betas_expr_start_id': 16, 'surface_model.num_expressions': E,
+                      'moshpp.pose_body_prior_fname': str(tmp_path / 'pose_body_prior.pkl'),
+                      'moshpp.pose_hand_prior_fname': str(tmp_path / 'pose_hand_prior.npz'),
+                      'moshpp.optimize_face': kind == 'expr', 'moshpp.optimize_dynamics': kind == 'dmpl'})
+    out = mosh_stageii(c3d, cfg, s['markers_latent'], s['latent_labels'], s['betas'], meta)
+    assert cfg.moshpp.optimize_face is (kind == 'expr')
+    key = 'expression' if kind == 'expr' else 'dmpls'
+    assert set(out) == {'fullpose', 'trans', 'stageii_debug_details', key}
+    errs = out['stageii_debug_details']['stageii_errs']
+    if kind == 'expr':
+        assert set(errs) == {'data', 'poseB', 'velo', 'poseF', 'expr'}
+    else:
+        assert set(errs) == {'data', 'poseB', 'velo', 'extrap_dmpl', 'dmpl'} and len(errs['extrap_dmpl']) == F - 1
+    pickle.dumps(out)
+    # c3d stores float32 millimetres: run the oracle on the parsed data
+    from moshpp_amd.mocap_interface import MocapSession
+    obs_p, vis_p = MocapSession(c3d, 'mm').markers_aslabeled_arrays(s['latent_labels'])
+    assert np.array_equal(vis_p, case['vis'])
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], obs_p, vis_p, model_type,
+                           optimize_face=kind == 'expr', free_shape=kind)
+    assert out[key].shape == (F, E)
+    assert np.abs(out[key] - ref['shape']).max() < 1e-5 and np.abs(ref['shape']).max() > 0.2
+    assert np.abs(out['fullpose'] - ref['fullpose']).max() < 1e-6
+    assert np.abs(out['trans'] - ref['trans']).max() < TIGHT
+    np.testing.assert_allclose(errs['expr' if kind == 'expr' else 'dmpl'], ref['errs']['shape'], rtol=1e-5)
