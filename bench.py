@@ -159,7 +159,12 @@ def main():
         result['roofline'] = {
             'kernel': name, 'bound': 'valu_f64 (dependency/latency-bound small dense solves; HBM traffic ~3 KB/frame)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
-            'traffic': None, 'step_ms_hip_events': round(kt * 1e3, 3),
+            # PMC (separate FETCH_SIZE / WRITE_SIZE passes on a 120-frame chain, profiles/r01_chain_pmc.txt): 13.3 KB fetched
+            # (x2 wide-load correction of the guide -> 26.5 KB) + 17.7 KB written per solved frame, incl. the one-time read of
+            # the 1.76 MB attachment slice and the kernel's scratch write-backs; scaled to the frames the timed mode solves
+            'traffic': int(44.2e3 * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0))),
+            'traffic_source': 'rocprofv3 PMC per solved frame (profiles/r01_chain_pmc.txt) x frames solved in pass 1; not collected live',
+            'step_ms_hip_events': round(kt * 1e3, 3),
             'algorithmic_gflop_per_step': round(fl / 1e9, 3),
             'note': 'algorithmic = the sequential chain\'s work on the recorded frames; warm-up and repair work is overhead',
             'dogleg_iters_per_frame': round(float(iters[solved_mask, 0].sum()) / max(solved, 1), 3),
@@ -236,7 +241,10 @@ def main():
             bytes_alg = Fl * (12 * sm.V + 4 * sm.NP + 12) + model_bytes
             result['roofline_lbs'] = {'kernel': 'k_lbs_mfma (+ k_lbs_prep)', 'bound': 'hbm', 'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives', 'achieved': round(bytes_alg / lt / 1e9, 1),
                                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
-                                      'traffic': None, 'frames': Fl, 'kernel_ms': round(lt * 1e3, 3),
+                                      # PMC at F=2000 (profiles/r01_lbs_pmc.txt): FETCH_SIZE 82.8 MB (x2 -> 165.6 MB), WRITE_SIZE 164 MB
+                                      'traffic': int((2 * 82.82e6 + 164.0e6) * Fl / 2000.0),
+                                      'traffic_source': 'rocprofv3 PMC at F=2000 (profiles/r01_lbs_pmc.txt), scaled by frames; not collected live',
+                                      'frames': Fl, 'kernel_ms': round(lt * 1e3, 3),
                                       'frames_per_s': round(Fl / lt, 1)}
         except Exception as e:   # the LBS leg must never take the headline number down
             result['roofline_lbs'] = {'error': repr(e)}
