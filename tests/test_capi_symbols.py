@@ -32,18 +32,22 @@ def test_struct_layouts_match_header(tmp_path):
     """sizeof / offsetof of every struct in include/moshii.h, as gcc sees them, equal the ctypes mirrors."""
     import ctypes as C
     import subprocess
-    structs = {'moshii_model_desc': capi.ModelDesc, 'moshii_solve_opts': capi.SolveOpts, 'moshii_chain_desc': capi.ChainDesc}
+    structs = {'moshii_model_desc': capi.ModelDesc, 'moshii_solve_opts': capi.SolveOpts, 'moshii_chain_desc': capi.ChainDesc,
+               'moshii_sequence_desc': capi.SequenceDesc, 'moshii_chunk_opts': capi.ChunkOpts,
+               'moshii_chunk_report': capi.ChunkReport}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "moshii.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
         for fname, _ in cls._fields_:
             lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append('printf("MOSHII_NERR %d\\n", MOSHII_NERR);')
     lines.append('return 0;}')
     src = tmp_path / 'layout.c'
     src.write_text('\n'.join(lines))
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert int(got['MOSHII_NERR']) == capi.NERR
     for cname, cls in structs.items():
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
