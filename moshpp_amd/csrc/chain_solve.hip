@@ -577,12 +577,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane /* wave-unifor
 // x_j = (b_j - sum_{i>j} c_ij x_i) / d_j from the packed factor.  A itself is left untouched (the dogleg needs
 // d^T A d afterwards).  Returns false on a non-positive pivot (the reference would fall back to lstsq; callers
 // take the Cauchy step).
-// BIG (NBLK > 8, extended variant only): the packed factor does not fit the LDS next to the solver state, so it is written
-// to this chain's global scratch (`Lp`, L2-resident) while the small broadcast area stays in LDS (`Sl_big`: trash word,
-// zero word, Cv, then a 16-row panel); the back-substitution then streams the factor through that panel, 16 rows per
-// barrier pair, and every lane of wave 0 owns up to four unknowns.
-template <int NBLK, bool BIG>
-__device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, double* Sl_big, const double* g, double* d, double* pinv, int n) {
+template <int NBLK>
+__device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, double* d, double* pinv, int n) {
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     PROF_BEGIN(); PROF_COUNT(22);
@@ -608,7 +604,7 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, double* Sl_big, const
     // Stores that do not apply go to `trash`, loads that do not apply read `zero` (= 0.0): straight-line LDS traffic.
     const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
     constexpr int CVR = NBLK * 16;                 // rows of one broadcast column
-    double* const Sl = BIG ? Sl_big : Lp + trash;  // LDS: [0] trash word, [1] zero word, [2..] Cv
+    double* const Sl = Lp + trash;                 // [0] trash word, [1] zero word, [2..] Cv
     double* Cv = Sl + 2;                           // [2][2][CVR]
     int rS[NBLK];                                  // packed offset of this thread's row q1 (or -1 beyond the border row)
 #pragma unroll
@@ -683,45 +679,6 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, double* Sl_big, const
     __syncthreads();
     PROF_LAP(9);
     if (!ok) return false;
-    if constexpr (BIG) {
-        constexpr int NY = (CVR + 63) / 64;   // unknowns per lane of wave 0
-        constexpr int PR = 16;                // panel rows
-        double* pan = Sl + 2 + 4 * CVR;       // [PR][CVR]
-        const int base = n * (n + 1) / 2;
-        double y[NY];
-#pragma unroll
-        for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k < n) ? Lp[base + tid + 64 * k] : 0.0;
-        for (int jhi = n - 1; jhi >= 0; jhi -= PR) {
-            const int jlo = max(jhi - PR + 1, 0), rows = jhi - jlo + 1;
-            for (int it = tid; it < rows * CVR; it += MOSHII_TPB) {   // row j of the factor: entries (j, 0 .. j-1), zero beyond
-                const int r = it / CVR, i = it - r * CVR, j = jlo + r;
-                pan[it] = (i < j) ? Lp[j * (j + 1) / 2 + i] : 0.0;
-            }
-            __syncthreads();
-            if (tid < 64) {
-                for (int jv = jhi; jv >= jlo; --jv) {
-                    const int j = __builtin_amdgcn_readfirstlane(jv);
-                    double l[NY];
-#pragma unroll
-                    for (int k = 0; k < NY; ++k) l[k] = pan[(j - jlo) * CVR + tid + 64 * k];
-                    double yj = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NY; ++k) if ((j >> 6) == k) yj = readlane_f64(y[k], j & 63);
-                    const double dj = yj * pinv[j];
-#pragma unroll
-                    for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k == j) ? dj : fma(-l[k], dj, y[k]);
-                }
-            }
-            __syncthreads();
-        }
-        if (tid < 64) {
-#pragma unroll
-            for (int k = 0; k < NY; ++k) if (tid + 64 * k < n) d[tid + 64 * k] = y[k];
-        }
-        __syncthreads();
-        PROF_LAP(10);
-        return true;
-    }
     // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
     // Row j of the factor and 1/d_j are fetched one step ahead (off the readlane -> multiply -> fma chain); rows are
     // read branch-free (lanes beyond the row read the zero word).
@@ -748,6 +705,157 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, double* Sl_big, const
         }
         if (tid < n) d[tid] = y0;
         if (tid + 64 < n) d[tid + 64] = y1;
+    }
+    __syncthreads();
+    PROF_LAP(10);
+    return true;
+}
+
+// n > 127 unknowns (extended variant, NBLK > 8).  Neither a packed factor in LDS (151 KB for n = 194) nor a second
+// register copy of the matrix (91 entries per thread) is affordable, so the elimination is LEFT-looking by 16-column
+// block: only the current block column is live in registers (<= NBLK entries per thread, taken from A, which stays
+// untouched), it first receives the updates of every finished column from the packed factor -- kept in this chain's
+// GLOBAL scratch (L2-resident; a row is read by 16 lanes at the same address) -- and is then eliminated two columns per
+// barrier exactly like ldl_solve, restricted to itself.  LDS holds the column broadcast buffer and a 16-row panel through
+// which the back-substitution streams the factor; every lane of wave 0 owns up to four unknowns.
+//   Lp (global): packed factor, entry (i, j) at i (i + 1) / 2 + j, rows 0..n (row n = right-hand side); [trash] spare word,
+//                [zero .. zero + 7] zeros.   Sl (LDS): [0] trash, [1] zero, [2 ..] Cv [2][2][CVR], then the panel [16][CVR].
+template <int NBLK>
+__device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* d, double* pinv, int n) {
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    PROF_BEGIN(); PROF_COUNT(22);
+    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
+    constexpr int CVR = NBLK * 16;
+    double* Cv = Sl + 2;
+    int rS[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int q1 = b * 16 + ty;
+        rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
+    }
+    if (tid == 0) Sl[1] = 0.0;
+    if (tid < 8) Lp[zero + tid] = 0.0;
+    bool ok = true;
+    int step = 0;
+#pragma unroll
+    for (int bj0 = 0; bj0 < NBLK; ++bj0) {   // (no early exit from THIS loop: with one, hipcc refuses to unroll it -- the
+        if (ok && bj0 * 16 < n) {             //  barriers inside are convergent -- and every array below lands in scratch)
+        // working block column of [A; g^T]
+        double W[NBLK];
+        const int q2 = bj0 * 16 + tx;
+        const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);
+#pragma unroll
+        for (int bi = bj0; bi < NBLK; ++bi) W[bi] = (bi * 16 + ty == n) ? gq : A.a[bi * (bi + 1) / 2 + bj0];
+        __syncthreads();   // the previous block column's last stores (and pivots) are visible
+        if (bj0 > 0) {
+            // W[bi] -= sum_{c < 16 bj0} C[q1][c] C[q2][c] / d_c     (C = the stored entries l_ic d_c)
+            const double* rk = Lp + ((q2 <= n) ? q2 * (q2 + 1) / 2 : zero);
+            const int kstep = (q2 <= n) ? 1 : 0;   // rows beyond the border read the zero words
+            for (int c0 = 0; c0 < bj0 * 16; c0 += 8) {   // 8 columns per batch: (rows + 1) x 8 independent loads in flight
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = rk[(c0 + u) * kstep] * pinv[c0 + u];
+#pragma unroll
+                for (int bi = bj0; bi < NBLK; ++bi) {
+                    const double* rp = Lp + ((rS[bi] >= 0) ? rS[bi] + c0 : zero);
+                    W[bi] -= ((rp[0] * t[0] + rp[1] * t[1]) + (rp[2] * t[2] + rp[3] * t[3])) +
+                             ((rp[4] * t[4] + rp[5] * t[5]) + (rp[6] * t[6] + rp[7] * t[7]));
+                }
+            }
+        }
+        PROF_LAP(13);
+        for (int jl = 0; jl < 16; jl += 2) {
+            const int j = bj0 * 16 + jl;
+            if (j >= n) break;
+            const bool pair = j + 1 < n;
+            double* cv = Cv + (step & 1) * 2 * CVR;
+            ++step;
+            const bool ownA = tx == jl, ownB = tx == jl + 1;
+#pragma unroll
+            for (int bi = bj0; bi < NBLK; ++bi) {
+                const int q1 = bi * 16 + ty;
+                const double v = W[bi];
+                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl;
+                *dst = v;
+                Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;
+            }
+            // LDS-only barrier: the step exchanges data through Cv / pinv (LDS); a __syncthreads() would also wait for the
+            // acknowledgement of the factor's global stores, ~2 us per step.  They are fenced once per block column.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const double p0 = cv[j], a10 = cv[j + 1], p1r = cv[CVR + j + 1];
+            double ci0[NBLK], ci1[NBLK];
+            const double* zr = Sl + 1;
+#pragma unroll
+            for (int b = bj0; b < NBLK; ++b) {
+                const int q1 = b * 16 + ty;
+                const bool vr = q1 > j + 1 && q1 <= n;
+                const double* r0 = vr ? cv + q1 : zr; const double* r1 = vr ? cv + CVR + q1 : zr;
+                ci0[b] = *r0; ci1[b] = *r1;
+            }
+            const bool vc = q2 > j + 1 && q2 <= n;
+            double ck0 = *(vc ? cv + q2 : zr), ck1 = *(vc ? cv + CVR + q2 : zr);
+            if (!(p0 > 0.0)) { ok = false; break; }
+            double pin0 = __builtin_amdgcn_rcp(p0);
+            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
+            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
+            const double l10 = a10 * pin0;
+            const double p1 = pair ? fma(-a10, l10, p1r) : 1.0;
+            if (!(p1 > 0.0)) { ok = false; break; }
+            double pin1 = __builtin_amdgcn_rcp(p1);
+            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
+            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
+            if (!pair) pin1 = 0.0;
+            if (tid == 0) { pinv[j] = pin0; if (pair) pinv[j + 1] = pin1; }
+            ck1 = fma(-ck0, l10, ck1);
+            ck0 *= pin0; ck1 *= pin1;
+#pragma unroll
+            for (int b = bj0; b < NBLK; ++b) {
+                ci1[b] = fma(-ci0[b], l10, ci1[b]);
+                const int q1 = b * 16 + ty;
+                Lp[(ownB && pair && q1 > j + 1 && rS[b] >= 0) ? rS[b] + j + 1 : trash] = ci1[b];
+                W[b] = fma(-ci1[b], ck1, fma(-ci0[b], ck0, W[b]));
+            }
+        }
+        PROF_LAP(14);
+        }
+    }
+    __syncthreads();
+    PROF_LAP(9);
+    if (!ok) return false;
+    constexpr int NY = (CVR + 63) / 64;   // unknowns per lane of wave 0
+    constexpr int PR = 16;                // panel rows
+    double* pan = Sl + 2 + 4 * CVR;       // [PR][CVR]
+    const int base = n * (n + 1) / 2;
+    double y[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k < n) ? Lp[base + tid + 64 * k] : 0.0;
+    for (int jhi = n - 1; jhi >= 0; jhi -= PR) {
+        const int jlo = max(jhi - PR + 1, 0), rows = jhi - jlo + 1;
+        for (int it = tid; it < rows * CVR; it += MOSHII_TPB) {   // row j of the factor: entries (j, 0 .. j-1), zero beyond
+            const int r = it / CVR, i = it - r * CVR, j = jlo + r;
+            pan[it] = (i < j) ? Lp[j * (j + 1) / 2 + i] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int jv = jhi; jv >= jlo; --jv) {
+                const int j = __builtin_amdgcn_readfirstlane(jv);
+                double l[NY];
+#pragma unroll
+                for (int k = 0; k < NY; ++k) l[k] = pan[(j - jlo) * CVR + tid + 64 * k];
+                double yj = 0.0;
+#pragma unroll
+                for (int k = 0; k < NY; ++k) if ((j >> 6) == k) yj = readlane_f64(y[k], j & 63);
+                const double dj = yj * pinv[j];
+#pragma unroll
+                for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k == j) ? dj : fma(-l[k], dj, y[k]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < NY; ++k) if (tid + 64 * k < n) d[tid + 64 * k] = y[k];
     }
     __syncthreads();
     PROF_LAP(10);
@@ -1353,7 +1461,10 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             if (!have_gn) {
                 // (BIG: factor in the chain's global scratch behind the shape-derivative arrays, LDS part at the head of `big`)
                 constexpr bool BIG = XT && NBLK > 8;
-                if (!ldl_solve<NBLK, BIG>(A, BIG ? qs + (size_t)6 * md.K * op.nshape : cx.big, cx.big, cx.g, cx.dgn, cx.y, n)) {
+                bool solved;
+                if constexpr (BIG) solved = ldl_big<NBLK>(A, qs + (size_t)6 * md.K * op.nshape, cx.big, cx.g, cx.dgn, cx.y, n);
+                else solved = ldl_solve<NBLK>(A, cx.big, cx.g, cx.dgn, cx.y, n);
+                if (!solved) {
                     fail = 1;
                     for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
                     __syncthreads();

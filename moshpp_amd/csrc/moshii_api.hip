@@ -861,7 +861,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     if (rc) return rc;
     char* dbase = m->scratch.ptr + ctl;
     // extended variant: per-chain scratch for the shape derivatives of the joint transforms ([2][K][E][3] doubles)
-    const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 4 : 0;   // global packed factor (ldl_solve BIG)
+    const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;   // global packed factor + trash / zero words (ldl_big)
     const size_t qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
     if (E > 0) {
         if ((rc = m->qscratch.reserve(qbytes * n_chains))) return rc;

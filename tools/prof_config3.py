@@ -26,7 +26,8 @@ lib.moshii_prof_read(buf, 1)
 p = np.array(list(buf), dtype=np.float64)
 names = {0: 'eval: shape+fullpose/rodrigues/chain', 1: 'eval: posedirs', 2: 'eval: skin+markers', 3: 'eval: prior+reduce',
          4: 'asm: pre-phase (+ shape chain) + T0', 5: 'asm: T1 vertex jac + T1s shape', 6: 'asm: T2 marker rows',
-         7: 'asm: T3 JtJ', 8: 'asm: structured', 9: 'ldl factor', 10: 'back-subst', 12: 'kernel total'}
+         7: 'asm: T3 JtJ', 8: 'asm: structured', 9: 'ldl: setup/tail', 13: 'ldl: block-column gather + left-looking update', 14: 'ldl: 16-column elimination',
+         10: 'back-subst', 12: 'kernel total'}
 tot = p[12]
 print(f'smplx E={E} F={F} wall {dt*1e3:.1f} ms ({dt/F*1e6:.1f} us/frame) launch {capi.last_launch_info()}')
 print(f'evals {p[20]/F:.2f}/frame assembles {p[21]/F:.2f}/frame ldl {p[22]/F:.2f}/frame')
