@@ -61,7 +61,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=400, help='frames of the workload timed on the CPU oracle')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
-    ap.add_argument('--lbs-frames', type=int, default=2000)
+    ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
     ap.add_argument('--many', type=int, default=32, help='extra leg: this many copies of the sequence in one call (0: skip)')
     args = ap.parse_args()
 
@@ -260,19 +260,24 @@ def main():
             pr = so.prepare_gmm_prior(seq['gmm'], 63)
             can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
             closest, coef = so.transformed_coeffs(can, job['markers_latent'])
-            tc0 = time.perf_counter()
-            ref = so.stageii_chain(m, pr, closest, coef, job['obs'][:S], job['vis'][:S], 'smplh')
-            tc = time.perf_counter() - tc0
-            n_ref = len(ref['frame_ids'])
+            # one core: the chain is sequential and its matrices are small (<= 385 x 111) -- BLAS threading buys nothing
+            # (measured: 23.8 vs 23.5 frames/s with 8 vs 1 threads), so the library is pinned to one thread and says so
+            import contextlib
             try:
                 import threadpoolctl
-                blas_threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] + [1])
+                pin, blas_threads = threadpoolctl.threadpool_limits(limits=1), 1
             except Exception:
-                blas_threads = os.cpu_count()
+                pin, blas_threads = contextlib.nullcontext(), os.cpu_count()
+            with pin:
+                tc0 = time.perf_counter()
+                ref = so.stageii_chain(m, pr, closest, coef, job['obs'][:S], job['vis'][:S], 'smplh')
+                tc = time.perf_counter() - tc0
+            n_ref = len(ref['frame_ids'])
             result['cpu_baseline'] = {'value': round(n_ref / tc, 2), 'unit': 'frames/s', 'cores': int(blas_threads),
                                       'kind': 'port', 'host_cores_visible': os.cpu_count(),
                                       'sample': f'first {S} frames of the same sequence, NumPy float64 oracle '
-                                                f'(lean marker-subset mode), single process, {tc:.1f} s'}
+                                                f'(lean marker-subset mode), single process, BLAS pinned to '
+                                                f'{blas_threads} thread(s), {tc:.1f} s'}
             gp = out['fullpose'][:S][status[:S] != 1]
             gm = out['markers_sim'][:S]
             sqd = []
