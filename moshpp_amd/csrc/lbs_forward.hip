@@ -11,7 +11,8 @@
 //   k_lbs_prep   one 64-thread workgroup per frame: hand-PCA -> fullpose, Rodrigues, kinematic chain;
 //                writes the skinning transforms A[j][f][12] (f32, translation folded with trans[f]) and the pose
 //                feature rows featT[f][KP] (f16).
-//   k_lbs_mfma   one workgroup (4 waves, one per SIMD) per 128 vertices x 128 frames:
+//   k_lbs_mfma   one workgroup (4 waves) per 128 vertices x 64 frames, two workgroups per CU (NT = 2; the description below
+//                is written for the NT = 4 form, 128 frames and one workgroup per CU, which MOSHII_LBS_NT=4 still selects):
 //                  * the 128 x KP feature panel is staged once in LDS (row pitch 16 x odd bytes: conflict-free b128 reads);
 //                  * each wave owns 32 vertices x 3 coordinates x 4 frame tiles = 12 accumulators (192 registers) and
 //                    streams its posedirs fragments from a fragment-major copy of the model (one contiguous 1 KiB
@@ -282,25 +283,26 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 // ---- the MFMA kernel --------------------------------------------------------------------------------------
 #define LBS_PITCH(KP) ((KP) + 8)   // halves; (KP + 8) * 2 bytes = 16 (2 KS + 1): 16 x odd  (464 -> 944 = 16 * 59)
 #define LBS_FCH 8                  // frame tiles per L2 chunk: 1024 frames of transforms (K x 48 KB) stay L2-resident
-__host__ __device__ inline size_t lbs_region_bytes(int KP, int K) {
-    const size_t panel = (size_t)LBS_TF * LBS_PITCH(KP) * 2;
-    const size_t epi = (size_t)K * 1552;   // (LBS_JSTRIDE)
+#define LBS_JSTRIDE 1552   // bytes between the LDS transform blocks of consecutive joints: 32 frames x 48 B + 16 (bank shift)
+#define LBS_JSTRIDE_H 784  // ... for the 16-frame half tiles of the two-workgroups-per-CU variant: 16 x 48 B + 16
+__host__ __device__ inline size_t lbs_region_bytes(int KP, int K, int nt) {
+    const size_t panel = (size_t)nt * 32 * LBS_PITCH(KP) * 2;
+    const size_t epi = (size_t)K * (nt == 2 ? LBS_JSTRIDE_H : LBS_JSTRIDE);
     return ((panel > epi ? panel : epi) + 15) & ~size_t(15);
 }
 
-#define LBS_JSTRIDE 1552   // bytes between the LDS transform blocks of consecutive joints: 32 frames x 48 B + 16 (bank shift)
-
 // Blend + apply + store for one 32-frame tile, on the accumulator layout (lane = vertex column, register = frame row).
 // Tl: this frame tile's joint transforms [K][LBS_JSTRIDE]; jw: this lane's influences {byte offset of the joint block, weight bits}.
-template <int NWT>
+// R0, RN: the accumulator registers handled by this call (all 16, or one half = 16 consecutive frames); FOFF: first frame held in Tl.
+template <int NWT, int R0 = 0, int RN = 16, int FOFF = 0>
 __device__ __forceinline__ void lbs_epilogue(const f32x16& ax, const f32x16& ay, const f32x16& az, float isc,
                                              const char* Tl, const int2 (&jw)[NWT], float vx, float vy, float vz,
                                              int V, int F, int fbase, int v, int lane, float* __restrict__ out, int dbg) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = R0; r < R0 + RN; ++r) {
         const int fr = (r & 3) + 8 * (r >> 2) + 4 * h;   // frame inside the tile
-        const char* Tf = Tl + fr * 48;
+        const char* Tf = Tl + (fr - FOFF) * 48;
         float4 A0[NWT], A1[NWT], A2[NWT];
 #pragma unroll
         for (int s2 = 0; s2 < NWT; ++s2) {
@@ -328,9 +330,13 @@ __device__ __forceinline__ void lbs_epilogue(const f32x16& ax, const f32x16& ay,
     }
 }
 
-template <int NWT>
-__global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F, int NVT, int NFT, int NVX,
-                                                      float* __restrict__ out, int dbg_stop) {
+// NT = frame tiles (of 32) per workgroup.  NT = 4: one workgroup per CU (192 accumulator registers per lane).  NT = 2: half the
+// accumulators and half the LDS, so that TWO workgroups share a CU and one's MFMA loop overlaps the other's epilogue
+// gathers and the drain of its stores (with one wave per SIMD every phase of a tile is exposed back to back).
+template <int NWT, int NT>
+__global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model lm, int V, int F, int NVT, int NFT, int NVX,
+                                                                      float* __restrict__ out, int dbg_stop) {
+    constexpr int TF = NT * 32;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8; each XCD owns the vertex tiles {xcd, xcd + 8, ...} and walks
@@ -347,11 +353,11 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     _Float16* Bp = reinterpret_cast<_Float16*>(lds_raw);                           // main loop: [128][pitch] f16
     const int K = lm.K;
     char* Tl = lds_raw;                                                            // epilogue: [K][LBS_JSTRIDE]
-    const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
+    const int f0 = ft * TF, v0 = vt * LBS_TV;
     // stage the feature panel (rows beyond F are zero) and this tile's influences / rest vertices
     {
         const int chunks = KP / 8;   // 16-byte chunks per row (<= 64: one lane per chunk, one wave per row, no index division)
-        for (int r0 = wv; r0 < LBS_TF; r0 += 4 * 8) {   // 8 independent 16-byte loads in flight per lane, then the LDS writes
+        for (int r0 = wv; r0 < TF; r0 += 4 * 8) {   // 8 independent 16-byte loads in flight per lane, then the LDS writes
             half8 v[8];
             const int cc = min(lane, chunks - 1);
 #pragma unroll
@@ -375,11 +381,11 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     const float vx = lm.vsh_pad[(size_t)vme * 3 + 0], vy = lm.vsh_pad[(size_t)vme * 3 + 1], vz = lm.vsh_pad[(size_t)vme * 3 + 2];
     __syncthreads();
     // ---- main loop: acc[i][nt] (32 frames x 32 vertices) += featT(nt, ks) x Pfrag(i, ks)^T
-    f32x16 acc[3][4];
+    f32x16 acc[3][NT];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][nt][e] = 0.0f;
     const int vg = vt * 4 + wv;   // this wave's 32-vertex group
@@ -389,12 +395,12 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     // Six rotating A-fragment sets (k-steps t .. t+5) and two B-fragment sets (t, t+1), addressed by NAME so that no register
     // copy ever waits on a load: step t computes from (A[t%6], B[t%2]) while the global loads for A[(t+5)%6] (five
     // k-steps = 1920 MFMA cycles ahead: covers an L2 miss with one wave per SIMD) and the LDS reads for B[(t+1)%2] fly.
-    half8 aS[6][3], bS[2][4];
+    half8 aS[6][3], bS[2][NT];
 #define LBS_LOAD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int i = 0; i < 3; ++i) aS[SET][i] = ap[i * astride + (size_t)kk_ * 64]; }
-#define LBS_LOAD_B(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) bS[SET][nt] = *reinterpret_cast<const half8*>(bp + (size_t)nt * 32 * pitch + kk_ * 16); }
+#define LBS_LOAD_B(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bS[SET][nt] = *reinterpret_cast<const half8*>(bp + (size_t)nt * 32 * pitch + kk_ * 16); }
     // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use and the
     //  loop waits vmcnt(0) every k-step -- measured 89 cycles per MFMA instead of 32)
-#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int i = 0; i < 3; ++i) \
+#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int i = 0; i < 3; ++i) \
         acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bS[BSET][nt], aS[ASET][i], acc[i][nt], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
     LBS_LOAD_A(0, 0) LBS_LOAD_A(1, 1) LBS_LOAD_A(2, 2) LBS_LOAD_A(3, 3) LBS_LOAD_A(4, 4) LBS_LOAD_B(0, 0)
     int ks = 0;
@@ -417,15 +423,16 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
 #undef LBS_MMA
     // (MOSHII_LBS_STOP=2|4|16|32: phase timing by truncation / ablation -- 2: stop after the k-loop, 4: after the first
     //  frame tile, 16: no stores, 32: every gather reads joint 0)
-    if (dbg_stop == 2) { if (acc[0][0][0] + acc[1][1][3] + acc[2][2][7] + acc[0][3][9] + acc[1][2][5] + acc[2][3][1] == 123.456f) out[0] = 1.0f; return; }
+    if (dbg_stop == 2) { if (acc[0][0][0] + acc[1][1][3] + acc[2][NT - 2][7] + acc[0][NT - 1][9] + acc[1][NT - 2][5] + acc[2][NT - 1][1] == 123.456f) out[0] = 1.0f; return; }
     if (dbg_stop & 32) for (int s2 = 0; s2 < NWT; ++s2) jw[s2].x = 0;
     // ---- epilogue, one 32-frame tile at a time.  The NEXT tile's joint transforms are pulled into registers (all of a
     // lane's <= 24 16-byte loads in flight at once) before the current tile is blended, and dropped into LDS behind an
     // LDS-only barrier -- a plain __syncthreads() would also wait for the tile's global stores to be acknowledged.
     const float isc = lm.inv_pscale;
+#define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if constexpr (NT == 4) {
     const int nchunk = K * 96;   // 16-byte chunks of one tile's transforms: [j][frame in tile][3]
     float4 tl0, tl1, tl2, tl3, tl4, tl5, tl6, tl7, tl8, tl9, tl10, tl11, tl12, tl13, tl14, tl15, tl16, tl17, tl18, tl19, tl20, tl21, tl22, tl23;   // (named scalars: hipcc keeps an array of these in scratch)
-#define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define LBS_FETCH1(K_, FB) { const int c = min(tid + 256 * K_, nchunk - 1); const int j = c / 96, rem = c - j * 96, fl2 = rem / 3, q = rem - fl2 * 3; \
         tl##K_ = reinterpret_cast<const float4*>(lm.Atr + ((size_t)j * F + min((FB) + fl2, F - 1)) * 12)[q]; }
 #define LBS_PUT1(K_) { const int c = tid + 256 * K_; const int j = c / 96, rem = c - j * 96; if (c < nchunk) *reinterpret_cast<float4*>(Tl + j * LBS_JSTRIDE + rem * 16) = tl##K_; }
@@ -447,6 +454,36 @@ __global__ __launch_bounds__(256, 1) void k_lbs_mfma(Lbs32Model lm, int V, int F
     lbs_epilogue<NWT>(acc[0][2], acc[1][2], acc[2][2], isc, Tl, jw, vx, vy, vz, V, F, f0 + 64, vme, lane, out, dbg_stop);
     LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
     lbs_epilogue<NWT>(acc[0][3], acc[1][3], acc[2][3], isc, Tl, jw, vx, vy, vz, V, F, f0 + 96, vme, lane, out, dbg_stop);
+#undef LBS_FETCH_TL
+#undef LBS_PUT_TL
+#undef LBS_FETCH1
+#undef LBS_PUT1
+    } else {
+        // 16-frame half tiles: K x 16 x 48 B of transforms per stage (joint blocks LBS_JSTRIDE_H apart)
+#pragma unroll
+        for (int s2 = 0; s2 < NWT; ++s2) jw[s2].x = (jw[s2].x / LBS_JSTRIDE) * LBS_JSTRIDE_H;
+        const int nchunk = K * 48;   // 16-byte chunks of one half tile: [j][frame][3]
+        float4 tl0, tl1, tl2, tl3, tl4, tl5, tl6, tl7, tl8, tl9, tl10, tl11;
+#define LBS_FETCH1(K_, FB) { const int c = min(tid + 256 * K_, nchunk - 1); const int j = c / 48, rem = c - j * 48, fl2 = rem / 3, q = rem - fl2 * 3; \
+        tl##K_ = reinterpret_cast<const float4*>(lm.Atr + ((size_t)j * F + min((FB) + fl2, F - 1)) * 12)[q]; }
+#define LBS_PUT1(K_) { const int c = tid + 256 * K_; const int j = c / 48, rem = c - j * 48; if (c < nchunk) *reinterpret_cast<float4*>(Tl + j * LBS_JSTRIDE_H + rem * 16) = tl##K_; }
+#define LBS_FETCH_TL(FB) { LBS_FETCH1(0, FB) LBS_FETCH1(1, FB) LBS_FETCH1(2, FB) LBS_FETCH1(3, FB) LBS_FETCH1(4, FB) LBS_FETCH1(5, FB) LBS_FETCH1(6, FB) LBS_FETCH1(7, FB) LBS_FETCH1(8, FB) LBS_FETCH1(9, FB) LBS_FETCH1(10, FB) LBS_FETCH1(11, FB) }
+#define LBS_PUT_TL() { LBS_PUT1(0) LBS_PUT1(1) LBS_PUT1(2) LBS_PUT1(3) LBS_PUT1(4) LBS_PUT1(5) LBS_PUT1(6) LBS_PUT1(7) LBS_PUT1(8) LBS_PUT1(9) LBS_PUT1(10) LBS_PUT1(11) }
+        LBS_FETCH_TL(f0)
+        LBS_LDS_BARRIER();   // every wave is done with the feature panel
+        LBS_PUT_TL()
+        LBS_LDS_BARRIER();
+        LBS_FETCH_TL(f0 + 16)
+        lbs_epilogue<NWT, 0, 8, 0>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, V, F, f0 + 0, vme, lane, out, dbg_stop);
+        LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+        LBS_FETCH_TL(f0 + 32)
+        lbs_epilogue<NWT, 8, 8, 16>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, V, F, f0 + 0, vme, lane, out, dbg_stop);
+        LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+        LBS_FETCH_TL(f0 + 48)
+        lbs_epilogue<NWT, 0, 8, 0>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, V, F, f0 + 32, vme, lane, out, dbg_stop);
+        LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+        lbs_epilogue<NWT, 8, 8, 16>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, V, F, f0 + 32, vme, lane, out, dbg_stop);
+    }
 #undef LBS_FETCH_TL
 #undef LBS_PUT_TL
 #undef LBS_FETCH1
@@ -566,14 +603,18 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     }
     const Lbs32Model lm = *lmp;
     hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KP, pose, trans, lm.Atr, lm.featT);
-    const int NVT = lm.Vp128 / LBS_TV, NFT = (F + LBS_TF - 1) / LBS_TF;
+    // frame tiles per workgroup: 2 = two workgroups per CU (default: measured 359 vs 394 us at F=4000), 4 = one per CU
+    int nt = 2;
+    if (const char* es = getenv("MOSHII_LBS_NT")) nt = (atoi(es) == 4) ? 4 : 2;
+    const int TF = nt * 32;
+    const int NVT = lm.Vp128 / LBS_TV, NFT = (F + TF - 1) / TF;
     const int NVX = (NVT + 7) / 8;                         // vertex tiles per XCD
     const int NCH = (NFT + LBS_FCH - 1) / LBS_FCH;         // frame chunks
     const int grid = 8 * NCH * NVX * LBS_FCH;
-    const size_t lds = lbs_region_bytes(lm.KP, lm.K);
+    const size_t lds = lbs_region_bytes(lm.KP, lm.K, nt);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = (lm.NW == 4) ? k_lbs_mfma<4> : k_lbs_mfma<8>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    auto kern = (nt == 2) ? ((lm.NW == 4) ? k_lbs_mfma<4, 2> : k_lbs_mfma<8, 2>) : ((lm.NW == 4) ? k_lbs_mfma<4, 4> : k_lbs_mfma<8, 4>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (nt == 2) ? 80 * 1024 : 160 * 1024);
     if (e != hipSuccess) return e;
     int dbg_stop = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg_stop = atoi(es);
