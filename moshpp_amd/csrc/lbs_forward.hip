@@ -42,6 +42,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));   // 12-byte, dword-aligned store unit
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte, dword-aligned
 
 #define LBS_NWMAX 8          // skinning influences per vertex (else the launch falls back to the plain kernel)
 #define LBS_TV 128           // vertices per workgroup (32 per wave)
@@ -285,9 +286,12 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 #define LBS_FCH 8                  // frame tiles per L2 chunk: 1024 frames of transforms (K x 48 KB) stay L2-resident
 #define LBS_JSTRIDE 1552   // bytes between the LDS transform blocks of consecutive joints: 32 frames x 48 B + 16 (bank shift)
 #define LBS_JSTRIDE_H 784  // ... for the 16-frame half tiles of the two-workgroups-per-CU variant: 16 x 48 B + 16
+#define LBS_SXP 392         // dwords per frame row of the NT = 2 result staging: 128 vertices x 3 + 8 (the two half-waves of a
+                            // store instruction are 4 rows apart: 4 x 392 = 32 mod 64 banks)
+__host__ __device__ inline size_t lbs_tl_bytes(int K, int nt) { return ((size_t)K * (nt == 2 ? LBS_JSTRIDE_H : LBS_JSTRIDE) + 15) & ~size_t(15); }
 __host__ __device__ inline size_t lbs_region_bytes(int KP, int K, int nt) {
     const size_t panel = (size_t)nt * 32 * LBS_PITCH(KP) * 2;
-    const size_t epi = (size_t)K * (nt == 2 ? LBS_JSTRIDE_H : LBS_JSTRIDE);
+    const size_t epi = lbs_tl_bytes(K, nt) + (nt == 2 ? (size_t)16 * LBS_SXP * 4 : 0);
     return ((panel > epi ? panel : epi) + 15) & ~size_t(15);
 }
 
@@ -327,6 +331,41 @@ __device__ __forceinline__ void lbs_epilogue(const f32x16& ax, const f32x16& ay,
             __builtin_nontemporal_store(val, reinterpret_cast<f32x3u*>(out + ((size_t)f * V + v) * 3));
         }
         if (r & 1) __builtin_amdgcn_sched_barrier(0);   // two frames at a time: their gathers overlap, the live set stays bounded
+    }
+}
+
+// The NT = 2 form of the epilogue: same blend + apply, but the results of one 16-frame half tile go to an LDS staging area
+// Sx[frame 16][LBS_SXP] (vertex-major inside a row) instead of to memory, so that the workgroup can then write whole
+// 1536-byte tile rows (tools/store_pattern.hip: 5.5 TB/s for that pattern, 3.1 TB/s for 384-byte runs per half-wave).
+template <int NWT, int R0, int FOFF>
+__device__ __forceinline__ void lbs_epilogue_lds(const f32x16& ax, const f32x16& ay, const f32x16& az, float isc,
+                                                 const char* Tl, const int2 (&jw)[NWT], float vx, float vy, float vz,
+                                                 int vl, int lane, float* Sx) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int r = R0; r < R0 + 8; ++r) {
+        const int frl = (r & 3) + 8 * (r >> 2) + 4 * h - FOFF;   // frame inside the half tile
+        const char* Tf = Tl + frl * 48;
+        float4 A0[NWT], A1[NWT], A2[NWT];
+#pragma unroll
+        for (int s2 = 0; s2 < NWT; ++s2) {
+            const float4* tp = reinterpret_cast<const float4*>(Tf + jw[s2].x);
+            A0[s2] = tp[0]; A1[s2] = tp[1]; A2[s2] = tp[2];
+        }
+        float4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0;
+#pragma unroll
+        for (int s2 = 0; s2 < NWT; ++s2) {
+            const float w = __int_as_float(jw[s2].y);
+            T0.x += w * A0[s2].x; T0.y += w * A0[s2].y; T0.z += w * A0[s2].z; T0.w += w * A0[s2].w;
+            T1.x += w * A1[s2].x; T1.y += w * A1[s2].y; T1.z += w * A1[s2].z; T1.w += w * A1[s2].w;
+            T2.x += w * A2[s2].x; T2.y += w * A2[s2].y; T2.z += w * A2[s2].z; T2.w += w * A2[s2].w;
+        }
+        const float px = vx + isc * ax[r], py = vy + isc * ay[r], pz = vz + isc * az[r];
+        float* o = Sx + frl * LBS_SXP + vl * 3;
+        o[0] = T0.x * px + T0.y * py + T0.z * pz + T0.w;
+        o[1] = T1.x * px + T1.y * py + T1.z * pz + T1.w;
+        o[2] = T2.x * px + T2.y * py + T2.z * pz + T2.w;
+        if (r & 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -469,20 +508,40 @@ __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model 
 #define LBS_PUT1(K_) { const int c = tid + 256 * K_; const int j = c / 48, rem = c - j * 48; if (c < nchunk) *reinterpret_cast<float4*>(Tl + j * LBS_JSTRIDE_H + rem * 16) = tl##K_; }
 #define LBS_FETCH_TL(FB) { LBS_FETCH1(0, FB) LBS_FETCH1(1, FB) LBS_FETCH1(2, FB) LBS_FETCH1(3, FB) LBS_FETCH1(4, FB) LBS_FETCH1(5, FB) LBS_FETCH1(6, FB) LBS_FETCH1(7, FB) LBS_FETCH1(8, FB) LBS_FETCH1(9, FB) LBS_FETCH1(10, FB) LBS_FETCH1(11, FB) }
 #define LBS_PUT_TL() { LBS_PUT1(0) LBS_PUT1(1) LBS_PUT1(2) LBS_PUT1(3) LBS_PUT1(4) LBS_PUT1(5) LBS_PUT1(6) LBS_PUT1(7) LBS_PUT1(8) LBS_PUT1(9) LBS_PUT1(10) LBS_PUT1(11) }
+        float* Sx = reinterpret_cast<float*>(lds_raw + lbs_tl_bytes(K, 2));   // [16][LBS_SXP] staged results of one half tile
+        const int vl = wv * 32 + (lane & 31);
+        const int nfl = min(LBS_TV, V - v0) * 3;   // valid floats of a tile row
+        // cooperative store of the staged half tile: 16 rows x 96 chunks of 16 bytes, consecutive lanes on consecutive chunks
+        auto put_rows = [&](int fb) {
+            if (dbg_stop & 16) return;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int q = tid + 256 * i, row = q / 96, c = (q - row * 96) * 4;
+                const int f = fb + row;
+                const float4 v4 = *reinterpret_cast<const float4*>(Sx + row * LBS_SXP + c);   // (16-byte aligned: one ds_read_b128)
+                const f32x4u val = {v4.x, v4.y, v4.z, v4.w};
+                float* o = out + ((size_t)f * V + v0) * 3 + c;
+                if (f < F) {
+                    if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
+                    else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e];
+                }
+            }
+        };
         LBS_FETCH_TL(f0)
         LBS_LDS_BARRIER();   // every wave is done with the feature panel
         LBS_PUT_TL()
         LBS_LDS_BARRIER();
         LBS_FETCH_TL(f0 + 16)
-        lbs_epilogue<NWT, 0, 8, 0>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, V, F, f0 + 0, vme, lane, out, dbg_stop);
-        LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+        lbs_epilogue_lds<NWT, 0, 0>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, vl, lane, Sx);
+        LBS_LDS_BARRIER(); LBS_PUT_TL() put_rows(f0 + 0); LBS_LDS_BARRIER();
         LBS_FETCH_TL(f0 + 32)
-        lbs_epilogue<NWT, 8, 8, 16>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, V, F, f0 + 0, vme, lane, out, dbg_stop);
-        LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
+        lbs_epilogue_lds<NWT, 8, 16>(acc[0][0], acc[1][0], acc[2][0], isc, Tl, jw, vx, vy, vz, vl, lane, Sx);
+        LBS_LDS_BARRIER(); LBS_PUT_TL() put_rows(f0 + 16); LBS_LDS_BARRIER();
         LBS_FETCH_TL(f0 + 48)
-        lbs_epilogue<NWT, 0, 8, 0>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, V, F, f0 + 32, vme, lane, out, dbg_stop);
-        LBS_LDS_BARRIER(); LBS_PUT_TL() LBS_LDS_BARRIER();
-        lbs_epilogue<NWT, 8, 8, 16>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, V, F, f0 + 32, vme, lane, out, dbg_stop);
+        lbs_epilogue_lds<NWT, 0, 0>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, vl, lane, Sx);
+        LBS_LDS_BARRIER(); LBS_PUT_TL() put_rows(f0 + 32); LBS_LDS_BARRIER();
+        lbs_epilogue_lds<NWT, 8, 16>(acc[0][1], acc[1][1], acc[2][1], isc, Tl, jw, vx, vy, vz, vl, lane, Sx);
+        LBS_LDS_BARRIER(); put_rows(f0 + 48);
     }
 #undef LBS_FETCH_TL
 #undef LBS_PUT_TL
