@@ -187,62 +187,105 @@ def read_c3d(fname):
 
 
 # --------------------------------------------------------------------------------------------------
-def _param(name, gid, dtype, dims, data_bytes, desc=b''):
+def _ieee_to_dec_bytes(vals):
+    """float32 values -> DEC VAX F-float bytes (exponent bias +2 = x4, the two 16-bit words swapped)."""
+    w = (np.asarray(vals, dtype='<f4') * np.float32(4.0)).astype('<f4').view('<u4')
+    w = np.where(np.asarray(vals, dtype='<f4') == 0, np.uint32(0), w)
+    return (((w & 0xFFFF) << 16) | (w >> 16)).astype('<u4').tobytes()
+
+
+class _Enc:
+    """Byte-level encoders of one processor format (Intel little-endian IEEE, MIPS big-endian IEEE, DEC)."""
+
+    def __init__(self, proc):
+        self.proc = proc
+        self.e = '>' if proc == PROC_MIPS else '<'
+
+    def i16(self, v): return struct.pack(self.e + 'h', int(v))
+    def u16(self, v): return struct.pack(self.e + 'H', int(v))
+
+    def f32(self, v):
+        return _ieee_to_dec_bytes([v]) if self.proc == PROC_DEC else struct.pack(self.e + 'f', float(v))
+
+    def f32_array(self, a):
+        return _ieee_to_dec_bytes(a) if self.proc == PROC_DEC else np.asarray(a).astype(self.e + 'f4').tobytes()
+
+    def i16_array(self, a):
+        return np.asarray(a).astype(self.e + 'i2').tobytes()
+
+
+def _param(name, gid, dtype, dims, data_bytes, desc=b'', enc=None):
+    enc = enc or _Enc(PROC_INTEL)
     body = struct.pack('<b', dtype) + struct.pack('<B', len(dims)) + bytes(dims) + data_bytes
     body += struct.pack('<B', len(desc)) + desc
     nm = name.encode('latin-1')
-    return struct.pack('<bb', len(nm), gid) + nm + struct.pack('<h', len(body) + 2) + body
+    return struct.pack('<bb', len(nm), gid) + nm + enc.i16(len(body) + 2) + body
 
 
-def _group(name, gid, desc=b''):
+def _group(name, gid, desc=b'', enc=None):
+    enc = enc or _Enc(PROC_INTEL)
     nm = name.encode('latin-1')
     body = struct.pack('<B', len(desc)) + desc
-    return struct.pack('<bb', len(nm), -gid) + nm + struct.pack('<h', len(body) + 2) + body
+    return struct.pack('<bb', len(nm), -gid) + nm + enc.i16(len(body) + 2) + body
 
 
-def write_c3d(fname, points, labels, frame_rate=120.0, units='mm'):
-    """Intel / float-format C3D.  points[F,N,3] in file units; NaN or all-zero samples are written as
-    invalid (residual -1), like the reference's writer (mocap_interface.py:51-84)."""
+def write_c3d(fname, points, labels, frame_rate=120.0, units='mm', processor=PROC_INTEL, int_scale=None):
+    """C3D writer.  points[F,N,3] in file units; NaN or all-zero samples are written as invalid (residual -1), like the
+    reference's writer (mocap_interface.py:51-84).  Default: Intel / float format (what the reference writes);
+    `processor` PROC_MIPS / PROC_DEC and `int_scale` (> 0: scaled-int16 point format, POINT:SCALE = int_scale) produce the
+    other on-disk variants the format allows (reference reader: tools/c3d.py:35-60, 1293-1385)."""
     points = np.asarray(points, dtype=np.float64)
     F, N, _ = points.shape
     assert len(labels) == N
     if F > 65535:
         raise ValueError('this writer stores at most 65535 frames')
+    enc = _Enc(processor)
     invalid = np.logical_or(np.isnan(points).any(-1), (points == 0).all(-1))
-    data = np.zeros((F, N, 4), dtype='<f4')
-    data[:, :, :3] = np.where(invalid[..., None], 0.0, points)
-    data[:, :, 3] = np.where(invalid, -1.0, 0.0)
+    scale = -1.0 if int_scale is None else float(int_scale)
+    if int_scale is None:
+        data = np.zeros((F, N, 4), dtype=np.float32)
+        data[:, :, :3] = np.where(invalid[..., None], 0.0, points)
+        data[:, :, 3] = np.where(invalid, -1.0, 0.0)
+        raw = enc.f32_array(data.ravel())
+    else:
+        q = np.rint(np.where(invalid[..., None], 0.0, points) / scale)
+        if np.abs(q).max() > 32767:
+            raise ValueError('int_scale too small for the coordinate range')
+        data = np.zeros((F, N, 4), dtype=np.int16)
+        data[:, :, :3] = q.astype(np.int16)
+        data[:, :, 3] = np.where(invalid, -1, 0)   # valid: residual byte 0, camera mask 0
+        raw = enc.i16_array(data.ravel())
     width = max(4, max((len(l) for l in labels), default=4))
-    recs = _group('POINT', 1) + _group('ANALOG', 2)
-    recs += _param('USED', 1, 2, [], struct.pack('<h', N))
-    recs += _param('FRAMES', 1, 2, [], struct.pack('<H', F))
-    recs += _param('SCALE', 1, 4, [], struct.pack('<f', -1.0))
-    recs += _param('RATE', 1, 4, [], struct.pack('<f', float(frame_rate)))
-    recs += _param('UNITS', 1, -1, [len(units)], units.encode('latin-1'))
+    P = lambda *a, **k: _param(*a, enc=enc, **k)   # noqa: E731
+    recs = _group('POINT', 1, enc=enc) + _group('ANALOG', 2, enc=enc)
+    recs += P('USED', 1, 2, [], enc.i16(N))
+    recs += P('FRAMES', 1, 2, [], enc.u16(F))
+    recs += P('SCALE', 1, 4, [], enc.f32(scale))
+    recs += P('RATE', 1, 4, [], enc.f32(float(frame_rate)))
+    recs += P('UNITS', 1, -1, [len(units)], units.encode('latin-1'))
     for blk in range(0, max(N, 1), 255):
         chunk = labels[blk:blk + 255]
         key = 'LABELS' if blk == 0 else f'LABELS{blk // 255 + 1}'
-        raw = b''.join(l.encode('latin-1').ljust(width)[:width] for l in chunk)
-        recs += _param(key, 1, -1, [width, len(chunk)], raw)
-    recs += _param('USED', 2, 2, [], struct.pack('<h', 0))
+        rawl = b''.join(l.encode('latin-1').ljust(width)[:width] for l in chunk)
+        recs += P(key, 1, -1, [width, len(chunk)], rawl)
+    recs += P('USED', 2, 2, [], enc.i16(0))
     # DATA_START needs the final parameter-section size: fixed-size record, so compute first
-    ds_len = len(_param('DATA_START', 1, 2, [], struct.pack('<h', 0)))
+    ds_len = len(P('DATA_START', 1, 2, [], enc.i16(0)))
     n_pblocks = (4 + len(recs) + ds_len + 2 + 511) // 512
     data_start = 2 + n_pblocks
-    recs += _param('DATA_START', 1, 2, [], struct.pack('<h', data_start))
-    psec = bytes([1, 0x50, n_pblocks, PROC_INTEL]) + recs + b'\x00\x00'
+    recs += P('DATA_START', 1, 2, [], enc.i16(data_start))
+    psec = bytes([1, 0x50, n_pblocks, processor]) + recs + b'\x00\x00'
     psec = psec.ljust(n_pblocks * 512, b'\x00')
     hdr = bytearray(512)
     hdr[0] = 2
     hdr[1] = 0x50
-    struct.pack_into('<HHHHH', hdr, 2, N, 0, 1, F, 0)
-    struct.pack_into('<f', hdr, 12, -1.0)
-    struct.pack_into('<HH', hdr, 16, data_start, 0)
-    struct.pack_into('<f', hdr, 20, float(frame_rate))
+    hdr[2:12] = enc.u16(N) + enc.u16(0) + enc.u16(1) + enc.u16(F) + enc.u16(0)
+    hdr[12:16] = enc.f32(scale)
+    hdr[16:20] = enc.u16(data_start) + enc.u16(0)
+    hdr[20:24] = enc.f32(float(frame_rate))
     with open(fname, 'wb') as f:
         f.write(bytes(hdr))
         f.write(psec)
-        raw = data.tobytes()
         f.write(raw)
         pad = (-len(raw)) % 512
         f.write(b'\x00' * pad)

@@ -179,3 +179,28 @@ def test_partition_units():
     parts = partition_units([10, 1, 1, 1, 7, 3], 2)
     loads = [sum([10, 1, 1, 1, 7, 3][i] for i in p) for p in parts]
     assert sorted(sum(parts, [])) == list(range(6)) and abs(loads[0] - loads[1]) <= 1
+
+
+@pytest.mark.parametrize('variant,tol', [('mips_float', 0.0), ('dec_float', 0.0), ('intel_int', 1e-4), ('mips_int', 1e-4)])
+def test_c3d_reader_on_processor_and_int_variants(variant, tol):
+    """The other on-disk forms of C3D (big-endian MIPS, DEC floats, scaled int16 points): files written by our writer,
+    parsed by the reference's vendored reader when the fixture was made (tests/golden/make_c3d_variants.py); our reader must
+    return the same coordinates and the same invalid mask, and both must match what was written to format precision."""
+    from moshpp_amd import c3d_io
+    g = np.load(os.path.join(GOLDEN, 'c3d_variants_expected.npz'))
+    d = c3d_io.read_c3d(os.path.join(GOLDEN, f'variant_{variant}.c3d'))
+    inv_ref = g[f'{variant}_invalid']
+    assert np.array_equal(np.isnan(d['points']).any(-1), inv_ref)
+    assert d['labels'] == [str(x) for x in g['labels']] and d['frame_rate'] == 100.0 == float(g[f'{variant}_rate'])
+    ours = d['points'][~inv_ref]
+    # the two readers agree: exactly on float files; to float32 rounding on int files (the reference scales in float32)
+    assert np.abs(ours - g[f'{variant}_xyz'][~inv_ref]).max() <= tol
+    written = g['points_written']
+    assert np.array_equal(np.isnan(written).any(-1), inv_ref)
+    assert np.abs(ours - written[~inv_ref]).max() < (0.051 if variant.endswith('int') else 1e-4)
+
+
+def test_c3d_writer_rejects_out_of_range_int_scale(tmp_path):
+    from moshpp_amd import c3d_io
+    with pytest.raises(ValueError):
+        c3d_io.write_c3d(str(tmp_path / 'x.c3d'), np.full((1, 1, 3), 5000.0), ['A'], int_scale=0.1)
