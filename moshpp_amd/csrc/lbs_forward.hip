@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
 __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KP,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
-                                                   float* __restrict__ Atr, _Float16* __restrict__ featT) {
+                                                   float* __restrict__ Atr, _Float16* __restrict__ featT,
+                                                   _Float16* __restrict__ Ah, int KJ) {
     // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own
     __shared__ float s_fullpose[4][3 * MOSHII_MAXK];
     __shared__ float s_Rl[4][MOSHII_MAXK * 9], s_Rw[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];
@@ -276,7 +277,22 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float r0 = Rw[tid * 9 + i * 3 + 0], r1 = Rw[tid * 9 + i * 3 + 1], r2 = Rw[tid * 9 + i * 3 + 2];
-            o[i] = make_float4(r0, r1, r2, tw[tid * 3 + i] - (r0 * Jme[0] + r1 * Jme[1] + r2 * Jme[2]) + tr[i]);
+            const float t3 = tw[tid * 3 + i] - (r0 * Jme[0] + r1 * Jme[1] + r2 * Jme[2]) + tr[i];
+            o[i] = make_float4(r0, r1, r2, t3);
+            if (Ah != nullptr) {
+                // the same row as f16 hi + lo in MFMA A-operand order: block of 8 frames, row rho = 4 slot + comp with
+                // slot = 2 (fo & 3) + (fo >> 2), fo = f % 8 (so that accumulator register 4 a + c of half-wave h is frame a + 4 h)
+                const int fo = f & 7, slot = 2 * (fo & 3) + (fo >> 2);
+                const float vals[4] = {r0, r1, r2, t3};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const _Float16 hi = (_Float16)vals[c];
+                    const _Float16 lo = (_Float16)(vals[c] - (float)hi);
+                    const size_t base = ((((size_t)(f >> 3) * 3 + i) * 2) * 32 + (4 * slot + c)) * KJ + tid;
+                    Ah[base] = hi;
+                    Ah[base + (size_t)32 * KJ] = lo;
+                }
+            }
         }
     }
 }
@@ -289,9 +305,12 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 #define LBS_SXP 392         // dwords per frame row of the NT = 2 result staging: 128 vertices x 3 + 8 (the two half-waves of a
                             // store instruction are 4 rows apart: 4 x 392 = 32 mod 64 banks)
 __host__ __device__ inline size_t lbs_tl_bytes(int K, int nt) { return ((size_t)K * (nt == 2 ? LBS_JSTRIDE_H : LBS_JSTRIDE) + 15) & ~size_t(15); }
-__host__ __device__ inline size_t lbs_region_bytes(int KP, int K, int nt) {
+// dense-blend epilogue (KSJ = KJ / 16 > 0): A-operand stage of one 8-frame block, 192 rows of KJ halves + 16 bytes, then Sx [8][LBS_SXP]
+__host__ __device__ inline size_t lbs_astage_bytes(int ksj) { return (size_t)192 * (ksj * 32 + 16); }
+__host__ __device__ inline size_t lbs_region_bytes(int KP, int K, int nt, int ksj = 0) {
     const size_t panel = (size_t)nt * 32 * LBS_PITCH(KP) * 2;
-    const size_t epi = lbs_tl_bytes(K, nt) + (nt == 2 ? (size_t)16 * LBS_SXP * 4 : 0);
+    const size_t epi = (ksj > 0) ? lbs_astage_bytes(ksj) + (size_t)8 * LBS_SXP * 4
+                                 : lbs_tl_bytes(K, nt) + (nt == 2 ? (size_t)16 * LBS_SXP * 4 : 0);
     return ((panel > epi ? panel : epi) + 15) & ~size_t(15);
 }
 
@@ -372,9 +391,11 @@ __device__ __forceinline__ void lbs_epilogue_lds(const f32x16& ax, const f32x16&
 // NT = frame tiles (of 32) per workgroup.  NT = 4: one workgroup per CU (192 accumulator registers per lane).  NT = 2: half the
 // accumulators and half the LDS, so that TWO workgroups share a CU and one's MFMA loop overlaps the other's epilogue
 // gathers and the drain of its stores (with one wave per SIMD every phase of a tile is exposed back to back).
-template <int NWT, int NT>
+// KSJ > 0 (NT = 2 only): the skinning blend runs on the matrix pipe instead of gathering from LDS -- see the epilogue.
+template <int NWT, int NT, int KSJ>
 __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model lm, int V, int F, int NVT, int NFT, int NVX,
                                                                       float* __restrict__ out, int dbg_stop) {
+    static_assert(KSJ == 0 || NT == 2, "the dense-blend epilogue is written for the two-workgroups-per-CU form");
     constexpr int TF = NT * 32;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model 
     const int vme = v0 + wv * 32 + (lane & 31);
     int2 jw[NWT];
 #pragma unroll
-    for (int s2 = 0; s2 < NWT; ++s2) jw[s2] = lm.sjw[(size_t)vme * NWT + s2];
+    for (int s2 = 0; s2 < NWT; ++s2) jw[s2] = (KSJ == 0) ? lm.sjw[(size_t)vme * NWT + s2] : make_int2(0, 0);
     const float vx = lm.vsh_pad[(size_t)vme * 3 + 0], vy = lm.vsh_pad[(size_t)vme * 3 + 1], vz = lm.vsh_pad[(size_t)vme * 3 + 2];
     __syncthreads();
     // ---- main loop: acc[i][nt] (32 frames x 32 vertices) += featT(nt, ks) x Pfrag(i, ks)^T
@@ -469,7 +490,103 @@ __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model 
     // LDS-only barrier -- a plain __syncthreads() would also wait for the tile's global stores to be acknowledged.
     const float isc = lm.inv_pscale;
 #define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    if constexpr (NT == 4) {
+    if constexpr (KSJ > 0) {
+        // ---- dense blend on the matrix pipe.  The LDS-gather epilogue below moves 4 influences x 48 B per (vertex, frame) out
+        // of LDS and is bound by the LDS return path (66 B/clk/CU measured, with or without bank conflicts).  Here the blended
+        // transform rows  T[r][c](v, f) = sum_j W[v][j] A[j][f][r][c]  of 32 vertices x 8 frames come out of three
+        // 32x32x16 MFMAs per 16 joints (f16 hi + lo operands: A_hi W_hi + A_lo W_hi + A_hi W_lo, f32 accumulate -- 2^-22
+        // relative), with A staged once per 8-frame block in operand order ([row r][hi|lo][rho = 4 slot + c][joint]) by
+        // k_lbs_prep and the weights W resident in registers as B fragments: 8 b128 LDS reads per 12 MFMAs.
+        // Accumulator register 4 a + c of half-wave h then holds T[r][c] of frame (8 fb + a + 4 h), the frame whose
+        // pose-corrected rest position sits in register a + 4 fb of the corrective accumulators.
+        constexpr int KJ = KSJ * 16, PA = KJ * 2 + 16;          // A-stage row pitch in bytes (16 x odd: conflict-free b128 rows)
+        constexpr int NCHT = (384 * KSJ + 255) / 256;            // 16-byte chunks per thread for one stage (192 rows x 2 KSJ)
+        char* Ab = lds_raw;                                      // [192][PA]
+        float* Sx = reinterpret_cast<float*>(lds_raw + lbs_astage_bytes(KSJ));   // [8][LBS_SXP]
+        const int vl = wv * 32 + (lane & 31), h = lane >> 5;
+        const int nfl = min(LBS_TV, V - v0) * 3;
+        half8 Wh[KSJ], Wl[KSJ];
+        {
+            const half8* wp = reinterpret_cast<const half8*>(lm.Wfrag) + ((size_t)vg * KSJ * 2) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KSJ; ++ks) { Wh[ks] = wp[(size_t)(ks * 2 + 0) * 64]; Wl[ks] = wp[(size_t)(ks * 2 + 1) * 64]; }
+        }
+        const int nfb8 = (F + 7) >> 3;
+        float4 st[NCHT];
+        auto fetch = [&](int q) {   // block of 8 frames number f0 / 8 + q (clamped: blocks past the end are never stored)
+            const int fb8 = min((f0 >> 3) + q, nfb8 - 1);
+            const float4* src = reinterpret_cast<const float4*>(lm.Ah + (size_t)fb8 * 192 * KJ);
+#pragma unroll
+            for (int i = 0; i < NCHT; ++i) st[i] = src[min(tid + 256 * i, 384 * KSJ - 1)];
+        };
+        auto put = [&]() {
+#pragma unroll
+            for (int i = 0; i < NCHT; ++i) {
+                const int c = tid + 256 * i, row = c / (2 * KSJ), cc = c - row * (2 * KSJ);
+                if (c < 384 * KSJ) *reinterpret_cast<float4*>(Ab + row * PA + cc * 16) = st[i];
+            }
+        };
+        auto put_rows = [&](int fb) {   // the staged 8 frames x 128 vertices leave as whole 1536-byte tile rows
+            if (dbg_stop & 16) return;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = tid + 256 * i, row = q / 96, c = (q - row * 96) * 4;
+                const int f = fb + row;
+                const float4 v4 = *reinterpret_cast<const float4*>(Sx + row * LBS_SXP + c);
+                const f32x4u val = {v4.x, v4.y, v4.z, v4.w};
+                float* o = out + ((size_t)f * V + v0) * 3 + c;
+                if (f < F) {
+                    if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
+                    else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e];
+                }
+            }
+        };
+        fetch(0);
+        LBS_LDS_BARRIER();   // every wave is done with the feature panel
+        put();
+        LBS_LDS_BARRIER();
+#pragma unroll
+        for (int q = 0; q < 2 * 4; ++q) {   // q = 4 nt + fb: compile-time accumulator indices
+            constexpr int dummy = 0; (void)dummy;
+            const int nt = q >> 2, fb = q & 3;
+            if (q + 1 < 8) fetch(q + 1);
+            float ox[4], oy[4], oz[4];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                f32x16 D;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) D[e] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KSJ; ++ks) {
+                    const char* ar = Ab + ((r * 2) * 32 + (lane & 31)) * PA + (ks * 16 + 8 * h) * 2;
+                    const half8 ah = *reinterpret_cast<const half8*>(ar);
+                    const half8 al = *reinterpret_cast<const half8*>(ar + 32 * PA);
+                    // (each MFMA is followed by 8 idle issue slots: its four-register A / B operands come straight from LDS reads
+                    //  and hipcc reuses those registers at once -- a VALU write landing one instruction behind the MFMA was seen to
+                    //  corrupt the operand for the later-read part of the tile: wrong columns 16..31, timing dependent)
+#define LBS_MFMA_SAFE(A_, B_) { D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, D, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+                                asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+                    LBS_MFMA_SAFE(ah, Wh[ks]) LBS_MFMA_SAFE(al, Wh[ks]) LBS_MFMA_SAFE(ah, Wl[ks])
+#undef LBS_MFMA_SAFE
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float px = vx + isc * acc[0][nt][a + 4 * fb], py = vy + isc * acc[1][nt][a + 4 * fb], pz = vz + isc * acc[2][nt][a + 4 * fb];
+                    const float o = D[4 * a + 0] * px + D[4 * a + 1] * py + D[4 * a + 2] * pz + D[4 * a + 3];
+                    if (r == 0) ox[a] = o; else if (r == 1) oy[a] = o; else oz[a] = o;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float* o = Sx + (a + 4 * h) * LBS_SXP + vl * 3;
+                o[0] = ox[a]; o[1] = oy[a]; o[2] = oz[a];
+            }
+            LBS_LDS_BARRIER();            // Sx complete, every wave done with this A stage
+            if (q + 1 < 8) put();
+            put_rows(f0 + 8 * q);
+            LBS_LDS_BARRIER();            // next A stage visible, Sx free
+        }
+    } else if constexpr (NT == 4) {
     const int nchunk = K * 96;   // 16-byte chunks of one tile's transforms: [j][frame in tile][3]
     float4 tl0, tl1, tl2, tl3, tl4, tl5, tl6, tl7, tl8, tl9, tl10, tl11, tl12, tl13, tl14, tl15, tl16, tl17, tl18, tl19, tl20, tl21, tl22, tl23;   // (named scalars: hipcc keeps an array of these in scratch)
 #define LBS_FETCH1(K_, FB) { const int c = min(tid + 256 * K_, nchunk - 1); const int j = c / 96, rem = c - j * 96, fl2 = rem / 3, q = rem - fl2 * 3; \
@@ -558,7 +675,7 @@ extern "C" void moshii_lbs32_free(void* l32) {
     Lbs32Model* lm = (Lbs32Model*)l32;
     free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
     free_ptr(lm->Pfrag); free_ptr(lm->vsh_pad); free_ptr(lm->sjw);
-    free_ptr(lm->Atr); free_ptr(lm->featT);
+    free_ptr(lm->Atr); free_ptr(lm->featT); free_ptr(lm->Ah); free_ptr(lm->Wfrag);
     memset(lm, 0, sizeof(*lm));
 }
 
@@ -626,6 +743,26 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
             if (hipMalloc((void**)&lm->sjw, sjw.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
             hipMemcpy(lm->sjw, sjw.data(), sjw.size() * sizeof(int), hipMemcpyHostToDevice);
             hipLaunchKernelGGL(k_pack_pfrag, dim3(4096), dim3(256), 0, 0, V, nfeat, KS, nvg, pscale, moshii_internal_posedirs(m), lm->Pfrag);
+            // dense-blend operands: weights as f16 hi + lo, B-operand fragment-major (lane l of group vg: vertex 32 vg + (l & 31),
+            // joints 16 ks + 8 (l >> 5) .. + 8)
+            const int KJ = (K + 15) / 16 * 16, KSJ = KJ / 16;
+            lm->KJ = KJ;
+            if (KJ <= 64) {
+                std::vector<_Float16> wf((size_t)nvg * KSJ * 2 * 64 * 8);
+                for (int g = 0; g < nvg; ++g)
+                    for (int ks = 0; ks < KSJ; ++ks)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int v = g * 32 + (l & 31), j = ks * 16 + 8 * (l >> 5) + e;
+                                const float w = (v < V && j < K) ? (float)wh[(size_t)v * K + j] : 0.0f;
+                                const _Float16 hi = (_Float16)w;
+                                const _Float16 lo = (_Float16)(w - (float)hi);
+                                wf[((((size_t)g * KSJ + ks) * 2 + 0) * 64 + l) * 8 + e] = hi;
+                                wf[((((size_t)g * KSJ + ks) * 2 + 1) * 64 + l) * 8 + e] = lo;
+                            }
+                if (hipMalloc((void**)&lm->Wfrag, wf.size() * sizeof(_Float16)) != hipSuccess) return MOSHII_ERR_HIP;
+                hipMemcpy(lm->Wfrag, wf.data(), wf.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+            }
             lm->mfma_ok = 1;
         }
     }
@@ -652,27 +789,44 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     }
     if (F > lmp->Fcap) {   // per-call scratch grows to the largest F seen (not stream-ordered: sync first)
         hipStreamSynchronize(stream);
-        free_ptr(lmp->Atr); free_ptr(lmp->featT);
-        lmp->Atr = nullptr; lmp->featT = nullptr; lmp->Fcap = 0;
+        free_ptr(lmp->Atr); free_ptr(lmp->featT); free_ptr(lmp->Ah);
+        lmp->Atr = nullptr; lmp->featT = nullptr; lmp->Ah = nullptr; lmp->Fcap = 0;
         hipError_t e = hipMalloc((void**)&lmp->Atr, (size_t)md->K * F * 12 * sizeof(float));
         if (e != hipSuccess) return e;
         e = hipMalloc((void**)&lmp->featT, (size_t)F * lmp->KP * sizeof(_Float16));
         if (e != hipSuccess) return e;
+        if (lmp->Wfrag) {   // A-operand copy of the transforms; joints K .. KJ-1 stay zero
+            const size_t nah = (size_t)((F + 7) / 8) * 192 * lmp->KJ;
+            e = hipMalloc((void**)&lmp->Ah, nah * sizeof(_Float16));
+            if (e != hipSuccess) return e;
+            e = hipMemset(lmp->Ah, 0, nah * sizeof(_Float16));
+            if (e != hipSuccess) return e;
+        }
         lmp->Fcap = F;
     }
     const Lbs32Model lm = *lmp;
-    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KP, pose, trans, lm.Atr, lm.featT);
+    // skinning blend: "mfma" = dense W x A on the matrix pipe (needs K <= 64), "gather" = sparse LDS gather of the influences
+    bool dense = lm.Wfrag != nullptr && lm.KJ <= 64 && (lm.KJ == 16 || lm.KJ == 32 || lm.KJ == 64);
+    if (const char* es = getenv("MOSHII_LBS_BLEND")) dense = dense && strcmp(es, "gather") != 0;
+    else dense = false;
+    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KP, pose, trans, lm.Atr, lm.featT,
+                       dense ? lm.Ah : (_Float16*)nullptr, lm.KJ);
     // frame tiles per workgroup: 2 = two workgroups per CU (default: measured 359 vs 394 us at F=4000), 4 = one per CU
     int nt = 2;
     if (const char* es = getenv("MOSHII_LBS_NT")) nt = (atoi(es) == 4) ? 4 : 2;
+    if (dense) nt = 2;
+    const int ksj = dense ? lm.KJ / 16 : 0;
     const int TF = nt * 32;
     const int NVT = lm.Vp128 / LBS_TV, NFT = (F + TF - 1) / TF;
     const int NVX = (NVT + 7) / 8;                         // vertex tiles per XCD
     const int NCH = (NFT + LBS_FCH - 1) / LBS_FCH;         // frame chunks
     const int grid = 8 * NCH * NVX * LBS_FCH;
-    const size_t lds = lbs_region_bytes(lm.KP, lm.K, nt);
+    const size_t lds = lbs_region_bytes(lm.KP, lm.K, nt, ksj);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = (nt == 2) ? ((lm.NW == 4) ? k_lbs_mfma<4, 2> : k_lbs_mfma<8, 2>) : ((lm.NW == 4) ? k_lbs_mfma<4, 4> : k_lbs_mfma<8, 4>);
+    auto kern = (nt == 2) ? ((lm.NW == 4) ? k_lbs_mfma<4, 2, 0> : k_lbs_mfma<8, 2, 0>) : ((lm.NW == 4) ? k_lbs_mfma<4, 4, 0> : k_lbs_mfma<8, 4, 0>);
+    if (ksj == 4) kern = k_lbs_mfma<4, 2, 4>;
+    else if (ksj == 2) kern = k_lbs_mfma<4, 2, 2>;
+    else if (ksj == 1) kern = k_lbs_mfma<4, 2, 1>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (nt == 2) ? 80 * 1024 : 160 * 1024);
     if (e != hipSuccess) return e;
     int dbg_stop = 0;

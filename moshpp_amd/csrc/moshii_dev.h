@@ -131,6 +131,10 @@ struct Lbs32Model {
     int Vp128, KP, KS;
     int mfma_ok;
     // per-call scratch
+    // dense blend on the matrix pipe (k_lbs_mfma<.., .., KSJ > 0>): skinning weights and joint transforms as f16 hi + lo
+    _Float16* Wfrag;       // [Vp128/32][KJ/16][2 hi,lo][64 lanes][8]  weights, B-operand fragment-major
+    _Float16* Ah;          // per call: [ceil(Fcap/8)][3 rows][2 hi,lo][32 = 4 slot + comp][KJ]  joint transforms, A-operand order
+    int KJ;                // joints padded to a multiple of 16
     float* Atr;            // [K][Fcap][12]
     _Float16* featT;       // [Fcap][KP]
     int Fcap;
