@@ -57,7 +57,9 @@ def main():
     ap.add_argument('--mode', choices=('chunked', 'sequential'), default='chunked')
     ap.add_argument('--chunks', type=int, default=0, help='chunks per sequence (0 = one per CU)')
     ap.add_argument('--chunk-warmup', type=int, default=32)
-    ap.add_argument('--verify-tol', type=float, default=1e-11)
+    # hand-off tolerance: 1e-9 rad / m yields the same stitched result as 1e-11 (max deviation from the sequential chain 1.4e-9
+    # rad on all 4000 frames, re-measured below every run) with fewer repairs of warm-ups that were converged to 1e-10
+    ap.add_argument('--verify-tol', type=float, default=1e-9)
     ap.add_argument('--cpu-sample', type=int, default=400, help='frames of the workload timed on the CPU oracle')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
