@@ -11,20 +11,21 @@
 //   k_lbs_prep   one 64-thread workgroup per frame: hand-PCA -> fullpose, Rodrigues, kinematic chain;
 //                writes the skinning transforms A[j][f][12] (f32, translation folded with trans[f]) and the pose
 //                feature rows featT[f][KP] (f16).
-//   k_lbs_mfma   one workgroup (4 waves) per 128 vertices x 64 frames, two workgroups per CU (NT = 2; the description below
-//                is written for the NT = 4 form, 128 frames and one workgroup per CU, which MOSHII_LBS_NT=4 still selects):
-//                  * the 128 x KP feature panel is staged once in LDS (row pitch 16 x odd bytes: conflict-free b128 reads);
-//                  * each wave owns 32 vertices x 3 coordinates x 4 frame tiles = 12 accumulators (192 registers) and
-//                    streams its posedirs fragments from a fragment-major copy of the model (one contiguous 1 KiB
-//                    record per wave-load, prefetched two k-steps ahead): 3 global + 4 LDS fragment loads feed 12 MFMAs;
+//   k_lbs_mfma   one workgroup (4 waves) per 128 vertices x 64 frames, two workgroups per CU (NT = 2; MOSHII_LBS_NT=4 selects the
+//                earlier form: 128 frames, one workgroup per CU, results stored straight from the accumulators):
+//                  * the 64 x KP feature panel is staged once in LDS (row pitch 16 x odd bytes: conflict-free b128 reads);
+//                  * each wave owns 32 vertices x 3 coordinates x 2 frame tiles = 6 accumulators (96 registers) and streams its
+//                    posedirs fragments from a fragment-major copy of the model (one contiguous 1 KiB record per wave-load,
+//                    prefetched five k-steps ahead): 3 global + 2 LDS fragment loads feed 6 MFMAs;
 //                  * the MFMA runs "features x posedirs": accumulator column (lane) = vertex, accumulator register = frame.
 //                    Epilogue on that layout: a lane keeps ITS vertex's <= 8 skinning influences and rest position in
-//                    registers for the whole tile; per 32-frame tile the K joint transforms are staged in LDS
-//                    ([joint][frame][12], joint blocks 1552 B apart so that different joints fall on different banks, equal
+//                    registers for the whole tile; per 16-frame half tile the K joint transforms are staged in LDS
+//                    ([joint][frame][12], joint blocks 784 B apart so that different joints fall on different banks, equal
 //                    joints broadcast) and each (lane, frame) gathers only its own influences -- sparse skinning, no
-//                    W x A GEMM: SMPL-family weights have <= 4 influences per vertex, the dense contraction is 13x the work;
-//                  * for a fixed frame the 32 lanes of a half-wave hold 32 consecutive vertices: results leave straight
-//                    from registers as 12-byte stores that tile contiguous 384-byte runs (no LDS transposition).
+//                    W x A GEMM (a dense-blend variant on the matrix pipe exists behind MOSHII_LBS_BLEND=mfma; slower as built);
+//                  * the results of a half tile are exchanged through LDS and leave as whole 1536-byte tile rows (128 vertices of
+//                    one frame, 16-byte streaming stores): tools/store_pattern.hip measures 5.5 TB/s for that pattern against
+//                    3.1 TB/s for 384-byte runs per half-wave.
 //                workgroup -> (vertex tile, frame tile) is XCD-aware: all frame tiles of one vertex tile run on the XCD
 //                whose L2 already holds that tile's 356 KB of posedirs fragments.
 //

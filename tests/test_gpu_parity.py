@@ -262,7 +262,7 @@ def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
 
 @pytest.mark.parametrize('model_type,F', [('smplh', 300), ('smplx', 150), ('mano', 200), ('smpl', 129)])
 def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
-    """The MFMA export kernel (f16-operand correctives, sparse in-register blend, LDS transpose) against the
+    """The MFMA export kernel (f16-operand correctives, sparse in-register blend, row stores through LDS) against the
     reference-precision kernel and against the plain f32 kernel, on frame counts and vertex counts that leave
     partial frame tiles and partial vertex tiles."""
     M = {'smplh': 53, 'smplx': 60, 'mano': 24, 'smpl': 41}[model_type]
