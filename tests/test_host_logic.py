@@ -204,3 +204,21 @@ def test_c3d_writer_rejects_out_of_range_int_scale(tmp_path):
     from moshpp_amd import c3d_io
     with pytest.raises(ValueError):
         c3d_io.write_c3d(str(tmp_path / 'x.c3d'), np.full((1, 1, 3), 5000.0), ['A'], int_scale=0.1)
+
+
+def test_face_and_dmpl_host_pieces(tmp_path):
+    """optimize_face id sets (chmosh.py:560-563, 685-689) agree with the oracle's; DMPL directions load from pkl / npz / dict
+    (chmosh.py:511: `pickle.load(f)['eigvec']`)."""
+    from moshpp_amd.chmosh import read_dmpl_pcs
+    a = stageii_pose_ids('smplx', 123, True, False, optimize_face=True)
+    _, _, _, st1, st2 = so.pose_id_sets('smplx', 123, True, False, optimize_face=True)
+    assert a['face'] == [66, 67, 68] == so.face_pose_ids('smplx', True)
+    assert a['step2'] == list(st2) and a['step1'] == list(st1) and len(a['step2']) == 60 + 48 + 3
+    assert stageii_pose_ids('smplh', 114, False, False, optimize_face=True)['face'] == []      # only SMPL-X has a jaw
+    assert so.face_pose_ids('smplh', True) == []
+    ev = np.random.default_rng(0).normal(0, 1, (7, 3, 9))
+    with open(tmp_path / 'd.pkl', 'wb') as f:
+        pickle.dump({'eigvec': ev}, f, protocol=2)
+    np.savez(tmp_path / 'd.npz', eigvec=ev)
+    for src in (str(tmp_path / 'd.pkl'), str(tmp_path / 'd.npz'), {'eigvec': ev}):
+        assert np.array_equal(read_dmpl_pcs(src), ev)
