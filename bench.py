@@ -159,7 +159,8 @@ def main():
         kt = float(np.mean(step_ms)) * 1e-3
         ach = fl / kt / 1e12
         result['roofline'] = {
-            'kernel': name, 'bound': 'valu_f64 (dependency/latency-bound small dense solves; HBM traffic ~3 KB/frame)',
+            'kernel': name, 'bound': 'valu_f64',
+            'bound_note': 'neither hbm nor mfma: float64 vector pipe, dependency/latency-bound small dense solves; HBM traffic ~44 KB/frame (PMC)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
             # PMC (separate FETCH_SIZE / WRITE_SIZE passes on a 120-frame chain, profiles/r01_chain_pmc.txt): 13.3 KB fetched
             # (x2 wide-load correction of the guide -> 26.5 KB) + 17.7 KB written per solved frame, incl. the one-time read of
