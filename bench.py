@@ -244,9 +244,10 @@ def main():
             bytes_alg = Fl * (12 * sm.V + 4 * sm.NP + 12) + model_bytes
             result['roofline_lbs'] = {'kernel': 'k_lbs_mfma (+ k_lbs_prep)', 'bound': 'hbm', 'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives', 'achieved': round(bytes_alg / lt / 1e9, 1),
                                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
-                                      # PMC at F=2000 (profiles/r01_lbs_pmc.txt): FETCH_SIZE 82.8 MB (x2 -> 165.6 MB), WRITE_SIZE 164 MB
-                                      'traffic': int((2 * 82.82e6 + 164.0e6) * Fl / 2000.0),
-                                      'traffic_source': 'rocprofv3 PMC at F=2000 (profiles/r01_lbs_pmc.txt), scaled by frames; not collected live',
+                                      # PMC at F=4000 (profiles/r01_lbs_pmc.txt): FETCH_SIZE 234.8 MB (x2 -> 469.6 MB), WRITE_SIZE 430.7 MB
+                                      # (+ k_lbs_prep 2 x 1.2 + 13.4 MB)
+                                      'traffic': int((2 * 234.794e6 + 430.65e6 + 2 * 1.175e6 + 13.376e6) * Fl / 4000.0),
+                                      'traffic_source': 'rocprofv3 PMC at F=4000 (profiles/r01_lbs_pmc.txt), scaled by frames; not collected live',
                                       'frames': Fl, 'kernel_ms': round(lt * 1e3, 3),
                                       'frames_per_s': round(Fl / lt, 1)}
         except Exception as e:   # the LBS leg must never take the headline number down
