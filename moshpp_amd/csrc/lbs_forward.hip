@@ -406,8 +406,10 @@ __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model 
     // transforms (2.5 MB for SMPL-H) stays L2-resident while every vertex tile of the XCD sweeps over it.
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int fl_t = slot % LBS_FCH, rest = slot / LBS_FCH;
-    const int vt = xcd + 8 * (rest % NVX), ft = (rest / NVX) * LBS_FCH + fl_t;
+    const int FCH = dbg_stop >> 8;   // frame tiles per L2 chunk (host: LBS_FCH or MOSHII_LBS_FCH), packed above the debug bits
+    dbg_stop &= 255;
+    const int fl_t = slot % FCH, rest = slot / FCH;
+    const int vt = xcd + 8 * (rest % NVX), ft = (rest / NVX) * FCH + fl_t;
     if (vt >= NVT || ft >= NFT) return;
     const int KP = lm.KP, KS = lm.KS, pitch = LBS_PITCH(KP);
     // LDS: one region R = max(feature panel [main loop], joint transforms of one frame tile [epilogue])
@@ -820,8 +822,10 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     const int TF = nt * 32;
     const int NVT = lm.Vp128 / LBS_TV, NFT = (F + TF - 1) / TF;
     const int NVX = (NVT + 7) / 8;                         // vertex tiles per XCD
-    const int NCH = (NFT + LBS_FCH - 1) / LBS_FCH;         // frame chunks
-    const int grid = 8 * NCH * NVX * LBS_FCH;
+    int fch = LBS_FCH;
+    if (const char* es = getenv("MOSHII_LBS_FCH")) fch = std::max(1, atoi(es));
+    const int NCH = (NFT + fch - 1) / fch;         // frame chunks
+    const int grid = 8 * NCH * NVX * fch;
     const size_t lds = lbs_region_bytes(lm.KP, lm.K, nt, ksj);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto kern = (nt == 2) ? ((lm.NW == 4) ? k_lbs_mfma<4, 2, 0> : k_lbs_mfma<8, 2, 0>) : ((lm.NW == 4) ? k_lbs_mfma<4, 4, 0> : k_lbs_mfma<8, 4, 0>);
@@ -831,7 +835,8 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (nt == 2) ? 80 * 1024 : 160 * 1024);
     if (e != hipSuccess) return e;
     int dbg_stop = 0;
-    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg_stop = atoi(es);
+    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg_stop = atoi(es) & 255;
+    dbg_stop |= fch << 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, lm, md->V, F, NVT, NFT, NVX, verts, dbg_stop);
     return hipGetLastError();
 }
