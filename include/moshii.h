@@ -200,6 +200,13 @@ typedef struct moshii_sequence_desc {
     int32_t F;
     const double*  obs;             /* [F][M][3]                                                   */
     const uint8_t* vis;             /* [F][M]                                                      */
+    /* optional start state (host pointers; all NULL = the first-frame schedule of :629-655 on the first solved frame).
+     * With init_pose / init_trans the sequence CONTINUES a chain: warm start from that state, and -- when init_pose_prev
+     * is given too -- the velocity term from the first frame on (:624-626).  Used to shard one long sequence over
+     * several GPUs: a rank re-solves its frame range from its left neighbour's end state (moshpp_amd/parallel.py). */
+    const double*  init_pose;       /* [NP] or NULL                                                */
+    const double*  init_trans;      /* [3]  (required with init_pose)                              */
+    const double*  init_pose_prev;  /* [NP] or NULL                                                */
     double*  pose;                  /* outputs as in moshii_chain_desc, one row per input frame    */
     double*  fullpose;
     double*  trans;

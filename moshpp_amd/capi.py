@@ -52,6 +52,7 @@ class ChainDesc(C.Structure):
 
 class SequenceDesc(C.Structure):
     _fields_ = [('attach', C.c_void_p), ('F', C.c_int32), ('obs', C.c_void_p), ('vis', C.c_void_p),
+                ('init_pose', _c_double_p), ('init_trans', _c_double_p), ('init_pose_prev', _c_double_p),
                 ('pose', C.c_void_p), ('fullpose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p),
                 ('errs', C.c_void_p), ('iters', C.c_void_p), ('status', C.c_void_p)]
 
@@ -351,8 +352,9 @@ def plan_chunks(F, num_chunks, warmup, cap=1 << 20):
 
 
 def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, warmup=32, verify_tol=1e-11):
-    """moshii_sequence_solve on host buffers.  seqs: list of dict(attach, obs[F,M,3], vis[F,M]).
-    Returns (list of per-sequence output dicts as chain_solve_host, report dict)."""
+    """moshii_sequence_solve on host buffers.  seqs: list of dict(attach, obs[F,M,3], vis[F,M], init_pose=None,
+    init_trans=None, init_pose_prev=None) -- with init_* the sequence continues a chain from that state instead of running
+    the first-frame schedule.  Returns (list of per-sequence output dicts as chain_solve_host, report dict)."""
     lib = load()
     opts, _keep = opts_tuple
     n = len(seqs)
@@ -369,6 +371,10 @@ def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, war
         d = descs[i]
         d.attach = att.handle; d.F = F; d.obs = obs.ctypes.data; d.vis = vis.ctypes.data
         keep += [obs, vis]
+        for key in ('init_pose', 'init_trans', 'init_pose_prev'):
+            if sq.get(key) is not None:
+                a = _f64(sq[key]); keep.append(a)
+                setattr(d, key, _dp(a))
         for key in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status'):
             setattr(d, key, o[key].ctypes.data)
         outs.append(o)

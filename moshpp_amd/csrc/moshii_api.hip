@@ -997,7 +997,29 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     HIP_TRY(hipMalloc((void**)&d_entry, (size_t)NC * S * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&d_final, (size_t)NC * S * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&d_dev, (size_t)NC * sizeof(double)));
-    auto cleanup = [&]() { hipFree(d_entry); hipFree(d_final); hipFree(d_dev); };
+    // start states of sequences that continue a chain (moshii_sequence_desc.init_*): [pose][pose_prev][trans][has_prev][first = 0]
+    double* d_init = nullptr;
+    {
+        bool any = false;
+        for (int q = 0; q < n_seq; ++q) any |= seqs[q].init_pose != nullptr;
+        if (any) {
+            std::vector<double> hinit((size_t)n_seq * S, 0.0);
+            for (int q = 0; q < n_seq; ++q) {
+                const moshii_sequence_desc& sq = seqs[q];
+                if (!sq.init_pose) continue;
+                if (!sq.init_trans) { hipFree(d_entry); hipFree(d_final); hipFree(d_dev); return fail(MOSHII_ERR_ARG, "init_trans is required with init_pose"); }
+                double* h = hinit.data() + (size_t)q * S;
+                memcpy(h, sq.init_pose, sizeof(double) * NP);
+                if (sq.init_pose_prev) memcpy(h + NP, sq.init_pose_prev, sizeof(double) * NP);
+                memcpy(h + 2 * NP, sq.init_trans, sizeof(double) * 3);
+                h[2 * NP + 3] = sq.init_pose_prev ? 1.0 : 0.0;
+                h[2 * NP + 4] = 0.0;
+            }
+            HIP_TRY(hipMalloc((void**)&d_init, hinit.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(d_init, hinit.data(), hinit.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    auto cleanup = [&]() { hipFree(d_entry); hipFree(d_final); hipFree(d_dev); if (d_init) hipFree(d_init); };
     std::vector<Staged> st(dev ? 0 : n_seq);
     std::vector<FrameBufs> fbs(n_seq), dbs(n_seq);
     for (int q = 0; q < n_seq; ++q) {
@@ -1035,6 +1057,8 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         if (repair) {
             cd.init_state = d_final + (size_t)ck.pred * S;
             cd.rejoin_tol = rejoin ? tol : 0.0;
+        } else if (ck.pred < 0 && d_init != nullptr && seqs[ck.seq].init_pose != nullptr) {
+            cd.init_state = d_init + (size_t)ck.seq * S;   // the sequence continues a chain instead of starting one
         }
         return cd;
     };

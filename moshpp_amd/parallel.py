@@ -45,3 +45,93 @@ def run_sharded(units: Sequence, costs: Sequence[float], solve_local: Callable[[
             out[i] = res
     assert all(o is not None for o in out)
     return out
+
+
+def frame_ranges(F: int, world_size: int) -> List[tuple]:
+    """Contiguous frame ranges [a_r, b_r) of one sequence, one per rank (sizes differ by at most one frame)."""
+    base, extra = divmod(int(F), int(world_size))
+    out, a = [], 0
+    for r in range(world_size):
+        b = a + base + (1 if r < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+def solve_sequence_sharded(solve_range: Callable, F: int, dist=None, warmup: int = 32, verify_tol: float = 1e-9,
+                           max_rounds: int = None):
+    """ONE long sequence over the ranks of the process group: the frames of a sequence partitioned across the GPUs of a
+    node (BASELINE configs 2 / 5), stitched so that the result equals the sequential chain's to `verify_tol`.
+
+    It is the chunk scheme of moshii_sequence_solve one level up.  Rank r owns frames [a_r, b_r).
+      pass 1   rank r > 0 starts `warmup` frames early with the first-frame schedule (chmosh.py:629-655) and discards those
+               frames; rank 0 starts at frame 0 as the reference does.
+      verify   the chain state after frame t is (pose_t, pose_{t-1}, trans_t).  Rank r's warm-up rows at a_r - 1, a_r - 2 are
+               compared with rank r-1's rows for the same frames (one small all_gather of 2 NP + 3 doubles per rank).
+      repair   a rank whose left hand-off misses re-solves its range from rank r-1's end state (warm start + velocity term
+               exactly as :624-626, 656-657); repeated until every hand-off verifies (at most world_size - 1 rounds).
+    No collective on the data path: only the boundary rows travel.
+
+    solve_range(a, b, init) -> dict(pose[b-a, NP], trans[b-a, 3], ...per-frame arrays...) solves frames [a, b) on this
+    rank's GPU; init = None (first-frame schedule) or dict(pose, trans, pose_prev) to continue a chain.
+    Returns (out, info): `out` holds this rank's frames [a_r, b_r) (arrays sliced to the owned range), info =
+    dict(range=(a_r, b_r), rounds, repaired=[ranks re-solved per round], max_handoff_dev)."""
+    import numpy as np
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = solve_range(0, F, None)
+        return out, dict(range=(0, F), rounds=0, repaired=[], max_handoff_dev=0.0)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ranges = frame_ranges(F, world)
+    a, b = ranges[rank]
+    if min(e - s for s, e in ranges) < 2:
+        raise ValueError('solve_sequence_sharded needs at least two frames per rank')
+    lead = min(warmup, a) if rank > 0 else 0
+    full = solve_range(a - lead, b, None)                       # pass 1 (incl. the warm-up frames)
+
+    def cut(res, skip):
+        return {k: (v[skip:] if hasattr(v, 'shape') and len(v) == (b - a + skip) else v) for k, v in res.items()}
+
+    def edge(res, upto):
+        """Chain state after the last solved frame below local index `upto`: (pose, previous solved pose, trans), or None
+        when fewer than two frames were solved there (frames without markers leave their rows untouched, :586-588)."""
+        st = res.get('status')
+        ok = np.arange(upto) if st is None else np.flatnonzero(np.asarray(st[:upto]) != 1)
+        if len(ok) < 2:
+            return None
+        i, j = int(ok[-1]), int(ok[-2])
+        return np.concatenate([res['pose'][i], res['pose'][j], res['trans'][i]])
+
+    # the state with which this rank ENTERED its first owned frame (from its own warm-up), and the state it ends in
+    entry = edge(full, lead) if rank > 0 else None
+    out = cut(full, lead)
+    rounds, repaired, max_dev = 0, [], 0.0
+    max_rounds = world if max_rounds is None else max_rounds
+    while True:
+        final = edge(out, b - a)
+        finals = [None] * world
+        dist.all_gather_object(finals, final)
+        miss = False
+        if rank > 0:
+            left = finals[rank - 1]
+            if left is None:
+                raise RuntimeError('rank %d solved fewer than two frames: no state to hand over' % (rank - 1))
+            dev = float('inf') if entry is None else float(np.max(np.abs(entry - left)))
+            miss = not (dev <= verify_tol)
+            if not miss:
+                max_dev = max(max_dev, dev)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(miss))
+        if not any(flags):
+            break
+        if rounds >= max_rounds:
+            raise RuntimeError('sharded sequence solve did not converge: hand-offs still failing after %d rounds' % rounds)
+        repaired.append([r for r, f in enumerate(flags) if f])
+        if miss:   # re-solve the owned range from the left neighbour's end state
+            NP = out['pose'].shape[1]
+            init = dict(pose=left[:NP], pose_prev=left[NP:2 * NP], trans=left[2 * NP:])
+            out = solve_range(a, b, init)
+            entry = left.copy()
+        rounds += 1
+    devs = [None] * world
+    dist.all_gather_object(devs, max_dev)
+    return out, dict(range=(a, b), rounds=rounds, repaired=repaired, max_handoff_dev=float(max(devs)))

@@ -45,3 +45,74 @@ def test_two_rank_gloo_sharding(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / 'ok.npy')
+
+
+# ---- one sequence sharded over ranks by frame ranges (solve_sequence_sharded) ----------------------------------------
+def _toy_chain(obs, init, seed_state=None):
+    """A stand-in for the Stage-II chain with the same structure: the state after frame t depends on the observation and on
+    the two previous states (warm start + velocity term), contracts like the real chain (0.45 per frame), and a fresh start
+    lands in a WRONG basin for frames 95..140 (it stays there until the basins merge at frame 141)."""
+    F = len(obs)
+    pose = np.zeros((F, 4)); trans = np.zeros((F, 3))
+    if init is None:
+        p1 = np.zeros(4); p2 = np.zeros(4); fresh = True
+    else:
+        p1, p2, fresh = np.array(init['pose']), np.array(init['pose_prev']), False
+    wrong = False
+    for t in range(F):
+        g = obs[t]                                            # global frame number, doubles as the "observation"
+        target = np.array([np.sin(0.05 * g), np.cos(0.03 * g), 0.01 * g, 1.0])
+        if fresh and t == 0 and 95 <= g <= 140:
+            wrong = True
+        if g > 140:
+            wrong = False
+        basin = np.array([0.5, 0.0, 0.0, 0.0]) if wrong else 0.0
+        if fresh and t == 0:
+            p = target + basin + 0.03                         # first-frame schedule: close, not converged
+        else:
+            p = target + basin + 0.45 * ((p1 - (_tgt(g - 1) + (basin if not (fresh and t == 0) else 0))) ) + 0.0 * p2
+        pose[t] = p; trans[t] = p[:3] * 0.1
+        p2, p1 = p1, p
+    return dict(pose=pose, trans=trans, status=np.zeros(F, dtype=np.int32))
+
+
+def _tgt(g):
+    return np.array([np.sin(0.05 * g), np.cos(0.03 * g), 0.01 * g, 1.0])
+
+
+def _worker_frames(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from moshpp_amd.parallel import solve_sequence_sharded, frame_ranges
+    F = 240
+    calls = []
+
+    def solve_range(a, b, init):
+        calls.append((a, b, init is not None))
+        return _toy_chain(np.arange(a, b), init)
+
+    out, info = solve_sequence_sharded(solve_range, F, dist=dist, warmup=32, verify_tol=1e-9)
+    a, b = frame_ranges(F, world)[rank]
+    assert info['range'] == (a, b) and out['pose'].shape == (b - a, 4)
+    ref = _toy_chain(np.arange(0, F), None)                   # the sequential chain over the whole sequence
+    assert np.abs(out['pose'] - ref['pose'][a:b]).max() < 1e-8, np.abs(out['pose'] - ref['pose'][a:b]).max()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (calls, info))
+    if rank == 0:
+        # rank 1 owns [80, 160): its fresh start at frame 48 is fine, ... the start of rank 2 (frame 128) sits in the wrong
+        # basin -> exactly that rank is repaired, from its neighbour's end state
+        assert gathered[0][1]['repaired'] == [[2]], gathered[0][1]
+        assert gathered[2][0] == [(128, 240, False), (160, 240, True)]
+        assert gathered[1][0] == [(48, 160, False)]
+        np.save(os.path.join(outdir, 'ok_frames.npy'), np.array([1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_gloo_one_sequence_by_frame_ranges(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_frames, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert os.path.exists(tmp_path / 'ok_frames.npy')
