@@ -550,7 +550,6 @@ __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model 
         LBS_LDS_BARRIER();
 #pragma unroll
         for (int q = 0; q < 2 * 4; ++q) {   // q = 4 nt + fb: compile-time accumulator indices
-            constexpr int dummy = 0; (void)dummy;
             const int nt = q >> 2, fb = q & 3;
             if (q + 1 < 8) fetch(q + 1);
             float ox[4], oy[4], oz[4];
