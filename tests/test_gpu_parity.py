@@ -439,3 +439,23 @@ def test_lbs_f32_dense_blend_variant_matches_f64(gpu_lib, model_type, F):
             assert np.abs(got - ref).max() < 2e-5
     finally:
         del os.environ['MOSHII_LBS_BLEND']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,mt,kind,E,F,M,seed', [('smplx_expr5_6f', 'smplx', 'expr', 5, 6, 40, 31),
+                                                       ('smplh_dmpl4_6f', 'smplh', 'dmpl', 4, 6, 40, 32)])
+def test_gpu_matches_committed_shape_goldens(gpu_lib, name, mt, kind, E, F, M, seed):
+    """The extended kernel variant against the committed fixtures (tests/golden/oracle_golden.npz), not a live oracle run."""
+    import os
+    from moshpp_amd import capi
+    from tests.helpers import shape_case
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_golden.npz'))
+    case = shape_case(mt, F=F, M=M, E=E, seed=seed, kind=kind)
+    dev = device_case(case, optimize_face=kind == 'expr', shape_kind=kind)
+    out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+    assert np.abs(out['fullpose'] - g[f'{name}/fullpose']).max() < TIGHT
+    assert np.abs(out['trans'] - g[f'{name}/trans']).max() < TIGHT
+    assert np.abs(out['shape'] - g[f'{name}/shape']).max() < 1e-6
+    np.testing.assert_array_equal(out['iters'][:, 0], g[f'{name}/iters'])
+    np.testing.assert_allclose(out['errs'][:, 5], g[f'{name}/err_shape'], rtol=1e-6)

@@ -176,3 +176,19 @@ def test_free_shape_block_jacobian_and_chain(model_type, kind):
         assert len(res['errs']['shape_stay']) == 4      # from the second solved frame on
     if face:
         assert np.abs(res['pose'][:, 66:69]).max() > 1e-3   # the jaw is free (weakly observed by this layout)
+
+
+@pytest.mark.parametrize('name,mt,kind,E,F,M,seed', [('smplx_expr5_6f', 'smplx', 'expr', 5, 6, 40, 31),
+                                                       ('smplh_dmpl4_6f', 'smplh', 'dmpl', 4, 6, 40, 32)])
+def test_oracle_reproduces_committed_shape_goldens(name, mt, kind, E, F, M, seed):
+    """The Step-2 extras (jaw + expression, DMPL) frozen in tests/golden/oracle_golden.npz: later edits of the oracle or of the
+    synthetic generators cannot silently move this parity target either."""
+    from tests.helpers import shape_case
+    g = np.load(GOLDEN)
+    case = shape_case(mt, F=F, M=M, E=E, seed=seed, kind=kind)
+    assert np.allclose(g[f'{name}/obs_checksum'], [case['obs'].sum(), case['vis'].sum(), case['coef'].sum()], rtol=1e-12)
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], mt,
+                           optimize_face=kind == 'expr', free_shape=kind)
+    assert np.abs(ref['fullpose'] - g[f'{name}/fullpose']).max() < 1e-9
+    assert np.abs(ref['shape'] - g[f'{name}/shape']).max() < 1e-9
+    np.testing.assert_array_equal(ref['iters'], g[f'{name}/iters'])
