@@ -222,3 +222,34 @@ def test_face_and_dmpl_host_pieces(tmp_path):
     np.savez(tmp_path / 'd.npz', eigvec=ev)
     for src in (str(tmp_path / 'd.pkl'), str(tmp_path / 'd.npz'), {'eigvec': ev}):
         assert np.array_equal(read_dmpl_pcs(src), ev)
+
+
+def test_c3d_roundtrip_property_over_every_variant(tmp_path):
+    """Property test (hypothesis): any small point cloud with NaN drop-outs survives write -> read in every on-disk variant
+    (Intel / MIPS / DEC floats, Intel / MIPS scaled int16): same invalid mask, coordinates to format precision, labels."""
+    from hypothesis import given, settings, strategies as st
+    from moshpp_amd import c3d_io
+    counter = [0]
+
+    @settings(max_examples=40, deadline=None)
+    @given(F=st.integers(1, 4), N=st.integers(1, 9), seed=st.integers(0, 10 ** 6),
+           proc=st.sampled_from([c3d_io.PROC_INTEL, c3d_io.PROC_MIPS, c3d_io.PROC_DEC]),
+           int_scale=st.sampled_from([None, None, 0.05, 0.25]), rate=st.sampled_from([60.0, 100.0, 120.0, 239.76]))
+    def run(F, N, seed, proc, int_scale, rate):
+        if proc == c3d_io.PROC_DEC and int_scale is not None:
+            int_scale = None                                    # (DEC + int is legal; the int path is endian-only)
+        rng = np.random.default_rng(seed)
+        pts = rng.normal(0, 500, (F, N, 3))
+        pts[rng.random((F, N)) < 0.2] = np.nan
+        labels = [f'L{seed % 7}_{i}' for i in range(N)]
+        counter[0] += 1
+        fn = str(tmp_path / f'p{counter[0]}.c3d')
+        c3d_io.write_c3d(fn, pts, labels, frame_rate=rate, processor=proc, int_scale=int_scale)
+        d = c3d_io.read_c3d(fn)
+        assert d['labels'] == labels and abs(d['frame_rate'] - rate) < 1e-3
+        inv = np.isnan(pts).any(-1)
+        assert np.array_equal(np.isnan(d['points']).any(-1), inv)
+        tol = (int_scale * 0.5 + 1e-3) if int_scale else 1e-3
+        assert np.abs(d['points'][~inv] - pts[~inv]).max(initial=0.0) <= tol
+
+    run()
