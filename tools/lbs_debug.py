@@ -34,4 +34,3 @@ for spec in sys.argv[1:] or ['smplx:150']:
         print('bad v%32 histogram:', np.bincount(vs % 32, minlength=32).tolist())
     del dev, case
     gc.collect()
-    # (appended diagnostics, last model only)
