@@ -873,6 +873,10 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     const int tid = threadIdx.x;
     const int LDJ = ly.LDJ, Tm = ly.Tm, NW = at.NW, Nvp = at.Nvp, bd = md.body_dof, nhf = md.nhand_full;
     const int nshp = XT ? n - ncp : 0;
+    // per-vertex strides of the tile tables xjs / tjs: 4 NW + 2 doubles and NW + 1 ints.  With the dense strides (16 NW bytes) the
+    // T1 items of a wavefront -- consecutive tile markers, 3 vertices apart -- fell onto two bank groups (PMC: 30 % of the kernel's
+    // LDS-active cycles were bank conflicts); an odd number of 16-byte units per marker spreads them over all banks.
+    const int XS = NW * 4 + 2, TS = NW + 1;
     PROF_BEGIN(); PROF_COUNT(21);
     A.zero();
     for (int q = tid; q < n; q += MOSHII_TPB) cx.g[q] = 0.0;
@@ -956,11 +960,11 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const double w = at.ww[av * NW + s];
                 double ox, oy, oz;
                 mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
-                cx.xjs[(tid * NW + s) * 4 + 0] = ox + cx.tw[j * 3 + 0];
-                cx.xjs[(tid * NW + s) * 4 + 1] = oy + cx.tw[j * 3 + 1];
-                cx.xjs[(tid * NW + s) * 4 + 2] = oz + cx.tw[j * 3 + 2];
-                cx.xjs[(tid * NW + s) * 4 + 3] = w;
-                cx.tjs[tid * NW + s] = j;
+                cx.xjs[tid * XS + s * 4 + 0] = ox + cx.tw[j * 3 + 0];
+                cx.xjs[tid * XS + s * 4 + 1] = oy + cx.tw[j * 3 + 1];
+                cx.xjs[tid * XS + s * 4 + 2] = oz + cx.tw[j * 3 + 2];
+                cx.xjs[tid * XS + s * 4 + 3] = w;
+                cx.tjs[tid * TS + s] = j;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) Tr[e] += w * cx.Rw[j * 9 + e];
             }
@@ -1014,8 +1018,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const int al = 3 * ml + sv, av = 3 * m + sv;
                 double ax = 0.0, ay = 0.0, az = 0.0;
                 for (int s2 = 0; s2 < NW; ++s2) {   // joints of this vertex inside the subtree of k (branch-free: weight 0 otherwise)
-                    const int j = cx.tjs[al * NW + s2];
-                    const double2* xw = reinterpret_cast<const double2*>(&cx.xjs[(al * NW + s2) * 4]);
+                    const int j = cx.tjs[al * TS + s2];
+                    const double2* xw = reinterpret_cast<const double2*>(&cx.xjs[al * XS + s2 * 4]);
                     const double2 xy = xw[0], zw = xw[1];   // two 16-byte reads; the weight rides with z, so it cannot be sunk into a branch
                     const double w = ((mask >> j) & 1ull) ? zw.y : 0.0;
                     ax += w * (xy.x - tkx);
@@ -1104,8 +1108,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                         double dy = Tr[3] * sx + Tr[4] * sy + Tr[5] * sz;
                         double dz = Tr[6] * sx + Tr[7] * sy + Tr[8] * sz;
                         for (int s2 = 0; s2 < NW; ++s2) {
-                            const int j = cx.tjs[al * NW + s2];
-                            const double w = cx.xjs[(al * NW + s2) * 4 + 3];
+                            const int j = cx.tjs[al * TS + s2];
+                            const double w = cx.xjs[al * XS + s2 * 4 + 3];
                             const double* qq = qv + ((size_t)j * nshp + e) * 3;
                             dx += w * qq[0]; dy += w * qq[1]; dz += w * qq[2];
                         }

@@ -301,8 +301,8 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     int t = 0;
     auto ttake = [&](int nd) { int o = t; t += (nd + 1) & ~1; return o; };
     ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 30);
-    ly.t_Trot = ttake(3 * Tm * 10); ly.t_xjs = ttake(3 * Tm * NWmax * 4); ly.t_rest = ttake(3 * Tm);
-    ly.t_tjs = ttake((3 * Tm * NWmax + 1) / 2);
+    ly.t_Trot = ttake(3 * Tm * 10); ly.t_xjs = ttake(3 * Tm * (NWmax * 4 + 2)); ly.t_rest = ttake(3 * Tm);   // (strides: assemble())
+    ly.t_tjs = ttake((3 * Tm * (NWmax + 1) + 1) / 2);
     // packed factor + trash / zero words + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
     // the factor lives in global scratch and LDS keeps the broadcast buffer plus a 16-row panel
     const int chol = (nblk > 8) ? 2 + 4 * LDJ + 16 * LDJ + 4 : (nmax + 1) * (nmax + 2) / 2 + 2 + 4 * LDJ + 4;
