@@ -1095,7 +1095,11 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         std::vector<char> todo_gross;
         {
             const double gross_dev = 1e-6;
-            int seq = -1;
+            // ... except when the slight miss lies far (>= far_frames) behind the start of the gross chain whose span it is in:
+            // gross chains re-join within ~140 frames on every sequence looked at, so such a chunk is repaired right away and
+            // bounds that chain (should the chain ever get there, the next round continues it).
+            static const int far_frames = []{ const char* e = getenv("MOSHII_FAR_FRAMES"); return e ? atoi(e) : 160; }();
+            int seq = -1, span_start = 0;
             bool in_span = false;
             for (int c = 0; c < NC; ++c) {
                 if (chunks[c].seq != seq) { seq = chunks[c].seq; in_span = false; }
@@ -1103,8 +1107,8 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                 const int p = chunks[c].pred;
                 const bool g = rejoin && hdev[c] > gross_dev, pg = rejoin && failing[p] && hdev[p] > gross_dev;
                 if (!rejoin) { if (!failing[p]) { todo.push_back(c); todo_gross.push_back(0); } continue; }
-                if (g) { if (!pg) { todo.push_back(c); todo_gross.push_back(1); in_span = true; } }
-                else if (!in_span) { todo.push_back(c); todo_gross.push_back(0); }
+                if (g) { if (!pg) { todo.push_back(c); todo_gross.push_back(1); in_span = true; span_start = chunks[c].s; } }
+                else if (!in_span || (far_frames > 0 && chunks[c].s - span_start >= far_frames && !failing[p])) { todo.push_back(c); todo_gross.push_back(0); }
             }
         }
         if (todo.empty()) break;
