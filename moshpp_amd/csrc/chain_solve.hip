@@ -1663,12 +1663,10 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         const bool same_sets = op.same_sets != 0;
         double prev_wt_pose = -1.0;
         int prev_terms = -1;
-        const bool lite = chp->first == 2;   // warm-up start of a chunk (not the sequence's first frame): rigid init + ONE round
         for (int kind = first ? 0 : 3; kind < 6; ++kind) {
             const bool round = kind < 3;
             const bool step2 = kind == 4;
-            if (lite && (kind == 1 || kind == 2)) continue;
-            fp.wt_pose = round ? ((kind == 0) ? (lite ? 1.0 : 10.0) : (kind == 1) ? 5.0 : 1.0) * wt_pose : wt_pose;
+            fp.wt_pose = round ? ((kind == 0) ? 10.0 : (kind == 1) ? 5.0 : 1.0) * wt_pose : wt_pose;
             fp.use_fingers = (kind >= 4 && op.nfinger > 0) ? 1 : 0;
             if constexpr (XT) {
                 fp.use_face = (kind >= 4 && op.nface > 0) ? 1 : 0;

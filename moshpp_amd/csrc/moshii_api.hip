@@ -1033,7 +1033,6 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             dbs[q].msim = s.msim; dbs[q].errs = s.errs; dbs[q].iters = s.iters; dbs[q].status = s.status;
         }
     }
-    static const bool lite_warmup = []{ const char* e = getenv("MOSHII_LITE_WARMUP"); return e ? atoi(e) != 0 : false; }();
     auto make_chain = [&](const Chunk& ck, int from, int idx, bool repair) {
         // a chain over frames [from, ck.e) of its sequence; rows are addressed relative to `from`
         const FrameBufs& b = dbs[ck.seq];
@@ -1041,7 +1040,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         ChainDev cd;
         memset(&cd, 0, sizeof(cd));
         cd.att = seqs[ck.seq].attach->d_self;
-        cd.F = ck.e - from; cd.first = (lite_warmup && ck.pred >= 0) ? 2 : 1; cd.skip = ck.s - from;
+        cd.F = ck.e - from; cd.first = 1; cd.skip = ck.s - from;
         cd.obs = b.obs + (size_t)from * M * 3; cd.vis = b.vis + (size_t)from * M;
         cd.pose = b.pose ? b.pose + (size_t)from * NP : nullptr;
         cd.fullpose = b.fullpose ? b.fullpose + (size_t)from * P : nullptr;
