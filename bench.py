@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=400, help='frames of the workload timed on the CPU oracle')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
+    ap.add_argument('--spread-seeds', default='5,71', help='extra leg: the same workload generated from these seeds ("" to skip)')
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
     ap.add_argument('--many', type=int, default=32, help='extra leg: this many copies of the sequence in one call (0: skip)')
     args = ap.parse_args()
@@ -218,6 +219,29 @@ def main():
                 del copies
             except Exception as e:
                 result['many_sequences'] = {'error': repr(e)}
+        # ---- the same workload from other seeds: the chunk-repair pattern depends on the motion (how long the regions are in
+        # which a fresh start sits in another basin), so the headline seed is not the whole story
+        if args.mode == 'chunked' and args.spread_seeds:
+            spread = {}
+            try:
+                for sd in [int(x) for x in args.spread_seeds.split(',') if x.strip()]:
+                    job2 = workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=sd)
+                    solver2 = workload.make_solver(job2)
+                    ds2 = workload.DeviceSequence(job2, solver2, dev)
+                    stream2 = torch.cuda.current_stream().cuda_stream
+                    ds2.solve_chunked(stream2, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol)
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    rep2 = ds2.solve_chunked(stream2, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol)
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t2
+                    n2 = int((ds2.results()['status'] != 1).sum())
+                    spread[str(sd)] = {'frames_per_s': round(n2 / dt2, 1), 'ms_per_step': round(dt2 * 1e3, 2),
+                                       'n_repaired': rep2['n_repaired'], 'repair_rounds': rep2['repair_rounds']}
+                    del ds2, solver2, job2
+                result['other_seeds'] = spread
+            except Exception as e:
+                result['other_seeds'] = {'error': repr(e)}
         # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names)
         try:
             import ctypes as C
