@@ -253,3 +253,30 @@ def test_c3d_roundtrip_property_over_every_variant(tmp_path):
         assert np.abs(d['points'][~inv] - pts[~inv]).max(initial=0.0) <= tol
 
     run()
+
+
+def test_frame_ranges_and_single_rank_sharded_solve():
+    """frame_ranges partitions [0, F) into contiguous near-equal ranges; without a process group solve_sequence_sharded is one call
+    over the whole sequence with the first-frame schedule."""
+    from hypothesis import given, settings, strategies as st
+    from moshpp_amd.parallel import frame_ranges, solve_sequence_sharded
+
+    @settings(max_examples=60, deadline=None)
+    @given(F=st.integers(1, 100000), world=st.integers(1, 16))
+    def prop(F, world):
+        r = frame_ranges(F, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == F
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(sizes) <= 1 and all(s >= 0 for s in sizes)
+
+    prop()
+    calls = []
+
+    def solve_range(a, b, init):
+        calls.append((a, b, init))
+        return dict(pose=np.zeros((b - a, 5)), trans=np.zeros((b - a, 3)), status=np.zeros(b - a, dtype=np.int32))
+
+    out, info = solve_sequence_sharded(solve_range, 37, dist=None)
+    assert calls == [(0, 37, None)] and out['pose'].shape == (37, 5)
+    assert info == dict(range=(0, 37), rounds=0, repaired=[], max_handoff_dev=0.0)
