@@ -16,15 +16,10 @@ import logging
 import numpy as np
 
 from . import capi
-from .mocap_interface import MocapSession
+from .mocap_interface import MocapSession, general_labels_map   # (the alias table of chmosh.py:466: moshpp_amd/data/label_aliases.json)
 from .models import load_surface_model
 from .prior import create_gmm_body_prior
 from .transformed_lm import TransformedCoeffs
-
-try:   # present when this package is injected into a reference installation
-    from moshpp.marker_layout.labels_map import general_labels_map   # type: ignore
-except Exception:   # pragma: no cover - the alias table is reference data, not part of this package
-    general_labels_map = {}
 
 logger = logging.getLogger('moshpp_amd')
 

@@ -106,7 +106,11 @@ def read_mocap(mocap_fname):
     markers = np.array(markers, dtype=np.float64)
     n = markers.shape[1]
     labels = [] if labels is None else [l.decode() if isinstance(l, bytes) else str(l) for l in labels]
-    labels += [f'*{i}' for i in range(len(labels), n)]   # unnamed trailing points
+    # unnamed trailing points: '*k' -- as the reference numbers them: a c3d file continues at the point index
+    # (mocap_interface.py:126-127), every other format restarts at 0 (:145-146); a missing label list names all points '*i' (:143-144)
+    if len(labels) < n:
+        first = len(labels) if (ext == '.c3d' or not labels) else 0
+        labels += [f'*{first + i}' for i in range(n - len(labels))]
     subjects = [l.split(':')[0] if ':' in l else 'null' for l in labels]
     subject_mask = OrderedDict()
     for s in subjects:
@@ -116,6 +120,19 @@ def read_mocap(mocap_fname):
         rate = float(np.asarray(rate).ravel()[0])
     return {'markers': markers, 'labels': labels, 'frame_rate': rate, '_marker_data': raw,
             'subject_mask': dict(subject_mask)}
+
+
+def _load_label_aliases():
+    """The reference's marker-label alias table (vendor / lab spellings -> canonical layout labels), applied on ingest via
+    `labels_map=general_labels_map` (chmosh.py:466, mocap_interface.py:195-201).  Data file made by tools/make_label_aliases.py."""
+    import json
+    import os
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'label_aliases.json')
+    with open(fn) as fh:
+        return json.load(fh)
+
+
+general_labels_map = _load_label_aliases()
 
 
 class MocapSession(object):

@@ -72,3 +72,30 @@ def prior_inputs():
 def rigid_inputs():
     z = _small()
     return list(zip(z['rigid_a'], z['rigid_b']))
+
+
+def mocap_inputs(outdir):
+    """Mocap files (npz / pkl) exercising the label and validity rules of MocapSession, plus the constructor arguments.
+    The files are written next to the fixtures (tiny) so that the tests read exactly what the reference class read."""
+    import pickle
+    rng = np.random.default_rng(777)
+    F, N = 5, 9
+    mk = rng.normal(0, 800, (F, N, 3))
+    mk[1, 2] = np.nan                     # NaN sample
+    mk[2, 4] = 0.0                        # all-zero sample = invalid (mocap_interface.py:275-279)
+    mk[3, 5, 1] = 0.0                     # one zero coordinate is still a valid sample
+    labels = ['subjA:LFHD', 'subjA:R SHO', '*7', 'subjA:C7', 'subjB:LFHD', 'subjB:RTOE', 'STRN ', 'subjA:T10', '*12']
+    f_npz = os.path.join(outdir, 'mocap_case.npz')
+    if not os.path.exists(f_npz):
+        np.savez(f_npz, markers=mk, labels=np.array(labels), frame_rate=100.0)
+    f_pkl = os.path.join(outdir, 'mocap_case.pkl')
+    if not os.path.exists(f_pkl):
+        with open(f_pkl, 'wb') as fh:
+            pickle.dump({'markers': mk, 'labels': labels[:7], 'required_parameters': {'frame_rate': 60.0}}, fh, protocol=2)
+    return {
+        'plain': (f_npz, dict(mocap_unit='mm')),
+        'subject': (f_npz, dict(mocap_unit='mm', only_subjects=['subjA'])),
+        'exclude': (f_npz, dict(mocap_unit='cm', exclude_markers=['C7', 'RTOE'], use_labels_map=True)),
+        'only': (f_npz, dict(mocap_unit='m', only_markers=['LFHD', 'STRN'])),
+        'pkl_short_labels': (f_pkl, dict(mocap_unit='mm', ignore_stared_labels=False)),
+    }

@@ -84,3 +84,24 @@ def test_amass_part_split_matches_reference_function(mt, P):
     for k, v in parts.items():
         assert v.shape[0] == 3
         assert np.array_equal(v[0].astype(np.int64), G[f'parts_{mt}_{k}'])
+
+
+@pytest.mark.parametrize('case', ['plain', 'subject', 'exclude', 'only', 'pkl_short_labels'])
+def test_mocap_session_matches_reference_class(case):
+    """MocapSession against the reference's own class (tools/mocap_interface.py:87-279) executed on the same
+    npz / pkl files: label clean-up (spaces, subject prefix, labels_map), starred / excluded / only_markers filtering, subject
+    selection, the invalid-sample rule (NaN or all-zero), unit scaling, frame rate, per-frame marker presence."""
+    from moshpp_amd.mocap_interface import MocapSession
+    from moshpp_amd import mocap_interface as mi
+    fname, kw = ref_inputs.mocap_inputs(os.path.join(os.path.dirname(__file__), 'golden'))[case]
+    kw = dict(kw)
+    if kw.pop('use_labels_map', False):
+        kw['labels_map'] = mi.general_labels_map
+    ms = MocapSession(fname, **kw)
+    assert list(ms.labels) == [str(x) for x in G[f'mocap_{case}_labels']]
+    ref_mk = G[f'mocap_{case}_markers']
+    assert ms.markers.shape == ref_mk.shape and np.array_equal(np.asarray(ms.markers), ref_mk)
+    assert float(ms.frame_rate) == float(G[f'mocap_{case}_rate'])
+    assert bool(ms.multi_subject) == bool(G[f'mocap_{case}_multi'])
+    present = np.array([[l in fr for l in ms.labels] for fr in ms.markers_asdict()])
+    assert np.array_equal(present, G[f'mocap_{case}_present'])
