@@ -16,7 +16,9 @@ scripts under tests/golden/, checked by tests/test_ref_golden.py and tests/test_
     incl. the sklearn kd-tree 8-NN and the SMPL-X eyeball exclusion)
   * prepare_gmm_prior / gmm_prior_eval       <- create_gmm_body_prior + MaxMixtureComplete values (gmm_prior_ch.py:42-134)
   * rigid_landmark_transform                 <- rigid_transformations.py:39-69
-  * (host package) C3D reader                <- the reference's vendored py-c3d writer (tools/c3d.py)
+  * (host package) C3D reader / writer       <- the reference's vendored py-c3d writer and reader (tools/c3d.py)
+  * (host package) MocapSession, load_surface_model, AMASS part split <- the reference's own class / functions
+    (tools/mocap_interface.py:87-279, models/smpl_fast_derivatives.py:52-150, tools/run_tools.py:70-85)
 UNPINNED (third-party code absent): the SMPL forward + its pose Jacobian, the node Jacobians, and
 `minimize_dogleg`.  These restate the *published* algorithms (SMPL's public `lbs.py`/`posemapper.py`/
 `verts.py`, chumpy's `optimization_internal.py`), anchored on the reference's call sites and validated by

@@ -99,3 +99,31 @@ def mocap_inputs(outdir):
         'only': (f_npz, dict(mocap_unit='m', only_markers=['LFHD', 'STRN'])),
         'pkl_short_labels': (f_pkl, dict(mocap_unit='mm', ignore_stared_labels=False)),
     }
+
+
+def tiny_model_dict(model_type, seed=0, V=24):
+    """A tiny model pickle dict with the exact joint counts of the type (the loaders infer the type from posedirs.shape[2] // 3)."""
+    import scipy.sparse as sp
+    from moshpp_amd import synth
+    K = synth.MODEL_DIMS[model_type][1]
+    rng = np.random.default_rng(seed + 31)
+    parents = synth.kintree_parents(model_type)
+    kt = np.vstack([np.where(np.asarray(parents) < 0, 4294967295, parents), np.arange(K)]).astype(np.int64)
+    w = rng.random((V, K)); w /= w.sum(1, keepdims=True)
+    jr = rng.random((K, V)); jr /= jr.sum(1, keepdims=True)
+    d = dict(v_template=rng.normal(0, 0.3, (V, 3)), shapedirs=rng.normal(0, 0.01, (V, 3, 5)),
+             posedirs=rng.normal(0, 0.001, (V, 3, 9 * (K - 1))), weights=w, J_regressor=sp.csc_matrix(jr),
+             kintree_table=kt, f=np.zeros((1, 3), dtype=np.int64), bs_style='lbs', bs_type='lrotmin')
+    if model_type == 'mano':
+        d['hands_components'] = np.linalg.qr(rng.normal(0, 1, (45, 45)))[0]
+        d['hands_mean'] = rng.normal(0, 0.1, 45)
+    return d
+
+
+def hand_prior_dict(seed=0):
+    from moshpp_amd import synth
+    return synth.synth_hand_prior(seed)
+
+
+MODEL_LOAD_CASES = [('smpl', False, 12), ('smplh', True, 12), ('smplh', False, 24), ('smplx', True, 6), ('mano', True, 9),
+                    ('mano', False, 15)]   # (type, use_hands_mean, dof_per_hand)

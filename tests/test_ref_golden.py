@@ -105,3 +105,27 @@ def test_mocap_session_matches_reference_class(case):
     assert bool(ms.multi_subject) == bool(G[f'mocap_{case}_multi'])
     present = np.array([[l in fr for l in ms.labels] for fr in ms.markers_asdict()])
     assert np.array_equal(present, G[f'mocap_{case}_present'])
+
+
+@pytest.mark.parametrize('mt,uhm,dph', ref_inputs.MODEL_LOAD_CASES)
+def test_model_loader_layout_matches_reference_function(tmp_path, mt, uhm, dph):
+    """load_surface_model (models.py) against the reference's own function (smpl_fast_derivatives.py:52-150, executed up to the
+    SmplModelLBS construction): model-type inference from posedirs, pose_body_dof / pose_hand_dof, pose-variable count,
+    the block-diagonal hand-PCA map and hands_mean incl. the `use_hands_mean` semantics (inverted for MANO, :114)."""
+    import pickle
+    from moshpp_amd.models import load_surface_model
+    mf = tmp_path / f'{mt}.pkl'
+    with open(mf, 'wb') as fh:
+        pickle.dump(ref_inputs.tiny_model_dict(mt), fh, protocol=2)
+    hp = tmp_path / 'hand_prior.npz'
+    np.savez(hp, **ref_inputs.hand_prior_dict(0))
+    sm = load_surface_model(str(mf), pose_hand_prior_fname=str(hp), use_hands_mean=uhm, dof_per_hand=dph)
+    tag = f'model_{mt}_{int(uhm)}_{dph}'
+    assert sm.model_type == str(G[f'{tag}_type'])
+    assert sm.NP == int(G[f'{tag}_pose_var_size'])
+    assert sm.body_dof == int(G[f'{tag}_body_dof']) and sm.hand_dof == int(G[f'{tag}_hand_dof'])
+    if f'{tag}_selected_components' in G.files:
+        assert np.array_equal(sm.selected_components, G[f'{tag}_selected_components'])
+        assert np.array_equal(sm.hands_mean, G[f'{tag}_hands_mean'])
+    else:
+        assert sm.hand_dof == 0
