@@ -127,3 +127,26 @@ def hand_prior_dict(seed=0):
 
 MODEL_LOAD_CASES = [('smpl', False, 12), ('smplh', True, 12), ('smplh', False, 24), ('smplx', True, 6), ('mano', True, 9),
                     ('mano', False, 15)]   # (type, use_hands_mean, dof_per_hand)
+
+
+def amass_inputs():
+    """Stage-II result dicts (as MoSh.mosh_stageii pickles them) + keyword arguments for load_as_amass_npz."""
+    def pkl(mt, P, face=False, betas=True, T=4):
+        rng = np.random.default_rng(P)
+        cfg = {'surface_model': {'gender': 'male', 'type': mt, 'fname': '/m/model.pkl', 'num_betas': 10, 'num_dmpls': 8,
+                                 'num_expressions': 5},
+               'moshpp': {'optimize_betas': betas, 'optimize_dynamics': False, 'optimize_face': face}}
+        d = {'fullpose': rng.normal(0, 1, (T, P)), 'trans': rng.normal(0, 1, (T, 3)), 'betas': np.arange(16.0),
+             'markers_latent': rng.normal(0, 1, (6, 3)), 'latent_labels': [f'L{i}' for i in range(6)],
+             'markers_latent_vids': {f'L{i}': i for i in range(6)}, 'marker_meta': {'marker_type': {}},
+             'stagei_debug_details': {'v_template': np.ones((3, 3))} if betas else {},
+             'stageii_debug_details': {'cfg': cfg, 'mocap_frame_rate': 120.0, 'mocap_time_length': T / 120.0,
+                                       'markers_orig': np.zeros((T, 7, 3)), 'labels_orig': list('abcdefg'),
+                                       'markers_obs': [np.zeros((5, 3))] * T, 'labels_obs': [['L0']] * T,
+                                       'markers_sim': [np.zeros((5, 3))] * T}}
+        if face:
+            d['expression'] = rng.normal(0, 1, (T, 100))
+        return d
+    return {'smplh': (pkl('smplh', 156), dict(include_markers=True, include_extra_details=True)),
+            'smplx_face': (pkl('smplx', 165, face=True), dict()),
+            'mano_nobetas': (pkl('mano', 48, betas=False), dict(include_markers=False))}

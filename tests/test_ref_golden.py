@@ -129,3 +129,18 @@ def test_model_loader_layout_matches_reference_function(tmp_path, mt, uhm, dph):
         assert np.array_equal(sm.hands_mean, G[f'{tag}_hands_mean'])
     else:
         assert sm.hand_dof == 0
+
+
+@pytest.mark.parametrize('case', ['smplh', 'smplx_face', 'mano_nobetas'])
+def test_amass_export_matches_reference_method(case):
+    """moshpp_amd.mosh_head.load_as_amass_npz against the reference's MoSh.load_as_amass_npz (mosh_head.py:444-541), whose source
+    was executed on the same stage-II dicts when the fixture was made: same keys, same arrays."""
+    from moshpp_amd.mosh_head import load_as_amass_npz
+    pkl, kw = ref_inputs.amass_inputs()[case]
+    res = load_as_amass_npz(pkl, **kw)
+    assert sorted(res) == [str(k) for k in G[f'amass_{case}_keys']]
+    for k in ('poses', 'trans', 'root_orient', 'pose_body', 'pose_hand', 'pose_jaw', 'pose_eye', 'betas', 'expression'):
+        if f'amass_{case}_{k}' in G.files:
+            assert np.array_equal(np.asarray(res[k]), G[f'amass_{case}_{k}']), k
+        else:
+            assert k not in res
