@@ -33,6 +33,7 @@ typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact 
 #define MOSHII_ERR_HIP         -2
 #define MOSHII_ERR_UNSUPPORTED -3
 #define MOSHII_ERR_NO_DEVICE   -4
+#define MOSHII_ERR_NUMERIC     -5
 
 /* flags for moshii_chain_solve / moshii_lbs_forward_* : where the big per-frame buffers live */
 #define MOSHII_BUFFERS_HOST    0u   /* obs/vis/outputs are host pointers (library stages them)     */
@@ -236,6 +237,51 @@ int moshii_plan_chunks(int32_t F, int32_t num_chunks, int32_t warmup, int32_t ca
 int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* opts, int32_t n_seq,
                           const moshii_sequence_desc* seqs, const moshii_chunk_opts* chunk_opts /* NULL: defaults */,
                           uint32_t flags, void* stream, moshii_chunk_report* report /* may be NULL */);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage-I: subject shape + latent marker placement from a handful of picked frames.  Replaces the numeric core of
+ * mosh_stagei (src/moshpp/chmosh.py:177-447): prepare_mosh_markers_latent (:57-80), the per-frame rigid start
+ * (:236-238), the annealing rounds of one dogleg each over [trans_f, markers_latent, pose_f[ids], betas[:nb]]
+ * (:313-415) with the terms data / poseB / init_* / beta / surf (+ poseH in the last two rounds), and the outputs of
+ * :417-447.  The marker attachment (TransformedCoeffs, transformed_lm.py:59-113) is re-evaluated at every evaluation
+ * point, as the reference's dependency graph does.  All buffers are HOST pointers (the problem is a few kilobytes);
+ * the model's own betas (moshii_model_set_betas) are ignored: the solve works on v_template + shapedirs[:, :, :nb].betas.
+ * Not covered: head-marker correlation term (:252-266), per-frame expressions (optimize_face).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct moshii_stagei_desc {
+    int32_t n_frames, M, n_faces, nb;       /* picked frames, latent markers, triangles, free betas             */
+    const int32_t* faces;                   /* [n_faces][3] surface triangles (can_model.f)                      */
+    const int32_t* marker_vids;             /* [M] marker_meta['marker_vids'] values                             */
+    const double*  m2b;                     /* [M] distance from skin per marker (m2b_distance by type, :62-64)  */
+    const double*  wt_init;                 /* [M] stagei_wt_init[_type] per marker, before annealing (:327-328) */
+    const int32_t* n_obs;                   /* [n_frames] observed latent markers per frame                      */
+    const int32_t* obs_ids;                 /* [sum n_obs] their latent ids (common_labels, :199-206)            */
+    const double*  obs;                     /* [sum n_obs][3] metres                                             */
+    const int32_t* exclude_vids;            /* vertices the attachment may not use (SMPL-X eyeballs) or NULL     */
+    int32_t        n_exclude;
+    const double*  betas_init;              /* [nb] or NULL (zeros)                                              */
+    double wt_data, wt_poseB, wt_poseH, wt_betas, wt_surf;   /* stagei_wt_* (moshpp_conf.yaml:103-116)           */
+    const double*  annealing;               /* [n_anneal] stagei_wt_annealing                                    */
+    int32_t        n_anneal;
+    const int32_t* pose_ids;                /* root + body (- toes) pose variables free in every round (:384-388) */
+    int32_t        n_pose_ids;
+    const int32_t* body_ids;                /* pose variables the GMM prior sees (pose_body_ids); n_body == prior npose */
+    int32_t        n_body;
+    const int32_t* finger_ids;              /* added (with poseH) in the last two rounds (:390-393); may be empty */
+    int32_t        n_finger;
+    int32_t        maxiter;                 /* cfg.opt_settings.maxiter                                          */
+    double         stagei_lr;               /* cfg.opt_settings.stagei_lr (dogleg e_3)                           */
+    /* outputs */
+    double*  betas;                         /* [nb]                                                              */
+    double*  markers_latent;                /* [M][3]                                                            */
+    int32_t* markers_latent_vids;           /* [M] nearest canonical vertex of each latent marker (:420-422)     */
+    double*  pose;                          /* [n_frames][NP]                                                    */
+    double*  trans;                         /* [n_frames][3]                                                     */
+    double*  errs;                          /* [6] SSE of data, poseB, init, beta, surf, poseH at the solution   */
+    int32_t* iters;                         /* [1] dogleg outer iterations over all rounds                       */
+} moshii_stagei_desc;
+
+int moshii_stagei_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL */, const moshii_stagei_desc* desc, void* stream);
 
 /* Introspection for benchmarks: name and dynamic-LDS bytes of the kernel the last moshii_chain_solve used. */
 int moshii_last_launch_info(char* kernel_name, int32_t name_cap, int32_t* lds_bytes, int32_t* block_threads);

@@ -7,12 +7,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['moshii_api.hip', 'chain_solve.hip', 'lbs_forward.hip']
+SOURCES = ['moshii_api.hip', 'chain_solve.hip', 'lbs_forward.hip', 'stagei.hip']
 # per-file extras.  chain_solve: the iterative-ILP machine scheduler orders the long dependent f64 chains of the solver better than the
 # default (measured 393 vs 414 us/frame on the bench sequence, same results); the LBS kernel pins its own order with sched_barriers
 # and is 4 % slower with it, so it keeps the default.
 EXTRA_FLAGS = {'chain_solve.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
-HEADERS = ['moshii_dev.h', os.path.join('..', '..', 'include', 'moshii.h')]
+HEADERS = ['moshii_dev.h', 'stagei_views.h', os.path.join('..', '..', 'include', 'moshii.h')]
 OUT = os.path.join(HERE, 'libmoshii.so')
 
 

@@ -392,3 +392,71 @@ def last_launch_info():
     lds = C.c_int32(0); thr = C.c_int32(0)
     load().moshii_last_launch_info(name, 128, C.byref(lds), C.byref(thr))
     return name.value.decode(), lds.value, thr.value
+
+
+# ---- Stage-I (moshii_stagei_solve) -------------------------------------------------------------------------------
+class StageIDesc(C.Structure):
+    _fields_ = [('n_frames', C.c_int32), ('M', C.c_int32), ('n_faces', C.c_int32), ('nb', C.c_int32),
+                ('faces', C.c_void_p), ('marker_vids', C.c_void_p), ('m2b', C.c_void_p), ('wt_init', C.c_void_p),
+                ('n_obs', C.c_void_p), ('obs_ids', C.c_void_p), ('obs', C.c_void_p),
+                ('exclude_vids', C.c_void_p), ('n_exclude', C.c_int32), ('betas_init', C.c_void_p),
+                ('wt_data', C.c_double), ('wt_poseB', C.c_double), ('wt_poseH', C.c_double), ('wt_betas', C.c_double),
+                ('wt_surf', C.c_double), ('annealing', C.c_void_p), ('n_anneal', C.c_int32),
+                ('pose_ids', C.c_void_p), ('n_pose_ids', C.c_int32), ('body_ids', C.c_void_p), ('n_body', C.c_int32),
+                ('finger_ids', C.c_void_p), ('n_finger', C.c_int32), ('maxiter', C.c_int32), ('stagei_lr', C.c_double),
+                ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
+                ('pose', C.c_void_p), ('trans', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p)]
+
+
+STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH')
+
+
+def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_ids, body_ids, finger_ids=(), exclude_vids=None,
+                betas_init=None, maxiter=100, stagei_lr=1e-3):
+    """Fill a StageIDesc from NumPy data.  `frames`: list of (latent ids, obs[n,3]).  Returns (desc, outputs dict, keep-alive list)."""
+    keep = []
+
+    def ptr(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+        return a.ctypes.data if a.size else None
+    F, M = len(frames), len(marker_vids)
+    d = StageIDesc()
+    d.n_frames, d.M, d.n_faces, d.nb = F, M, len(faces), int(nb)
+    d.faces = ptr(faces, np.int32); d.marker_vids = ptr(marker_vids, np.int32)
+    d.m2b = ptr(m2b, np.float64); d.wt_init = ptr(wt_init, np.float64)
+    d.n_obs = ptr([len(ids) for ids, _ in frames], np.int32)
+    d.obs_ids = ptr(np.concatenate([np.asarray(ids) for ids, _ in frames]), np.int32)
+    d.obs = ptr(np.vstack([np.asarray(o, dtype=np.float64).reshape(-1, 3) for _, o in frames]), np.float64)
+    ex = np.zeros(0, np.int32) if exclude_vids is None else np.asarray(exclude_vids, np.int32)
+    d.exclude_vids = ptr(ex, np.int32); d.n_exclude = len(ex)
+    d.betas_init = ptr(np.asarray(betas_init, np.float64)[:nb], np.float64) if betas_init is not None else None
+    d.wt_data, d.wt_poseB, d.wt_poseH = weights['stagei_wt_data'], weights['stagei_wt_poseB'], weights['stagei_wt_poseH']
+    d.wt_betas, d.wt_surf = weights['stagei_wt_betas'], weights['stagei_wt_surf']
+    ann = list(weights['stagei_wt_annealing'])
+    d.annealing = ptr(ann, np.float64); d.n_anneal = len(ann)
+    d.pose_ids = ptr(pose_ids, np.int32); d.n_pose_ids = len(pose_ids)
+    d.body_ids = ptr(body_ids, np.int32); d.n_body = len(body_ids)
+    d.finger_ids = ptr(list(finger_ids), np.int32); d.n_finger = len(finger_ids)
+    d.maxiter, d.stagei_lr = int(maxiter), float(stagei_lr)
+    out = dict(betas=np.zeros(max(nb, 1)), markers_latent=np.zeros((M, 3)), markers_latent_vids=np.zeros(M, np.int32),
+               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), errs=np.zeros(6), iters=np.zeros(1, np.int32))
+    for k, v in out.items():
+        setattr(d, k, v.ctypes.data)
+    out['betas'] = out['betas'][:nb]
+    keep.append(out)
+    return d, out, keep
+
+
+EXPORTS['moshii_stagei_solve'] = (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StageIDesc), C.c_void_p])
+
+
+def stagei_solve_host(model: Model, prior, **kw):
+    """moshii_stagei_solve on host buffers; kw as stagei_desc().  Returns dict(betas, markers_latent, markers_latent_vids, pose,
+    trans, errs{term: SSE}, iters)."""
+    require_device()
+    desc, out, _keep = stagei_desc(NP=model.NP, **kw)
+    check(load().moshii_stagei_solve(model.handle, prior.handle if prior is not None else None, C.byref(desc), None))
+    out = dict(out)
+    out['errs'] = dict(zip(STAGEI_ERR_NAMES, out['errs'].tolist()))
+    out['iters'] = int(out['iters'][0])
+    return out

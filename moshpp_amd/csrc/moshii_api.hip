@@ -1,6 +1,7 @@
 // libmoshii C ABI (include/moshii.h): handles, setup kernels, host-side staging and launch logic.
 #include "../../include/moshii.h"
 #include "moshii_dev.h"
+#include "stagei_views.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1155,6 +1156,22 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         for (int q = 0; q < n_seq; ++q)
             if ((rc = stage_out(fbs[q], NP, P, &st[q]))) { cleanup(); return rc; }
     cleanup();
+    return MOSHII_OK;
+}
+
+int moshii_stagei_solve(moshii_model_t m, moshii_prior_t prior, const moshii_stagei_desc* desc, void* stream) {
+    if (!m || !desc) return fail(MOSHII_ERR_ARG, "stagei: null model or desc");
+    if (!desc->faces || !desc->marker_vids || !desc->m2b || !desc->wt_init || !desc->n_obs || !desc->obs_ids || !desc->obs ||
+        !desc->annealing || !desc->pose_ids) return fail(MOSHII_ERR_ARG, "stagei: missing input array");
+    S1ModelView mv;
+    mv.V = m->V; mv.K = m->K; mv.NB = m->NB; mv.NP = m->NP; mv.body_dof = m->body_dof; mv.hand_dof = m->hand_dof;
+    mv.parents = m->d_parents; mv.anc = m->d_anc; mv.vt = m->d_vt; mv.shapedirs = m->d_shapedirs; mv.posedirs = m->d_posedirs;
+    mv.weights = m->d_weights; mv.Jreg = m->d_Jreg; mv.hands_mean = m->d_hands_mean; mv.comps = m->d_comps;
+    S1PriorView pv;
+    if (prior) { pv.G = prior->G; pv.npose = prior->npose; pv.means = prior->d_means; pv.chols = prior->d_chols; pv.neglogw = prior->d_neglogw; }
+    char err[256] = {0};
+    int rc = moshii_stagei_core(&mv, prior ? &pv : nullptr, desc, stream, err, sizeof(err));
+    if (rc != MOSHII_OK) return fail(rc, err);
     return MOSHII_OK;
 }
 

@@ -1,0 +1,1247 @@
+// MoSh++ Stage-I on gfx950: shape (betas) + latent markers + one pose per picked frame, solved jointly (chmosh.py:83-455).
+//
+// Everything numeric runs on the device in f64: the canonical body, the re-evaluated marker attachment (3-NN, local frames,
+// coefficients), the signed point-to-surface distance (exhaustive nearest triangle), the posed marker vertices with their pose and
+// shape Jacobians, the residual rows and the dense Jacobian, the normal equations (tiled SYRK), the Cholesky solve.  The host
+// drives Powell's dogleg (the trust-region bookkeeping on n-vectors) and the four annealing rounds.
+//
+// Kernels are written with block-strided loops over TID/NT so that tests/emu can compile this very file with g++ (-DS1_EMU,
+// one "thread" per block) and debug the arithmetic on a CPU-only container.  The emulation is test infrastructure: the product
+// library is built from this file by hipcc only.
+#ifndef S1_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include "stagei_views.h"
+#include "../../include/moshii.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#ifdef S1_EMU
+#define KERNEL static void
+#define DEVFN static inline
+static int s1_bx, s1_by;
+#define TID 0
+#define NT 1
+#define BX s1_bx
+#define BY s1_by
+#define SYNC()
+#define SHARED static
+#define S1_TPB 1
+#define S1_CHOL_TPB 1
+#define LAUNCH(k, gx, gy, nt, stream, ...) do { for (int _y = 0; _y < (int)(gy); ++_y) for (int _x = 0; _x < (int)(gx); ++_x) { s1_bx = _x; s1_by = _y; k(__VA_ARGS__); } } while (0)
+#else
+#define KERNEL __global__ void
+#define DEVFN __device__ static inline
+#define TID ((int)threadIdx.x)
+#define NT ((int)blockDim.x)
+#define BX ((int)blockIdx.x)
+#define BY ((int)blockIdx.y)
+#define SYNC() __syncthreads()
+#define SHARED __shared__
+#define S1_TPB 256
+#define S1_CHOL_TPB 1024
+#define LAUNCH(k, gx, gy, nt, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), 0, stream, __VA_ARGS__)
+#endif
+
+#define S1_NMAX 2048     // unknowns (one column of the factor is staged in LDS)
+#define S1_NWMAX 16      // non-zero skinning weights per vertex the vertex kernel keeps in registers
+
+namespace {
+
+struct S1Dims {
+    int F, M, nb, NPZ;        // frames, markers, free betas, poses evaluated (F + canonical)
+    int V, K, P, NP, body_dof, hand_dof, nhand_full, NBtot, nfeat;
+    int nfaces, npid, nbody, nfinger, npose_prior, G;
+    int n, ldn, R;            // unknowns, Jacobian pitch, residual rows
+    int o_ml, o_pose, o_b;    // column offsets
+    int r_data, r_prior, r_init, r_beta, r_surf, r_poseH;   // row offsets
+    int ncan;                 // canonical vertex list length = 9 M  [closest | closest0 | nearest-triangle vertices]
+};
+
+struct S1Ptr {
+    // model
+    const int* parents; const unsigned long long* anc;
+    const double *vt, *shapedirs, *posedirs, *weights, *Jreg, *hands_mean, *comps;
+    // prior
+    const double *means, *chols, *neglogw;
+    // problem constants
+    const int* faces; const int* v2f_ptr; const int* v2f; const unsigned char* excl;
+    const int* obs_ids; const int* obs_off; const double* obs; const double* m2b; const double* wt_init;
+    const int* colmap;        // [NP] column of a pose variable inside one frame's block, -1 if frozen
+    const int* body_ids; const int* finger_ids;
+    int* cl0; double* coef0;
+    // evaluation point
+    double *pose, *trans, *ml, *betas;
+    // setup products
+    double *J0, *JS;          // [K][3], [K][nb][3]
+    // per pose
+    double *fp, *Rl, *Jl, *Rw, *tw, *feat, *om, *Bm, *Jb, *q;
+    // canonical body + attachment + surface
+    double* can; int* cl; double *coef, *Fc, *dcdb; int* tv; double *sdist, *sdp, *sdabc; int* status;
+    // vertex evaluations
+    int* vlist;               // [NPZ][ncan] global vertex ids (frames use the first 3M entries of the canonical list)
+    double *vv, *dvs, *dv, *Lb;
+    // rows
+    double *r, *Jm;
+    // weights of the round: data, poseB, poseH, beta, surf, anneal
+    double w_data, w_poseB, w_poseH, w_beta, w_surf, w_anneal;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------------------------
+DEVFN void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+DEVFN double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DEVFN void matvec3(const double* Rm, const double* v, double* o) {
+    for (int a = 0; a < 3; ++a) o[a] = Rm[3 * a] * v[0] + Rm[3 * a + 1] * v[1] + Rm[3 * a + 2] * v[2];
+}
+DEVFN void matmul3(const double* A, const double* B, double* C) {
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = A[3 * a] * B[b] + A[3 * a + 1] * B[3 + b] + A[3 * a + 2] * B[6 + b];
+}
+DEVFN void skew3(const double* v, double* Km) {
+    Km[0] = 0; Km[1] = -v[2]; Km[2] = v[1]; Km[3] = v[2]; Km[4] = 0; Km[5] = -v[0]; Km[6] = -v[1]; Km[7] = v[0]; Km[8] = 0;
+}
+
+// R = I + a K + b K^2, Jl = I + b K + c K^2 with the series of the oracle below |r|^2 < 1e-6
+DEVFN void rodrigues_dev(const double* r, double* Rm, double* Jm) {
+    double t2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double a, b, c;
+    if (t2 < 1e-6) {
+        a = 1.0 - t2 / 6.0 + t2 * t2 / 120.0; b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0; c = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0;
+    } else {
+        double t = sqrt(t2);
+        a = sin(t) / t; b = (1.0 - cos(t)) / t2; c = (t - sin(t)) / (t2 * t);
+    }
+    double Km[9], K2[9];
+    skew3(r, Km); matmul3(Km, Km, K2);
+    for (int i = 0; i < 9; ++i) {
+        double e = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+        Rm[i] = e + a * Km[i] + b * K2[i];
+        Jm[i] = e + b * Km[i] + c * K2[i];
+    }
+}
+
+// frame vectors f1,f2,f3 (rows of Fm) of a vertex triple
+DEVFN void frame_of(const double* v0, const double* v1, const double* v2, double* Fm) {
+    double e1[3], e2[3], nv[3];
+    for (int a = 0; a < 3; ++a) { e1[a] = v1[a] - v0[a]; e2[a] = v2[a] - v0[a]; }
+    double l1 = sqrt(dot3(e1, e1));
+    cross3(e1, e2, nv);
+    double ln = sqrt(dot3(nv, nv));
+    for (int a = 0; a < 3; ++a) { Fm[a] = e1[a] / l1; Fm[3 + a] = nv[a] / ln; }
+    cross3(Fm, Fm + 3, Fm + 6);
+}
+
+// d(c0 f1 + c1 f2 + c2 f3)/d(v0,v1,v2): L[3][9] (without the identity of the anchor vertex)  -- markers_from_verts of the oracle
+DEVFN void frame_jac(const double* v0, const double* v1, const double* v2, const double* c, double* L) {
+    double e1[3], e2[3], nv[3], f1[3], f2[3];
+    for (int a = 0; a < 3; ++a) { e1[a] = v1[a] - v0[a]; e2[a] = v2[a] - v0[a]; }
+    double l1 = sqrt(dot3(e1, e1));
+    cross3(e1, e2, nv);
+    double ln = sqrt(dot3(nv, nv));
+    for (int a = 0; a < 3; ++a) { f1[a] = e1[a] / l1; f2[a] = nv[a] / ln; }
+    double D1[9], D2[9], S[9], T[9], df2e1[9], df2e2[9], sf1[9], sf2[9], df3e1[9], df3e2[9], tmp[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        double e = a == b ? 1.0 : 0.0;
+        D1[3 * a + b] = (e - f1[a] * f1[b]) / l1;
+        D2[3 * a + b] = (e - f2[a] * f2[b]) / ln;
+    }
+    skew3(e2, S); for (int i = 0; i < 9; ++i) S[i] = -S[i];      // dn/de1 = -[e2]x
+    skew3(e1, T);                                                 // dn/de2 =  [e1]x
+    matmul3(D2, S, df2e1); matmul3(D2, T, df2e2);
+    skew3(f1, sf1); skew3(f2, sf2);
+    matmul3(sf2, D1, tmp); matmul3(sf1, df2e1, df3e1);
+    for (int i = 0; i < 9; ++i) df3e1[i] -= tmp[i];
+    matmul3(sf1, df2e2, df3e2);
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+        double de1 = c[0] * D1[3 * a + b] + c[1] * df2e1[3 * a + b] + c[2] * df3e1[3 * a + b];
+        double de2 = c[1] * df2e2[3 * a + b] + c[2] * df3e2[3 * a + b];
+        L[9 * a + b] = -de1 - de2; L[9 * a + 3 + b] = de1; L[9 * a + 6 + b] = de2;
+    }
+}
+
+// closest point on triangle (Ericson) with the part code: 0 interior, 1 ab, 2 bc, 3 ca, 4 a, 5 b, 6 c
+DEVFN int closest_on_tri(const double* p, const double* a, const double* b, const double* c, double* q) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
+    double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { for (int i = 0; i < 3; ++i) q[i] = a[i]; return 4; }
+    double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { for (int i = 0; i < 3; ++i) q[i] = b[i]; return 5; }
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double t = d1 / (d1 - d3); for (int i = 0; i < 3; ++i) q[i] = a[i] + t * ab[i]; return 1; }
+    double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { for (int i = 0; i < 3; ++i) q[i] = c[i]; return 6; }
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double t = d2 / (d2 - d6); for (int i = 0; i < 3; ++i) q[i] = a[i] + t * ac[i]; return 3; }
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        double t = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int i = 0; i < 3; ++i) q[i] = b[i] + t * (c[i] - b[i]);
+        return 2;
+    }
+    double den = 1.0 / (va + vb + vc);
+    double v = vb * den, w = vc * den;
+    for (int i = 0; i < 3; ++i) q[i] = a[i] + ab[i] * v + ac[i] * w;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// setup: J0 = Jreg . v_template, JS = Jreg . shapedirs[:, :, :nb]            grid (K, nb + 1)
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_setup(S1Dims d, S1Ptr p) {
+    SHARED double red[3 * 256];
+    int k = BX, e = BY;     // e == nb: template
+    double acc[3] = {0, 0, 0};
+    for (int v = TID; v < d.V; v += NT) {
+        double w = p.Jreg[(size_t)k * d.V + v];
+        if (w == 0.0) continue;
+        for (int a = 0; a < 3; ++a)
+            acc[a] += w * (e == d.nb ? p.vt[3 * v + a] : p.shapedirs[((size_t)v * 3 + a) * d.NBtot + e]);
+    }
+    for (int a = 0; a < 3; ++a) red[a * 256 + TID] = acc[a];
+    SYNC();
+    if (TID == 0) {
+        for (int a = 0; a < 3; ++a) {
+            double s = 0;
+            for (int t = 0; t < NT; ++t) s += red[a * 256 + t];
+            if (e == d.nb) p.J0[3 * k + a] = s; else p.JS[((size_t)k * d.nb + e) * 3 + a] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// per pose (grid NPZ): fullpose, Rodrigues, joints at the current betas, forward kinematics, shape derivative of the joint
+// world positions (q), pose features, rotation axes, corrective derivative matrices
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
+    int z = BX;
+    const double* pose = p.pose + (size_t)z * d.NP;
+    double* fp = p.fp + (size_t)z * d.P;
+    double* Rl = p.Rl + (size_t)z * d.K * 9; double* Jl = p.Jl + (size_t)z * d.K * 9;
+    double* Rw = p.Rw + (size_t)z * d.K * 9; double* tw = p.tw + (size_t)z * d.K * 3;
+    double* Jb = p.Jb + (size_t)z * d.K * 3;
+    double* q = p.q + (size_t)z * d.K * d.nb * 3;
+    double* feat = p.feat + (size_t)z * d.nfeat;
+    double* om = p.om + (size_t)z * d.K * 9; double* Bm = p.Bm + (size_t)z * d.K * 27;
+    for (int i = TID; i < d.P; i += NT) {
+        if (i < d.body_dof) fp[i] = pose[i];
+        else {
+            int c = i - d.body_dof;
+            double s = p.hands_mean ? p.hands_mean[c] : 0.0;
+            for (int h = 0; h < d.hand_dof; ++h) s += pose[d.body_dof + h] * p.comps[(size_t)h * d.nhand_full + c];
+            fp[i] = s;
+        }
+    }
+    for (int i = TID; i < 3 * d.K; i += NT) {
+        double s = p.J0[i];
+        int k = i / 3, a = i % 3;
+        for (int e = 0; e < d.nb; ++e) s += p.JS[((size_t)k * d.nb + e) * 3 + a] * p.betas[e];
+        Jb[i] = s;
+    }
+    SYNC();
+    for (int k = TID; k < d.K; k += NT) rodrigues_dev(fp + 3 * k, Rl + 9 * k, Jl + 9 * k);
+    SYNC();
+    if (TID == 0) {
+        for (int i = 0; i < 9; ++i) Rw[i] = Rl[i];
+        for (int a = 0; a < 3; ++a) tw[a] = Jb[a];
+        for (int j = 1; j < d.K; ++j) {
+            int pa = p.parents[j];
+            matmul3(Rw + 9 * pa, Rl + 9 * j, Rw + 9 * j);
+            double dj[3] = {Jb[3 * j] - Jb[3 * pa], Jb[3 * j + 1] - Jb[3 * pa + 1], Jb[3 * j + 2] - Jb[3 * pa + 2]}, o[3];
+            matvec3(Rw + 9 * pa, dj, o);
+            for (int a = 0; a < 3; ++a) tw[3 * j + a] = o[a] + tw[3 * pa + a];
+        }
+    }
+    SYNC();
+    // q_je = dt_je - Rw_j JS_je, dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par): one thread per coefficient walks the tree
+    for (int e = TID; e < d.nb; e += NT) {
+        for (int j = 0; j < d.K; ++j) {
+            const double* js = p.JS + ((size_t)j * d.nb + e) * 3;
+            double dt[3];
+            if (j == 0) { for (int a = 0; a < 3; ++a) dt[a] = js[a]; }
+            else {
+                int pa = p.parents[j];
+                const double* jp = p.JS + ((size_t)pa * d.nb + e) * 3;
+                // dt of the parent is recovered from its q: dt_par = q_par + Rw_par JS_par
+                double rp[3], dj[3] = {js[0] - jp[0], js[1] - jp[1], js[2] - jp[2]}, o[3];
+                matvec3(Rw + 9 * pa, jp, rp);
+                matvec3(Rw + 9 * pa, dj, o);
+                for (int a = 0; a < 3; ++a) dt[a] = q[((size_t)pa * d.nb + e) * 3 + a] + rp[a] + o[a];
+            }
+            double rj[3];
+            matvec3(Rw + 9 * j, js, rj);
+            for (int a = 0; a < 3; ++a) q[((size_t)j * d.nb + e) * 3 + a] = dt[a] - rj[a];
+        }
+    }
+    for (int i = TID; i < d.nfeat; i += NT) {
+        int k = 1 + i / 9, c = i % 9;
+        feat[i] = Rl[9 * k + c] - ((c == 0 || c == 4 || c == 8) ? 1.0 : 0.0);
+    }
+    for (int i = TID; i < 3 * d.K; i += NT) {
+        int k = i / 3, c = i % 3;
+        double col[3] = {Jl[9 * k + c], Jl[9 * k + 3 + c], Jl[9 * k + 6 + c]};
+        double o[3];
+        if (k == 0) { for (int a = 0; a < 3; ++a) o[a] = col[a]; }
+        else matvec3(Rw + 9 * p.parents[k], col, o);
+        for (int a = 0; a < 3; ++a) om[9 * k + 3 * c + a] = o[a];
+        double Sk[9];
+        skew3(col, Sk);
+        matmul3(Sk, Rl + 9 * k, Bm + 27 * k + 9 * c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// vertex evaluation: grid (ceil(nlist / S1_TPB), number of poses); pose index z = zbase + BY, list = vlist[z], nlist entries.
+// mode 0: positions only into `out` [nlist][3] (canonical full mesh); 1: v; 2: v + dvs; 3: v + dvs + dv (pose Jacobian)
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out, int full_mesh) {
+    int z = zbase + BY;
+    int a = BX * NT + TID;
+    if (a >= nlist) return;
+    int v = full_mesh ? a : p.vlist[(size_t)z * d.ncan + a];
+    const double* Rw = p.Rw + (size_t)z * d.K * 9; const double* tw = p.tw + (size_t)z * d.K * 3;
+    const double* Jb = p.Jb + (size_t)z * d.K * 3; const double* feat = p.feat + (size_t)z * d.nfeat;
+    const double* tr = p.trans + 3 * z;
+    double vs[3], vp[3];
+    for (int c = 0; c < 3; ++c) {
+        double s = p.vt[3 * v + c];
+        const double* sd = p.shapedirs + ((size_t)v * 3 + c) * d.NBtot;
+        for (int e = 0; e < d.nb; ++e) s += sd[e] * p.betas[e];
+        vs[c] = s;
+        const double* pd = p.posedirs + ((size_t)v * 3 + c) * d.nfeat;
+        double t = 0;
+        for (int i = 0; i < d.nfeat; ++i) t += pd[i] * feat[i];
+        vp[c] = s + t;
+    }
+    int jj[S1_NWMAX]; double wj[S1_NWMAX], xj[S1_NWMAX][3];
+    int nw = 0;
+    const double* wrow = p.weights + (size_t)v * d.K;
+    for (int j = 0; j < d.K; ++j) {
+        double w = wrow[j];
+        if (w == 0.0) continue;
+        if (nw >= S1_NWMAX) { p.status[0] = 3; return; }
+        jj[nw] = j; wj[nw] = w;
+        double df[3] = {vp[0] - Jb[3 * j], vp[1] - Jb[3 * j + 1], vp[2] - Jb[3 * j + 2]}, o[3];
+        matvec3(Rw + 9 * j, df, o);
+        for (int c = 0; c < 3; ++c) xj[nw][c] = o[c] + tw[3 * j + c];
+        ++nw;
+    }
+    double pos[3] = {tr[0], tr[1], tr[2]}, Trot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nw; ++s) {
+        for (int c = 0; c < 3; ++c) pos[c] += wj[s] * xj[s][c];
+        for (int i = 0; i < 9; ++i) Trot[i] += wj[s] * Rw[9 * jj[s] + i];
+    }
+    if (mode == 0) { for (int c = 0; c < 3; ++c) out[3 * (size_t)a + c] = pos[c]; return; }
+    size_t slot = (size_t)z * d.ncan + a;
+    for (int c = 0; c < 3; ++c) p.vv[3 * slot + c] = pos[c];
+    if (mode < 2) return;
+    if (d.nb) {
+        const double* q = p.q + (size_t)z * d.K * d.nb * 3;
+        for (int e = 0; e < d.nb; ++e) {
+            double se[3] = {p.shapedirs[((size_t)v * 3 + 0) * d.NBtot + e], p.shapedirs[((size_t)v * 3 + 1) * d.NBtot + e],
+                            p.shapedirs[((size_t)v * 3 + 2) * d.NBtot + e]}, o[3];
+            matvec3(Trot, se, o);
+            for (int s = 0; s < nw; ++s) for (int c = 0; c < 3; ++c) o[c] += wj[s] * q[((size_t)jj[s] * d.nb + e) * 3 + c];
+            for (int c = 0; c < 3; ++c) p.dvs[(slot * 3 + c) * d.nb + e] = o[c];
+        }
+    }
+    if (mode < 3) return;
+    // pose Jacobian: dof (k, c): omega_kc x (S_k - W_k tw_k) + Trot . (posedirs[v, :, 9(k-1):9k] . vec(B_kc))
+    const double* om = p.om + (size_t)z * d.K * 9; const double* Bm = p.Bm + (size_t)z * d.K * 27;
+    double* dv = p.dv + ((size_t)z * 3 * d.M + a) * 3 * d.P;      // [3][P]
+    for (int k = 0; k < d.K; ++k) {
+        unsigned long long am = p.anc[k];
+        double Sk[3] = {0, 0, 0}, Wk = 0;
+        for (int s = 0; s < nw; ++s) if ((am >> jj[s]) & 1ull) { Wk += wj[s]; for (int c = 0; c < 3; ++c) Sk[c] += wj[s] * xj[s][c]; }
+        double arm[3] = {Sk[0] - Wk * tw[3 * k], Sk[1] - Wk * tw[3 * k + 1], Sk[2] - Wk * tw[3 * k + 2]};
+        for (int c = 0; c < 3; ++c) {
+            double o[3];
+            cross3(om + 9 * k + 3 * c, arm, o);
+            if (k >= 1) {
+                double pc[3], t[3];
+                for (int i = 0; i < 3; ++i) {
+                    const double* pd = p.posedirs + ((size_t)v * 3 + i) * d.nfeat + 9 * (k - 1);
+                    double s = 0;
+                    for (int e = 0; e < 9; ++e) s += pd[e] * Bm[27 * k + 9 * c + e];
+                    pc[i] = s;
+                }
+                matvec3(Trot, pc, t);
+                for (int i = 0; i < 3; ++i) o[i] += t[i];
+            }
+            for (int i = 0; i < 3; ++i) dv[(size_t)i * d.P + 3 * k + c] = o[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// attachment: the three nearest canonical vertices of every latent marker (grid M); ties go to the lower vertex id
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl_out) {
+    SHARED double bd[256]; SHARED int bi[256];
+    int m = BX;
+    const double* x = p.ml + 3 * m;
+    int found[3] = {-1, -1, -1};
+    for (int pass = 0; pass < 3; ++pass) {
+        double best = 1e300; int besti = 0x7fffffff;
+        for (int v = TID; v < d.V; v += NT) {
+            if (p.excl[v] || v == found[0] || v == found[1]) continue;
+            double dx = x[0] - p.can[3 * v], dy = x[1] - p.can[3 * v + 1], dz = x[2] - p.can[3 * v + 2];
+            double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best || (d2 == best && v < besti)) { best = d2; besti = v; }
+        }
+        bd[TID] = best; bi[TID] = besti;
+        SYNC();
+        if (TID == 0) {
+            for (int t = 1; t < NT; ++t) if (bd[t] < bd[0] || (bd[t] == bd[0] && bi[t] < bi[0])) { bd[0] = bd[t]; bi[0] = bi[t]; }
+        }
+        SYNC();
+        found[pass] = bi[0];
+        SYNC();
+    }
+    if (TID == 0) for (int s = 0; s < 3; ++s) cl_out[3 * m + s] = found[s];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// signed distance of every latent marker to the canonical surface (grid M): exhaustive nearest triangle, part code, sign from
+// the face / vertex normals, closed-form gradients wrt the marker and the triangle's vertices
+// ---------------------------------------------------------------------------------------------------------------------------
+DEVFN void vertex_normal(const S1Ptr& p, int v, double* n) {
+    n[0] = n[1] = n[2] = 0;
+    for (int i = p.v2f_ptr[v]; i < p.v2f_ptr[v + 1]; ++i) {
+        const int* f = p.faces + 3 * p.v2f[i];
+        double e1[3], e2[3], t[3];
+        for (int a = 0; a < 3; ++a) { e1[a] = p.can[3 * f[1] + a] - p.can[3 * f[0] + a]; e2[a] = p.can[3 * f[2] + a] - p.can[3 * f[0] + a]; }
+        cross3(e1, e2, t);
+        for (int a = 0; a < 3; ++a) n[a] += t[a];
+    }
+    double ss = dot3(n, n);
+    if (ss == 0) ss = 1e-10;
+    double s = 1.0 / sqrt(ss);
+    for (int a = 0; a < 3; ++a) n[a] *= s;
+}
+
+KERNEL k_s1_surface(S1Dims d, S1Ptr p) {
+    SHARED double bd[256]; SHARED int bi[256];
+    int m = BX;
+    const double* x = p.ml + 3 * m;
+    double best = 1e300; int besti = 0x7fffffff;
+    for (int f = TID; f < d.nfaces; f += NT) {
+        const int* fv = p.faces + 3 * f;
+        double q[3];
+        closest_on_tri(x, p.can + 3 * fv[0], p.can + 3 * fv[1], p.can + 3 * fv[2], q);
+        double dx = x[0] - q[0], dy = x[1] - q[1], dz = x[2] - q[2];
+        double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < best || (d2 == best && f < besti)) { best = d2; besti = f; }
+    }
+    bd[TID] = best; bi[TID] = besti;
+    SYNC();
+    if (TID == 0) {
+        for (int t = 1; t < NT; ++t) if (bd[t] < bd[0] || (bd[t] == bd[0] && bi[t] < bi[0])) { bd[0] = bd[t]; bi[0] = bi[t]; }
+        const int* fv = p.faces + 3 * bi[0];
+        const double *A = p.can + 3 * fv[0], *B = p.can + 3 * fv[1], *C = p.can + 3 * fv[2];
+        double q[3], diff[3], e1[3], e2[3], nrm[3], nh[3], nn[3];
+        int part = closest_on_tri(x, A, B, C, q);
+        for (int a = 0; a < 3; ++a) { diff[a] = x[a] - q[a]; e1[a] = B[a] - A[a]; e2[a] = C[a] - A[a]; }
+        cross3(e1, e2, nrm);
+        double s = sqrt(dot3(nrm, nrm));
+        for (int a = 0; a < 3; ++a) nh[a] = nrm[a] / s;
+        if (part == 0) { for (int a = 0; a < 3; ++a) nn[a] = nh[a]; }
+        else if (part > 3) vertex_normal(p, fv[part - 4], nn);
+        else {
+            double n2[3];
+            vertex_normal(p, fv[part - 1], nn); vertex_normal(p, fv[part % 3], n2);
+            for (int a = 0; a < 3; ++a) nn[a] += n2[a];
+        }
+        double sd = dot3(diff, nn);
+        double dir = sd > 0 ? 1.0 : (sd < 0 ? -1.0 : 0.0);
+        double d2 = dot3(diff, diff), dist = sqrt(d2);
+        p.sdist[m] = dist * dir;
+        for (int s3 = 0; s3 < 3; ++s3) p.tv[3 * m + s3] = fv[s3];
+        double* dp = p.sdp + 3 * m; double* da = p.sdabc + 9 * m;
+        for (int i = 0; i < 9; ++i) da[i] = 0;
+        if (part == 0) {
+            double pa[3] = {x[0] - A[0], x[1] - A[1], x[2] - A[2]};
+            double h = dot3(pa, nh), u[3], gb[3], gc[3];
+            for (int a = 0; a < 3; ++a) u[a] = (pa[a] - h * nh[a]) / s;
+            cross3(e2, u, gb); cross3(u, e1, gc);
+            double sg = (h > 0 ? 1.0 : (h < 0 ? -1.0 : 0.0)) * dir;
+            for (int a = 0; a < 3; ++a) { dp[a] = sg * nh[a]; da[3 + a] = sg * gb[a]; da[6 + a] = sg * gc[a]; da[a] = sg * (-nh[a] - gb[a] - gc[a]); }
+        } else {
+            double uh[3];
+            for (int a = 0; a < 3; ++a) uh[a] = dist > 0 ? diff[a] / dist : 0.0;
+            for (int a = 0; a < 3; ++a) dp[a] = dir * uh[a];
+            if (part > 3) { for (int a = 0; a < 3; ++a) da[3 * (part - 4) + a] = -dir * uh[a]; }
+            else {
+                int i0 = part - 1, i1 = part % 3;
+                const double* P0 = p.can + 3 * fv[i0]; const double* Q0 = p.can + 3 * fv[i1];
+                double pq[3] = {Q0[0] - P0[0], Q0[1] - P0[1], Q0[2] - P0[2]}, np_[3] = {q[0] - P0[0], q[1] - P0[1], q[2] - P0[2]};
+                double t = dot3(np_, pq) / dot3(pq, pq);
+                for (int a = 0; a < 3; ++a) { da[3 * i0 + a] = -dir * (1 - t) * uh[a]; da[3 * i1 + a] = -dir * t * uh[a]; }
+            }
+        }
+    }
+}
+
+// vertex lists: canonical pose gets [closest | closest0 | nearest-triangle vertices], every frame gets `closest`
+KERNEL k_s1_lists(S1Dims d, S1Ptr p) {
+    int i = BX * NT + TID;
+    if (i >= 3 * d.M) return;
+    for (int z = 0; z < d.F; ++z) p.vlist[(size_t)z * d.ncan + i] = p.cl[i];
+    int* lc = p.vlist + (size_t)d.F * d.ncan;
+    lc[i] = p.cl[i]; lc[3 * d.M + i] = p.cl0[i]; lc[6 * d.M + i] = p.tv[i];
+}
+
+// Arun / Procrustes fit R a + T ~= b (rigid_transformations.py:39-69) and cv2.Rodrigues(R) (:82); a, b [n][3]
+DEVFN void rigid_fit(const double* A_, const double* B_, int cnt, double* rv, double* T) {
+    double am[3] = {0, 0, 0}, bm[3] = {0, 0, 0};
+    for (int m = 0; m < cnt; ++m) for (int i = 0; i < 3; ++i) { am[i] += A_[3 * m + i]; bm[i] += B_[3 * m + i]; }
+    for (int i = 0; i < 3; ++i) { am[i] /= cnt; bm[i] /= cnt; }
+    double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < cnt; ++m) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) G[i * 3 + j] += (A_[3 * m + i] - am[i]) * (B_[3 * m + j] - bm[j]);
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};      // one-sided Jacobi: G V = U S
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p_ = 0; p_ < 2; ++p_) for (int q_ = p_ + 1; q_ < 3; ++q_) {
+            double al = 0, be = 0, ga = 0;
+            for (int i = 0; i < 3; ++i) { al += G[i * 3 + p_] * G[i * 3 + p_]; be += G[i * 3 + q_] * G[i * 3 + q_]; ga += G[i * 3 + p_] * G[i * 3 + q_]; }
+            if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+            off = fmax(off, fabs(ga) / sqrt(al * be));
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = ((zeta >= 0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            for (int i = 0; i < 3; ++i) {
+                const double gp = G[i * 3 + p_], gq = G[i * 3 + q_];
+                G[i * 3 + p_] = c * gp - sn * gq; G[i * 3 + q_] = sn * gp + c * gq;
+                const double vp = V[i * 3 + p_], vq = V[i * 3 + q_];
+                V[i * 3 + p_] = c * vp - sn * vq; V[i * 3 + q_] = sn * vp + c * vq;
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    double sv[3], U[9];
+    int imin = 0, imax = 0;
+    for (int c = 0; c < 3; ++c) {
+        sv[c] = sqrt(G[c] * G[c] + G[3 + c] * G[3 + c] + G[6 + c] * G[6 + c]);
+        if (sv[c] < sv[imin]) imin = c;
+        if (sv[c] > sv[imax]) imax = c;
+    }
+    for (int c = 0; c < 3; ++c) for (int i = 0; i < 3; ++i) U[i * 3 + c] = (sv[c] > 0) ? G[i * 3 + c] / sv[c] : 0.0;
+    if (sv[imin] <= 1e-13 * sv[imax]) {
+        const int c1 = (imin + 1) % 3, c2 = (imin + 2) % 3;
+        U[0 * 3 + imin] = U[1 * 3 + c1] * U[2 * 3 + c2] - U[2 * 3 + c1] * U[1 * 3 + c2];
+        U[1 * 3 + imin] = U[2 * 3 + c1] * U[0 * 3 + c2] - U[0 * 3 + c1] * U[2 * 3 + c2];
+        U[2 * 3 + imin] = U[0 * 3 + c1] * U[1 * 3 + c2] - U[1 * 3 + c1] * U[0 * 3 + c2];
+    }
+    double Rm[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rm[i * 3 + j] = V[i * 3] * U[j * 3] + V[i * 3 + 1] * U[j * 3 + 1] + V[i * 3 + 2] * U[j * 3 + 2];
+    const double det = Rm[0] * (Rm[4] * Rm[8] - Rm[5] * Rm[7]) - Rm[1] * (Rm[3] * Rm[8] - Rm[5] * Rm[6]) + Rm[2] * (Rm[3] * Rm[7] - Rm[4] * Rm[6]);
+    if (det < 0.0) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rm[i * 3 + j] -= 2.0 * V[i * 3 + imin] * U[j * 3 + imin];
+    double rx = Rm[7] - Rm[5], ry = Rm[2] - Rm[6], rz = Rm[3] - Rm[1];
+    const double sn = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (Rm[0] + Rm[4] + Rm[8] - 1.0) * 0.5;
+    c = fmin(1.0, fmax(-1.0, c));
+    const double theta = acos(c);
+    if (sn < 1e-5) {
+        if (c > 0) { rv[0] = rv[1] = rv[2] = 0.0; }
+        else {
+            double x = sqrt(fmax((Rm[0] + 1.0) * 0.5, 0.0));
+            double y = sqrt(fmax((Rm[4] + 1.0) * 0.5, 0.0)) * ((Rm[1] >= 0) ? 1.0 : -1.0);
+            double z = sqrt(fmax((Rm[8] + 1.0) * 0.5, 0.0)) * ((Rm[2] >= 0) ? 1.0 : -1.0);
+            if (fabs(x) < fabs(y) && fabs(x) < fabs(z) && ((Rm[5] > 0) != (y * z > 0))) z = -z;
+            const double nn = sqrt(x * x + y * y + z * z);
+            rv[0] = x * theta / nn; rv[1] = y * theta / nn; rv[2] = z * theta / nn;
+        }
+    } else {
+        const double k = 0.5 * theta / sn;
+        rv[0] = rx * k; rv[1] = ry * k; rv[2] = rz * k;
+    }
+    for (int i = 0; i < 3; ++i) T[i] = bm[i] - (Rm[i * 3] * am[0] + Rm[i * 3 + 1] * am[1] + Rm[i * 3 + 2] * am[2]);
+}
+
+// rigid start of every frame (grid F): markers simulated at the uploaded point vs the observations; out[f] = [rotvec, T]
+KERNEL k_s1_rigid(S1Dims d, S1Ptr p, double* sim, double* out) {
+    int f = BX;
+    int o0 = p.obs_off[f], nobs = p.obs_off[f + 1] - o0;
+    const double* vv = p.vv + 3 * ((size_t)f * d.ncan);
+    for (int k = TID; k < nobs; k += NT) {
+        int m = p.obs_ids[o0 + k];
+        const double* v0 = vv + 9 * m; const double* c = p.coef + 3 * m;
+        double Fm[9];
+        frame_of(v0, v0 + 3, v0 + 6, Fm);
+        for (int a = 0; a < 3; ++a) sim[3 * (size_t)(o0 + k) + a] = v0[a] + c[0] * Fm[a] + c[1] * Fm[3 + a] + c[2] * Fm[6 + a];
+    }
+    SYNC();
+    if (TID == 0) rigid_fit(sim + 3 * (size_t)o0, p.obs + 3 * (size_t)o0, nobs, out + 6 * f, out + 6 * f + 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// shared rows (grid ceil(M / S1_TPB)): coefficients and canonical frames of the attachment, their shape derivative, the
+// init / surf / beta rows.  want_J = 0 skips the Jacobian.
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
+    int m = BX * NT + TID;
+    if (m >= d.M) return;
+    const size_t zc = (size_t)d.F * d.ncan;                         // canonical slots
+    const double* vc = p.vv + 3 * (zc + 3 * m);                     // v0c v1c v2c
+    double Fc[9], diff[3], coef[3];
+    frame_of(vc, vc + 3, vc + 6, Fc);
+    for (int a = 0; a < 3; ++a) diff[a] = p.ml[3 * m + a] - vc[a];
+    for (int i = 0; i < 3; ++i) coef[i] = dot3(diff, Fc + 3 * i);
+    if (!(coef[0] == coef[0]) || !(coef[1] == coef[1]) || !(coef[2] == coef[2])) p.status[2] = 1;   // collinear neighbours
+    for (int i = 0; i < 9; ++i) p.Fc[9 * m + i] = Fc[i];
+    for (int i = 0; i < 3; ++i) p.coef[3 * m + i] = coef[i];
+    const int nb = d.nb;
+    if (want_J && nb) {
+        // dc_i/dbeta = (diff^T df_i/dV - f_i^T [I 0 0]) dV/dbeta
+        const double* dV = p.dvs + (zc + 3 * m) * 3 * nb;           // [9][nb]
+        for (int i = 0; i < 3; ++i) {
+            double unit[3] = {0, 0, 0}, L[27], row[9];
+            unit[i] = 1.0;
+            frame_jac(vc, vc + 3, vc + 6, unit, L);
+            for (int b = 0; b < 9; ++b) row[b] = diff[0] * L[b] + diff[1] * L[9 + b] + diff[2] * L[18 + b];
+            for (int a = 0; a < 3; ++a) row[a] -= Fc[3 * i + a];
+            for (int e = 0; e < nb; ++e) {
+                double s = 0;
+                for (int b = 0; b < 9; ++b) s += row[b] * dV[(size_t)b * nb + e];
+                p.dcdb[((size_t)m * 3 + i) * nb + e] = s;
+            }
+        }
+    }
+    // init rows: (ml - init(betas)) wt_m anneal, init = v0 + F(can[closest0]) coef0
+    {
+        const double* v0 = p.vv + 3 * (zc + 3 * d.M + 3 * m);
+        double F0[9], L0[27];
+        frame_of(v0, v0 + 3, v0 + 6, F0);
+        const double* c0 = p.coef0 + 3 * m;
+        double w = p.wt_init[m] * p.w_anneal;
+        for (int a = 0; a < 3; ++a) {
+            double init = v0[a] + c0[0] * F0[a] + c0[1] * F0[3 + a] + c0[2] * F0[6 + a];
+            p.r[d.r_init + 3 * m + a] = (p.ml[3 * m + a] - init) * w;
+        }
+        if (want_J) {
+            for (int a = 0; a < 3; ++a) p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_ml + 3 * m + a] = w;
+            if (nb) {
+                frame_jac(v0, v0 + 3, v0 + 6, c0, L0);
+                for (int a = 0; a < 3; ++a) L0[9 * a + a] += 1.0;
+                const double* dV = p.dvs + (zc + 3 * d.M + 3 * m) * 3 * nb;
+                for (int a = 0; a < 3; ++a) for (int e = 0; e < nb; ++e) {
+                    double s = 0;
+                    for (int b = 0; b < 9; ++b) s += L0[9 * a + b] * dV[(size_t)b * nb + e];
+                    p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_b + e] = -w * s;
+                }
+            }
+        }
+    }
+    // surf row
+    p.r[d.r_surf + m] = (p.sdist[m] - p.m2b[m]) * p.w_surf;
+    if (want_J) {
+        double* Jr = p.Jm + (size_t)(d.r_surf + m) * d.ldn;
+        for (int a = 0; a < 3; ++a) Jr[d.o_ml + 3 * m + a] = p.sdp[3 * m + a] * p.w_surf;
+        if (nb) {
+            const double* dV = p.dvs + (zc + 6 * d.M + 3 * m) * 3 * nb;
+            for (int e = 0; e < nb; ++e) {
+                double s = 0;
+                for (int b = 0; b < 9; ++b) s += p.sdabc[9 * m + b] * dV[(size_t)b * nb + e];
+                Jr[d.o_b + e] = s * p.w_surf;
+            }
+        }
+    }
+    if (m < nb) {
+        p.r[d.r_beta + m] = p.betas[m] * p.w_beta;
+        if (want_J) p.Jm[(size_t)(d.r_beta + m) * d.ldn + d.o_b + m] = p.w_beta;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// per-frame rows (grid F): data, poseB, poseH
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J) {
+    SHARED double score[64]; SHARED int kbest;
+    int f = BX;
+    const int M = d.M, nb = d.nb, npid = d.npid;
+    const double* vv = p.vv + 3 * ((size_t)f * d.ncan);
+    double* Lb = p.Lb + (size_t)f * M * 36;              // per marker: L[27] + posed frame F'[9]
+    for (int m = TID; m < M; m += NT) {
+        const double* v0 = vv + 9 * m;
+        double L[27], Fp[9];
+        frame_jac(v0, v0 + 3, v0 + 6, p.coef + 3 * m, L);
+        for (int a = 0; a < 3; ++a) L[9 * a + a] += 1.0;
+        frame_of(v0, v0 + 3, v0 + 6, Fp);
+        for (int i = 0; i < 27; ++i) Lb[36 * m + i] = L[i];
+        for (int i = 0; i < 9; ++i) Lb[36 * m + 27 + i] = Fp[i];
+    }
+    SYNC();
+    int o0 = p.obs_off[f], nobs = p.obs_off[f + 1] - o0;
+    const int colbase = d.o_pose + f * npid;
+    // residual
+    for (int i = TID; i < 3 * nobs; i += NT) {
+        int k = i / 3, a = i % 3, m = p.obs_ids[o0 + k];
+        const double* v0 = vv + 9 * m; const double* Fp = Lb + 36 * m + 27; const double* c = p.coef + 3 * m;
+        double sim = v0[a] + c[0] * Fp[a] + c[1] * Fp[3 + a] + c[2] * Fp[6 + a];
+        p.r[d.r_data + 3 * o0 + i] = (p.obs[3 * (size_t)(o0 + k) + a] - sim) * p.w_data;
+    }
+    if (want_J) {
+        const double* dv = p.dv + (size_t)f * 3 * M * 3 * d.P;
+        // pose columns
+        for (int it = TID; it < nobs * d.NP; it += NT) {
+            int k = it / d.NP, pid = it % d.NP, col = p.colmap[pid];
+            if (col < 0) continue;
+            int m = p.obs_ids[o0 + k];
+            const double* L = Lb + 36 * m;
+            double o[3] = {0, 0, 0};
+            for (int s = 0; s < 3; ++s) for (int c = 0; c < 3; ++c) {
+                const double* dvr = dv + ((size_t)(3 * m + s) * 3 + c) * d.P;
+                double g;
+                if (pid < d.body_dof) g = dvr[pid];
+                else {
+                    const double* cm = p.comps + (size_t)(pid - d.body_dof) * d.nhand_full;
+                    g = 0;
+                    for (int qd = 0; qd < d.nhand_full; ++qd) g += cm[qd] * dvr[d.body_dof + qd];
+                }
+                for (int a = 0; a < 3; ++a) o[a] += L[9 * a + 3 * s + c] * g;
+            }
+            for (int a = 0; a < 3; ++a) p.Jm[(size_t)(d.r_data + 3 * (o0 + k) + a) * d.ldn + colbase + col] = -p.w_data * o[a];
+        }
+        // trans, latent marker, betas
+        for (int it = TID; it < nobs * 3; it += NT) {
+            int k = it / 3, a = it % 3, m = p.obs_ids[o0 + k];
+            double* Jr = p.Jm + (size_t)(d.r_data + 3 * (o0 + k) + a) * d.ldn;
+            const double* L = Lb + 36 * m; const double* Fp = L + 27; const double* Fc = p.Fc + 9 * m;
+            Jr[3 * f + a] = -p.w_data;
+            for (int b = 0; b < 3; ++b) Jr[d.o_ml + 3 * m + b] = -p.w_data * (Fp[a] * Fc[b] + Fp[3 + a] * Fc[3 + b] + Fp[6 + a] * Fc[6 + b]);
+            if (nb) {
+                const double* dV = p.dvs + ((size_t)f * d.ncan + 3 * m) * 3 * nb;
+                const double* dc = p.dcdb + (size_t)m * 3 * nb;
+                for (int e = 0; e < nb; ++e) {
+                    double s = 0;
+                    for (int b = 0; b < 9; ++b) s += L[9 * a + b] * dV[(size_t)b * nb + e];
+                    for (int i = 0; i < 3; ++i) s += Fp[3 * i + a] * dc[(size_t)i * nb + e];
+                    Jr[d.o_b + e] = -p.w_data * s;
+                }
+            }
+        }
+    }
+    // poseB: max-mixture prior on pose[body_ids]
+    if (d.G > 0 && d.nbody > 0) {
+        const int np_ = d.npose_prior;
+        const double* pose = p.pose + (size_t)f * d.NP;
+        double* ell = p.Lb + (size_t)d.F * M * 36 + (size_t)f * d.G * np_;      // scratch behind the L buffers
+        for (int it = TID; it < d.G * np_; it += NT) {
+            int g = it / np_, a = it % np_;
+            double s = 0;
+            for (int b = 0; b < np_; ++b) s += (pose[p.body_ids[b]] - p.means[(size_t)g * np_ + b]) * p.chols[((size_t)g * np_ + b) * np_ + a];
+            ell[it] = 0.70710678118654752440 * s;
+        }
+        SYNC();
+        for (int g = TID; g < d.G; g += NT) {
+            double s = 0;
+            for (int a = 0; a < np_; ++a) s += ell[g * np_ + a] * ell[g * np_ + a];
+            score[g] = s + p.neglogw[g];
+        }
+        SYNC();
+        if (TID == 0) { int kb = 0; for (int g = 1; g < d.G; ++g) if (score[g] < score[kb]) kb = g; kbest = kb; }
+        SYNC();
+        int g = kbest;
+        int r0 = d.r_prior + f * (np_ + 1);
+        for (int a = TID; a < np_; a += NT) p.r[r0 + a] = ell[g * np_ + a] * p.w_poseB;
+        if (TID == 0) p.r[r0 + np_] = sqrt(p.neglogw[g]) * p.w_poseB;
+        if (want_J) {
+            for (int it = TID; it < np_ * np_; it += NT) {
+                int a = it / np_, b = it % np_, col = p.colmap[p.body_ids[b]];
+                if (col < 0) continue;
+                p.Jm[(size_t)(r0 + a) * d.ldn + colbase + col] = p.w_poseB * 0.70710678118654752440 * p.chols[((size_t)g * np_ + b) * np_ + a];
+            }
+        }
+        SYNC();
+    }
+    for (int k = TID; k < d.nfinger; k += NT) {
+        int pid = p.finger_ids[k];
+        p.r[d.r_poseH + f * d.nfinger + k] = p.pose[(size_t)f * d.NP + pid] * p.w_poseH;
+        if (want_J) p.Jm[(size_t)(d.r_poseH + f * d.nfinger + k) * d.ldn + colbase + p.colmap[pid]] = p.w_poseH;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dense linear algebra on the row-major Jacobian Jm[R][ldn]
+// ---------------------------------------------------------------------------------------------------------------------------
+#define S1_T 32
+// A = J^T J, lower tiles (grid (nt, nt), tile (BX >= BY)); 256 threads, 2 x 2 outputs each; mirrored on write
+KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A) {
+    int ti = BX, tj = BY;
+    if (tj > ti) return;
+#ifdef S1_EMU
+    for (int i = ti * S1_T; i < std::min(n, (ti + 1) * S1_T); ++i) for (int j = tj * S1_T; j < std::min(n, (tj + 1) * S1_T); ++j) {
+        double s = 0;
+        for (int r = 0; r < R; ++r) s += Jm[(size_t)r * ldn + i] * Jm[(size_t)r * ldn + j];
+        A[(size_t)i * n + j] = s; A[(size_t)j * n + i] = s;
+    }
+#else
+    __shared__ double Si[S1_T][S1_T + 1], Sj[S1_T][S1_T + 1];
+    int tx = TID % 16, ty = TID / 16;
+    double acc[2][2] = {{0, 0}, {0, 0}};
+    for (int r0 = 0; r0 < R; r0 += S1_T) {
+        for (int e = TID; e < S1_T * S1_T; e += NT) {
+            int rr = e / S1_T, cc = e % S1_T;
+            int r = r0 + rr, ci = ti * S1_T + cc, cj = tj * S1_T + cc;
+            Si[rr][cc] = (r < R && ci < n) ? Jm[(size_t)r * ldn + ci] : 0.0;
+            Sj[rr][cc] = (r < R && cj < n) ? Jm[(size_t)r * ldn + cj] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < S1_T; ++rr) {
+            double a0 = Si[rr][ty], a1 = Si[rr][ty + 16], b0 = Sj[rr][tx], b1 = Sj[rr][tx + 16];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        __syncthreads();
+    }
+    for (int u = 0; u < 2; ++u) for (int w = 0; w < 2; ++w) {
+        int i = ti * S1_T + ty + 16 * u, j = tj * S1_T + tx + 16 * w;
+        if (i < n && j < n) { A[(size_t)i * n + j] = acc[u][w]; A[(size_t)j * n + i] = acc[u][w]; }
+    }
+#endif
+}
+
+// y[n] = sign * J^T r   (grid ceil(n / S1_TPB))
+KERNEL k_s1_gemv_t(const double* Jm, const double* r, int R, int n, int ldn, double sign, double* y) {
+    int i = BX * NT + TID;
+    if (i >= n) return;
+    double s = 0;
+    for (int k = 0; k < R; ++k) s += Jm[(size_t)k * ldn + i] * r[k];
+    y[i] = sign * s;
+}
+
+// y[R] = Mx[R][ld] . x[n]   (grid R; one block per row)
+KERNEL k_s1_gemv(const double* Mx, const double* x, int n, int ld, double* y) {
+    SHARED double red[256];
+    int r = BX;
+    double s = 0;
+    for (int i = TID; i < n; i += NT) s += Mx[(size_t)r * ld + i] * x[i];
+    red[TID] = s;
+    SYNC();
+    if (TID == 0) { double t = 0; for (int k = 0; k < NT; ++k) t += red[k]; y[r] = t; }
+}
+
+// in-place lower Cholesky of A[n][n] by one workgroup (right-looking), then L y = g, L^T d = y.  status[1] = 1 if not SPD.
+KERNEL k_s1_chol_solve(double* A, int n, const double* g, double* dsol, int* status) {
+    SHARED double piv; SHARED int bad; SHARED double colj[S1_NMAX];
+    const int lanes = NT < 64 ? NT : 64, lane = TID % lanes, wave = TID / lanes, nwave = NT / lanes;
+    if (TID == 0) bad = 0;
+    SYNC();
+    for (int j = 0; j < n; ++j) {
+        if (TID == 0) {
+            double djj = A[(size_t)j * n + j];
+            if (!(djj > 0)) { bad = 1; djj = 1.0; }
+            piv = sqrt(djj);
+            A[(size_t)j * n + j] = piv;
+        }
+        SYNC();
+        double ip = 1.0 / piv;
+        for (int i = j + 1 + TID; i < n; i += NT) A[(size_t)i * n + j] *= ip;
+        SYNC();
+        // trailing update of the lower triangle: A[i][k] -= L[i][j] L[k][j], j < k <= i
+        for (int i = j + 1 + TID; i < n; i += NT) colj[i] = A[(size_t)i * n + j];
+        SYNC();
+        for (int i = j + 1 + wave; i < n; i += nwave) {     // one row per wavefront, lanes along the row: coalesced
+            double lij = colj[i];
+            double* Ai = A + (size_t)i * n;
+            for (int k = j + 1 + lane; k <= i; k += lanes) Ai[k] -= lij * colj[k];
+        }
+        SYNC();
+    }
+    // forward / backward substitution (column oriented so that the inner loops are parallel)
+    for (int i = TID; i < n; i += NT) dsol[i] = g[i];
+    SYNC();
+    for (int j = 0; j < n; ++j) {
+        if (TID == 0) dsol[j] /= A[(size_t)j * n + j];
+        SYNC();
+        double yj = dsol[j];
+        for (int i = j + 1 + TID; i < n; i += NT) dsol[i] -= A[(size_t)i * n + j] * yj;
+        SYNC();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (TID == 0) dsol[j] /= A[(size_t)j * n + j];
+        SYNC();
+        double xj = dsol[j];
+        for (int i = TID; i < j; i += NT) dsol[i] -= A[(size_t)j * n + i] * xj;
+        SYNC();
+    }
+    if (TID == 0 && bad) status[1] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifdef S1_EMU
+typedef void* hipStream_t;
+static int emuMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 1; }
+#define hipMalloc(p, n) emuMalloc((void**)(p), n)
+#define hipFree(p) free(p)
+#define hipMemcpyAsync(d, s, n, kind, st) (memcpy(d, s, n), 0)
+#define hipMemsetAsync(d, v, n, st) (memset(d, v, n), 0)
+#define hipStreamSynchronize(st) 0
+#define hipSuccess 0
+#define hipGetLastError() 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+#endif
+
+struct DevPool {        // every device allocation of one solve; freed together
+    std::vector<void*> ptrs;
+    bool ok = true;
+    template <class T> T* get(size_t count) {
+        void* q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { ok = false; return nullptr; }
+        ptrs.push_back(q);
+        return (T*)q;
+    }
+    template <class T> T* put(const T* src, size_t count, hipStream_t st) {
+        T* q = get<T>(count);
+        if (q && count) hipMemcpyAsync(q, src, count * sizeof(T), hipMemcpyHostToDevice, st);
+        return q;
+    }
+    ~DevPool() { for (void* q : ptrs) hipFree(q); }
+};
+
+static double nrm2(const std::vector<double>& v) { double s = 0; for (double x : v) s += x * x; return sqrt(s); }
+static double dotv(const std::vector<double>& a, const std::vector<double>& b) { double s = 0; for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i]; return s; }
+
+}  // namespace
+
+// One Stage-I solve.  `mv` / `pv`: device views of the model / prior (moshii_api.hip fills them from the handles).
+int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshii_stagei_desc* ds, void* stream_, char* err, int errlen) {
+    hipStream_t st = (hipStream_t)stream_;
+    auto fail = [&](int code, const char* msg) { snprintf(err, errlen, "%s", msg); return code; };
+    S1Dims d; memset(&d, 0, sizeof(d));
+    S1Ptr p; memset(&p, 0, sizeof(p));
+    d.F = ds->n_frames; d.M = ds->M; d.nb = ds->nb; d.NPZ = d.F + 1;
+    d.V = mv->V; d.K = mv->K; d.P = 3 * mv->K; d.NP = mv->NP; d.body_dof = mv->body_dof; d.hand_dof = mv->hand_dof;
+    d.nhand_full = d.P - d.body_dof; d.NBtot = mv->NB; d.nfeat = 9 * (mv->K - 1);
+    d.nfaces = ds->n_faces; d.nbody = ds->n_body; d.G = pv ? pv->G : 0; d.npose_prior = pv ? pv->npose : 0;
+    d.ncan = 9 * d.M;
+    if (d.F < 1 || d.M < 3 || d.nb < 0 || d.nb > d.NBtot) return fail(MOSHII_ERR_ARG, "stagei: bad sizes");
+    if (pv && d.nbody != pv->npose) return fail(MOSHII_ERR_ARG, "stagei: prior size != number of body pose ids");
+    if (d.G > 64) return fail(MOSHII_ERR_ARG, "stagei: more than 64 mixture components");
+    const int F = d.F, M = d.M, nb = d.nb, NP = d.NP, K = d.K;
+    int ntot_obs = 0;
+    std::vector<int> obs_off(F + 1, 0);
+    for (int f = 0; f < F; ++f) { ntot_obs += ds->n_obs[f]; obs_off[f + 1] = ntot_obs; }
+    for (int i = 0; i < ntot_obs; ++i) if (ds->obs_ids[i] < 0 || ds->obs_ids[i] >= M) return fail(MOSHII_ERR_ARG, "stagei: observed marker id out of range");
+
+    DevPool pool;
+    // ---- constants
+    p.parents = mv->parents; p.vt = mv->vt; p.shapedirs = mv->shapedirs; p.posedirs = mv->posedirs; p.weights = mv->weights;
+    p.Jreg = mv->Jreg; p.hands_mean = mv->hands_mean; p.comps = mv->comps; p.anc = mv->anc;
+    if (pv) { p.means = pv->means; p.chols = pv->chols; p.neglogw = pv->neglogw; }
+    p.faces = pool.put(ds->faces, (size_t)3 * d.nfaces, st);
+    {   // vertex -> incident faces
+        std::vector<int> ptr(d.V + 1, 0), lst((size_t)3 * d.nfaces);
+        for (int i = 0; i < 3 * d.nfaces; ++i) {
+            if (ds->faces[i] < 0 || ds->faces[i] >= d.V) return fail(MOSHII_ERR_ARG, "stagei: face index out of range");
+            ptr[ds->faces[i] + 1]++;
+        }
+        for (int v = 0; v < d.V; ++v) ptr[v + 1] += ptr[v];
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+        for (int f = 0; f < d.nfaces; ++f) for (int c = 0; c < 3; ++c) lst[fill[ds->faces[3 * f + c]]++] = f;
+        p.v2f_ptr = pool.put(ptr.data(), ptr.size(), st); p.v2f = pool.put(lst.data(), lst.size(), st);
+        hipStreamSynchronize(st);
+    }
+    {
+        std::vector<unsigned char> ex(d.V, 0);
+        for (int i = 0; i < ds->n_exclude; ++i) if (ds->exclude_vids[i] >= 0 && ds->exclude_vids[i] < d.V) ex[ds->exclude_vids[i]] = 1;
+        p.excl = pool.put(ex.data(), ex.size(), st);
+        hipStreamSynchronize(st);
+    }
+    p.obs_ids = pool.put(ds->obs_ids, ntot_obs, st); p.obs_off = pool.put(obs_off.data(), obs_off.size(), st);
+    p.obs = pool.put(ds->obs, (size_t)3 * ntot_obs, st); p.m2b = pool.put(ds->m2b, M, st); p.wt_init = pool.put(ds->wt_init, M, st);
+    p.body_ids = pool.put(ds->body_ids, d.nbody, st);
+    int* d_colmap = pool.get<int>(NP); p.colmap = d_colmap;
+    int* d_finger = pool.get<int>(std::max(1, ds->n_finger)); p.finger_ids = d_finger;
+    p.cl0 = pool.get<int>(3 * M); p.coef0 = pool.get<double>(3 * M);
+    p.pose = pool.get<double>((size_t)d.NPZ * NP); p.trans = pool.get<double>((size_t)d.NPZ * 3);
+    p.ml = pool.get<double>(3 * M); p.betas = pool.get<double>(std::max(1, nb));
+    p.J0 = pool.get<double>(3 * K); p.JS = pool.get<double>((size_t)std::max(1, K * nb * 3));
+    p.fp = pool.get<double>((size_t)d.NPZ * d.P); p.Rl = pool.get<double>((size_t)d.NPZ * K * 9); p.Jl = pool.get<double>((size_t)d.NPZ * K * 9);
+    p.Rw = pool.get<double>((size_t)d.NPZ * K * 9); p.tw = pool.get<double>((size_t)d.NPZ * K * 3); p.feat = pool.get<double>((size_t)d.NPZ * d.nfeat);
+    p.om = pool.get<double>((size_t)d.NPZ * K * 9); p.Bm = pool.get<double>((size_t)d.NPZ * K * 27); p.Jb = pool.get<double>((size_t)d.NPZ * K * 3);
+    p.q = pool.get<double>((size_t)d.NPZ * K * std::max(1, nb) * 3);
+    p.can = pool.get<double>((size_t)3 * d.V); p.cl = pool.get<int>(3 * M); p.coef = pool.get<double>(3 * M); p.Fc = pool.get<double>(9 * M);
+    p.dcdb = pool.get<double>((size_t)M * 3 * std::max(1, nb)); p.tv = pool.get<int>(3 * M); p.sdist = pool.get<double>(M);
+    p.sdp = pool.get<double>(3 * M); p.sdabc = pool.get<double>(9 * M); p.status = pool.get<int>(4);
+    p.vlist = pool.get<int>((size_t)d.NPZ * d.ncan); p.vv = pool.get<double>((size_t)d.NPZ * d.ncan * 3);
+    p.dvs = pool.get<double>((size_t)d.NPZ * d.ncan * 3 * std::max(1, nb)); p.dv = pool.get<double>((size_t)F * 3 * M * 3 * d.P);
+    p.Lb = pool.get<double>((size_t)F * M * 36 + (size_t)F * std::max(1, d.G * d.npose_prior));
+    // largest problem of the rounds: all of body + fingers free
+    const int npid_max = ds->n_pose_ids + ds->n_finger;
+    const int n_max = 3 * F + 3 * M + F * npid_max + nb;
+    const int R_max = 3 * ntot_obs + F * (d.G ? d.npose_prior + 1 : 0) + 3 * M + nb + M + F * ds->n_finger;
+    const int ld_max = (n_max + 15) & ~15;
+    p.r = pool.get<double>(R_max); p.Jm = pool.get<double>((size_t)R_max * ld_max);
+    if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 2048 unknowns");
+    double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max); double* d_g = pool.get<double>(n_max); double* d_vec = pool.get<double>(n_max);
+    double* d_out = pool.get<double>(std::max(n_max, R_max));
+    if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed");
+    hipMemsetAsync(p.status, 0, 4 * sizeof(int), st);
+
+    // ---- host state
+    std::vector<double> pose((size_t)d.NPZ * NP, 0.0), trans((size_t)d.NPZ * 3, 0.0), ml(3 * M), betas(std::max(1, nb), 0.0);
+    if (ds->betas_init) for (int e = 0; e < nb; ++e) betas[e] = ds->betas_init[e];
+    std::vector<int> pose_ids, finger_ids, colmap(NP, -1);
+
+    auto upload_point = [&]() {
+        hipMemcpyAsync(p.pose, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(p.trans, trans.data(), trans.size() * 8, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(p.ml, ml.data(), ml.size() * 8, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(p.betas, betas.data(), betas.size() * 8, hipMemcpyHostToDevice, st);
+    };
+    auto canonical = [&]() {   // pose kernels + canonical mesh at the uploaded point
+        LAUNCH(k_s1_pose, d.NPZ, 1, S1_TPB, st, d, p);
+        LAUNCH(k_s1_verts, (d.V + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.V, 0, p.can, 1);
+    };
+    // evaluation of residual (and Jacobian) at the uploaded point
+    auto evaluate = [&](int want_J) {
+        canonical();
+        LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl);
+        LAUNCH(k_s1_surface, M, 1, S1_TPB, st, d, p);
+        LAUNCH(k_s1_lists, (3 * M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p);
+        LAUNCH(k_s1_verts, (d.ncan + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0);
+        LAUNCH(k_s1_verts, (3 * M + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p, 0, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
+        if (want_J) hipMemsetAsync(p.Jm, 0, (size_t)d.R * d.ldn * 8, st);
+        LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J);
+        LAUNCH(k_s1_rows, F, 1, S1_TPB, st, d, p, want_J);
+    };
+    auto fetch = [&](std::vector<double>& h, const double* dev, size_t count) {
+        h.resize(count);
+        hipMemcpyAsync(h.data(), dev, count * 8, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+    };
+
+    // ---- setup: regressed joints, initial latent markers (vertex + normal . m2b), frozen init attachment, rigid start
+    LAUNCH(k_s1_setup, K, nb + 1, S1_TPB, st, d, p);
+    upload_point();
+    canonical();
+    std::vector<double> can;
+    fetch(can, p.can, (size_t)3 * d.V);
+    {   // prepare_mosh_markers_latent (chmosh.py:57-67); normals from the incident faces
+        for (int m = 0; m < M; ++m) {
+            int v = ds->marker_vids[m];
+            if (v < 0 || v >= d.V) return fail(MOSHII_ERR_ARG, "stagei: marker vertex id out of range");
+            double nrm[3] = {0, 0, 0};
+            for (int f = 0; f < d.nfaces; ++f) {
+                const int* fv = ds->faces + 3 * f;
+                if (fv[0] != v && fv[1] != v && fv[2] != v) continue;
+                double e1[3], e2[3];
+                for (int a = 0; a < 3; ++a) { e1[a] = can[3 * fv[1] + a] - can[3 * fv[0] + a]; e2[a] = can[3 * fv[2] + a] - can[3 * fv[0] + a]; }
+                nrm[0] += e1[1] * e2[2] - e1[2] * e2[1]; nrm[1] += e1[2] * e2[0] - e1[0] * e2[2]; nrm[2] += e1[0] * e2[1] - e1[1] * e2[0];
+            }
+            double ss = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+            if (ss == 0) ss = 1e-10;
+            for (int a = 0; a < 3; ++a) ml[3 * m + a] = can[3 * v + a] + nrm[a] / sqrt(ss) * ds->m2b[m];
+        }
+    }
+    upload_point();
+    // frozen attachment of the init markers (chmosh.py:188-190): closest0 / coef0 at the start point
+    d.npid = 0; d.n = 3 * F + 3 * M + nb; d.ldn = (d.n + 15) & ~15; d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose;
+    d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior; d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.R = d.r_poseH;
+    d.nfinger = 0;
+    {
+        int Gkeep = d.G; d.G = 0;                      // no prior rows while the column map is empty
+        hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
+        LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl0);
+        evaluate(0);                                    // fills coef (== coef0 here) and the posed markers of every frame
+        hipMemcpyAsync(p.coef0, p.coef, 3 * M * 8, hipMemcpyDeviceToDevice, st);
+        d.G = Gkeep;
+    }
+    {   // rigid start per frame (chmosh.py:236-238, rigid_transformations.py:39-83): Procrustes on the zero-pose markers
+        double* d_sim = pool.get<double>((size_t)3 * std::max(1, ntot_obs)); double* d_rt = pool.get<double>(6 * F);
+        if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed");
+        LAUNCH(k_s1_rigid, F, 1, S1_TPB, st, d, p, d_sim, d_rt);
+        std::vector<double> rt;
+        fetch(rt, d_rt, 6 * F);
+        for (int f = 0; f < F; ++f) for (int a = 0; a < 3; ++a) { pose[(size_t)f * NP + a] = rt[6 * f + a]; trans[3 * f + a] = rt[6 * f + 3 + a]; }
+#ifdef S1_EMU
+        if (getenv("S1_DEBUG")) {
+            std::vector<double> t_; std::vector<int> ti_(3 * M);
+            fetch(t_, p.can, 9); printf("can %g %g %g | %g %g %g\n", t_[0], t_[1], t_[2], t_[3], t_[4], t_[5]);
+            memcpy(ti_.data(), p.cl0, 3 * M * 4); printf("cl0 %d %d %d\n", ti_[0], ti_[1], ti_[2]);
+            fetch(t_, p.coef0, 6); printf("coef0 %g %g %g\n", t_[0], t_[1], t_[2]);
+            fetch(t_, p.vv, 9); printf("vv %g %g %g | %g %g %g\n", t_[0], t_[1], t_[2], t_[3], t_[4], t_[5]);
+            fetch(t_, d_sim, 6); printf("sim %g %g %g\n", t_[0], t_[1], t_[2]);
+            printf("rt %g %g %g %g %g %g\n", rt[0], rt[1], rt[2], rt[3], rt[4], rt[5]);
+            printf("ml %g %g %g\n", ml[0], ml[1], ml[2]);
+            printf("obs %g %g %g nobs %d %d ids %d %d\n", ds->obs[0], ds->obs[1], ds->obs[2], ds->n_obs[0], ds->n_obs[1], ds->obs_ids[0], ds->obs_ids[1]);
+            { double rv_[3], T_[3]; std::vector<double> sm_; fetch(sm_, d_sim, 3 * ds->n_obs[0]); for (int i_ = 0; i_ < 3 * ds->n_obs[0]; ++i_) if (!(sm_[i_] == sm_[i_])) printf("nan sim at %d\n", i_); rigid_fit(sm_.data(), ds->obs, ds->n_obs[0], rv_, T_); printf("host fit %g %g %g | %g %g %g\n", rv_[0], rv_[1], rv_[2], T_[0], T_[1], T_[2]); }
+        }
+#endif
+    }
+
+    // ---- annealing rounds
+    int total_iters = 0;
+    std::vector<double> r, rnew, g, x, dsd, dgn, ddl, tmp;
+    for (int round = 0; round < ds->n_anneal; ++round) {
+        const double a = ds->annealing[round];
+        const bool detailed = round > ds->n_anneal - 3;
+        pose_ids.assign(ds->pose_ids, ds->pose_ids + ds->n_pose_ids);
+        finger_ids.clear();
+        if (detailed) finger_ids.assign(ds->finger_ids, ds->finger_ids + ds->n_finger);
+        pose_ids.insert(pose_ids.end(), finger_ids.begin(), finger_ids.end());
+        std::sort(pose_ids.begin(), pose_ids.end());
+        pose_ids.erase(std::unique(pose_ids.begin(), pose_ids.end()), pose_ids.end());
+        std::fill(colmap.begin(), colmap.end(), -1);
+        for (size_t c = 0; c < pose_ids.size(); ++c) colmap[pose_ids[c]] = (int)c;
+        for (int b = 0; b < d.nbody; ++b) if (ds->body_ids[b] < 0 || ds->body_ids[b] >= NP) return fail(MOSHII_ERR_ARG, "stagei: body id out of range");
+        d.npid = (int)pose_ids.size(); d.nfinger = (int)finger_ids.size();
+        d.n = 3 * F + 3 * M + F * d.npid + nb; d.ldn = (d.n + 15) & ~15;
+        d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose + F * d.npid;
+        d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior + F * (d.G ? d.npose_prior + 1 : 0);
+        d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.R = d.r_poseH + F * d.nfinger;
+        p.w_anneal = a; p.w_data = (ds->wt_data / a) * (46.0 / M); p.w_poseB = ds->wt_poseB * a; p.w_poseH = ds->wt_poseH * a;
+        p.w_beta = ds->wt_betas * a; p.w_surf = ds->wt_surf;
+        hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
+        if (d.nfinger) hipMemcpyAsync(d_finger, finger_ids.data(), d.nfinger * sizeof(int), hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
+        const int n = d.n, R = d.R;
+        auto pack = [&](std::vector<double>& xx) {
+            xx.resize(n);
+            for (int f = 0; f < F; ++f) for (int c = 0; c < 3; ++c) xx[3 * f + c] = trans[3 * f + c];
+            for (int i = 0; i < 3 * M; ++i) xx[d.o_ml + i] = ml[i];
+            for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) xx[d.o_pose + f * d.npid + c] = pose[(size_t)f * NP + pose_ids[c]];
+            for (int e = 0; e < nb; ++e) xx[d.o_b + e] = betas[e];
+        };
+        auto unpack = [&](const std::vector<double>& xx) {
+            for (int f = 0; f < F; ++f) for (int c = 0; c < 3; ++c) trans[3 * f + c] = xx[3 * f + c];
+            for (int i = 0; i < 3 * M; ++i) ml[i] = xx[d.o_ml + i];
+            for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) pose[(size_t)f * NP + pose_ids[c]] = xx[d.o_pose + f * d.npid + c];
+            for (int e = 0; e < nb; ++e) betas[e] = xx[d.o_b + e];
+        };
+        auto eval_at = [&](const std::vector<double>& xx, int want_J, std::vector<double>& rr) {
+            unpack(xx); upload_point(); evaluate(want_J); fetch(rr, p.r, R);
+        };
+        auto normal_eq = [&]() {     // A = J^T J, g = -J^T r on the device; g to the host
+            int nt = (n + S1_T - 1) / S1_T;
+            LAUNCH(k_s1_syrk, nt, nt, 256, st, p.Jm, R, n, d.ldn, d_A);
+            LAUNCH(k_s1_gemv_t, (n + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, p.Jm, p.r, R, n, d.ldn, -1.0, d_g);
+            fetch(g, d_g, n);
+        };
+        auto Ax = [&](const std::vector<double>& v, std::vector<double>& out) {   // A . v (A must still be unfactored)
+            hipMemcpyAsync(d_vec, v.data(), n * 8, hipMemcpyHostToDevice, st);
+            LAUNCH(k_s1_gemv, n, 1, S1_TPB, st, d_A, d_vec, n, n, d_out);
+            fetch(out, d_out, n);
+        };
+        // ---- Powell dogleg (chumpy minimize_dogleg as restated in oracle/stageii_oracle.py:minimize_dogleg)
+        const double e1 = 1e-15, e2 = 1e-15, e3 = ds->stagei_lr;
+        pack(x);
+        eval_at(x, 1, r);
+        normal_eq();
+        double delta = 0.5;
+        bool done = false;
+        int iteration = 0;
+        auto norminf = [](const std::vector<double>& v) { double s = 0; for (double t : v) s = std::max(s, fabs(t)); return s; };
+        if (norminf(g) < e1) done = true;
+        std::vector<double> Ag, xt;
+        while (!done) {
+            ++iteration;
+            // |J g|^2 = g^T A g
+            Ax(g, Ag);
+            double gg = dotv(g, g), gAg = dotv(g, Ag);
+            dsd = g;
+            for (double& t : dsd) t *= gg / gAg;
+            bool have_gn = false;
+            while (true) {
+                double nsd = nrm2(dsd);
+                if (nsd >= delta) { ddl = dsd; for (double& t : ddl) t *= delta / nsd; }
+                else {
+                    if (!have_gn) {
+                        // the factorisation overwrites A: keep a copy for the rho denominator products
+                        hipMemcpyAsync(d_L, d_A, (size_t)n * n * 8, hipMemcpyDeviceToDevice, st);
+                        LAUNCH(k_s1_chol_solve, 1, 1, S1_CHOL_TPB, st, d_L, n, d_g, d_out, p.status);
+                        fetch(dgn, d_out, n);
+                        have_gn = true;
+                    }
+                    double ngn = nrm2(dgn);
+                    if (ngn <= delta) ddl = dgn;
+                    else {
+                        double dsq = delta * delta, sq_sd = nsd * nsd, dd = 0, dsdd = 0;
+                        for (int i = 0; i < n; ++i) { double df = dgn[i] - dsd[i]; dd += df * df; dsdd += df * dsd[i]; }
+                        double gs = dotv(dgn, dsd);
+                        double pnow = dd * dsq + gs * gs - ngn * ngn * sq_sd;
+                        double beta = (dsq - sq_sd) / (dsdd + sqrt(pnow));
+                        ddl.resize(n);
+                        for (int i = 0; i < n; ++i) ddl[i] = dsd[i] + beta * (dgn[i] - dsd[i]);
+                    }
+                }
+                double step = nrm2(ddl);
+                bool improved = false;
+                if (step <= e2 * nrm2(x)) done = true;
+                else {
+                    xt = x;
+                    for (int i = 0; i < n; ++i) xt[i] += ddl[i];
+                    eval_at(xt, 0, rnew);
+                    double sse = dotv(r, r), sse_new = dotv(rnew, rnew);
+                    double rho = sse - sse_new;
+                    if (rho > 0) {
+                        Ax(ddl, tmp);
+                        rho = rho / (2.0 * dotv(g, ddl) - dotv(ddl, tmp));
+                    }
+                    improved = rho > 0;
+                    if (improved) {
+                        x = xt;
+                        if (e3 > 0 && (sse - sse_new) / sse < e3) done = true;
+                        else {
+                            eval_at(x, 1, r);
+                            normal_eq();
+                            if (norminf(g) < e1) done = true;
+                        }
+                    }
+                    if (rho > 0.9) delta = std::max(delta, 2.5 * step);
+                    else if (rho < 0.05) delta *= 0.25;
+                    if (delta <= e2 * nrm2(x)) done = true;
+                }
+                if (done || improved) break;
+            }
+            if (iteration >= ds->maxiter) done = true;
+        }
+        total_iters += iteration;
+        unpack(x);
+        if (round == ds->n_anneal - 1) {
+            upload_point(); evaluate(0); fetch(r, p.r, R);
+            auto sse = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
+            if (ds->errs) {
+                ds->errs[0] = sse(d.r_data, d.r_prior); ds->errs[1] = sse(d.r_prior, d.r_init); ds->errs[2] = sse(d.r_init, d.r_beta);
+                ds->errs[3] = sse(d.r_beta, d.r_surf); ds->errs[4] = sse(d.r_surf, d.r_poseH); ds->errs[5] = sse(d.r_poseH, d.R);
+            }
+        }
+        int hstat[4];
+        hipMemcpyAsync(hstat, p.status, sizeof(hstat), hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        if (hstat[0] == 3) return fail(MOSHII_ERR_ARG, "stagei: a vertex has more than 16 non-zero skinning weights");
+        if (hstat[1]) return fail(MOSHII_ERR_NUMERIC, "stagei: normal equations not positive definite");
+        if (hstat[2]) return fail(MOSHII_ERR_NUMERIC, "stagei: the three nearest vertices of a marker are collinear (the reference falls back to the next neighbour, transformed_lm.py:94-101; not implemented)");
+    }
+    if (hipGetLastError() != hipSuccess) return fail(MOSHII_ERR_HIP, "stagei: kernel launch failed");
+    // ---- outputs; nearest canonical vertex of every latent marker (chmosh.py:420-422)
+    upload_point(); canonical();
+    fetch(can, p.can, (size_t)3 * d.V);
+    for (int m = 0; m < M; ++m) {
+        double best = 1e300; int bi = 0;
+        for (int v = 0; v < d.V; ++v) {
+            double s = 0;
+            for (int a = 0; a < 3; ++a) { double t = ml[3 * m + a] - can[3 * v + a]; s += t * t; }
+            if (s < best) { best = s; bi = v; }
+        }
+        if (ds->markers_latent_vids) ds->markers_latent_vids[m] = bi;
+    }
+    if (ds->betas) for (int e = 0; e < nb; ++e) ds->betas[e] = betas[e];
+    if (ds->markers_latent) memcpy(ds->markers_latent, ml.data(), 3 * M * 8);
+    if (ds->pose) memcpy(ds->pose, pose.data(), (size_t)F * NP * 8);
+    if (ds->trans) memcpy(ds->trans, trans.data(), (size_t)F * 3 * 8);
+    if (ds->iters) ds->iters[0] = total_iters;
+    return MOSHII_OK;
+}

@@ -126,45 +126,9 @@ def _dist_to_segments(pts, a, b):
     return np.sqrt(((pts[:, None, :] - proj) ** 2).sum(-1))
 
 
-def synth_model(model_type, seed=0, num_betas=16, chunk=2048):
-    """A synthetic body model with the exact topology sizes of `model_type`, in the layout of the
-    reference's model pickles (keys as read by smpl_fast_derivatives.py:52-166)."""
-    V, K = MODEL_DIMS[model_type]
-    rng = np.random.default_rng(seed + 7919 * (list(MODEL_DIMS).index(model_type) + 1))
-    parents = kintree_parents(model_type)
-    J0 = rest_joints(model_type)
-    assert J0.shape[0] == K, (J0.shape, K)
-    seg_a, seg_b = _segments(J0, parents)
-    rad = np.array([_bone_radius(model_type, j, K) for j in range(K)])
-    length = np.linalg.norm(seg_b - seg_a, axis=1)
-    area = (length + 2 * rad) * rad
-    counts = np.floor(area / area.sum() * V).astype(int)
-    counts = np.maximum(counts, 6)
-    while counts.sum() > V:
-        counts[np.argmax(counts)] -= 1
-    while counts.sum() < V:
-        counts[rng.integers(K)] += 1
-    verts = []
-    for j in range(K):
-        n = counts[j]
-        t = rng.uniform(-0.15, 1.15, n)
-        axis = seg_b[j] - seg_a[j]
-        axis_n = axis / np.linalg.norm(axis)
-        ref = np.array([0.0, 0.0, 1.0]) if abs(axis_n[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
-        u = np.cross(axis_n, ref); u /= np.linalg.norm(u)
-        w = np.cross(axis_n, u)
-        ang = rng.uniform(0, 2 * np.pi, n)
-        rr = rad[j] * (0.9 + 0.2 * rng.random(n))
-        # round the caps
-        cap = np.clip(np.minimum(t + 0.15, 1.15 - t) / 0.15, 0.0, 1.0)
-        rr = rr * np.sqrt(0.15 + 0.85 * cap)
-        p = seg_a[j][None] + t[:, None] * axis[None] + rr[:, None] * (np.cos(ang)[:, None] * u[None]
-                                                                         + np.sin(ang)[:, None] * w[None])
-        verts.append(p)
-    v_template = np.vstack(verts)
-    perm = rng.permutation(V)
-    v_template = v_template[perm]
-
+def _skin_and_blend(model_type, v_template, J0, seg_a, seg_b, rad, rng, num_betas, chunk):
+    """Skinning weights, outward directions, joint regressor and blendshapes for a vertex set around the skeleton."""
+    V, K = v_template.shape[0], J0.shape[0]
     # skinning weights: <= 4 nonzeros per vertex, rows sum to 1
     weights = np.zeros((V, K))
     outward = np.zeros((V, 3))
@@ -211,11 +175,143 @@ def synth_model(model_type, seed=0, num_betas=16, chunk=2048):
         g = 0.002 * np.exp(-d2 / (2 * sig * sig)) + 2e-5
         posedirs[:, :, 9 * (k - 1):9 * k] = g[:, None, None] * rng.normal(0, 1, (V, 3, 9))
 
+    return weights, outward, J_regressor, shapedirs, posedirs
+
+
+def synth_model(model_type, seed=0, num_betas=16, chunk=2048):
+    """A synthetic body model with the exact topology sizes of `model_type`, in the layout of the
+    reference's model pickles (keys as read by smpl_fast_derivatives.py:52-166)."""
+    V, K = MODEL_DIMS[model_type]
+    rng = np.random.default_rng(seed + 7919 * (list(MODEL_DIMS).index(model_type) + 1))
+    parents = kintree_parents(model_type)
+    J0 = rest_joints(model_type)
+    assert J0.shape[0] == K, (J0.shape, K)
+    seg_a, seg_b = _segments(J0, parents)
+    rad = np.array([_bone_radius(model_type, j, K) for j in range(K)])
+    length = np.linalg.norm(seg_b - seg_a, axis=1)
+    area = (length + 2 * rad) * rad
+    counts = np.floor(area / area.sum() * V).astype(int)
+    counts = np.maximum(counts, 6)
+    while counts.sum() > V:
+        counts[np.argmax(counts)] -= 1
+    while counts.sum() < V:
+        counts[rng.integers(K)] += 1
+    verts = []
+    for j in range(K):
+        n = counts[j]
+        t = rng.uniform(-0.15, 1.15, n)
+        axis = seg_b[j] - seg_a[j]
+        axis_n = axis / np.linalg.norm(axis)
+        ref = np.array([0.0, 0.0, 1.0]) if abs(axis_n[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        u = np.cross(axis_n, ref); u /= np.linalg.norm(u)
+        w = np.cross(axis_n, u)
+        ang = rng.uniform(0, 2 * np.pi, n)
+        rr = rad[j] * (0.9 + 0.2 * rng.random(n))
+        # round the caps
+        cap = np.clip(np.minimum(t + 0.15, 1.15 - t) / 0.15, 0.0, 1.0)
+        rr = rr * np.sqrt(0.15 + 0.85 * cap)
+        p = seg_a[j][None] + t[:, None] * axis[None] + rr[:, None] * (np.cos(ang)[:, None] * u[None]
+                                                                         + np.sin(ang)[:, None] * w[None])
+        verts.append(p)
+    v_template = np.vstack(verts)
+    perm = rng.permutation(V)
+    v_template = v_template[perm]
+
+    weights, outward, J_regressor, shapedirs, posedirs = _skin_and_blend(model_type, v_template, J0, seg_a, seg_b, rad, rng,
+                                                                         num_betas, chunk)
     kintree_table = np.vstack([np.where(parents < 0, 4294967295, parents), np.arange(K)]).astype(np.int64)
     dd = dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, weights=weights,
               J_regressor=J_regressor, kintree_table=kintree_table, bs_style='lbs', bs_type='lrotmin',
               f=np.zeros((0, 3), dtype=np.int64), model_type=model_type,
               _outward=outward, _rest_joints=J0)
+    if model_type == 'mano':
+        q, _ = np.linalg.qr(rng.normal(0, 1, (45, 45)))
+        dd['hands_components'] = q
+        dd['hands_mean'] = rng.normal(0, 0.08, 45)
+    return dd
+
+
+def _capsule_mesh(a, b, R, n_target):
+    """Closed capsule around the segment a->b: two poles, rings of `ns` vertices over both caps and the cylinder.
+    Returns vertices [n,3] and outward-wound triangles [t,3]."""
+    axis = b - a
+    L = np.linalg.norm(axis)
+    ax = axis / L
+    ref = np.array([0.0, 0.0, 1.0]) if abs(ax[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
+    u = np.cross(ax, ref); u /= np.linalg.norm(u)
+    w = np.cross(ax, u)
+    ns = int(np.clip(round(np.sqrt(max(n_target, 8) * 2 * np.pi * R / (L + np.pi * R))), 6, 48))
+    nr = max(5, int(round((n_target - 2) / ns)))
+    nh = max(2, int(round(nr * (0.5 * np.pi * R) / (L + np.pi * R))))     # rings per cap
+    nc = max(1, nr - 2 * nh)                                               # rings on the cylinder (incl. both rims)
+    rings = []
+    for i in range(nh):                                                    # cap at a: polar angle from the pole
+        ph = 0.5 * np.pi * (i + 1) / (nh + (0 if nc > 1 else 1))
+        rings.append((a - R * np.cos(ph) * ax, R * np.sin(ph)))
+    for i in range(nc):
+        t = (i + 0.5) / nc if nc > 1 else 0.5
+        rings.append((a + t * axis, R))
+    for i in range(nh - 1, -1, -1):
+        ph = 0.5 * np.pi * (i + 1) / (nh + (0 if nc > 1 else 1))
+        rings.append((b + R * np.cos(ph) * ax, R * np.sin(ph)))
+    th = 2 * np.pi * np.arange(ns) / ns
+    circ = np.cos(th)[:, None] * u[None] + np.sin(th)[:, None] * w[None]
+    v = [a - R * ax] + [c[None] + r * circ for c, r in rings] + [b + R * ax]
+    v = np.vstack([x.reshape(-1, 3) for x in v])
+    f = []
+    ring0 = lambda i: 1 + i * ns
+    for k in range(ns):
+        k1 = (k + 1) % ns
+        f.append([0, ring0(0) + k1, ring0(0) + k])
+        last = ring0(len(rings) - 1)
+        f.append([len(v) - 1, last + k, last + k1])
+        for i in range(len(rings) - 1):
+            p, q = ring0(i), ring0(i + 1)
+            f.append([p + k, p + k1, q + k1])
+            f.append([p + k, q + k1, q + k])
+    f = np.array(f, dtype=np.int64)
+    # wind every triangle outward (normal pointing away from the axis)
+    cen = v[f].mean(1)
+    tpar = np.clip((cen - a).dot(ax), 0, L)
+    out = cen - (a[None] + tpar[:, None] * ax[None])
+    nrm = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    flip = (nrm * out).sum(1) < 0
+    f[flip] = f[flip][:, [0, 2, 1]]
+    return v, f
+
+
+def synth_mesh_model(model_type, seed=0, num_betas=16, n_verts=None, chunk=2048):
+    """Like synth_model but with a triangulated surface (`f`), as Stage-I needs one (vertex normals, point-to-surface
+    distance): one closed capsule per bone, vertex count close to (not exactly) the family's V.  Same skeleton, radii,
+    skinning / regressor / blendshape construction as synth_model."""
+    V, K = MODEL_DIMS[model_type]
+    V = V if n_verts is None else int(n_verts)
+    rng = np.random.default_rng(seed + 104729 * (list(MODEL_DIMS).index(model_type) + 1))
+    parents = kintree_parents(model_type)
+    J0 = rest_joints(model_type)
+    seg_a, seg_b = _segments(J0, parents)
+    rad = np.array([_bone_radius(model_type, j, K) for j in range(K)])
+    length = np.linalg.norm(seg_b - seg_a, axis=1)
+    area = (length + 2 * rad) * rad
+    counts = np.maximum(np.floor(area / area.sum() * V).astype(int), 32)
+    vs, fs, off = [], [], 0
+    for j in range(K):
+        v, f = _capsule_mesh(seg_a[j], seg_b[j], rad[j], counts[j])
+        vs.append(v); fs.append(f + off); off += len(v)
+    v_template = np.vstack(vs)
+    v_template += rng.normal(0, 0.0006, v_template.shape)   # breaks the exact collinearity of the ring / generator grid
+    faces = np.vstack(fs)
+    weights, outward, J_regressor, shapedirs, posedirs = _skin_and_blend(model_type, v_template, J0, seg_a, seg_b, rad, rng,
+                                                                         num_betas, chunk)
+    kintree_table = np.vstack([np.where(parents < 0, 4294967295, parents), np.arange(K)]).astype(np.int64)
+    dd = dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, weights=weights,
+              J_regressor=J_regressor, kintree_table=kintree_table, bs_style='lbs', bs_type='lrotmin',
+              f=faces, model_type=model_type, _outward=outward, _rest_joints=J0)
+    # vertices not buried inside another bone's capsule: where markers may sit
+    d = _dist_to_segments(v_template, seg_a, seg_b) - rad[None]
+    own = np.repeat(np.arange(K), [len(x) for x in vs])
+    d[np.arange(len(own)), own] = np.inf
+    dd['_exposed'] = d.min(1) > 0.02
     if model_type == 'mano':
         q, _ = np.linalg.qr(rng.normal(0, 1, (45, 45)))
         dd['hands_components'] = q

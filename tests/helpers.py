@@ -110,3 +110,66 @@ def shape_case(model_type='smplx', F=6, M=40, E=6, seed=0, kind='expr', boost=6.
     prior = so.prepare_gmm_prior(s['gmm'], npose)
     return dict(s=s, m=m, model=model, can=can, closest=closest, coef=coef, prior=prior, obs=obs, vis=vis,
                 model_type=model_type, shp_gt=shp_gt, pose_gt=pose_gt, E=E, start=16, kind=kind)
+
+
+# ---- Stage-I ----------------------------------------------------------------------------------------------------
+def stagei_case(model_type='smplh', n_verts=2500, nb=6, M=30, F=6, seed=0, dof_per_hand=12, finger_markers=False):
+    """A seeded Stage-I problem on the triangulated synthetic body (synth.synth_mesh_model): ground-truth betas, latent markers
+    displaced a few millimetres from their layout positions, F observed frames with dropouts."""
+    from oracle import stagei_oracle as s1
+    rng = np.random.default_rng(seed)
+    dd = synth.synth_mesh_model(model_type, seed=seed, num_betas=10, n_verts=n_verts)
+    K = dd['weights'].shape[1]
+    parents = synth.kintree_parents(model_type)
+    hp = synth.synth_hand_prior(seed)
+    body_dof = 3 * K - 90
+    comps = np.zeros((2 * dof_per_hand, 90))
+    comps[:dof_per_hand, :45] = hp['componentsl'][:dof_per_hand]
+    comps[dof_per_hand:, 45:] = hp['componentsr'][:dof_per_hand]
+    model = dict(v_template=dd['v_template'], shapedirs=dd['shapedirs'], posedirs=dd['posedirs'], weights=dd['weights'],
+                 J_regressor=dd['J_regressor'], parents=parents, body_dof=body_dof, hand_dof=2 * dof_per_hand,
+                 hands_mean=np.zeros(90), selected_components=comps)
+    m = so.prepare_model(model)
+    so.set_free_shape(m, 0, nb)
+    prior = so.prepare_gmm_prior(synth.synth_gmm_prior(seed), 63)
+    dom = np.argmax(dd['weights'], 1)
+    ok = dd['_exposed'] & ((dom <= 21) | finger_markers)
+    cand = np.flatnonzero(ok)
+    v = dd['v_template']
+    vids = [cand[rng.integers(len(cand))]]
+    dmin = ((v[cand] - v[vids[0]]) ** 2).sum(1)
+    for _ in range(M - 1):
+        nxt = cand[int(np.argmax(dmin))]
+        vids.append(nxt)
+        dmin = np.minimum(dmin, ((v[cand] - v[nxt]) ** 2).sum(1))
+    vids = np.array(vids)
+    betas_gt = rng.normal(0, 0.8, nb)
+    fp_can = so.fullpose_from_pose(m, np.zeros(m['NP']))
+    can_gt = so.verts_forward(m, fp_can, np.zeros(3), None, shp=betas_gt)
+    m2b = np.ones(M) * 0.0095
+    ml_gt = s1.markers_latent_init(can_gt, dd['f'], vids, m2b) + rng.normal(0, 0.004, (M, 3))
+    cl, coef = so.transformed_coeffs(can_gt, ml_gt)
+    pose_gt, trans_gt = synth.synth_motion(m['NP'], body_dof, 400, seed=seed)
+    frames = []
+    for t in np.linspace(60, 399, F).astype(int):
+        p = pose_gt[t].copy()
+        if not finger_markers:
+            p[body_dof:] = 0
+        p[30:36] = 0
+        vv = so.verts_forward(m, so.fullpose_from_pose(m, p), trans_gt[t], cl.reshape(-1), shp=betas_gt).reshape(M, 3, 3)
+        sim = so.markers_from_verts(coef, vv[:, 0], vv[:, 1], vv[:, 2]) + rng.normal(0, 0.0003, (M, 3))
+        ids = np.flatnonzero(rng.random(M) > 0.05)
+        frames.append((ids, sim[ids]))
+    return dict(m=m, model=model, faces=dd['f'], prior=prior, frames=frames, vids=vids, betas_gt=betas_gt, ml_gt=ml_gt, nb=nb, M=M,
+                mask={'body': np.ones(M, bool)}, m2b={'body': 0.0095}, model_type=model_type, dd=dd)
+
+
+def stagei_kwargs(case, optimize_fingers=False):
+    """The arguments of capi.stagei_desc for a stagei_case (reference default weights)."""
+    from oracle import stagei_oracle as s1
+    m = case['m']
+    root, body, finger, step1, _ = so.pose_id_sets(case['model_type'], m['NP'], optimize_fingers=optimize_fingers)
+    M = case['M']
+    W = s1.stagei_weights_default()
+    return dict(faces=case['faces'], marker_vids=case['vids'], m2b=np.ones(M) * 0.0095, wt_init=np.ones(M) * W['stagei_wt_init'],
+                frames=case['frames'], nb=case['nb'], weights=W, pose_ids=step1, body_ids=body, finger_ids=finger)

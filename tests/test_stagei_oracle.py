@@ -1,0 +1,104 @@
+"""Stage-I oracle self-checks (oracle/stagei_oracle.py) and the arithmetic of the Stage-I kernels, run through the g++ emulation build
+of moshpp_amd/csrc/stagei.hip (tests/emu): same source as the GPU library, one sequential "thread" per block."""
+import numpy as np
+import pytest
+
+from oracle import stageii_oracle as so
+from oracle import stagei_oracle as s1
+from tests import helpers
+
+
+@pytest.fixture(scope='module')
+def case():
+    return helpers.stagei_case()
+
+
+def _objective(case, fingers=True):
+    m, M, nb = case['m'], case['M'], case['nb']
+    m2b = np.ones(M) * 0.0095
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3), None, shp=np.zeros(nb))
+    ml0 = s1.markers_latent_init(can, case['faces'], case['vids'], m2b)
+    root, body, finger, step1, step2 = so.pose_id_sets('smplh', m['NP'], optimize_fingers=fingers)
+    obj = s1.StageIObjective(m, case['faces'], case['prior'], body, case['frames'], ml0, m2b, [(np.arange(M), 300.0)], nb)
+    rng = np.random.default_rng(3)
+    obj.pose[:, step2] = rng.normal(0, 0.2, (obj.F, len(step2)))
+    obj.trans[:] = rng.normal(0, 0.3, (obj.F, 3))
+    obj.betas = rng.normal(0, 0.5, nb)
+    obj.ml = ml0 + rng.normal(0, 0.003, ml0.shape)
+    a = 0.5
+    obj.set_round(step2, finger, dict(anneal=a, data=(75 / a) * (46.0 / M), poseB=3 * a, poseH=3 * a, beta=10 * a, surf=1e4,
+                                      init_head=300 * a))
+    return obj
+
+
+def test_markers_start_at_the_skin_distance(case):
+    m = case['m']
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3), None, shp=np.zeros(case['nb']))
+    ml = s1.markers_latent_init(can, case['faces'], case['vids'], np.ones(case['M']) * 0.0095)
+    d, tri, part = s1.signed_surface_distance(ml, can, case['faces'])
+    assert (d <= 0.0095 + 1e-12).all() and (d > 0.009).all()   # a vertex pushed out along its normal: at most 9.5 mm from the surface
+
+
+def test_surface_distance_gradients_match_finite_differences(case):
+    m = case['m']
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3), None, shp=np.zeros(case['nb']))
+    rng = np.random.default_rng(1)
+    ml = s1.markers_latent_init(can, case['faces'], case['vids'], np.ones(case['M']) * 0.0095)
+    pts = ml + rng.normal(0, 0.01, ml.shape)                  # both sides of the surface, all part types
+    d, tri, part, dp, dabc, fv = s1.signed_surface_distance(pts, can, case['faces'], want_jac=True)
+    assert len(np.unique(part)) >= 3 and (d < 0).any() and (d > 0).any()
+    h = 1e-7
+    for k in range(3):
+        e = np.zeros(3); e[k] = h
+        fd = (s1.signed_surface_distance(pts + e, can, case['faces'])[0] - s1.signed_surface_distance(pts - e, can, case['faces'])[0]) / (2 * h)
+        assert np.abs(fd - dp[:, k]).max() < 1e-6
+    dv = rng.normal(0, 1, can.shape)
+    fd = (s1.signed_surface_distance(pts, can + h * dv, case['faces'])[0] - s1.signed_surface_distance(pts, can - h * dv, case['faces'])[0]) / (2 * h)
+    assert np.abs(fd - np.einsum('mva,mva->m', dabc, dv[fv])).max() < 1e-6
+
+
+def test_objective_jacobian_matches_finite_differences(case):
+    obj = _objective(case)
+    x = obj.x()
+    res, jac = obj.evaluate(x, want_J=True)
+    F, M, npid = obj.F, obj.M, len(obj.pose_ids)
+    blocks = {'trans': (0, 3 * F), 'ml': (3 * F, 3 * F + 3 * M), 'pose': (3 * F + 3 * M, 3 * F + 3 * M + F * npid),
+              'beta': (3 * F + 3 * M + F * npid, len(x))}
+    rng = np.random.default_rng(5)
+    h = 1e-6
+    for s, e in blocks.values():
+        d = np.zeros(len(x)); d[s:e] = rng.normal(0, 1, e - s)
+        rp, rm = obj.evaluate(x + h * d), obj.evaluate(x - h * d)
+        for name in res:
+            fd = (rp[name] - rm[name]) / (2 * h)
+            an = jac[name].dot(d)
+            assert np.abs(fd - an).max() < 1e-6 * max(1.0, np.abs(an).max()) + 2e-3 * (name == 'surf'), (name, s, e)
+
+
+def test_stagei_fits_the_frames(case):
+    out = s1.stagei_solve(case['m'], case['faces'], case['prior'], 'smplh', case['frames'], case['vids'], case['mask'], case['m2b'],
+                          case['nb'])
+    obj = out['objective']
+    for f, (ids, obs) in enumerate(obj.frames):
+        assert np.sqrt(((obj.markers_sim(f)[ids] - obs) ** 2).sum(1).mean()) < 5e-3
+    d = s1.signed_surface_distance(out['markers_latent'], obj.can_verts(out['betas']), case['faces'])[0]
+    assert np.abs(d - 0.0095).max() < 2e-3                    # the surface term keeps the markers near their skin distance
+    assert np.linalg.norm(out['markers_latent'] - case['ml_gt'], axis=1).mean() < 0.012
+
+
+@pytest.mark.parametrize('fingers', [False, True])
+def test_kernel_arithmetic_matches_oracle_in_emulation(case, fingers):
+    """stagei.hip compiled by g++ (tests/emu): same kernels and host dogleg as the GPU library, bit-for-bit the same control flow."""
+    from tests.emu import emu_stagei
+    c = case if not fingers else helpers.stagei_case(finger_markers=True, M=36, seed=2)
+    kw = helpers.stagei_kwargs(c, optimize_fingers=fingers)
+    out = emu_stagei.solve(c['m'], c['prior'], **kw)
+    ref = s1.stagei_solve(c['m'], c['faces'], c['prior'], 'smplh', c['frames'], c['vids'], c['mask'], c['m2b'], c['nb'],
+                          optimize_fingers=fingers)
+    assert np.abs(out['betas'] - ref['betas']).max() < 1e-8
+    assert np.abs(out['markers_latent'] - ref['markers_latent']).max() < 1e-9
+    assert np.abs(out['pose'] - ref['pose']).max() < 1e-8 and np.abs(out['trans'] - ref['trans']).max() < 1e-9
+    assert (out['markers_latent_vids'] == ref['markers_latent_vids']).all()
+    e = ref['errs']
+    want = [e['data'], e['poseB'], e['init_0'], e['beta'], e['surf'], e.get('poseH', 0.0)]
+    assert np.allclose(out['errs'], want, rtol=1e-7, atol=1e-12)
