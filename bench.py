@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--verify-tol', type=float, default=1e-9)
     ap.add_argument('--cpu-sample', type=int, default=400, help='frames of the workload timed on the CPU oracle')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-stagei', action='store_true', help='skip the Stage-I leg')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
     ap.add_argument('--spread-seeds', default='5,71', help='extra leg: the same workload generated from these seeds ("" to skip)')
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
@@ -317,6 +318,35 @@ def main():
                                 'marker_rmse_m': float(np.sqrt(np.concatenate(sqd).mean())),
                                 'tolerance': {'pose_rad': 1e-4, 'marker_rmse_m': 1e-3}}
             result['speedup_vs_cpu_port'] = round(value / max(n_ref / tc, 1e-9), 1)
+        # ---- Stage-I leg (BASELINE config 4's calibration part): 12 picked frames, 53 markers, 10 betas on a
+        #      triangulated SMPL-H-sized body; the joint solve on the GPU beside the NumPy oracle on the host
+        if not args.no_stagei:
+            try:
+                from moshpp_amd import capi
+                from tests import helpers
+                c1 = helpers.stagei_case(n_verts=6890, nb=10, M=53, F=12, seed=1, dof_per_hand=24)
+                mdl = c1['model']
+                dev1 = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'],
+                                  mdl['parents'], mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
+                pr1 = capi.Prior(c1['prior']['means'], c1['prior']['chols'], c1['prior']['weights'])
+                kw1 = helpers.stagei_kwargs(c1)
+                capi.stagei_solve_host(dev1, pr1, **kw1)
+                ts = []
+                for _ in range(3):
+                    t1 = time.perf_counter(); o1 = capi.stagei_solve_host(dev1, pr1, **kw1); ts.append(time.perf_counter() - t1)
+                leg = {'workload': f"12 frames, 53 markers, 10 betas, V={mdl['v_template'].shape[0]}, {len(c1['faces'])} triangles",
+                       'unknowns': int(3 * 12 + 3 * 53 + 12 * len(kw1['pose_ids']) + 10), 'seconds': round(float(np.median(ts)), 4),
+                       'dogleg_iterations': o1['iters']}
+                if not args.no_cpu:
+                    from oracle import stagei_oracle as s1o
+                    t1 = time.perf_counter()
+                    r1 = s1o.stagei_solve(c1['m'], c1['faces'], c1['prior'], 'smplh', c1['frames'], c1['vids'], c1['mask'], c1['m2b'], c1['nb'])
+                    leg['cpu_oracle_seconds'] = round(time.perf_counter() - t1, 2)
+                    leg['max_abs_betas_diff'] = float(np.abs(o1['betas'] - r1['betas']).max())
+                    leg['max_abs_markers_latent_diff_m'] = float(np.abs(o1['markers_latent'] - r1['markers_latent']).max())
+                result['stagei'] = leg
+            except Exception as e:
+                result['stagei'] = {'error': repr(e)}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

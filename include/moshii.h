@@ -246,7 +246,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
  * :417-447.  The marker attachment (TransformedCoeffs, transformed_lm.py:59-113) is re-evaluated at every evaluation
  * point, as the reference's dependency graph does.  All buffers are HOST pointers (the problem is a few kilobytes);
  * the model's own betas (moshii_model_set_betas) are ignored: the solve works on v_template + shapedirs[:, :, :nb].betas.
- * Not covered: head-marker correlation term (:252-266), per-frame expressions (optimize_face).
+ * Not covered: per-frame expressions in Stage-I (optimize_face), opt_settings.extra_initial_rigid_adjustment.
  * ------------------------------------------------------------------------------------------- */
 typedef struct moshii_stagei_desc {
     int32_t n_frames, M, n_faces, nb;       /* picked frames, latent markers, triangles, free betas             */
@@ -269,6 +269,10 @@ typedef struct moshii_stagei_desc {
     int32_t        n_body;
     const int32_t* finger_ids;              /* added (with poseH) in the last two rounds (:390-393); may be empty */
     int32_t        n_finger;
+    const int32_t* head_ids;                /* [n_head] latent ids of the head markers, or NULL: no correlation term */
+    const double*  head_corr;               /* [n_head_rows][n_head] `corr` of head_marker_corr_fname (:252-266, 362-369) */
+    int32_t        n_head, n_head_rows;
+    double         wt_init_head;            /* stagei_wt_init_body if the layout has a 'body' type, else stagei_wt_init */
     int32_t        maxiter;                 /* cfg.opt_settings.maxiter                                          */
     double         stagei_lr;               /* cfg.opt_settings.stagei_lr (dogleg e_3)                           */
     /* outputs */
@@ -277,7 +281,7 @@ typedef struct moshii_stagei_desc {
     int32_t* markers_latent_vids;           /* [M] nearest canonical vertex of each latent marker (:420-422)     */
     double*  pose;                          /* [n_frames][NP]                                                    */
     double*  trans;                         /* [n_frames][3]                                                     */
-    double*  errs;                          /* [6] SSE of data, poseB, init, beta, surf, poseH at the solution   */
+    double*  errs;                          /* [7] SSE of data, poseB, init, beta, surf, poseH, init_head_corr   */
     int32_t* iters;                         /* [1] dogleg outer iterations over all rounds                       */
 } moshii_stagei_desc;
 

@@ -403,16 +403,18 @@ class StageIDesc(C.Structure):
                 ('wt_data', C.c_double), ('wt_poseB', C.c_double), ('wt_poseH', C.c_double), ('wt_betas', C.c_double),
                 ('wt_surf', C.c_double), ('annealing', C.c_void_p), ('n_anneal', C.c_int32),
                 ('pose_ids', C.c_void_p), ('n_pose_ids', C.c_int32), ('body_ids', C.c_void_p), ('n_body', C.c_int32),
-                ('finger_ids', C.c_void_p), ('n_finger', C.c_int32), ('maxiter', C.c_int32), ('stagei_lr', C.c_double),
+                ('finger_ids', C.c_void_p), ('n_finger', C.c_int32),
+                ('head_ids', C.c_void_p), ('head_corr', C.c_void_p), ('n_head', C.c_int32), ('n_head_rows', C.c_int32),
+                ('wt_init_head', C.c_double), ('maxiter', C.c_int32), ('stagei_lr', C.c_double),
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
                 ('pose', C.c_void_p), ('trans', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p)]
 
 
-STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH')
+STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH', 'init_head_corr')
 
 
 def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_ids, body_ids, finger_ids=(), exclude_vids=None,
-                betas_init=None, maxiter=100, stagei_lr=1e-3):
+                betas_init=None, maxiter=100, stagei_lr=1e-3, head_corr=None, wt_init_head=None):
     """Fill a StageIDesc from NumPy data.  `frames`: list of (latent ids, obs[n,3]).  Returns (desc, outputs dict, keep-alive list)."""
     keep = []
 
@@ -438,8 +440,14 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
     d.body_ids = ptr(body_ids, np.int32); d.n_body = len(body_ids)
     d.finger_ids = ptr(list(finger_ids), np.int32); d.n_finger = len(finger_ids)
     d.maxiter, d.stagei_lr = int(maxiter), float(stagei_lr)
+    if head_corr is not None:
+        hid, Cm = head_corr
+        Cm = np.atleast_2d(np.asarray(Cm, np.float64))
+        assert Cm.shape[1] == len(hid)
+        d.head_ids = ptr(hid, np.int32); d.head_corr = ptr(Cm, np.float64); d.n_head, d.n_head_rows = Cm.shape[1], Cm.shape[0]
+    d.wt_init_head = float(weights['stagei_wt_init'] if wt_init_head is None else wt_init_head)
     out = dict(betas=np.zeros(max(nb, 1)), markers_latent=np.zeros((M, 3)), markers_latent_vids=np.zeros(M, np.int32),
-               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), errs=np.zeros(6), iters=np.zeros(1, np.int32))
+               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), errs=np.zeros(7), iters=np.zeros(1, np.int32))
     for k, v in out.items():
         setattr(d, k, v.ctypes.data)
     out['betas'] = out['betas'][:nb]

@@ -22,6 +22,19 @@ STAGEII_WEIGHTS = {   # moshpp_conf.yaml:118-125 (smplh == smplx), :166-173 (smp
 }
 
 
+_STAGEI = dict(stagei_wt_poseH=3.0, stagei_wt_poseF=3.0, stagei_wt_expr=34.0, stagei_wt_pose=3.0, stagei_wt_poseB=3.0,
+               stagei_wt_init_finger_left=400.0, stagei_wt_init_finger_right=400.0, stagei_wt_init_finger=400.0,
+               stagei_wt_betas=10.0, stagei_wt_init=300, stagei_wt_data=75.0, stagei_wt_surf=10000.0,
+               stagei_wt_annealing=[1.0, 0.5, 0.25, 0.125])          # moshpp_conf.yaml:104-117 (smplh == smplx)
+STAGEII_WEIGHTS['smplh'].update(_STAGEI)
+STAGEII_WEIGHTS['smplx'].update(_STAGEI)
+STAGEII_WEIGHTS['smplx_grab_vtemplate'].update(dict(        # moshpp_conf.yaml:148-165
+    stagei_wt_surf=10000.0, stagei_wt_init_hand=347.36, stagei_wt_init_finger=789.47, stagei_wt_init_finger_left=789.47,
+    stagei_wt_init_finger_right=789.47, stagei_wt_init_head=220.69, stagei_wt_init_face=1100.0, stagei_wt_poseH=5.31,
+    stagei_wt_poseF=28.97, stagei_wt_expr=6.99, stagei_wt_pose=3.0, stagei_wt_poseB=3.0, stagei_wt_betas=10.0, stagei_wt_init=300.0,
+    stagei_wt_data=75.0, stagei_wt_annealing=[1.0, 0.5, 0.25, 0.125]))
+
+
 class Cfg(dict):
     """dict with attribute access, recursively (enough of DictConfig for the Stage-II path)."""
 
@@ -61,15 +74,19 @@ class Cfg(dict):
 def default_cfg():
     """Stage-II relevant subset of support_data/conf/moshpp_conf.yaml with its default values."""
     return Cfg({
-        'mocap': dict(fname=None, unit='mm', rotate=None, exclude_markers=None, only_markers=None,
+        'mocap': dict(fname=None, unit='mm', rotate=None, exclude_markers=None, only_markers=None, exclude_marker_types=None,
                       subject_id=-1, subject_name=None, multi_subject=False, start_fidx=0, end_fidx=-1, ds_rate=1),
         'surface_model': dict(type='smplx', fname=None, dmpl_fname=None, num_betas=16, betas_expr_start_id=300,
                               num_dmpls=8, dof_per_hand=24, num_expressions=80, use_hands_mean=True, gender='neutral'),
         'moshpp': dict(pose_body_prior_fname=None, pose_hand_prior_fname=None, optimize_fingers=False,
                        optimize_face=False, optimize_toes=False, optimize_betas=True, optimize_dynamics=False,
+                       head_marker_corr_fname=None,
+                       stagei_frame_picker=dict(type='random_strict', seed=100, num_frames=12, least_avail_markers=1.0,
+                                                stagei_mocap_fnames=None),
                        verbosity=1, visualization=dict(marker_radius=dict(body=0.009, face=0.004, finger=0.005))),
-        'dirs': dict(support_base_dir=None, work_base_dir=None, stagei_fname=None, stageii_fname=None, log_fname=None),
-        'opt_settings': dict(weights_type=None, weights=None, maxiter=100),
+        'dirs': dict(support_base_dir=None, work_base_dir=None, stagei_fname=None, stageii_fname=None, log_fname=None,
+                     marker_layout=dict(fname=None)),
+        'opt_settings': dict(weights_type=None, weights=None, maxiter=100, stagei_lr=1e-3, extra_initial_rigid_adjustment=False),
         # extensions of this implementation (absent in the reference; all default to reference behaviour)
         'moshpp_amd': dict(chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, device=None),
         'runtime': dict(stagei_only=False),

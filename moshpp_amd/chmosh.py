@@ -283,3 +283,147 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
         if solver.optimize_face:       # :723-724  betas[exp_start_id:] -- the whole tail, as the reference stores it
             stageii_data['expression'] = betas_t[:, solver.shape_start:].copy()
     return stageii_data
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stage-I
+# ---------------------------------------------------------------------------------------------------------------------
+SMPLX_EYEBALL_VIDS = np.arange(9383, 10475)   # support_data/smplx_eyeballs.npz: the attachment never uses them (transformed_lm.py:49-50)
+
+
+def stagei_pose_ids(surface_model_type, pose_size, optimize_fingers, optimize_toes):
+    """chmosh.py:281-310, 383-388: (pose ids free in every round, body ids the prior sees, finger ids of the last two rounds)."""
+    allp = list(range(pose_size))
+    body, finger = [], []
+    root = allp[:3]
+    if surface_model_type == 'smpl':
+        body = allp[3:]
+    elif surface_model_type == 'smplh':
+        body = allp[3:66]
+        finger = allp[66:] if optimize_fingers else []
+    elif surface_model_type == 'smplx':
+        body = allp[3:66]
+        finger = allp[75:] if optimize_fingers else []
+    elif surface_model_type == 'mano':
+        finger = allp[3:]
+    else:
+        raise NotImplementedError(f'Stage-I for surface model type {surface_model_type}')
+    pose_ids = root + body
+    if len(body) and not optimize_toes:
+        pose_ids = sorted(set(pose_ids).difference(set(allp[30:36])))
+    return pose_ids, body, finger
+
+
+def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> dict:
+    """Drop-in for the reference's `mosh_stagei` (src/moshpp/chmosh.py:83-455): same arguments, cfg fields, side effects on `cfg`
+    (:103-137) and returned dict (:432-455).  `stagei_frames`: list of `label -> xyz` dicts, one per picked frame
+    (frame_picker.load_marker_sessions_*).  The joint solve runs in libmoshii (moshii_stagei_solve, HIP); no CPU fallback."""
+    from .marker_layout import marker_layout_load
+    betas = None
+    if betas_fname is not None:
+        logger.debug(f'loading pre-computed betas: {betas_fname}')
+        assert str(betas_fname).endswith('.npz'), ValueError(f'invalid numpy betas_fname: {betas_fname}')
+        betas = np.load(betas_fname)['betas']
+    excl_types = _get(cfg.mocap, 'exclude_marker_types')
+    if cfg.surface_model.type == 'smplx' and cfg.moshpp.optimize_betas and (excl_types is not None and 'face' in excl_types):
+        logger.info('Setting moshpp.optimize_face to False')      # :103-120
+        cfg.moshpp.optimize_face = False
+    layout = cfg.dirs.marker_layout.fname
+    logger.info(f'using marker_layout_fname: {layout}')
+    marker_meta = marker_layout_load(layout, include_nan=True, exclude_markers=_get(cfg.mocap, 'exclude_markers'),
+                                     exclude_marker_types=excl_types, only_markers=_get(cfg.mocap, 'only_markers'),
+                                     labels_map=general_labels_map)
+    avail_labels = list(set(k for l in stagei_frames for k in list(l.keys())))
+    for body_part, cfg_key in {'finger': 'optimize_fingers', 'face': 'optimize_face'}.items():      # :128-139
+        if not cfg.moshpp[cfg_key]:
+            continue
+        if not np.any([body_part in m for m in marker_meta['marker_type_mask'].keys()]):
+            cfg.moshpp[cfg_key] = False
+            logger.warning(f'{cfg_key} was activated but no {body_part} marker type detected in the marker layout: {cfg_key} = False.')
+        elif not np.any([(body_part in ltype) and l in avail_labels for l, ltype in marker_meta['marker_type'].items()]):
+            cfg.moshpp[cfg_key] = False
+            logger.warning(f'{cfg_key} was activated but no {body_part} marker type detected in the mocaps: {cfg_key} = False.')
+    if cfg.moshpp.optimize_face:
+        raise NotImplementedError('Stage-I with per-frame facial expressions (moshpp.optimize_face) is not implemented on the GPU path; '
+                                  'run Stage-I with optimize_face=false (the reference cannot combine it with optimize_betas either, '
+                                  'chmosh.py:295-299)')
+    sm = load_surface_model(surface_model_fname=cfg.surface_model.fname, surface_model_type=cfg.surface_model.type,
+                            pose_hand_prior_fname=cfg.moshpp.pose_hand_prior_fname, use_hands_mean=cfg.surface_model.use_hands_mean,
+                            dof_per_hand=cfg.surface_model.dof_per_hand, v_template_fname=v_template_fname)
+    assert marker_meta['surface_model_type'] == sm.model_type == cfg.surface_model.type, ValueError(
+        f"marker layout surface_model_type doesnt match that of curent mosh session surface_model.type: "
+        f"{marker_meta['surface_model_type']} == {sm.model_type} == {cfg.surface_model.type}")
+    if sm.f is None:
+        raise ValueError('the surface model file has no faces (`f`): Stage-I needs the triangulated surface')
+    prior = None
+    if cfg.moshpp.pose_body_prior_fname and sm.model_type != 'mano':
+        prior = create_gmm_body_prior(cfg.moshpp.pose_body_prior_fname, exclude_hands=sm.model_type in ['smplh', 'smplx'])
+    optimize_betas = bool(cfg.moshpp.optimize_betas)
+    num_betas = int(cfg.surface_model.num_betas)
+    nb = num_betas if optimize_betas else 0
+    all_betas = np.zeros(sm.num_total_betas)
+    if betas is not None:
+        all_betas[:num_betas] = np.asarray(betas, dtype=np.float64)[:num_betas]       # :164-170
+    # the solver works on v_template + shapedirs[:, :, :nb] . betas: betas that stay fixed are folded into the template
+    v_template = sm.v_template if optimize_betas else sm.v_template + sm.shapedirs.dot(all_betas)
+    dev = capi.Model(v_template, sm.shapedirs, sm.posedirs, sm.weights, sm.J_regressor, sm.parents, sm.body_dof, sm.hand_dof,
+                     sm.hands_mean, sm.selected_components)
+    latent_labels = list(marker_meta['marker_vids'].keys())
+    M = len(latent_labels)
+    logger.debug(f'Estimating for #latent markers: {M}')
+    m2b = np.ones(M) * 0.0095                                                          # :62-64
+    for mask_type, mask in marker_meta['marker_type_mask'].items():
+        m2b[np.asarray(mask, dtype=bool)] = marker_meta['m2b_distance'][mask_type]
+    W = cfg.opt_settings.weights
+    wt_init = np.zeros(M)
+    for k, mask in marker_meta['marker_type_mask'].items():                            # :327-328 (before annealing)
+        wt_init[np.asarray(mask, dtype=bool)] = _get(W, f'stagei_wt_init_{k}', W['stagei_wt_init'])
+    frames, markers_obs, labels_obs = [], [], []
+    lab_idx = {l: i for i, l in enumerate(latent_labels)}
+    for obs_frame in stagei_frames:                                                    # :199-213
+        obs_labels = [k for k, v in obs_frame.items() if not np.any(np.isnan(v))]
+        common = [l for l in latent_labels if l in set(obs_labels)]                   # (the reference's set order is arbitrary)
+        obf = np.vstack([obs_frame[k] for k in common]) if common else np.zeros((0, 3))
+        frames.append((np.array([lab_idx[k] for k in common], dtype=np.int32), obf))
+        markers_obs.append(obf); labels_obs.append(common)
+    logger.debug('Number of available markers in each stagei selected frames: {}'.format(
+        ', '.join([f'(F{fi:02d}, {len(fr)})' for fi, fr in enumerate(markers_obs)])))
+    if _get(cfg.opt_settings, 'extra_initial_rigid_adjustment', False):
+        raise NotImplementedError('opt_settings.extra_initial_rigid_adjustment')
+    head_corr = None
+    hfn = _get(cfg.moshpp, 'head_marker_corr_fname')
+    if hfn is not None:                                                                # :252-266
+        head_meta = np.load(hfn)
+        if all(m in marker_meta['marker_vids'] for m in head_meta['mrk_labels']):
+            head_corr = (np.array([lab_idx[str(m)] for m in head_meta['mrk_labels']], dtype=np.int32), np.asarray(head_meta['corr']))
+            logger.info('Successfully took into account the correlation of the head markers')
+    pose_ids, body_ids, finger_ids = stagei_pose_ids(sm.model_type, sm.NP, cfg.moshpp.optimize_fingers, cfg.moshpp.optimize_toes)
+    if prior is None:
+        body_prior_ids = []
+    else:
+        body_prior_ids = body_ids
+    weights = {k: (list(W[k]) if k == 'stagei_wt_annealing' else float(W[k])) for k in
+               ('stagei_wt_data', 'stagei_wt_poseB', 'stagei_wt_poseH', 'stagei_wt_betas', 'stagei_wt_surf', 'stagei_wt_annealing')}
+    pr_dev = capi.Prior(prior['means'], prior['chols'], prior['weights']) if prior is not None else None
+    out = capi.stagei_solve_host(dev, pr_dev, faces=sm.f,
+                                 marker_vids=list(marker_meta['marker_vids'].values()), m2b=m2b, wt_init=wt_init, frames=frames,
+                                 nb=nb, weights=weights, pose_ids=pose_ids, body_ids=body_prior_ids, finger_ids=finger_ids,
+                                 exclude_vids=SMPLX_EYEBALL_VIDS if sm.V == 10475 else None,
+                                 betas_init=all_betas[:nb] if nb else None, maxiter=int(cfg.opt_settings.maxiter),
+                                 stagei_lr=float(cfg.opt_settings.stagei_lr), head_corr=head_corr,
+                                 wt_init_head=float(_get(W, 'stagei_wt_init_body', W['stagei_wt_init'])))
+    if nb:
+        all_betas[:nb] = out['betas']
+    errs = {k: v for k, v in out['errs'].items() if not (k == 'poseH' and not finger_ids) and not (k == 'beta' and not nb)
+            and not (k == 'poseB' and prior is None) and not (k == 'init_head_corr' and head_corr is None)}
+    stagei_debug_details = {'opt_models_trans': [t for t in out['trans']], 'opt_models_pose': [p for p in out['pose']],
+                            'stagei_errs': errs, 'stagei_markers_obs': markers_obs, 'stagei_labels_obs': labels_obs,
+                            'stagei_iters': out['iters']}
+    stagei_data = {'betas': all_betas, 'markers_latent': out['markers_latent'], 'latent_labels': latent_labels,
+                   'marker_meta': marker_meta,
+                   'markers_latent_vids': {l: int(v) for l, v in zip(latent_labels, out['markers_latent_vids'])}}
+    if v_template_fname is not None:
+        stagei_data['v_template_fname'] = v_template_fname
+        stagei_debug_details['v_template'] = sm.v_template
+    stagei_data['stagei_debug_details'] = stagei_debug_details
+    return stagei_data

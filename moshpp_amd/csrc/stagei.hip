@@ -58,7 +58,8 @@ struct S1Dims {
     int nfaces, npid, nbody, nfinger, npose_prior, G;
     int n, ldn, R;            // unknowns, Jacobian pitch, residual rows
     int o_ml, o_pose, o_b;    // column offsets
-    int r_data, r_prior, r_init, r_beta, r_surf, r_poseH;   // row offsets
+    int r_data, r_prior, r_init, r_beta, r_surf, r_poseH, r_head;   // row offsets
+    int nhead, nhead_rows;    // head-marker correlation term: C[nhead_rows][nhead]
     int ncan;                 // canonical vertex list length = 9 M  [closest | closest0 | nearest-triangle vertices]
 };
 
@@ -74,6 +75,8 @@ struct S1Ptr {
     const int* colmap;        // [NP] column of a pose variable inside one frame's block, -1 if frozen
     const int* body_ids; const int* finger_ids;
     int* cl0; double* coef0;
+    const int* head_ids; const double* head_C; double w_init_head;
+    double *loss, *dinit;     // [M][3] init loss, [M][3][nb] d init / d betas (inputs of the head term)
     // evaluation point
     double *pose, *trans, *ml, *betas;
     // setup products
@@ -624,6 +627,7 @@ KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
         for (int a = 0; a < 3; ++a) {
             double init = v0[a] + c0[0] * F0[a] + c0[1] * F0[3 + a] + c0[2] * F0[6 + a];
             p.r[d.r_init + 3 * m + a] = (p.ml[3 * m + a] - init) * w;
+            p.loss[3 * m + a] = p.ml[3 * m + a] - init;
         }
         if (want_J) {
             for (int a = 0; a < 3; ++a) p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_ml + 3 * m + a] = w;
@@ -635,6 +639,7 @@ KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
                     double s = 0;
                     for (int b = 0; b < 9; ++b) s += L0[9 * a + b] * dV[(size_t)b * nb + e];
                     p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_b + e] = -w * s;
+                    p.dinit[((size_t)m * 3 + a) * nb + e] = s;
                 }
             }
         }
@@ -656,6 +661,26 @@ KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
     if (m < nb) {
         p.r[d.r_beta + m] = p.betas[m] * p.w_beta;
         if (want_J) p.Jm[(size_t)(d.r_beta + m) * d.ldn + d.o_b + m] = p.w_beta;
+    }
+}
+
+// head-marker correlation rows (chmosh.py:252-266, 362-369): C . init_loss[head ids] . wt      (one block, after k_s1_shared)
+KERNEL k_s1_head(S1Dims d, S1Ptr p, int want_J) {
+    for (int it = TID; it < d.nhead_rows * 3; it += NT) {
+        int g = it / 3, a = it % 3;
+        const double* Cg = p.head_C + (size_t)g * d.nhead;
+        double s = 0;
+        for (int h = 0; h < d.nhead; ++h) s += Cg[h] * p.loss[3 * p.head_ids[h] + a];
+        p.r[d.r_head + it] = s * p.w_init_head;
+        if (want_J) {
+            double* Jr = p.Jm + (size_t)(d.r_head + it) * d.ldn;
+            for (int h = 0; h < d.nhead; ++h) Jr[d.o_ml + 3 * p.head_ids[h] + a] = Cg[h] * p.w_init_head;
+            for (int e = 0; e < d.nb; ++e) {
+                double t = 0;
+                for (int h = 0; h < d.nhead; ++h) t += Cg[h] * p.dinit[((size_t)p.head_ids[h] * 3 + a) * d.nb + e];
+                Jr[d.o_b + e] = -t * p.w_init_head;
+            }
+        }
     }
 }
 
@@ -960,11 +985,24 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         hipStreamSynchronize(st);
     }
     p.obs_ids = pool.put(ds->obs_ids, ntot_obs, st); p.obs_off = pool.put(obs_off.data(), obs_off.size(), st);
-    p.obs = pool.put(ds->obs, (size_t)3 * ntot_obs, st); p.m2b = pool.put(ds->m2b, M, st); p.wt_init = pool.put(ds->wt_init, M, st);
+    p.obs = pool.put(ds->obs, (size_t)3 * ntot_obs, st); p.m2b = pool.put(ds->m2b, M, st);
     p.body_ids = pool.put(ds->body_ids, d.nbody, st);
     int* d_colmap = pool.get<int>(NP); p.colmap = d_colmap;
     int* d_finger = pool.get<int>(std::max(1, ds->n_finger)); p.finger_ids = d_finger;
     p.cl0 = pool.get<int>(3 * M); p.coef0 = pool.get<double>(3 * M);
+    p.loss = pool.get<double>(3 * M); p.dinit = pool.get<double>((size_t)3 * M * std::max(1, nb));
+    d.nhead = ds->head_ids ? ds->n_head : 0; d.nhead_rows = ds->head_ids ? ds->n_head_rows : 0;
+    std::vector<double> wt_init_eff(ds->wt_init, ds->wt_init + M);
+    if (d.nhead_rows) {
+        if (!ds->head_corr) return fail(MOSHII_ERR_ARG, "stagei: head_ids without head_corr");
+        for (int h = 0; h < d.nhead; ++h) {
+            if (ds->head_ids[h] < 0 || ds->head_ids[h] >= M) return fail(MOSHII_ERR_ARG, "stagei: head marker id out of range");
+            wt_init_eff[ds->head_ids[h]] = 0.0;          // the head markers leave their per-type init rows (chmosh.py:364-367)
+        }
+        p.head_ids = pool.put(ds->head_ids, d.nhead, st); p.head_C = pool.put(ds->head_corr, (size_t)d.nhead_rows * d.nhead, st);
+    }
+    p.wt_init = pool.put(wt_init_eff.data(), M, st);
+    hipStreamSynchronize(st);
     p.pose = pool.get<double>((size_t)d.NPZ * NP); p.trans = pool.get<double>((size_t)d.NPZ * 3);
     p.ml = pool.get<double>(3 * M); p.betas = pool.get<double>(std::max(1, nb));
     p.J0 = pool.get<double>(3 * K); p.JS = pool.get<double>((size_t)std::max(1, K * nb * 3));
@@ -981,7 +1019,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     // largest problem of the rounds: all of body + fingers free
     const int npid_max = ds->n_pose_ids + ds->n_finger;
     const int n_max = 3 * F + 3 * M + F * npid_max + nb;
-    const int R_max = 3 * ntot_obs + F * (d.G ? d.npose_prior + 1 : 0) + 3 * M + nb + M + F * ds->n_finger;
+    const int R_max = 3 * ntot_obs + F * (d.G ? d.npose_prior + 1 : 0) + 3 * M + nb + M + F * ds->n_finger + 3 * d.nhead_rows;
     const int ld_max = (n_max + 15) & ~15;
     p.r = pool.get<double>(R_max); p.Jm = pool.get<double>((size_t)R_max * ld_max);
     if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 2048 unknowns");
@@ -1015,6 +1053,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         LAUNCH(k_s1_verts, (3 * M + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p, 0, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
         if (want_J) hipMemsetAsync(p.Jm, 0, (size_t)d.R * d.ldn * 8, st);
         LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J);
+        if (d.nhead_rows) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
         LAUNCH(k_s1_rows, F, 1, S1_TPB, st, d, p, want_J);
     };
     auto fetch = [&](std::vector<double>& h, const double* dev, size_t count) {
@@ -1049,7 +1088,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     upload_point();
     // frozen attachment of the init markers (chmosh.py:188-190): closest0 / coef0 at the start point
     d.npid = 0; d.n = 3 * F + 3 * M + nb; d.ldn = (d.n + 15) & ~15; d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose;
-    d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior; d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.R = d.r_poseH;
+    d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior; d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH; d.R = d.r_head + 3 * d.nhead_rows;
     d.nfinger = 0;
     {
         int Gkeep = d.G; d.G = 0;                      // no prior rows while the column map is empty
@@ -1101,9 +1140,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         d.n = 3 * F + 3 * M + F * d.npid + nb; d.ldn = (d.n + 15) & ~15;
         d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose + F * d.npid;
         d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior + F * (d.G ? d.npose_prior + 1 : 0);
-        d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.R = d.r_poseH + F * d.nfinger;
+        d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH + F * d.nfinger; d.R = d.r_head + 3 * d.nhead_rows;
         p.w_anneal = a; p.w_data = (ds->wt_data / a) * (46.0 / M); p.w_poseB = ds->wt_poseB * a; p.w_poseH = ds->wt_poseH * a;
-        p.w_beta = ds->wt_betas * a; p.w_surf = ds->wt_surf;
+        p.w_beta = ds->wt_betas * a; p.w_surf = ds->wt_surf; p.w_init_head = ds->wt_init_head * a;
         hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
         if (d.nfinger) hipMemcpyAsync(d_finger, finger_ids.data(), d.nfinger * sizeof(int), hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
@@ -1215,7 +1254,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             auto sse = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
             if (ds->errs) {
                 ds->errs[0] = sse(d.r_data, d.r_prior); ds->errs[1] = sse(d.r_prior, d.r_init); ds->errs[2] = sse(d.r_init, d.r_beta);
-                ds->errs[3] = sse(d.r_beta, d.r_surf); ds->errs[4] = sse(d.r_surf, d.r_poseH); ds->errs[5] = sse(d.r_poseH, d.R);
+                ds->errs[3] = sse(d.r_beta, d.r_surf); ds->errs[4] = sse(d.r_surf, d.r_poseH); ds->errs[5] = sse(d.r_poseH, d.r_head); ds->errs[6] = sse(d.r_head, d.R);
             }
         }
         int hstat[4];

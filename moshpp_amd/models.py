@@ -111,6 +111,7 @@ class SurfaceModel:
     hand_dof: int = 0
     hands_mean: Optional[np.ndarray] = None
     selected_components: Optional[np.ndarray] = None
+    f: Optional[np.ndarray] = None            # [T][3] surface triangles (Stage-I: vertex normals, point-to-surface distance)
     _device: object = field(default=None, repr=False)
 
     @property
@@ -196,4 +197,5 @@ def load_surface_model(surface_model_fname, pose_hand_prior_fname=None, use_hand
         pose_body_dof = njoint_parms + 3
     return SurfaceModel(model_type=model_type, v_template=v_template, shapedirs=shapedirs, posedirs=posedirs,
                         weights=weights, J_regressor=Jreg, parents=parents, body_dof=int(pose_body_dof),
-                        hand_dof=int(hand_dof), hands_mean=hands_mean, selected_components=selected_components)
+                        hand_dof=int(hand_dof), hands_mean=hands_mean, selected_components=selected_components,
+                        f=np.asarray(dd['f'], dtype=np.int64).reshape(-1, 3) if 'f' in dd and np.size(dd['f']) else None)

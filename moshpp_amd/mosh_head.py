@@ -104,6 +104,60 @@ def run_stageii(stagei_data_or_fname, cfg, stageii_fname=None, mosh_stageii_func
     return stageii_data
 
 
+def prepare_stagei_frames(cfg, stagei_mocap_fnames):
+    """The dispatch of `MoSh.prepare_stagei_frames` (mosh_head.py:156-197) on an explicit list of mocap files: picks the Stage-I
+    frames with the configured picker (`cfg.moshpp.stagei_frame_picker.{type,num_frames,seed,least_avail_markers}`)."""
+    from . import frame_picker
+    from .mocap_interface import general_labels_map
+    fp = cfg.moshpp.stagei_frame_picker
+    common = dict(mocap_unit=cfg.mocap.unit, mocap_rotate=cfg.mocap.rotate, only_markers=cfg.mocap.only_markers,
+                  only_subjects=[cfg.mocap.subject_name] if cfg.mocap.multi_subject else None,
+                  exclude_markers=cfg.mocap.exclude_markers, labels_map=general_labels_map)
+    if fp.type == 'random':
+        return frame_picker.load_marker_sessions_random(stagei_mocap_fnames, num_frames=fp.num_frames, seed=fp.seed,
+                                                        least_avail_markers=fp.least_avail_markers, **common)
+    if fp.type == 'random_strict':
+        return frame_picker.load_marker_sessions_random_strict(stagei_mocap_fnames, num_frames=fp.num_frames, seed=fp.seed,
+                                                               least_avail_markers=fp.least_avail_markers, **common)
+    if fp.type == 'manual':
+        return frame_picker.load_marker_sessions_manual(stagei_mocap_fnames, **common)
+    raise ValueError(f'Wrong frame_picker value: {fp.type}')
+
+
+def run_stagei(cfg, stagei_mocap_fnames, stagei_fname=None, mosh_stagei_func=None):
+    """`MoSh.mosh_stagei` (mosh_head.py:199-263) without the class around it: loads `stagei_fname` if it exists (checking the
+    model file it was made with, :210-217), otherwise picks the frames, calls `mosh_stagei_func` (default: the libmoshii drop-in)
+    with the reference's keyword arguments (:238-240), records frames / names / cfg / elapsed time (:244-249) and pickles."""
+    if stagei_fname and osp.exists(stagei_fname):
+        with open(stagei_fname, 'rb') as fh:
+            stagei_data = pickle.load(fh)
+        prev = stagei_data['stagei_debug_details']['cfg']['surface_model']['fname']
+        assert prev == cfg.surface_model.fname, ValueError(
+            f'The surface_model_fname used for previous stagei ({prev}) is different than the current surface model '
+            f'({cfg.surface_model.type})')
+        logger.info(f'loading mosh stagei results from {stagei_fname}')
+        return stagei_data
+    if mosh_stagei_func is None:
+        from .chmosh import mosh_stagei as mosh_stagei_func
+    stagei_frames, stagei_fnames = prepare_stagei_frames(cfg, stagei_mocap_fnames)
+    logger.info(f'Attempting mosh stagei to create {stagei_fname}')
+    tm = time.time()
+    stagei_data = mosh_stagei_func(stagei_frames=stagei_frames, cfg=cfg, betas_fname=cfg.moshpp.get('betas_fname'),
+                                   v_template_fname=cfg.moshpp.get('v_template_fname'))
+    elapsed = time.time() - tm
+    dd = stagei_data['stagei_debug_details']
+    dd['stagei_fnames'] = stagei_fnames
+    dd['stagei_frames'] = stagei_frames
+    dd['cfg'] = _cfg_container(cfg)
+    dd['stagei_elapsed_time'] = elapsed
+    if stagei_fname:
+        with open(_makepath(stagei_fname), 'wb') as fh:
+            pickle.dump(stagei_data, fh)
+        logger.debug(f'created stagei_fname: {stagei_fname}')
+    logger.debug(f'finished mosh stagei in {timedelta(seconds=elapsed)}')
+    return stagei_data
+
+
 _STAGEI_NPZ_KEYS = ('gender', 'surface_model_type', 'markers_latent', 'latent_labels', 'markers_latent_vids', 'betas',
                     'v_template')
 

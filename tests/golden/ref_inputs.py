@@ -150,3 +150,42 @@ def amass_inputs():
     return {'smplh': (pkl('smplh', 156), dict(include_markers=True, include_extra_details=True)),
             'smplx_face': (pkl('smplx', 165, face=True), dict()),
             'mano_nobetas': (pkl('mano', 48, betas=False), dict(include_markers=False))}
+
+
+def picker_inputs(outdir):
+    """Two small mocap files with gaps + the arguments of the three Stage-I frame pickers (frame_picker.py)."""
+    rng = np.random.default_rng(99)
+    files = []
+    for i in range(2):
+        fn = os.path.join(outdir, f'picker_mocap_{i}.npz')
+        if not os.path.exists(fn):
+            F, N = 40, 8
+            mk = rng.normal(0, 500, (F, N, 3))
+            mk[rng.random((F, N)) < 0.15] = np.nan
+            mk[5:9, 2] = 0.0
+            np.savez(fn, markers=mk, labels=np.array([f'M{j}' for j in range(N - 1)] + ['*9']), frame_rate=120.0)
+        files.append(fn)
+    return {
+        'manual': ('load_marker_sessions_manual', ([f'{files[0]}_3', f'{files[1]}_17', f'{files[0]}_30'],), dict(mocap_unit='mm')),
+        'random': ('load_marker_sessions_random', (files,), dict(mocap_unit='mm', num_frames=6, seed=100, least_avail_markers=0.8)),
+        'random_lowered': ('load_marker_sessions_random', (files[:1],), dict(mocap_unit='mm', num_frames=6, seed=3, least_avail_markers=1.0)),
+        'strict': ('load_marker_sessions_random_strict', (files,), dict(mocap_unit='mm', num_frames=5, seed=100, least_avail_markers=0.85)),
+    }
+
+
+def layout_inputs(outdir):
+    """A marker-layout json (three marker sets, one vendor alias, one default skin distance) + marker_layout_load arguments."""
+    import json
+    fn = os.path.join(outdir, 'layout_case.json')
+    if not os.path.exists(fn):
+        d = {'surface_model_type': 'smplh', 'markersets': [
+            {'type': 'finger_left', 'distance_from_skin': 0.002, 'indices': {'LIDX3': 2133, 'LTHM3': 2746}},
+            {'type': 'body', 'distance_from_skin': 0.0095, 'indices': {'RFHD': 3512, 'C7': 3470, 'LFHD': 0, 'STRN': 3506, 'T10': 3016,
+                                                                     'LeftShoulder': 3011}},
+            {'type': 'head', 'indices': {'ARIEL': 411}}]}
+        with open(fn, 'w') as fh:
+            json.dump(d, fh, indent=1)
+    return {'all': (fn, dict()),
+            'no_fingers': (fn, dict(exclude_marker_types=['finger_left'])),
+            'only': (fn, dict(only_markers=['C7', 'LFHD', 'ARIEL', 'LIDX3'])),
+            'excluded_label': (fn, dict(exclude_markers=['T10']))}

@@ -52,3 +52,72 @@ def test_stagei_rejects_bad_input():
     kw['frames'] = [(np.array([0, 1, c['M'] + 3]), np.zeros((3, 3)))] + list(kw['frames'][1:])
     with pytest.raises(capi.MoshiiError):
         capi.stagei_solve_host(dev, pr, **kw)
+
+
+def test_mosh_stagei_then_stageii_end_to_end(tmp_path):
+    """Files in, files out: model pickle with faces, priors, marker-layout json, two npz captures -> frame picker -> mosh_stagei
+    (GPU) -> mosh_stageii (GPU) through the reference's plugin signatures; Stage-I checked against the oracle on the same picked frames."""
+    import json
+    import os
+    import pickle
+    from moshpp_amd import synth
+    from moshpp_amd.cfg import make_cfg
+    from moshpp_amd.mosh_head import run_stagei, run_stageii
+    from oracle import stageii_oracle as so
+    from oracle import stagei_oracle as s1
+    c = helpers.stagei_case(M=32, F=4, seed=5)
+    dd, m, M, nb = c['dd'], c['m'], c['M'], c['nb']
+    raw = {k: v for k, v in dd.items() if not k.startswith('_')}
+    with open(tmp_path / 'model.pkl', 'wb') as f:
+        pickle.dump(raw, f)
+    with open(tmp_path / 'pose_body_prior.pkl', 'wb') as f:
+        pickle.dump(synth.synth_gmm_prior(5), f)
+    np.savez(tmp_path / 'pose_hand_prior.npz', **synth.synth_hand_prior(5))
+    labels = [f'MK{i:02d}' for i in range(M)]
+    layout = {'surface_model_type': 'smplh', 'markersets': [
+        {'type': 'body', 'distance_from_skin': 0.0095, 'indices': {l: int(v) for l, v in zip(labels[:M - 4], c['vids'][:M - 4])}},
+        {'type': 'head', 'distance_from_skin': 0.0095, 'indices': {l: int(v) for l, v in zip(labels[M - 4:], c['vids'][M - 4:])}}]}
+    with open(tmp_path / 'layout.json', 'w') as f:
+        json.dump(layout, f)
+    # a capture: ground-truth motion of the case's subject, 60 frames, a few dropouts
+    cl, coef = so.transformed_coeffs(so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3), None, shp=c['betas_gt']),
+                                     c['ml_gt'])
+    pose_gt, trans_gt = synth.synth_motion(m['NP'], m['body_dof'], 60, seed=5)
+    rng = np.random.default_rng(8)
+    mk = np.zeros((60, M, 3))
+    for t in range(60):
+        p = pose_gt[t].copy(); p[m['body_dof']:] = 0; p[30:36] = 0
+        vv = so.verts_forward(m, so.fullpose_from_pose(m, p), trans_gt[t], cl.reshape(-1), shp=c['betas_gt']).reshape(M, 3, 3)
+        mk[t] = so.markers_from_verts(coef, vv[:, 0], vv[:, 1], vv[:, 2]) + rng.normal(0, 0.0003, (M, 3))
+    mk[rng.random((60, M)) < 0.03] = np.nan
+    cap = str(tmp_path / 'capture.npz')
+    np.savez(cap, markers=mk * 1000.0, labels=np.array(labels), frame_rate=120.0)
+    cfg = make_cfg(**{'mocap.fname': cap, 'surface_model.type': 'smplh', 'surface_model.fname': str(tmp_path / 'model.pkl'),
+                      'surface_model.num_betas': nb, 'surface_model.dof_per_hand': 12, 'surface_model.use_hands_mean': False,
+                      'moshpp.pose_body_prior_fname': str(tmp_path / 'pose_body_prior.pkl'),
+                      'moshpp.pose_hand_prior_fname': str(tmp_path / 'pose_hand_prior.npz'),
+                      'dirs.marker_layout.fname': str(tmp_path / 'layout.json'),
+                      'moshpp.stagei_frame_picker.num_frames': 5, 'moshpp.stagei_frame_picker.least_avail_markers': 0.9})
+    stagei = run_stagei(cfg, [cap], stagei_fname=str(tmp_path / 'out' / 'stagei.pkl'))
+    assert set(stagei) >= {'betas', 'markers_latent', 'latent_labels', 'marker_meta', 'markers_latent_vids', 'stagei_debug_details'}
+    assert stagei['latent_labels'] == labels and stagei['betas'].shape == (10,) and stagei['markers_latent'].shape == (M, 3)
+    dbg = stagei['stagei_debug_details']
+    assert set(dbg['stagei_errs']) == {'data', 'poseB', 'init', 'beta', 'surf'} and len(dbg['stagei_fnames']) == 5
+    assert os.path.exists(tmp_path / 'out' / 'stagei.pkl')
+    # oracle on the same picked frames
+    frames = []
+    for fr in dbg['stagei_frames']:
+        common = [l for l in labels if l in fr and not np.any(np.isnan(fr[l]))]
+        frames.append((np.array([labels.index(l) for l in common]), np.vstack([fr[l] for l in common])))
+    mm = stagei['marker_meta']
+    ref = s1.stagei_solve(m, dd['f'], c['prior'], 'smplh', frames, np.array(list(mm['marker_vids'].values())), mm['marker_type_mask'],
+                          mm['m2b_distance'], nb)
+    assert np.abs(stagei['betas'][:nb] - ref['betas']).max() < 1e-5
+    assert np.abs(stagei['markers_latent'] - ref['markers_latent']).max() < 1e-6
+    # Stage-II with the Stage-I result, through the head function (merges the Stage-I keys)
+    cfg.mocap.end_fidx = 20
+    stageii = run_stageii(stagei, cfg, stageii_fname=str(tmp_path / 'out' / 'capture_stageii.pkl'))
+    assert stageii['fullpose'].shape == (20, 156) and 'markers_latent' in stageii
+    rm = np.sqrt(np.mean([((a - b) ** 2).sum(1).mean() for a, b in zip(stageii['stageii_debug_details']['markers_sim'],
+                                                                     stageii['stageii_debug_details']['markers_obs'])]))
+    assert rm < 5e-3        # the solved subject + layout reproduce the capture to a few millimetres

@@ -239,7 +239,7 @@ def test_c3d_roundtrip_property_over_every_variant(tmp_path):
         if proc == c3d_io.PROC_DEC and int_scale is not None:
             int_scale = None                                    # (DEC + int is legal; the int path is endian-only)
         rng = np.random.default_rng(seed)
-        pts = rng.normal(0, 500, (F, N, 3))
+        pts = np.clip(rng.normal(0, 500, (F, N, 3)), -1500, 1500)    # inside the int16 range at the smallest scale (0.05 mm)
         pts[rng.random((F, N)) < 0.2] = np.nan
         labels = [f'L{seed % 7}_{i}' for i in range(N)]
         counter[0] += 1

@@ -12,7 +12,8 @@ import pytest
 from oracle import stageii_oracle as so
 from tests.golden import ref_inputs
 
-G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_nodes.npz'))
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+G = np.load(os.path.join(GOLD, 'ref_nodes.npz'))
 EYEBALLS = np.arange(9383, 10475)
 
 
@@ -144,3 +145,34 @@ def test_amass_export_matches_reference_method(case):
             assert np.array_equal(np.asarray(res[k]), G[f'amass_{case}_{k}']), k
         else:
             assert k not in res
+
+
+@pytest.mark.parametrize('case', ['manual', 'random', 'random_lowered', 'strict'])
+def test_frame_pickers_match_reference_functions(case):
+    """moshpp_amd.frame_picker against the reference's frame_picker.py:43-213, executed (with the reference's own MocapSession) on the
+    same files with the same legacy-RNG state: the same frames are picked, in the same order."""
+    from moshpp_amd import frame_picker
+    fn_name, args, kw = ref_inputs.picker_inputs(GOLD)[case]
+    np.random.seed(4242)
+    frames, names = getattr(frame_picker, fn_name)(*args, **kw)
+    assert [os.path.basename(str(n)) for n in names] == [str(n) for n in G[f'picker_{case}_names']]
+    assert [len(fr) for fr in frames] == G[f'picker_{case}_nlabels'].tolist()
+    first = np.array([np.asarray(list(fr.values())[0], dtype=np.float64) for fr in frames])
+    assert np.array_equal(first, G[f'picker_{case}_first'], equal_nan=True)
+
+
+@pytest.mark.parametrize('case', ['all', 'no_fingers', 'only', 'excluded_label'])
+def test_marker_layout_load_matches_reference_function(case):
+    """moshpp_amd.marker_layout.marker_layout_load against the reference's (edit_tools.py:83-183): label order (sets by type, labels
+    sorted, aliases applied first), vertex ids, type of each label, type masks, skin distances -- incl. the reference's behaviour of
+    keeping `exclude_markers` labels in the layout."""
+    from moshpp_amd.marker_layout import marker_layout_load
+    fname, kw = ref_inputs.layout_inputs(GOLD)[case]
+    mm = marker_layout_load(fname, **kw)
+    assert list(mm['marker_vids'].keys()) == [str(l) for l in G[f'layout_{case}_labels']]
+    assert list(mm['marker_vids'].values()) == G[f'layout_{case}_vids'].tolist()
+    assert [mm['marker_type'][l] for l in mm['marker_vids']] == [str(t) for t in G[f'layout_{case}_types']]
+    assert list(mm['marker_type_mask'].keys()) == [str(t) for t in G[f'layout_{case}_masktypes']]
+    assert np.array_equal(np.array([mm['marker_type_mask'][k] for k in mm['marker_type_mask']]), G[f'layout_{case}_masks'])
+    assert np.allclose([mm['m2b_distance'][k] for k in mm['marker_type_mask']], G[f'layout_{case}_m2b'])
+    assert mm['surface_model_type'] == str(G[f'layout_{case}_model'])
