@@ -22,6 +22,7 @@
 
 #ifdef S1_EMU
 #define KERNEL static void
+#define KERNEL_LB(n) static void
 #define DEVFN static inline
 static int s1_bx, s1_by;
 #define TID 0
@@ -32,9 +33,12 @@ static int s1_bx, s1_by;
 #define SHARED static
 #define S1_TPB 1
 #define S1_CHOL_TPB 1
+#define S1_VL 1
+#define S1_TRSM_TPB 1
 #define LAUNCH(k, gx, gy, nt, stream, ...) do { for (int _y = 0; _y < (int)(gy); ++_y) for (int _x = 0; _x < (int)(gx); ++_x) { s1_bx = _x; s1_by = _y; k(__VA_ARGS__); } } while (0)
 #else
 #define KERNEL __global__ void
+#define KERNEL_LB(n) __global__ void __launch_bounds__(n)
 #define DEVFN __device__ static inline
 #define TID ((int)threadIdx.x)
 #define NT ((int)blockDim.x)
@@ -44,6 +48,8 @@ static int s1_bx, s1_by;
 #define SHARED __shared__
 #define S1_TPB 256
 #define S1_CHOL_TPB 1024
+#define S1_TRSM_TPB 64
+#define S1_VL 64          // lanes that share one vertex's pose-corrective dot products
 #define LAUNCH(k, gx, gy, nt, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), 0, stream, __VA_ARGS__)
 #endif
 
@@ -82,12 +88,15 @@ struct S1Ptr {
     // setup products
     double *J0, *JS;          // [K][3], [K][nb][3]
     // per pose
-    double *fp, *Rl, *Jl, *Rw, *tw, *feat, *om, *Bm, *Jb, *q;
+    double *fp, *Rl, *Jl, *Rw, *tw, *feat, *om, *Bm, *Jb, *q; int* featzero;
     // canonical body + attachment + surface
     double* can; int* cl; double *coef, *Fc, *dcdb; int* tv; double *sdist, *sdp, *sdabc; int* status;
     // vertex evaluations
     int* vlist;               // [NPZ][ncan] global vertex ids (frames use the first 3M entries of the canonical list)
     double *vv, *dvs, *dv, *Lb;
+    // per (frame, attached vertex) forward state kept for the pose-Jacobian kernel: blended rotation, skinning influences,
+    // rigidly attached positions
+    double *vi_T, *vi_w, *vi_x; int *vi_n, *vi_j;
     // rows
     double *r, *Jm;
     // weights of the round: data, poseB, poseH, beta, surf, anneal
@@ -251,17 +260,26 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
     SYNC();
     for (int k = TID; k < d.K; k += NT) rodrigues_dev(fp + 3 * k, Rl + 9 * k, Jl + 9 * k);
     SYNC();
+    // forward kinematics through LDS (the chain is serial; global round trips per joint would dominate)
+    SHARED double sRl[64 * 9], sRw[64 * 9], sJb[64 * 3], stw[64 * 3]; SHARED int spar[64];
+    for (int i = TID; i < 9 * d.K; i += NT) sRl[i] = Rl[i];
+    for (int i = TID; i < 3 * d.K; i += NT) sJb[i] = Jb[i];
+    for (int i = TID; i < d.K; i += NT) spar[i] = p.parents[i];
+    SYNC();
     if (TID == 0) {
-        for (int i = 0; i < 9; ++i) Rw[i] = Rl[i];
-        for (int a = 0; a < 3; ++a) tw[a] = Jb[a];
+        for (int i = 0; i < 9; ++i) sRw[i] = sRl[i];
+        for (int a = 0; a < 3; ++a) stw[a] = sJb[a];
         for (int j = 1; j < d.K; ++j) {
-            int pa = p.parents[j];
-            matmul3(Rw + 9 * pa, Rl + 9 * j, Rw + 9 * j);
-            double dj[3] = {Jb[3 * j] - Jb[3 * pa], Jb[3 * j + 1] - Jb[3 * pa + 1], Jb[3 * j + 2] - Jb[3 * pa + 2]}, o[3];
-            matvec3(Rw + 9 * pa, dj, o);
-            for (int a = 0; a < 3; ++a) tw[3 * j + a] = o[a] + tw[3 * pa + a];
+            int pa = spar[j];
+            matmul3(sRw + 9 * pa, sRl + 9 * j, sRw + 9 * j);
+            double dj[3] = {sJb[3 * j] - sJb[3 * pa], sJb[3 * j + 1] - sJb[3 * pa + 1], sJb[3 * j + 2] - sJb[3 * pa + 2]}, o[3];
+            matvec3(sRw + 9 * pa, dj, o);
+            for (int a = 0; a < 3; ++a) stw[3 * j + a] = o[a] + stw[3 * pa + a];
         }
     }
+    SYNC();
+    for (int i = TID; i < 9 * d.K; i += NT) Rw[i] = sRw[i];
+    for (int i = TID; i < 3 * d.K; i += NT) tw[i] = stw[i];
     SYNC();
     // q_je = dt_je - Rw_j JS_je, dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par): one thread per coefficient walks the tree
     for (int e = TID; e < d.nb; e += NT) {
@@ -270,16 +288,16 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
             double dt[3];
             if (j == 0) { for (int a = 0; a < 3; ++a) dt[a] = js[a]; }
             else {
-                int pa = p.parents[j];
+                int pa = spar[j];
                 const double* jp = p.JS + ((size_t)pa * d.nb + e) * 3;
                 // dt of the parent is recovered from its q: dt_par = q_par + Rw_par JS_par
                 double rp[3], dj[3] = {js[0] - jp[0], js[1] - jp[1], js[2] - jp[2]}, o[3];
-                matvec3(Rw + 9 * pa, jp, rp);
-                matvec3(Rw + 9 * pa, dj, o);
+                matvec3(sRw + 9 * pa, jp, rp);
+                matvec3(sRw + 9 * pa, dj, o);
                 for (int a = 0; a < 3; ++a) dt[a] = q[((size_t)pa * d.nb + e) * 3 + a] + rp[a] + o[a];
             }
             double rj[3];
-            matvec3(Rw + 9 * j, js, rj);
+            matvec3(sRw + 9 * j, js, rj);
             for (int a = 0; a < 3; ++a) q[((size_t)j * d.nb + e) * 3 + a] = dt[a] - rj[a];
         }
     }
@@ -298,6 +316,17 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
         skew3(col, Sk);
         matmul3(Sk, Rl + 9 * k, Bm + 27 * k + 9 * c);
     }
+    // a pose without any rotation away from the rest pose (the canonical one) has no corrective offsets
+    SHARED int nzf[S1_TPB];
+    int mine = 0;
+    for (int i = TID; i < d.nfeat; i += NT) if (sRl[9 * (1 + i / 9) + i % 9] - ((i % 9 == 0 || i % 9 == 4 || i % 9 == 8) ? 1.0 : 0.0) != 0.0) mine = 1;
+    nzf[TID] = mine;
+    SYNC();
+    if (TID == 0) {
+        int any = 0;
+        for (int t = 0; t < NT; ++t) any |= nzf[t];
+        p.featzero[z] = any ? 0 : 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -305,23 +334,36 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
 // mode 0: positions only into `out` [nlist][3] (canonical full mesh); 1: v; 2: v + dvs; 3: v + dvs + dv (pose Jacobian)
 // ---------------------------------------------------------------------------------------------------------------------------
 KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out, int full_mesh) {
+    SHARED double part[S1_TPB * 3];
     int z = zbase + BY;
-    int a = BX * NT + TID;
-    if (a >= nlist) return;
-    int v = full_mesh ? a : p.vlist[(size_t)z * d.ncan + a];
+    const int lane = TID % S1_VL, wv = TID / S1_VL;
+    int a = (BX * NT + TID) / S1_VL;
+    const bool valid = a < nlist;
+    int v = 0;
     const double* Rw = p.Rw + (size_t)z * d.K * 9; const double* tw = p.tw + (size_t)z * d.K * 3;
     const double* Jb = p.Jb + (size_t)z * d.K * 3; const double* feat = p.feat + (size_t)z * d.nfeat;
     const double* tr = p.trans + 3 * z;
-    double vs[3], vp[3];
+    double vs[3] = {0, 0, 0}, vp[3];
+    if (valid) {
+        v = full_mesh ? a : p.vlist[(size_t)z * d.ncan + a];
+        const bool fz = p.featzero[z] != 0;
+        for (int c = 0; c < 3; ++c) {
+            double sacc = p.vt[3 * v + c];
+            const double* sd = p.shapedirs + ((size_t)v * 3 + c) * d.NBtot;
+            for (int e = 0; e < d.nb; ++e) sacc += sd[e] * p.betas[e];
+            vs[c] = sacc;
+            const double* pd = p.posedirs + ((size_t)v * 3 + c) * d.nfeat;
+            double t = 0;
+            if (!fz) for (int i = lane; i < d.nfeat; i += S1_VL) t += pd[i] * feat[i];      // lanes split the 9(K-1) features
+            part[TID * 3 + c] = t;
+        }
+    }
+    SYNC();
+    if (!valid || lane != 0) return;
     for (int c = 0; c < 3; ++c) {
-        double s = p.vt[3 * v + c];
-        const double* sd = p.shapedirs + ((size_t)v * 3 + c) * d.NBtot;
-        for (int e = 0; e < d.nb; ++e) s += sd[e] * p.betas[e];
-        vs[c] = s;
-        const double* pd = p.posedirs + ((size_t)v * 3 + c) * d.nfeat;
         double t = 0;
-        for (int i = 0; i < d.nfeat; ++i) t += pd[i] * feat[i];
-        vp[c] = s + t;
+        for (int l = 0; l < S1_VL; ++l) t += part[(wv * S1_VL + l) * 3 + c];
+        vp[c] = vs[c] + t;
     }
     int jj[S1_NWMAX]; double wj[S1_NWMAX], xj[S1_NWMAX][3];
     int nw = 0;
@@ -356,30 +398,54 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
         }
     }
     if (mode < 3) return;
-    // pose Jacobian: dof (k, c): omega_kc x (S_k - W_k tw_k) + Trot . (posedirs[v, :, 9(k-1):9k] . vec(B_kc))
-    const double* om = p.om + (size_t)z * d.K * 9; const double* Bm = p.Bm + (size_t)z * d.K * 27;
-    double* dv = p.dv + ((size_t)z * 3 * d.M + a) * 3 * d.P;      // [3][P]
-    for (int k = 0; k < d.K; ++k) {
-        unsigned long long am = p.anc[k];
-        double Sk[3] = {0, 0, 0}, Wk = 0;
-        for (int s = 0; s < nw; ++s) if ((am >> jj[s]) & 1ull) { Wk += wj[s]; for (int c = 0; c < 3; ++c) Sk[c] += wj[s] * xj[s][c]; }
-        double arm[3] = {Sk[0] - Wk * tw[3 * k], Sk[1] - Wk * tw[3 * k + 1], Sk[2] - Wk * tw[3 * k + 2]};
-        for (int c = 0; c < 3; ++c) {
-            double o[3];
-            cross3(om + 9 * k + 3 * c, arm, o);
-            if (k >= 1) {
-                double pc[3], t[3];
-                for (int i = 0; i < 3; ++i) {
-                    const double* pd = p.posedirs + ((size_t)v * 3 + i) * d.nfeat + 9 * (k - 1);
-                    double s = 0;
-                    for (int e = 0; e < 9; ++e) s += pd[e] * Bm[27 * k + 9 * c + e];
-                    pc[i] = s;
-                }
-                matvec3(Trot, pc, t);
-                for (int i = 0; i < 3; ++i) o[i] += t[i];
-            }
-            for (int i = 0; i < 3; ++i) dv[(size_t)i * d.P + 3 * k + c] = o[i];
+    {   // keep the forward state for k_s1_vjac (frames only: slots z * 3M + a)
+        size_t fs = (size_t)z * 3 * d.M + a;
+        for (int i = 0; i < 9; ++i) p.vi_T[fs * 9 + i] = Trot[i];
+        p.vi_n[fs] = nw;
+        for (int s2 = 0; s2 < nw; ++s2) {
+            p.vi_j[fs * S1_NWMAX + s2] = jj[s2]; p.vi_w[fs * S1_NWMAX + s2] = wj[s2];
+            for (int c = 0; c < 3; ++c) p.vi_x[(fs * S1_NWMAX + s2) * 3 + c] = xj[s2][c];
         }
+    }
+}
+
+// pose Jacobian of the attached vertices: one thread per (vertex, joint k), its three dofs:
+//   dv = omega_kc x (S_k - W_k tw_k) + Trot . (posedirs[v, :, 9(k-1):9k] . vec(B_kc))            grid (ceil(3M K / S1_TPB), F)
+KERNEL k_s1_vjac(S1Dims d, S1Ptr p) {
+    int z = BY;
+    int it = BX * NT + TID;
+    if (it >= 3 * d.M * d.K) return;
+    int a = it / d.K, k = it % d.K;
+    int v = p.vlist[(size_t)z * d.ncan + a];
+    size_t fs = (size_t)z * 3 * d.M + a;
+    const double* tw = p.tw + (size_t)z * d.K * 3;
+    const double* om = p.om + (size_t)z * d.K * 9; const double* Bm = p.Bm + (size_t)z * d.K * 27;
+    const double* Trot = p.vi_T + fs * 9;
+    const int nw = p.vi_n[fs];
+    unsigned long long am = p.anc[k];
+    double Sk[3] = {0, 0, 0}, Wk = 0;
+    for (int s2 = 0; s2 < nw; ++s2) if ((am >> p.vi_j[fs * S1_NWMAX + s2]) & 1ull) {
+        double w = p.vi_w[fs * S1_NWMAX + s2];
+        Wk += w;
+        for (int c = 0; c < 3; ++c) Sk[c] += w * p.vi_x[(fs * S1_NWMAX + s2) * 3 + c];
+    }
+    double arm[3] = {Sk[0] - Wk * tw[3 * k], Sk[1] - Wk * tw[3 * k + 1], Sk[2] - Wk * tw[3 * k + 2]};
+    double* dv = p.dv + fs * 3 * d.P;      // [3][P]
+    for (int c = 0; c < 3; ++c) {
+        double o[3];
+        cross3(om + 9 * k + 3 * c, arm, o);
+        if (k >= 1) {
+            double pc[3], t[3];
+            for (int i = 0; i < 3; ++i) {
+                const double* pd = p.posedirs + ((size_t)v * 3 + i) * d.nfeat + 9 * (k - 1);
+                double sacc = 0;
+                for (int e = 0; e < 9; ++e) sacc += pd[e] * Bm[27 * k + 9 * c + e];
+                pc[i] = sacc;
+            }
+            matvec3(Trot, pc, t);
+            for (int i = 0; i < 3; ++i) o[i] += t[i];
+        }
+        for (int i = 0; i < 3; ++i) dv[(size_t)i * d.P + 3 * k + c] = o[i];
     }
 }
 
@@ -797,8 +863,22 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J) {
 // dense linear algebra on the row-major Jacobian Jm[R][ldn]
 // ---------------------------------------------------------------------------------------------------------------------------
 #define S1_T 32
+// flags[row chunk][column block] = 1 iff that 32 x 32 block of J holds a non-zero (most do not: a frame's pose columns appear only
+// in that frame's rows)                                                    grid (ceil(R / 32), ceil(n / 32))
+KERNEL k_s1_nzflags(const double* Jm, int R, int n, int ldn, int* flags) {
+    SHARED int any[256];
+    int rc = BX, cb = BY, mine = 0;
+    for (int e = TID; e < S1_T * S1_T; e += NT) {
+        int r = rc * S1_T + e / S1_T, c = cb * S1_T + e % S1_T;
+        if (r < R && c < n && Jm[(size_t)r * ldn + c] != 0.0) mine = 1;
+    }
+    any[TID] = mine;
+    SYNC();
+    if (TID == 0) { int a = 0; for (int t = 0; t < NT; ++t) a |= any[t]; flags[rc * ((n + S1_T - 1) / S1_T) + cb] = a; }
+}
+
 // A = J^T J, lower tiles (grid (nt, nt), tile (BX >= BY)); 256 threads, 2 x 2 outputs each; mirrored on write
-KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A) {
+KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A, const int* flags) {
     int ti = BX, tj = BY;
     if (tj > ti) return;
 #ifdef S1_EMU
@@ -811,7 +891,10 @@ KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A) {
     __shared__ double Si[S1_T][S1_T + 1], Sj[S1_T][S1_T + 1];
     int tx = TID % 16, ty = TID / 16;
     double acc[2][2] = {{0, 0}, {0, 0}};
+    const int ncb = (n + S1_T - 1) / S1_T;
     for (int r0 = 0; r0 < R; r0 += S1_T) {
+        const int* fl = flags + (r0 / S1_T) * ncb;
+        if (!fl[ti] || !fl[tj]) continue;               // uniform over the workgroup
         for (int e = TID; e < S1_T * S1_T; e += NT) {
             int rr = e / S1_T, cc = e % S1_T;
             int r = r0 + rr, ci = ti * S1_T + cc, cj = tj * S1_T + cc;
@@ -833,13 +916,22 @@ KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A) {
 #endif
 }
 
-// y[n] = sign * J^T r   (grid ceil(n / S1_TPB))
-KERNEL k_s1_gemv_t(const double* Jm, const double* r, int R, int n, int ldn, double sign, double* y) {
+// partial[BY][n] = J[rows of chunk BY]^T r ; then y = sign * sum over chunks        grid (ceil(n / S1_TPB), S1_GT_CHUNKS)
+#define S1_GT_CHUNKS 16
+KERNEL k_s1_gemv_t(const double* Jm, const double* r, int R, int n, int ldn, double* partial) {
     int i = BX * NT + TID;
     if (i >= n) return;
-    double s = 0;
-    for (int k = 0; k < R; ++k) s += Jm[(size_t)k * ldn + i] * r[k];
-    y[i] = sign * s;
+    int per = (R + S1_GT_CHUNKS - 1) / S1_GT_CHUNKS, k0 = BY * per, k1 = (k0 + per < R) ? k0 + per : R;
+    double sacc = 0;
+    for (int k = k0; k < k1; ++k) sacc += Jm[(size_t)k * ldn + i] * r[k];
+    partial[(size_t)BY * n + i] = sacc;
+}
+KERNEL k_s1_gemv_t_sum(const double* partial, int n, double sign, double* y) {
+    int i = BX * NT + TID;
+    if (i >= n) return;
+    double sacc = 0;
+    for (int c = 0; c < S1_GT_CHUNKS; ++c) sacc += partial[(size_t)c * n + i];
+    y[i] = sign * sacc;
 }
 
 // y[R] = Mx[R][ld] . x[n]   (grid R; one block per row)
@@ -853,51 +945,156 @@ KERNEL k_s1_gemv(const double* Mx, const double* x, int n, int ld, double* y) {
     if (TID == 0) { double t = 0; for (int k = 0; k < NT; ++k) t += red[k]; y[r] = t; }
 }
 
-// in-place lower Cholesky of A[n][n] by one workgroup (right-looking), then L y = g, L^T d = y.  status[1] = 1 if not SPD.
-KERNEL k_s1_chol_solve(double* A, int n, const double* g, double* dsol, int* status) {
-    SHARED double piv; SHARED int bad; SHARED double colj[S1_NMAX];
-    const int lanes = NT < 64 ? NT : 64, lane = TID % lanes, wave = TID / lanes, nwave = NT / lanes;
-    if (TID == 0) bad = 0;
+// Blocked right-looking Cholesky of A[n][n] (lower), panel width S1_PB.  Per panel: k_s1_chol_diag (one workgroup: the diagonal
+// block is factored and inverted in LDS), k_s1_chol_trsm (every row below: its 32 entries times the inverse) and k_s1_chol_update (one 32 x 32 tile of the
+// trailing matrix per workgroup: A_ik -= L_i L_k^T).  status[1] = 1 if a pivot is not positive.
+#define S1_PB 32
+KERNEL_LB(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status) {
+    SHARED double D[S1_PB][S1_PB + 1];
+    const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
+    for (int e = TID; e < S1_PB * S1_PB; e += NT) { int r = e / S1_PB, c = e % S1_PB; D[r][c] = (r < jb && c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : (r == c ? 1.0 : 0.0); }
     SYNC();
-    for (int j = 0; j < n; ++j) {
+    for (int c = 0; c < jb; ++c) {
         if (TID == 0) {
-            double djj = A[(size_t)j * n + j];
-            if (!(djj > 0)) { bad = 1; djj = 1.0; }
-            piv = sqrt(djj);
-            A[(size_t)j * n + j] = piv;
+            double v = D[c][c];
+            if (!(v > 0)) { status[1] = 1; v = 1.0; }
+            D[c][c] = sqrt(v);
         }
         SYNC();
-        double ip = 1.0 / piv;
-        for (int i = j + 1 + TID; i < n; i += NT) A[(size_t)i * n + j] *= ip;
+        const double ip = 1.0 / D[c][c];
+        for (int r = c + 1 + TID; r < jb; r += NT) D[r][c] *= ip;
         SYNC();
-        // trailing update of the lower triangle: A[i][k] -= L[i][j] L[k][j], j < k <= i
-        for (int i = j + 1 + TID; i < n; i += NT) colj[i] = A[(size_t)i * n + j];
-        SYNC();
-        for (int i = j + 1 + wave; i < n; i += nwave) {     // one row per wavefront, lanes along the row: coalesced
-            double lij = colj[i];
-            double* Ai = A + (size_t)i * n;
-            for (int k = j + 1 + lane; k <= i; k += lanes) Ai[k] -= lij * colj[k];
+        // rank-1 update of the rows below: lane -> (row, column parity), no integer division
+        for (int t = TID; t < 2 * S1_PB; t += NT) {
+            const int r = t % S1_PB, h = t / S1_PB;
+            if (r > c && r < jb) {
+                const double lrc = D[r][c];
+                for (int k = c + 1 + h; k <= r; k += 2) D[r][k] -= lrc * D[k][c];
+            }
         }
         SYNC();
     }
-    // forward / backward substitution (column oriented so that the inner loops are parallel)
-    for (int i = TID; i < n; i += NT) dsol[i] = g[i];
+    for (int e = TID; e < jb * jb; e += NT) { int r = e / jb, c = e % jb; if (c <= r) A[(size_t)(j0 + r) * n + j0 + c] = D[r][c]; }
+    // inverse of the (padded, unit-extended) 32 x 32 factor, one column per thread: L x = e_c
+    double* Di = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
+    SHARED double X[S1_PB][S1_PB + 1];
+    for (int c = TID; c < S1_PB; c += NT) {
+        for (int r = 0; r < S1_PB; ++r) {
+            double s0 = (r == c) ? 1.0 : 0.0, s1 = 0, s2 = 0, s3 = 0;        // four independent chains hide the LDS latency
+            int k = c;
+            for (; k + 3 < r; k += 4) {
+                s0 -= D[r][k] * X[k][c]; s1 -= D[r][k + 1] * X[k + 1][c]; s2 -= D[r][k + 2] * X[k + 2][c]; s3 -= D[r][k + 3] * X[k + 3][c];
+            }
+            for (; k < r; ++k) s0 -= D[r][k] * X[k][c];
+            X[r][c] = (r < c) ? 0.0 : ((s0 + s1) + (s2 + s3)) / D[r][r];
+        }
+        for (int r = 0; r < S1_PB; ++r) Di[r * S1_PB + c] = X[r][c];
+    }
+}
+
+// rows below the diagonal block: x = a . L_D^{-T}, i.e. x_c = sum_{k <= c} a_k Dinv[c][k]        grid ceil(rows / 64), 64 threads
+KERNEL_LB(64) k_s1_chol_trsm(double* A, int n, int j0, const double* dinv) {
+    SHARED double Di[S1_PB][S1_PB + 1];
+    const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
+    const double* Dg = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
+    for (int e = TID; e < S1_PB * S1_PB; e += NT) Di[e / S1_PB][e % S1_PB] = Dg[e];
     SYNC();
-    for (int j = 0; j < n; ++j) {
-        if (TID == 0) dsol[j] /= A[(size_t)j * n + j];
+    SHARED double Ap[S1_TRSM_TPB][S1_PB + 1];          // this workgroup's rows of the panel
+    int i = j0 + jb + BX * NT + TID;
+    if (i >= n) return;
+    double* Ai = A + (size_t)i * n + j0;
+    double* av = Ap[TID];
+    for (int c = 0; c < S1_PB; ++c) av[c] = (c < jb) ? Ai[c] : 0.0;
+    for (int c = S1_PB - 1; c >= 0; --c) {      // x_c needs a_k only for k <= c: overwrite in place, highest first
+        double sacc = 0;
+        for (int k = 0; k <= c; ++k) sacc += av[k] * Di[c][k];
+        av[c] = sacc;
+    }
+    for (int c = 0; c < jb; ++c) Ai[c] = av[c];
+}
+
+// trailing update, tiles (BX >= BY) of the block that starts at row / column j0 + jb      grid (nt, nt), 256 threads
+KERNEL k_s1_chol_update(double* A, int n, int j0, int jb) {
+    int ti = BX, tj = BY;
+    if (tj > ti) return;
+    const int s0 = j0 + jb;
+#ifdef S1_EMU
+    for (int i = s0 + ti * S1_PB; i < std::min(n, s0 + (ti + 1) * S1_PB); ++i) for (int k = s0 + tj * S1_PB; k < std::min(n, s0 + (tj + 1) * S1_PB); ++k) {
+        if (k > i) continue;
+        double sacc = 0;
+        for (int c = 0; c < jb; ++c) sacc += A[(size_t)i * n + j0 + c] * A[(size_t)k * n + j0 + c];
+        A[(size_t)i * n + k] -= sacc;
+    }
+#else
+    __shared__ double Li[S1_PB][S1_PB + 1], Lk[S1_PB][S1_PB + 1];
+    for (int e = TID; e < S1_PB * S1_PB; e += NT) {
+        int r = e / S1_PB, c = e % S1_PB;
+        int i = s0 + ti * S1_PB + r, k = s0 + tj * S1_PB + r;
+        Li[r][c] = (i < n && c < jb) ? A[(size_t)i * n + j0 + c] : 0.0;
+        Lk[r][c] = (k < n && c < jb) ? A[(size_t)k * n + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    int tx = TID % 16, ty = TID / 16;
+    double acc[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll 8
+    for (int c = 0; c < S1_PB; ++c) {
+        double a0 = Li[ty][c], a1 = Li[ty + 16][c], b0 = Lk[tx][c], b1 = Lk[tx + 16][c];
+        acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+    for (int u = 0; u < 2; ++u) for (int w = 0; w < 2; ++w) {
+        int i = s0 + ti * S1_PB + ty + 16 * u, k = s0 + tj * S1_PB + tx + 16 * w;
+        if (i < n && k <= i) A[(size_t)i * n + k] -= acc[u][w];
+    }
+#endif
+}
+
+// L y = g, L^T x = y with the factor of the kernels above, one workgroup, panel by panel: the 32 x 32 diagonal block goes through
+// LDS, the rest of the panel is applied in the coalesced direction (forward: one row per thread, 32 contiguous entries; backward:
+// one earlier unknown per thread, reading 32 rows of the factor along the row).
+KERNEL k_s1_tri_solve(const double* L, int n, const double* dinv, const double* g, double* out) {
+    SHARED double y[S1_NMAX]; SHARED double Di[S1_PB][S1_PB + 1]; SHARED double yb[S1_PB];
+    for (int i = TID; i < n; i += NT) y[i] = g[i];
+    SYNC();
+    for (int j0 = 0; j0 < n; j0 += S1_PB) {
+        const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
+        const double* Dg = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
+        for (int e = TID; e < S1_PB * S1_PB; e += NT) Di[e / S1_PB][e % S1_PB] = Dg[e];
         SYNC();
-        double yj = dsol[j];
-        for (int i = j + 1 + TID; i < n; i += NT) dsol[i] -= A[(size_t)i * n + j] * yj;
+        for (int c = TID; c < jb; c += NT) {            // y_blk <- L_D^{-1} y_blk
+            double sacc = 0;
+            for (int k = 0; k <= c; ++k) sacc += Di[c][k] * y[j0 + k];
+            yb[c] = sacc;
+        }
+        SYNC();
+        for (int c = TID; c < jb; c += NT) y[j0 + c] = yb[c];
+        for (int i = j0 + jb + TID; i < n; i += NT) {
+            const double* Li = L + (size_t)i * n + j0;
+            double sacc = 0;
+            for (int c = 0; c < jb; ++c) sacc += Li[c] * yb[c];
+            y[i] -= sacc;
+        }
         SYNC();
     }
-    for (int j = n - 1; j >= 0; --j) {
-        if (TID == 0) dsol[j] /= A[(size_t)j * n + j];
+    for (int j0 = ((n - 1) / S1_PB) * S1_PB; j0 >= 0; j0 -= S1_PB) {
+        const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
+        const double* Dg = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
+        for (int e = TID; e < S1_PB * S1_PB; e += NT) Di[e / S1_PB][e % S1_PB] = Dg[e];
         SYNC();
-        double xj = dsol[j];
-        for (int i = TID; i < j; i += NT) dsol[i] -= A[(size_t)j * n + i] * xj;
+        for (int c = TID; c < jb; c += NT) {            // x_blk <- L_D^{-T} y_blk
+            double sacc = 0;
+            for (int k = c; k < jb; ++k) sacc += Di[k][c] * y[j0 + k];
+            yb[c] = sacc;
+        }
+        SYNC();
+        for (int c = TID; c < jb; c += NT) y[j0 + c] = yb[c];
+        for (int k = TID; k < j0; k += NT) {
+            double sacc = 0;
+            for (int c = 0; c < jb; ++c) sacc += L[(size_t)(j0 + c) * n + k] * yb[c];
+            y[k] -= sacc;
+        }
         SYNC();
     }
-    if (TID == 0 && bad) status[1] = 1;
+    for (int i = TID; i < n; i += NT) out[i] = y[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1009,12 +1206,14 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.fp = pool.get<double>((size_t)d.NPZ * d.P); p.Rl = pool.get<double>((size_t)d.NPZ * K * 9); p.Jl = pool.get<double>((size_t)d.NPZ * K * 9);
     p.Rw = pool.get<double>((size_t)d.NPZ * K * 9); p.tw = pool.get<double>((size_t)d.NPZ * K * 3); p.feat = pool.get<double>((size_t)d.NPZ * d.nfeat);
     p.om = pool.get<double>((size_t)d.NPZ * K * 9); p.Bm = pool.get<double>((size_t)d.NPZ * K * 27); p.Jb = pool.get<double>((size_t)d.NPZ * K * 3);
-    p.q = pool.get<double>((size_t)d.NPZ * K * std::max(1, nb) * 3);
+    p.q = pool.get<double>((size_t)d.NPZ * K * std::max(1, nb) * 3); p.featzero = pool.get<int>(d.NPZ);
     p.can = pool.get<double>((size_t)3 * d.V); p.cl = pool.get<int>(3 * M); p.coef = pool.get<double>(3 * M); p.Fc = pool.get<double>(9 * M);
     p.dcdb = pool.get<double>((size_t)M * 3 * std::max(1, nb)); p.tv = pool.get<int>(3 * M); p.sdist = pool.get<double>(M);
     p.sdp = pool.get<double>(3 * M); p.sdabc = pool.get<double>(9 * M); p.status = pool.get<int>(4);
     p.vlist = pool.get<int>((size_t)d.NPZ * d.ncan); p.vv = pool.get<double>((size_t)d.NPZ * d.ncan * 3);
     p.dvs = pool.get<double>((size_t)d.NPZ * d.ncan * 3 * std::max(1, nb)); p.dv = pool.get<double>((size_t)F * 3 * M * 3 * d.P);
+    p.vi_T = pool.get<double>((size_t)F * 3 * M * 9); p.vi_w = pool.get<double>((size_t)F * 3 * M * S1_NWMAX);
+    p.vi_x = pool.get<double>((size_t)F * 3 * M * S1_NWMAX * 3); p.vi_n = pool.get<int>((size_t)F * 3 * M); p.vi_j = pool.get<int>((size_t)F * 3 * M * S1_NWMAX);
     p.Lb = pool.get<double>((size_t)F * M * 36 + (size_t)F * std::max(1, d.G * d.npose_prior));
     // largest problem of the rounds: all of body + fingers free
     const int npid_max = ds->n_pose_ids + ds->n_finger;
@@ -1023,7 +1222,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     const int ld_max = (n_max + 15) & ~15;
     p.r = pool.get<double>(R_max); p.Jm = pool.get<double>((size_t)R_max * ld_max);
     if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 2048 unknowns");
-    double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max); double* d_g = pool.get<double>(n_max); double* d_vec = pool.get<double>(n_max);
+    double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max);
+    double* d_dinv = pool.get<double>((size_t)(n_max / S1_PB + 1) * S1_PB * S1_PB); int* d_flags = pool.get<int>((size_t)((R_max + S1_T - 1) / S1_T) * ((n_max + S1_T - 1) / S1_T));
+    double* d_g = pool.get<double>(n_max); double* d_part = pool.get<double>((size_t)S1_GT_CHUNKS * n_max); double* d_vec = pool.get<double>(n_max);
     double* d_out = pool.get<double>(std::max(n_max, R_max));
     if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed");
     hipMemsetAsync(p.status, 0, 4 * sizeof(int), st);
@@ -1041,7 +1242,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     };
     auto canonical = [&]() {   // pose kernels + canonical mesh at the uploaded point
         LAUNCH(k_s1_pose, d.NPZ, 1, S1_TPB, st, d, p);
-        LAUNCH(k_s1_verts, (d.V + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.V, 0, p.can, 1);
+        LAUNCH(k_s1_verts, (d.V * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.V, 0, p.can, 1);
     };
     // evaluation of residual (and Jacobian) at the uploaded point
     auto evaluate = [&](int want_J) {
@@ -1049,8 +1250,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl);
         LAUNCH(k_s1_surface, M, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_lists, (3 * M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p);
-        LAUNCH(k_s1_verts, (d.ncan + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0);
-        LAUNCH(k_s1_verts, (3 * M + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p, 0, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
+        LAUNCH(k_s1_verts, (d.ncan * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0);
+        LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p, 0, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
+        if (want_J) LAUNCH(k_s1_vjac, (3 * M * K + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p);
         if (want_J) hipMemsetAsync(p.Jm, 0, (size_t)d.R * d.ldn * 8, st);
         LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J);
         if (d.nhead_rows) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
@@ -1165,8 +1367,10 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         };
         auto normal_eq = [&]() {     // A = J^T J, g = -J^T r on the device; g to the host
             int nt = (n + S1_T - 1) / S1_T;
-            LAUNCH(k_s1_syrk, nt, nt, 256, st, p.Jm, R, n, d.ldn, d_A);
-            LAUNCH(k_s1_gemv_t, (n + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, p.Jm, p.r, R, n, d.ldn, -1.0, d_g);
+            LAUNCH(k_s1_nzflags, (R + S1_T - 1) / S1_T, nt, 256, st, p.Jm, R, n, d.ldn, d_flags);
+            LAUNCH(k_s1_syrk, nt, nt, 256, st, p.Jm, R, n, d.ldn, d_A, d_flags);
+            LAUNCH(k_s1_gemv_t, (n + S1_TPB - 1) / S1_TPB, S1_GT_CHUNKS, S1_TPB, st, p.Jm, p.r, R, n, d.ldn, d_part);
+            LAUNCH(k_s1_gemv_t_sum, (n + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_part, n, -1.0, d_g);
             fetch(g, d_g, n);
         };
         auto Ax = [&](const std::vector<double>& v, std::vector<double>& out) {   // A . v (A must still be unfactored)
@@ -1200,7 +1404,13 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                     if (!have_gn) {
                         // the factorisation overwrites A: keep a copy for the rho denominator products
                         hipMemcpyAsync(d_L, d_A, (size_t)n * n * 8, hipMemcpyDeviceToDevice, st);
-                        LAUNCH(k_s1_chol_solve, 1, 1, S1_CHOL_TPB, st, d_L, n, d_g, d_out, p.status);
+                        for (int j0 = 0; j0 < n; j0 += S1_PB) {
+                            const int jb = std::min(S1_PB, n - j0), rem = n - j0 - jb;
+                            LAUNCH(k_s1_chol_diag, 1, 1, S1_TRSM_TPB, st, d_L, n, j0, d_dinv, p.status);
+                            if (rem > 0) LAUNCH(k_s1_chol_trsm, (rem + S1_TRSM_TPB - 1) / S1_TRSM_TPB, 1, S1_TRSM_TPB, st, d_L, n, j0, d_dinv);
+                            if (rem > 0) { int nt = (rem + S1_PB - 1) / S1_PB; LAUNCH(k_s1_chol_update, nt, nt, 256, st, d_L, n, j0, jb); }
+                        }
+                        LAUNCH(k_s1_tri_solve, 1, 1, S1_CHOL_TPB, st, d_L, n, d_dinv, d_g, d_out);
                         fetch(dgn, d_out, n);
                         have_gn = true;
                     }
