@@ -949,6 +949,7 @@ KERNEL k_s1_gemv(const double* Mx, const double* x, int n, int ld, double* y) {
 // block is factored and inverted in LDS), k_s1_chol_trsm (every row below: its 32 entries times the inverse) and k_s1_chol_update (one 32 x 32 tile of the
 // trailing matrix per workgroup: A_ik -= L_i L_k^T).  status[1] = 1 if a pivot is not positive.
 #define S1_PB 32
+#ifdef S1_EMU
 KERNEL_LB(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status) {
     SHARED double D[S1_PB][S1_PB + 1];
     const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
@@ -991,6 +992,51 @@ KERNEL_LB(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status
         for (int r = 0; r < S1_PB; ++r) Di[r * S1_PB + c] = X[r][c];
     }
 }
+
+#else
+// GPU version: one wavefront, lane r keeps row r of the block in registers; pivots and columns travel by lane shuffles.
+// Then lane c solves L x = e_c for column c of the inverse with the factor's entries broadcast the same way.
+__global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status) {
+    const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
+    const int r = threadIdx.x & 31;
+    double a[S1_PB];
+#pragma unroll
+    for (int c = 0; c < S1_PB; ++c) a[c] = (r < jb && c <= r && c < jb) ? A[(size_t)(j0 + r) * n + j0 + c] : (r == c ? 1.0 : 0.0);
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < S1_PB; ++c) {
+        double piv = __shfl(a[c], c);
+        if (!(piv > 0)) { bad = 1; piv = 1.0; }
+        const double dd = sqrt(piv);
+        a[c] = (r == c) ? dd : a[c] / dd;            // rows above the diagonal hold zeros here
+        const double lrc = a[c];
+#pragma unroll
+        for (int k = c + 1; k < S1_PB; ++k) {
+            const double lkc = __shfl(a[c], k);
+            if (r >= k) a[k] -= lrc * lkc;
+        }
+    }
+    if (bad && threadIdx.x == 0) status[1] = 1;
+    if (threadIdx.x < 32 && r < jb) {
+#pragma unroll
+        for (int c = 0; c < S1_PB; ++c) if (c <= r) A[(size_t)(j0 + r) * n + j0 + c] = a[c];
+    }
+    // inverse: lane c owns column c
+    double x[S1_PB];
+#pragma unroll
+    for (int rr = 0; rr < S1_PB; ++rr) {
+        double sacc = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < S1_PB; ++k) if (k < rr) sacc -= __shfl(a[k], rr) * x[k];
+        x[rr] = (rr < r) ? 0.0 : sacc / __shfl(a[rr], rr);
+    }
+    double* Di = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
+    if (threadIdx.x < 32) {
+#pragma unroll
+        for (int rr = 0; rr < S1_PB; ++rr) Di[rr * S1_PB + r] = x[rr];
+    }
+}
+#endif
 
 // rows below the diagonal block: x = a . L_D^{-T}, i.e. x_c = sum_{k <= c} a_k Dinv[c][k]        grid ceil(rows / 64), 64 threads
 KERNEL_LB(64) k_s1_chol_trsm(double* A, int n, int j0, const double* dinv) {
