@@ -121,19 +121,26 @@ def stagei_case(model_type='smplh', n_verts=2500, nb=6, M=30, F=6, seed=0, dof_p
     dd = synth.synth_mesh_model(model_type, seed=seed, num_betas=10, n_verts=n_verts)
     K = dd['weights'].shape[1]
     parents = synth.kintree_parents(model_type)
-    hp = synth.synth_hand_prior(seed)
-    body_dof = 3 * K - 90
-    comps = np.zeros((2 * dof_per_hand, 90))
-    comps[:dof_per_hand, :45] = hp['componentsl'][:dof_per_hand]
-    comps[dof_per_hand:, 45:] = hp['componentsr'][:dof_per_hand]
+    if model_type in ('smplh', 'smplx'):
+        hp = synth.synth_hand_prior(seed)
+        body_dof = 3 * K - 90
+        comps = np.zeros((2 * dof_per_hand, 90))
+        comps[:dof_per_hand, :45] = hp['componentsl'][:dof_per_hand]
+        comps[dof_per_hand:, 45:] = hp['componentsr'][:dof_per_hand]
+        hand_dof, hands_mean = 2 * dof_per_hand, np.zeros(90)
+    elif model_type == 'mano':
+        body_dof, hand_dof, hands_mean, comps = 3, dof_per_hand, dd['hands_mean'], dd['hands_components'][:dof_per_hand]
+    else:
+        body_dof, hand_dof, hands_mean, comps = 3 * K, 0, None, None
     model = dict(v_template=dd['v_template'], shapedirs=dd['shapedirs'], posedirs=dd['posedirs'], weights=dd['weights'],
-                 J_regressor=dd['J_regressor'], parents=parents, body_dof=body_dof, hand_dof=2 * dof_per_hand,
-                 hands_mean=np.zeros(90), selected_components=comps)
+                 J_regressor=dd['J_regressor'], parents=parents, body_dof=body_dof, hand_dof=hand_dof,
+                 hands_mean=hands_mean, selected_components=comps)
     m = so.prepare_model(model)
     so.set_free_shape(m, 0, nb)
-    prior = so.prepare_gmm_prior(synth.synth_gmm_prior(seed), 63)
+    npose = 63 if model_type in ('smplh', 'smplx') else 69
+    prior = so.prepare_gmm_prior(synth.synth_gmm_prior(seed), npose) if model_type != 'mano' else None
     dom = np.argmax(dd['weights'], 1)
-    ok = dd['_exposed'] & ((dom <= 21) | finger_markers)
+    ok = dd['_exposed'] & ((dom <= 21) | finger_markers) if model_type != 'mano' else np.ones(len(dom), bool)
     cand = np.flatnonzero(ok)
     v = dd['v_template']
     vids = [cand[rng.integers(len(cand))]]
@@ -144,32 +151,39 @@ def stagei_case(model_type='smplh', n_verts=2500, nb=6, M=30, F=6, seed=0, dof_p
         dmin = np.minimum(dmin, ((v[cand] - v[nxt]) ** 2).sum(1))
     vids = np.array(vids)
     betas_gt = rng.normal(0, 0.8, nb)
+    shp = betas_gt if nb else None
     fp_can = so.fullpose_from_pose(m, np.zeros(m['NP']))
-    can_gt = so.verts_forward(m, fp_can, np.zeros(3), None, shp=betas_gt)
-    m2b = np.ones(M) * 0.0095
-    ml_gt = s1.markers_latent_init(can_gt, dd['f'], vids, m2b) + rng.normal(0, 0.004, (M, 3))
+    can_gt = so.verts_forward(m, fp_can, np.zeros(3), None, shp=shp)
+    m2b = np.ones(M) * (0.0095 if model_type != 'mano' else 0.003)
+    ml_gt = s1.markers_latent_init(can_gt, dd['f'], vids, m2b) + rng.normal(0, 0.004 if model_type != 'mano' else 0.001, (M, 3))
     cl, coef = so.transformed_coeffs(can_gt, ml_gt)
     pose_gt, trans_gt = synth.synth_motion(m['NP'], body_dof, 400, seed=seed)
     frames = []
     for t in np.linspace(60, 399, F).astype(int):
         p = pose_gt[t].copy()
-        if not finger_markers:
+        if not finger_markers and model_type != 'mano':
             p[body_dof:] = 0
-        p[30:36] = 0
-        vv = so.verts_forward(m, so.fullpose_from_pose(m, p), trans_gt[t], cl.reshape(-1), shp=betas_gt).reshape(M, 3, 3)
+        if model_type != 'mano':
+            p[30:36] = 0
+        if model_type == 'smplx':
+            p[66:75] = 0
+        vv = so.verts_forward(m, so.fullpose_from_pose(m, p), trans_gt[t], cl.reshape(-1), shp=shp).reshape(M, 3, 3)
         sim = so.markers_from_verts(coef, vv[:, 0], vv[:, 1], vv[:, 2]) + rng.normal(0, 0.0003, (M, 3))
         ids = np.flatnonzero(rng.random(M) > 0.05)
         frames.append((ids, sim[ids]))
     return dict(m=m, model=model, faces=dd['f'], prior=prior, frames=frames, vids=vids, betas_gt=betas_gt, ml_gt=ml_gt, nb=nb, M=M,
-                mask={'body': np.ones(M, bool)}, m2b={'body': 0.0095}, model_type=model_type, dd=dd)
+                mask={'body': np.ones(M, bool)}, m2b={'body': float(m2b[0])}, model_type=model_type, dd=dd)
 
 
-def stagei_kwargs(case, optimize_fingers=False):
+def stagei_kwargs(case, optimize_fingers=False, exclude_vids=None, head_corr=None, betas_init=None):
     """The arguments of capi.stagei_desc for a stagei_case (reference default weights)."""
     from oracle import stagei_oracle as s1
     m = case['m']
     root, body, finger, step1, _ = so.pose_id_sets(case['model_type'], m['NP'], optimize_fingers=optimize_fingers)
+    if case['model_type'] == 'mano' and not optimize_fingers:
+        finger = []                       # chmosh.py:300-301 sets the ids, :390-393 adds them only with optimize_fingers
     M = case['M']
     W = s1.stagei_weights_default()
-    return dict(faces=case['faces'], marker_vids=case['vids'], m2b=np.ones(M) * 0.0095, wt_init=np.ones(M) * W['stagei_wt_init'],
-                frames=case['frames'], nb=case['nb'], weights=W, pose_ids=step1, body_ids=body, finger_ids=finger)
+    return dict(faces=case['faces'], marker_vids=case['vids'], m2b=np.ones(M) * case['m2b']['body'], wt_init=np.ones(M) * W['stagei_wt_init'],
+                frames=case['frames'], nb=case['nb'], weights=W, pose_ids=step1, body_ids=body if case['prior'] is not None else [],
+                finger_ids=finger, exclude_vids=exclude_vids, head_corr=head_corr, betas_init=betas_init)

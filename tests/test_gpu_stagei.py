@@ -44,6 +44,47 @@ def test_stagei_matches_oracle(fingers):
         assert abs(out['errs'][k] - v) <= 1e-5 * max(1.0, abs(v)), k
 
 
+def _variant(name):
+    """(case, optimize_fingers, extra arguments) of the Stage-I parity variants."""
+    if name == 'smplx_exclude':      # SMPL-X topology; a vertex set the attachment may not use (the eyeballs of transformed_lm.py:49-50)
+        c = helpers.stagei_case('smplx', seed=3)
+        dom = np.argmax(c['dd']['weights'], 1)
+        return c, False, dict(exclude_vids=np.flatnonzero(dom >= 23)[:200])
+    if name == 'smpl':
+        return helpers.stagei_case('smpl', seed=4), False, {}
+    if name == 'mano':               # no body prior, only root + fingers
+        return helpers.stagei_case('mano', n_verts=700, M=14, seed=5, nb=4), True, {}
+    if name == 'fixed_betas':        # optimize_betas = false: no shape unknowns, no beta term
+        return helpers.stagei_case('smplh', seed=6, nb=0), False, {}
+    if name == 'betas_init':         # betas_fname given and optimize_betas = true: the solve starts from them (chmosh.py:164-170)
+        return helpers.stagei_case('smplh', seed=7), False, dict(betas_init=np.array([0.3, -0.2, 0.1, 0.0, 0.4, -0.5]))
+    if name == 'head_corr':          # head-marker correlation term (chmosh.py:252-266, 362-369)
+        rng = np.random.default_rng(0)
+        return helpers.stagei_case(), False, dict(head_corr=(np.array([3, 7, 11, 20]), rng.normal(0, 1, (3, 4))))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr'])
+def test_stagei_variants_match_oracle(name):
+    from moshpp_amd import capi
+    from oracle import stagei_oracle as s1
+    c, fingers, extra = _variant(name)
+    mdl = c['model']
+    dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'], mdl['parents'],
+                     mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
+    pr = capi.Prior(c['prior']['means'], c['prior']['chols'], c['prior']['weights']) if c['prior'] is not None else None
+    out = capi.stagei_solve_host(dev, pr, **helpers.stagei_kwargs(c, optimize_fingers=fingers, **extra))
+    ref = s1.stagei_solve(c['m'], c['faces'], c['prior'], c['model_type'], c['frames'], c['vids'], c['mask'], c['m2b'], c['nb'],
+                          optimize_fingers=fingers, **extra)
+    if c['nb']:
+        assert np.abs(out['betas'] - ref['betas']).max() < 1e-5
+    assert np.abs(out['markers_latent'] - ref['markers_latent']).max() < 1e-6
+    assert np.abs(out['pose'] - ref['pose']).max() < 1e-5 and np.abs(out['trans'] - ref['trans']).max() < 1e-6
+    assert (out['markers_latent_vids'] == ref['markers_latent_vids']).all()
+    if name == 'head_corr':
+        assert abs(out['errs']['init_head_corr'] - ref['errs']['init_head_corr']) < 1e-6 * max(1.0, ref['errs']['init_head_corr'])
+
+
 def test_stagei_rejects_bad_input():
     from moshpp_amd import capi
     c = helpers.stagei_case()

@@ -102,3 +102,18 @@ def test_kernel_arithmetic_matches_oracle_in_emulation(case, fingers):
     e = ref['errs']
     want = [e['data'], e['poseB'], e['init_0'], e['beta'], e['surf'], e.get('poseH', 0.0)]
     assert np.allclose(out['errs'][:6], want, rtol=1e-7, atol=1e-12) and out['errs'][6] == 0.0
+
+
+@pytest.mark.parametrize('name', ['mano', 'fixed_betas', 'head_corr'])
+def test_kernel_arithmetic_variants_in_emulation(name):
+    """Other model families / options through the emulated kernels (the GPU tests run the full list)."""
+    from tests.emu import emu_stagei
+    from tests.test_gpu_stagei import _variant
+    c, fingers, extra = _variant(name)
+    out = emu_stagei.solve(c['m'], c['prior'], **helpers.stagei_kwargs(c, optimize_fingers=fingers, **extra))
+    ref = s1.stagei_solve(c['m'], c['faces'], c['prior'], c['model_type'], c['frames'], c['vids'], c['mask'], c['m2b'], c['nb'],
+                          optimize_fingers=fingers, **extra)
+    assert np.abs(out['markers_latent'] - ref['markers_latent']).max() < 1e-9
+    assert np.abs(out['pose'] - ref['pose']).max() < 1e-8 and np.abs(out['trans'] - ref['trans']).max() < 1e-9
+    if c['nb']:
+        assert np.abs(out['betas'] - ref['betas']).max() < 1e-8
