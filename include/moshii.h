@@ -275,6 +275,15 @@ typedef struct moshii_stagei_desc {
     double         wt_init_head;            /* stagei_wt_init_body if the layout has a 'body' type, else stagei_wt_init */
     int32_t        maxiter;                 /* cfg.opt_settings.maxiter                                          */
     double         stagei_lr;               /* cfg.opt_settings.stagei_lr (dogleg e_3)                           */
+    /* optional: frames of ONE problem spread over ranks (one process per GPU).  Every rank passes the same problem; rank r evaluates
+     * the data / prior / finger rows of frames [frame_lo, frame_hi), exactly one rank (owns_shared_rows) the init / beta / surf / head
+     * rows.  allreduce_sum sums `count` doubles in place over the ranks (host buffer): the normal equations [A | g] once per dogleg
+     * iteration, a scalar per residual evaluation, the rigid starts and the final SSEs.  Every rank then takes the same step and
+     * returns the same result.  This is the reference deployment's "shared betas" coupling (all frames share betas and the latent
+     * markers) as a reduction; sharded == 0 ignores all of it. */
+    int32_t  sharded, frame_lo, frame_hi, owns_shared_rows;
+    int    (*allreduce_sum)(double* buf, int64_t count, void* user);
+    void*    allreduce_user;
     /* outputs */
     double*  betas;                         /* [nb]                                                              */
     double*  markers_latent;                /* [M][3]                                                            */

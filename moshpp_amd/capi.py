@@ -406,15 +406,19 @@ class StageIDesc(C.Structure):
                 ('finger_ids', C.c_void_p), ('n_finger', C.c_int32),
                 ('head_ids', C.c_void_p), ('head_corr', C.c_void_p), ('n_head', C.c_int32), ('n_head_rows', C.c_int32),
                 ('wt_init_head', C.c_double), ('maxiter', C.c_int32), ('stagei_lr', C.c_double),
+                ('sharded', C.c_int32), ('frame_lo', C.c_int32), ('frame_hi', C.c_int32), ('owns_shared_rows', C.c_int32),
+                ('allreduce_sum', C.c_void_p), ('allreduce_user', C.c_void_p),
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
                 ('pose', C.c_void_p), ('trans', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p)]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
 STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH', 'init_head_corr')
 
 
 def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_ids, body_ids, finger_ids=(), exclude_vids=None,
-                betas_init=None, maxiter=100, stagei_lr=1e-3, head_corr=None, wt_init_head=None):
+                betas_init=None, maxiter=100, stagei_lr=1e-3, head_corr=None, wt_init_head=None, frame_range=None,
+                owns_shared_rows=True, allreduce=None):
     """Fill a StageIDesc from NumPy data.  `frames`: list of (latent ids, obs[n,3]).  Returns (desc, outputs dict, keep-alive list)."""
     keep = []
 
@@ -446,6 +450,22 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
         assert Cm.shape[1] == len(hid)
         d.head_ids = ptr(hid, np.int32); d.head_corr = ptr(Cm, np.float64); d.n_head, d.n_head_rows = Cm.shape[1], Cm.shape[0]
     d.wt_init_head = float(weights['stagei_wt_init'] if wt_init_head is None else wt_init_head)
+    if allreduce is not None:
+        # allreduce(array) sums a 1-D float64 NumPy array in place over the ranks (moshpp_amd.parallel.make_allreduce)
+        def _cb(buf, count, _user):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:          # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLREDUCE_CB(_cb)
+        keep.append(cb)
+        d.sharded = 1
+        d.frame_lo, d.frame_hi = (0, F) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
+        d.owns_shared_rows = 1 if owns_shared_rows else 0
+        d.allreduce_sum = C.cast(cb, C.c_void_p)
     out = dict(betas=np.zeros(max(nb, 1)), markers_latent=np.zeros((M, 3)), markers_latent_vids=np.zeros(M, np.int32),
                pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), errs=np.zeros(7), iters=np.zeros(1, np.int32))
     for k, v in out.items():

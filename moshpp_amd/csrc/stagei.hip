@@ -411,8 +411,8 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
 
 // pose Jacobian of the attached vertices: one thread per (vertex, joint k), its three dofs:
 //   dv = omega_kc x (S_k - W_k tw_k) + Trot . (posedirs[v, :, 9(k-1):9k] . vec(B_kc))            grid (ceil(3M K / S1_TPB), F)
-KERNEL k_s1_vjac(S1Dims d, S1Ptr p) {
-    int z = BY;
+KERNEL k_s1_vjac(S1Dims d, S1Ptr p, int zbase) {
+    int z = zbase + BY;
     int it = BX * NT + TID;
     if (it >= 3 * d.M * d.K) return;
     int a = it / d.K, k = it % d.K;
@@ -635,8 +635,8 @@ DEVFN void rigid_fit(const double* A_, const double* B_, int cnt, double* rv, do
 }
 
 // rigid start of every frame (grid F): markers simulated at the uploaded point vs the observations; out[f] = [rotvec, T]
-KERNEL k_s1_rigid(S1Dims d, S1Ptr p, double* sim, double* out) {
-    int f = BX;
+KERNEL k_s1_rigid(S1Dims d, S1Ptr p, double* sim, double* out, int fbase) {
+    int f = fbase + BX;
     int o0 = p.obs_off[f], nobs = p.obs_off[f + 1] - o0;
     const double* vv = p.vv + 3 * ((size_t)f * d.ncan);
     for (int k = TID; k < nobs; k += NT) {
@@ -654,7 +654,7 @@ KERNEL k_s1_rigid(S1Dims d, S1Ptr p, double* sim, double* out) {
 // shared rows (grid ceil(M / S1_TPB)): coefficients and canonical frames of the attachment, their shape derivative, the
 // init / surf / beta rows.  want_J = 0 skips the Jacobian.
 // ---------------------------------------------------------------------------------------------------------------------------
-KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
+KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J, int write_rows) {
     int m = BX * NT + TID;
     if (m >= d.M) return;
     const size_t zc = (size_t)d.F * d.ncan;                         // canonical slots
@@ -692,11 +692,11 @@ KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
         double w = p.wt_init[m] * p.w_anneal;
         for (int a = 0; a < 3; ++a) {
             double init = v0[a] + c0[0] * F0[a] + c0[1] * F0[3 + a] + c0[2] * F0[6 + a];
-            p.r[d.r_init + 3 * m + a] = (p.ml[3 * m + a] - init) * w;
+            if (write_rows) p.r[d.r_init + 3 * m + a] = (p.ml[3 * m + a] - init) * w;
             p.loss[3 * m + a] = p.ml[3 * m + a] - init;
         }
         if (want_J) {
-            for (int a = 0; a < 3; ++a) p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_ml + 3 * m + a] = w;
+            if (write_rows) for (int a = 0; a < 3; ++a) p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_ml + 3 * m + a] = w;
             if (nb) {
                 frame_jac(v0, v0 + 3, v0 + 6, c0, L0);
                 for (int a = 0; a < 3; ++a) L0[9 * a + a] += 1.0;
@@ -704,13 +704,14 @@ KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J) {
                 for (int a = 0; a < 3; ++a) for (int e = 0; e < nb; ++e) {
                     double s = 0;
                     for (int b = 0; b < 9; ++b) s += L0[9 * a + b] * dV[(size_t)b * nb + e];
-                    p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_b + e] = -w * s;
+                    if (write_rows) p.Jm[(size_t)(d.r_init + 3 * m + a) * d.ldn + d.o_b + e] = -w * s;
                     p.dinit[((size_t)m * 3 + a) * nb + e] = s;
                 }
             }
         }
     }
     // surf row
+    if (!write_rows) return;
     p.r[d.r_surf + m] = (p.sdist[m] - p.m2b[m]) * p.w_surf;
     if (want_J) {
         double* Jr = p.Jm + (size_t)(d.r_surf + m) * d.ldn;
@@ -753,9 +754,9 @@ KERNEL k_s1_head(S1Dims d, S1Ptr p, int want_J) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // per-frame rows (grid F): data, poseB, poseH
 // ---------------------------------------------------------------------------------------------------------------------------
-KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J) {
+KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
     SHARED double score[64]; SHARED int kbest;
-    int f = BX;
+    int f = fbase + BX;
     const int M = d.M, nb = d.nb, npid = d.npid;
     const double* vv = p.vv + 3 * ((size_t)f * d.ncan);
     double* Lb = p.Lb + (size_t)f * M * 36;              // per marker: L[27] + posed frame F'[9]
@@ -1203,6 +1204,15 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     for (int f = 0; f < F; ++f) { ntot_obs += ds->n_obs[f]; obs_off[f + 1] = ntot_obs; }
     for (int i = 0; i < ntot_obs; ++i) if (ds->obs_ids[i] < 0 || ds->obs_ids[i] >= M) return fail(MOSHII_ERR_ARG, "stagei: observed marker id out of range");
 
+    // frames of this rank (moshii_stagei_desc.sharded): every rank evaluates the canonical body and the attachment, the data / prior /
+    // finger rows of its own frames, one rank the shared rows; normal equations and SSE are summed over the ranks through the
+    // caller's all-reduce, after which every rank holds the same system and takes the same step
+    const bool shard = ds->sharded && ds->allreduce_sum;
+    const int f_lo = shard ? ds->frame_lo : 0, f_hi = shard ? ds->frame_hi : F, nown = f_hi - f_lo;
+    const int own_shared = shard ? (ds->owns_shared_rows ? 1 : 0) : 1;
+    if (shard && (f_lo < 0 || f_hi > F || nown < 0)) return fail(MOSHII_ERR_ARG, "stagei: frame range of this rank out of bounds");
+    int reduce_rc = 0;
+    auto reduce = [&](double* buf, long long count) { if (shard && ds->allreduce_sum(buf, count, ds->allreduce_user) != 0) reduce_rc = 1; };
     DevPool pool;
     // ---- constants
     p.parents = mv->parents; p.vt = mv->vt; p.shapedirs = mv->shapedirs; p.posedirs = mv->posedirs; p.weights = mv->weights;
@@ -1297,12 +1307,13 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         LAUNCH(k_s1_surface, M, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_lists, (3 * M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_verts, (d.ncan * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0);
-        LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p, 0, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
-        if (want_J) LAUNCH(k_s1_vjac, (3 * M * K + S1_TPB - 1) / S1_TPB, F, S1_TPB, st, d, p);
+        if (nown > 0) LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
+        if (want_J && nown > 0) LAUNCH(k_s1_vjac, (3 * M * K + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo);
         if (want_J) hipMemsetAsync(p.Jm, 0, (size_t)d.R * d.ldn * 8, st);
-        LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J);
-        if (d.nhead_rows) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
-        LAUNCH(k_s1_rows, F, 1, S1_TPB, st, d, p, want_J);
+        if (shard) hipMemsetAsync(p.r, 0, (size_t)d.R * 8, st);          // rows of frames other ranks own stay zero here
+        LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J, own_shared);
+        if (d.nhead_rows && own_shared) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
+        if (nown > 0) LAUNCH(k_s1_rows, nown, 1, S1_TPB, st, d, p, want_J, f_lo);
     };
     auto fetch = [&](std::vector<double>& h, const double* dev, size_t count) {
         h.resize(count);
@@ -1349,9 +1360,11 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     {   // rigid start per frame (chmosh.py:236-238, rigid_transformations.py:39-83): Procrustes on the zero-pose markers
         double* d_sim = pool.get<double>((size_t)3 * std::max(1, ntot_obs)); double* d_rt = pool.get<double>(6 * F);
         if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed");
-        LAUNCH(k_s1_rigid, F, 1, S1_TPB, st, d, p, d_sim, d_rt);
+        hipMemsetAsync(d_rt, 0, 6 * F * 8, st);
+        if (nown > 0) LAUNCH(k_s1_rigid, nown, 1, S1_TPB, st, d, p, d_sim, d_rt, f_lo);
         std::vector<double> rt;
         fetch(rt, d_rt, 6 * F);
+        reduce(rt.data(), 6 * F);
         for (int f = 0; f < F; ++f) for (int a = 0; a < 3; ++a) { pose[(size_t)f * NP + a] = rt[6 * f + a]; trans[3 * f + a] = rt[6 * f + 3 + a]; }
 #ifdef S1_EMU
         if (getenv("S1_DEBUG")) {
@@ -1371,7 +1384,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
 
     // ---- annealing rounds
     int total_iters = 0;
-    std::vector<double> r, rnew, g, x, dsd, dgn, ddl, tmp;
+    std::vector<double> r, rnew, g, x, dsd, dgn, ddl, tmp, hbuf;
     for (int round = 0; round < ds->n_anneal; ++round) {
         const double a = ds->annealing[round];
         const bool detailed = round > ds->n_anneal - 3;
@@ -1408,8 +1421,11 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) pose[(size_t)f * NP + pose_ids[c]] = xx[d.o_pose + f * d.npid + c];
             for (int e = 0; e < nb; ++e) betas[e] = xx[d.o_b + e];
         };
-        auto eval_at = [&](const std::vector<double>& xx, int want_J, std::vector<double>& rr) {
+        auto eval_at = [&](const std::vector<double>& xx, int want_J, std::vector<double>& rr) -> double {
             unpack(xx); upload_point(); evaluate(want_J); fetch(rr, p.r, R);
+            double sse_ = dotv(rr, rr);
+            reduce(&sse_, 1);
+            return sse_;
         };
         auto normal_eq = [&]() {     // A = J^T J, g = -J^T r on the device; g to the host
             int nt = (n + S1_T - 1) / S1_T;
@@ -1417,6 +1433,16 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             LAUNCH(k_s1_syrk, nt, nt, 256, st, p.Jm, R, n, d.ldn, d_A, d_flags);
             LAUNCH(k_s1_gemv_t, (n + S1_TPB - 1) / S1_TPB, S1_GT_CHUNKS, S1_TPB, st, p.Jm, p.r, R, n, d.ldn, d_part);
             LAUNCH(k_s1_gemv_t_sum, (n + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_part, n, -1.0, d_g);
+            if (shard) {        // sum the ranks' normal equations: [A | g] through the host (a few MB per iteration)
+                hbuf.resize((size_t)n * n + n);
+                hipMemcpyAsync(hbuf.data(), d_A, (size_t)n * n * 8, hipMemcpyDeviceToHost, st);
+                hipMemcpyAsync(hbuf.data() + (size_t)n * n, d_g, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+                hipStreamSynchronize(st);
+                reduce(hbuf.data(), (long long)n * n + n);
+                hipMemcpyAsync(d_A, hbuf.data(), (size_t)n * n * 8, hipMemcpyHostToDevice, st);
+                hipMemcpyAsync(d_g, hbuf.data() + (size_t)n * n, (size_t)n * 8, hipMemcpyHostToDevice, st);
+                hipStreamSynchronize(st);
+            }
             fetch(g, d_g, n);
         };
         auto Ax = [&](const std::vector<double>& v, std::vector<double>& out) {   // A . v (A must still be unfactored)
@@ -1427,7 +1453,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         // ---- Powell dogleg (chumpy minimize_dogleg as restated in oracle/stageii_oracle.py:minimize_dogleg)
         const double e1 = 1e-15, e2 = 1e-15, e3 = ds->stagei_lr;
         pack(x);
-        eval_at(x, 1, r);
+        double sse = eval_at(x, 1, r);
         normal_eq();
         double delta = 0.5;
         bool done = false;
@@ -1478,8 +1504,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                 else {
                     xt = x;
                     for (int i = 0; i < n; ++i) xt[i] += ddl[i];
-                    eval_at(xt, 0, rnew);
-                    double sse = dotv(r, r), sse_new = dotv(rnew, rnew);
+                    const double sse_new = eval_at(xt, 0, rnew);
                     double rho = sse - sse_new;
                     if (rho > 0) {
                         Ax(ddl, tmp);
@@ -1490,7 +1515,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                         x = xt;
                         if (e3 > 0 && (sse - sse_new) / sse < e3) done = true;
                         else {
-                            eval_at(x, 1, r);
+                            sse = eval_at(x, 1, r);
                             normal_eq();
                             if (norminf(g) < e1) done = true;
                         }
@@ -1507,15 +1532,17 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         unpack(x);
         if (round == ds->n_anneal - 1) {
             upload_point(); evaluate(0); fetch(r, p.r, R);
-            auto sse = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
+            auto sse_rows = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
             if (ds->errs) {
-                ds->errs[0] = sse(d.r_data, d.r_prior); ds->errs[1] = sse(d.r_prior, d.r_init); ds->errs[2] = sse(d.r_init, d.r_beta);
-                ds->errs[3] = sse(d.r_beta, d.r_surf); ds->errs[4] = sse(d.r_surf, d.r_poseH); ds->errs[5] = sse(d.r_poseH, d.r_head); ds->errs[6] = sse(d.r_head, d.R);
+                ds->errs[0] = sse_rows(d.r_data, d.r_prior); ds->errs[1] = sse_rows(d.r_prior, d.r_init); ds->errs[2] = sse_rows(d.r_init, d.r_beta);
+                ds->errs[3] = sse_rows(d.r_beta, d.r_surf); ds->errs[4] = sse_rows(d.r_surf, d.r_poseH); ds->errs[5] = sse_rows(d.r_poseH, d.r_head); ds->errs[6] = sse_rows(d.r_head, d.R);
+                reduce(ds->errs, 7);
             }
         }
         int hstat[4];
         hipMemcpyAsync(hstat, p.status, sizeof(hstat), hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
+        if (reduce_rc) return fail(MOSHII_ERR_ARG, "stagei: the all-reduce callback failed");
         if (hstat[0] == 3) return fail(MOSHII_ERR_ARG, "stagei: a vertex has more than 16 non-zero skinning weights");
         if (hstat[1]) return fail(MOSHII_ERR_NUMERIC, "stagei: normal equations not positive definite");
         if (hstat[2]) return fail(MOSHII_ERR_NUMERIC, "stagei: the three nearest vertices of a marker are collinear (the reference falls back to the next neighbour, transformed_lm.py:94-101; not implemented)");

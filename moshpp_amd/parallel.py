@@ -135,3 +135,29 @@ def solve_sequence_sharded(solve_range: Callable, F: int, dist=None, warmup: int
     devs = [None] * world
     dist.all_gather_object(devs, max_dev)
     return out, dict(range=(a, b), rounds=rounds, repaired=repaired, max_handoff_dev=float(max(devs)))
+
+
+# ---- Stage-I: frames of one subject over the ranks ----------------------------------------------------------------
+def make_allreduce(dist, device=None):
+    """In-place sum of a 1-D float64 NumPy array over the ranks of `dist` (torch.distributed).  gloo reduces the host buffer
+    directly; nccl (= RCCL over xGMI) goes through a device tensor."""
+    import torch
+
+    def allreduce(arr):
+        t = torch.from_numpy(arr)
+        if dist.get_backend() == 'nccl':
+            g = t.to(device if device is not None else 'cuda')
+            dist.all_reduce(g)
+            t.copy_(g.cpu())
+        else:
+            dist.all_reduce(t)
+    return allreduce
+
+
+def stagei_solve_sharded(solve, n_frames, dist):
+    """One Stage-I problem over the ranks: rank r evaluates frames frame_ranges(n_frames, world)[r], rank 0 the shared rows; the
+    normal equations are summed with an all-reduce per dogleg iteration (moshii_stagei_desc.sharded) and every rank returns the
+    same solution.  `solve(frame_range=..., owns_shared_rows=..., allreduce=...)` is capi.stagei_solve_host with the problem bound."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = frame_ranges(n_frames, world)[rank]
+    return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce(dist))

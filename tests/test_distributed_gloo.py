@@ -116,3 +116,47 @@ def test_three_rank_gloo_one_sequence_by_frame_ranges(tmp_path):
     port = _free_port()
     mp.spawn(_worker_frames, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert os.path.exists(tmp_path / 'ok_frames.npy')
+
+
+# ---- Stage-I: frames of one subject over ranks, normal equations all-reduced (moshii_stagei_desc.sharded) --------------------
+def _stagei_worker(rank, world, port, outdir):
+    """The Stage-I solver with its frames split over `world` ranks and gloo as the all-reduce.  On this CPU-only box the kernels run
+    through the g++ emulation build of stagei.hip (tests/emu): same source, same host code, same sharding logic as the GPU library."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from moshpp_amd.parallel import stagei_solve_sharded
+    from tests import helpers
+    from tests.emu import emu_stagei
+    c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
+    kw = helpers.stagei_kwargs(c)
+    out = stagei_solve_sharded(lambda **sh: emu_stagei.solve(c['m'], c['prior'], **kw, **sh), len(c['frames']), dist)
+    np.savez(os.path.join(outdir, f'rank{rank}.npz'), **{k: np.asarray(v) for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stagei_frames_sharded_over_ranks_gloo(tmp_path):
+    """world_size 2 and 3 (uneven split of 5 frames): every rank returns the same solution, equal to the single-process solve up to
+    the summation order of the reduced normal equations."""
+    sys.path.insert(0, ROOT)
+    from tests import helpers
+    from tests.emu import emu_stagei
+    emu_stagei.build_emu.build()                 # compile once, before the ranks race for it
+    c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
+    single = emu_stagei.solve(c['m'], c['prior'], **helpers.stagei_kwargs(c))
+    for world in (2, 3):
+        d = tmp_path / f'w{world}'
+        os.makedirs(d)
+        mp.spawn(_stagei_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        outs = [np.load(d / f'rank{r}.npz') for r in range(world)]
+        for o in outs:
+            assert int(o['iters'][0]) == int(single['iters'][0])
+            assert np.abs(o['betas'] - single['betas']).max() < 1e-9
+            assert np.abs(o['markers_latent'] - single['markers_latent']).max() < 1e-10
+            assert np.abs(o['pose'] - single['pose']).max() < 1e-9 and np.abs(o['trans'] - single['trans']).max() < 1e-10
+            assert np.allclose(o['errs'], single['errs'], rtol=1e-8, atol=1e-12)
+        for o in outs[1:]:
+            assert np.array_equal(o['betas'], outs[0]['betas']) and np.array_equal(o['pose'], outs[0]['pose'])

@@ -58,3 +58,44 @@ def test_one_sequence_over_two_ranks_equals_sequential_chain(gpu_lib, tmp_path):
         assert r['info']['max_handoff_dev'] <= 1e-9
     assert res[0]['calls'] == [(0, 600, False)]
     assert res[1]['calls'][0] == (600 - 32, 1200, False)
+
+
+# ---- Stage-I: the picked frames of one subject over ranks, normal equations all-reduced ---------------------------------------
+def _stagei_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from moshpp_amd import capi
+    from moshpp_amd.parallel import stagei_solve_sharded
+    from tests import helpers
+    c = helpers.stagei_case(seed=12)
+    mdl = c['model']
+    dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'], mdl['parents'],
+                     mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
+    pr = capi.Prior(c['prior']['means'], c['prior']['chols'], c['prior']['weights'])
+    kw = helpers.stagei_kwargs(c)
+    out = stagei_solve_sharded(lambda **sh: capi.stagei_solve_host(dev, pr, **kw, **sh), len(c['frames']), dist)
+    np.savez(os.path.join(outdir, f'rank{rank}.npz'), betas=out['betas'], markers_latent=out['markers_latent'], pose=out['pose'],
+             trans=out['trans'], iters=out['iters'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stagei_frames_over_two_ranks_equals_single_process(gpu_lib, tmp_path):
+    from moshpp_amd import capi
+    from tests import helpers
+    mp.spawn(_stagei_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    c = helpers.stagei_case(seed=12)
+    mdl = c['model']
+    dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'], mdl['parents'],
+                     mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
+    pr = capi.Prior(c['prior']['means'], c['prior']['chols'], c['prior']['weights'])
+    single = capi.stagei_solve_host(dev, pr, **helpers.stagei_kwargs(c))
+    outs = [np.load(tmp_path / f'rank{r}.npz') for r in range(2)]
+    for o in outs:
+        assert int(o['iters']) == single['iters']
+        assert np.abs(o['betas'] - single['betas']).max() < 1e-8 and np.abs(o['markers_latent'] - single['markers_latent']).max() < 1e-9
+        assert np.abs(o['pose'] - single['pose']).max() < 1e-8 and np.abs(o['trans'] - single['trans']).max() < 1e-9
+    assert np.array_equal(outs[0]['betas'], outs[1]['betas']) and np.array_equal(outs[0]['pose'], outs[1]['pose'])
