@@ -290,6 +290,7 @@ typedef struct moshii_stagei_desc {
     int32_t* markers_latent_vids;           /* [M] nearest canonical vertex of each latent marker (:420-422)     */
     double*  pose;                          /* [n_frames][NP]                                                    */
     double*  trans;                         /* [n_frames][3]                                                     */
+    double*  markers_sim;                   /* [n_frames][M][3] or NULL: every latent marker simulated on every frame's body */
     double*  errs;                          /* [7] SSE of data, poseB, init, beta, surf, poseH, init_head_corr   */
     int32_t* iters;                         /* [1] dogleg outer iterations over all rounds                       */
 } moshii_stagei_desc;

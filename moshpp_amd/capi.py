@@ -409,7 +409,7 @@ class StageIDesc(C.Structure):
                 ('sharded', C.c_int32), ('frame_lo', C.c_int32), ('frame_hi', C.c_int32), ('owns_shared_rows', C.c_int32),
                 ('allreduce_sum', C.c_void_p), ('allreduce_user', C.c_void_p),
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
-                ('pose', C.c_void_p), ('trans', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p)]
+                ('pose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
@@ -467,7 +467,8 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
         d.owns_shared_rows = 1 if owns_shared_rows else 0
         d.allreduce_sum = C.cast(cb, C.c_void_p)
     out = dict(betas=np.zeros(max(nb, 1)), markers_latent=np.zeros((M, 3)), markers_latent_vids=np.zeros(M, np.int32),
-               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), errs=np.zeros(7), iters=np.zeros(1, np.int32))
+               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), markers_sim=np.zeros((F, M, 3)), errs=np.zeros(7),
+               iters=np.zeros(1, np.int32))
     for k, v in out.items():
         setattr(d, k, v.ctypes.data)
     out['betas'] = out['betas'][:nb]

@@ -416,8 +416,22 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
         all_betas[:nb] = out['betas']
     errs = {k: v for k, v in out['errs'].items() if not (k == 'poseH' and not finger_ids) and not (k == 'beta' and not nb)
             and not (k == 'poseB' and prior is None) and not (k == 'init_head_corr' and head_corr is None)}
+    # markers_latent_all_vids (:424-430): nearest vertex of the LAST frame's posed body for every valid marker of that frame
+    dev.set_betas(all_betas if optimize_betas else np.zeros_like(all_betas))
+    last_body = dev.lbs_forward(out['pose'][-1:], out['trans'][-1:])[0]
+    last = stagei_frames[-1]
+    keys = [k for k, v in last.items() if not np.any(np.isnan(v))]
+    all_vids = {}
+    if keys:
+        locs = np.array([np.asarray(last[k], dtype=np.float64) for k in keys])
+        nearest = np.argmin(((locs[:, None, :] - last_body[None]) ** 2).sum(-1), axis=1)
+        all_vids = {k: int(v) for k, v in zip(keys, nearest)}
+    sim_all = out['markers_sim']
     stagei_debug_details = {'opt_models_trans': [t for t in out['trans']], 'opt_models_pose': [p for p in out['pose']],
-                            'stagei_errs': errs, 'stagei_markers_obs': markers_obs, 'stagei_labels_obs': labels_obs,
+                            'stagei_errs': errs, 'markers_latent_all_vids': all_vids,
+                            'stagei_markers_sim_all': [sim_all[f] for f in range(len(frames))],
+                            'stagei_markers_sim': [sim_all[f][ids] for f, (ids, _) in enumerate(frames)],
+                            'stagei_markers_obs': markers_obs, 'stagei_labels_obs': labels_obs,
                             'stagei_iters': out['iters']}
     stagei_data = {'betas': all_betas, 'markers_latent': out['markers_latent'], 'latent_labels': latent_labels,
                    'marker_meta': marker_meta,

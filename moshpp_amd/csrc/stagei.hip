@@ -650,6 +650,18 @@ KERNEL k_s1_rigid(S1Dims d, S1Ptr p, double* sim, double* out, int fbase) {
     if (TID == 0) rigid_fit(sim + 3 * (size_t)o0, p.obs + 3 * (size_t)o0, nobs, out + 6 * f, out + 6 * f + 3);
 }
 
+// simulated markers of every frame at the uploaded point (all M latent markers): out[F][M][3]        grid F
+KERNEL k_s1_simall(S1Dims d, S1Ptr p, double* out, int fbase) {
+    int f = fbase + BX;
+    const double* vv = p.vv + 3 * ((size_t)f * d.ncan);
+    for (int m = TID; m < d.M; m += NT) {
+        const double* v0 = vv + 9 * m; const double* c = p.coef + 3 * m;
+        double Fm[9];
+        frame_of(v0, v0 + 3, v0 + 6, Fm);
+        for (int a = 0; a < 3; ++a) out[((size_t)f * d.M + m) * 3 + a] = v0[a] + c[0] * Fm[a] + c[1] * Fm[3 + a] + c[2] * Fm[6 + a];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // shared rows (grid ceil(M / S1_TPB)): coefficients and canonical frames of the attachment, their shape derivative, the
 // init / surf / beta rows.  want_J = 0 skips the Jacobian.
@@ -1366,20 +1378,6 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         fetch(rt, d_rt, 6 * F);
         reduce(rt.data(), 6 * F);
         for (int f = 0; f < F; ++f) for (int a = 0; a < 3; ++a) { pose[(size_t)f * NP + a] = rt[6 * f + a]; trans[3 * f + a] = rt[6 * f + 3 + a]; }
-#ifdef S1_EMU
-        if (getenv("S1_DEBUG")) {
-            std::vector<double> t_; std::vector<int> ti_(3 * M);
-            fetch(t_, p.can, 9); printf("can %g %g %g | %g %g %g\n", t_[0], t_[1], t_[2], t_[3], t_[4], t_[5]);
-            memcpy(ti_.data(), p.cl0, 3 * M * 4); printf("cl0 %d %d %d\n", ti_[0], ti_[1], ti_[2]);
-            fetch(t_, p.coef0, 6); printf("coef0 %g %g %g\n", t_[0], t_[1], t_[2]);
-            fetch(t_, p.vv, 9); printf("vv %g %g %g | %g %g %g\n", t_[0], t_[1], t_[2], t_[3], t_[4], t_[5]);
-            fetch(t_, d_sim, 6); printf("sim %g %g %g\n", t_[0], t_[1], t_[2]);
-            printf("rt %g %g %g %g %g %g\n", rt[0], rt[1], rt[2], rt[3], rt[4], rt[5]);
-            printf("ml %g %g %g\n", ml[0], ml[1], ml[2]);
-            printf("obs %g %g %g nobs %d %d ids %d %d\n", ds->obs[0], ds->obs[1], ds->obs[2], ds->n_obs[0], ds->n_obs[1], ds->obs_ids[0], ds->obs_ids[1]);
-            { double rv_[3], T_[3]; std::vector<double> sm_; fetch(sm_, d_sim, 3 * ds->n_obs[0]); for (int i_ = 0; i_ < 3 * ds->n_obs[0]; ++i_) if (!(sm_[i_] == sm_[i_])) printf("nan sim at %d\n", i_); rigid_fit(sm_.data(), ds->obs, ds->n_obs[0], rv_, T_); printf("host fit %g %g %g | %g %g %g\n", rv_[0], rv_[1], rv_[2], T_[0], T_[1], T_[2]); }
-        }
-#endif
     }
 
     // ---- annealing rounds
@@ -1532,6 +1530,16 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         unpack(x);
         if (round == ds->n_anneal - 1) {
             upload_point(); evaluate(0); fetch(r, p.r, R);
+            if (ds->markers_sim) {       // stagei_markers_sim_all (chmosh.py:441): every latent marker on every frame's body
+                double* d_simall = pool.get<double>((size_t)F * M * 3);
+                if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed");
+                hipMemsetAsync(d_simall, 0, (size_t)F * M * 3 * 8, st);
+                if (nown > 0) LAUNCH(k_s1_simall, nown, 1, S1_TPB, st, d, p, d_simall, f_lo);
+                std::vector<double> sa;
+                fetch(sa, d_simall, (size_t)F * M * 3);
+                reduce(sa.data(), (long long)F * M * 3);
+                memcpy(ds->markers_sim, sa.data(), sa.size() * 8);
+            }
             auto sse_rows = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
             if (ds->errs) {
                 ds->errs[0] = sse_rows(d.r_data, d.r_prior); ds->errs[1] = sse_rows(d.r_prior, d.r_init); ds->errs[2] = sse_rows(d.r_init, d.r_beta);

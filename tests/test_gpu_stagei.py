@@ -145,6 +145,10 @@ def test_mosh_stagei_then_stageii_end_to_end(tmp_path):
     dbg = stagei['stagei_debug_details']
     assert set(dbg['stagei_errs']) == {'data', 'poseB', 'init', 'beta', 'surf'} and len(dbg['stagei_fnames']) == 5
     assert os.path.exists(tmp_path / 'out' / 'stagei.pkl')
+    assert len(dbg['stagei_markers_sim_all']) == 5 and dbg['stagei_markers_sim_all'][0].shape == (M, 3)
+    assert all(a.shape == b.shape for a, b in zip(dbg['stagei_markers_sim'], dbg['stagei_markers_obs']))
+    fit = np.sqrt(np.mean([((a - b) ** 2).sum(1).mean() for a, b in zip(dbg['stagei_markers_sim'], dbg['stagei_markers_obs'])]))
+    assert fit < 5e-3 and set(dbg['markers_latent_all_vids']) <= set(labels)
     # oracle on the same picked frames
     frames = []
     for fr in dbg['stagei_frames']:
