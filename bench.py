@@ -323,24 +323,21 @@ def main():
         if not args.no_stagei:
             try:
                 from moshpp_amd import capi
-                from tests import helpers
-                c1 = helpers.stagei_case(n_verts=6890, nb=10, M=53, F=12, seed=1, dof_per_hand=24)
-                mdl = c1['model']
-                dev1 = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'],
-                                  mdl['parents'], mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
-                pr1 = capi.Prior(c1['prior']['means'], c1['prior']['chols'], c1['prior']['weights'])
-                kw1 = helpers.stagei_kwargs(c1)
+                pb1, dev1, pr1, kw1 = workload.make_stagei_job()
                 capi.stagei_solve_host(dev1, pr1, **kw1)
                 ts = []
                 for _ in range(3):
                     t1 = time.perf_counter(); o1 = capi.stagei_solve_host(dev1, pr1, **kw1); ts.append(time.perf_counter() - t1)
-                leg = {'workload': f"12 frames, 53 markers, 10 betas, V={mdl['v_template'].shape[0]}, {len(c1['faces'])} triangles",
+                leg = {'workload': f"12 frames, 53 markers, 10 betas, V={pb1['model']['v_template'].shape[0]}, {len(pb1['faces'])} triangles",
                        'unknowns': int(3 * 12 + 3 * 53 + 12 * len(kw1['pose_ids']) + 10), 'seconds': round(float(np.median(ts)), 4),
                        'dogleg_iterations': o1['iters']}
-                if not args.no_cpu:
-                    from oracle import stagei_oracle as s1o
+                if not args.no_cpu:     # the CPU side of this leg: the NumPy oracle on the same problem (checker + timing)
+                    from oracle import stageii_oracle as so1, stagei_oracle as s1o
+                    m1 = so1.prepare_model(pb1['model'])
+                    so1.set_free_shape(m1, 0, pb1['nb'])
                     t1 = time.perf_counter()
-                    r1 = s1o.stagei_solve(c1['m'], c1['faces'], c1['prior'], 'smplh', c1['frames'], c1['vids'], c1['mask'], c1['m2b'], c1['nb'])
+                    r1 = s1o.stagei_solve(m1, pb1['faces'], so1.prepare_gmm_prior(pb1['gmm'], 63), 'smplh', pb1['frames'], pb1['vids'],
+                                          {'body': np.ones(pb1['M'], bool)}, {'body': pb1['skin']}, pb1['nb'])
                     leg['cpu_oracle_seconds'] = round(time.perf_counter() - t1, 2)
                     leg['max_abs_betas_diff'] = float(np.abs(o1['betas'] - r1['betas']).max())
                     leg['max_abs_markers_latent_diff_m'] = float(np.abs(o1['markers_latent'] - r1['markers_latent']).max())

@@ -514,3 +514,84 @@ def make_sequence(model_type='smplh', n_frames=120, n_markers=53, seed=0, noise=
                 latent_labels=labels, marker_meta=marker_meta, markers=markers, labels=list(labels),
                 frame_rate=120.0, pose_gt=pose_gt, trans_gt=trans_gt, model_type=model_type,
                 dof_per_hand=dof_per_hand, use_hands_mean=use_hands_mean, num_betas=num_betas)
+
+
+# ------------------------------------------------------------------------------------------
+# Stage-I problems (generator only; carries its own NumPy pieces like the Stage-II generator above)
+# ------------------------------------------------------------------------------------------
+def vertex_normals(v, f):
+    """Area-weighted vertex normals of a triangle mesh."""
+    tn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    vn = np.zeros_like(v)
+    for c in range(3):
+        np.add.at(vn, f[:, c], tn)
+    n = np.linalg.norm(vn, axis=1, keepdims=True)
+    return vn / np.where(n == 0, 1.0, n)
+
+
+def make_stagei_problem(model_type='smplh', n_verts=2500, nb=6, M=30, F=6, seed=0, dof_per_hand=12, finger_markers=False):
+    """A seeded Stage-I problem on the triangulated synthetic body: model arrays with the pose-variable layout of the family,
+    raw GMM prior, marker layout vertex ids on exposed body vertices, a ground-truth subject (betas, latent markers a few
+    millimetres off their layout positions) and F observed frames `(latent ids, xyz[n,3])` with dropouts and noise."""
+    rng = np.random.default_rng(seed)
+    dd = synth_mesh_model(model_type, seed=seed, num_betas=10, n_verts=n_verts)
+    K = dd['weights'].shape[1]
+    parents = kintree_parents(model_type)
+    if model_type in ('smplh', 'smplx'):
+        hp = synth_hand_prior(seed)
+        body_dof = 3 * K - 90
+        comps = np.zeros((2 * dof_per_hand, 90))
+        comps[:dof_per_hand, :45] = hp['componentsl'][:dof_per_hand]
+        comps[dof_per_hand:, 45:] = hp['componentsr'][:dof_per_hand]
+        hand_dof, hands_mean = 2 * dof_per_hand, np.zeros(90)
+    elif model_type == 'mano':
+        body_dof, hand_dof, hands_mean, comps = 3, dof_per_hand, dd['hands_mean'], dd['hands_components'][:dof_per_hand]
+    else:
+        body_dof, hand_dof, hands_mean, comps = 3 * K, 0, None, None
+    NP = body_dof + hand_dof
+    model = dict(v_template=dd['v_template'], shapedirs=dd['shapedirs'], posedirs=dd['posedirs'], weights=dd['weights'],
+                 J_regressor=dd['J_regressor'], parents=parents, body_dof=body_dof, hand_dof=hand_dof,
+                 hands_mean=hands_mean, selected_components=comps)
+
+    def fullpose_of(pose):
+        if hand_dof == 0:
+            return pose[:body_dof].copy()
+        return np.concatenate([pose[:body_dof], hands_mean + pose[body_dof:].dot(comps)])
+
+    dom = np.argmax(dd['weights'], 1)
+    ok = dd['_exposed'] & ((dom <= 21) | finger_markers) if model_type != 'mano' else np.ones(len(dom), bool)
+    cand = np.flatnonzero(ok)
+    v = dd['v_template']
+    vids = [cand[rng.integers(len(cand))]]
+    dmin = ((v[cand] - v[vids[0]]) ** 2).sum(1)
+    for _ in range(M - 1):
+        nxt = cand[int(np.argmax(dmin))]
+        vids.append(nxt)
+        dmin = np.minimum(dmin, ((v[cand] - v[nxt]) ** 2).sum(1))
+    vids = np.array(vids)
+    betas_gt = rng.normal(0, 0.8, nb)
+    v_shaped = dd['v_template'] + dd['shapedirs'][:, :, :nb].dot(betas_gt)
+    J = dd['J_regressor'].dot(v_shaped)
+    can_gt = lbs_numpy(v_shaped, J, dd['posedirs'], dd['weights'], parents, fullpose_of(np.zeros(NP)), np.zeros(3))
+    skin = 0.0095 if model_type != 'mano' else 0.003
+    ml_gt = can_gt[vids] + vertex_normals(can_gt, dd['f'])[vids] * skin \
+        + rng.normal(0, 0.004 if model_type != 'mano' else 0.001, (M, 3))
+    cl, coef = attach_markers(can_gt, ml_gt)
+    pose_gt, trans_gt = synth_motion(NP, body_dof, 400, seed=seed)
+    frames = []
+    for t in np.linspace(60, 399, F).astype(int):
+        p = pose_gt[t].copy()
+        if not finger_markers and model_type != 'mano':
+            p[body_dof:] = 0
+        if model_type != 'mano':
+            p[30:36] = 0
+        if model_type == 'smplx':
+            p[66:75] = 0
+        vv = lbs_numpy(v_shaped, J, dd['posedirs'], dd['weights'], parents, fullpose_of(p), trans_gt[t],
+                       vids=cl.reshape(-1)).reshape(M, 3, 3)
+        sim = markers_numpy(coef, vv[:, 0], vv[:, 1], vv[:, 2]) + rng.normal(0, 0.0003, (M, 3))
+        ids = np.flatnonzero(rng.random(M) > 0.05)
+        frames.append((ids, sim[ids]))
+    return dict(model=model, faces=dd['f'], gmm=synth_gmm_prior(seed), frames=frames, vids=vids, betas_gt=betas_gt, ml_gt=ml_gt,
+                nb=nb, M=M, skin=skin, model_type=model_type, dd=dd, NP=NP,
+                attach_gt=(cl, coef), v_shaped_gt=v_shaped, J_gt=J, fullpose_of=fullpose_of)

@@ -113,3 +113,29 @@ def solve_many_chunked(seqs, stream, num_chunks=0, warmup=32, verify_tol=1e-11):
     capi.check(capi.load().moshii_sequence_solve(mh, ph, C.byref(opts), len(seqs), descs, C.byref(co), capi.BUFFERS_DEVICE,
                                                  C.c_void_p(stream), C.byref(rep)))
     return {k: getattr(rep, k) for k, _ in capi.ChunkReport._fields_}
+
+
+# ---- Stage-I -------------------------------------------------------------------------------------------------------
+def make_stagei_job(model_type='smplh', n_verts=6890, nb=10, n_markers=53, n_frames=12, seed=1, dof_per_hand=24,
+                    optimize_fingers=False):
+    """Device handles + `capi.stagei_solve_host` keyword arguments of a seeded Stage-I problem (BASELINE config 4's calibration
+    part: 12 picked frames, 53 markers, 10 betas on the triangulated SMPL-H-sized body).  Returns (problem, model, prior, kwargs)."""
+    from . import capi
+    from .cfg import STAGEII_WEIGHTS
+    from .chmosh import stagei_pose_ids
+    pb = synth.make_stagei_problem(model_type, n_verts=n_verts, nb=nb, M=n_markers, F=n_frames, seed=seed,
+                                   dof_per_hand=dof_per_hand, finger_markers=optimize_fingers)
+    mdl = pb['model']
+    dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'], mdl['parents'],
+                     mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
+    prior = None
+    if model_type != 'mano':
+        g = create_gmm_body_prior(pb['gmm'], exclude_hands=model_type in ('smplh', 'smplx'))
+        prior = capi.Prior(g['means'], g['chols'], g['weights'])
+    W = STAGEII_WEIGHTS['smplh']
+    pose_ids, body_ids, finger_ids = stagei_pose_ids(model_type, pb['NP'], optimize_fingers, False)
+    M = pb['M']
+    kw = dict(faces=pb['faces'], marker_vids=pb['vids'], m2b=np.ones(M) * pb['skin'], wt_init=np.ones(M) * W['stagei_wt_init'],
+              frames=pb['frames'], nb=pb['nb'], weights=W, pose_ids=pose_ids, body_ids=body_ids if prior is not None else [],
+              finger_ids=finger_ids)
+    return pb, dev, prior, kw

@@ -114,65 +114,16 @@ def shape_case(model_type='smplx', F=6, M=40, E=6, seed=0, kind='expr', boost=6.
 
 # ---- Stage-I ----------------------------------------------------------------------------------------------------
 def stagei_case(model_type='smplh', n_verts=2500, nb=6, M=30, F=6, seed=0, dof_per_hand=12, finger_markers=False):
-    """A seeded Stage-I problem on the triangulated synthetic body (synth.synth_mesh_model): ground-truth betas, latent markers
-    displaced a few millimetres from their layout positions, F observed frames with dropouts."""
-    from oracle import stagei_oracle as s1
-    rng = np.random.default_rng(seed)
-    dd = synth.synth_mesh_model(model_type, seed=seed, num_betas=10, n_verts=n_verts)
-    K = dd['weights'].shape[1]
-    parents = synth.kintree_parents(model_type)
-    if model_type in ('smplh', 'smplx'):
-        hp = synth.synth_hand_prior(seed)
-        body_dof = 3 * K - 90
-        comps = np.zeros((2 * dof_per_hand, 90))
-        comps[:dof_per_hand, :45] = hp['componentsl'][:dof_per_hand]
-        comps[dof_per_hand:, 45:] = hp['componentsr'][:dof_per_hand]
-        hand_dof, hands_mean = 2 * dof_per_hand, np.zeros(90)
-    elif model_type == 'mano':
-        body_dof, hand_dof, hands_mean, comps = 3, dof_per_hand, dd['hands_mean'], dd['hands_components'][:dof_per_hand]
-    else:
-        body_dof, hand_dof, hands_mean, comps = 3 * K, 0, None, None
-    model = dict(v_template=dd['v_template'], shapedirs=dd['shapedirs'], posedirs=dd['posedirs'], weights=dd['weights'],
-                 J_regressor=dd['J_regressor'], parents=parents, body_dof=body_dof, hand_dof=hand_dof,
-                 hands_mean=hands_mean, selected_components=comps)
-    m = so.prepare_model(model)
+    """synth.make_stagei_problem prepared for the oracle: `m` (prepare_model + free shape block) and the prepared GMM prior."""
+    pb = synth.make_stagei_problem(model_type, n_verts=n_verts, nb=nb, M=M, F=F, seed=seed, dof_per_hand=dof_per_hand,
+                                   finger_markers=finger_markers)
+    m = so.prepare_model(pb['model'])
     so.set_free_shape(m, 0, nb)
     npose = 63 if model_type in ('smplh', 'smplx') else 69
-    prior = so.prepare_gmm_prior(synth.synth_gmm_prior(seed), npose) if model_type != 'mano' else None
-    dom = np.argmax(dd['weights'], 1)
-    ok = dd['_exposed'] & ((dom <= 21) | finger_markers) if model_type != 'mano' else np.ones(len(dom), bool)
-    cand = np.flatnonzero(ok)
-    v = dd['v_template']
-    vids = [cand[rng.integers(len(cand))]]
-    dmin = ((v[cand] - v[vids[0]]) ** 2).sum(1)
-    for _ in range(M - 1):
-        nxt = cand[int(np.argmax(dmin))]
-        vids.append(nxt)
-        dmin = np.minimum(dmin, ((v[cand] - v[nxt]) ** 2).sum(1))
-    vids = np.array(vids)
-    betas_gt = rng.normal(0, 0.8, nb)
-    shp = betas_gt if nb else None
-    fp_can = so.fullpose_from_pose(m, np.zeros(m['NP']))
-    can_gt = so.verts_forward(m, fp_can, np.zeros(3), None, shp=shp)
-    m2b = np.ones(M) * (0.0095 if model_type != 'mano' else 0.003)
-    ml_gt = s1.markers_latent_init(can_gt, dd['f'], vids, m2b) + rng.normal(0, 0.004 if model_type != 'mano' else 0.001, (M, 3))
-    cl, coef = so.transformed_coeffs(can_gt, ml_gt)
-    pose_gt, trans_gt = synth.synth_motion(m['NP'], body_dof, 400, seed=seed)
-    frames = []
-    for t in np.linspace(60, 399, F).astype(int):
-        p = pose_gt[t].copy()
-        if not finger_markers and model_type != 'mano':
-            p[body_dof:] = 0
-        if model_type != 'mano':
-            p[30:36] = 0
-        if model_type == 'smplx':
-            p[66:75] = 0
-        vv = so.verts_forward(m, so.fullpose_from_pose(m, p), trans_gt[t], cl.reshape(-1), shp=shp).reshape(M, 3, 3)
-        sim = so.markers_from_verts(coef, vv[:, 0], vv[:, 1], vv[:, 2]) + rng.normal(0, 0.0003, (M, 3))
-        ids = np.flatnonzero(rng.random(M) > 0.05)
-        frames.append((ids, sim[ids]))
-    return dict(m=m, model=model, faces=dd['f'], prior=prior, frames=frames, vids=vids, betas_gt=betas_gt, ml_gt=ml_gt, nb=nb, M=M,
-                mask={'body': np.ones(M, bool)}, m2b={'body': float(m2b[0])}, model_type=model_type, dd=dd)
+    prior = so.prepare_gmm_prior(pb['gmm'], npose) if model_type != 'mano' else None
+    return dict(m=m, model=pb['model'], faces=pb['faces'], prior=prior, frames=pb['frames'], vids=pb['vids'], betas_gt=pb['betas_gt'],
+                ml_gt=pb['ml_gt'], nb=nb, M=M, mask={'body': np.ones(M, bool)}, m2b={'body': pb['skin']}, model_type=model_type,
+                dd=pb['dd'], problem=pb)
 
 
 def stagei_kwargs(case, optimize_fingers=False, exclude_vids=None, head_corr=None, betas_init=None):

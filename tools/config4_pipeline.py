@@ -12,30 +12,25 @@ from moshpp_amd import capi, synth                     # noqa: E402
 from moshpp_amd.cfg import STAGEII_WEIGHTS              # noqa: E402
 from moshpp_amd.chmosh import StageIISolver             # noqa: E402
 from moshpp_amd.models import SurfaceModel              # noqa: E402
-from tests import helpers                               # noqa: E402
-from oracle import stageii_oracle as so                 # noqa: E402  (generator of the synthetic capture only)
+from moshpp_amd import workload                         # noqa: E402
 
 
 def main(F2=50000):
-    c = helpers.stagei_case(n_verts=6890, nb=10, M=53, F=12, seed=1, dof_per_hand=24)
-    mdl, m, M, nb = c['model'], c['m'], c['M'], c['nb']
-    dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'], mdl['parents'],
-                     mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
-    pr = capi.Prior(c['prior']['means'], c['prior']['chols'], c['prior']['weights'])
-    kw = helpers.stagei_kwargs(c)
+    pb, dev, pr, kw = workload.make_stagei_job()
+    mdl, M, nb = pb['model'], pb['M'], pb['nb']
     capi.stagei_solve_host(dev, pr, **kw)
     t = time.perf_counter(); s1 = capi.stagei_solve_host(dev, pr, **kw); t_s1 = time.perf_counter() - t
-    # the long capture: ground-truth subject (betas_gt, ml_gt) in smooth motion
-    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3), None, shp=c['betas_gt'])
-    cl, coef = so.transformed_coeffs(can, c['ml_gt'])
-    pose_gt, trans_gt = synth.synth_motion(m['NP'], m['body_dof'], F2, seed=3)
-    pose_gt[:, m['body_dof']:] = 0; pose_gt[:, 30:36] = 0
+    # the long capture: the ground-truth subject (betas_gt, ml_gt) in smooth motion
+    cl, coef = pb['attach_gt']
+    pose_gt, trans_gt = synth.synth_motion(pb['NP'], mdl['body_dof'], F2, seed=3)
+    pose_gt[:, mdl['body_dof']:] = 0; pose_gt[:, 30:36] = 0
     rng = np.random.default_rng(4)
     obs = np.zeros((F2, M, 3))
     t = time.perf_counter()
     for f in range(F2):
-        vv = so.verts_forward(m, so.fullpose_from_pose(m, pose_gt[f]), trans_gt[f], cl.reshape(-1), shp=c['betas_gt']).reshape(M, 3, 3)
-        obs[f] = so.markers_from_verts(coef, vv[:, 0], vv[:, 1], vv[:, 2])
+        vv = synth.lbs_numpy(pb['v_shaped_gt'], pb['J_gt'], mdl['posedirs'], mdl['weights'], mdl['parents'], pb['fullpose_of'](pose_gt[f]),
+                             trans_gt[f], vids=cl.reshape(-1)).reshape(M, 3, 3)
+        obs[f] = synth.markers_numpy(coef, vv[:, 0], vv[:, 1], vv[:, 2])
     obs += rng.normal(0, 0.0003, obs.shape)
     vis = rng.random((F2, M)) > 0.02
     t_gen = time.perf_counter() - t
@@ -44,7 +39,8 @@ def main(F2=50000):
                       body_dof=mdl['body_dof'], hand_dof=mdl['hand_dof'], hands_mean=mdl['hands_mean'],
                       selected_components=mdl['selected_components'])
     betas = np.zeros(mdl['shapedirs'].shape[2]); betas[:nb] = s1['betas']
-    prior = dict(means=c['prior']['means'], chols=c['prior']['chols'], weights=c['prior']['weights'], npose=c['prior']['npose'])
+    from moshpp_amd.prior import create_gmm_body_prior
+    prior = create_gmm_body_prior(pb['gmm'], exclude_hands=True)
     solver = StageIISolver(sm, betas, s1['markers_latent'], prior, dict(STAGEII_WEIGHTS['smplh']), surface_model_type='smplh',
                            num_betas=nb)
     solver.solve(obs[:2000], vis[:2000], chain_mode='chunked', verify_tol=1e-9)

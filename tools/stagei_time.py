@@ -8,16 +8,11 @@ import numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from moshpp_amd import capi        # noqa: E402
-from tests import helpers          # noqa: E402
+from moshpp_amd import workload    # noqa: E402
 
 
 def main(reps=3, fingers=False):
-    c = helpers.stagei_case(n_verts=6890, nb=10, M=53, F=12, seed=1, dof_per_hand=24, finger_markers=fingers)
-    mdl = c['model']
-    dev = capi.Model(mdl['v_template'], mdl['shapedirs'], mdl['posedirs'], mdl['weights'], mdl['J_regressor'], mdl['parents'],
-                     mdl['body_dof'], mdl['hand_dof'], mdl['hands_mean'], mdl['selected_components'])
-    pr = capi.Prior(c['prior']['means'], c['prior']['chols'], c['prior']['weights'])
-    kw = helpers.stagei_kwargs(c, optimize_fingers=fingers)
+    pb, dev, pr, kw = workload.make_stagei_job(optimize_fingers=fingers)
     for i in range(reps):
         t = time.perf_counter()
         out = capi.stagei_solve_host(dev, pr, **kw)
