@@ -117,3 +117,77 @@ def test_kernel_arithmetic_variants_in_emulation(name):
     assert np.abs(out['pose'] - ref['pose']).max() < 1e-8 and np.abs(out['trans'] - ref['trans']).max() < 1e-9
     if c['nb']:
         assert np.abs(out['betas'] - ref['betas']).max() < 1e-8
+
+
+def test_mosh_stagei_host_path_on_cpu(tmp_path, monkeypatch):
+    """The drop-in `mosh_stagei` (files in, dict out) with libmoshii's entry points replaced by the emulation build + oracle LBS:
+    exercises the host code (layout, cfg switches, frame packing, weights, output dict) without a GPU."""
+    import json
+    import pickle
+    from moshpp_amd import capi, chmosh, synth
+    from moshpp_amd.cfg import make_cfg
+    from tests.emu import emu_stagei
+
+    class FakeModel:
+        def __init__(self, v_template, shapedirs, posedirs, weights, J_regressor, parents, body_dof, hand_dof, hands_mean, comps):
+            self.model = dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, weights=weights, J_regressor=J_regressor,
+                              parents=parents, body_dof=body_dof, hand_dof=hand_dof, hands_mean=hands_mean, selected_components=comps)
+            self.m = so.prepare_model(self.model)
+            self.NP = self.m['NP']
+
+        def set_betas(self, betas):
+            self.m = so.prepare_model(self.model, betas)
+
+        def lbs_forward(self, pose, trans):
+            return np.array([so.verts_forward(self.m, so.fullpose_from_pose(self.m, p), t) for p, t in zip(pose, trans)])
+
+    class FakePrior:
+        def __init__(self, means, chols, weights):
+            self.p = dict(means=means, chols=chols, weights=weights, npose=means.shape[1])
+
+    def fake_solve(dev, prior, **kw):
+        so.set_free_shape(dev.m, 0, kw['nb'])
+        out = dict(emu_stagei.solve(dev.m, prior.p if prior is not None else None, **kw))
+        out['errs'] = dict(zip(capi.STAGEI_ERR_NAMES, out['errs'].tolist()))
+        out['iters'] = int(out['iters'][0])
+        return out
+    monkeypatch.setattr(capi, 'Model', FakeModel)
+    monkeypatch.setattr(capi, 'Prior', FakePrior)
+    monkeypatch.setattr(capi, 'stagei_solve_host', fake_solve)
+    pb = synth.make_stagei_problem('smplh', n_verts=1500, nb=4, M=20, F=3, seed=21)
+    raw = {k: v for k, v in pb['dd'].items() if not k.startswith('_')}
+    with open(tmp_path / 'model.pkl', 'wb') as f:
+        pickle.dump(raw, f)
+    with open(tmp_path / 'prior.pkl', 'wb') as f:
+        pickle.dump(pb['gmm'], f)
+    np.savez(tmp_path / 'hands.npz', **synth.synth_hand_prior(21))
+    labels = [f'MK{i:02d}' for i in range(20)]
+    with open(tmp_path / 'layout.json', 'w') as f:
+        json.dump({'surface_model_type': 'smplh', 'markersets': [
+            {'type': 'body', 'indices': {l: int(v) for l, v in zip(labels, pb['vids'])}}]}, f)
+    frames = [{labels[i]: xyz for i, xyz in zip(ids, obs)} for ids, obs in pb['frames']]
+    frames[0]['UNKNOWN'] = np.zeros(3)                     # a label the layout does not know: ignored (chmosh.py:199-206)
+    frames[1][labels[0]] = np.full(3, np.nan)              # NaN observation: dropped from that frame
+    cfg = make_cfg(**{'surface_model.type': 'smplh', 'surface_model.fname': str(tmp_path / 'model.pkl'), 'surface_model.num_betas': 4,
+                      'surface_model.dof_per_hand': 12, 'surface_model.use_hands_mean': False,
+                      'moshpp.pose_body_prior_fname': str(tmp_path / 'prior.pkl'), 'moshpp.pose_hand_prior_fname': str(tmp_path / 'hands.npz'),
+                      'moshpp.optimize_fingers': True,    # the layout has no finger markers -> switched off (:128-139)
+                      'dirs.marker_layout.fname': str(tmp_path / 'layout.json')})
+    res = chmosh.mosh_stagei(frames, cfg)
+    assert cfg.moshpp.optimize_fingers is False
+    assert set(res) == {'betas', 'markers_latent', 'latent_labels', 'marker_meta', 'markers_latent_vids', 'stagei_debug_details'}
+    assert res['latent_labels'] == labels and res['betas'].shape == (10,) and np.all(res['betas'][4:] == 0)
+    dbg = res['stagei_debug_details']
+    assert set(dbg['stagei_errs']) == {'data', 'poseB', 'init', 'beta', 'surf'}
+    assert [len(l) for l in dbg['stagei_labels_obs']] == [len(pb['frames'][0][0]), len(pb['frames'][1][0]) - (0 in pb['frames'][1][0]),
+                                                          len(pb['frames'][2][0])]
+    assert labels[0] not in dbg['stagei_labels_obs'][1]
+    fit = np.sqrt(np.mean([((a - b) ** 2).sum(1).mean() for a, b in zip(dbg['stagei_markers_sim'], dbg['stagei_markers_obs'])]))
+    assert fit < 5e-3
+    assert set(res['markers_latent_vids']) == set(labels) and set(dbg['markers_latent_all_vids']) <= set(labels)
+    pickle.dumps(res)
+    # optimize_betas = false with given betas: they are kept, no beta term
+    np.savez(tmp_path / 'betas.npz', betas=np.array([0.5, -0.3, 0.2, 0.1]))
+    cfg.moshpp.optimize_betas = False
+    res2 = chmosh.mosh_stagei(frames, cfg, betas_fname=str(tmp_path / 'betas.npz'))
+    assert np.allclose(res2['betas'][:4], [0.5, -0.3, 0.2, 0.1]) and 'beta' not in res2['stagei_debug_details']['stagei_errs']
