@@ -14,6 +14,14 @@ positions on the canonical body and one pose + translation per frame (chmosh.py:
   scan2mesh/mesh_distance/sample2meshdist.h:67-205  closed-form distance derivatives per nearest part (plane / line / point)
   scan2mesh/ch_vert_normals.py:36-135, robustifiers.py:45-57  vertex / triangle normals, SignedSqrt
 
+PINNED to reference code executed / compiled here (tests/test_ref_golden.py):
+  * the closed-form distance gradients per nearest part  <- the reference's own C++ header sample2meshdist.h, compiled in place
+    into oracle/_ref/libs2m_ref.so (oracle/ref_build/, with a stand-in for the few Eigen types it uses)
+  * the normal chosen per part code, the sign rule, the signed square root  <- MeshDistanceSquared.direction and SignedSqrt method
+    sources executed on our nearest-triangle data
+  * (host package) marker_layout_load, the three frame pickers  <- the reference's functions
+UNPINNED: the nearest-triangle search itself (psbody's AABB tree), chumpy's graph evaluation order / dogleg, psbody's SMPL.
+
 Third-party pieces restated from their published behaviour: psbody.mesh `aabbtree_nearest` (closest point on a triangle mesh with
 the part code 0 interior, 1-3 edges ab/bc/ca, 4-6 vertices a/b/c -- here an exhaustive search with Ericson's region tests) and
 `Mesh.estimate_vertex_normals` (area-weighted sum of the incident triangle normals, normalised).

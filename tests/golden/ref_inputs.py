@@ -189,3 +189,17 @@ def layout_inputs(outdir):
             'no_fingers': (fn, dict(exclude_marker_types=['finger_left'])),
             'only': (fn, dict(only_markers=['C7', 'LFHD', 'ARIEL', 'LIDX3'])),
             'excluded_label': (fn, dict(exclude_markers=['T10']))}
+
+
+def surface_inputs():
+    """A small closed mesh (two capsules of the synthetic body generator) and sample points on both sides of it, chosen so that
+    interior / edge / vertex nearest parts all occur; plus signed squared distances incl. an exact zero."""
+    from moshpp_amd import synth
+    v1, f1 = synth._capsule_mesh(np.array([0.0, 0.0, 0.0]), np.array([0.0, 0.3, 0.0]), 0.08, 120)
+    v2, f2 = synth._capsule_mesh(np.array([0.3, 0.0, 0.0]), np.array([0.5, 0.2, 0.1]), 0.05, 80)
+    v = np.vstack([v1, v2]); f = np.vstack([f1, f2 + len(v1)])
+    rng = np.random.default_rng(5)
+    v = v + rng.normal(0, 0.001, v.shape)
+    base = v[rng.integers(0, len(v), 60)]
+    pts = base + rng.normal(0, 0.02, base.shape)
+    return dict(v=v, f=f, pts=pts, signed_sq=np.concatenate([rng.normal(0, 1e-3, 20), [0.0]]))

@@ -176,3 +176,64 @@ def test_marker_layout_load_matches_reference_function(case):
     assert np.array_equal(np.array([mm['marker_type_mask'][k] for k in mm['marker_type_mask']]), G[f'layout_{case}_masks'])
     assert np.allclose([mm['m2b_distance'][k] for k in mm['marker_type_mask']], G[f'layout_{case}_m2b'])
     assert mm['surface_model_type'] == str(G[f'layout_{case}_model'])
+
+
+def test_surface_sign_matches_reference_direction_method():
+    """oracle signed_surface_distance: the normal chosen per nearest part (face / vertex / the two vertices of an edge), the sign rule
+    and the signed square root against the reference's MeshDistanceSquared.direction (mesh_distance_main.py:266-297) and SignedSqrt
+    (robustifiers.py:45-57), whose method sources were executed on the same nearest-triangle data."""
+    from oracle import stagei_oracle as s1
+    si = ref_inputs.surface_inputs()
+    dist, tri, part = s1.signed_surface_distance(si['pts'], si['v'], si['f'])
+    assert np.array_equal(tri, G['surf_tri']) and np.array_equal(part, G['surf_part'])
+    assert len(np.unique(part)) >= 3 and (G['surf_direction'] < 0).any() and (G['surf_direction'] > 0).any()
+    assert np.array_equal(np.sign(dist), G['surf_direction'])
+    # SignedSqrt(d^2 . direction) == our dist; its derivative 0.5 / sqrt|x| (0 at x = 0) is what cancels against d(d^2) = 2 d dd
+    x = si['signed_sq']
+    assert np.allclose(G['signedsqrt_r'], np.sqrt(np.abs(x)) * np.sign(x), rtol=0, atol=0)
+    with np.errstate(divide='ignore'):
+        want = np.where(x != 0, 0.5 / np.sqrt(np.abs(x)), 0.0)
+    assert np.allclose(G['signedsqrt_dr'], want, rtol=1e-15)
+    _, _, near = s1.nearest_on_mesh(si['pts'], si['v'], si['f'])
+    d2 = ((si['pts'] - near) ** 2).sum(1)
+    assert np.allclose(np.sqrt(d2) * G['surf_direction'], dist, rtol=0, atol=1e-15)
+
+
+def _s2m_ref():
+    """oracle/_ref/libs2m_ref.so: the reference's own sample2meshdist.h compiled in place (oracle/ref_build/Makefile)."""
+    import ctypes as C
+    import subprocess
+    so_path = os.path.join(os.path.dirname(GOLD), '..', 'oracle', '_ref', 'libs2m_ref.so')
+    so_path = os.path.abspath(so_path)
+    if not os.path.exists(so_path):
+        if not os.path.exists('/root/reference/src/moshpp/scan2mesh/mesh_distance/sample2meshdist.h'):
+            pytest.skip('reference sources not present and oracle/_ref not prebuilt')
+        subprocess.check_call(['make', '-C', os.path.join(os.path.dirname(so_path), '..', 'ref_build')])
+    lib = C.CDLL(so_path)
+    lib.s2m_ref_squared.restype = C.c_double
+    lib.s2m_ref_squared.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 8
+    return lib
+
+
+def test_surface_distance_derivatives_match_compiled_reference_header():
+    """The oracle's closed-form gradients of the point-to-surface distance against the REFERENCE'S OWN C++ (sample2meshdist.h:67-205:
+    pointPlane / pointLine / pointPoint with Square), compiled from /root/reference in place: squared distance and its gradients wrt the
+    point and the triangle's vertices for every nearest-part code."""
+    import ctypes as C
+    from oracle import stagei_oracle as s1
+    lib = _s2m_ref()
+    si = ref_inputs.surface_inputs()
+    v, f, pts = si['v'], si['f'], si['pts']
+    dist, tri, part, dp, dabc, fv = s1.signed_surface_distance(pts, v, f, want_jac=True)
+    P = C.POINTER(C.c_double)
+    seen = set()
+    for i in range(len(pts)):
+        x = np.ascontiguousarray(pts[i]); a, b, c = [np.ascontiguousarray(v[k]) for k in fv[i]]
+        g = [np.zeros(3) for _ in range(4)]
+        d2 = lib.s2m_ref_squared(int(part[i]), *[z.ctypes.data_as(P) for z in (x, a, b, c)], *[z.ctypes.data_as(P) for z in g])
+        seen.add(int(part[i]))
+        assert abs(d2 - dist[i] ** 2) < 1e-15
+        # ours: d(signed dist) = direction . d|dist|  ->  d(dist^2) = 2 dist . d(signed dist)
+        assert np.abs(g[0] - 2 * dist[i] * dp[i]).max() < 1e-12
+        assert np.abs(np.array(g[1:]) - 2 * dist[i] * dabc[i]).max() < 1e-12
+    assert {0} < seen and len(seen) >= 3
