@@ -246,7 +246,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
  * :417-447.  The marker attachment (TransformedCoeffs, transformed_lm.py:59-113) is re-evaluated at every evaluation
  * point, as the reference's dependency graph does.  All buffers are HOST pointers (the problem is a few kilobytes);
  * the model's own betas (moshii_model_set_betas) are ignored: the solve works on v_template + shapedirs[:, :, :nb].betas.
- * Not covered: per-frame expressions in Stage-I (optimize_face), opt_settings.extra_initial_rigid_adjustment.
+ * Not covered: opt_settings.extra_initial_rigid_adjustment.
  * ------------------------------------------------------------------------------------------- */
 typedef struct moshii_stagei_desc {
     int32_t n_frames, M, n_faces, nb;       /* picked frames, latent markers, triangles, free betas             */
@@ -269,6 +269,13 @@ typedef struct moshii_stagei_desc {
     int32_t        n_body;
     const int32_t* finger_ids;              /* added (with poseH) in the last two rounds (:390-393); may be empty */
     int32_t        n_finger;
+    /* optimize_face (chmosh.py:295-305, 394-398): per-frame expression coefficients betas[expr_start : expr_start + n_expr] and the
+     * jaw pose ids become free in the last two rounds, with the terms expr (wt_expr) and poseF (wt_poseF).  Needs nb == 0: the
+     * reference cannot share betas and free expressions either (:295-299) -- fold the fixed betas into the model's template.  */
+    int32_t        n_expr, expr_start;
+    const int32_t* face_ids;                /* pose_face_ids (66:69 for SMPL-X) or NULL                          */
+    int32_t        n_face;
+    double         wt_expr, wt_poseF;       /* stagei_wt_expr, stagei_wt_poseF                                   */
     const int32_t* head_ids;                /* [n_head] latent ids of the head markers, or NULL: no correlation term */
     const double*  head_corr;               /* [n_head_rows][n_head] `corr` of head_marker_corr_fname (:252-266, 362-369) */
     int32_t        n_head, n_head_rows;
@@ -291,7 +298,8 @@ typedef struct moshii_stagei_desc {
     double*  pose;                          /* [n_frames][NP]                                                    */
     double*  trans;                         /* [n_frames][3]                                                     */
     double*  markers_sim;                   /* [n_frames][M][3] or NULL: every latent marker simulated on every frame's body */
-    double*  errs;                          /* [7] SSE of data, poseB, init, beta, surf, poseH, init_head_corr   */
+    double*  expression;                    /* [n_frames][n_expr] or NULL                                        */
+    double*  errs;                          /* [8] SSE of data, poseB, init, beta (expr when n_expr > 0), surf, poseH, init_head_corr, poseF */
     int32_t* iters;                         /* [1] dogleg outer iterations over all rounds                       */
 } moshii_stagei_desc;
 

@@ -404,21 +404,24 @@ class StageIDesc(C.Structure):
                 ('wt_surf', C.c_double), ('annealing', C.c_void_p), ('n_anneal', C.c_int32),
                 ('pose_ids', C.c_void_p), ('n_pose_ids', C.c_int32), ('body_ids', C.c_void_p), ('n_body', C.c_int32),
                 ('finger_ids', C.c_void_p), ('n_finger', C.c_int32),
+                ('n_expr', C.c_int32), ('expr_start', C.c_int32), ('face_ids', C.c_void_p), ('n_face', C.c_int32),
+                ('wt_expr', C.c_double), ('wt_poseF', C.c_double),
                 ('head_ids', C.c_void_p), ('head_corr', C.c_void_p), ('n_head', C.c_int32), ('n_head_rows', C.c_int32),
                 ('wt_init_head', C.c_double), ('maxiter', C.c_int32), ('stagei_lr', C.c_double),
                 ('sharded', C.c_int32), ('frame_lo', C.c_int32), ('frame_hi', C.c_int32), ('owns_shared_rows', C.c_int32),
                 ('allreduce_sum', C.c_void_p), ('allreduce_user', C.c_void_p),
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
-                ('pose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('errs', C.c_void_p), ('iters', C.c_void_p)]
+                ('pose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('expression', C.c_void_p),
+                ('errs', C.c_void_p), ('iters', C.c_void_p)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
-STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH', 'init_head_corr')
+STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH', 'init_head_corr', 'poseF')   # 'beta' holds expr with n_expr > 0
 
 
 def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_ids, body_ids, finger_ids=(), exclude_vids=None,
                 betas_init=None, maxiter=100, stagei_lr=1e-3, head_corr=None, wt_init_head=None, frame_range=None,
-                owns_shared_rows=True, allreduce=None):
+                owns_shared_rows=True, allreduce=None, n_expr=0, expr_start=0, face_ids=()):
     """Fill a StageIDesc from NumPy data.  `frames`: list of (latent ids, obs[n,3]).  Returns (desc, outputs dict, keep-alive list)."""
     keep = []
 
@@ -444,6 +447,9 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
     d.body_ids = ptr(body_ids, np.int32); d.n_body = len(body_ids)
     d.finger_ids = ptr(list(finger_ids), np.int32); d.n_finger = len(finger_ids)
     d.maxiter, d.stagei_lr = int(maxiter), float(stagei_lr)
+    d.n_expr, d.expr_start = int(n_expr), int(expr_start)
+    d.face_ids = ptr(list(face_ids), np.int32); d.n_face = len(face_ids)
+    d.wt_expr, d.wt_poseF = float(weights.get('stagei_wt_expr', 0.0)), float(weights.get('stagei_wt_poseF', 0.0))
     if head_corr is not None:
         hid, Cm = head_corr
         Cm = np.atleast_2d(np.asarray(Cm, np.float64))
@@ -467,11 +473,12 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
         d.owns_shared_rows = 1 if owns_shared_rows else 0
         d.allreduce_sum = C.cast(cb, C.c_void_p)
     out = dict(betas=np.zeros(max(nb, 1)), markers_latent=np.zeros((M, 3)), markers_latent_vids=np.zeros(M, np.int32),
-               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), markers_sim=np.zeros((F, M, 3)), errs=np.zeros(7),
+               pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), markers_sim=np.zeros((F, M, 3)), expression=np.zeros((F, max(int(n_expr), 1))), errs=np.zeros(8),
                iters=np.zeros(1, np.int32))
     for k, v in out.items():
         setattr(d, k, v.ctypes.data)
     out['betas'] = out['betas'][:nb]
+    out['expression'] = out['expression'][:, :int(n_expr)]
     keep.append(out)
     return d, out, keep
 

@@ -343,10 +343,10 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
         elif not np.any([(body_part in ltype) and l in avail_labels for l, ltype in marker_meta['marker_type'].items()]):
             cfg.moshpp[cfg_key] = False
             logger.warning(f'{cfg_key} was activated but no {body_part} marker type detected in the mocaps: {cfg_key} = False.')
-    if cfg.moshpp.optimize_face:
-        raise NotImplementedError('Stage-I with per-frame facial expressions (moshpp.optimize_face) is not implemented on the GPU path; '
-                                  'run Stage-I with optimize_face=false (the reference cannot combine it with optimize_betas either, '
-                                  'chmosh.py:295-299)')
+    if cfg.moshpp.optimize_face and cfg.moshpp.optimize_betas and cfg.surface_model.type == 'smplx':
+        raise NotImplementedError(                                                                     # :295-299
+            'MoSh requires in the shape stage a single (shared) beta across frames and different per-frame facial expressions. '
+            'So if you want to optimize the face you need to provide the shape, or provide a v_template.')
     sm = load_surface_model(surface_model_fname=cfg.surface_model.fname, surface_model_type=cfg.surface_model.type,
                             pose_hand_prior_fname=cfg.moshpp.pose_hand_prior_fname, use_hands_mean=cfg.surface_model.use_hands_mean,
                             dof_per_hand=cfg.surface_model.dof_per_hand, v_template_fname=v_template_fname)
@@ -398,12 +398,17 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
             head_corr = (np.array([lab_idx[str(m)] for m in head_meta['mrk_labels']], dtype=np.int32), np.asarray(head_meta['corr']))
             logger.info('Successfully took into account the correlation of the head markers')
     pose_ids, body_ids, finger_ids = stagei_pose_ids(sm.model_type, sm.NP, cfg.moshpp.optimize_fingers, cfg.moshpp.optimize_toes)
+    face_kw = {}
+    if cfg.moshpp.optimize_face and sm.model_type == 'smplx':       # jaw + per-frame expressions in the last two rounds (:300-305, 394-398)
+        face_kw = dict(n_expr=int(cfg.surface_model.num_expressions), expr_start=int(cfg.surface_model.betas_expr_start_id),
+                       face_ids=list(range(66, 69)))
     if prior is None:
         body_prior_ids = []
     else:
         body_prior_ids = body_ids
     weights = {k: (list(W[k]) if k == 'stagei_wt_annealing' else float(W[k])) for k in
-               ('stagei_wt_data', 'stagei_wt_poseB', 'stagei_wt_poseH', 'stagei_wt_betas', 'stagei_wt_surf', 'stagei_wt_annealing')}
+               ('stagei_wt_data', 'stagei_wt_poseB', 'stagei_wt_poseH', 'stagei_wt_betas', 'stagei_wt_surf', 'stagei_wt_annealing',
+                'stagei_wt_expr', 'stagei_wt_poseF', 'stagei_wt_init')}
     pr_dev = capi.Prior(prior['means'], prior['chols'], prior['weights']) if prior is not None else None
     out = capi.stagei_solve_host(dev, pr_dev, faces=sm.f,
                                  marker_vids=list(marker_meta['marker_vids'].values()), m2b=m2b, wt_init=wt_init, frames=frames,
@@ -411,11 +416,15 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
                                  exclude_vids=SMPLX_EYEBALL_VIDS if sm.V == 10475 else None,
                                  betas_init=all_betas[:nb] if nb else None, maxiter=int(cfg.opt_settings.maxiter),
                                  stagei_lr=float(cfg.opt_settings.stagei_lr), head_corr=head_corr,
-                                 wt_init_head=float(_get(W, 'stagei_wt_init_body', W['stagei_wt_init'])))
+                                 wt_init_head=float(_get(W, 'stagei_wt_init_body', W['stagei_wt_init'])), **face_kw)
     if nb:
         all_betas[:nb] = out['betas']
     errs = {k: v for k, v in out['errs'].items() if not (k == 'poseH' and not finger_ids) and not (k == 'beta' and not nb)
             and not (k == 'poseB' and prior is None) and not (k == 'init_head_corr' and head_corr is None)}
+    if face_kw:
+        errs['expr'] = out['errs']['beta']          # the shape block held the expressions
+    else:
+        errs.pop('poseF', None)
     # markers_latent_all_vids (:424-430): nearest vertex of the LAST frame's posed body for every valid marker of that frame
     dev.set_betas(all_betas if optimize_betas else np.zeros_like(all_betas))
     last_body = dev.lbs_forward(out['pose'][-1:], out['trans'][-1:])[0]
@@ -433,6 +442,8 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
                             'stagei_markers_sim': [sim_all[f][ids] for f, (ids, _) in enumerate(frames)],
                             'stagei_markers_obs': markers_obs, 'stagei_labels_obs': labels_obs,
                             'stagei_iters': out['iters']}
+    if face_kw:
+        stagei_debug_details['opt_models_expression'] = [e for e in out['expression']]
     stagei_data = {'betas': all_betas, 'markers_latent': out['markers_latent'], 'latent_labels': latent_labels,
                    'marker_meta': marker_meta,
                    'markers_latent_vids': {l: int(v) for l, v in zip(latent_labels, out['markers_latent_vids'])}}

@@ -53,7 +53,7 @@ static int s1_bx, s1_by;
 #define LAUNCH(k, gx, gy, nt, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), 0, stream, __VA_ARGS__)
 #endif
 
-#define S1_NMAX 2048     // unknowns (one column of the factor is staged in LDS)
+#define S1_NMAX 4096     // unknowns (one column of the factor is staged in LDS)
 #define S1_NWMAX 16      // non-zero skinning weights per vertex the vertex kernel keeps in registers
 
 namespace {
@@ -66,6 +66,9 @@ struct S1Dims {
     int o_ml, o_pose, o_b;    // column offsets
     int r_data, r_prior, r_init, r_beta, r_surf, r_poseH, r_head;   // row offsets
     int nhead, nhead_rows;    // head-marker correlation term: C[nhead_rows][nhead]
+    // the free shape block: shared betas (columns [0, nb) of shapedirs, one value set) or, per_frame = 1, the expression columns
+    // [shape_start, shape_start + nb) with one value set per frame (optimize_face); shape_free: its columns exist in this round
+    int per_frame, shape_start, shape_free, nface, r_poseF;
     int ncan;                 // canonical vertex list length = 9 M  [closest | closest0 | nearest-triangle vertices]
 };
 
@@ -79,7 +82,7 @@ struct S1Ptr {
     const int* faces; const int* v2f_ptr; const int* v2f; const unsigned char* excl;
     const int* obs_ids; const int* obs_off; const double* obs; const double* m2b; const double* wt_init;
     const int* colmap;        // [NP] column of a pose variable inside one frame's block, -1 if frozen
-    const int* body_ids; const int* finger_ids;
+    const int* body_ids; const int* finger_ids; const int* face_ids; double w_poseF;
     int* cl0; double* coef0;
     const int* head_ids; const double* head_C; double w_init_head;
     double *loss, *dinit;     // [M][3] init loss, [M][3][nb] d init / d betas (inputs of the head term)
@@ -215,7 +218,7 @@ KERNEL k_s1_setup(S1Dims d, S1Ptr p) {
         double w = p.Jreg[(size_t)k * d.V + v];
         if (w == 0.0) continue;
         for (int a = 0; a < 3; ++a)
-            acc[a] += w * (e == d.nb ? p.vt[3 * v + a] : p.shapedirs[((size_t)v * 3 + a) * d.NBtot + e]);
+            acc[a] += w * (e == d.nb ? p.vt[3 * v + a] : p.shapedirs[((size_t)v * 3 + a) * d.NBtot + d.shape_start + e]);
     }
     for (int a = 0; a < 3; ++a) red[a * 256 + TID] = acc[a];
     SYNC();
@@ -254,7 +257,8 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
     for (int i = TID; i < 3 * d.K; i += NT) {
         double s = p.J0[i];
         int k = i / 3, a = i % 3;
-        for (int e = 0; e < d.nb; ++e) s += p.JS[((size_t)k * d.nb + e) * 3 + a] * p.betas[e];
+        const double* bz = p.betas + (d.per_frame ? (size_t)z * d.nb : 0);
+        for (int e = 0; e < d.nb; ++e) s += p.JS[((size_t)k * d.nb + e) * 3 + a] * bz[e];
         Jb[i] = s;
     }
     SYNC();
@@ -349,8 +353,9 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
         const bool fz = p.featzero[z] != 0;
         for (int c = 0; c < 3; ++c) {
             double sacc = p.vt[3 * v + c];
-            const double* sd = p.shapedirs + ((size_t)v * 3 + c) * d.NBtot;
-            for (int e = 0; e < d.nb; ++e) sacc += sd[e] * p.betas[e];
+            const double* sd = p.shapedirs + ((size_t)v * 3 + c) * d.NBtot + d.shape_start;
+            const double* bz = p.betas + (d.per_frame ? (size_t)z * d.nb : 0);
+            for (int e = 0; e < d.nb; ++e) sacc += sd[e] * bz[e];
             vs[c] = sacc;
             const double* pd = p.posedirs + ((size_t)v * 3 + c) * d.nfeat;
             double t = 0;
@@ -390,8 +395,9 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
     if (d.nb) {
         const double* q = p.q + (size_t)z * d.K * d.nb * 3;
         for (int e = 0; e < d.nb; ++e) {
-            double se[3] = {p.shapedirs[((size_t)v * 3 + 0) * d.NBtot + e], p.shapedirs[((size_t)v * 3 + 1) * d.NBtot + e],
-                            p.shapedirs[((size_t)v * 3 + 2) * d.NBtot + e]}, o[3];
+            const int ec = d.shape_start + e;
+            double se[3] = {p.shapedirs[((size_t)v * 3 + 0) * d.NBtot + ec], p.shapedirs[((size_t)v * 3 + 1) * d.NBtot + ec],
+                            p.shapedirs[((size_t)v * 3 + 2) * d.NBtot + ec]}, o[3];
             matvec3(Trot, se, o);
             for (int s = 0; s < nw; ++s) for (int c = 0; c < 3; ++c) o[c] += wj[s] * q[((size_t)jj[s] * d.nb + e) * 3 + c];
             for (int c = 0; c < 3; ++c) p.dvs[(slot * 3 + c) * d.nb + e] = o[c];
@@ -678,7 +684,7 @@ KERNEL k_s1_shared(S1Dims d, S1Ptr p, int want_J, int write_rows) {
     if (!(coef[0] == coef[0]) || !(coef[1] == coef[1]) || !(coef[2] == coef[2])) p.status[2] = 1;   // collinear neighbours
     for (int i = 0; i < 9; ++i) p.Fc[9 * m + i] = Fc[i];
     for (int i = 0; i < 3; ++i) p.coef[3 * m + i] = coef[i];
-    const int nb = d.nb;
+    const int nb = d.per_frame ? 0 : d.nb;          // the canonical body does not see per-frame expressions
     if (want_J && nb) {
         // dc_i/dbeta = (diff^T df_i/dV - f_i^T [I 0 0]) dV/dbeta
         const double* dV = p.dvs + (zc + 3 * m) * 3 * nb;           // [9][nb]
@@ -754,7 +760,7 @@ KERNEL k_s1_head(S1Dims d, S1Ptr p, int want_J) {
         if (want_J) {
             double* Jr = p.Jm + (size_t)(d.r_head + it) * d.ldn;
             for (int h = 0; h < d.nhead; ++h) Jr[d.o_ml + 3 * p.head_ids[h] + a] = Cg[h] * p.w_init_head;
-            for (int e = 0; e < d.nb; ++e) {
+            for (int e = 0; e < (d.per_frame ? 0 : d.nb); ++e) {
                 double t = 0;
                 for (int h = 0; h < d.nhead; ++h) t += Cg[h] * p.dinit[((size_t)p.head_ids[h] * 3 + a) * d.nb + e];
                 Jr[d.o_b + e] = -t * p.w_init_head;
@@ -820,14 +826,15 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
             const double* L = Lb + 36 * m; const double* Fp = L + 27; const double* Fc = p.Fc + 9 * m;
             Jr[3 * f + a] = -p.w_data;
             for (int b = 0; b < 3; ++b) Jr[d.o_ml + 3 * m + b] = -p.w_data * (Fp[a] * Fc[b] + Fp[3 + a] * Fc[3 + b] + Fp[6 + a] * Fc[6 + b]);
-            if (nb) {
+            if (nb && d.shape_free) {
                 const double* dV = p.dvs + ((size_t)f * d.ncan + 3 * m) * 3 * nb;
                 const double* dc = p.dcdb + (size_t)m * 3 * nb;
+                const int cb = d.o_b + (d.per_frame ? f * nb : 0);
                 for (int e = 0; e < nb; ++e) {
                     double s = 0;
                     for (int b = 0; b < 9; ++b) s += L[9 * a + b] * dV[(size_t)b * nb + e];
-                    for (int i = 0; i < 3; ++i) s += Fp[3 * i + a] * dc[(size_t)i * nb + e];
-                    Jr[d.o_b + e] = -p.w_data * s;
+                    if (!d.per_frame) for (int i = 0; i < 3; ++i) s += Fp[3 * i + a] * dc[(size_t)i * nb + e];
+                    Jr[cb + e] = -p.w_data * s;
                 }
             }
         }
@@ -864,6 +871,17 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
             }
         }
         SYNC();
+    }
+    for (int k = TID; k < d.nface; k += NT) {          // poseF: the jaw (chmosh.py:394-396)
+        int pid = p.face_ids[k];
+        p.r[d.r_poseF + f * d.nface + k] = p.pose[(size_t)f * d.NP + pid] * p.w_poseF;
+        if (want_J) p.Jm[(size_t)(d.r_poseF + f * d.nface + k) * d.ldn + colbase + p.colmap[pid]] = p.w_poseF;
+    }
+    if (d.per_frame && d.shape_free) {                  // expr: this frame's expression coefficients (:397)
+        for (int e = TID; e < nb; e += NT) {
+            p.r[d.r_beta + f * nb + e] = p.betas[(size_t)f * nb + e] * p.w_beta;
+            if (want_J) p.Jm[(size_t)(d.r_beta + f * nb + e) * d.ldn + d.o_b + f * nb + e] = p.w_beta;
+        }
     }
     for (int k = TID; k < d.nfinger; k += NT) {
         int pid = p.finger_ids[k];
@@ -1202,12 +1220,15 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     auto fail = [&](int code, const char* msg) { snprintf(err, errlen, "%s", msg); return code; };
     S1Dims d; memset(&d, 0, sizeof(d));
     S1Ptr p; memset(&p, 0, sizeof(p));
-    d.F = ds->n_frames; d.M = ds->M; d.nb = ds->nb; d.NPZ = d.F + 1;
+    d.F = ds->n_frames; d.M = ds->M; d.NPZ = d.F + 1;
+    d.per_frame = ds->n_expr > 0 ? 1 : 0;
+    d.nb = d.per_frame ? ds->n_expr : ds->nb; d.shape_start = d.per_frame ? ds->expr_start : 0;
+    if (d.per_frame && ds->nb != 0) return fail(MOSHII_ERR_ARG, "stagei: free expressions need fixed betas (nb = 0; chmosh.py:295-299)");
     d.V = mv->V; d.K = mv->K; d.P = 3 * mv->K; d.NP = mv->NP; d.body_dof = mv->body_dof; d.hand_dof = mv->hand_dof;
     d.nhand_full = d.P - d.body_dof; d.NBtot = mv->NB; d.nfeat = 9 * (mv->K - 1);
     d.nfaces = ds->n_faces; d.nbody = ds->n_body; d.G = pv ? pv->G : 0; d.npose_prior = pv ? pv->npose : 0;
     d.ncan = 9 * d.M;
-    if (d.F < 1 || d.M < 3 || d.nb < 0 || d.nb > d.NBtot) return fail(MOSHII_ERR_ARG, "stagei: bad sizes");
+    if (d.F < 1 || d.M < 3 || d.nb < 0 || d.shape_start < 0 || d.shape_start + d.nb > d.NBtot) return fail(MOSHII_ERR_ARG, "stagei: bad sizes");
     if (pv && d.nbody != pv->npose) return fail(MOSHII_ERR_ARG, "stagei: prior size != number of body pose ids");
     if (d.G > 64) return fail(MOSHII_ERR_ARG, "stagei: more than 64 mixture components");
     const int F = d.F, M = d.M, nb = d.nb, NP = d.NP, K = d.K;
@@ -1254,6 +1275,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.body_ids = pool.put(ds->body_ids, d.nbody, st);
     int* d_colmap = pool.get<int>(NP); p.colmap = d_colmap;
     int* d_finger = pool.get<int>(std::max(1, ds->n_finger)); p.finger_ids = d_finger;
+    const int nface_all = d.per_frame ? ds->n_face : 0;
+    for (int k = 0; k < nface_all; ++k) if (ds->face_ids[k] < 0 || ds->face_ids[k] >= NP) return fail(MOSHII_ERR_ARG, "stagei: face pose id out of range");
+    p.face_ids = pool.put(ds->face_ids, nface_all, st);
     p.cl0 = pool.get<int>(3 * M); p.coef0 = pool.get<double>(3 * M);
     p.loss = pool.get<double>(3 * M); p.dinit = pool.get<double>((size_t)3 * M * std::max(1, nb));
     d.nhead = ds->head_ids ? ds->n_head : 0; d.nhead_rows = ds->head_ids ? ds->n_head_rows : 0;
@@ -1269,7 +1293,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.wt_init = pool.put(wt_init_eff.data(), M, st);
     hipStreamSynchronize(st);
     p.pose = pool.get<double>((size_t)d.NPZ * NP); p.trans = pool.get<double>((size_t)d.NPZ * 3);
-    p.ml = pool.get<double>(3 * M); p.betas = pool.get<double>(std::max(1, nb));
+    p.ml = pool.get<double>(3 * M); p.betas = pool.get<double>((size_t)std::max(1, nb) * (d.per_frame ? d.NPZ : 1));
     p.J0 = pool.get<double>(3 * K); p.JS = pool.get<double>((size_t)std::max(1, K * nb * 3));
     p.fp = pool.get<double>((size_t)d.NPZ * d.P); p.Rl = pool.get<double>((size_t)d.NPZ * K * 9); p.Jl = pool.get<double>((size_t)d.NPZ * K * 9);
     p.Rw = pool.get<double>((size_t)d.NPZ * K * 9); p.tw = pool.get<double>((size_t)d.NPZ * K * 3); p.feat = pool.get<double>((size_t)d.NPZ * d.nfeat);
@@ -1284,12 +1308,13 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.vi_x = pool.get<double>((size_t)F * 3 * M * S1_NWMAX * 3); p.vi_n = pool.get<int>((size_t)F * 3 * M); p.vi_j = pool.get<int>((size_t)F * 3 * M * S1_NWMAX);
     p.Lb = pool.get<double>((size_t)F * M * 36 + (size_t)F * std::max(1, d.G * d.npose_prior));
     // largest problem of the rounds: all of body + fingers free
-    const int npid_max = ds->n_pose_ids + ds->n_finger;
-    const int n_max = 3 * F + 3 * M + F * npid_max + nb;
-    const int R_max = 3 * ntot_obs + F * (d.G ? d.npose_prior + 1 : 0) + 3 * M + nb + M + F * ds->n_finger + 3 * d.nhead_rows;
+    const int npid_max = ds->n_pose_ids + ds->n_finger + nface_all;
+    const int nsh_max = d.per_frame ? F * nb : nb;
+    const int n_max = 3 * F + 3 * M + F * npid_max + nsh_max;
+    const int R_max = 3 * ntot_obs + F * (d.G ? d.npose_prior + 1 : 0) + 3 * M + nsh_max + M + F * ds->n_finger + 3 * d.nhead_rows + F * nface_all;
     const int ld_max = (n_max + 15) & ~15;
     p.r = pool.get<double>(R_max); p.Jm = pool.get<double>((size_t)R_max * ld_max);
-    if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 2048 unknowns");
+    if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 4096 unknowns");
     double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max);
     double* d_dinv = pool.get<double>((size_t)(n_max / S1_PB + 1) * S1_PB * S1_PB); int* d_flags = pool.get<int>((size_t)((R_max + S1_T - 1) / S1_T) * ((n_max + S1_T - 1) / S1_T));
     double* d_g = pool.get<double>(n_max); double* d_part = pool.get<double>((size_t)S1_GT_CHUNKS * n_max); double* d_vec = pool.get<double>(n_max);
@@ -1298,8 +1323,8 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     hipMemsetAsync(p.status, 0, 4 * sizeof(int), st);
 
     // ---- host state
-    std::vector<double> pose((size_t)d.NPZ * NP, 0.0), trans((size_t)d.NPZ * 3, 0.0), ml(3 * M), betas(std::max(1, nb), 0.0);
-    if (ds->betas_init) for (int e = 0; e < nb; ++e) betas[e] = ds->betas_init[e];
+    std::vector<double> pose((size_t)d.NPZ * NP, 0.0), trans((size_t)d.NPZ * 3, 0.0), ml(3 * M), betas((size_t)std::max(1, nb) * (d.per_frame ? d.NPZ : 1), 0.0);
+    if (ds->betas_init && !d.per_frame) for (int e = 0; e < nb; ++e) betas[e] = ds->betas_init[e];
     std::vector<int> pose_ids, finger_ids, colmap(NP, -1);
 
     auto upload_point = [&]() {
@@ -1358,9 +1383,11 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     }
     upload_point();
     // frozen attachment of the init markers (chmosh.py:188-190): closest0 / coef0 at the start point
-    d.npid = 0; d.n = 3 * F + 3 * M + nb; d.ldn = (d.n + 15) & ~15; d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose;
-    d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior; d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH; d.R = d.r_head + 3 * d.nhead_rows;
-    d.nfinger = 0;
+    d.shape_free = d.per_frame ? 0 : 1;
+    const int nsh0 = d.per_frame ? 0 : nb;
+    d.npid = 0; d.n = 3 * F + 3 * M + nsh0; d.ldn = (d.n + 15) & ~15; d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose;
+    d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior; d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nsh0; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH; d.r_poseF = d.r_head + 3 * d.nhead_rows; d.R = d.r_poseF;
+    d.nfinger = 0; d.nface = 0;
     {
         int Gkeep = d.G; d.G = 0;                      // no prior rows while the column map is empty
         hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
@@ -1390,18 +1417,24 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         finger_ids.clear();
         if (detailed) finger_ids.assign(ds->finger_ids, ds->finger_ids + ds->n_finger);
         pose_ids.insert(pose_ids.end(), finger_ids.begin(), finger_ids.end());
+        d.nface = (detailed && d.per_frame) ? nface_all : 0;
+        if (d.nface) pose_ids.insert(pose_ids.end(), ds->face_ids, ds->face_ids + d.nface);
+        d.shape_free = d.per_frame ? (detailed ? 1 : 0) : 1;
+        const int nsh = d.per_frame ? (d.shape_free ? F * nb : 0) : nb;
         std::sort(pose_ids.begin(), pose_ids.end());
         pose_ids.erase(std::unique(pose_ids.begin(), pose_ids.end()), pose_ids.end());
         std::fill(colmap.begin(), colmap.end(), -1);
         for (size_t c = 0; c < pose_ids.size(); ++c) colmap[pose_ids[c]] = (int)c;
         for (int b = 0; b < d.nbody; ++b) if (ds->body_ids[b] < 0 || ds->body_ids[b] >= NP) return fail(MOSHII_ERR_ARG, "stagei: body id out of range");
         d.npid = (int)pose_ids.size(); d.nfinger = (int)finger_ids.size();
-        d.n = 3 * F + 3 * M + F * d.npid + nb; d.ldn = (d.n + 15) & ~15;
+        d.n = 3 * F + 3 * M + F * d.npid + nsh; d.ldn = (d.n + 15) & ~15;
         d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose + F * d.npid;
         d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior + F * (d.G ? d.npose_prior + 1 : 0);
-        d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nb; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH + F * d.nfinger; d.R = d.r_head + 3 * d.nhead_rows;
+        d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nsh; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH + F * d.nfinger;
+        d.r_poseF = d.r_head + 3 * d.nhead_rows; d.R = d.r_poseF + F * d.nface;
         p.w_anneal = a; p.w_data = (ds->wt_data / a) * (46.0 / M); p.w_poseB = ds->wt_poseB * a; p.w_poseH = ds->wt_poseH * a;
-        p.w_beta = ds->wt_betas * a; p.w_surf = ds->wt_surf; p.w_init_head = ds->wt_init_head * a;
+        p.w_beta = (d.per_frame ? ds->wt_expr : ds->wt_betas) * a; p.w_surf = ds->wt_surf; p.w_init_head = ds->wt_init_head * a;
+        p.w_poseF = ds->wt_poseF * a;
         hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
         if (d.nfinger) hipMemcpyAsync(d_finger, finger_ids.data(), d.nfinger * sizeof(int), hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
@@ -1411,13 +1444,13 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             for (int f = 0; f < F; ++f) for (int c = 0; c < 3; ++c) xx[3 * f + c] = trans[3 * f + c];
             for (int i = 0; i < 3 * M; ++i) xx[d.o_ml + i] = ml[i];
             for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) xx[d.o_pose + f * d.npid + c] = pose[(size_t)f * NP + pose_ids[c]];
-            for (int e = 0; e < nb; ++e) xx[d.o_b + e] = betas[e];
+            for (int e = 0; e < nsh; ++e) xx[d.o_b + e] = betas[e];          // per-frame mode: [frame][coefficient], canonical row last
         };
         auto unpack = [&](const std::vector<double>& xx) {
             for (int f = 0; f < F; ++f) for (int c = 0; c < 3; ++c) trans[3 * f + c] = xx[3 * f + c];
             for (int i = 0; i < 3 * M; ++i) ml[i] = xx[d.o_ml + i];
             for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) pose[(size_t)f * NP + pose_ids[c]] = xx[d.o_pose + f * d.npid + c];
-            for (int e = 0; e < nb; ++e) betas[e] = xx[d.o_b + e];
+            for (int e = 0; e < nsh; ++e) betas[e] = xx[d.o_b + e];
         };
         auto eval_at = [&](const std::vector<double>& xx, int want_J, std::vector<double>& rr) -> double {
             unpack(xx); upload_point(); evaluate(want_J); fetch(rr, p.r, R);
@@ -1543,8 +1576,8 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             auto sse_rows = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
             if (ds->errs) {
                 ds->errs[0] = sse_rows(d.r_data, d.r_prior); ds->errs[1] = sse_rows(d.r_prior, d.r_init); ds->errs[2] = sse_rows(d.r_init, d.r_beta);
-                ds->errs[3] = sse_rows(d.r_beta, d.r_surf); ds->errs[4] = sse_rows(d.r_surf, d.r_poseH); ds->errs[5] = sse_rows(d.r_poseH, d.r_head); ds->errs[6] = sse_rows(d.r_head, d.R);
-                reduce(ds->errs, 7);
+                ds->errs[3] = sse_rows(d.r_beta, d.r_surf); ds->errs[4] = sse_rows(d.r_surf, d.r_poseH); ds->errs[5] = sse_rows(d.r_poseH, d.r_head); ds->errs[6] = sse_rows(d.r_head, d.r_poseF); ds->errs[7] = sse_rows(d.r_poseF, d.R);
+                reduce(ds->errs, 8);
             }
         }
         int hstat[4];
@@ -1568,7 +1601,8 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         }
         if (ds->markers_latent_vids) ds->markers_latent_vids[m] = bi;
     }
-    if (ds->betas) for (int e = 0; e < nb; ++e) ds->betas[e] = betas[e];
+    if (ds->betas && !d.per_frame) for (int e = 0; e < nb; ++e) ds->betas[e] = betas[e];
+    if (ds->expression && d.per_frame) memcpy(ds->expression, betas.data(), (size_t)F * nb * 8);
     if (ds->markers_latent) memcpy(ds->markers_latent, ml.data(), 3 * M * 8);
     if (ds->pose) memcpy(ds->pose, pose.data(), (size_t)F * NP * 8);
     if (ds->trans) memcpy(ds->trans, trans.data(), (size_t)F * 3 * 8);

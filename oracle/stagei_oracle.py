@@ -241,7 +241,13 @@ class StageIObjective:
         self.betas = np.zeros(self.nb)
         self.pose_ids = []
         self.finger_ids = []
+        self.face_ids = []
         self.w = {}
+        # per-frame expression coefficients (optimize_face; chmosh.py:295-305, 394-398): the model's free shape block then holds the
+        # expression columns and nb must be 0 (the reference cannot share betas and free expressions either, :295-299)
+        self.E = 0
+        self.expr = np.zeros((self.F, 0))
+        self.expr_on = False
         self.fp_can = o2.fullpose_from_pose(m, np.zeros(m['NP']))
         # init markers: coefficients frozen at the start values, canonical body live (chmosh.py:188-190)
         can = self.can_verts(self.betas)
@@ -251,12 +257,21 @@ class StageIObjective:
     def can_verts(self, betas, vids=None):
         return o2.verts_forward(self.m, self.fp_can, np.zeros(3), vids, shp=betas if self.nb else None)
 
-    def set_round(self, pose_ids, finger_ids, w):
-        """w: dict(data, poseB, poseH, beta, surf, anneal) -- the per-round weights of chmosh.py:318-330."""
+    def set_expressions(self, n_expr):
+        assert self.nb == 0, 'free expressions need fixed betas'
+        self.E = int(n_expr)
+        self.expr = np.zeros((self.F, self.E))
+
+    def set_round(self, pose_ids, finger_ids, w, face_ids=(), expr_on=False):
+        """w: dict(data, poseB, poseH, beta, surf, anneal[, poseF, expr]) -- the per-round weights of chmosh.py:318-330."""
         self.pose_ids, self.finger_ids, self.w = list(pose_ids), list(finger_ids), dict(w)
+        self.face_ids, self.expr_on = list(face_ids), bool(expr_on) and self.E > 0
 
     def x(self):
-        return np.concatenate([self.trans.ravel(), self.ml.ravel(), self.pose[:, self.pose_ids].ravel(), self.betas])
+        parts = [self.trans.ravel(), self.ml.ravel(), self.pose[:, self.pose_ids].ravel(), self.betas]
+        if self.expr_on:
+            parts.append(self.expr.ravel())
+        return np.concatenate(parts)
 
     def _unpack(self, x):
         F, M, npid = self.F, self.M, len(self.pose_ids)
@@ -264,11 +279,14 @@ class StageIObjective:
         ml = x[3 * F:3 * F + 3 * M].reshape(M, 3)
         pose = self.pose.copy()
         pose[:, self.pose_ids] = x[3 * F + 3 * M:3 * F + 3 * M + F * npid].reshape(F, npid)
-        betas = x[3 * F + 3 * M + F * npid:]
+        o_b = 3 * F + 3 * M + F * npid
+        betas = x[o_b:o_b + self.nb]
+        self._expr_x = x[o_b + self.nb:].reshape(F, self.E) if self.expr_on else self.expr
         return trans, ml, pose, betas
 
     def set_x(self, x):
         self.trans, self.ml, self.pose, self.betas = [np.array(a) for a in self._unpack(x)]
+        self.expr = np.array(self._expr_x)
 
     def markers_sim(self, f, ml=None, pose=None, trans=None, betas=None):
         ml = self.ml if ml is None else ml
@@ -276,17 +294,19 @@ class StageIObjective:
         can = self.can_verts(betas)
         cl, coef = o2.transformed_coeffs(can, ml, self.exclude_vids)
         fp = o2.fullpose_from_pose(self.m, self.pose[f] if pose is None else pose)
-        v = o2.verts_forward(self.m, fp, self.trans[f] if trans is None else trans, cl.reshape(-1),
-                             shp=betas if self.nb else None).reshape(-1, 3, 3)
+        shp = self.expr[f] if self.E else (betas if self.nb else None)
+        v = o2.verts_forward(self.m, fp, self.trans[f] if trans is None else trans, cl.reshape(-1), shp=shp).reshape(-1, 3, 3)
         return o2.markers_from_verts(coef, v[:, 0], v[:, 1], v[:, 2])
 
     def evaluate(self, x, want_J=False):
         """Residual dict (term -> vector) and, optionally, the dense Jacobian dict (term -> [rows, n])."""
         m, F, M, nb = self.m, self.F, self.M, self.nb
         trans, ml, pose, betas = self._unpack(x)
+        expr, E = self._expr_x, self.E
         npid = len(self.pose_ids)
         n = len(x)
         o_ml, o_pose, o_b = 3 * F, 3 * F + 3 * M, 3 * F + 3 * M + F * npid
+        o_e = o_b + nb
         shp = betas if nb else None
         w = self.w
         can = self.can_verts(betas)
@@ -310,13 +330,14 @@ class StageIObjective:
         rd, Jd = [], []
         for f, (ids, obs) in enumerate(self.frames):
             fp = o2.fullpose_from_pose(m, pose[f])
+            shp_f = expr[f] if E else shp                          # per-frame expressions ride in the model's free shape block
             if want_J:
-                if nb:
-                    v, dv, dvs = o2.verts_jacobian(m, fp, trans[f], flat, shp=shp, want_shape=True)
+                if nb or self.expr_on:
+                    v, dv, dvs = o2.verts_jacobian(m, fp, trans[f], flat, shp=shp_f, want_shape=True)
                 else:
-                    v, dv = o2.verts_jacobian(m, fp, trans[f], flat, shp=shp)
+                    v, dv = o2.verts_jacobian(m, fp, trans[f], flat, shp=shp_f)
             else:
-                v = o2.verts_forward(m, fp, trans[f], flat, shp=shp)
+                v = o2.verts_forward(m, fp, trans[f], flat, shp=shp_f)
             v3 = v.reshape(M, 3, 3)
             if want_J:
                 sim, L = o2.markers_from_verts(coef, v3[:, 0], v3[:, 1], v3[:, 2], want_jac=True)
@@ -334,7 +355,10 @@ class StageIObjective:
                     Jf[k, :, o_ml + 3 * i:o_ml + 3 * i + 3] = dsim_dml[i]
                 if nb:
                     Jb = np.einsum('mab,mbe->mae', L, dvs.reshape(M, 9, nb)) + np.einsum('mia,mie->mae', Fp, dc_db)
-                    Jf[:, :, o_b:] = Jb[ids]
+                    Jf[:, :, o_b:o_b + nb] = Jb[ids]
+                if self.expr_on:                                            # the canonical body does not see a frame's expression
+                    Je = np.einsum('mab,mbe->mae', L, dvs.reshape(M, 9, E))
+                    Jf[:, :, o_e + f * E:o_e + (f + 1) * E] = Je[ids]
                 Jd.append(-w['data'] * Jf.reshape(-1, n))
         res['data'] = np.concatenate(rd)
         if want_J:
@@ -371,7 +395,7 @@ class StageIObjective:
             for i in range(M):
                 Jl[i, :, o_ml + 3 * i:o_ml + 3 * i + 3] = np.eye(3)
             if nb:
-                Jl[:, :, o_b:] = -dinit_db
+                Jl[:, :, o_b:o_b + nb] = -dinit_db
         head_ids = set(self.head_corr[0].tolist()) if self.head_corr is not None else set()
         for t, (ids, wt) in enumerate(self.init_terms):
             keep = np.array([i for i in ids if i not in head_ids], dtype=np.int64)
@@ -387,7 +411,7 @@ class StageIObjective:
         if nb:
             res['beta'] = betas * w['beta']
             if want_J:
-                Jb = np.zeros((nb, n)); Jb[:, o_b:] = np.eye(nb) * w['beta']
+                Jb = np.zeros((nb, n)); Jb[:, o_b:o_b + nb] = np.eye(nb) * w['beta']
                 jac['beta'] = Jb
         # ---- surf (chmosh.py:69-80, 373)
         if want_J:
@@ -397,7 +421,7 @@ class StageIObjective:
                 Js[i, o_ml + 3 * i:o_ml + 3 * i + 3] = dp[i]
             if nb:
                 _, _, dtri = o2.verts_jacobian(m, self.fp_can, np.zeros(3), fv.reshape(-1), shp=shp, want_shape=True)
-                Js[:, o_b:] = np.einsum('mva,mvae->me', dabc, dtri.reshape(M, 3, 3, nb))
+                Js[:, o_b:o_b + nb] = np.einsum('mva,mvae->me', dabc, dtri.reshape(M, 3, 3, nb))
             jac['surf'] = Js * w['surf']
         else:
             dist, tri, part = signed_surface_distance(ml, can, self.faces)
@@ -412,6 +436,21 @@ class StageIObjective:
                     for k, pid in enumerate(self.finger_ids):
                         Jh[f, k, o_pose + f * npid + cols[pid]] = w['poseH']
                 jac['poseH'] = Jh.reshape(-1, n)
+        # ---- poseF / expr (chmosh.py:394-398): jaw pose and the per-frame expression coefficients, last two rounds
+        if len(self.face_ids):
+            res['poseF'] = (pose[:, self.face_ids] * w['poseF']).ravel()
+            if want_J:
+                cols = {pid: k for k, pid in enumerate(self.pose_ids)}
+                Jh = np.zeros((F, len(self.face_ids), n))
+                for f in range(F):
+                    for k, pid in enumerate(self.face_ids):
+                        Jh[f, k, o_pose + f * npid + cols[pid]] = w['poseF']
+                jac['poseF'] = Jh.reshape(-1, n)
+        if self.expr_on:
+            res['expr'] = (expr * w['expr']).ravel()
+            if want_J:
+                Je = np.zeros((F * E, n)); Je[:, o_e:] = np.eye(F * E) * w['expr']
+                jac['expr'] = Je
         return (res, jac) if want_J else res
 
     def r(self, x):
@@ -425,13 +464,17 @@ class StageIObjective:
 
 def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_mask, m2b_distance, nb, weights=None,
                  optimize_fingers=False, optimize_toes=False, betas_init=None, maxiter=100, stagei_lr=1e-3, exclude_vids=None,
-                 head_corr=None, stats=None):
+                 head_corr=None, stats=None, optimize_face=False, expr_start=None, n_expr=0):
     """mosh_stagei's numeric core (chmosh.py:177-447).  `frames`: list of (latent marker ids, obs[n,3]) -- the `common_labels`
     selection of :199-206 already applied; `marker_vids`[M]; `marker_type_mask`: {type: bool[M]}; `m2b_distance`: {type: metres}.
     Returns betas, markers_latent, markers_latent_vids, per-frame pose / trans, per-term SSE of the last round."""
     W = stagei_weights_default() if weights is None else weights
     M = len(marker_vids)
-    o2.set_free_shape(m, 0, nb)
+    if optimize_face:
+        assert nb == 0, 'optimize_face needs fixed betas (chmosh.py:295-299)'
+        o2.set_free_shape(m, expr_start, n_expr)          # the free block now holds the expression columns, one value set per frame
+    else:
+        o2.set_free_shape(m, 0, nb)
     m2b = np.ones(M) * 0.0095
     for k, mask in marker_type_mask.items():
         m2b[np.asarray(mask, dtype=bool)] = m2b_distance[k]
@@ -444,6 +487,9 @@ def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_m
                   for k, mask in marker_type_mask.items()]
     obj = StageIObjective(m, faces, prior, body, frames, ml0, m2b, init_terms, nb, exclude_vids=exclude_vids, head_corr=head_corr)
     obj.betas = b0.copy()
+    if optimize_face:
+        obj.set_expressions(n_expr)
+    face = o2.face_pose_ids(model_type, optimize_face)
     obj.cl0, obj.coef0 = o2.transformed_coeffs(obj.can_verts(obj.betas), obj.ml, exclude_vids)
     # rigid initialisation per frame (chmosh.py:236-238, rigid_transformations.py:73-83)
     for f, (ids, obs) in enumerate(obj.frames):
@@ -457,18 +503,19 @@ def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_m
         detailed = tidx > len(anneal) - 3
         w = dict(anneal=a, data=(W['stagei_wt_data'] / a) * (46.0 / M), poseB=W['stagei_wt_poseB'] * a,
                  poseH=W['stagei_wt_poseH'] * a, beta=W['stagei_wt_betas'] * a, surf=W['stagei_wt_surf'],
-                 init_head=W.get('stagei_wt_init_body', W['stagei_wt_init'] * a))
+                 init_head=W.get('stagei_wt_init_body', W['stagei_wt_init']) * a, poseF=W['stagei_wt_poseF'] * a, expr=W['stagei_wt_expr'] * a)
         pose_ids = list(root) + list(body)
         if len(body) and not optimize_toes:
             pose_ids = sorted(set(pose_ids).difference(range(30, 36)))
         fing = list(finger) if (detailed and optimize_fingers) else []
-        pose_ids = sorted(set(pose_ids + fing))
-        obj.set_round(pose_ids, fing, w)
+        fc = list(face) if detailed else []
+        pose_ids = sorted(set(pose_ids + fing + fc))
+        obj.set_round(pose_ids, fing, w, face_ids=fc, expr_on=detailed and optimize_face)
         x = o2.minimize_dogleg(obj, obj.x(), e_3=stagei_lr, delta_0=0.5, maxiter=maxiter, stats=stats)
         obj.set_x(x)
         res = obj.evaluate(x)
     can = obj.can_verts(obj.betas)
     d2 = ((obj.ml[:, None, :] - can[None]) ** 2).sum(-1)
-    return dict(betas=obj.betas.copy(), markers_latent=obj.ml.copy(), markers_latent_vids=np.argmin(d2, axis=1),
+    return dict(expression=obj.expr.copy(), betas=obj.betas.copy(), markers_latent=obj.ml.copy(), markers_latent_vids=np.argmin(d2, axis=1),
                 pose=obj.pose.copy(), trans=obj.trans.copy(), errs={k: float((v ** 2).sum()) for k, v in res.items()},
                 objective=obj)

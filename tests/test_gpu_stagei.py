@@ -61,10 +61,12 @@ def _variant(name):
     if name == 'head_corr':          # head-marker correlation term (chmosh.py:252-266, 362-369)
         rng = np.random.default_rng(0)
         return helpers.stagei_case(), False, dict(head_corr=(np.array([3, 7, 11, 20]), rng.normal(0, 1, (3, 4))))
+    if name == 'face':               # SMPL-X, fixed betas, jaw + per-frame expression coefficients free in the last two rounds
+        return helpers.stagei_case('smplx', seed=3, nb=0), False, dict(n_expr=5, expr_start=4, face_ids=[66, 67, 68])
     raise KeyError(name)
 
 
-@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr'])
+@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr', 'face'])
 def test_stagei_variants_match_oracle(name):
     from moshpp_amd import capi
     from oracle import stagei_oracle as s1
@@ -75,7 +77,9 @@ def test_stagei_variants_match_oracle(name):
     pr = capi.Prior(c['prior']['means'], c['prior']['chols'], c['prior']['weights']) if c['prior'] is not None else None
     out = capi.stagei_solve_host(dev, pr, **helpers.stagei_kwargs(c, optimize_fingers=fingers, **extra))
     ref = s1.stagei_solve(c['m'], c['faces'], c['prior'], c['model_type'], c['frames'], c['vids'], c['mask'], c['m2b'], c['nb'],
-                          optimize_fingers=fingers, **extra)
+                          optimize_fingers=fingers, **helpers.stagei_oracle_extra(extra))
+    if name == 'face':
+        assert np.abs(out['expression'] - ref['expression']).max() < 1e-5 and np.abs(ref['expression']).max() > 1e-3
     if c['nb']:
         assert np.abs(out['betas'] - ref['betas']).max() < 1e-5
     assert np.abs(out['markers_latent'] - ref['markers_latent']).max() < 1e-6

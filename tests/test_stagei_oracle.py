@@ -104,7 +104,7 @@ def test_kernel_arithmetic_matches_oracle_in_emulation(case, fingers):
     assert np.allclose(out['errs'][:6], want, rtol=1e-7, atol=1e-12) and out['errs'][6] == 0.0
 
 
-@pytest.mark.parametrize('name', ['mano', 'fixed_betas', 'head_corr'])
+@pytest.mark.parametrize('name', ['mano', 'fixed_betas', 'head_corr', 'face'])
 def test_kernel_arithmetic_variants_in_emulation(name):
     """Other model families / options through the emulated kernels (the GPU tests run the full list)."""
     from tests.emu import emu_stagei
@@ -112,7 +112,9 @@ def test_kernel_arithmetic_variants_in_emulation(name):
     c, fingers, extra = _variant(name)
     out = emu_stagei.solve(c['m'], c['prior'], **helpers.stagei_kwargs(c, optimize_fingers=fingers, **extra))
     ref = s1.stagei_solve(c['m'], c['faces'], c['prior'], c['model_type'], c['frames'], c['vids'], c['mask'], c['m2b'], c['nb'],
-                          optimize_fingers=fingers, **extra)
+                          optimize_fingers=fingers, **helpers.stagei_oracle_extra(extra))
+    if name == 'face':
+        assert np.abs(out['expression'] - ref['expression']).max() < 1e-8
     assert np.abs(out['markers_latent'] - ref['markers_latent']).max() < 1e-9
     assert np.abs(out['pose'] - ref['pose']).max() < 1e-8 and np.abs(out['trans'] - ref['trans']).max() < 1e-9
     if c['nb']:
