@@ -80,7 +80,8 @@ def default_cfg():
                               num_dmpls=8, dof_per_hand=24, num_expressions=80, use_hands_mean=True, gender='neutral'),
         'moshpp': dict(pose_body_prior_fname=None, pose_hand_prior_fname=None, optimize_fingers=False,
                        optimize_face=False, optimize_toes=False, optimize_betas=True, optimize_dynamics=False,
-                       head_marker_corr_fname=None,
+                       head_marker_corr_fname=None, betas_fname=None, v_template_fname=None, wrist_markers_on_stick=False,
+                       separate_types=['body', 'face', 'finger'],
                        stagei_frame_picker=dict(type='random_strict', seed=100, num_frames=12, least_avail_markers=1.0,
                                                 stagei_mocap_fnames=None),
                        verbosity=1, visualization=dict(marker_radius=dict(body=0.009, face=0.004, finger=0.005))),

@@ -105,3 +105,65 @@ def marker_layout_write(marker_meta, marker_layout_fname):
             'distance_from_skin': marker_meta['m2b_distance'][marker_type], 'type': marker_type})
     with open(marker_layout_fname, 'w') as f:
         json.dump(layout, f, sort_keys=True, indent=2, separators=(',', ': '))
+
+
+def _marker_vid_tables():
+    """(all_marker_vids, marker_type_labels) of the reference's marker_vids.py, shipped as data (tools/make_marker_vids.py)."""
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'marker_vids.json')
+    with open(fn) as fh:
+        d = json.load(fh)
+    return d['all_marker_vids'], d['marker_type_labels']
+
+
+def marker_labels_to_marker_layout(chosen_markers, marker_layout_fname, surface_model_type, labels_map=general_labels_map,
+                                   wrist_markers_on_stick=False, separate_types=None) -> bool:
+    """Create a marker-layout json for the labels seen in a capture (create_marker_layout_for_mocaps.py:44-131): known labels get
+    their table vertex id, are sorted, typed (face / finger_left / finger_right / wrist-on-stick / body) and written with the default
+    skin distances.  Unknown labels are skipped with an error message."""
+    all_marker_vids, marker_type_labels = _marker_vid_tables()
+    if separate_types is None:
+        separate_types = ['body', 'face', 'finger']
+    assert surface_model_type in all_marker_vids, \
+        ValueError(f'No suitable database of labels found for surface_model_type: {surface_model_type}')
+    mean_dist_from_skin = {'wrist': 0.039, 'body': 0.0095, 'face': 0.0002, 'finger_right': 0.0002, 'finger_left': 0.0002}
+    has_face = surface_model_type in ['smplx', 'flame'] and 'face' in separate_types
+    has_finger = surface_model_type in ['smplh', 'smplx', 'mano'] and 'finger' in separate_types
+    has_body = surface_model_type not in ['mano', 'flame']
+    unique_labels = list(set(labels_map.get(l, l) for l in chosen_markers))
+    marker_vids, unknown = {}, []
+    for l in sorted(unique_labels):
+        if l not in all_marker_vids[surface_model_type]:
+            unknown.append(l)
+            continue
+        marker_vids[l] = all_marker_vids[surface_model_type][l]
+    if unknown:
+        logger.error(f'Unknown marker label(s) for surface_model_type {surface_model_type} skipped: {unknown}.')
+    n = len(marker_vids)
+    mask = {}
+    if has_face:
+        mask['face'] = np.zeros(n, dtype=bool)
+    if has_finger:
+        mask['finger_left'] = np.zeros(n, dtype=bool)
+        mask['finger_right'] = np.zeros(n, dtype=bool)
+    if has_body:
+        mask['body'] = np.zeros(n, dtype=bool)
+    if wrist_markers_on_stick:
+        mask['wrist'] = np.zeros(n, dtype=bool)
+    for i, l in enumerate(marker_vids):
+        if has_face and l in marker_type_labels['face']:
+            mask['face'][i] = True
+        elif has_finger and l in marker_type_labels['finger_left']:
+            mask['finger_left'][i] = True
+        elif has_finger and l in marker_type_labels['finger_right']:
+            mask['finger_right'][i] = True
+        elif wrist_markers_on_stick and l in marker_type_labels['wrist']:
+            mask['wrist'][i] = True
+        elif has_body:
+            mask['body'][i] = True
+        else:
+            raise ValueError(f'Marker {l} could not be assigned to any marker type.')
+    marker_layout_write({'marker_vids': marker_vids, 'marker_type_mask': {k: v for k, v in mask.items() if v.sum() != 0},
+                         'm2b_distance': {k: mean_dist_from_skin[k] for k, v in mask.items() if v.sum() != 0},
+                         'surface_model_type': surface_model_type}, marker_layout_fname)
+    logger.info(f'Created marker layout: {marker_layout_fname}')
+    return True

@@ -140,6 +140,16 @@ def run_stagei(cfg, stagei_mocap_fnames, stagei_fname=None, mosh_stagei_func=Non
     if mosh_stagei_func is None:
         from .chmosh import mosh_stagei as mosh_stagei_func
     stagei_frames, stagei_fnames = prepare_stagei_frames(cfg, stagei_mocap_fnames)
+    layout_fname = cfg.dirs.marker_layout.fname
+    if layout_fname and not isinstance(layout_fname, dict) and not osp.exists(layout_fname):      # mosh_head.py:227-236
+        from .marker_layout import marker_labels_to_marker_layout
+        from .mocap_interface import general_labels_map
+        logger.debug(f'Marker layout not available. It will be produced: {layout_fname}')
+        marker_labels_to_marker_layout(chosen_markers=[l for fr in stagei_frames for l in fr.keys()],
+                                       marker_layout_fname=layout_fname, surface_model_type=cfg.surface_model.type,
+                                       labels_map=general_labels_map,
+                                       wrist_markers_on_stick=cfg.moshpp.get('wrist_markers_on_stick', False),
+                                       separate_types=cfg.moshpp.get('separate_types'))
     logger.info(f'Attempting mosh stagei to create {stagei_fname}')
     tm = time.time()
     stagei_data = mosh_stagei_func(stagei_frames=stagei_frames, cfg=cfg, betas_fname=cfg.moshpp.get('betas_fname'),
@@ -156,6 +166,23 @@ def run_stagei(cfg, stagei_mocap_fnames, stagei_fname=None, mosh_stagei_func=Non
         logger.debug(f'created stagei_fname: {stagei_fname}')
     logger.debug(f'finished mosh stagei in {timedelta(seconds=elapsed)}')
     return stagei_data
+
+
+def run_moshpp_once(cfg, stagei_mocap_fnames=None):
+    """The two-stage pipeline of the reference's `run_moshpp_once` (mosh_head.py:584-606) on the libmoshii drop-ins: Stage-I
+    (load-or-run, pickled to cfg.dirs.stagei_fname) then, unless cfg.runtime.stagei_only, Stage-II of cfg.mocap.fname
+    (cfg.dirs.stageii_fname).  `stagei_mocap_fnames`: the captures Stage-I picks its frames from (default:
+    cfg.moshpp.stagei_frame_picker.stagei_mocap_fnames, else the capture itself -- the reference's per-sequence mode)."""
+    fnames = stagei_mocap_fnames or cfg.moshpp.stagei_frame_picker.get('stagei_mocap_fnames') or [cfg.mocap.fname]
+    stagei = run_stagei(cfg, list(fnames), stagei_fname=cfg.dirs.get('stagei_fname'))
+    logger.debug('Final mosh stagei loss: {}'.format(' | '.join(
+        f'{k} = {np.sum(v):2.2e}' for k, v in stagei['stagei_debug_details']['stagei_errs'].items())))
+    if cfg.runtime.get('stagei_only', False):
+        return stagei, None
+    stageii = run_stageii(stagei, cfg, stageii_fname=cfg.dirs.get('stageii_fname'))
+    logger.debug('Final mosh stageii loss: {}'.format(' | '.join(
+        f'{k} = {np.sum(np.asarray(v) ** 2):2.2e}' for k, v in stageii['stageii_debug_details']['stageii_errs'].items())))
+    return stagei, stageii
 
 
 _STAGEI_NPZ_KEYS = ('gender', 'surface_model_type', 'markers_latent', 'latent_labels', 'markers_latent_vids', 'betas',

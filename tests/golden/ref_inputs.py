@@ -203,3 +203,14 @@ def surface_inputs():
     base = v[rng.integers(0, len(v), 60)]
     pts = base + rng.normal(0, 0.02, base.shape)
     return dict(v=v, f=f, pts=pts, signed_sq=np.concatenate([rng.normal(0, 1e-3, 20), [0.0]]))
+
+
+def layout_creation_inputs():
+    """Label lists as a capture would give them (vendor spellings, unknown labels, duplicates) -> marker_labels_to_marker_layout."""
+    body = ['C7', 'LFHD', 'RFHD', 'T10', 'STRN', 'CLAV', 'LSHO', 'RSHO', 'LeftShoulder', 'RWRA', 'RWRB', 'LWRA', 'LWRB', 'FOO', 'C7']
+    hands = ['LIDX3', 'LTHM3', 'RIDX3', 'RPNK3']
+    face = ['ARIEL', 'LFHD']
+    return {'smplh_body': (body, 'smplh', {}),
+            'smplh_hands': (body + hands, 'smplh', {}),
+            'smplx_face_wrist': (body + hands + face, 'smplx', dict(wrist_markers_on_stick=True)),
+            'smpl_no_split': (body + hands, 'smpl', dict(separate_types=['body']))}

@@ -237,3 +237,14 @@ def test_surface_distance_derivatives_match_compiled_reference_header():
         assert np.abs(g[0] - 2 * dist[i] * dp[i]).max() < 1e-12
         assert np.abs(np.array(g[1:]) - 2 * dist[i] * dabc[i]).max() < 1e-12
     assert {0} < seen and len(seen) >= 3
+
+
+@pytest.mark.parametrize('case', ['smplh_body', 'smplh_hands', 'smplx_face_wrist', 'smpl_no_split'])
+def test_marker_layout_creation_matches_reference_functions(case, tmp_path):
+    """moshpp_amd.marker_layout.marker_labels_to_marker_layout (+ marker_layout_write, + the shipped label / type tables) against the
+    reference's two functions executed on the same label lists: the json files are identical text."""
+    from moshpp_amd.marker_layout import marker_labels_to_marker_layout
+    labels_in, mtype, kw = ref_inputs.layout_creation_inputs()[case]
+    fn = str(tmp_path / 'layout.json')
+    marker_labels_to_marker_layout(labels_in, fn, mtype, **kw)
+    assert open(fn).read() == str(G[f'mklayout_{case}'])

@@ -125,6 +125,7 @@ def test_mosh_stagei_host_path_on_cpu(tmp_path, monkeypatch):
     """The drop-in `mosh_stagei` (files in, dict out) with libmoshii's entry points replaced by the emulation build + oracle LBS:
     exercises the host code (layout, cfg switches, frame packing, weights, output dict) without a GPU."""
     import json
+    import os
     import pickle
     from moshpp_amd import capi, chmosh, synth
     from moshpp_amd.cfg import make_cfg
@@ -188,6 +189,25 @@ def test_mosh_stagei_host_path_on_cpu(tmp_path, monkeypatch):
     assert fit < 5e-3
     assert set(res['markers_latent_vids']) == set(labels) and set(dbg['markers_latent_all_vids']) <= set(labels)
     pickle.dumps(res)
+    # the pipeline driver: Stage-I frames picked from a capture, pickled, re-loaded on the second call
+    from moshpp_amd.mosh_head import run_moshpp_once
+    F, N = 30, 20
+    cap = np.zeros((F, N, 3))
+    rng = np.random.default_rng(2)
+    for t in range(F):
+        ids, obs = pb['frames'][t % 3]
+        cap[t] = np.nan
+        cap[t, ids] = obs + rng.normal(0, 1e-4, obs.shape)
+    np.savez(tmp_path / 'capture.npz', markers=cap * 1000.0, labels=np.array(labels), frame_rate=120.0)
+    cfg.mocap.fname = str(tmp_path / 'capture.npz')
+    cfg.dirs.stagei_fname = str(tmp_path / 'res' / 'stagei.pkl')
+    cfg.runtime.stagei_only = True
+    cfg.moshpp.stagei_frame_picker.num_frames = 3
+    cfg.moshpp.stagei_frame_picker.least_avail_markers = 0.5
+    st1, st2 = run_moshpp_once(cfg)
+    assert st2 is None and os.path.exists(cfg.dirs.stagei_fname) and len(st1['stagei_debug_details']['stagei_fnames']) == 3
+    st1b, _ = run_moshpp_once(cfg)
+    assert np.array_equal(st1b['markers_latent'], st1['markers_latent'])       # loaded, not re-solved
     # optimize_betas = false with given betas: they are kept, no beta term
     np.savez(tmp_path / 'betas.npz', betas=np.array([0.5, -0.3, 0.2, 0.1]))
     cfg.moshpp.optimize_betas = False
