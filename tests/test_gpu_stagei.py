@@ -38,6 +38,10 @@ def test_stagei_matches_oracle(fingers):
     assert np.abs(out['markers_latent'] - ref['markers_latent']).max() < 1e-6      # metres
     assert np.abs(out['pose'] - ref['pose']).max() < 1e-5 and np.abs(out['trans'] - ref['trans']).max() < 1e-6
     assert (out['markers_latent_vids'] == ref['markers_latent_vids']).all()
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stagei_golden.npz'))      # committed oracle output
+    gname = 'fingers' if fingers else 'body'
+    assert np.abs(out['betas'] - G[f'{gname}_betas']).max() < 1e-5 and np.abs(out['markers_latent'] - G[f'{gname}_markers_latent']).max() < 1e-6
     e = ref['errs']
     want = dict(data=e['data'], poseB=e['poseB'], init=e['init_0'], beta=e['beta'], surf=e['surf'], poseH=e.get('poseH', 0.0))
     for k, v in want.items():

@@ -213,3 +213,17 @@ def test_mosh_stagei_host_path_on_cpu(tmp_path, monkeypatch):
     cfg.moshpp.optimize_betas = False
     res2 = chmosh.mosh_stagei(frames, cfg, betas_fname=str(tmp_path / 'betas.npz'))
     assert np.allclose(res2['betas'][:4], [0.5, -0.3, 0.2, 0.1]) and 'beta' not in res2['stagei_debug_details']['stagei_errs']
+
+
+@pytest.mark.parametrize('name', ['body', 'fingers'])
+def test_oracle_reproduces_committed_stagei_golden(name):
+    """tests/golden/stagei_golden.npz (tests/golden/make_stagei_golden.py): the oracle's Stage-I solution is pinned against drift."""
+    import os
+    from tests.golden.make_stagei_golden import CASES
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stagei_golden.npz'))
+    kw, fingers = CASES[name]
+    c = helpers.stagei_case(**kw)
+    ref = s1.stagei_solve(c['m'], c['faces'], c['prior'], 'smplh', c['frames'], c['vids'], c['mask'], c['m2b'], c['nb'],
+                          optimize_fingers=fingers)
+    assert np.abs(ref['betas'] - G[f'{name}_betas']).max() < 1e-9 and np.abs(ref['markers_latent'] - G[f'{name}_markers_latent']).max() < 1e-10
+    assert np.abs(ref['pose'] - G[f'{name}_pose']).max() < 1e-9 and (ref['markers_latent_vids'] == G[f'{name}_markers_latent_vids']).all()
