@@ -1,102 +1,118 @@
-"""Stage-I frame pickers: src/moshpp/frame_picker.py:43-213 with the same NumPy legacy-RNG call sequence, so that a seed picks the
-same frames as the reference does.  Each returns (frames, names): an object array of per-frame `label -> xyz` dicts
-(`MocapSession.markers_asdict()` entries) and the `<file>_<frame:06d>` keys."""
+"""Stage-I frame pickers.
+
+Behavioural mirror of the reference's three pickers (src/moshpp/frame_picker.py:43-213).  What has to agree is WHICH frames a seed
+picks, so each picker consumes NumPy's legacy global RNG in the reference's order (`choice` per file, then `seed` + `shuffle` for
+"random"; `seed` first, then a permutation per file and a final `choice` for "random_strict"); the tests replay the reference's own
+functions on the same files and compare the picks (tests/test_ref_golden.py).
+
+All pickers return `(frames, keys)`: an object array of per-frame `{label: xyz}` dicts (entries of `MocapSession.markers_asdict()`)
+and the matching `<file>_<index:06d>` keys.
+"""
 from __future__ import annotations
 
-import os.path as osp
+import os
 
 import numpy as np
 
 from .mocap_interface import MocapSession
 
+_POOL_LIMIT = 100      # the reference stops opening further files once the pool holds more frames than this
 
-def _obj_array(items):
-    a = np.empty(len(items), dtype=object)
-    for i, it in enumerate(items):
-        a[i] = it
-    return a
+
+def _as_object_array(seq):
+    arr = np.empty(len(seq), dtype=object)
+    arr[:] = list(seq) if len(seq) != 1 else [seq[0]]
+    return arr
+
+
+def _session(fname, unit, rotate, subjects, only, exclude, aliases):
+    return MocapSession(mocap_fname=fname, mocap_unit=unit, mocap_rotate=rotate, only_subjects=subjects, only_markers=only,
+                        exclude_markers=exclude, labels_map=aliases)
+
+
+def _named_markers_present(frame):
+    """Labels of a frame dict that carry a finite sample and are not anonymous ('*...')."""
+    return sum(1 for label, xyz in frame.items() if '*' not in label and not np.any(np.isnan(xyz)))
 
 
 def load_marker_sessions_manual(mocap_fnames, mocap_unit, mocap_rotate=None, only_subjects=None, only_markers=None,
                                 exclude_markers=None, labels_map={}):
-    """names are /path/to/mocap_<frame number>.<ext> split at the last underscore (:48-66)."""
-    frames, names = [], []
-    for frame in mocap_fnames:
-        parts = frame.split('_')
-        fname, fid = '_'.join(parts[:-1]), int(parts[-1])
-        assert osp.exists(fname), FileNotFoundError(fname)
-        names.append(f'{fname}_{fid:06d}')
-        frames.append(MocapSession(mocap_fname=fname, mocap_unit=mocap_unit, only_subjects=only_subjects, mocap_rotate=mocap_rotate,
-                                   only_markers=only_markers, exclude_markers=exclude_markers,
-                                   labels_map=labels_map).markers_asdict()[fid])
-    return _obj_array(frames), np.array(names)
+    """Explicit picks: every entry is `<capture path>_<frame number>` (split at the LAST underscore)."""
+    keys, picked = [], []
+    for entry in mocap_fnames:
+        path, _, number = entry.rpartition('_')
+        if not os.path.exists(path):
+            raise AssertionError(FileNotFoundError(path))
+        index = int(number)
+        keys.append('%s_%06d' % (path, index))
+        picked.append(_session(path, mocap_unit, mocap_rotate, only_subjects, only_markers, exclude_markers,
+                               labels_map).markers_asdict()[index])
+    return _as_object_array(picked), np.array(keys)
 
 
 def load_marker_sessions_random(mocap_fnames, mocap_unit, mocap_rotate=None, num_frames=12, only_subjects=None, seed=None,
                                 least_avail_markers=.1, only_markers=None, exclude_markers=None, labels_map={}):
-    """:71-146.  Per file `num_frames` frames drawn with replacement BEFORE the seed is applied (the seed only fixes the
-    shuffle), keys numbered by draw order; frames with too few usable markers are skipped; the threshold is lowered by 0.01 and
-    the whole procedure repeated (without `exclude_markers`, as the reference's recursive call does) until enough are found."""
-    pool = {}
-    for fname in mocap_fnames:
-        mocap = MocapSession(mocap_fname=fname, mocap_unit=mocap_unit, mocap_rotate=mocap_rotate, only_subjects=only_subjects,
-                             only_markers=only_markers, exclude_markers=exclude_markers, labels_map=labels_map)
-        fmd = mocap.markers_asdict()
-        fmd = [fmd[i] for i in np.random.choice(len(mocap), num_frames)]
-        for fidx in range(len(fmd)):
-            pool[f'{fname}_{fidx:06d}'] = fmd[fidx]
-        if len(pool) > 100:
-            break
-    idxs = list(range(len(pool)))
-    if seed is not None:
-        np.random.seed(seed=seed)
-    np.random.shuffle(idxs)
-    all_frames, all_names = list(pool.values()), list(pool.keys())
-    frames, names = [], []
-    for idx in idxs:
-        frame = all_frames[idx]
-        nonans = [k for k in frame.keys() if ~np.any(np.isnan(frame[k])) and ('*' not in k)]
-        if len(nonans) >= (least_avail_markers * len(frame)):
-            names.append(all_names[idx]); frames.append(frame)
-        if len(frames) >= num_frames:
-            break
-    if len(frames) < num_frames:
-        least_avail_markers = least_avail_markers - 0.01
-        if least_avail_markers < 0.01:
-            raise ValueError(f'Not enough frames were found that have at least %{least_avail_markers * 100.:.1f} of the markers.\n')
-        return load_marker_sessions_random(mocap_fnames, mocap_unit=mocap_unit, mocap_rotate=mocap_rotate, seed=seed,
-                                           num_frames=num_frames, only_subjects=only_subjects,
-                                           least_avail_markers=least_avail_markers, only_markers=only_markers, labels_map=labels_map)
-    return _obj_array(frames), np.array(names)
+    """`num_frames` draws WITH replacement from every capture (made before the seed is applied -- the seed only fixes the shuffle),
+    keyed by draw order; the shuffled pool is scanned for frames whose named, finite markers make up at least
+    `least_avail_markers` of the frame.  If too few qualify the threshold drops by 0.01 and everything is redone (the retry does
+    not pass `exclude_markers` on, as in the reference); below 0.01 it gives up."""
+    threshold = least_avail_markers
+    drop_excluded = exclude_markers
+    while True:
+        pool = {}
+        for fname in mocap_fnames:
+            session = _session(fname, mocap_unit, mocap_rotate, only_subjects, only_markers, drop_excluded, labels_map)
+            per_frame = session.markers_asdict()
+            for slot, src in enumerate(np.random.choice(len(session), num_frames)):
+                pool['%s_%06d' % (fname, slot)] = per_frame[src]
+            if len(pool) > _POOL_LIMIT:
+                break
+        order = list(range(len(pool)))
+        if seed is not None:
+            np.random.seed(seed=seed)
+        np.random.shuffle(order)
+        names, frames = list(pool.keys()), list(pool.values())
+        keep = []
+        for idx in order:
+            if _named_markers_present(frames[idx]) >= threshold * len(frames[idx]):
+                keep.append(idx)
+            if len(keep) >= num_frames:
+                break
+        if len(keep) >= num_frames:
+            return _as_object_array([frames[i] for i in keep]), np.array([names[i] for i in keep])
+        threshold = threshold - 0.01
+        drop_excluded = None
+        if threshold < 0.01:
+            raise ValueError(f'Not enough frames were found that have at least %{threshold * 100.:.1f} of the markers.\n')
 
 
 def load_marker_sessions_random_strict(mocap_fnames, mocap_unit, mocap_rotate=None, num_frames=12, only_subjects=None, seed=None,
                                        least_avail_markers=.1, only_markers=None, exclude_markers=None, labels_map={}):
-    """:149-213.  Seeded first; per file a random permutation of the frames, taking up to `num_frames` whose share of valid
-    markers reaches the threshold; then `num_frames` of the pool without replacement.  Raises when the pool is too small."""
+    """Seeded from the start.  Per capture: walk a random permutation of its frames and take up to `num_frames` whose share of
+    valid samples reaches `least_avail_markers` (never lowered); finally `num_frames` of the pool, drawn without replacement."""
     np.random.seed(seed=seed)
-    assert 0.1 <= least_avail_markers <= 1.0
+    if not 0.1 <= least_avail_markers <= 1.0:
+        raise AssertionError(least_avail_markers)
     pool = {}
     for fname in mocap_fnames:
-        mocap = MocapSession(mocap_fname=fname, mocap_unit=mocap_unit, mocap_rotate=mocap_rotate, only_markers=only_markers,
-                             only_subjects=only_subjects, exclude_markers=exclude_markers, labels_map=labels_map)
-        if not mocap.read_status:
+        session = _session(fname, mocap_unit, mocap_rotate, only_subjects, only_markers, exclude_markers, labels_map)
+        if not session.read_status:
             continue
-        avail = MocapSession.marker_availability_mask(mocap.markers)
-        avail = avail.sum(-1) / avail.shape[1]
-        frames = mocap.markers_asdict()
-        n_picks = 0
-        for fidx in np.random.choice(len(frames), len(frames), replace=False):
-            if avail[fidx] >= least_avail_markers:
-                pool[f'{fname}_{fidx:06d}'] = frames[fidx]
-                n_picks += 1
-            if n_picks >= num_frames:
+        valid = MocapSession.marker_availability_mask(session.markers)
+        share = valid.sum(-1) / valid.shape[1]
+        per_frame = session.markers_asdict()
+        taken = 0
+        for src in np.random.choice(len(per_frame), len(per_frame), replace=False):
+            if share[src] >= least_avail_markers:
+                pool['%s_%06d' % (fname, src)] = per_frame[src]
+                taken += 1
+            if taken >= num_frames:
                 break
-        if len(pool) > 100:
+        if len(pool) > _POOL_LIMIT:
             break
     if len(pool) < num_frames:
         raise ValueError(f'Not enough frames were found that have at least {least_avail_markers * 100.:.1f}% of the markers.\n'
-                         f'either try moshpp.stagei_frame_picker.type: random or set '
-                         f'moshpp.stagei_frame_picker.least_avail_markers to lower number in ange [0.1,1.0].')
-    ids = np.random.choice(len(pool), num_frames, replace=False)
-    return _obj_array(list(pool.values()))[ids], np.array(list(pool.keys()))[ids]
+                         f'Use moshpp.stagei_frame_picker.type: random, or lower moshpp.stagei_frame_picker.least_avail_markers '
+                         f'(range [0.1, 1.0]).')
+    chosen = np.random.choice(len(pool), num_frames, replace=False)
+    return _as_object_array(list(pool.values()))[chosen], np.array(list(pool.keys()))[chosen]
