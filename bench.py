@@ -176,7 +176,8 @@ def main():
             'residual_evals_per_frame': round(float(iters[solved_mask, 1].sum()) / max(solved, 1), 3), 'lds_bytes': lds,
         }
         # ---- the literal frame order on one workgroup, and the timed mode's deviation from it over all frames
-        if args.mode == 'chunked' and not args.no_sequential:
+        extras = world == 1     # the reference / spread / CPU / Stage-I legs run at N = 1 only: at N > 1 the other ranks would idle at the barrier
+        if extras and args.mode == 'chunked' and not args.no_sequential:
             dsq = workload.DeviceSequence(job, solver, dev)
             stream = torch.cuda.current_stream().cuda_stream
             torch.cuda.synchronize()
@@ -197,7 +198,7 @@ def main():
             del dsq
         # ---- the same kernel with the chip full: 32 copies of the sequence in one call (BASELINE config[2] shape: many
         # sequences per GPU).  8 chunks per sequence, so warm-up is 7 % of the work and every CU carries a chain.
-        if args.many > 0:
+        if extras and args.many > 0:
             try:
                 copies = [workload.DeviceSequence(job, solver, dev) for _ in range(args.many)]
                 stream = torch.cuda.current_stream().cuda_stream
@@ -222,7 +223,7 @@ def main():
                 result['many_sequences'] = {'error': repr(e)}
         # ---- the same workload from other seeds: the chunk-repair pattern depends on the motion (how long the regions are in
         # which a fresh start sits in another basin), so the headline seed is not the whole story
-        if args.mode == 'chunked' and args.spread_seeds:
+        if extras and args.mode == 'chunked' and args.spread_seeds:
             spread = {}
             try:
                 for sd in [int(x) for x in args.spread_seeds.split(',') if x.strip()]:
@@ -278,7 +279,7 @@ def main():
         except Exception as e:   # the LBS leg must never take the headline number down
             result['roofline_lbs'] = {'error': repr(e)}
         # ---- CPU baseline: the NumPy oracle ("port") on a bounded sample of the same workload; parity on that sample
-        if not args.no_cpu:
+        if extras and not args.no_cpu:
             from oracle import stageii_oracle as so
             S = min(args.cpu_sample, F)
             seq = job['seq']
@@ -320,7 +321,7 @@ def main():
             result['speedup_vs_cpu_port'] = round(value / max(n_ref / tc, 1e-9), 1)
         # ---- Stage-I leg (BASELINE config 4's calibration part): 12 picked frames, 53 markers, 10 betas on a
         #      triangulated SMPL-H-sized body; the joint solve on the GPU beside the NumPy oracle on the host
-        if not args.no_stagei:
+        if extras and not args.no_stagei:
             try:
                 from moshpp_amd import capi
                 pb1, dev1, pr1, kw1 = workload.make_stagei_job()
