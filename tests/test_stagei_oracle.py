@@ -227,3 +227,51 @@ def test_oracle_reproduces_committed_stagei_golden(name):
                           optimize_fingers=fingers)
     assert np.abs(ref['betas'] - G[f'{name}_betas']).max() < 1e-9 and np.abs(ref['markers_latent'] - G[f'{name}_markers_latent']).max() < 1e-10
     assert np.abs(ref['pose'] - G[f'{name}_pose']).max() < 1e-9 and (ref['markers_latent_vids'] == G[f'{name}_markers_latent_vids']).all()
+
+
+def test_closest_point_on_triangle_properties():
+    """The exhaustive nearest-triangle search the oracle restates (psbody's aabbtree_nearest): the returned point lies in the triangle,
+    no sampled point of the triangle is closer, and the part code agrees with where the point sits (interior / edge / vertex)."""
+    rng = np.random.default_rng(0)
+    n = 400
+    a, b, c = rng.normal(0, 1, (3, n, 3))
+    p = rng.normal(0, 1.5, (n, 3))
+    q, part = s1._closest_on_triangles(p, a, b, c)
+    # barycentric coordinates of q
+    T = np.stack([b - a, c - a], axis=2)                      # n,3,2
+    uv = np.array([np.linalg.lstsq(T[i], (q - a)[i], rcond=None)[0] for i in range(n)])
+    u, v = uv[:, 0], uv[:, 1]
+    w = 1 - u - v
+    assert (u > -1e-9).all() and (v > -1e-9).all() and (w > -1e-9).all()
+    assert np.abs(a + u[:, None] * (b - a) + v[:, None] * (c - a) - q).max() < 1e-9
+    tol = 1e-9
+    zero = np.stack([w < tol, u < tol, v < tol], axis=1)      # weight of a, b, c vanishes
+    # part codes: 0 interior; 1 ab (c-weight 0), 2 bc (a-weight 0), 3 ca (b-weight 0); 4 a, 5 b, 6 c
+    expect = {0: (False, False, False), 1: (False, False, True), 2: (True, False, False), 3: (False, True, False),
+              4: (False, True, True), 5: (True, False, True), 6: (True, True, False)}
+    for i in range(n):
+        assert tuple(zero[i]) == expect[int(part[i])], (i, part[i], zero[i])
+    assert set(part.tolist()) == set(range(7))
+    # no point of a dense barycentric sampling is closer
+    g = np.linspace(0, 1, 41)
+    uu, vv = np.meshgrid(g, g)
+    keep = uu + vv <= 1
+    uu, vv = uu[keep], vv[keep]
+    samples = a[:, None, :] + uu[None, :, None] * (b - a)[:, None, :] + vv[None, :, None] * (c - a)[:, None, :]
+    dmin = np.sqrt(((samples - p[:, None, :]) ** 2).sum(-1)).min(1)
+    assert (np.sqrt(((q - p) ** 2).sum(1)) <= dmin + 1e-12).all()
+
+
+def test_nearest_on_mesh_equals_unpruned_search(case):
+    """The candidate pruning of nearest_on_mesh (triangles with a vertex within d_nearest_vertex + longest edge) never changes the result."""
+    m = case['m']
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3), None, shp=np.zeros(case['nb']))
+    f = case['faces']
+    rng = np.random.default_rng(4)
+    pts = can[rng.integers(0, len(can), 25)] + rng.normal(0, 0.03, (25, 3))
+    tri, part, near = s1.nearest_on_mesh(pts, can, f)
+    a, b, c = can[f[:, 0]], can[f[:, 1]], can[f[:, 2]]
+    for i, p in enumerate(pts):
+        q, pc = s1._closest_on_triangles(np.broadcast_to(p, (len(f), 3)), a, b, c)
+        k = int(np.argmin(((q - p) ** 2).sum(1)))
+        assert k == tri[i] and pc[k] == part[i] and np.array_equal(q[k], near[i])
