@@ -155,12 +155,34 @@ class StageIISolver:
             return out
         if chain_mode == 'chunked':
             if self.n_shape:
-                raise NotImplementedError('chunked mode does not carry free shape coefficients across chunk hand-offs; '
-                                          "use chain_mode='sequential' with optimize_face / optimize_dynamics")
+                raise NotImplementedError('moshii_sequence_solve does not carry free shape coefficients across chunk hand-offs; '
+                                          "use chain_mode='chunked_host' (host-driven chunks) or 'sequential' with optimize_face / optimize_dynamics")
             outs, report = capi.sequence_solve_host(self.dev, self.prior, self.opts, [dict(attach=self.attach, obs=obs, vis=vis, **ikw)],
                                                     num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol)
             outs[0]['chunk_report'] = report
             return outs[0]
+        if chain_mode == 'chunked_host':
+            # the chunk scheme driven from the host over ONE batched moshii_chain_solve per round (parallel.solve_sequence_chunked_host):
+            # also carries the free shape coefficients across the hand-offs, which moshii_sequence_solve does not
+            from .parallel import solve_sequence_chunked_host
+            if init is not None:
+                raise NotImplementedError("chain_mode='chunked_host' starts at the first frame")
+
+            def solve_ranges(items):
+                chains = []
+                for a, b, st in items:
+                    ch = dict(attach=self.attach, obs=obs[a:b], vis=vis[a:b], first=st is None)
+                    if st is not None:
+                        ch.update(init_pose=st['pose'], init_trans=st['trans'], init_pose_prev=st['pose_prev'])
+                        if self.n_shape:
+                            ch['init_shape'] = st['shape']
+                    chains.append(ch)
+                return capi.chain_solve_host(self.dev, self.prior, self.opts, chains)
+            keys = ('pose', 'trans', 'shape') if self.n_shape else ('pose', 'trans')
+            out, info = solve_sequence_chunked_host(solve_ranges, F, num_chunks or 64, warmup=chunk_warmup, verify_tol=verify_tol,
+                                                    state_keys=keys)
+            out['chunk_report'] = info
+            return out
         raise ValueError(f'unknown chain_mode {chain_mode}')
 
 

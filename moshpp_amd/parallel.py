@@ -161,3 +161,69 @@ def stagei_solve_sharded(solve, n_frames, dist):
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = frame_ranges(n_frames, world)[rank]
     return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce(dist))
+
+
+# ---- one sequence as concurrent chunks, stitched on the host (for chain variants moshii_sequence_solve does not cover) --------
+def solve_sequence_chunked_host(solve_ranges: Callable, F: int, n_chunks: int, warmup: int = 32, verify_tol: float = 1e-9,
+                                max_rounds: int = None, state_keys=('pose', 'trans')):
+    """The chunk scheme of moshii_sequence_solve driven from the host over a batched chain solve -- for the extended chain
+    variant (free expression / DMPL coefficients), whose extra state moshii_sequence_solve does not hand over.
+
+    solve_ranges([(a, b, init), ...]) -> [out, ...] solves all listed frame ranges concurrently (one chain each, one
+    moshii_chain_solve call); init = None (first-frame schedule) or the dict `edge_state` returns.  Every out holds per-frame
+    arrays incl. 'pose', 'trans', 'status' and whatever `state_keys` names (e.g. 'shape').
+      pass 1   chunk c > 0 starts `warmup` frames early with the first-frame schedule; the warm-up rows are discarded.
+      verify   the state with which chunk c entered its first frame (from its own warm-up) against the end state of chunk c-1.
+      repair   every chunk whose hand-off misses is re-solved from its left neighbour's end state; all such chunks of a round run
+               concurrently; repeated until every hand-off verifies (a fix-point: at most n_chunks - 1 rounds).
+    Returns (out over frames [0, F), info = dict(n_chunks, rounds, repaired=[chunks per round], max_handoff_dev))."""
+    import numpy as np
+    C = max(1, min(int(n_chunks), F // 2 if F >= 4 else 1))
+    ranges = frame_ranges(F, C)
+
+    def edge_state(res, upto):
+        st = res.get('status')
+        ok = np.arange(upto) if st is None else np.flatnonzero(np.asarray(st[:upto]) != 1)
+        if len(ok) < 2:
+            return None
+        i, j = int(ok[-1]), int(ok[-2])
+        s = dict(pose=np.array(res['pose'][i]), pose_prev=np.array(res['pose'][j]), trans=np.array(res['trans'][i]))
+        for k in state_keys:
+            if k not in ('pose', 'trans'):
+                s[k] = np.array(res[k][i])
+        return s
+
+    def deviation(x, y):
+        return max(float(np.max(np.abs(np.asarray(x[k]) - np.asarray(y[k])))) if np.size(x[k]) else 0.0 for k in x)
+
+    leads = [0] + [min(warmup, a) for a, _ in ranges[1:]]
+    first = solve_ranges([(a - l, b, None) for (a, b), l in zip(ranges, leads)])
+    entries = [None] + [edge_state(r, l) for r, l in zip(first[1:], leads[1:])]
+    outs = [{k: (v[l:] if hasattr(v, 'shape') and len(v) == (b - a + l) else v) for k, v in r.items()}
+            for r, l, (a, b) in zip(first, leads, ranges)]
+    rounds, repaired, max_dev = 0, [], 0.0
+    max_rounds = C if max_rounds is None else max_rounds
+    while True:
+        finals = [edge_state(o, b - a) for o, (a, b) in zip(outs, ranges)]
+        todo = []
+        for c in range(1, C):
+            if finals[c - 1] is None:
+                raise RuntimeError(f'chunk {c - 1} solved fewer than two frames: no state to hand over')
+            dev = float('inf') if entries[c] is None else deviation(entries[c], finals[c - 1])
+            if dev <= verify_tol:
+                max_dev = max(max_dev, dev)
+            else:
+                todo.append(c)
+        if not todo:
+            break
+        if rounds >= max_rounds:
+            raise RuntimeError(f'chunked solve did not converge: hand-offs still failing after {rounds} rounds')
+        redo = solve_ranges([(ranges[c][0], ranges[c][1], finals[c - 1]) for c in todo])
+        for c, r in zip(todo, redo):
+            outs[c] = r
+            entries[c] = {k: np.array(v) for k, v in finals[c - 1].items()}
+        repaired.append(list(todo))
+        rounds += 1
+    keys = [k for k, v in outs[0].items() if hasattr(v, 'shape') and len(v) == ranges[0][1] - ranges[0][0]]
+    out = {k: np.concatenate([o[k] for o in outs], axis=0) for k in keys}
+    return out, dict(n_chunks=C, rounds=rounds, repaired=repaired, max_handoff_dev=max_dev)

@@ -459,3 +459,30 @@ def test_gpu_matches_committed_shape_goldens(gpu_lib, name, mt, kind, E, F, M, s
     assert np.abs(out['shape'] - g[f'{name}/shape']).max() < 1e-6
     np.testing.assert_array_equal(out['iters'][:, 0], g[f'{name}/iters'])
     np.testing.assert_allclose(out['errs'][:, 5], g[f'{name}/err_shape'], rtol=1e-6)
+
+
+def test_host_level_chunks_carry_the_free_shape_block(gpu_lib):
+    """StageIISolver-style chain_mode='chunked_host' on the extended kernel (expression coefficients + jaw free): chunks solved
+    concurrently through ONE batched moshii_chain_solve per round, hand-offs verified on pose / trans / shape and repaired from the
+    left neighbour, equal to the sequential chain."""
+    from moshpp_amd import capi
+    from moshpp_amd.parallel import solve_sequence_chunked_host
+    from tests.helpers import shape_case
+    F = 96
+    case = shape_case('smplx', F=F, M=40, E=6, seed=9, kind='expr')
+    dev = device_case(case, optimize_face=True, shape_kind='expr')
+    seq = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+
+    def solve_ranges(items):
+        chains = []
+        for a, b, st in items:
+            ch = dict(attach=dev['attach'], obs=case['obs'][a:b], vis=case['vis'][a:b], first=st is None)
+            if st is not None:
+                ch.update(init_pose=st['pose'], init_trans=st['trans'], init_pose_prev=st['pose_prev'], init_shape=st['shape'])
+            chains.append(ch)
+        return capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], chains)
+    out, info = solve_sequence_chunked_host(solve_ranges, F, n_chunks=4, warmup=12, verify_tol=1e-9, state_keys=('pose', 'trans', 'shape'))
+    print(info)
+    assert info['n_chunks'] == 4
+    assert np.abs(out['fullpose'] - seq['fullpose']).max() < 1e-6 and np.abs(out['shape'] - seq['shape']).max() < 1e-6

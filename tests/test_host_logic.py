@@ -280,3 +280,55 @@ def test_frame_ranges_and_single_rank_sharded_solve():
     out, info = solve_sequence_sharded(solve_range, 37, dist=None)
     assert calls == [(0, 37, None)] and out['pose'].shape == (37, 5)
     assert info == dict(range=(0, 37), rounds=0, repaired=[], max_handoff_dev=0.0)
+
+
+def test_host_level_chunk_scheme_reproduces_the_sequential_chain():
+    """parallel.solve_sequence_chunked_host with a stand-in chain that carries an extra per-frame state ('shape', like the expression /
+    DMPL coefficients of the extended kernel): a fresh start that lands in another basin is detected at the hand-off and repaired from
+    the left neighbour's end state, a repair that changes a chunk's end state cascades to the right neighbour in the next round, and
+    the stitched result equals the sequential chain."""
+    from moshpp_amd.parallel import solve_sequence_chunked_host
+    F = 400
+
+    def tgt(g):
+        return np.array([np.sin(0.05 * g), np.cos(0.03 * g), 0.01 * g, 1.0])
+
+    def chain(a, b, init):
+        n = b - a
+        pose = np.zeros((n, 4)); shape = np.zeros((n, 2))
+        fresh = init is None
+        p1 = np.zeros(4) if fresh else np.array(init['pose'])
+        s1 = np.zeros(2) if fresh else np.array(init.get('shape', np.zeros(2)))
+        wrong = False
+        for t in range(n):
+            g = a + t
+            if fresh and t == 0 and 180 <= g <= 260:
+                wrong = True                                  # a fresh start in this stretch converges to another basin ...
+            if g > 300:
+                wrong = False                                 # ... which only merges with the right one at frame 301
+            off = np.array([0.4, 0, 0, 0]) if wrong else 0.0
+            p = tgt(g) + off + (0.02 if (fresh and t == 0) else 0.45 * (p1 - tgt(g - 1) - off))
+            s = 0.9 * s1 + 0.1 * np.array([np.sin(0.02 * g), 1.0]) if not (fresh and t == 0) else np.array([0.3, 0.3])
+            pose[t], shape[t] = p, s
+            p1, s1 = p, s
+        return dict(pose=pose, trans=pose[:, :3] * 0.1, shape=shape, status=np.zeros(n, dtype=np.int32))
+
+    calls = []
+
+    def solve_ranges(items):
+        calls.append([(a, b, init is not None) for a, b, init in items])
+        return [chain(a, b, init) for a, b, init in items]
+
+    # the slowly forgetting 'shape' state needs a long warm-up to verify at 1e-9 (0.9^n): with 32 frames EVERY hand-off misses on it
+    out, info = solve_sequence_chunked_host(solve_ranges, F, n_chunks=8, warmup=32, verify_tol=1e-9, state_keys=('pose', 'trans', 'shape'))
+    ref = chain(0, F, None)
+    assert np.abs(out['pose'] - ref['pose']).max() < 1e-8 and np.abs(out['shape'] - ref['shape']).max() < 1e-8
+    assert info['n_chunks'] == 8 and info['repaired'][0] == list(range(1, 8)) and info['rounds'] == 4     # the cascade dies out once
+    # the remaining difference of the shape state has decayed below the tolerance (0.9^n)
+    # a state that forgets quickly: only the wrong-basin chunk (start 200 - 32 = 168 ... fresh at 168 is outside 180..260; chunk 5
+    # starts fresh at 250 - 32 = 218, inside) is repaired
+    calls.clear()
+    out2, info2 = solve_sequence_chunked_host(solve_ranges, F, n_chunks=8, warmup=32, verify_tol=1e-9, state_keys=('pose', 'trans'))
+    assert np.abs(out2['pose'] - ref['pose']).max() < 1e-8
+    assert info2['repaired'] == [[5, 6], [6]], info2
+    assert all(not has_init for _, _, has_init in calls[0]) and all(has_init for _, _, has_init in calls[1])
