@@ -33,6 +33,8 @@ static int s1_bx, s1_by;
 #define SHARED static
 #define S1_TPB 1
 #define S1_CHOL_TPB 1
+#define DYN_LDS(name) static double name[S1_FSMAX * (S1_FSMAX + 1) + S1_FSMAX]
+#define LAUNCH_LDS(k, gx, gy, nt, bytes, stream, ...) LAUNCH(k, gx, gy, nt, stream, __VA_ARGS__)
 #define S1_VL 1
 #define S1_TRSM_TPB 1
 #define LAUNCH(k, gx, gy, nt, stream, ...) do { for (int _y = 0; _y < (int)(gy); ++_y) for (int _x = 0; _x < (int)(gx); ++_x) { s1_bx = _x; s1_by = _y; k(__VA_ARGS__); } } while (0)
@@ -48,12 +50,15 @@ static int s1_bx, s1_by;
 #define SHARED __shared__
 #define S1_TPB 256
 #define S1_CHOL_TPB 1024
+#define DYN_LDS(name) extern __shared__ double name[]
+#define LAUNCH_LDS(k, gx, gy, nt, bytes, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), bytes, stream, __VA_ARGS__)
 #define S1_TRSM_TPB 64
 #define S1_VL 64          // lanes that share one vertex's pose-corrective dot products
 #define LAUNCH(k, gx, gy, nt, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), 0, stream, __VA_ARGS__)
 #endif
 
 #define S1_NMAX 4096     // unknowns (one column of the factor is staged in LDS)
+#define S1_FSMAX 120     // per-frame unknowns the elimination kernel keeps in LDS (120 x 121 doubles = 116 KB)
 #define S1_NWMAX 16      // non-zero skinning weights per vertex the vertex kernel keeps in registers
 
 namespace {
@@ -1175,6 +1180,91 @@ KERNEL k_s1_tri_solve(const double* L, int n, const double* dinv, const double* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Arrow structure of the Stage-I normal equations (experimental solver, MOSHII_S1_SOLVER=schur): a frame's unknowns (trans, pose,
+// per-frame expressions) are coupled to other frames only through the shared block (latent markers, betas).  Per frame one
+// workgroup factors its diagonal block in LDS, inverts the factor in place and forms Y_f = L_f^{-1} A_fs, z_f = L_f^{-1} g_f; the
+// shared block is then solved on the Schur complement S = A_ss - sum_f Y_f^T Y_f (a few panels of the blocked Cholesky instead of
+// ~30), and every frame back-substitutes d_f = L_f^{-T} (z_f - Y_f d_s).
+// ---------------------------------------------------------------------------------------------------------------------------
+KERNEL k_s1_elim(const double* A, int n, const double* g, const int* fcols, int fs, const int* scols, int ns, int nsp,
+                 double* Linv, double* Y, double* z, int* status) {       // grid F, dynamic LDS (fs (fs + 1) + fs) doubles
+    DYN_LDS(lds);
+    const int f = BX, ld = fs + 1;
+    double* Lm = lds; double* tmp = lds + (size_t)fs * ld;
+    const int* fc = fcols + (size_t)f * fs;
+    for (int e = TID; e < fs * fs; e += NT) { int i = e / fs, j = e % fs; Lm[i * ld + j] = (j <= i) ? A[(size_t)fc[i] * n + fc[j]] : 0.0; }
+    SYNC();
+    for (int c = 0; c < fs; ++c) {                       // Cholesky, right-looking, in LDS
+        if (TID == 0) { double v = Lm[c * ld + c]; if (!(v > 0)) { status[1] = 1; v = 1.0; } Lm[c * ld + c] = sqrt(v); }
+        SYNC();
+        const double ip = 1.0 / Lm[c * ld + c];
+        for (int r = c + 1 + TID; r < fs; r += NT) Lm[r * ld + c] *= ip;
+        SYNC();
+        const int rem = fs - c - 1;
+        for (int e = TID; e < rem * rem; e += NT) {
+            int r = c + 1 + e / rem, k = c + 1 + e % rem;
+            if (k <= r) Lm[r * ld + k] -= Lm[r * ld + c] * Lm[k * ld + c];
+        }
+        SYNC();
+    }
+    for (int j = fs - 1; j >= 0; --j) {                  // in-place inverse of the lower factor (column by column, last first)
+        if (TID == 0) Lm[j * ld + j] = 1.0 / Lm[j * ld + j];
+        for (int i = j + 1 + TID; i < fs; i += NT) tmp[i] = Lm[i * ld + j];
+        SYNC();
+        const double ajj = Lm[j * ld + j];
+        for (int i = j + 1 + TID; i < fs; i += NT) {     // (trailing inverse) . column, trailing block already inverted
+            double sacc = 0;
+            for (int k = j + 1; k <= i; ++k) sacc += Lm[i * ld + k] * tmp[k];
+            Lm[i * ld + j] = -ajj * sacc;
+        }
+        SYNC();
+    }
+    double* Lg = Linv + (size_t)f * fs * fs;
+    for (int e = TID; e < fs * fs; e += NT) { int i = e / fs, j = e % fs; Lg[e] = (j <= i) ? Lm[i * ld + j] : 0.0; }
+    // Y_f = L^{-1} A_fs (+ the gradient as one more column -> z_f)
+    for (int e = TID; e < fs * (ns + 1); e += NT) {
+        int i = e / (ns + 1), c = e % (ns + 1);
+        double sacc = 0;
+        if (c < ns) { const int sc = scols[c]; for (int k = 0; k <= i; ++k) sacc += Lm[i * ld + k] * A[(size_t)fc[k] * n + sc]; }
+        else for (int k = 0; k <= i; ++k) sacc += Lm[i * ld + k] * g[fc[k]];
+        if (c < ns) Y[((size_t)f * fs + i) * nsp + c] = sacc; else z[(size_t)f * fs + i] = sacc;
+    }
+}
+
+// S = A_ss - T (T = Y^T Y from the tiled SYRK), h = g_s - Y^T z                                  grid ceil(ns / S1_TPB)
+KERNEL k_s1_schur_sub(const double* A, int n, const double* g, const int* scols, int ns, const double* T, const double* Y, int nsp,
+                      const double* z, int rows, double* S, double* h) {
+    int c = BX * NT + TID;
+    if (c >= ns) return;
+    const int sc = scols[c];
+    for (int k = 0; k < ns; ++k) S[(size_t)c * ns + k] = A[(size_t)sc * n + scols[k]] - T[(size_t)c * ns + k];
+    double sacc = 0;
+    for (int r = 0; r < rows; ++r) sacc += Y[(size_t)r * nsp + c] * z[r];
+    h[c] = g[sc] - sacc;
+}
+
+// d_f = L_f^{-T} (z_f - Y_f d_s), scattered into the full step; block 0 also scatters d_s                        grid F
+KERNEL k_s1_back(const int* fcols, int fs, const int* scols, int ns, int nsp, const double* Linv, const double* Y, const double* z,
+                 const double* ds, double* dfull) {
+    SHARED double w[S1_FSMAX];
+    const int f = BX;
+    for (int i = TID; i < fs; i += NT) {
+        const double* Yr = Y + ((size_t)f * fs + i) * nsp;
+        double sacc = z[(size_t)f * fs + i];
+        for (int c = 0; c < ns; ++c) sacc -= Yr[c] * ds[c];
+        w[i] = sacc;
+    }
+    SYNC();
+    const double* Lg = Linv + (size_t)f * fs * fs;
+    for (int k = TID; k < fs; k += NT) {
+        double sacc = 0;
+        for (int i = k; i < fs; ++i) sacc += Lg[(size_t)i * fs + k] * w[i];
+        dfull[fcols[(size_t)f * fs + k]] = sacc;
+    }
+    if (f == 0) for (int c = TID; c < ns; c += NT) dfull[scols[c]] = ds[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
 #ifdef S1_EMU
@@ -1316,6 +1406,18 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.r = pool.get<double>(R_max); p.Jm = pool.get<double>((size_t)R_max * ld_max);
     if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 4096 unknowns");
     double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max);
+    // experimental arrow-structured solver (off unless MOSHII_S1_SOLVER=schur)
+    const char* solver_env = getenv("MOSHII_S1_SOLVER");
+    const bool want_schur = solver_env && strcmp(solver_env, "schur") == 0 && !shard;
+    const int fs_max = 3 + npid_max + (d.per_frame ? nb : 0), ns_max = 3 * M + (d.per_frame ? 0 : nb), nsp_max = (ns_max + 15) & ~15;
+    int *d_fcols = nullptr, *d_scols = nullptr, *d_ones = nullptr;
+    double *d_Linv = nullptr, *d_Y = nullptr, *d_z = nullptr, *d_T = nullptr, *d_S = nullptr, *d_h = nullptr, *d_ds = nullptr;
+    if (want_schur) {
+        d_fcols = pool.get<int>((size_t)F * fs_max); d_scols = pool.get<int>(ns_max);
+        d_Linv = pool.get<double>((size_t)F * fs_max * fs_max); d_Y = pool.get<double>((size_t)F * fs_max * nsp_max); d_z = pool.get<double>((size_t)F * fs_max);
+        d_T = pool.get<double>((size_t)ns_max * ns_max); d_S = pool.get<double>((size_t)ns_max * ns_max); d_h = pool.get<double>(ns_max); d_ds = pool.get<double>(ns_max);
+        d_ones = pool.get<int>((size_t)((F * fs_max + S1_T - 1) / S1_T) * ((ns_max + S1_T - 1) / S1_T));
+    }
     double* d_dinv = pool.get<double>((size_t)(n_max / S1_PB + 1) * S1_PB * S1_PB); int* d_flags = pool.get<int>((size_t)((R_max + S1_T - 1) / S1_T) * ((n_max + S1_T - 1) / S1_T));
     double* d_g = pool.get<double>(n_max); double* d_part = pool.get<double>((size_t)S1_GT_CHUNKS * n_max); double* d_vec = pool.get<double>(n_max);
     double* d_out = pool.get<double>(std::max(n_max, R_max));
@@ -1437,6 +1539,22 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         p.w_poseF = ds->wt_poseF * a;
         hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
         if (d.nfinger) hipMemcpyAsync(d_finger, finger_ids.data(), d.nfinger * sizeof(int), hipMemcpyHostToDevice, st);
+        const int fs = 3 + d.npid + ((d.per_frame && d.shape_free) ? nb : 0), ns = 3 * M + (d.per_frame ? 0 : nb), nsp = (ns + 15) & ~15;
+        const bool schur = want_schur && fs <= S1_FSMAX;
+        if (schur) {
+            std::vector<int> fcols((size_t)F * fs), scols(ns), ones((size_t)((F * fs + S1_T - 1) / S1_T) * ((ns + S1_T - 1) / S1_T), 1);
+            for (int f = 0; f < F; ++f) {
+                int* fc = fcols.data() + (size_t)f * fs;
+                for (int c = 0; c < 3; ++c) fc[c] = 3 * f + c;
+                for (int c = 0; c < d.npid; ++c) fc[3 + c] = d.o_pose + f * d.npid + c;
+                for (int e = 0; e < fs - 3 - d.npid; ++e) fc[3 + d.npid + e] = d.o_b + f * nb + e;
+            }
+            for (int i = 0; i < 3 * M; ++i) scols[i] = d.o_ml + i;
+            for (int e = 0; e < ns - 3 * M; ++e) scols[3 * M + e] = d.o_b + e;
+            hipMemcpyAsync(d_fcols, fcols.data(), fcols.size() * sizeof(int), hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(d_scols, scols.data(), scols.size() * sizeof(int), hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(d_ones, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, st);
+        }
         hipStreamSynchronize(st);
         const int n = d.n, R = d.R;
         auto pack = [&](std::vector<double>& xx) {
@@ -1504,6 +1622,26 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                 double nsd = nrm2(dsd);
                 if (nsd >= delta) { ddl = dsd; for (double& t : ddl) t *= delta / nsd; }
                 else {
+                    if (!have_gn && schur) {
+                        const size_t lds_bytes = ((size_t)fs * (fs + 1) + fs) * sizeof(double);
+                        hipMemsetAsync(d_Y, 0, (size_t)F * fs * nsp * 8, st);
+#ifndef S1_EMU
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_s1_elim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#endif
+                        LAUNCH_LDS(k_s1_elim, F, 1, S1_TPB, lds_bytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, p.status);
+                        { int nt = (ns + S1_T - 1) / S1_T; LAUNCH(k_s1_syrk, nt, nt, 256, st, d_Y, F * fs, ns, nsp, d_T, d_ones); }
+                        LAUNCH(k_s1_schur_sub, (ns + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_A, n, d_g, d_scols, ns, d_T, d_Y, nsp, d_z, F * fs, d_S, d_h);
+                        for (int j0 = 0; j0 < ns; j0 += S1_PB) {
+                            const int jb = std::min(S1_PB, ns - j0), rem = ns - j0 - jb;
+                            LAUNCH(k_s1_chol_diag, 1, 1, S1_TRSM_TPB, st, d_S, ns, j0, d_dinv, p.status);
+                            if (rem > 0) LAUNCH(k_s1_chol_trsm, (rem + S1_TRSM_TPB - 1) / S1_TRSM_TPB, 1, S1_TRSM_TPB, st, d_S, ns, j0, d_dinv);
+                            if (rem > 0) { int nt = (rem + S1_PB - 1) / S1_PB; LAUNCH(k_s1_chol_update, nt, nt, 256, st, d_S, ns, j0, jb); }
+                        }
+                        LAUNCH(k_s1_tri_solve, 1, 1, S1_CHOL_TPB, st, d_S, ns, d_dinv, d_h, d_ds);
+                        LAUNCH(k_s1_back, F, 1, S1_TPB, st, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, d_ds, d_out);
+                        fetch(dgn, d_out, n);
+                        have_gn = true;
+                    }
                     if (!have_gn) {
                         // the factorisation overwrites A: keep a copy for the rho denominator products
                         hipMemcpyAsync(d_L, d_A, (size_t)n * n * 8, hipMemcpyDeviceToDevice, st);

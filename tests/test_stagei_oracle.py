@@ -294,3 +294,19 @@ def test_stagei_dogleg_keeps_descending_and_scipy_agrees_on_descent(case):
     cd, cs = (obj.r(xd) ** 2).sum(), (sol.fun ** 2).sum()
     assert cd < c0 and cs < c0
     assert (c0 - cd) / c0 < 0.05 and (c0 - cs) / c0 < 0.10            # the solution was already close to a local minimum
+
+
+@pytest.mark.parametrize('fingers', [False, True])
+def test_schur_solver_equals_dense_solver_in_emulation(case, fingers, monkeypatch):
+    """MOSHII_S1_SOLVER=schur (per-frame elimination + Schur complement on the shared block; off by default, not yet validated on a GPU)
+    takes the same Gauss-Newton steps as the dense blocked Cholesky."""
+    from tests.emu import emu_stagei
+    c = case if not fingers else helpers.stagei_case(finger_markers=True, M=36, seed=2)
+    kw = helpers.stagei_kwargs(c, optimize_fingers=fingers)
+    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
+    a = emu_stagei.solve(c['m'], c['prior'], **kw)
+    monkeypatch.setenv('MOSHII_S1_SOLVER', 'schur')
+    b = emu_stagei.solve(c['m'], c['prior'], **kw)
+    assert int(a['iters'][0]) == int(b['iters'][0])
+    assert np.abs(a['betas'] - b['betas']).max() < 1e-10 and np.abs(a['markers_latent'] - b['markers_latent']).max() < 1e-11
+    assert np.abs(a['pose'] - b['pose']).max() < 1e-10
