@@ -310,3 +310,21 @@ def test_schur_solver_equals_dense_solver_in_emulation(case, fingers, monkeypatc
     assert int(a['iters'][0]) == int(b['iters'][0])
     assert np.abs(a['betas'] - b['betas']).max() < 1e-10 and np.abs(a['markers_latent'] - b['markers_latent']).max() < 1e-11
     assert np.abs(a['pose'] - b['pose']).max() < 1e-10
+
+
+@pytest.mark.parametrize('name', ['face', 'mano', 'fixed_betas'])
+def test_schur_solver_variants_in_emulation(name, monkeypatch):
+    """The arrow-structured solver with per-frame expression columns in the frame blocks (face), without a prior / body block (mano)
+    and without shared betas (fixed_betas): same steps as the dense solver."""
+    from tests.emu import emu_stagei
+    from tests.test_gpu_stagei import _variant
+    c, fingers, extra = _variant(name)
+    kw = helpers.stagei_kwargs(c, optimize_fingers=fingers, **extra)
+    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
+    a = emu_stagei.solve(c['m'], c['prior'], **kw)
+    monkeypatch.setenv('MOSHII_S1_SOLVER', 'schur')
+    b = emu_stagei.solve(c['m'], c['prior'], **kw)
+    assert int(a['iters'][0]) == int(b['iters'][0])
+    assert np.abs(a['markers_latent'] - b['markers_latent']).max() < 1e-11 and np.abs(a['pose'] - b['pose']).max() < 1e-9
+    if a['expression'].size:
+        assert np.abs(a['expression'] - b['expression']).max() < 1e-10
