@@ -1187,9 +1187,9 @@ KERNEL k_s1_tri_solve(const double* L, int n, const double* dinv, const double* 
 // ~30), and every frame back-substitutes d_f = L_f^{-T} (z_f - Y_f d_s).
 // ---------------------------------------------------------------------------------------------------------------------------
 KERNEL k_s1_elim(const double* A, int n, const double* g, const int* fcols, int fs, const int* scols, int ns, int nsp,
-                 double* Linv, double* Y, double* z, int* status) {       // grid F, dynamic LDS (fs (fs + 1) + fs) doubles
+                 double* Linv, double* Y, double* z, int* status, int fbase) {       // grid frames, dynamic LDS (fs (fs + 1) + fs) doubles
     DYN_LDS(lds);
-    const int f = BX, ld = fs + 1;
+    const int f = fbase + BX, ld = fs + 1;
     double* Lm = lds; double* tmp = lds + (size_t)fs * ld;
     const int* fc = fcols + (size_t)f * fs;
     for (int e = TID; e < fs * fs; e += NT) { int i = e / fs, j = e % fs; Lm[i * ld + j] = (j <= i) ? A[(size_t)fc[i] * n + fc[j]] : 0.0; }
@@ -1245,9 +1245,9 @@ KERNEL k_s1_schur_sub(const double* A, int n, const double* g, const int* scols,
 
 // d_f = L_f^{-T} (z_f - Y_f d_s), scattered into the full step; block 0 also scatters d_s                        grid F
 KERNEL k_s1_back(const int* fcols, int fs, const int* scols, int ns, int nsp, const double* Linv, const double* Y, const double* z,
-                 const double* ds, double* dfull) {
+                 const double* ds, double* dfull, int fbase, int scatter_shared) {
     SHARED double w[S1_FSMAX];
-    const int f = BX;
+    const int f = fbase + BX;
     for (int i = TID; i < fs; i += NT) {
         const double* Yr = Y + ((size_t)f * fs + i) * nsp;
         double sacc = z[(size_t)f * fs + i];
@@ -1261,7 +1261,7 @@ KERNEL k_s1_back(const int* fcols, int fs, const int* scols, int ns, int nsp, co
         for (int i = k; i < fs; ++i) sacc += Lg[(size_t)i * fs + k] * w[i];
         dfull[fcols[(size_t)f * fs + k]] = sacc;
     }
-    if (f == 0) for (int c = TID; c < ns; c += NT) dfull[scols[c]] = ds[c];
+    if (BX == 0 && scatter_shared) for (int c = TID; c < ns; c += NT) dfull[scols[c]] = ds[c];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1408,7 +1408,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max);
     // experimental arrow-structured solver (off unless MOSHII_S1_SOLVER=schur)
     const char* solver_env = getenv("MOSHII_S1_SOLVER");
-    const bool want_schur = solver_env && strcmp(solver_env, "schur") == 0 && !shard;
+    const bool want_schur = solver_env && strcmp(solver_env, "schur") == 0;
     const int fs_max = 3 + npid_max + (d.per_frame ? nb : 0), ns_max = 3 * M + (d.per_frame ? 0 : nb), nsp_max = (ns_max + 15) & ~15;
     int *d_fcols = nullptr, *d_scols = nullptr, *d_ones = nullptr;
     double *d_Linv = nullptr, *d_Y = nullptr, *d_z = nullptr, *d_T = nullptr, *d_S = nullptr, *d_h = nullptr, *d_ds = nullptr;
@@ -1582,6 +1582,11 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             LAUNCH(k_s1_syrk, nt, nt, 256, st, p.Jm, R, n, d.ldn, d_A, d_flags);
             LAUNCH(k_s1_gemv_t, (n + S1_TPB - 1) / S1_TPB, S1_GT_CHUNKS, S1_TPB, st, p.Jm, p.r, R, n, d.ldn, d_part);
             LAUNCH(k_s1_gemv_t_sum, (n + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_part, n, -1.0, d_g);
+            if (shard && schur) {   // arrow-structured solver: A stays rank-local; only the gradient (and later the Schur block) is summed
+                fetch(g, d_g, n);
+                reduce(g.data(), n);
+                return;
+            }
             if (shard) {        // sum the ranks' normal equations: [A | g] through the host (a few MB per iteration)
                 hbuf.resize((size_t)n * n + n);
                 hipMemcpyAsync(hbuf.data(), d_A, (size_t)n * n * 8, hipMemcpyDeviceToHost, st);
@@ -1598,6 +1603,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             hipMemcpyAsync(d_vec, v.data(), n * 8, hipMemcpyHostToDevice, st);
             LAUNCH(k_s1_gemv, n, 1, S1_TPB, st, d_A, d_vec, n, n, d_out);
             fetch(out, d_out, n);
+            if (shard && schur) reduce(out.data(), n);          // A is rank-local there: sum the products
         };
         // ---- Powell dogleg (chumpy minimize_dogleg as restated in oracle/stageii_oracle.py:minimize_dogleg)
         const double e1 = 1e-15, e2 = 1e-15, e3 = ds->stagei_lr;
@@ -1625,12 +1631,25 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                     if (!have_gn && schur) {
                         const size_t lds_bytes = ((size_t)fs * (fs + 1) + fs) * sizeof(double);
                         hipMemsetAsync(d_Y, 0, (size_t)F * fs * nsp * 8, st);
+                        hipMemsetAsync(d_z, 0, (size_t)F * fs * 8, st);
 #ifndef S1_EMU
                         hipFuncSetAttribute(reinterpret_cast<const void*>(k_s1_elim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 #endif
-                        LAUNCH_LDS(k_s1_elim, F, 1, S1_TPB, lds_bytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, p.status);
+                        // (sharded: every rank eliminates its own frames -- their rows live only here, so A_ff, A_fs and g_f are complete --
+                        //  and contributes A_ss,r - Y_r^T Y_r and g_s,r - Y_r^T z_r; the sum over ranks is the Schur system: ns^2 + ns doubles)
+                        if (nown > 0) LAUNCH_LDS(k_s1_elim, nown, 1, S1_TPB, lds_bytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, p.status, f_lo);
                         { int nt = (ns + S1_T - 1) / S1_T; LAUNCH(k_s1_syrk, nt, nt, 256, st, d_Y, F * fs, ns, nsp, d_T, d_ones); }
                         LAUNCH(k_s1_schur_sub, (ns + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_A, n, d_g, d_scols, ns, d_T, d_Y, nsp, d_z, F * fs, d_S, d_h);
+                        if (shard) {
+                            hbuf.resize((size_t)ns * ns + ns);
+                            hipMemcpyAsync(hbuf.data(), d_S, (size_t)ns * ns * 8, hipMemcpyDeviceToHost, st);
+                            hipMemcpyAsync(hbuf.data() + (size_t)ns * ns, d_h, (size_t)ns * 8, hipMemcpyDeviceToHost, st);
+                            hipStreamSynchronize(st);
+                            reduce(hbuf.data(), (long long)ns * ns + ns);
+                            hipMemcpyAsync(d_S, hbuf.data(), (size_t)ns * ns * 8, hipMemcpyHostToDevice, st);
+                            hipMemcpyAsync(d_h, hbuf.data() + (size_t)ns * ns, (size_t)ns * 8, hipMemcpyHostToDevice, st);
+                            hipStreamSynchronize(st);
+                        }
                         for (int j0 = 0; j0 < ns; j0 += S1_PB) {
                             const int jb = std::min(S1_PB, ns - j0), rem = ns - j0 - jb;
                             LAUNCH(k_s1_chol_diag, 1, 1, S1_TRSM_TPB, st, d_S, ns, j0, d_dinv, p.status);
@@ -1638,8 +1657,11 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                             if (rem > 0) { int nt = (rem + S1_PB - 1) / S1_PB; LAUNCH(k_s1_chol_update, nt, nt, 256, st, d_S, ns, j0, jb); }
                         }
                         LAUNCH(k_s1_tri_solve, 1, 1, S1_CHOL_TPB, st, d_S, ns, d_dinv, d_h, d_ds);
-                        LAUNCH(k_s1_back, F, 1, S1_TPB, st, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, d_ds, d_out);
+                        hipMemsetAsync(d_out, 0, (size_t)n * 8, st);
+                        if (nown > 0) LAUNCH(k_s1_back, nown, 1, S1_TPB, st, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, d_ds, d_out, f_lo, own_shared);
+                        else if (own_shared) return fail(MOSHII_ERR_ARG, "stagei: the rank that owns the shared rows must own at least one frame");
                         fetch(dgn, d_out, n);
+                        if (shard) reduce(dgn.data(), n);
                         have_gn = true;
                     }
                     if (!have_gn) {

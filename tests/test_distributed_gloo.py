@@ -119,7 +119,7 @@ def test_three_rank_gloo_one_sequence_by_frame_ranges(tmp_path):
 
 
 # ---- Stage-I: frames of one subject over ranks, normal equations all-reduced (moshii_stagei_desc.sharded) --------------------
-def _stagei_worker(rank, world, port, outdir):
+def _stagei_worker(rank, world, port, outdir, solver=''):
     """The Stage-I solver with its frames split over `world` ranks and gloo as the all-reduce.  On this CPU-only box the kernels run
     through the g++ emulation build of stagei.hip (tests/emu): same source, same host code, same sharding logic as the GPU library."""
     sys.path.insert(0, ROOT)
@@ -130,6 +130,8 @@ def _stagei_worker(rank, world, port, outdir):
     from moshpp_amd.parallel import stagei_solve_sharded
     from tests import helpers
     from tests.emu import emu_stagei
+    if solver:
+        os.environ['MOSHII_S1_SOLVER'] = solver
     c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
     kw = helpers.stagei_kwargs(c)
     out = stagei_solve_sharded(lambda **sh: emu_stagei.solve(c['m'], c['prior'], **kw, **sh), len(c['frames']), dist)
@@ -158,5 +160,28 @@ def test_stagei_frames_sharded_over_ranks_gloo(tmp_path):
             assert np.abs(o['markers_latent'] - single['markers_latent']).max() < 1e-10
             assert np.abs(o['pose'] - single['pose']).max() < 1e-9 and np.abs(o['trans'] - single['trans']).max() < 1e-10
             assert np.allclose(o['errs'], single['errs'], rtol=1e-8, atol=1e-12)
+        for o in outs[1:]:
+            assert np.array_equal(o['betas'], outs[0]['betas']) and np.array_equal(o['pose'], outs[0]['pose'])
+
+
+def test_stagei_sharded_schur_allreduces_only_the_shared_block(tmp_path):
+    """MOSHII_S1_SOLVER=schur with the frames over 2 and 3 ranks: every rank eliminates its own frames and only the Schur system of the
+    shared block (ns^2 + ns doubles) plus a few n-vectors are summed -- the reduction SURVEY 8(e) describes.  Same solution as the
+    single-process dense solve."""
+    sys.path.insert(0, ROOT)
+    from tests import helpers
+    from tests.emu import emu_stagei
+    emu_stagei.build_emu.build()
+    c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
+    single = emu_stagei.solve(c['m'], c['prior'], **helpers.stagei_kwargs(c))
+    for world in (2, 3):
+        d = tmp_path / f'w{world}'
+        os.makedirs(d)
+        mp.spawn(_stagei_worker, args=(world, _free_port(), str(d), 'schur'), nprocs=world, join=True)
+        outs = [np.load(d / f'rank{r}.npz') for r in range(world)]
+        for o in outs:
+            assert int(o['iters'][0]) == int(single['iters'][0])
+            assert np.abs(o['betas'] - single['betas']).max() < 1e-9 and np.abs(o['markers_latent'] - single['markers_latent']).max() < 1e-10
+            assert np.abs(o['pose'] - single['pose']).max() < 1e-9 and np.abs(o['trans'] - single['trans']).max() < 1e-10
         for o in outs[1:]:
             assert np.array_equal(o['betas'], outs[0]['betas']) and np.array_equal(o['pose'], outs[0]['pose'])
