@@ -174,3 +174,19 @@ def test_mosh_stagei_then_stageii_end_to_end(tmp_path):
     rm = np.sqrt(np.mean([((a - b) ** 2).sum(1).mean() for a, b in zip(stageii['stageii_debug_details']['markers_sim'],
                                                                      stageii['stageii_debug_details']['markers_obs'])]))
     assert rm < 5e-3        # the solved subject + layout reproduce the capture to a few millimetres
+
+
+def test_stagei_schur_solver_matches_dense(monkeypatch):
+    """MOSHII_S1_SOLVER=schur (per-frame elimination + Schur complement of the shared block; opt-in) takes the same Gauss-Newton steps
+    as the default dense blocked Cholesky."""
+    from moshpp_amd import capi
+    c = helpers.stagei_case()
+    dev, pr = _device(c)
+    kw = helpers.stagei_kwargs(c)
+    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
+    a = capi.stagei_solve_host(dev, pr, **kw)
+    monkeypatch.setenv('MOSHII_S1_SOLVER', 'schur')
+    b = capi.stagei_solve_host(dev, pr, **kw)
+    assert a['iters'] == b['iters']
+    assert np.abs(a['betas'] - b['betas']).max() < 1e-6 and np.abs(a['markers_latent'] - b['markers_latent']).max() < 1e-7
+    assert np.abs(a['pose'] - b['pose']).max() < 1e-6
