@@ -1324,7 +1324,10 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     const int F = d.F, M = d.M, nb = d.nb, NP = d.NP, K = d.K;
     int ntot_obs = 0;
     std::vector<int> obs_off(F + 1, 0);
-    for (int f = 0; f < F; ++f) { ntot_obs += ds->n_obs[f]; obs_off[f + 1] = ntot_obs; }
+    for (int f = 0; f < F; ++f) {
+        if (ds->n_obs[f] < 3) return fail(MOSHII_ERR_ARG, "stagei: a picked frame has fewer than 3 observed layout markers (no rigid start possible)");
+        ntot_obs += ds->n_obs[f]; obs_off[f + 1] = ntot_obs;
+    }
     for (int i = 0; i < ntot_obs; ++i) if (ds->obs_ids[i] < 0 || ds->obs_ids[i] >= M) return fail(MOSHII_ERR_ARG, "stagei: observed marker id out of range");
 
     // frames of this rank (moshii_stagei_desc.sharded): every rank evaluates the canonical body and the attachment, the data / prior /
