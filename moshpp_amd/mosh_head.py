@@ -164,8 +164,37 @@ def run_stagei(cfg, stagei_mocap_fnames, stagei_fname=None, mosh_stagei_func=Non
         with open(_makepath(stagei_fname), 'wb') as fh:
             pickle.dump(stagei_data, fh)
         logger.debug(f'created stagei_fname: {stagei_fname}')
+        if cfg.dirs.get('write_optimized_marker_layout', False):       # mosh_head.py:259-260
+            dump_stagei_marker_layout(stagei_fname)
     logger.debug(f'finished mosh stagei in {timedelta(seconds=elapsed)}')
     return stagei_data
+
+
+def extract_marker_layout_from_mosh(mosh_stagei, template_marker_layout_fname=None) -> dict:
+    """`MoSh.extract_marker_layout_from_mosh` (mosh_head.py:562-581): the Stage-I marker layout with every label's vertex id replaced
+    by the optimised one (`markers_latent_vids`); optionally on top of a template layout file."""
+    import copy
+    from .marker_layout import marker_layout_load
+    if not isinstance(mosh_stagei, dict):
+        with open(mosh_stagei, 'rb') as fh:
+            mosh_stagei = pickle.load(fh)
+    opt_vids = mosh_stagei['markers_latent_vids']
+    meta = marker_layout_load(template_marker_layout_fname) if template_marker_layout_fname else copy.deepcopy(mosh_stagei['marker_meta'])
+    for label in meta['marker_vids']:
+        if label in opt_vids:
+            meta['marker_vids'][label] = opt_vids[label]
+    return meta
+
+
+def dump_stagei_marker_layout(mosh_stagei_pkl_fname, out_marker_layout_fname=None, template_marker_layout_fname=None):
+    """The json part of `MoSh.dump_stagei_marker_layout` (mosh_head.py:303-321; its mesh / c3d exports need the visualisation stack and
+    are out of scope): writes the optimised layout next to the Stage-I pickle."""
+    from .marker_layout import marker_layout_write
+    assert str(mosh_stagei_pkl_fname).endswith('.pkl'), ValueError(f'mosh_stagei_pkl_fname should be a valid pkl file: {mosh_stagei_pkl_fname}')
+    meta = extract_marker_layout_from_mosh(mosh_stagei_pkl_fname, template_marker_layout_fname)
+    out = out_marker_layout_fname or str(mosh_stagei_pkl_fname).replace('.pkl', '.json')
+    marker_layout_write(meta, out)
+    return out
 
 
 def run_moshpp_once(cfg, stagei_mocap_fnames=None):

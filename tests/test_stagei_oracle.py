@@ -207,6 +207,11 @@ def test_mosh_stagei_host_path_on_cpu(tmp_path, monkeypatch):
     st1, st2 = run_moshpp_once(cfg)
     assert st2 is None and os.path.exists(cfg.dirs.stagei_fname) and len(st1['stagei_debug_details']['stagei_fnames']) == 3
     st1b, _ = run_moshpp_once(cfg)
+    from moshpp_amd.mosh_head import dump_stagei_marker_layout
+    from moshpp_amd.marker_layout import marker_layout_load
+    opt = marker_layout_load(dump_stagei_marker_layout(cfg.dirs.stagei_fname))
+    assert list(opt['marker_vids'].keys()) == labels
+    assert [opt['marker_vids'][l] for l in labels] == [st1['markers_latent_vids'][l] for l in labels]      # optimised vertex ids
     assert np.array_equal(st1b['markers_latent'], st1['markers_latent'])       # loaded, not re-solved
     # optimize_betas = false with given betas: they are kept, no beta term
     np.savez(tmp_path / 'betas.npz', betas=np.array([0.5, -0.3, 0.2, 0.1]))
