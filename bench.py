@@ -19,6 +19,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
   sequential_chain   the literal frame order on the GPU (one workgroup) and the timed mode's deviation from it over
                      ALL frames
   many_sequences     32 copies of the sequence in one call: the dominant kernel with every CU busy
+  other_seeds        the same workload generated from two other seeds (the repair pattern depends on the motion)
+  stagei             Stage-I on 12 frames / 53 markers / 10 betas: GPU seconds (default dense solver and the opt-in
+                     arrow-structured one), iterations, and the NumPy oracle's seconds + differences on the same problem
+All extra legs except roofline / roofline_lbs run at N = 1 only.
 """
 from __future__ import annotations
 
