@@ -332,3 +332,51 @@ def test_host_level_chunk_scheme_reproduces_the_sequential_chain():
     assert np.abs(out2['pose'] - ref['pose']).max() < 1e-8
     assert info2['repaired'] == [[5, 6], [6]], info2
     assert all(not has_init for _, _, has_init in calls[0]) and all(has_init for _, _, has_init in calls[1])
+
+
+def test_marker_layout_roundtrip_filter_and_pose_id_sets(tmp_path):
+    """marker_layout_write -> marker_layout_load round trip, marker_meta_filter, and the Stage-I free-variable sets of every model
+    family against the oracle's (chmosh.py:281-310, 383-388)."""
+    from moshpp_amd.chmosh import stagei_pose_ids
+    from moshpp_amd.marker_layout import marker_layout_load, marker_layout_write, marker_meta_filter
+    from oracle import stageii_oracle as so
+    meta = marker_layout_load({'surface_model_type': 'smplx', 'markersets': [
+        {'type': 'face', 'distance_from_skin': 0.0002, 'indices': {'CHIN': 8800, 'NOSE': 8970}},
+        {'type': 'body', 'indices': {'C7': 3832, 'T10': 5623, 'STRN': 5532}}]}, labels_map={})
+    fn = str(tmp_path / 'sub' / 'layout.json')
+    marker_layout_write(meta, fn)
+    back = marker_layout_load(fn, labels_map={})
+    assert list(back['marker_vids'].items()) == list(meta['marker_vids'].items())
+    assert {k: v.tolist() for k, v in back['marker_type_mask'].items()} == {k: v.tolist() for k, v in meta['marker_type_mask'].items()}
+    assert dict(back['m2b_distance']) == {'body': 0.0095, 'face': 0.0002} and back['surface_model_type'] == 'smplx'
+    sub = marker_meta_filter(meta, ['C7', 'NOSE'])
+    assert list(sub['marker_vids']) == ['C7', 'NOSE'] and sub['marker_type_mask']['body'] == [True, False]
+    assert set(sub['marker_colors']) == {'C7', 'NOSE', 'nan'}
+    for mt, NP in (('smpl', 72), ('smplh', 66 + 24), ('smplx', 75 + 48), ('mano', 3 + 24)):
+        for fingers in (False, True):
+            pose_ids, body, finger = stagei_pose_ids(mt, NP, fingers, False)
+            root, obody, ofinger, step1, _ = so.pose_id_sets(mt, NP, optimize_fingers=fingers)
+            assert pose_ids == step1 and body == obody
+            assert finger == (ofinger if (fingers or mt == 'mano') else [])
+
+
+def test_prepare_stagei_frames_dispatch(tmp_path):
+    """mosh_head.prepare_stagei_frames: picker type and arguments come from cfg (mosh_head.py:156-197)."""
+    from moshpp_amd.cfg import make_cfg
+    from moshpp_amd.mosh_head import prepare_stagei_frames
+    rng = np.random.default_rng(0)
+    mk = rng.normal(0, 500, (20, 6, 3))
+    mk[3, 2] = np.nan
+    fn = str(tmp_path / 'cap.npz')
+    np.savez(fn, markers=mk, labels=np.array([f'L{i}' for i in range(6)]), frame_rate=100.0)
+    cfg = make_cfg(**{'surface_model.type': 'smplh', 'mocap.fname': fn, 'moshpp.stagei_frame_picker.type': 'manual'})
+    frames, names = prepare_stagei_frames(cfg, [f'{fn}_3', f'{fn}_7'])
+    assert [os.path.basename(n) for n in names] == ['cap.npz_000003', 'cap.npz_000007'] and 'L2' not in frames[0] and len(frames[1]) == 6
+    assert np.allclose(frames[1]['L0'], mk[7, 0] / 1000.0)
+    cfg.moshpp.stagei_frame_picker.type = 'random_strict'
+    cfg.moshpp.stagei_frame_picker.num_frames = 4
+    frames, names = prepare_stagei_frames(cfg, [fn])
+    assert len(frames) == 4 and all(len(f) == 6 for f in frames)              # least_avail_markers = 1.0: the NaN frame is never picked
+    cfg.moshpp.stagei_frame_picker.type = 'nope'
+    with pytest.raises(ValueError):
+        prepare_stagei_frames(cfg, [fn])
