@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE: builds tests/emu/libmoshii_emu.so = the product's moshii_api.hip + chain_solve.hip (UNCHANGED sources, compiled
+by g++ against tests/emu/fakehip/hip/hip_runtime.h) + the fiber scheduler + stagei.hip in its own emulation mode.  The Stage-II chain
+kernel then runs on the CPU, 256 fibers per workgroup, so its arithmetic can be held to the oracle (and run under sanitizers) without
+a GPU.  Never loaded by the product; the GPU tests check the hipcc build."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'moshpp_amd', 'csrc')
+OUT = os.path.join(HERE, 'libmoshii_emu.so')
+UNITS = [(os.path.join(CSRC, 'moshii_api.hip'), []), (os.path.join(CSRC, 'chain_solve.hip'), []),
+         (os.path.join(CSRC, 'stagei.hip'), ['-DS1_EMU']), (os.path.join(HERE, 'hip_emu_runtime.cpp'), []),
+         (os.path.join(HERE, 'chain_emu_stubs.cpp'), [])]
+
+
+def build(force=False, opt='-O1'):
+    deps = [u for u, _ in UNITS] + [os.path.join(HERE, 'fakehip', 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'moshii_dev.h'),
+                                    os.path.join(ROOT, 'include', 'moshii.h')]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
+        return OUT
+    objs, procs = [], []
+    for src, extra in UNITS:
+        obj = os.path.join(HERE, '_' + os.path.basename(src).replace('.', '_') + '.o')
+        cmd = ['g++', opt, '-std=c++17', '-fPIC', '-w', '-I', os.path.join(HERE, 'fakehip'), '-I', os.path.join(ROOT, 'include'),
+               '-x', 'c++', '-c', src, '-o', obj] + extra
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'g++ failed on {src}')
+    subprocess.check_call(['g++', '-shared', '-fPIC', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force=True))

@@ -1,0 +1,109 @@
+// TEST INFRASTRUCTURE.  A stand-in for <hip/hip_runtime.h> that lets g++ compile moshpp_amd/csrc/{moshii_api,chain_solve}.hip UNCHANGED
+// and run their kernels on the CPU: every workgroup is executed as one fiber per thread (ucontext), with real barrier semantics for
+// __syncthreads / s_barrier and wave-level rendezvous for the cross-lane operations the kernels use (__shfl_down, readlane,
+// wave_barrier).  "Device" memory is host memory.  Used only by tests/emu (build_chain_emu.py); the product is built by hipcc.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct int2 { int x, y; };
+struct alignas(16) double2 { double x, y; };
+inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
+struct alignas(16) double4 { double x, y, z, w; };
+
+namespace hipemu {
+struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
+ThreadCtx& cur();                                   // the running fiber's indices
+void barrier();                                     // workgroup barrier
+void wave_sync();                                   // all lanes of the caller's wavefront rendezvous
+double wave_exchange(double v, int src_lane);       // value of `v` in lane `src_lane` of the caller's wavefront (all lanes call)
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+}
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ thread_local                     // one OS thread runs one workgroup at a time: thread_local == per-workgroup
+#define __constant__ static
+#define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+#define _Float16 unsigned short                      // only pointer members of Lbs32Model (the f16 LBS path is not emulated)
+#define HIP_SYMBOL(x) (&(x))
+#define threadIdx (hipemu::cur().tid)
+#define blockIdx (hipemu::cur().bid)
+#define blockDim (hipemu::cur().bdim)
+#define gridDim (hipemu::cur().gdim)
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipDeviceAttributeMultiprocessorCount = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 2 };
+
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n) { memcpy(d, sym, n); return hipSuccess; }
+inline hipError_t hipMemcpyToSymbol(void* sym, const void* s, size_t n) { memcpy(sym, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }     // 8 "CUs": small chunk counts in the emulated runs
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
+    hipemu::launch(grid, block, lds, [&]() { kern(__VA_ARGS__); })
+
+inline void __syncthreads() { hipemu::barrier(); }
+template <class T> inline T __shfl_down(T v, int delta, int width = 64) {
+    int lane = (int)(hipemu::cur().tid.x % 64);
+    int src = lane + delta;
+    double got = hipemu::wave_exchange((double)v, (src < width && src < 64) ? src : lane);
+    return (T)got;
+}
+inline int __double2loint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b & 0xffffffff); }
+inline int __double2hiint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) { int64_t b = ((int64_t)hi << 32) | (uint32_t)lo; double v; memcpy(&v, &b, 8); return v; }
+inline int __builtin_amdgcn_readlane(int v, int lane) {          // exact for 32-bit payloads: a double carries any int exactly
+    return (int)hipemu::wave_exchange((double)v, lane);
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used to scalarise wave-uniform values
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
+inline void __builtin_amdgcn_fence(int, const char*) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline long long clock64() { return 0; }
+inline long long wall_clock64() { return 0; }
+inline double rsqrt(double x) { return 1.0 / sqrt(x); }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline double min(double a, double b) { return a < b ? a : b; }
+inline double max(double a, double b) { return a > b ? a : b; }
+inline size_t min(size_t a, size_t b) { return a < b ? a : b; }
+inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
+
+// dynamic LDS: the kernels declare `extern __shared__ double lds[]` (namespace moshii, chain_solve.hip) and `... sm[]` (unnamed
+// namespace, moshii_api.hip); with __shared__ = thread_local these block-scope externs need a definition in their namespace
+namespace moshii { inline alignas(16) thread_local double lds[160 * 1024 / 8]; }
+namespace { alignas(16) thread_local double sm[160 * 1024 / 8]; }
+
+// the one inline-assembly statement of the chain kernel is a workgroup barrier ("s_waitcnt ...; s_barrier"):
+//   asm volatile("..." ::: "memory")  ->  hipemu::barrier()
+#define asm
+#define volatile(...) hipemu::barrier()

@@ -1,0 +1,92 @@
+// TEST INFRASTRUCTURE.  Fiber scheduler behind tests/emu/fakehip/hip/hip_runtime.h: one ucontext per GPU thread of the running
+// workgroup; a fiber blocks at a workgroup barrier or at a wavefront rendezvous and the scheduler releases a group when all of its
+// live members have arrived (convergent use of the collectives is assumed; anything else is reported as a deadlock).
+#include <ucontext.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+namespace hipemu {
+struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
+
+namespace {
+enum State { RUN, AT_BARRIER, AT_WAVE, DONE };
+struct Fiber { ucontext_t ctx; char* stack; State st; ThreadCtx tc; double xval; int xsrc; double xgot; };
+const size_t STACK = 1 << 20;
+std::vector<Fiber> fibers;
+std::vector<char*> stacks;
+ucontext_t sched_ctx;
+int cur_fiber = -1;
+const std::function<void()>* cur_body = nullptr;
+
+void trampoline() {
+    (*cur_body)();
+    fibers[cur_fiber].st = DONE;
+    swapcontext(&fibers[cur_fiber].ctx, &sched_ctx);
+}
+void yield_as(State s) {
+    Fiber& f = fibers[cur_fiber];
+    f.st = s;
+    swapcontext(&f.ctx, &sched_ctx);
+}
+}  // namespace
+
+ThreadCtx& cur() { return fibers[cur_fiber].tc; }
+void barrier() { yield_as(AT_BARRIER); }
+void wave_sync() { fibers[cur_fiber].xsrc = -1; yield_as(AT_WAVE); }
+double wave_exchange(double v, int src_lane) {
+    Fiber& f = fibers[cur_fiber];
+    f.xval = v; f.xsrc = src_lane;
+    yield_as(AT_WAVE);
+    return fibers[cur_fiber].xgot;
+}
+
+void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
+    const int nt = (int)(block.x * block.y * block.z);
+    while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+        fibers.assign(nt, Fiber());
+        cur_body = &body;
+        for (int t = 0; t < nt; ++t) {
+            Fiber& f = fibers[t];
+            f.stack = stacks[t]; f.st = RUN;
+            f.tc.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            f.tc.bid = dim3(bx, by, bz); f.tc.bdim = block; f.tc.gdim = grid;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &sched_ctx;
+            makecontext(&f.ctx, trampoline, 0);
+        }
+        while (true) {
+            bool progressed = false;
+            for (int t = 0; t < nt; ++t) if (fibers[t].st == RUN) {
+                cur_fiber = t;
+                swapcontext(&sched_ctx, &fibers[t].ctx);
+                progressed = true;
+            }
+            // release wavefronts whose live lanes have all arrived
+            const int nw = (nt + 63) / 64;
+            for (int w = 0; w < nw; ++w) {
+                int lo = w * 64, hi = std::min(nt, lo + 64), waiting = 0, live = 0;
+                for (int t = lo; t < hi; ++t) { if (fibers[t].st != DONE) ++live; if (fibers[t].st == AT_WAVE) ++waiting; }
+                if (live && waiting == live) {
+                    for (int t = lo; t < hi; ++t) if (fibers[t].st == AT_WAVE) {
+                        int s = fibers[t].xsrc;
+                        fibers[t].xgot = (s >= 0 && lo + s < hi) ? fibers[lo + s].xval : 0.0;
+                    }
+                    for (int t = lo; t < hi; ++t) if (fibers[t].st == AT_WAVE) fibers[t].st = RUN;
+                    progressed = true;
+                }
+            }
+            int live = 0, atb = 0;
+            for (int t = 0; t < nt; ++t) { if (fibers[t].st != DONE) ++live; if (fibers[t].st == AT_BARRIER) ++atb; }
+            if (live == 0) break;
+            if (atb == live) { for (int t = 0; t < nt; ++t) if (fibers[t].st == AT_BARRIER) fibers[t].st = RUN; progressed = true; }
+            if (!progressed) { fprintf(stderr, "hipemu: deadlock (divergent barrier / collective) in block %u\n", bx); abort(); }
+        }
+    }
+    cur_fiber = -1;
+}
+}  // namespace hipemu

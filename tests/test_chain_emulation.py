@@ -1,0 +1,58 @@
+"""The product's Stage-II kernels on the CPU: moshii_api.hip + chain_solve.hip compiled UNCHANGED by g++ against a stand-in for
+<hip/hip_runtime.h> (tests/emu/fakehip) and executed one fiber per GPU thread with real barrier / wavefront-rendezvous semantics
+(tests/emu/hip_emu_runtime.cpp).  Same parity checks as tests/test_gpu_parity.py, at sizes the emulation finishes in seconds.  This
+checks the kernels' arithmetic and control flow; the GPU tests check the hipcc build on the device."""
+import numpy as np
+import pytest
+
+from oracle import stageii_oracle as so
+from tests.emu.emu_moshii import emulated_libmoshii
+from tests.helpers import device_case, oracle_case
+
+
+@pytest.mark.parametrize('model_type,fingers,F', [('smplh', False, 4), ('smpl', False, 3), ('smplh', True, 3), ('smplx', True, 3),
+                                                  ('mano', True, 4)])
+def test_chain_kernel_matches_oracle_in_emulation(model_type, fingers, F):
+    M = {'smpl': 41, 'smplh': 53, 'smplx': 89, 'mano': 33}[model_type]
+    case = oracle_case(model_type, F=F, M=M, seed=1, body_only_markers=not fingers)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_fingers=fingers)
+        out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                    [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        kernel = capi.last_launch_info()[0]
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], model_type,
+                           optimize_fingers=fingers)
+    assert kernel.startswith('k_chain_solve<')
+    solved = np.flatnonzero(out['status'] == 0)
+    assert list(solved) == list(ref['frame_ids'])
+    assert np.abs(out['fullpose'][solved] - ref['fullpose']).max() < 1e-9 and np.abs(out['trans'][solved] - ref['trans']).max() < 1e-10
+    np.testing.assert_array_equal(out['iters'][solved, 0], ref['iters'])
+
+
+def test_extended_kernel_matches_oracle_in_emulation():
+    """The xt variant (jaw + expression coefficients free, chmosh.py:562-567, 685-699)."""
+    from tests.helpers import shape_case
+    case = shape_case('smplx', F=3, M=40, E=6, seed=3, kind='expr')
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_face=True, shape_kind='expr')
+        out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                    [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        assert capi.last_launch_info()[0].endswith(',xt>')
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplx',
+                           optimize_face=True, free_shape='expr')
+    assert np.abs(out['fullpose'] - ref['fullpose']).max() < 1e-8 and np.abs(out['shape'] - ref['shape']).max() < 1e-8
+    np.testing.assert_array_equal(out['iters'][:, 0], ref['iters'])
+
+
+def test_chunked_sequence_solve_equals_sequential_chain_in_emulation():
+    """moshii_sequence_solve (chunks, on-device hand-off verification, repairs) against moshii_chain_solve on the same sequence."""
+    case = oracle_case('smplh', F=40, M=53, seed=2)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case)
+        seq = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                    [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        outs, report = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                                [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                                num_chunks=4, warmup=6, verify_tol=1e-9)
+    assert report['n_chunks'] == 4
+    assert np.abs(outs[0]['fullpose'] - seq['fullpose']).max() < 1e-7 and np.abs(outs[0]['trans'] - seq['trans']).max() < 1e-8
