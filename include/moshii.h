@@ -194,7 +194,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL whe
  *   repair  a chunk that fails is re-solved from its predecessor's exact end state (warm start + velocity
  *           term exactly as :624-626, 656-657), and its successor is re-verified; repeated until clean.
  * The call synchronises `stream` (the verification result is read on the host).
- * Free shape coefficients (n_shape > 0) are not supported here (MOSHII_ERR_UNSUPPORTED): use moshii_chain_solve.
+ * Free shape coefficients (n_shape > 0) travel with the hand-off states (verified and repaired like pose / trans).
  * ------------------------------------------------------------------------------------------- */
 typedef struct moshii_sequence_desc {
     moshii_attach_t attach;
@@ -215,6 +215,9 @@ typedef struct moshii_sequence_desc {
     double*  errs;
     int32_t* iters;
     int32_t* status;
+    /* extended variant (n_shape > 0): the free coefficients travel with the chunk hand-off states */
+    const double* init_shape;       /* [n_shape] start values when init_pose is given, or NULL (zeros) */
+    double*       shape;            /* [F][n_shape] output, or NULL                                 */
 } moshii_sequence_desc;
 
 typedef struct moshii_chunk_opts {

@@ -54,7 +54,8 @@ class SequenceDesc(C.Structure):
     _fields_ = [('attach', C.c_void_p), ('F', C.c_int32), ('obs', C.c_void_p), ('vis', C.c_void_p),
                 ('init_pose', _c_double_p), ('init_trans', _c_double_p), ('init_pose_prev', _c_double_p),
                 ('pose', C.c_void_p), ('fullpose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p),
-                ('errs', C.c_void_p), ('iters', C.c_void_p), ('status', C.c_void_p)]
+                ('errs', C.c_void_p), ('iters', C.c_void_p), ('status', C.c_void_p),
+                ('init_shape', _c_double_p), ('shape', C.c_void_p)]
 
 
 class ChunkOpts(C.Structure):
@@ -367,16 +368,18 @@ def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, war
         assert obs.shape == (F, M, 3) and M == att.M
         o = dict(pose=np.zeros((F, model.NP)), fullpose=np.zeros((F, model.P)), trans=np.zeros((F, 3)),
                  markers_sim=np.zeros((F, M, 3)), errs=np.zeros((F, NERR)), iters=np.zeros((F, 2), dtype=np.int32),
-                 status=np.zeros(F, dtype=np.int32))
+                 status=np.zeros(F, dtype=np.int32), shape=np.zeros((F, int(opts.n_shape))))
         d = descs[i]
         d.attach = att.handle; d.F = F; d.obs = obs.ctypes.data; d.vis = vis.ctypes.data
         keep += [obs, vis]
-        for key in ('init_pose', 'init_trans', 'init_pose_prev'):
+        for key in ('init_pose', 'init_trans', 'init_pose_prev', 'init_shape'):
             if sq.get(key) is not None:
                 a = _f64(sq[key]); keep.append(a)
                 setattr(d, key, _dp(a))
         for key in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status'):
             setattr(d, key, o[key].ctypes.data)
+        if int(opts.n_shape):
+            d.shape = o['shape'].ctypes.data
         outs.append(o)
     co = ChunkOpts(int(num_chunks), int(warmup), float(verify_tol))
     rep = ChunkReport()

@@ -145,7 +145,8 @@ class StageIISolver:
         """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
         chain_mode 'sequential': one chain, the reference's exact frame order (chmosh.py:584).
         chain_mode 'chunked': moshii_sequence_solve -- concurrent chunks with warm-up overlap, verified and
-        repaired against the sequential chain to `verify_tol` (out['chunk_report'])."""
+        repaired against the sequential chain to `verify_tol` (out['chunk_report']); free expression / DMPL coefficients travel in
+        the hand-off states.  chain_mode 'chunked_host': the same scheme driven from the host (parallel.solve_sequence_chunked_host)."""
         F = obs.shape[0]
         # init = dict(pose, trans, pose_prev | None): continue a chain from that state (no first-frame schedule)
         ikw = {} if init is None else dict(init_pose=init['pose'], init_trans=init['trans'], init_pose_prev=init.get('pose_prev'))
@@ -154,9 +155,6 @@ class StageIISolver:
                                         [dict(attach=self.attach, obs=obs, vis=vis, first=init is None, **ikw)])[0]
             return out
         if chain_mode == 'chunked':
-            if self.n_shape:
-                raise NotImplementedError('moshii_sequence_solve does not carry free shape coefficients across chunk hand-offs; '
-                                          "use chain_mode='chunked_host' (host-driven chunks) or 'sequential' with optimize_face / optimize_dynamics")
             outs, report = capi.sequence_solve_host(self.dev, self.prior, self.opts, [dict(attach=self.attach, obs=obs, vis=vis, **ikw)],
                                                     num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol)
             outs[0]['chunk_report'] = report

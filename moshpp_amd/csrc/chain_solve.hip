@@ -1572,7 +1572,8 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         if (tid < 3) cx.trans[tid] = is ? is[2 * NP + tid] : (it ? it[tid] : 0.0);
         if constexpr (XT) {
             const double* ish = chp->init_shape;
-            for (int e = tid; e < op.nshape; e += MOSHII_TPB) { cx.pose[NP + e] = ish ? ish[e] : 0.0; cx.shp0[e] = 0.0; }
+            // (chunk hand-off states carry the coefficients behind the flags: [pose][pose_prev][trans][has_prev][first][shape])
+            for (int e = tid; e < op.nshape; e += MOSHII_TPB) { cx.pose[NP + e] = is ? is[2 * NP + 5 + e] : (ish ? ish[e] : 0.0); cx.shp0[e] = 0.0; }
         }
         has_prev = is ? (is[2 * NP + 3] != 0.0) : (iv != nullptr);
         first = is ? (is[2 * NP + 4] != 0.0) : (chp->first != 0);
@@ -1599,15 +1600,17 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if (tid < 3) so[2 * NP + tid] = cx.trans[tid];
             if (tid == 3) so[2 * NP + 3] = has_prev ? 1.0 : 0.0;
             if (tid == 4) so[2 * NP + 4] = first ? 1.0 : 0.0;
+            if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) so[2 * NP + 5 + e] = cx.pose[NP + e];
         }
         if (bi_next < chp->nb && t == chp->bnd[bi_next]) {   // a chunk boundary inside a run-through repair chain
-            const int S = 2 * NP + 5;
+            const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
             double* s1 = chp->run_final + (size_t)bi_next * S;
             double* s2 = chp->run_entry + (size_t)(bi_next + 1) * S;
             for (int i = tid; i < NP; i += MOSHII_TPB) { s1[i] = cx.pose[i]; s1[NP + i] = cx.pose_prev[i]; s2[i] = cx.pose[i]; s2[NP + i] = cx.pose_prev[i]; }
             if (tid < 3) { s1[2 * NP + tid] = cx.trans[tid]; s2[2 * NP + tid] = cx.trans[tid]; }
             if (tid == 3) { s1[2 * NP + 3] = has_prev ? 1.0 : 0.0; s2[2 * NP + 3] = has_prev ? 1.0 : 0.0; }
             if (tid == 4) { s1[2 * NP + 4] = first ? 1.0 : 0.0; s2[2 * NP + 4] = first ? 1.0 : 0.0; }
+            if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) { s1[2 * NP + 5 + e] = cx.pose[NP + e]; s2[2 * NP + 5 + e] = cx.pose[NP + e]; }
             ++bi_next;
         }
         if (t == F) break;
@@ -1687,6 +1690,9 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             const double* po = chp->pose + (size_t)t * NP;
             for (int i = tid; i < NP; i += MOSHII_TPB) dv = fmax(dv, fabs(cx.pose[i] - po[i]));
             if (tid < 3) dv = fmax(dv, fabs(cx.trans[tid] - chp->trans[t * 3 + tid]));
+            if constexpr (XT)
+                if (chp->shape != nullptr)
+                    for (int e = tid; e < op.nshape; e += MOSHII_TPB) dv = fmax(dv, fabs(cx.pose[NP + e] - chp->shape[(size_t)t * op.nshape + e]));
             dv = block_max(dv, cx.red);
             rejoin_run = (dv <= chp->rejoin_tol) ? rejoin_run + 1 : 0;   // (NaN compares false)
         }

@@ -812,7 +812,7 @@ int stage_out(const FrameBufs& h, int NP, int P, Staged* s) {
 
 // max |entry_c - final_pred(c)| per chunk (pose, trans, and pose_prev when the velocity term is live); a flag
 // mismatch (first-frame schedule pending / velocity term missing on one side) counts as infinite deviation.
-__global__ void k_verify_chunks(int n, int NP, const int* __restrict__ pred, const double* __restrict__ entry,
+__global__ void k_verify_chunks(int n, int NP, int E, const int* __restrict__ pred, const double* __restrict__ entry,
                                 const double* __restrict__ fin, double* __restrict__ dev) {
     const int c = blockIdx.x;
     if (c >= n) return;
@@ -820,7 +820,7 @@ __global__ void k_verify_chunks(int n, int NP, const int* __restrict__ pred, con
     __shared__ double red[64];
     double d = 0.0;
     if (p >= 0) {
-        const int S = 2 * NP + 5;
+        const int S = 2 * NP + 5 + E;
         const double* a = entry + (size_t)c * S;
         const double* b = fin + (size_t)p * S;
         const bool flags_ok = (a[2 * NP + 3] == b[2 * NP + 3]) && (a[2 * NP + 4] == b[2 * NP + 4]);
@@ -829,6 +829,7 @@ __global__ void k_verify_chunks(int n, int NP, const int* __restrict__ pred, con
             if (i >= NP && i < 2 * NP && !hp) continue;
             d = fmax(d, fabs(a[i] - b[i]));
         }
+        for (int e = threadIdx.x; e < E; e += blockDim.x) d = fmax(d, fabs(a[2 * NP + 5 + e] - b[2 * NP + 5 + e]));   // free shape block
         if (!flags_ok || !(d == d)) d = 1e300;
     }
     red[threadIdx.x] = d;
@@ -938,10 +939,10 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                           const moshii_sequence_desc* seqs, const moshii_chunk_opts* co, uint32_t flags, void* stream_,
                           moshii_chunk_report* report) {
     if (!m || !o || !seqs || n_seq < 1) return fail(MOSHII_ERR_ARG, "bad argument");
-    if (o->n_shape > 0) return fail(MOSHII_ERR_UNSUPPORTED, "free shape coefficients: the chunk hand-off state does not carry them; use moshii_chain_solve");
     hipStream_t stream = (hipStream_t)stream_;
     const bool dev = (flags & MOSHII_BUFFERS_DEVICE) != 0;
-    const int NP = m->NP, P = m->P, S = 2 * NP + 5;
+    const int NP = m->NP, P = m->P, E = o->n_shape, S = 2 * NP + 5 + E;   // hand-off state: [pose][pose_prev][trans][has_prev][first][shape]
+    if (E > 0 && E != m->nshape) return fail(MOSHII_ERR_ARG, "n_shape does not match moshii_model_set_free_shape");
     const int warmup = co ? std::max(0, co->warmup) : 32;
     const double tol = (co && co->verify_tol > 0.0) ? co->verify_tol : 1e-11;
     const bool rejoin = getenv("MOSHII_NO_REJOIN") == nullptr;   // repair chains stop where they re-join the stored trajectory
@@ -1015,6 +1016,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                 memcpy(h + 2 * NP, sq.init_trans, sizeof(double) * 3);
                 h[2 * NP + 3] = sq.init_pose_prev ? 1.0 : 0.0;
                 h[2 * NP + 4] = 0.0;
+                if (E > 0 && sq.init_shape) memcpy(h + 2 * NP + 5, sq.init_shape, sizeof(double) * E);
             }
             HIP_TRY(hipMalloc((void**)&d_init, hinit.size() * sizeof(double)));
             HIP_TRY(hipMemcpy(d_init, hinit.data(), hinit.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1034,6 +1036,24 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             dbs[q].msim = s.msim; dbs[q].errs = s.errs; dbs[q].iters = s.iters; dbs[q].status = s.status;
         }
     }
+    // extended variant: per-sequence shape rows (device) and per-chain scratch for the shape derivatives of the joint transforms
+    std::vector<double*> shp(n_seq, nullptr);
+    std::vector<char> shp_owned(n_seq, 0);
+    size_t qbytes = 0;
+    auto cleanup_shape = [&]() { for (int q = 0; q < n_seq; ++q) if (shp_owned[q] && shp[q]) hipFree(shp[q]); };
+    if (E > 0) {
+        const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;
+        qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
+        if ((rc = m->qscratch.reserve(qbytes * NC))) { cleanup(); return rc; }
+        m->qscratch.used = true; m->qscratch.last_stream = stream;
+        for (int q = 0; q < n_seq; ++q) {
+            if (dev) { shp[q] = seqs[q].shape; continue; }
+            if (seqs[q].F < 1) continue;
+            if (hipMalloc((void**)&shp[q], (size_t)seqs[q].F * E * sizeof(double)) != hipSuccess) { cleanup_shape(); cleanup(); return fail(MOSHII_ERR_HIP, "hipMalloc failed"); }
+            shp_owned[q] = 1;
+            hipMemsetAsync(shp[q], 0, (size_t)seqs[q].F * E * sizeof(double), stream);
+        }
+    }
     auto make_chain = [&](const Chunk& ck, int from, int idx, bool repair) {
         // a chain over frames [from, ck.e) of its sequence; rows are addressed relative to `from`
         const FrameBufs& b = dbs[ck.seq];
@@ -1050,6 +1070,10 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         cd.errs = b.errs ? b.errs + (size_t)from * MOSHII_NERR : nullptr;
         cd.iters = b.iters ? b.iters + (size_t)from * 2 : nullptr;
         cd.status = b.status ? b.status + (size_t)from : nullptr;
+        if (E > 0) {
+            cd.shape = shp[ck.seq] ? shp[ck.seq] + (size_t)from * E : nullptr;
+            cd.qscratch = (double*)(m->qscratch.ptr + qbytes * idx);      // repair chains reuse the slot of their first chunk
+        }
         cd.final_state = d_final + (size_t)idx * S;
         // every chain records the state with which it enters its first recorded frame; a repair chain's is the
         // predecessor's end state it was started from, so if that predecessor is itself re-solved later the
@@ -1075,7 +1099,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     int n_repaired = 0, rounds = 0;
     double max_dev = 0.0;
     while (true) {
-        hipLaunchKernelGGL(k_verify_chunks, dim3(NC), dim3(64), 0, stream, NC, NP, d_pred, d_entry, d_final, d_dev);
+        hipLaunchKernelGGL(k_verify_chunks, dim3(NC), dim3(64), 0, stream, NC, NP, E, d_pred, d_entry, d_final, d_dev);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(hdev.data(), d_dev, sizeof(double) * NC, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1154,7 +1178,13 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                   report->warmup = warmup; report->verify_tol = tol; }
     if (!dev)
         for (int q = 0; q < n_seq; ++q)
-            if ((rc = stage_out(fbs[q], NP, P, &st[q]))) { cleanup(); return rc; }
+            if ((rc = stage_out(fbs[q], NP, P, &st[q]))) { cleanup_shape(); cleanup(); return rc; }
+    if (!dev && E > 0) {
+        hipStreamSynchronize(stream);
+        for (int q = 0; q < n_seq; ++q)
+            if (shp[q] && seqs[q].shape) hipMemcpy(seqs[q].shape, shp[q], (size_t)seqs[q].F * E * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    cleanup_shape();
     cleanup();
     return MOSHII_OK;
 }

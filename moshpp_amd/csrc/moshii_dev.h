@@ -72,7 +72,7 @@ struct ChainDev {
     int* iters;
     int* status;
     // chunked sequences (moshii_sequence_solve): the first `skip` frames are warm-up -- solved, not recorded.
-    // state vectors are [pose NP][pose_prev NP][trans 3][has_prev][first] = 2 NP + 5 doubles.
+    // state vectors are [pose NP][pose_prev NP][trans 3][has_prev][first] = 2 NP + 5 doubles (+ [shape E] in the extended variant).
     int skip;
     const double* init_state;   // device; overrides init_pose/init_trans/init_prev/first when non-null
     double* entry_state;        // device or null: state on entering frame `skip`

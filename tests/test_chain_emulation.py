@@ -56,3 +56,22 @@ def test_chunked_sequence_solve_equals_sequential_chain_in_emulation():
                                                 num_chunks=4, warmup=6, verify_tol=1e-9)
     assert report['n_chunks'] == 4
     assert np.abs(outs[0]['fullpose'] - seq['fullpose']).max() < 1e-7 and np.abs(outs[0]['trans'] - seq['trans']).max() < 1e-8
+
+
+@pytest.mark.parametrize('kind,model_type', [('expr', 'smplx'), ('dmpl', 'smplh')])
+def test_chunked_sequence_solve_carries_the_free_shape_block_in_emulation(kind, model_type):
+    """moshii_sequence_solve with n_shape > 0: the expression / DMPL coefficients travel in the chunk hand-off states (verified with
+    pose and trans, re-solved from the predecessor's end state, rejoin test on the shape rows too) -- equal to the sequential chain."""
+    from tests.helpers import shape_case
+    F = 30
+    case = shape_case(model_type, F=F, M=40, E=4, seed=9, kind=kind)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_face=(kind == 'expr'), shape_kind=kind)
+        seq = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                    [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                             [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                             num_chunks=3, warmup=6, verify_tol=1e-9)
+    assert rep['n_chunks'] == 3 and np.abs(seq['shape']).max() > 0.2
+    assert np.abs(outs[0]['fullpose'] - seq['fullpose']).max() < 1e-7 and np.abs(outs[0]['shape'] - seq['shape']).max() < 1e-7
+    assert np.array_equal(outs[0]['status'], seq['status'])
