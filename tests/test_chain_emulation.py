@@ -75,3 +75,21 @@ def test_chunked_sequence_solve_carries_the_free_shape_block_in_emulation(kind, 
     assert rep['n_chunks'] == 3 and np.abs(seq['shape']).max() > 0.2
     assert np.abs(outs[0]['fullpose'] - seq['fullpose']).max() < 1e-7 and np.abs(outs[0]['shape'] - seq['shape']).max() < 1e-7
     assert np.array_equal(outs[0]['status'], seq['status'])
+
+
+def test_empty_frames_and_chain_continuation_in_emulation():
+    """Frames without any visible marker are skipped (status 1, chmosh.py:586-588) and the chain carries on; a chain continued from an
+    earlier chain's state (init_pose / init_trans / init_pose_prev, no first-frame schedule) reproduces the uninterrupted chain."""
+    case = oracle_case('smplh', F=12, M=53, seed=4, empty_frames=(5,))
+    with emulated_libmoshii() as capi:
+        dev = device_case(case)
+        args = (dev['model'], dev['prior'], dev['opts'])
+        full = capi.chain_solve_host(*args, [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        head = capi.chain_solve_host(*args, [dict(attach=dev['attach'], obs=case['obs'][:8], vis=case['vis'][:8], first=True)])[0]
+        tail = capi.chain_solve_host(*args, [dict(attach=dev['attach'], obs=case['obs'][8:], vis=case['vis'][8:], first=False,
+                                                  init_pose=head['pose'][7], init_trans=head['trans'][7], init_pose_prev=head['pose'][6])])[0]
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplh')
+    assert full['status'].tolist() == [0] * 5 + [1] + [0] * 6 and list(ref['frame_ids']) == [t for t in range(12) if t != 5]
+    solved = np.flatnonzero(full['status'] == 0)
+    assert np.abs(full['fullpose'][solved] - ref['fullpose']).max() < 1e-9
+    assert np.abs(np.vstack([head['fullpose'], tail['fullpose']])[solved] - full['fullpose'][solved]).max() < 1e-12
