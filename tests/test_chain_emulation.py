@@ -93,3 +93,39 @@ def test_empty_frames_and_chain_continuation_in_emulation():
     solved = np.flatnonzero(full['status'] == 0)
     assert np.abs(full['fullpose'][solved] - ref['fullpose']).max() < 1e-9
     assert np.abs(np.vstack([head['fullpose'], tail['fullpose']])[solved] - full['fullpose'][solved]).max() < 1e-12
+
+
+def test_bench_call_path_in_emulation():
+    """bench.py's device-resident path (workload.DeviceSequence: moshii_sequence_solve / moshii_chain_solve with MOSHII_BUFFERS_DEVICE,
+    outputs in caller-owned buffers; workload.solve_many_chunked with several sequence descriptors) run against the emulated library with
+    CPU tensors standing in for HBM: chunked == sequential, struct layouts of the ctypes descriptors match the header."""
+    from moshpp_amd import workload
+    with emulated_libmoshii():
+        job = workload.make_job('smplh', n_frames=24, n_markers=53, seed=3)
+        solver = workload.make_solver(job)
+        ds = workload.DeviceSequence(job, solver, 'cpu')
+        rep = ds.solve_chunked(None, num_chunks=3, warmup=5, verify_tol=1e-9)
+        chunked = ds.results()
+        ds.solve_sequential(None)
+        seq = ds.results()
+        two = [workload.DeviceSequence(job, solver, 'cpu') for _ in range(2)]
+        rep2 = workload.solve_many_chunked(two, None, num_chunks=3, warmup=5, verify_tol=1e-9)
+        many = [d.results() for d in two]
+    assert rep['n_chunks'] == 3 and rep2['n_chunks'] == 6
+    assert np.abs(chunked['fullpose'] - seq['fullpose']).max() < 1e-7 and np.array_equal(chunked['status'], seq['status'])
+    for r in many:
+        assert np.abs(r['fullpose'] - seq['fullpose']).max() < 1e-7
+
+
+def test_sequence_solve_continues_a_chain_in_emulation():
+    """moshii_sequence_desc.init_*: a chunked solve that starts from another chain's end state (how one sequence is spread over ranks)."""
+    case = oracle_case('smplh', F=36, M=53, seed=6)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case)
+        args = (dev['model'], dev['prior'], dev['opts'])
+        full = capi.chain_solve_host(*args, [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        outs, rep = capi.sequence_solve_host(*args, [dict(attach=dev['attach'], obs=case['obs'][12:], vis=case['vis'][12:],
+                                                         init_pose=full['pose'][11], init_trans=full['trans'][11],
+                                                         init_pose_prev=full['pose'][10])], num_chunks=3, warmup=5, verify_tol=1e-9)
+    assert rep['n_chunks'] == 3
+    assert np.abs(outs[0]['fullpose'] - full['fullpose'][12:]).max() < 1e-7
