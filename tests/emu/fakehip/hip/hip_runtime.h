@@ -26,6 +26,7 @@ void barrier();                                     // workgroup barrier
 void wave_sync();                                   // all lanes of the caller's wavefront rendezvous
 double wave_exchange(double v, int src_lane);       // value of `v` in lane `src_lane` of the caller's wavefront (all lanes call)
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `extern __shared__`: guarded beyond the launch's lds_bytes
 }
 
 #define __global__
@@ -102,6 +103,7 @@ inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
 // namespace, moshii_api.hip); with __shared__ = thread_local these block-scope externs need a definition in their namespace
 namespace moshii { inline alignas(16) thread_local double lds[160 * 1024 / 8]; }
 namespace { alignas(16) thread_local double sm[160 * 1024 / 8]; }
+namespace { struct HipEmuLdsRegistration { HipEmuLdsRegistration() { hipemu::register_dynamic_lds(moshii::lds, sizeof(moshii::lds)); hipemu::register_dynamic_lds(sm, sizeof(sm)); } } hipemu_lds_registration; }
 
 // the one inline-assembly statement of the chain kernel is a workgroup barrier ("s_waitcnt ...; s_barrier"):
 //   asm volatile("..." ::: "memory")  ->  hipemu::barrier()

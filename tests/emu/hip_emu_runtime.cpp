@@ -34,6 +34,14 @@ void yield_as(State s) {
 }
 }  // namespace
 
+struct LdsArray { double* base; size_t bytes; };
+std::vector<LdsArray>& lds_arrays() { static std::vector<LdsArray> v; return v; }
+void register_dynamic_lds(double* base, size_t bytes) {
+    for (auto& a : lds_arrays()) if (a.base == base) return;
+    lds_arrays().push_back(LdsArray{base, bytes});
+}
+static const double CANARY = -7.25e77;
+
 ThreadCtx& cur() { return fibers[cur_fiber].tc; }
 void barrier() { yield_as(AT_BARRIER); }
 void wave_sync() { fibers[cur_fiber].xsrc = -1; yield_as(AT_WAVE); }
@@ -44,8 +52,11 @@ double wave_exchange(double v, int src_lane) {
     return fibers[cur_fiber].xgot;
 }
 
-void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
     const int nt = (int)(block.x * block.y * block.z);
+    if (const char* e = getenv("HIPEMU_LDS_SHRINK")) { size_t cut = (size_t)atol(e); lds_bytes = lds_bytes > cut ? lds_bytes - cut : 0; }   // (self-test of the guard)
+    // everything beyond the dynamic LDS this launch asked for is a canary: a kernel writing past its allocation is caught below
+    for (auto& a : lds_arrays()) for (size_t i = (lds_bytes + 7) / 8; i < a.bytes / 8; ++i) a.base[i] = CANARY;
     while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
     for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
         fibers.assign(nt, Fiber());
@@ -82,7 +93,11 @@ void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
             }
             int live = 0, atb = 0;
             for (int t = 0; t < nt; ++t) { if (fibers[t].st != DONE) ++live; if (fibers[t].st == AT_BARRIER) ++atb; }
-            if (live == 0) break;
+            if (live == 0) {
+                for (auto& a : lds_arrays()) for (size_t i = (lds_bytes + 7) / 8; i < a.bytes / 8; ++i)
+                    if (a.base[i] != CANARY) { fprintf(stderr, "hipemu: write past the %zu bytes of dynamic LDS (double index %zu) in block %u\n", lds_bytes, i, bx); abort(); }
+                break;
+            }
             if (atb == live) { for (int t = 0; t < nt; ++t) if (fibers[t].st == AT_BARRIER) fibers[t].st = RUN; progressed = true; }
             if (!progressed) { fprintf(stderr, "hipemu: deadlock (divergent barrier / collective) in block %u\n", bx); abort(); }
         }
