@@ -12,6 +12,8 @@ SOURCES = ['moshii_api.hip', 'chain_solve.hip', 'lbs_forward.hip', 'stagei.hip']
 # default (measured 393 vs 414 us/frame on the bench sequence, same results); the LBS kernel pins its own order with sched_barriers
 # and is 4 % slower with it, so it keeps the default.
 EXTRA_FLAGS = {'chain_solve.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
+if os.environ.get('MOSHII_NO_ILP'):
+    EXTRA_FLAGS = {}
 HEADERS = ['moshii_dev.h', 'stagei_views.h', os.path.join('..', '..', 'include', 'moshii.h')]
 OUT = os.path.join(HERE, 'libmoshii.so')
 
@@ -31,17 +33,20 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True, profile=False):
-    """profile=True builds libmoshii_prof.so with in-kernel clock64() phase laps (tools/prof_chain.py)."""
-    out = OUT.replace('libmoshii.so', 'libmoshii_prof.so') if profile else OUT
-    if not force and not profile and not needs_build():
+def build(force=False, verbose=True, profile=False, variant=None, defines=()):
+    """profile=True builds libmoshii_prof.so with in-kernel clock64() phase laps (tools/prof_chain.py).
+    variant / defines: development builds libmoshii_<variant>[_prof].so with extra -D flags (kernel experiments; selected at run
+    time with MOSHII_LIB)."""
+    tag = ('_' + variant if variant else '') + ('_prof' if profile else '')
+    out = OUT.replace('libmoshii.so', f'libmoshii{tag}.so')
+    if not force and not tag and not needs_build():
         return OUT
     objs = []
     procs = []
     for s in SOURCES:
-        obj = os.path.join(CSRC, s.replace('.hip', '_prof.o' if profile else '.o'))
+        obj = os.path.join(CSRC, s.replace('.hip', f'{tag}.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-value',
-               '-c', os.path.join(CSRC, s), '-o', obj] + (['-DMOSHII_PROFILE'] if profile else []) + EXTRA_FLAGS.get(s, [])
+               '-c', os.path.join(CSRC, s), '-o', obj] + (['-DMOSHII_PROFILE'] if profile else []) + list(defines) + EXTRA_FLAGS.get(s, [])
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -57,4 +62,6 @@ def build(force=False, verbose=True, profile=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, profile='--profile' in sys.argv))
+    _var = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--variant=')]
+    print(build(force='--force' in sys.argv, profile='--profile' in sys.argv, variant=_var[0] if _var else None,
+                defines=[a for a in sys.argv[1:] if a.startswith('-D')]))

@@ -14,8 +14,11 @@
 // registers with one LDS-published column and one barrier per step.  DESIGN.md section 4 has the
 // per-phase timings and the rules this file follows (branch-free LDS traffic, loads batched ahead of use).
 #include "moshii_dev.h"
+#include <utility>
 
 namespace moshii {
+
+typedef double v2d __attribute__((vector_size(16)));   // one 16-byte load
 
 #ifdef MOSHII_PROFILE
 __device__ long long g_prof[32];
@@ -54,15 +57,49 @@ struct FrameParams {
 
 struct Sse { double data, prior, velo, hand, total, face, shape, stay; };
 
+// Cross-lane moves on the DPP path (a v_mov per 32-bit half: no LDS crossbar round trip as with ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane /* wave-uniform */) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+enum { DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140 };
+
+// Sum over the wavefront, the bitwise-identical total in every lane: an exchange butterfly inside each row of 16 lanes
+// (pairs, quads, halves, row -- both partners add the same two numbers, so all 16 lanes agree), then the four row sums.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v += dpp_f64<DPP_QUAD_1032>(v);
+    v += dpp_f64<DPP_QUAD_2301>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ void wave_sum3(double& a, double& b, double& c) {   // three independent reductions, interleaved
+    a += dpp_f64<DPP_QUAD_1032>(a); b += dpp_f64<DPP_QUAD_1032>(b); c += dpp_f64<DPP_QUAD_1032>(c);
+    a += dpp_f64<DPP_QUAD_2301>(a); b += dpp_f64<DPP_QUAD_2301>(b); c += dpp_f64<DPP_QUAD_2301>(c);
+    a += dpp_f64<DPP_ROW_HALF_MIRROR>(a); b += dpp_f64<DPP_ROW_HALF_MIRROR>(b); c += dpp_f64<DPP_ROW_HALF_MIRROR>(c);
+    a += dpp_f64<DPP_ROW_MIRROR>(a); b += dpp_f64<DPP_ROW_MIRROR>(b); c += dpp_f64<DPP_ROW_MIRROR>(c);
+    a = (readlane_f64(a, 0) + readlane_f64(a, 16)) + (readlane_f64(a, 32) + readlane_f64(a, 48));
+    b = (readlane_f64(b, 0) + readlane_f64(b, 16)) + (readlane_f64(b, 32) + readlane_f64(b, 48));
+    c = (readlane_f64(c, 0) + readlane_f64(c, 16)) + (readlane_f64(c, 32) + readlane_f64(c, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_f64<DPP_QUAD_1032>(v));
+    v = fmax(v, dpp_f64<DPP_QUAD_2301>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 // Sum over the 256-thread block; every thread returns the bitwise-identical total.
 __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red) {
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    wave_sum3(a, b, c);
     __syncthreads();
     const int tid = threadIdx.x;
     if ((tid & 63) == 0) { red[(tid >> 6) * 3 + 0] = a; red[(tid >> 6) * 3 + 1] = b; red[(tid >> 6) * 3 + 2] = c; }
@@ -77,8 +114,7 @@ __device__ __forceinline__ double block_sum(double a, double* red) {
     return a;
 }
 __device__ __forceinline__ double block_max(double a, double* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a = fmax(a, __shfl_down(a, o, 64));
+    a = wave_max(a);
     __syncthreads();
     const int tid = threadIdx.x;
     if ((tid & 63) == 0) red[tid >> 6] = a;
@@ -226,20 +262,32 @@ __device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev&
     for (int it = tid; it < 3 * Nvh; it += MOSHII_TPB) {
         const int i = it / Nvh, a2 = it - i * Nvh;
         double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0, s2x = 0.0, s2y = 0.0;
-        const double2* pp = reinterpret_cast<const double2*>(at.Pt) + (size_t)(i * 9) * Nvh + a2;
-#pragma unroll 3
-        for (int idx = 0; idx < nk; ++idx) {
-            const int k = klist[idx];
-            const double* f = &cx.feat[k * 9];
-            const double2* pk = pp + (size_t)((k - 1) * 27) * Nvh;
-            double2 q[9];
+        const auto* pp = gptr(reinterpret_cast<const v2d*>(at.Pt)) + (size_t)(i * 9) * Nvh + a2;
+        // bursts of PB joints: all 9 PB row loads of a burst are issued before the first is consumed.  The stream runs at the
+        // CU's L2 bandwidth only with >= 27 loads in flight per lane (measured: 9 in flight 39 us/frame, 27 in flight 30;
+        // interleaving the loads with the multiplies of the previous joint was slower than either).
+        constexpr int PB = 3;
+        for (int idx0 = 0; idx0 < nk; idx0 += PB) {
+            v2d q[PB][9];
+            int kk[PB];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) q[e] = pk[(size_t)e * Nvh];
+            for (int u = 0; u < PB; ++u) {
+                kk[u] = klist[min(idx0 + u, nk - 1)];   // (past the list: a re-read that is not added)
+                const auto* pk = pp + (size_t)((kk[u] - 1) * 27) * Nvh;
 #pragma unroll
-            for (int e = 0; e < 9; e += 3) {
-                s0x += q[e].x * f[e]; s0y += q[e].y * f[e];
-                s1x += q[e + 1].x * f[e + 1]; s1y += q[e + 1].y * f[e + 1];
-                s2x += q[e + 2].x * f[e + 2]; s2y += q[e + 2].y * f[e + 2];
+                for (int e = 0; e < 9; ++e) q[u][e] = pk[(size_t)e * Nvh];
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (idx0 + u < nk) {   // (uniform)
+                    const double* f = &cx.feat[kk[u] * 9];
+#pragma unroll
+                    for (int e = 0; e < 9; e += 3) {
+                        s0x += q[u][e][0] * f[e]; s0y += q[u][e][1] * f[e];
+                        s1x += q[u][e + 1][0] * f[e + 1]; s1y += q[u][e + 1][1] * f[e + 1];
+                        s2x += q[u][e + 2][0] * f[e + 2]; s2y += q[u][e + 2][1] * f[e + 2];
+                    }
+                }
             }
         }
         const int a = 2 * a2;
@@ -270,7 +318,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             const int E = op.nshape, Nvp = at.Nvp;
             const double* shp = pose + md.NP;
             for (int i = tid; i < 3 * K; i += MOSHII_TPB) {   // J = J0 + JS . s
-                const double* js = md.JS + (size_t)(i / 3) * E * 3 + (i % 3);
+                const auto* js = md.JS + (size_t)(i / 3) * E * 3 + (i % 3);
                 double s0 = md.J[i], s1 = 0.0;
                 int e = 0;
                 for (; e + 2 <= E; e += 2) { s0 += js[e * 3] * shp[e]; s1 += js[(e + 1) * 3] * shp[e + 1]; }
@@ -279,7 +327,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             }
             for (int it = tid; it < 3 * Nvp; it += MOSHII_TPB) {   // rest vertices: vbase + S . s (vertex fastest: coalesced rows)
                 const int i = it / Nvp, a = it - i * Nvp;
-                const double* sp = at.Ssh + (size_t)i * Nvp + a;
+                const auto* sp = gptr(at.Ssh) + (size_t)i * Nvp + a;
                 const size_t st = (size_t)3 * Nvp;
                 double s0 = 0.0, s1 = 0.0;
                 int e = 0;
@@ -345,8 +393,8 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         const double px = cx.vposed[a * 3 + 0], py = cx.vposed[a * 3 + 1], pz = cx.vposed[a * 3 + 2];
         double ax = 0.0, ay = 0.0, az = 0.0;
         for (int s = 0; s < NW; ++s) {
-            const int j = at.wj[a * NW + s];
-            const double w = at.ww[a * NW + s];
+            const int j = gptr(at.wj)[a * NW + s];
+            const double w = gptr(at.ww)[a * NW + s];
             double ox, oy, oz;
             mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
             ax += w * (ox + cx.tw[j * 3 + 0]);
@@ -363,13 +411,13 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     const int M = at.M;
     for (int m = tid; m < M; m += MOSHII_TPB) {
         double mk[3];
-        const double c[3] = {at.coef[m * 3 + 0], at.coef[m * 3 + 1], at.coef[m * 3 + 2]};
+        const double c[3] = {gptr(at.coef)[m * 3 + 0], gptr(at.coef)[m * 3 + 1], gptr(at.coef)[m * 3 + 2]};
         marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, nullptr);
-        const bool v = visrow != nullptr && visrow[m] != 0;
+        const bool v = visrow != nullptr && gptr(visrow)[m] != 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             cx.msim[m * 3 + i] = mk[i];
-            const double r = v ? fp.wt_data * (mk[i] - fp.obs[m * 3 + i]) : 0.0;
+            const double r = v ? fp.wt_data * (mk[i] - gptr(fp.obs)[m * 3 + i]) : 0.0;
             cx.res[m * 3 + i] = r;
             sd += r * r;
         }
@@ -395,74 +443,143 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     }
     // F7: prior: l_g = sqrt(.5) (x - mu_g) . L_g for every component, argmin of |l_g|^2 - log w_g
     const int np_ = op.nbody;
+    double prior_ss = 0.0;
     if (np_ > 0) {
         for (int b = tid; b < np_; b += MOSHII_TPB) cx.xb[b] = pose[op.body[b]];
         __syncthreads();
         const int G = pr.G;
-        // one wavefront per mixture component; lane a accumulates column a (and a + 64) of L_g while b runs uniformly over
-        // the rows, so that every load is one contiguous run of row b -- eight rows in flight per lane -- and |l_g|^2 falls
-        // out of a wave reduction.  x - mu_g is parked in this component's slice of cx.ell first (the wavefront's LDS
-        // operations complete in order, so its own later overwrite with l_g is safe).
+        // one wavefront per PAIR of mixture components; lane a accumulates column a (and a + 64) of both L_g while b runs
+        // uniformly over the rows, so that every load is one contiguous run of row b; 2 x 16 row loads are in flight per lane
+        // and every column sum is split into an even-row and an odd-row chain (four independent fma chains per lane: a
+        // single chain of 63 dependent f64 fmas per component was most of this phase).  The entries above the diagonal are
+        // stored zeros (moshii_prior_create), so no triangle mask is needed.  x - mu_g is parked in the component's slice of
+        // cx.ell (uniform-address LDS reads below); |l_g|^2 falls out of a wave reduction.
         {
             const int lane = tid & 63;
             const int c0 = min(lane, np_ - 1), c1 = min(lane + 64, np_ - 1);   // clamped: every load is in bounds, no branch
-            for (int gc = tid >> 6; gc < G; gc += MOSHII_TPB / 64) {
-                const double* Lg = pr.chols + (size_t)gc * np_ * np_;
-                const double* mu = pr.means + (size_t)gc * np_;
-                double* dxg = &cx.ell[gc * np_];
-                for (int b = lane; b < np_; b += 64) dxg[b] = cx.xb[b] - mu[b];
+            for (int ga = (tid >> 6) * 2; ga < G; ga += (MOSHII_TPB / 64) * 2) {
+                const int gb = min(ga + 1, G - 1);   // (odd G: the last wave works its component twice)
+                const auto* La = pr.chols + (size_t)ga * np_ * np_;
+                const auto* Lb = pr.chols + (size_t)gb * np_ * np_;
+                double* dxa = &cx.ell[ga * np_];
+                double* dxb = &cx.ell[gb * np_];
+                for (int b = lane; b < np_; b += 64) { dxa[b] = cx.xb[b] - pr.means[(size_t)ga * np_ + b]; dxb[b] = cx.xb[b] - pr.means[(size_t)gb * np_ + b]; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                double s0 = 0.0, s1 = 0.0;
-                for (int b0 = 0; b0 < np_; b0 += 32) {   // 32 coalesced row loads in flight per lane
-                    double v[32];
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                for (int r0 = 0; r0 < np_; r0 += 16) {
+                    double va[16], vb[16];
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) v[k] = Lg[(size_t)min(b0 + k, np_ - 1) * np_ + c0];
+                    for (int k = 0; k < 16; ++k) {
+                        const size_t ro = (size_t)min(r0 + k, np_ - 1) * np_ + c0;
+                        va[k] = La[ro]; vb[k] = Lb[ro];
+                    }
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) {
-                        const int b = b0 + k;
-                        const double dx = dxg[min(b, np_ - 1)];
-                        // lower triangle: rows b >= column.  The 0/1 factor (instead of a conditional expression) keeps the
-                        // LDS read above unconditional: hipcc otherwise sinks it into an exec-masked branch with its own
-                        // lgkmcnt(0) wait -- 63 serialized LDS round trips per component.
-                        const double m = (b < np_ && lane <= b) ? 1.0 : 0.0;
-                        s0 = fma(dx * m, v[k], s0);
+                    for (int k = 0; k < 16; k += 2) {
+                        const int r = r0 + k;
+                        const double m0 = (r < np_) ? 1.0 : 0.0, m1 = (r + 1 < np_) ? 1.0 : 0.0;   // (uniform)
+                        const int q0 = min(r, np_ - 1), q1 = min(r + 1, np_ - 1);
+                        a0 = fma(dxa[q0] * m0, va[k], a0); a1 = fma(dxa[q1] * m1, va[k + 1], a1);
+                        b0 = fma(dxb[q0] * m0, vb[k], b0); b1 = fma(dxb[q1] * m1, vb[k + 1], b1);
                     }
                 }
-                if (np_ > 64)   // columns 64.. (SMPL's 69-dof prior): rows b >= 64 only
-                    for (int b = 64; b < np_; ++b) { const double v1 = Lg[(size_t)b * np_ + c1]; const double m = (lane + 64 <= b) ? 1.0 : 0.0; s1 = fma(dxg[b] * m, v1, s1); }
-                s0 *= 0.70710678118654757; s1 *= 0.70710678118654757;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < np_) cx.ell[gc * np_ + lane] = s0;
-                if (lane + 64 < np_) cx.ell[gc * np_ + lane + 64] = s1;
-                const double sq = wave_sum(s0 * s0 + s1 * s1);
-                if (lane == 0) cx.score[gc] = sq;
+                double sa = (a0 + a1) * 0.70710678118654757, sb = (b0 + b1) * 0.70710678118654757;
+                double sqa = (lane < np_) ? sa * sa : 0.0, sqb = (lane < np_) ? sb * sb : 0.0;
+                if (np_ > 64) {   // columns 64.. (SMPL's 69-dof prior): rows b >= 64 only
+                    double ha = 0.0, hb = 0.0;
+                    for (int b = 64; b < np_; ++b) { ha = fma(dxa[b], La[(size_t)b * np_ + c1], ha); hb = fma(dxb[b], Lb[(size_t)b * np_ + c1], hb); }
+                    ha *= 0.70710678118654757; hb *= 0.70710678118654757;
+                    if (lane + 64 < np_) { sqa += ha * ha; sqb += hb * hb; }
+                }
+                double dum = 0.0;
+                wave_sum3(sqa, sqb, dum);
+                if (lane == 0) { cx.score[ga] = sqa; cx.score[gb] = sqb; }
             }
         }
         __syncthreads();
-        if (tid == 0) {
+        {   // argmin by every thread for itself (uniform LDS / scalar reads: no single-thread section to wait for)
             int kb = 0;
             double best = cx.score[0] + pr.neglogw[0];
             for (int gc = 1; gc < G; ++gc) {
                 const double sc = cx.score[gc] + pr.neglogw[gc];
                 if (sc < best) { best = sc; kb = gc; }
             }
-            cx.scal[S_KBEST] = (double)kb;
-            cx.scal[S_PRIOR_SS] = cx.score[kb] + pr.neglogw[kb];
+            prior_ss = best;
+            if (tid == 0) cx.scal[S_KBEST] = (double)kb;   // (read by assemble(), many barriers later)
         }
     }
-    block_sum3(sd, sv, sh, cx.red);   // (contains the barriers that publish scal[])
+    block_sum3(sd, sv, sh, cx.red);
     if constexpr (XT) block_sum3(sf, ss, sy, cx.red);
     PROF_LAP(3);
     Sse out;
     out.data = sd; out.velo = sv; out.hand = sh;
     out.face = sf; out.shape = ss; out.stay = sy;
-    out.prior = (np_ > 0) ? fp.wt_pose * fp.wt_pose * cx.scal[S_PRIOR_SS] : 0.0;
+    out.prior = (np_ > 0) ? fp.wt_pose * fp.wt_pose * prior_ss : 0.0;
     out.total = ((out.data + out.prior) + out.velo) + out.hand;
     if constexpr (XT) out.total += (sf + ss) + sy;
     return out;
 }
+
+// ------------------------------------------------------------------------------------------------
+// J^T J on the matrix pipe.  The lower-triangle 16x16 tiles (bi, bj), numbered e = bi (bi + 1) / 2 + bj, are dealt to the
+// four wavefronts round-robin (tile e belongs to wave e % 4); a wave accumulates its tiles with v_mfma_f64_16x16x4_f64
+// over groups of four Jacobian rows: lane l supplies J[r0 + (l >> 4)][16 b + (l & 15)] -- the SAME fragment serves as the
+// A operand of block-row b and as the B operand of block-column b, so a row group costs NBLK 8-byte LDS reads per lane
+// for up to ceil(NE / 4) MFMAs (the former register-tile form read 2 NBLK operands per row per thread for NE fmas and ran
+// at LDS speed).  Result layout (f64 MFMA): lane l, register i holds C[(l >> 4) + 4 i][l & 15].
+// ------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((vector_size(32)));
+
+constexpr int tile_bi(int e) { int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= e) ++bi; return bi; }
+constexpr int tile_bj(int e) { return e - tile_bi(e) * (tile_bi(e) + 1) / 2; }
+
+template <int NBLK>
+struct JtJAcc {
+    static constexpr int NE = NBLK * (NBLK + 1) / 2;
+    static constexpr int NT = (NE + 3) / 4;      // tiles per wave
+    static constexpr int XR = 16;                // tiles per exchange round (XR x 256 doubles of LDS)
+    v4d c[NT];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) c[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
+    template <int W, int T>
+    __device__ __forceinline__ void mm1(const double (&f)[NBLK]) {
+        constexpr int e = 4 * T + W;
+        if constexpr (e < NE) {
+            constexpr int bi = tile_bi(e), bj = tile_bj(e);
+            c[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], c[T], 0, 0, 0);
+        }
+    }
+    template <int W, int... T>
+    __device__ __forceinline__ void mm(const double (&f)[NBLK], std::integer_sequence<int, T...>) { (mm1<W, T>(f), ...); }
+    // c += rows^T rows over this wave's tiles (rows: nr x LDJ in LDS; rows >= nr of the last group count as zero)
+    template <int W>
+    __device__ __forceinline__ void accumulate_w(const double* rows, int nr, int LDJ) {
+        const int lane = threadIdx.x & 63, kr = lane >> 4, cc = lane & 15;
+        for (int r0 = 0; r0 < nr; r0 += 8) {   // two row groups per trip: 2 NBLK reads in flight
+            double f0[NBLK], f1[NBLK];
+            const int ra = r0 + kr, rb = r0 + 4 + kr;
+            const double* pa = rows + min(ra, nr - 1) * LDJ + cc;
+            const double* pb = rows + min(rb, nr - 1) * LDJ + cc;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) { f0[b] = pa[16 * b]; f1[b] = pb[16 * b]; }
+            const double la = (ra < nr) ? 1.0 : 0.0, lb = (rb < nr) ? 1.0 : 0.0;   // (the clamped re-read of the last row must not count)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) { f0[b] *= la; f1[b] *= lb; }
+            mm<W>(f0, std::make_integer_sequence<int, NT>());
+            mm<W>(f1, std::make_integer_sequence<int, NT>());
+        }
+    }
+    __device__ __forceinline__ void accumulate(const double* rows, int nr, int LDJ) {
+        switch (threadIdx.x >> 6) {   // wave-uniform: the tile indices of a wave are compile-time constants in its branch
+            case 0: accumulate_w<0>(rows, nr, LDJ); break;
+            case 1: accumulate_w<1>(rows, nr, LDJ); break;
+            case 2: accumulate_w<2>(rows, nr, LDJ); break;
+            default: accumulate_w<3>(rows, nr, LDJ); break;
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // J^T J in registers: thread (ty, tx) of a 16x16 grid owns A[bi*16+ty][bj*16+tx] for bj <= bi.
@@ -475,29 +592,31 @@ struct AReg {
 #pragma unroll
         for (int e = 0; e < NE; ++e) a[e] = 0.0;
     }
-    // A += rows^T rows  (rows: nr x LDJ in LDS, columns >= n are zero)
-    __device__ __forceinline__ void rank_update(const double* rows, int nr, int LDJ) {
-        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-        constexpr int RB = (NBLK <= 5) ? 4 : 2;   // rows per batch: all 2 NBLK RB LDS reads are issued before the first multiply
-        for (int r0 = 0; r0 < nr; r0 += RB) {
-            double av[RB][NBLK], bv[RB][NBLK];
+    // a = the tiles of acc, re-dealt to the interleaved ownership above.  Register i of lane l of the owning wave holds entry
+    // ((l >> 4) + 4 i, l & 15) of its tile, which is thread (wave i, lane l)'s entry here: the exchange is one 8-byte LDS word
+    // per (tile, register, lane), written and read conflict-free.  X: XR x 256 doubles of LDS nobody else uses meanwhile
+    // (callers: the Jacobian tile region after its last use); all threads call.
+    __device__ __forceinline__ void take(const JtJAcc<NBLK>& acc, double* X) {
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        constexpr int XR = JtJAcc<NBLK>::XR;
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const double* row = rows + min(r0 + k, nr - 1) * LDJ;
+        for (int e0 = 0; e0 < NE; e0 += XR) {
+            if (e0 > 0) __syncthreads();   // the previous round's reads are done
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) { av[k][b] = row[b * 16 + ty]; bv[k][b] = row[b * 16 + tx]; }
-            }
+            for (int tt = 0; tt < XR / 4; ++tt) {
+                const int t = e0 / 4 + tt;
+                if (t < JtJAcc<NBLK>::NT) {
+                    const int e = 4 * t + w;
+                    if (e < NE) {
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const double live = (r0 + k < nr) ? 1.0 : 0.0;   // the clamped re-read of the last row counts once
-                int e = 0;
-#pragma unroll
-                for (int bi = 0; bi < NBLK; ++bi) {
-                    const double al = live * av[k][bi];
-#pragma unroll
-                    for (int bj = 0; bj <= bi; ++bj) { a[e] += al * bv[k][bj]; ++e; }
+                        for (int i = 0; i < 4; ++i) X[(e - e0) * 256 + i * 64 + lane] = acc.c[t][i];
+                    }
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (int e = e0; e < e0 + XR; ++e)
+                if (e < NE) a[e] = X[(e - e0) * 256 + w * 64 + lane];
         }
     }
     __device__ __forceinline__ void add_diag(const double* dvec /* LDS [n] */, int n) {
@@ -513,7 +632,7 @@ struct AReg {
             }
     }
     // A[q1][q2] += scale * Pk[colprior[q1]][colprior[q2]]   (branch-free: clamped gathers, 0/1 factor)
-    __device__ __forceinline__ void add_prior(double scale, const double* Pk, int np_, const int* colprior, int n) {
+    __device__ __forceinline__ void add_prior(double scale, MOSHII_GP(const double) Pk, int np_, const int* colprior, int n) {
         const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
         int pr_[NBLK], pc_[NBLK];
 #pragma unroll
@@ -561,12 +680,6 @@ struct AReg {
     }
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int lane /* wave-uniform */) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 // Solve A d = g by a right-looking L D L^T elimination carried out in REGISTERS: every thread keeps a working copy
 // of its 16x16-interleaved entries of [A; g^T] (the right-hand side rides along as row n), and per column j
 //   owners of column j publish c_ij = l_ij d_j (their current entries) to the packed factor in LDS,
@@ -577,8 +690,18 @@ __device__ __forceinline__ double readlane_f64(double v, int lane /* wave-unifor
 // x_j = (b_j - sum_{i>j} c_ij x_i) / d_j from the packed factor.  A itself is left untouched (the dogleg needs
 // d^T A d afterwards).  Returns false on a non-positive pivot (the reference would fall back to lstsq; callers
 // take the Cauchy step).
+// NOT inlined, and handed LDS offsets instead of pointers: inside the frame loop this code shared the register file with
+// the whole solver state -- the elimination step then reloaded spilled scalars from scratch memory (a vector-memory round
+// trip, several per step, in the one loop of the kernel whose cost is pure latency).  As a function of its own it is
+// allocated with nothing live but its arguments.
+// (Two functions, elimination and back-substitution: as one, hipcc's register allocator crashes on it under the
+// iterative-ILP scheduler the rest of this file is built with.)
 template <int NBLK>
-__device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, double* d, double* pinv, int n) {
+__device__ __noinline__ bool ldl_factor(const AReg<NBLK> A, int o_Lp, int o_g, int o_pinv, int n) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const Lp = lds + o_Lp;
+    const double* const g = lds + o_g;
+    double* const pinv = lds + o_pinv;
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
     PROF_BEGIN(); PROF_COUNT(22);
@@ -601,18 +724,20 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
     // steps ahead of another after both passed the barrier in between).  Two columns are eliminated per step: one
     // barrier and one LDS round trip per PAIR; the second column's entries are corrected by the first on the fly,
     //   c'_{i,j+1} = c_{i,j+1} - c_{ij} a / d_j ,   d'_{j+1} = d_{j+1} - a^2 / d_j ,   a = A[j+1][j].
-    // Stores that do not apply go to `trash`, loads that do not apply read `zero` (= 0.0): straight-line LDS traffic.
-    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
+    // Stores that do not apply go to a per-lane `trash` word (64 of them: a shared one made every such store a many-way
+    // same-bank write), loads that do not apply read `zero` (= 0.0): straight-line LDS traffic.
+    const int trash = (n + 1) * (n + 2) / 2 + (tid & 63), zero = (n + 1) * (n + 2) / 2 + 64;
     constexpr int CVR = NBLK * 16;                 // rows of one broadcast column
-    double* const Sl = Lp + trash;                 // [0] trash word, [1] zero word, [2..] Cv
-    double* Cv = Sl + 2;                           // [2][2][CVR]
+    double* const Sl = Lp + trash;                 // this lane's trash word
+    double* const Zr = Lp + zero;                  // the zero word
+    double* Cv = Zr + 2;                           // [2][2][CVR]
     int rS[NBLK];                                  // packed offset of this thread's row q1 (or -1 beyond the border row)
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int q1 = b * 16 + ty;
         rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
     }
-    if (tid == 0) Sl[1] = 0.0;
+    if (tid == 0) Zr[0] = 0.0;
     bool ok = true;
     int step = 0;
     // outer loop over 16-column blocks is unrolled, so every register index below is a compile-time constant
@@ -636,29 +761,32 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
             }
             __syncthreads();
             const double p0 = cv[j], a10 = cv[j + 1], p1r = cv[CVR + j + 1];
+            // Row / column entries of the two pivot columns, read WITHOUT a validity mask: the entries this leaves wrong are
+            // dead ones -- rows or columns <= j + 1 are final and published, rows beyond the border row n are zero and stay
+            // zero, and the corner (n, n) is never read -- so nothing that is used later sees them.
             double ci0[NBLK], ci1[NBLK], ck0[NBLK], ck1[NBLK];
 #pragma unroll
             for (int b = bj0; b < NBLK; ++b) {
                 const int q1 = b * 16 + ty, q2 = b * 16 + tx;
-                const bool vr = q1 > j + 1 && q1 <= n, vc = q2 > j + 1 && q2 <= n;
-                const double* zr = Sl + 1;   // (address select, not value select: the loads stay unconditional)
-                const double* r0 = vr ? cv + q1 : zr; const double* r1 = vr ? cv + CVR + q1 : zr;
-                const double* c0p = vc ? cv + q2 : zr; const double* c1p = vc ? cv + CVR + q2 : zr;
-                ci0[b] = *r0; ci1[b] = *r1; ck0[b] = *c0p; ck1[b] = *c1p;
+                ci0[b] = cv[q1]; ci1[b] = cv[CVR + q1]; ck0[b] = cv[q2]; ck1[b] = cv[CVR + q2];
             }
-            if (!(p0 > 0.0)) { ok = false; break; }   // uniform: every thread reads the same LDS words
+            // (no exit between the barrier and the arithmetic: all LDS reads of the step are issued together, ONE round trip;
+            //  a non-positive pivot -- every thread sees the same two -- ends the elimination after this step's (then
+            //  meaningless) update)
+            const bool bad0 = !(p0 > 0.0);
             // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
             double pin0 = __builtin_amdgcn_rcp(p0);
             pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
             pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
             const double l10 = a10 * pin0;
             const double p1 = pair ? fma(-a10, l10, p1r) : 1.0;
-            if (!(p1 > 0.0)) { ok = false; break; }
+            const bool bad = bad0 || !(p1 > 0.0);
             double pin1 = __builtin_amdgcn_rcp(p1);
             pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
             pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
             if (!pair) pin1 = 0.0;
-            if (tid == 0) { pinv[j] = pin0; if (pair) pinv[j + 1] = pin1; }
+            *((tid == 0) ? pinv + j : Sl) = pin0;              // (branch-free: the other threads write their trash word)
+            *((tid == 0 && pair) ? pinv + j + 1 : Sl) = pin1;
 #pragma unroll
             for (int b = bj0; b < NBLK; ++b) {
                 ci1[b] = fma(-ci0[b], l10, ci1[b]);          // column j+1 corrected by column j
@@ -674,40 +802,69 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
                     const int e = bi * (bi + 1) / 2 + bj;
                     w[e] = fma(-ci1[bi], ck1[bj], fma(-ci0[bi], ck0[bj], w[e]));
                 }
+            if (bad) { ok = false; break; }
         }
     }
     __syncthreads();
     PROF_LAP(9);
-    if (!ok) return false;
+    return ok;
+}
+
+template <int NBLK>
+__device__ __noinline__ void ldl_backsub(int o_Lp, int o_d, int o_pinv, int n) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const double* const Lp = lds + o_Lp;
+    double* const d = lds + o_d;
+    const double* const pinv = lds + o_pinv;
+    const int tid = threadIdx.x;
+    const int zero = (n + 1) * (n + 2) / 2 + 64;
+    PROF_BEGIN();
     // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
-    // Row j of the factor and 1/d_j are fetched one step ahead (off the readlane -> multiply -> fma chain); rows are
-    // read branch-free (lanes beyond the row read the zero word).
+    // Rows of the factor and 1/d_j are fetched a whole group of U steps ahead (an LDS round trip is several times the
+    // readlane -> multiply -> fma chain of a step); rows are read branch-free (lanes beyond the row read the zero word).
     if (tid < 64) {
+        constexpr int U = 8;
+        constexpr bool HI = NBLK > 4;   // unknowns 64.. exist
         const int base = n * (n + 1) / 2;
         double y0 = Lp[(tid < n) ? base + tid : zero];
-        double y1 = Lp[(tid + 64 < n) ? base + tid + 64 : zero];
-        int rowj = (n - 1) * n / 2;
-        double l0 = Lp[(tid < n - 1) ? rowj + tid : zero];
-        double l1 = Lp[(tid + 64 < n - 1) ? rowj + tid + 64 : zero];
-        double pv = pinv[n - 1];
-        for (int jv = n - 1; jv >= 0; --jv) {
-            const int j = __builtin_amdgcn_readfirstlane(jv);
-            const int jn = (j > 0) ? j - 1 : 0;   // next row (row 0 is re-read harmlessly at the last step)
-            rowj -= j;                            // (j-1) j / 2
-            const double nl0 = Lp[(tid < jn) ? rowj + tid : zero];
-            const double nl1 = Lp[(tid + 64 < jn) ? rowj + tid + 64 : zero];
-            const double npv = pinv[jn];
-            const double yj = (j < 64) ? readlane_f64(y0, j) : readlane_f64(y1, j - 64);
-            const double dj = yj * pv;
-            y0 = (tid == j) ? dj : fma(-l0, dj, y0);        // l0 / l1 are zero on and beyond the diagonal
-            y1 = (tid + 64 == j) ? dj : fma(-l1, dj, y1);
-            l0 = nl0; l1 = nl1; pv = npv;
+        double y1 = HI ? Lp[(tid + 64 < n) ? base + tid + 64 : zero] : 0.0;
+        double L0[U], L1[U], PV[U];
+        auto fetch = [&](int jr, double& a0, double& a1, double& pv) {   // row jr (rows below 0: row 0 again, harmlessly)
+            const int jn = max(jr, 0), off = jn * (jn + 1) / 2;
+            a0 = Lp[(tid < jn) ? off + tid : zero];
+            a1 = HI ? Lp[(tid + 64 < jn) ? off + tid + 64 : zero] : 0.0;
+            pv = pinv[jn];
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(n - 1 - u, L0[u], L1[u], PV[u]);
+        for (int jb = n - 1; jb >= 0; jb -= U) {
+            double N0[U], N1[U], NPV[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) fetch(jb - U - u, N0[u], N1[u], NPV[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = __builtin_amdgcn_readfirstlane(jb - u);
+                if (j >= 0) {
+                    const double yj = (!HI || j < 64) ? readlane_f64(y0, j) : readlane_f64(y1, j - 64);
+                    const double dj = yj * PV[u];
+                    y0 = (tid == j) ? dj : fma(-L0[u], dj, y0);        // L0 / L1 are zero on and beyond the diagonal
+                    if (HI) y1 = (tid + 64 == j) ? dj : fma(-L1[u], dj, y1);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { L0[u] = N0[u]; L1[u] = N1[u]; PV[u] = NPV[u]; }
         }
         if (tid < n) d[tid] = y0;
-        if (tid + 64 < n) d[tid + 64] = y1;
+        if (HI && tid + 64 < n) d[tid + 64] = y1;
     }
     __syncthreads();
     PROF_LAP(10);
+}
+
+template <int NBLK>
+__device__ __forceinline__ bool ldl_solve(const AReg<NBLK>& A, int o_Lp, int o_g, int o_d, int o_pinv, int n) {
+    if (!ldl_factor<NBLK>(A, o_Lp, o_g, o_pinv, n)) return false;
+    ldl_backsub<NBLK>(o_Lp, o_d, o_pinv, n);
     return true;
 }
 
@@ -719,7 +876,7 @@ __device__ bool ldl_solve(const AReg<NBLK>& A, double* Lp, const double* g, doub
 // barrier exactly like ldl_solve, restricted to itself.  LDS holds the column broadcast buffer and a 16-row panel through
 // which the back-substitution streams the factor; every lane of wave 0 owns up to four unknowns.
 //   Lp (global): packed factor, entry (i, j) at i (i + 1) / 2 + j, rows 0..n (row n = right-hand side); [trash] spare word,
-//                [zero .. zero + 7] zeros.   Sl (LDS): [0] trash, [1] zero, [2 ..] Cv [2][2][CVR], then the panel [16][CVR].
+//                [zero .. zero + 7] zeros.   Sl (LDS): [0 .. 63] per-lane trash, [64] zero, [66 ..] Cv [2][2][CVR], then the panel [16][CVR].
 template <int NBLK>
 __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* d, double* pinv, int n) {
     const int tid = threadIdx.x;
@@ -727,14 +884,14 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
     PROF_BEGIN(); PROF_COUNT(22);
     const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
     constexpr int CVR = NBLK * 16;
-    double* Cv = Sl + 2;
+    double* Cv = Sl + 66;
     int rS[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int q1 = b * 16 + ty;
         rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
     }
-    if (tid == 0) Sl[1] = 0.0;
+    if (tid == 0) Sl[64] = 0.0;
     if (tid < 8) Lp[zero + tid] = 0.0;
     bool ok = true;
     int step = 0;
@@ -776,7 +933,7 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
             for (int bi = bj0; bi < NBLK; ++bi) {
                 const int q1 = bi * 16 + ty;
                 const double v = W[bi];
-                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl;
+                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl + (tid & 63);
                 *dst = v;
                 Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;
             }
@@ -785,7 +942,7 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const double p0 = cv[j], a10 = cv[j + 1], p1r = cv[CVR + j + 1];
             double ci0[NBLK], ci1[NBLK];
-            const double* zr = Sl + 1;
+            const double* zr = Sl + 64;
 #pragma unroll
             for (int b = bj0; b < NBLK; ++b) {
                 const int q1 = b * 16 + ty;
@@ -825,7 +982,7 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
     if (!ok) return false;
     constexpr int NY = (CVR + 63) / 64;   // unknowns per lane of wave 0
     constexpr int PR = 16;                // panel rows
-    double* pan = Sl + 2 + 4 * CVR;       // [PR][CVR]
+    double* pan = Sl + 66 + 4 * CVR;       // [PR][CVR]
     const int base = n * (n + 1) / 2;
     double y[NY];
 #pragma unroll
@@ -878,8 +1035,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     // LDS-active cycles were bank conflicts); an odd number of 16-byte units per marker spreads them over all banks.
     const int XS = NW * 4 + 2, TS = NW + 1;
     PROF_BEGIN(); PROF_COUNT(21);
-    A.zero();
-    for (int q = tid; q < n; q += MOSHII_TPB) cx.g[q] = 0.0;
+    JtJAcc<NBLK> acc;
+    acc.zero();
     for (int e = tid; e < 3 * Tm * LDJ; e += MOSHII_TPB) cx.Jrow[e] = 0.0;
     // Jacobian-only joint quantities at the current point (the forward state of the last evaluation is in LDS):
     // left-Jacobian columns a_c of each joint rotation and dR/dtheta_c = [a_c]x R
@@ -924,12 +1081,12 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 for (int it = tid; it < KE; it += MOSHII_TPB) {
                     const int j = it / E, e = it - j * E;
                     if (md.depth[j] != lvl) continue;
-                    const double* js = md.JS + (size_t)it * 3;
+                    const auto* js = md.JS + (size_t)it * 3;
                     const double jx = js[0], jy = js[1], jz = js[2];
                     double dx = jx, dy = jy, dz = jz;
                     if (j > 0) {
                         const int p = md.parents[j];
-                        const double* jp = md.JS + ((size_t)p * E + e) * 3;
+                        const auto* jp = md.JS + ((size_t)p * E + e) * 3;
                         const double* dp = dtv + ((size_t)p * E + e) * 3;
                         double ox, oy, oz;
                         mat3_vec(&cx.Rw[p * 9], jx - jp[0], jy - jp[1], jz - jp[2], ox, oy, oz);
@@ -956,8 +1113,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 #pragma unroll
             for (int e = 0; e < 9; ++e) Tr[e] = 0.0;
             for (int s = 0; s < NW; ++s) {
-                const int j = at.wj[av * NW + s];
-                const double w = at.ww[av * NW + s];
+                const int j = gptr(at.wj)[av * NW + s];
+                const double w = gptr(at.ww)[av * NW + s];
                 double ox, oy, oz;
                 mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
                 cx.xjs[tid * XS + s * 4 + 0] = ox + cx.tw[j * 3 + 0];
@@ -973,7 +1130,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         } else if (tid >= 128 && tid < 128 + cnt) {
             const int ml = tid - 128;
             const int m = cx.visidx[tile0 + ml];
-            const double c[3] = {at.coef[m * 3 + 0], at.coef[m * 3 + 1], at.coef[m * 3 + 2]};
+            const double c[3] = {gptr(at.coef)[m * 3 + 0], gptr(at.coef)[m * 3 + 1], gptr(at.coef)[m * 3 + 2]};
             double mk[3], L[27];
             marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, L);
 #pragma unroll
@@ -983,7 +1140,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 #pragma unroll
                     for (int x = 0; x < 3; ++x) cx.Lm[(ml * 3 + sv) * 10 + row * 3 + x] = L[row * 9 + sv * 3 + x];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) cx.rest[ml * 3 + i] = cx.res[m * 3 + i];
+            for (int i = 0; i < 3; ++i) cx.Jrow[(3 * ml + i) * LDJ + n] = cx.res[m * 3 + i];   // residual = column n of the tile (T3)
         }
         __syncthreads();
         PROF_LAP(4);
@@ -1015,7 +1172,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
 #pragma unroll
             for (int sv = 0; sv < 3; ++sv) {
-                const int al = 3 * ml + sv, av = 3 * m + sv;
+                const int al = 3 * ml + sv;
                 double ax = 0.0, ay = 0.0, az = 0.0;
                 for (int s2 = 0; s2 < NW; ++s2) {   // joints of this vertex inside the subtree of k (branch-free: weight 0 otherwise)
                     const int j = cx.tjs[al * TS + s2];
@@ -1036,10 +1193,10 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 {   // pose-corrective part; the root joint (k = 0) has none: it reads joint 1's record and scales by 0
                     const double cs = (k >= 1) ? 1.0 : 0.0;
                     const int kk = max(k, 1);
-                    double pv[28];   // one 224-byte record: 14 x 16-byte loads per lane
-                    const double2* pp = reinterpret_cast<const double2*>(at.Pj + ((size_t)(kk - 1) * Nvp + av) * 28);
+                    double pv[28];   // 14 x 16-byte loads per lane, contiguous across the markers of a wavefront (AttachDev::Pj)
+                    const auto* pp = gptr(reinterpret_cast<const v2d*>(at.Pj)) + (size_t)((kk - 1) * 3 + sv) * 14 * at.M + m;
 #pragma unroll
-                    for (int q = 0; q < 14; ++q) { const double2 t2 = pp[q]; pv[2 * q] = t2.x; pv[2 * q + 1] = t2.y; }
+                    for (int q = 0; q < 14; ++q) { const v2d t2 = pp[(size_t)q * at.M]; pv[2 * q] = t2[0]; pv[2 * q + 1] = t2[1]; }
                     double Tr[10];
                     {
                         const double2* t2p = reinterpret_cast<const double2*>(&cx.Trot[al * 10]);
@@ -1101,7 +1258,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 #pragma unroll
                     for (int sv = 0; sv < 3; ++sv) {
                         const int al = 3 * ml + sv, av = 3 * m + sv;
-                        const double* sp = at.Ssh + (size_t)e * 3 * Nvp + av;
+                        const auto* sp = gptr(at.Ssh) + (size_t)e * 3 * Nvp + av;
                         const double sx = sp[0], sy = sp[Nvp], sz = sp[2 * Nvp];
                         const double* Tr = &cx.Trot[al * 10];
                         double dx = Tr[0] * sx + Tr[1] * sy + Tr[2] * sz;
@@ -1150,22 +1307,23 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             __syncthreads();
         }
         PROF_LAP(6);
-        // T3: A += Jt^T Jt ; g -= Jt^T r
-        A.rank_update(cx.Jrow, ntv, LDJ);
-        for (int q = tid; q < n; q += MOSHII_TPB) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int r = 0;
-            for (; r + 4 <= ntv; r += 4) {
-                s0 += cx.Jrow[r * LDJ + q] * cx.rest[r];
-                s1 += cx.Jrow[(r + 1) * LDJ + q] * cx.rest[r + 1];
-                s2 += cx.Jrow[(r + 2) * LDJ + q] * cx.rest[r + 2];
-                s3 += cx.Jrow[(r + 3) * LDJ + q] * cx.rest[r + 3];
-            }
-            for (; r < ntv; ++r) s0 += cx.Jrow[r * LDJ + q] * cx.rest[r];
-            cx.g[q] -= (s0 + s1) + (s2 + s3);
-        }
+        // T3: [A; -g^T] += [Jt r]^T [Jt r]: the weighted residual rides as column n of the tile (n < LDJ), so the same
+        // matrix-pipe pass that accumulates J^T J leaves J^T r in row n of the product -- no separate gradient loop
+        acc.accumulate(cx.Jrow, ntv, LDJ);
         __syncthreads();
         PROF_LAP(7);
+    }
+    A.take(acc, cx.big);   // (the tile loop ended with a barrier: the Jacobian tile region is free)
+    {   // data-term gradient g = -J^T r: row n of the product (its owners: ty == n % 16 in block row n / 16)
+        const int ty = tid >> 4, tx = tid & 15, bn = n >> 4;
+        if (ty == (n & 15)) {
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = 0; bj <= bi; ++bj)
+                    if (bi == bn && bj * 16 + tx < n) cx.g[bj * 16 + tx] = -A.a[bi * (bi + 1) / 2 + bj];
+        }
+        __syncthreads();
     }
     // structured terms: prior (dense, precomputed 0.5 L L^T per component), velocity and finger terms (diagonal)
     const int np_ = op.nbody;
@@ -1184,18 +1342,18 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             if (fp.has_velo) { const double w2 = fp.wt_velo * fp.wt_velo; dg += w2; gq -= w2 * (pose[pid] - cx.vtarget[pid]); }
             const int pb = cx.colprior[q];
             if (pb >= 0) {   // prior gradient w^2 (1/2 L L^T)(x - mu): column pb of the symmetric half-precision, b uniform
-                const double* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
-                const double* mu = pr.means + (size_t)kb * np_;
+                const auto* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
+                const auto* mu = pr.means + (size_t)kb * np_;
                 double s0 = 0.0, s1 = 0.0;
-                for (int b0 = 0; b0 < np_; b0 += 8) {   // 8 column entries + 8 means in flight per lane
-                    double h[8], m8[8];
+                for (int b0 = 0; b0 < np_; b0 += 32) {   // 32 column entries in flight per lane (two round trips for 63)
+                    double h[32];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const int b = min(b0 + k, np_ - 1); h[k] = Hk[b * np_]; m8[k] = mu[b]; }
+                    for (int k = 0; k < 32; ++k) h[k] = Hk[(size_t)min(b0 + k, np_ - 1) * np_];
 #pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
+                    for (int k = 0; k < 32; k += 2) {
                         const int b = b0 + k;
-                        s0 = fma(h[k] * ((b < np_) ? 1.0 : 0.0), cx.xb[min(b, np_ - 1)] - m8[k], s0);
-                        s1 = fma(h[k + 1] * ((b + 1 < np_) ? 1.0 : 0.0), cx.xb[min(b + 1, np_ - 1)] - m8[k + 1], s1);
+                        s0 = fma(h[k] * ((b < np_) ? 1.0 : 0.0), cx.xb[min(b, np_ - 1)] - mu[min(b, np_ - 1)], s0);
+                        s1 = fma(h[k + 1] * ((b + 1 < np_) ? 1.0 : 0.0), cx.xb[min(b + 1, np_ - 1)] - mu[min(b + 1, np_ - 1)], s1);
                     }
                 }
                 gq -= fp.wt_pose * fp.wt_pose * (s0 + s1);
@@ -1220,6 +1378,82 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     if (np_ > 0) A.add_prior(fp.wt_pose * fp.wt_pose, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
     __syncthreads();
     PROF_LAP(8);
+}
+
+__device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
+    Ctx cx;
+    cx.pose = lds + ly.o_pose; cx.trans = lds + ly.o_trans; cx.pose_t = lds + ly.o_pose_t; cx.trans_t = lds + ly.o_trans_t;
+    cx.pose_prev = lds + ly.o_pose_prev; cx.vtarget = lds + ly.o_vtarget; cx.fullpose = lds + ly.o_fullpose;
+    cx.Jl = lds + ly.o_Jl; cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
+    cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
+    cx.vshp = lds + ly.o_vshp; cx.shp0 = lds + ly.o_shp0;
+    cx.vconst = lds + ly.o_vconst; cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
+    cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
+    cx.g = lds + ly.o_g; cx.dsd = lds + ly.o_dsd; cx.dgn = lds + ly.o_dgn; cx.ddl = lds + ly.o_ddl; cx.y = lds + ly.o_y;
+    cx.red = lds + ly.o_red; cx.scal = lds + ly.o_scal;
+    cx.anc = reinterpret_cast<unsigned long long*>(lds + ly.o_anc);
+    int* ints = reinterpret_cast<int*>(lds + ly.o_ints);
+    cx.visidx = ints + ly.i_visidx; cx.colpid = ints + ly.i_colpid; cx.colprior = ints + ly.i_colprior;
+    cx.pid2prior = ints + ly.i_pid2prior; cx.jointslot = ints + ly.i_jointslot; cx.kfree = ints + ly.i_kfree;
+    cx.colq = ints + ly.i_colq; cx.ksum = ints + ly.i_ksum; cx.kconst = ints + ly.i_kconst;
+    cx.big = lds + ly.o_big;
+    cx.Jh = cx.big + ly.t_Jh; cx.Jrow = cx.big + ly.t_Jrow; cx.Lm = cx.big + ly.t_Lm; cx.Trot = cx.big + ly.t_Trot;
+    cx.xjs = cx.big + ly.t_xjs; cx.rest = cx.big + ly.t_rest;
+    cx.tjs = reinterpret_cast<int*>(cx.big + ly.t_tjs);
+
+    return cx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The two big phases as functions of their own.  Inlined into the frame loop they shared one register allocation with the
+// whole solver state (the kernel then spilled several hundred scalar and vector registers, with reloads inside the hot
+// loops); compiled separately each starts from its few arguments and fetches its context -- layout, model, prior,
+// options, attachment -- from the KernelCtx copy at the head of the LDS, as wave-uniform (scalar) values.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T uniform_load(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "word-sized descriptors only");
+    T out;
+    int* o = reinterpret_cast<int*>(&out);
+    const int* q = reinterpret_cast<const int*>(p);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) o[i] = __builtin_amdgcn_readfirstlane(q[i]);
+    return out;
+}
+
+template <bool XT>
+__device__ __noinline__ Sse eval_forward_fn(const FrameParams fp_, const uint8_t* visrow, int o_pose, int o_trans, int i_klist, int nk,
+                                            int o_vbase) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
+    const ChainLayout ly = uniform_load(&kc->ly);
+    const ModelDev md = uniform_load(&kc->md);
+    const PriorDev pr = uniform_load(&kc->pr);
+    const OptsDev op = uniform_load(&kc->op);
+    const AttachDev at = uniform_load(&kc->at);
+    const FrameParams fp = uniform_load(&fp_);
+    const Ctx cx = make_ctx(lds, ly);
+    const int* ints = reinterpret_cast<const int*>(lds + ly.o_ints);
+    return eval_forward<XT>(cx, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), lds + __builtin_amdgcn_readfirstlane(o_trans),
+                            fp, visrow, ints + __builtin_amdgcn_readfirstlane(i_klist), __builtin_amdgcn_readfirstlane(nk),
+                            lds + __builtin_amdgcn_readfirstlane(o_vbase));
+}
+
+template <int NBLK, bool XT>
+__device__ __noinline__ AReg<NBLK> assemble_fn(const FrameParams fp_, int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
+    const ChainLayout ly = uniform_load(&kc->ly);
+    const ModelDev md = uniform_load(&kc->md);
+    const PriorDev pr = uniform_load(&kc->pr);
+    const OptsDev op = uniform_load(&kc->op);
+    const AttachDev at = uniform_load(&kc->at);
+    const FrameParams fp = uniform_load(&fp_);
+    const Ctx cx = make_ctx(lds, ly);
+    AReg<NBLK> A;
+    assemble<NBLK, XT>(cx, ly, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), fp, __builtin_amdgcn_readfirstlane(n),
+                       __builtin_amdgcn_readfirstlane(ncp), __builtin_amdgcn_readfirstlane(nkf), __builtin_amdgcn_readfirstlane(nfree_hand), qs, A);
+    return A;
 }
 
 // Arun/Procrustes rigid init (rigid_transformations.py:39-83), serial on one thread (first solved frame only).
@@ -1313,7 +1547,7 @@ __device__ __noinline__ void rigid_init_serial(const Ctx& cx, const FrameParams&
 // behind the pose variables (cx.pose[NP ..]), so a shape column q has colpid[q] = NP + e and moves with the same code.
 template <int NBLK, bool XT>
 __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
-                         const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, const int* ids, int nids, int nshp,
+                         const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, MOSHII_GP(const int) ids, int nids, int nshp,
                          double* qs, double e3,
                          bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int set_id, int& vc_key,
                          int& tab_key, int& n_iter, int& n_fev, int& fail) {
@@ -1387,7 +1621,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     bool skip_eval = reuse && !rigid;
     while (true) {
         if (skip_eval) { last = carried; skip_eval = false; }
-        else last = eval_forward<XT>(cx, md, at, pr, op, cx.pose_t, cx.trans_t, fp, visrow, cx.ksum, nks, cx.vconst);
+        else last = eval_forward_fn<XT>(fp, visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst);
         at_pose = true;   // cleared below when a trial point is rejected
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
@@ -1422,7 +1656,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
         if (do_assemble) {
-            assemble<NBLK, XT>(cx, ly, md, at, pr, op, cx.pose, fp, n, ncp, nkf, nfree_hand, qs, A);
+            A = assemble_fn<NBLK, XT>(fp, ly.o_pose, n, ncp, nkf, nfree_hand, qs);
             double gm = 0.0;
             for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
             if (block_max(gm, cx.red) < 1e-15) done = true;
@@ -1467,7 +1701,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 constexpr bool BIG = XT && NBLK > 8;
                 bool solved;
                 if constexpr (BIG) solved = ldl_big<NBLK>(A, qs + (size_t)6 * md.K * op.nshape, cx.big, cx.g, cx.dgn, cx.y, n);
-                else solved = ldl_solve<NBLK>(A, cx.big, cx.g, cx.dgn, cx.y, n);
+                else solved = ldl_solve<NBLK>(A, ly.o_big, ly.o_g, ly.o_dgn, ly.o_y, n);
                 if (!solved) {
                     fail = 1;
                     for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
@@ -1518,30 +1752,6 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 }
 
 
-__device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
-    Ctx cx;
-    cx.pose = lds + ly.o_pose; cx.trans = lds + ly.o_trans; cx.pose_t = lds + ly.o_pose_t; cx.trans_t = lds + ly.o_trans_t;
-    cx.pose_prev = lds + ly.o_pose_prev; cx.vtarget = lds + ly.o_vtarget; cx.fullpose = lds + ly.o_fullpose;
-    cx.Jl = lds + ly.o_Jl; cx.feat = lds + ly.o_feat; cx.B = lds + ly.o_B; cx.omega = lds + ly.o_omega; cx.Rw = lds + ly.o_Rw; cx.tw = lds + ly.o_tw;
-    cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
-    cx.vshp = lds + ly.o_vshp; cx.shp0 = lds + ly.o_shp0;
-    cx.vconst = lds + ly.o_vconst; cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
-    cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
-    cx.g = lds + ly.o_g; cx.dsd = lds + ly.o_dsd; cx.dgn = lds + ly.o_dgn; cx.ddl = lds + ly.o_ddl; cx.y = lds + ly.o_y;
-    cx.red = lds + ly.o_red; cx.scal = lds + ly.o_scal;
-    cx.anc = reinterpret_cast<unsigned long long*>(lds + ly.o_anc);
-    int* ints = reinterpret_cast<int*>(lds + ly.o_ints);
-    cx.visidx = ints + ly.i_visidx; cx.colpid = ints + ly.i_colpid; cx.colprior = ints + ly.i_colprior;
-    cx.pid2prior = ints + ly.i_pid2prior; cx.jointslot = ints + ly.i_jointslot; cx.kfree = ints + ly.i_kfree;
-    cx.colq = ints + ly.i_colq; cx.ksum = ints + ly.i_ksum; cx.kconst = ints + ly.i_kconst;
-    cx.big = lds + ly.o_big;
-    cx.Jh = cx.big + ly.t_Jh; cx.Jrow = cx.big + ly.t_Jrow; cx.Lm = cx.big + ly.t_Lm; cx.Trot = cx.big + ly.t_Trot;
-    cx.xjs = cx.big + ly.t_xjs; cx.rest = cx.big + ly.t_rest;
-    cx.tjs = reinterpret_cast<int*>(cx.big + ly.t_tjs);
-
-    return cx;
-}
-
 // MINW = 1: one workgroup per CU, the compiler may use the whole 512-entry register file (lowest latency per chain);
 // MINW = 2: registers capped at 256 so that two workgroups share a CU and cover each other's dependency stalls
 //           (highest throughput when there are more chains than CUs).
@@ -1555,6 +1765,10 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     const ChainDev* chp = chains + blockIdx.x;   // fields are (re)loaded where used: keeps SGPR pressure down
     const AttachDev at = *chp->att;
     const Ctx cx = make_ctx(lds, ly);
+    if (tid == 0) {   // the descriptors for the separately compiled phases (eval_forward_fn / assemble_fn)
+        KernelCtx* kc = reinterpret_cast<KernelCtx*>(lds);
+        kc->ly = ly; kc->md = md; kc->pr = pr; kc->op = op; kc->at = at;
+    }
 
     const int NP = md.NP, M = at.M, F = chp->F, skip = chp->skip;
     bool has_prev, first;
@@ -1617,10 +1831,16 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         const bool record = t >= skip;
         const uint8_t* visrow = chp->vis + (size_t)t * M;
         // visible-marker list (chmosh.py:591-594), kept in label order
-        if (tid == 0) {
+        if (tid < 64) {   // wave 0: one ballot per 64 markers, list position = number of visible markers before this one
             int c = 0;
-            for (int m = 0; m < M; ++m) if (visrow[m]) cx.visidx[c++] = m;
-            cx.scal[S_TMP1] = (double)c;
+            for (int m0 = 0; m0 < M; m0 += 64) {
+                const int m = m0 + tid;
+                const bool v = m < M && gptr(visrow)[min(m, M - 1)] != 0;
+                const unsigned long long mask = __ballot(v);
+                if (v) cx.visidx[c + __popcll(mask & ((1ull << tid) - 1ull))] = m;
+                c += __popcll(mask);
+            }
+            if (tid == 0) cx.scal[S_TMP1] = (double)c;
         }
         __syncthreads();
         const int nobs = (int)cx.scal[S_TMP1];
@@ -1724,6 +1944,9 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
 #endif
 }
 
+#ifdef MOSHII_DEV_ONLY_NBLK4   // development builds: one instantiation (the 63-unknown body solve) compiles in seconds
+template __global__ void k_chain_solve<4, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+#else
 #define MOSHII_INSTANTIATE(N) \
     template __global__ void k_chain_solve<N, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout); \
     template __global__ void k_chain_solve<N, 2, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
@@ -1742,6 +1965,8 @@ MOSHII_INSTANTIATE_XT(10)
 MOSHII_INSTANTIATE_XT(13)
 #undef MOSHII_INSTANTIATE_XT
 
+
+#endif
 
 // Simulated markers for explicit pose variables (TransformedLms.r), one frame per workgroup.
 __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restrict__ attp, ModelDev md, ChainLayout ly,
@@ -1778,6 +2003,10 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
                                                 const OptsDev* op, const ChainLayout* ly) {
     using namespace moshii;
     void (*kern)(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout) = nullptr;
+#ifdef MOSHII_DEV_ONLY_NBLK4
+    if (xt || nblk != 4 || two_per_cu) return hipErrorInvalidValue;
+    kern = k_chain_solve<4, 1, false>;
+#else
     if (xt) {
         switch (nblk) {
             case 5: kern = k_chain_solve<5, 1, true>; break;
@@ -1799,6 +2028,7 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
         case 17: kern = k_chain_solve<8, 2, false>; break;
         default: return hipErrorInvalidValue;
     }
+#endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_chains), dim3(MOSHII_TPB), lds_bytes, stream, chains, *md, *pr, *op, *ly);

@@ -80,9 +80,10 @@ struct moshii_model_s {
         ModelDev md;
         md.V = V; md.K = K; md.P = P; md.NP = NP; md.body_dof = body_dof; md.hand_dof = hand_dof;
         md.nhand_full = nhand_full; md.maxdepth = maxdepth;
-        md.parents = d_parents; md.J = d_J; md.hands_mean = d_hands_mean; md.comps = d_comps;
-        md.comp_lo = d_comp_lo; md.comp_hi = d_comp_hi; md.col_lo = d_col_lo; md.col_hi = d_col_hi; md.anc = d_anc; md.depth = d_depth;
-        md.nshape = nshape; md.JS = d_JS;
+        md.parents = as_gp(d_parents); md.J = as_gp(d_J); md.hands_mean = as_gp(d_hands_mean); md.comps = as_gp(d_comps);
+        md.comp_lo = as_gp(d_comp_lo); md.comp_hi = as_gp(d_comp_hi); md.col_lo = as_gp(d_col_lo); md.col_hi = as_gp(d_col_hi);
+        md.anc = as_gp(d_anc); md.depth = as_gp(d_depth);
+        md.nshape = nshape; md.JS = as_gp(d_JS);
         return md;
     }
 };
@@ -90,7 +91,7 @@ struct moshii_model_s {
 struct moshii_prior_s {
     int G = 0, npose = 0;
     double *d_means = nullptr, *d_chols = nullptr, *d_halfprec = nullptr, *d_neglogw = nullptr;
-    PriorDev dev() const { PriorDev p; p.G = G; p.npose = npose; p.means = d_means; p.chols = d_chols; p.halfprec = d_halfprec; p.neglogw = d_neglogw; return p; }
+    PriorDev dev() const { PriorDev p; p.G = G; p.npose = npose; p.means = as_gp(d_means); p.chols = as_gp(d_chols); p.halfprec = as_gp(d_halfprec); p.neglogw = as_gp(d_neglogw); return p; }
 };
 
 struct moshii_attach_s {
@@ -146,8 +147,11 @@ __global__ void k_pack_attach(int Nv, int Nvp, int K, const int* __restrict__ vi
         double v = 0.0;
         if (a < Nv) v = posedirs[((size_t)vids[a] * 3 + q / 9) * nfeat + 9 * km1 + q % 9];
         Pt[idx] = v;
-        Pj[((size_t)km1 * Nvp + a) * 28 + q] = v;
-        if (q == 26) Pj[((size_t)km1 * Nvp + a) * 28 + 27] = 0.0;
+        if (a < Nv) {   // Pj[k-1][s][q/2][m] as 16-byte pairs, marker index fastest (a = 3 m + s): see AttachDev
+            const int M = Nv / 3, mk = a / 3, sv = a % 3;
+            Pj[((((size_t)km1 * 3 + sv) * 14 + q / 2) * M + mk) * 2 + (q & 1)] = v;
+            if (q == 26) Pj[((((size_t)km1 * 3 + sv) * 14 + 13) * M + mk) * 2 + 1] = 0.0;
+        }
     }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < Nv * 3) vsh_out[t] = vsh[(size_t)vids[t / 3] * 3 + t % 3];
@@ -279,7 +283,7 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     if (nblk <= 0) nblk = pick_nblk(nmax);
     const int LDJ = nblk * 16;
     ly.Mmax = Mmax; ly.Nvmax = Nvmax; ly.NWmax = NWmax; ly.nmax = nmax; ly.Tm = Tm; ly.nkfmax = nkfmax; ly.LDJ = LDJ; ly.nhj = nhj;
-    int off = 0;
+    int off = MOSHII_KC_DOUBLES;   // (the KernelCtx copy sits at the head of the LDS)
     auto take = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
     const int NPX = NP + nshape;   // free shape coefficients ride behind the pose variables
     ly.NPX = NPX;
@@ -304,10 +308,10 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.t_Jh = ttake(Tm * nhj * 9); ly.t_Jrow = ttake(3 * Tm * LDJ); ly.t_Lm = ttake(Tm * 30);
     ly.t_Trot = ttake(3 * Tm * 10); ly.t_xjs = ttake(3 * Tm * (NWmax * 4 + 2)); ly.t_rest = ttake(3 * Tm);   // (strides: assemble())
     ly.t_tjs = ttake((3 * Tm * (NWmax + 1) + 1) / 2);
-    // packed factor + trash / zero words + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
+    // packed factor + 64 per-lane trash words / zero word + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
     // the factor lives in global scratch and LDS keeps the broadcast buffer plus a 16-row panel
-    const int chol = (nblk > 8) ? 2 + 4 * LDJ + 16 * LDJ + 4 : (nmax + 1) * (nmax + 2) / 2 + 2 + 4 * LDJ + 4;
-    ly.big_doubles = std::max(t, chol);
+    const int chol = (nblk > 8) ? 66 + 4 * LDJ + 16 * LDJ + 4 : (nmax + 1) * (nmax + 2) / 2 + 66 + 4 * LDJ + 4;
+    ly.big_doubles = std::max(std::max(t, chol), 16 * 256);   // (16 x 256: the J^T J tile exchange, AReg::take)
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
     return ly;
@@ -518,9 +522,11 @@ int moshii_prior_create(int32_t G, int32_t npose, const double* means, const dou
     auto* p = new moshii_prior_s();
     p->G = G; p->npose = npose;
     const size_t nn = (size_t)npose * npose;
-    std::vector<double> half((size_t)G * nn), nlw(G);
-    for (int g = 0; g < G; ++g) {
+    std::vector<double> half((size_t)G * nn), nlw(G), lower((size_t)G * nn, 0.0);   // lower: the factors with explicit zeros above the
+    for (int g = 0; g < G; ++g) {                                                    // diagonal (the chain kernel reads whole rows)
         const double* L = chols + g * nn;
+        for (int i = 0; i < npose; ++i)
+            for (int j = 0; j <= i; ++j) lower[g * nn + (size_t)i * npose + j] = L[(size_t)i * npose + j];
         for (int i = 0; i < npose; ++i)
             for (int j = 0; j <= i; ++j) {
                 double s = 0.0;
@@ -532,7 +538,7 @@ int moshii_prior_create(int32_t G, int32_t npose, const double* means, const dou
     }
     int rc;
     if ((rc = dev_upload(means, (size_t)G * npose, &p->d_means))) return rc;
-    if ((rc = dev_upload(chols, (size_t)G * nn, &p->d_chols))) return rc;
+    if ((rc = dev_upload(lower.data(), lower.size(), &p->d_chols))) return rc;
     if ((rc = dev_upload(half.data(), half.size(), &p->d_halfprec))) return rc;
     if ((rc = dev_upload(nlw.data(), nlw.size(), &p->d_neglogw))) return rc;
     *out = p;
@@ -580,7 +586,7 @@ int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, co
     HIP_TRY(hipMalloc((void**)&a->d_vsh, (size_t)a->Nv * 3 * sizeof(double)));
     const size_t npt = (size_t)(m->K - 1) * 27 * a->Nvp;
     HIP_TRY(hipMalloc((void**)&a->d_Pt, std::max<size_t>(npt, 1) * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&a->d_Pj, std::max<size_t>((size_t)(m->K - 1) * a->Nvp * 28, 1) * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&a->d_Pj, std::max<size_t>((size_t)(m->K - 1) * 3 * 14 * M * 2, 1) * sizeof(double)));
     const int blocks = (int)std::min<size_t>(4096, std::max<size_t>((npt + 255) / 256, (size_t)(a->Nv * 3 + 255) / 256));
     hipLaunchKernelGGL(k_pack_attach, dim3(std::max(blocks, 1)), dim3(256), 0, 0, a->Nv, a->Nvp, m->K, a->d_vids, m->d_posedirs,
                        m->d_vsh, a->d_Pt, a->d_Pj, a->d_vsh);
@@ -596,8 +602,8 @@ int moshii_attach_create(moshii_model_t m, int32_t M, const int32_t* closest, co
     HIP_TRY(hipDeviceSynchronize());
     AttachDev& av = a->host_view;
     av.M = M; av.Nv = a->Nv; av.Nvp = a->Nvp; av.NW = NW;
-    av.vsh = a->d_vsh; av.Pt = a->d_Pt; av.Pj = a->d_Pj; av.wj = a->d_wj; av.ww = a->d_ww; av.coef = a->d_coef;
-    av.Ssh = a->d_Ssh;
+    av.vsh = as_gp(a->d_vsh); av.Pt = as_gp(a->d_Pt); av.Pj = as_gp(a->d_Pj); av.wj = as_gp(a->d_wj); av.ww = as_gp(a->d_ww);
+    av.coef = as_gp(a->d_coef); av.Ssh = as_gp(a->d_Ssh);
     if ((rc = dev_upload(&av, 1, &a->d_self))) return rc;
     *out = a;
     return MOSHII_OK;
@@ -698,13 +704,27 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     for (int i = 0; i < o->n_step1; ++i) hand_free |= o->step1_ids[i] >= m->body_dof;
     for (int i = 0; i < o->n_step2; ++i) hand_free |= o->step2_ids[i] >= m->body_dof;
     const int nhj = hand_free ? (m->K - m->body_dof / 3) : 0;
-    int Tm = std::min(40, std::max(2, Mmax));   // T0 maps tile vertices to threads 0..127: 3 Tm <= 120
-    if (const char* e = getenv("MOSHII_TM")) Tm = std::max(1, std::min(40, atoi(e)));
+    // Marker-tile size Tm (T0 maps tile vertices to threads 0..127: 3 Tm <= 120).  The Jacobian rows of a tile are built by
+    // (tile marker, needed joint) items, 256 at a time, so among the sizes that fit the LDS budget take the one with the
+    // fewest item rounds + tiles over a fully visible frame (53 markers x 20 joints: 38 + 15 = 3 + 2 rounds, where two equal
+    // tiles of 27 / 26 cost 3 + 3), weighted by what a round and a tile's fixed work cost (about 3 : 4).
+    int Tm = std::min(40, std::max(2, Mmax));
     ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
-    while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) { --Tm; ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape); }
-    if (!getenv("MOSHII_TM") && Tm < Mmax) {   // balance the tiles: same tile count, equal sizes
-        const int ntiles = (Mmax + Tm - 1) / Tm;
-        Tm = (Mmax + ntiles - 1) / ntiles;
+    if (const char* e = getenv("MOSHII_TM")) {
+        Tm = std::max(1, std::min(40, atoi(e)));
+        ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
+    } else {
+        int best = -1, best_cost = 0;
+        for (int t = std::min(40, std::max(2, Mmax)); t >= 2; --t) {
+            const ChainLayout lt = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, t, nblk, nhj, nshape);
+            if ((size_t)lt.total_doubles * 8 > (size_t)budget) continue;
+            const int full = Mmax / t, rem = Mmax % t;
+            const int rounds = full * ((t * nkfmax + 255) / 256) + (rem ? (rem * nkfmax + 255) / 256 : 0);
+            const int cost = 3 * rounds + 4 * (full + (rem ? 1 : 0));
+            if (best < 0 || cost < best_cost) { best = t; best_cost = cost; }
+        }
+        if (best < 0) best = 2;   // (does not fit: reported below)
+        Tm = best;
         ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
     }
     const size_t lds_bytes = (size_t)ly.total_doubles * sizeof(double);
@@ -740,7 +760,7 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     od.wt_poseF = o->wt_poseF; od.wt_shape = o->wt_shape; od.wt_shape_stay = o->wt_shape_stay;
     od.nface = o->n_face; od.nshape = nshape;
     const int* dids = (const int*)dbase;
-    od.step1 = dids + e1; od.step2 = dids + e2; od.body = dids + eb; od.finger = dids + ef; od.face = dids + efc;
+    od.step1 = as_gp(dids + e1); od.step2 = as_gp(dids + e2); od.body = as_gp(dids + eb); od.finger = as_gp(dids + ef); od.face = as_gp(dids + efc);
     memset(&cfg->pd, 0, sizeof(cfg->pd));
     if (prior) cfg->pd = prior->dev();
     cfg->md = m->dev();

@@ -4,56 +4,81 @@
 #include <stdint.h>
 
 #define MOSHII_MAXK 64      // joints (ancestor sets are 64-bit masks)
+
+// Pointers that a kernel LOADS from a descriptor (AttachDev / ChainDev fields) are generic to the compiler, and every access
+// through them becomes a FLAT instruction: it counts against the LDS counter as well as the vector-memory one, returns out
+// of order with respect to both, and so every wait behind it is a full drain (no partial vmcnt waits, no overlap with LDS
+// reads).  gptr() types such a pointer as a global-memory address at its use site; kernel arguments do not need it.
+#ifndef MOSHII_AS_GLOBAL
+#define MOSHII_AS_GLOBAL __attribute__((address_space(1)))
+#endif
+template <class T> __device__ __forceinline__ const T MOSHII_AS_GLOBAL* gptr(const T* p) { return (const T MOSHII_AS_GLOBAL*)p; }
+template <class T> __device__ __forceinline__ T MOSHII_AS_GLOBAL* gptr(T* p) { return (T MOSHII_AS_GLOBAL*)p; }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ const T MOSHII_AS_GLOBAL* gptr(const T MOSHII_AS_GLOBAL* p) { return p; }   // (already typed)
+#endif
+// The by-value descriptors below (ModelDev, AttachDev, PriorDev, OptsDev) declare their device arrays with MOSHII_GP: a plain
+// pointer to the host pass, a global-memory pointer to the device pass (same size and layout), so that device code reaches
+// them with global loads wherever the descriptor itself came from (kernel argument, LDS copy, memory).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOSHII_GP(T) T MOSHII_AS_GLOBAL*
+#else
+#define MOSHII_GP(T) T*
+#endif
+template <class T> __host__ __device__ inline MOSHII_GP(const T) as_gp(const T* p) { return (MOSHII_GP(const T))p; }   // (filling a descriptor)
 #define MOSHII_TPB 256      // threads per chain workgroup: 4 waves, one per SIMD
 
 struct ModelDev {
     int V, K, P, NP, body_dof, hand_dof, nhand_full, maxdepth;
-    const int* parents;              // [K]
-    const double* J;                 // [K][3] regressed joints (current betas)
-    const double* hands_mean;        // [nhand_full]
-    const double* comps;             // [hand_dof][nhand_full]
-    const int* comp_lo;              // [hand_dof] first non-zero column of each component row
-    const int* comp_hi;              // [hand_dof] one past the last non-zero column
-    const int* col_lo;               // [nhand_full] first component with a non-zero entry in this column
-    const int* col_hi;               // [nhand_full] one past the last such component
-    const unsigned long long* anc;   // [K] bit j set iff k is j or an ancestor of j
-    const int* depth;                // [K]
+    MOSHII_GP(const int) parents;              // [K]
+    MOSHII_GP(const double) J;                 // [K][3] regressed joints (current betas)
+    MOSHII_GP(const double) hands_mean;        // [nhand_full]
+    MOSHII_GP(const double) comps;             // [hand_dof][nhand_full]
+    MOSHII_GP(const int) comp_lo;              // [hand_dof] first non-zero column of each component row
+    MOSHII_GP(const int) comp_hi;              // [hand_dof] one past the last non-zero column
+    MOSHII_GP(const int) col_lo;               // [nhand_full] first component with a non-zero entry in this column
+    MOSHII_GP(const int) col_hi;               // [nhand_full] one past the last such component
+    MOSHII_GP(const unsigned long long) anc;   // [K] bit j set iff k is j or an ancestor of j
+    MOSHII_GP(const int) depth;                // [K]
     // free shape block (moshii_model_set_free_shape): dJ/ds, joint-major so that (joint, coefficient) items are contiguous
     int nshape;
-    const double* JS;                // [K][nshape][3]
+    MOSHII_GP(const double) JS;                // [K][nshape][3]
 };
 
 struct AttachDev {
     int M, Nv, Nvp, NW;
-    const double* vsh;     // [Nv][3] v_shaped rows of the attached vertices (a = 3*m + s)
-    const double* Pt;      // [(K-1)*27][Nvp] posedirs slice, vertex index fastest (forward pass: coalesced rows)
-    const double* Pj;      // [(K-1)][Nvp][28] the same slice, one 224-byte record per (joint, vertex) (Jacobian pass)
-    const int* wj;         // [Nv][NW] joints with non-zero skinning weight (padded: joint 0, weight 0)
-    const double* ww;      // [Nv][NW]
-    const double* coef;    // [M][3]
-    const double* Ssh;     // [nshape][3][Nvp] rows of the free shape block, vertex index fastest (null when nshape == 0)
+    MOSHII_GP(const double) vsh;     // [Nv][3] v_shaped rows of the attached vertices (a = 3*m + s)
+    MOSHII_GP(const double) Pt;      // [(K-1)*27][Nvp] posedirs slice, vertex index fastest (forward pass: coalesced rows)
+    MOSHII_GP(const double) Pj;      // [(K-1)][3][14][M] x 16 bytes: the same slice for the Jacobian pass -- the 27 (+1 pad) entries of (joint, vertex
+                           // a = 3 m + s) as 14 pairs, marker index fastest, so that a wavefront whose lanes are consecutive markers
+                           // (the T1 items) reads contiguous 16-byte runs (the former 224-byte-record-per-lane form cost one
+                           // cache-line look-up per lane per load)
+    MOSHII_GP(const int) wj;         // [Nv][NW] joints with non-zero skinning weight (padded: joint 0, weight 0)
+    MOSHII_GP(const double) ww;      // [Nv][NW]
+    MOSHII_GP(const double) coef;    // [M][3]
+    MOSHII_GP(const double) Ssh;     // [nshape][3][Nvp] rows of the free shape block, vertex index fastest (null when nshape == 0)
 };
 
 struct PriorDev {
     int G, npose;
-    const double* means;     // [G][npose]
-    const double* chols;     // [G][npose][npose] lower, L L^T = precision
-    const double* halfprec;  // [G][npose][npose] 0.5 * L L^T
-    const double* neglogw;   // [G] -log(weight)
+    MOSHII_GP(const double) means;     // [G][npose]
+    MOSHII_GP(const double) chols;     // [G][npose][npose] lower, L L^T = precision
+    MOSHII_GP(const double) halfprec;  // [G][npose][npose] 0.5 * L L^T
+    MOSHII_GP(const double) neglogw;   // [G] -log(weight)
 };
 
 struct OptsDev {
     double wt_data, wt_velo, wt_poseB, wt_poseH, wt_annealing, num_train_markers;
     double e3_first, e3, delta0;
     int maxiter, n1, n2, nbody, nfinger, same_sets;
-    const int* step1;
-    const int* step2;
-    const int* body;
-    const int* finger;
+    MOSHII_GP(const int) step1;
+    MOSHII_GP(const int) step2;
+    MOSHII_GP(const int) body;
+    MOSHII_GP(const int) finger;
     // Step-2 extras (extended kernel variant only)
     double wt_poseF, wt_shape, wt_shape_stay;
     int nface, nshape;
-    const int* face;
+    MOSHII_GP(const int) face;
 };
 
 struct ChainDev {
@@ -113,6 +138,18 @@ struct ChainLayout {
     // tile sub-offsets inside big (in doubles)
     int t_Jh, t_Jrow, t_Lm, t_Trot, t_xjs, t_rest, t_tjs;
 };
+
+// Copy of the chain kernel's descriptors at the head of its dynamic LDS (ChainLayout offsets start behind it): the phases
+// of the solver that are compiled as functions of their own (chain_solve.hip) pick their context up from here instead of
+// receiving several hundred bytes of arguments.
+struct KernelCtx {
+    ChainLayout ly;
+    ModelDev md;
+    PriorDev pr;
+    OptsDev op;
+    AttachDev at;
+};
+#define MOSHII_KC_DOUBLES ((int)((sizeof(KernelCtx) + 15) / 16 * 2))
 
 // single-precision / half-precision copies of the model for the full-mesh export kernels (lbs_forward.hip)
 struct Lbs32Model {

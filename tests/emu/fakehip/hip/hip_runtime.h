@@ -25,6 +25,7 @@ ThreadCtx& cur();                                   // the running fiber's indic
 void barrier();                                     // workgroup barrier
 void wave_sync();                                   // all lanes of the caller's wavefront rendezvous
 double wave_exchange(double v, int src_lane);       // value of `v` in lane `src_lane` of the caller's wavefront (all lanes call)
+void wave_gather2(double a, double b, const double** all);   // every lane's (a, b) of the caller's wavefront: all[0][2*lane], all[0][2*lane+1]
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
 void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `extern __shared__`: guarded beyond the launch's lds_bytes
 }
@@ -37,6 +38,7 @@ void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `exter
 #define __forceinline__ inline
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
+#define MOSHII_AS_GLOBAL                             // (address spaces: nothing to say on the CPU)
 #define _Float16 unsigned short                      // only pointer members of Lbs32Model (the f16 LBS path is not emulated)
 #define HIP_SYMBOL(x) (&(x))
 #define threadIdx (hipemu::cur().tid)
@@ -83,7 +85,39 @@ inline double __hiloint2double(int hi, int lo) { int64_t b = ((int64_t)hi << 32)
 inline int __builtin_amdgcn_readlane(int v, int lane) {          // exact for 32-bit payloads: a double carries any int exactly
     return (int)hipemu::wave_exchange((double)v, lane);
 }
+// DPP moves: the lane controls the kernels use (quad_perm, row_mirror, row_half_mirror), all rows and banks enabled
+inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+    const int lane = (int)(hipemu::cur().tid.x % 64);
+    int from;
+    if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+    else { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
+    return (int)hipemu::wave_exchange((double)src, from);
+}
+inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (hipemu::wave_exchange(pred ? 1.0 : 0.0, l) != 0.0) m |= 1ull << l;
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used to scalarise wave-uniform values
+// v_mfma_f64_16x16x4_f64: D = A (16x4) . B (4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15], register i of
+// lane l holds C/D[(l >> 4) + 4 i][l & 15]; the sum over k is taken as an in-order fma chain
+typedef double hipemu_v4d __attribute__((vector_size(32)));
+inline hipemu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_v4d c, int, int, int) {
+    const double* all = nullptr;
+    hipemu::wave_gather2(a, b, &all);
+    const int lane = (int)(hipemu::cur().tid.x % 64), n = lane & 15;
+    hipemu_v4d d = c;
+    for (int i = 0; i < 4; ++i) {
+        const int m = (lane >> 4) + 4 * i;
+        double acc = c[i];
+        for (int k = 0; k < 4; ++k) acc = std::fma(all[2 * (m + 16 * k)], all[2 * (n + 16 * k) + 1], acc);
+        d[i] = acc;
+    }
+    return d;
+}
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
