@@ -21,23 +21,27 @@ namespace moshii {
 typedef double v2d __attribute__((vector_size(16)));   // one 16-byte load
 
 #ifdef MOSHII_PROFILE
-__device__ long long g_prof[32];
+__device__ long long g_prof[64];
 #define PROF_BEGIN() long long _pt = clock64()
 #define PROF_LAP(slot) do { __syncthreads(); if (threadIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - _pt; _pt = _n; } else { _pt = 0; } } while (0)
 #define PROF_COUNT(slot) do { if (threadIdx.x == 0) g_prof[slot] += 1; } while (0)
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ACC(slot, var) do { if (threadIdx.x == 0) g_prof[slot] += clock64() - var; } while (0)   // thread 0's time since PROF_T
 #else
 #define PROF_BEGIN() do {} while (0)
 #define PROF_LAP(slot) do {} while (0)
 #define PROF_COUNT(slot) do {} while (0)
+#define PROF_T(var) do {} while (0)
+#define PROF_ACC(slot, var) do {} while (0)
 #endif
 
-enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6 };
+enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6, S_PRIOR_REF = 7, S_PRIOR_KB0 = 8 };
 
 struct Ctx {
     double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
     double *feat, *B, *omega, *Rw, *tw, *Rloc, *acol, *Jl;
     double *vposed, *vpos, *msim, *res, *vconst, *vshp, *shp0;
-    double *xb, *ell, *score;
+    double *xb, *ell, *score, *px0, *ps0;
     double *g, *dsd, *dgn, *ddl, *y;
     double *red, *scal;
     unsigned long long* anc;
@@ -441,6 +445,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                 if (fp.has_stay) { const double d2 = (sv_ - cx.shp0[e]) * op.wt_shape_stay; sy += d2 * d2; }
             }
     }
+    PROF_LAP(40);
     // F7: prior: l_g = sqrt(.5) (x - mu_g) . L_g for every component, argmin of |l_g|^2 - log w_g
     const int np_ = op.nbody;
     double prior_ss = 0.0;
@@ -448,65 +453,112 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         for (int b = tid; b < np_; b += MOSHII_TPB) cx.xb[b] = pose[op.body[b]];
         __syncthreads();
         const int G = pr.G;
-        // one wavefront per PAIR of mixture components; lane a accumulates column a (and a + 64) of both L_g while b runs
-        // uniformly over the rows, so that every load is one contiguous run of row b; 2 x 16 row loads are in flight per lane
-        // and every column sum is split into an even-row and an odd-row chain (four independent fma chains per lane: a
-        // single chain of 63 dependent f64 fmas per component was most of this phase).  The entries above the diagonal are
-        // stored zeros (moshii_prior_create), so no triangle mask is needed.  x - mu_g is parked in the component's slice of
-        // cx.ell (uniform-address LDS reads below); |l_g|^2 falls out of a wave reduction.
-        {
-            const int lane = tid & 63;
-            const int c0 = min(lane, np_ - 1), c1 = min(lane + 64, np_ - 1);   // clamped: every load is in bounds, no branch
-            for (int ga = (tid >> 6) * 2; ga < G; ga += (MOSHII_TPB / 64) * 2) {
-                const int gb = min(ga + 1, G - 1);   // (odd G: the last wave works its component twice)
-                const auto* La = pr.chols + (size_t)ga * np_ * np_;
-                const auto* Lb = pr.chols + (size_t)gb * np_ * np_;
-                double* dxa = &cx.ell[ga * np_];
-                double* dxb = &cx.ell[gb * np_];
-                for (int b = lane; b < np_; b += 64) { dxa[b] = cx.xb[b] - pr.means[(size_t)ga * np_ + b]; dxb[b] = cx.xb[b] - pr.means[(size_t)gb * np_ + b]; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-                for (int r0 = 0; r0 < np_; r0 += 16) {
-                    double va[16], vb[16];
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index as a scalar: scalar row addresses)
+        const int c0 = min(lane, np_ - 1), c1 = min(lane + 64, np_ - 1);   // clamped: every load is in bounds, no branch
+        // Scores |l_g|^2 of the components ga and gb (may be the same one), by all four wavefronts: wave w takes the rows
+        // [w RC, (w + 1) RC) of L_g -- lane a accumulates column a (and a + 64), every load one contiguous run of a row, 2 x 16
+        // row loads in flight per lane, each column sum split into an even-row and an odd-row chain -- the four partial column
+        // sums meet in LDS (cx.ell) and wave 0 squares and reduces them.  The entries above the diagonal are stored zeros
+        // (moshii_prior_create): no triangle mask.  The arithmetic of a component does not depend on its partner, so a score
+        // is the same bits whichever pair it was computed in.  Ends with a barrier; cx.score[ga], cx.score[gb] are then valid.
+        auto prior_pair = [&](int ga, int gb) {
+            const int RC = 16 * ((np_ + 63) / 64);
+            const int r_lo = wv * RC, r_hi = min(np_, r_lo + RC);
+            // (the factors, the means and cx.xb are padded by 16 rows / entries: rows past the end are read and weighted 0)
+            const auto* La = pr.chols + (size_t)ga * np_ * np_ + c0;
+            const auto* Lb = pr.chols + (size_t)gb * np_ * np_ + c0;
+            const auto* mua = pr.means + (size_t)ga * np_;
+            const auto* mub = pr.means + (size_t)gb * np_;
+            // x - mu_g of both components first goes to this wave's two slices of cx.ell (one coalesced load of the means per
+            // lane; 63 scalar loads of them inside the fma chains cost as much as the matrix loads), is read back with uniform
+            // addresses in the chains, and the slices then take the wave's partial column sums (a wave's LDS traffic is ordered).
+            double* pa = cx.ell + (size_t)wv * np_;               // [2][4 waves][np_ (+ slack: the next slice, cx.score)]
+            double* pb = cx.ell + (size_t)(4 + wv) * np_;
+            for (int r = lane; r < np_; r += 64) { pa[r] = cx.xb[r] - mua[r]; pb[r] = cx.xb[r] - mub[r]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, ha = 0.0, hb = 0.0;
+            for (int r0 = r_lo; r0 < r_hi; r0 += 16) {
+                double va[16], vb[16];
+                const auto* Ra = La + (size_t)r0 * np_;
+                const auto* Rb = Lb + (size_t)r0 * np_;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const size_t ro = (size_t)min(r0 + k, np_ - 1) * np_ + c0;
-                        va[k] = La[ro]; vb[k] = Lb[ro];
-                    }
+                for (int k = 0; k < 16; ++k) { va[k] = Ra[k * np_]; vb[k] = Rb[k * np_]; }
 #pragma unroll
-                    for (int k = 0; k < 16; k += 2) {
-                        const int r = r0 + k;
-                        const double m0 = (r < np_) ? 1.0 : 0.0, m1 = (r + 1 < np_) ? 1.0 : 0.0;   // (uniform)
-                        const int q0 = min(r, np_ - 1), q1 = min(r + 1, np_ - 1);
-                        a0 = fma(dxa[q0] * m0, va[k], a0); a1 = fma(dxa[q1] * m1, va[k + 1], a1);
-                        b0 = fma(dxb[q0] * m0, vb[k], b0); b1 = fma(dxb[q1] * m1, vb[k + 1], b1);
+                for (int k = 0; k < 16; k += 2) {
+                    const int r = r0 + k;
+                    const double m0 = (r < r_hi) ? 1.0 : 0.0, m1 = (r + 1 < r_hi) ? 1.0 : 0.0;   // (uniform; rows past r_hi: whatever is there)
+                    a0 = fma(pa[r] * m0, va[k], a0); a1 = fma(pa[r + 1] * m1, va[k + 1], a1);
+                    b0 = fma(pb[r] * m0, vb[k], b0); b1 = fma(pb[r + 1] * m1, vb[k + 1], b1);
+                }
+                if (np_ > 64)   // columns 64.. (SMPL's 69-dof prior): non-zero in rows >= 64 only
+                    for (int r = max(r0, 64); r < min(r0 + 16, r_hi); ++r) {
+                        ha = fma(pa[r], La[(size_t)r * np_ + (c1 - c0)], ha);
+                        hb = fma(pb[r], Lb[(size_t)r * np_ + (c1 - c0)], hb);
                     }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < np_) { pa[lane] = a0 + a1; pb[lane] = b0 + b1; }
+            if (lane + 64 < np_) { pa[lane + 64] = ha; pb[lane + 64] = hb; }
+            __syncthreads();
+            if (wv == 0) {
+                double sqa = 0.0, sqb = 0.0, dum = 0.0;
+                for (int c = lane; c < np_; c += 64) {
+                    const double* qa = cx.ell + c;
+                    const double* qb = cx.ell + (size_t)4 * np_ + c;
+                    const double la = ((qa[0] + qa[np_]) + (qa[2 * np_] + qa[3 * np_])) * 0.70710678118654757;
+                    const double lb = ((qb[0] + qb[np_]) + (qb[2 * np_] + qb[3 * np_])) * 0.70710678118654757;
+                    sqa += la * la; sqb += lb * lb;
                 }
-                double sa = (a0 + a1) * 0.70710678118654757, sb = (b0 + b1) * 0.70710678118654757;
-                double sqa = (lane < np_) ? sa * sa : 0.0, sqb = (lane < np_) ? sb * sb : 0.0;
-                if (np_ > 64) {   // columns 64.. (SMPL's 69-dof prior): rows b >= 64 only
-                    double ha = 0.0, hb = 0.0;
-                    for (int b = 64; b < np_; ++b) { ha = fma(dxa[b], La[(size_t)b * np_ + c1], ha); hb = fma(dxb[b], Lb[(size_t)b * np_ + c1], hb); }
-                    ha *= 0.70710678118654757; hb *= 0.70710678118654757;
-                    if (lane + 64 < np_) { sqa += ha * ha; sqb += hb * hb; }
-                }
-                double dum = 0.0;
                 wave_sum3(sqa, sqb, dum);
                 if (lane == 0) { cx.score[ga] = sqa; cx.score[gb] = sqb; }
             }
+            __syncthreads();
+        };
+        // The max-mixture needs the argmin and its value only.  With a reference point x0 at which every component's
+        // |l_g| is known, |l_g(x)| >= |l_g(x0)| - cnorm_g |x - x0| bounds every other component from below; if the
+        // component that won last time, evaluated exactly, stays below all those bounds (with a margin far above rounding),
+        // it IS the minimum and the other seven evaluations are skipped -- the result is what the full evaluation gives.
+        int kb = 0;
+        bool settled = false;
+        PROF_LAP(41);
+        if (cx.scal[S_PRIOR_REF] != 0.0) {
+            double d2 = 0.0;
+            for (int b = lane; b < np_; b += 64) { const double d = cx.xb[b] - cx.px0[b]; d2 += d * d; }
+            const double dist = sqrt(wave_sum(d2));   // (every wave for itself: same data, same order, same bits)
+            const int k0 = __builtin_amdgcn_readfirstlane((int)cx.scal[S_PRIOR_KB0]);
+            prior_pair(k0, k0);
+            const double val = cx.score[k0] + pr.neglogw[k0];
+            // lane g tests component g (every wave for itself, same data: a uniform verdict without a barrier)
+            const int gl = min(lane, G - 1);
+            const double lb = fmax(0.0, cx.ps0[gl] - pr.cnorm[gl] * dist);
+            const double LB = lb * lb + pr.neglogw[gl];
+            const bool open_ = lane < G && lane != k0 && !(val + 1e-9 * (fabs(val) + fabs(LB) + 1.0) < LB);
+            settled = __ballot(open_) == 0ull;
+            kb = k0; prior_ss = val;
         }
-        __syncthreads();
-        {   // argmin by every thread for itself (uniform LDS / scalar reads: no single-thread section to wait for)
-            int kb = 0;
-            double best = cx.score[0] + pr.neglogw[0];
-            for (int gc = 1; gc < G; ++gc) {
-                const double sc = cx.score[gc] + pr.neglogw[gc];
-                if (sc < best) { best = sc; kb = gc; }
+        PROF_LAP(42);
+        if (settled) PROF_COUNT(28);
+        if (!settled) {
+            PROF_COUNT(29);
+            for (int ga = 0; ga < G; ga += 2) prior_pair(ga, min(ga + 1, G - 1));
+            // argmin (lowest index on ties): lane g holds component g's total, every thread walks them by readlane
+            const double sc = cx.score[min(lane, G - 1)] + pr.neglogw[min(lane, G - 1)];
+            kb = 0;
+            double best = readlane_f64(sc, 0);
+            for (int gc = 1; gc < min(G, 64); ++gc) {
+                const double v = readlane_f64(sc, gc);
+                if (v < best) { best = v; kb = gc; }
             }
             prior_ss = best;
-            if (tid == 0) cx.scal[S_KBEST] = (double)kb;   // (read by assemble(), many barriers later)
+            // new reference: this point (the barriers of the evaluations above separate these writes from the reads of the test)
+            for (int b = tid; b < np_; b += MOSHII_TPB) cx.px0[b] = cx.xb[b];
+            if (tid < G) cx.ps0[tid] = sqrt(cx.score[tid]);
+            if (tid == 0) { cx.scal[S_PRIOR_REF] = 1.0; cx.scal[S_PRIOR_KB0] = (double)kb; }
         }
+        if (tid == 0) cx.scal[S_KBEST] = (double)kb;   // (read by assemble(), many barriers later)
+        PROF_LAP(43);
     }
     block_sum3(sd, sv, sh, cx.red);
     if constexpr (XT) block_sum3(sf, ss, sy, cx.red);
@@ -572,7 +624,7 @@ struct JtJAcc {
         }
     }
     __device__ __forceinline__ void accumulate(const double* rows, int nr, int LDJ) {
-        switch (threadIdx.x >> 6) {   // wave-uniform: the tile indices of a wave are compile-time constants in its branch
+        switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {   // wave-uniform: the tile indices of a wave are compile-time constants in its branch
             case 0: accumulate_w<0>(rows, nr, LDJ); break;
             case 1: accumulate_w<1>(rows, nr, LDJ); break;
             case 2: accumulate_w<2>(rows, nr, LDJ); break;
@@ -1388,7 +1440,7 @@ __device__ __forceinline__ Ctx make_ctx(double* lds, const ChainLayout& ly) {
     cx.Rloc = lds + ly.o_Rloc; cx.acol = lds + ly.o_acol;
     cx.vshp = lds + ly.o_vshp; cx.shp0 = lds + ly.o_shp0;
     cx.vconst = lds + ly.o_vconst; cx.vposed = lds + ly.o_vposed; cx.vpos = lds + ly.o_vpos; cx.msim = lds + ly.o_msim; cx.res = lds + ly.o_res;
-    cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score;
+    cx.xb = lds + ly.o_xb; cx.ell = lds + ly.o_ell; cx.score = lds + ly.o_score; cx.px0 = lds + ly.o_px0; cx.ps0 = lds + ly.o_ps0;
     cx.g = lds + ly.o_g; cx.dsd = lds + ly.o_dsd; cx.dgn = lds + ly.o_dgn; cx.ddl = lds + ly.o_ddl; cx.y = lds + ly.o_y;
     cx.red = lds + ly.o_red; cx.scal = lds + ly.o_scal;
     cx.anc = reinterpret_cast<unsigned long long*>(lds + ly.o_anc);
@@ -1621,7 +1673,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     bool skip_eval = reuse && !rigid;
     while (true) {
         if (skip_eval) { last = carried; skip_eval = false; }
-        else last = eval_forward_fn<XT>(fp, visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst);
+        else { PROF_T(_te); last = eval_forward_fn<XT>(fp, visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst); PROF_ACC(15, _te); }
         at_pose = true;   // cleared below when a trial point is rejected
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
@@ -1634,6 +1686,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         }
         if (eval_only) break;
         ++n_fev;
+        PROF_T(_t1);
         bool improved = false, do_assemble = false;
         double rho = 0.0;
         if (init) {
@@ -1655,12 +1708,16 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 else { do_assemble = true; sse = last.total; }
             }
         }
+        PROF_ACC(23, _t1);
         if (do_assemble) {
-            A = assemble_fn<NBLK, XT>(fp, ly.o_pose, n, ncp, nkf, nfree_hand, qs);
+            { PROF_T(_ta); A = assemble_fn<NBLK, XT>(fp, ly.o_pose, n, ncp, nkf, nfree_hand, qs); PROF_ACC(16, _ta); }
+            PROF_T(_t2);
             double gm = 0.0;
             for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
             if (block_max(gm, cx.red) < 1e-15) done = true;
+            PROF_ACC(24, _t2);
         }
+        PROF_T(_t3);
         if (!init) {   // updateRadius + trust-region floor
             double pnorm2 = p2;
             if (improved) {
@@ -1691,6 +1748,8 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             break;
         }
         init = false;
+        PROF_ACC(25, _t3);
+        PROF_T(_t4);
         // ---- update_step
         if (norm_sd >= delta) {
             const double sc = delta / norm_sd;
@@ -1700,8 +1759,11 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 // (BIG: factor in the chain's global scratch behind the shape-derivative arrays, LDS part at the head of `big`)
                 constexpr bool BIG = XT && NBLK > 8;
                 bool solved;
+                PROF_T(_ts);
                 if constexpr (BIG) solved = ldl_big<NBLK>(A, qs + (size_t)6 * md.K * op.nshape, cx.big, cx.g, cx.dgn, cx.y, n);
                 else solved = ldl_solve<NBLK>(A, ly.o_big, ly.o_g, ly.o_dgn, ly.o_y, n);
+                PROF_ACC(17, _ts);
+                PROF_ACC(26, _t4);   // (includes the solve: subtract slot 17)
                 if (!solved) {
                     fail = 1;
                     for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
@@ -1729,6 +1791,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
         __syncthreads();
+        PROF_T(_t5);
         // ---- trial point and norms
         double s2 = 0.0;
         p2 = 0.0; gd = 0.0;
@@ -1745,6 +1808,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         __syncthreads();
         for (int q = 3 + tid; q < n; q += MOSHII_TPB) cx.pose_t[cx.colpid[q]] += cx.ddl[q];
         __syncthreads();
+        PROF_ACC(27, _t5);
     }
     n_iter += iteration;
     carried = last;
@@ -1792,6 +1856,8 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         has_prev = is ? (is[2 * NP + 3] != 0.0) : (iv != nullptr);
         first = is ? (is[2 * NP + 4] != 0.0) : (chp->first != 0);
     }
+    if (tid == 0) cx.scal[S_PRIOR_REF] = 0.0;   // no prior reference point yet (eval_forward)
+    if (tid < 16) cx.ell[8 * pr.npose + tid] = 0.0;   // the slack behind the prior's partial-sum slices is read (times 0): keep it finite
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];   // regressed joints: read in every phase, keep them in LDS
     __syncthreads();
@@ -1806,6 +1872,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
 #endif
 
     for (int t = 0; t <= F; ++t) {
+        PROF_T(_tf);
         // chunk hand-off states: moshii_sequence_solve checks a chunk's entry state against its predecessor's final one
         for (int which = 0; which < 2; ++which) {
             double* so = (which == 0) ? ((t == skip) ? chp->entry_state : nullptr) : ((t == F) ? chp->final_state : nullptr);
@@ -1879,6 +1946,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         }
         __syncthreads();
         int n_iter = 0, n_fev = 0, fail = 0;
+        PROF_ACC(18, _tf);
         // phases: [rigid + annealed rounds x10 x5 x1 (first solved frame only, :629-655)] step 1 (:665-671),
         //         step 2 (:676-705), record (:712-724)
         Sse fin, carried;
@@ -1904,6 +1972,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             prev_wt_pose = fp.wt_pose; prev_terms = terms;
         }
         first = false;
+        PROF_T(_tr);
         if (record && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
             // repair chains: has this chain re-joined the trajectory already stored for this chunk?
             double dv = 0.0;
@@ -1937,6 +2006,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         __syncthreads();
         if (rejoin_run >= 2 && t + 1 < F) { if (tid == 0 && chp->frames_done) *chp->frames_done = t + 1; break; }   // pose and pose_prev both match: the stored rows (and final state) stand
         if (t + 1 == F && tid == 0 && chp->frames_done) *chp->frames_done = F;
+        PROF_ACC(19, _tr);
     }
     PROF_LAP(12);
 #ifdef MOSHII_PROFILE
@@ -2047,8 +2117,8 @@ extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t
 
 #ifdef MOSHII_PROFILE
 extern "C" int moshii_prof_read(long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(moshii::g_prof), sizeof(long long) * 32) != hipSuccess) return -1;
-    if (reset) { long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(moshii::g_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(moshii::g_prof), sizeof(long long) * 64) != hipSuccess) return -1;
+    if (reset) { long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(moshii::g_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

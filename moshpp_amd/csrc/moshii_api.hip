@@ -90,8 +90,12 @@ struct moshii_model_s {
 
 struct moshii_prior_s {
     int G = 0, npose = 0;
-    double *d_means = nullptr, *d_chols = nullptr, *d_halfprec = nullptr, *d_neglogw = nullptr;
-    PriorDev dev() const { PriorDev p; p.G = G; p.npose = npose; p.means = as_gp(d_means); p.chols = as_gp(d_chols); p.halfprec = as_gp(d_halfprec); p.neglogw = as_gp(d_neglogw); return p; }
+    double *d_means = nullptr, *d_chols = nullptr, *d_halfprec = nullptr, *d_neglogw = nullptr, *d_cnorm = nullptr;
+    PriorDev dev() const {
+        PriorDev p; p.G = G; p.npose = npose; p.means = as_gp(d_means); p.chols = as_gp(d_chols); p.halfprec = as_gp(d_halfprec);
+        p.neglogw = as_gp(d_neglogw); p.cnorm = as_gp(d_cnorm);
+        return p;
+    }
 };
 
 struct moshii_attach_s {
@@ -293,7 +297,9 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.o_feat = take(K * 9); ly.o_B = take(K * 28); ly.o_omega = take(K * 10); ly.o_Jl = take(K * 3); ly.o_Rw = take(K * 9); ly.o_tw = take(K * 3);
     ly.o_Rloc = take(K * 9); ly.o_acol = take(K * 9);
     ly.o_vconst = take(Nvmax * 3); ly.o_vposed = take(Nvmax * 3); ly.o_vpos = take(Nvmax * 3); ly.o_msim = take(Mmax * 3); ly.o_res = take(Mmax * 3);
-    ly.o_xb = take(std::max(npose, 1)); ly.o_ell = take(std::max(G * npose, 1)); ly.o_score = take(std::max(G, 1));
+    ly.o_xb = take(std::max(npose, 1) + 16);   // (+16: read unclamped in 16-row groups)
+    ly.o_ell = take(std::max(8 * npose, 1) + 16); ly.o_score = take(std::max(G, 1));   // (ell: [2][4 waves][npose] + 16 zeros: read in 16-row groups)
+    ly.o_px0 = take(std::max(npose, 1)); ly.o_ps0 = take(std::max(G, 1));
     ly.o_g = take(LDJ); ly.o_dsd = take(LDJ); ly.o_dgn = take(LDJ); ly.o_ddl = take(LDJ); ly.o_y = take(LDJ);
     ly.o_red = take(16); ly.o_scal = take(16);
     ly.o_anc = take(K);
@@ -522,7 +528,7 @@ int moshii_prior_create(int32_t G, int32_t npose, const double* means, const dou
     auto* p = new moshii_prior_s();
     p->G = G; p->npose = npose;
     const size_t nn = (size_t)npose * npose;
-    std::vector<double> half((size_t)G * nn), nlw(G), lower((size_t)G * nn, 0.0);   // lower: the factors with explicit zeros above the
+    std::vector<double> half((size_t)G * nn), nlw(G), cn(G), lower((size_t)G * nn, 0.0);   // lower: the factors with explicit zeros above the
     for (int g = 0; g < G; ++g) {                                                    // diagonal (the chain kernel reads whole rows)
         const double* L = chols + g * nn;
         for (int i = 0; i < npose; ++i)
@@ -535,12 +541,27 @@ int moshii_prior_create(int32_t G, int32_t npose, const double* means, const dou
                 half[g * nn + (size_t)j * npose + i] = 0.5 * s;
             }
         nlw[g] = -std::log(weights[g]);
+        // |L|_2 <= min(|L|_F, sqrt(|L|_1 |L|_inf)); a hair above, so that rounding here cannot make the bound too small
+        double fro = 0.0, n1 = 0.0, ninf = 0.0;
+        std::vector<double> colsum(npose, 0.0);
+        for (int i = 0; i < npose; ++i) {
+            double rs = 0.0;
+            for (int j = 0; j <= i; ++j) { const double v = std::fabs(L[(size_t)i * npose + j]); fro += v * v; rs += v; colsum[j] += v; }
+            ninf = std::max(ninf, rs);
+        }
+        for (int j = 0; j < npose; ++j) n1 = std::max(n1, colsum[j]);
+        cn[g] = std::min(std::sqrt(fro), std::sqrt(n1 * ninf)) * 0.70710678118654757 * (1.0 + 1e-12);
     }
     int rc;
-    if ((rc = dev_upload(means, (size_t)G * npose, &p->d_means))) return rc;
+    // (means and factors carry 16 entries / rows of zero padding: the chain kernel reads whole 16-row groups unclamped)
+    std::vector<double> means_p((size_t)G * npose + 16, 0.0);
+    std::copy(means, means + (size_t)G * npose, means_p.begin());
+    lower.resize((size_t)G * nn + (size_t)16 * npose, 0.0);
+    if ((rc = dev_upload(means_p.data(), means_p.size(), &p->d_means))) return rc;
     if ((rc = dev_upload(lower.data(), lower.size(), &p->d_chols))) return rc;
     if ((rc = dev_upload(half.data(), half.size(), &p->d_halfprec))) return rc;
     if ((rc = dev_upload(nlw.data(), nlw.size(), &p->d_neglogw))) return rc;
+    if ((rc = dev_upload(cn.data(), cn.size(), &p->d_cnorm))) return rc;
     *out = p;
     return MOSHII_OK;
 }
@@ -548,7 +569,7 @@ int moshii_prior_create(int32_t G, int32_t npose, const double* means, const dou
 int moshii_prior_destroy(moshii_prior_t p) {
     if (!p) return MOSHII_OK;
     hipDeviceSynchronize();
-    void* ptrs[] = {p->d_means, p->d_chols, p->d_halfprec, p->d_neglogw};
+    void* ptrs[] = {p->d_means, p->d_chols, p->d_halfprec, p->d_neglogw, p->d_cnorm};
     for (void* q : ptrs) if (q) hipFree(q);
     delete p;
     return MOSHII_OK;

@@ -65,6 +65,8 @@ struct PriorDev {
     MOSHII_GP(const double) chols;     // [G][npose][npose] lower, L L^T = precision
     MOSHII_GP(const double) halfprec;  // [G][npose][npose] 0.5 * L L^T
     MOSHII_GP(const double) neglogw;   // [G] -log(weight)
+    MOSHII_GP(const double) cnorm;     // [G] an upper bound of |L_g|_2 / sqrt(2): |l_g(x) - l_g(y)| <= cnorm_g |x - y| (the kernel's
+                                       //     exact shortcut past components that cannot be the minimum)
 };
 
 struct OptsDev {
@@ -126,6 +128,7 @@ struct ChainLayout {
     int o_feat, o_B, o_omega, o_Rw, o_tw, o_Rloc, o_acol, o_Jl;
     int o_vposed, o_vpos, o_msim, o_res, o_vconst;
     int o_xb, o_ell, o_score;
+    int o_px0, o_ps0;          // prior reference point [npose] and sqrt of every component's score there [G]
     int o_g, o_dsd, o_dgn, o_ddl, o_y;
     int o_red, o_scal;
     int o_anc;                 // K x u64

@@ -2,6 +2,9 @@
 // workgroup; a fiber blocks at a workgroup barrier or at a wavefront rendezvous and the scheduler releases a group when all of its
 // live members have arrived (convergent use of the collectives is assumed; anything else is reported as a deadlock).
 #include <ucontext.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,8 +63,26 @@ void wave_gather2(double a, double b, const double** all) {
     *all = &gather_buf[(size_t)(cur_fiber / 64) * 128];
 }
 
+static void segv_backtrace(int) {   // a kernel bug on the CPU: say where (symbols: build with -g, resolve with addr2line)
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    const char msg[] = "hipemu: SIGSEGV inside an emulated kernel; backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(139);
+}
+
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
     const int nt = (int)(block.x * block.y * block.z);
+    static bool handler_installed = false;
+    if (!handler_installed) {
+        static char altstack[1 << 16];
+        stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof(altstack); ss.ss_flags = 0;
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa; memset(&sa, 0, sizeof(sa)); sa.sa_handler = segv_backtrace; sa.sa_flags = SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, nullptr);
+        handler_installed = true;
+    }
     gather_buf.assign((size_t)((nt + 63) / 64) * 128, 0.0);
     if (const char* e = getenv("HIPEMU_LDS_SHRINK")) { size_t cut = (size_t)atol(e); lds_bytes = lds_bytes > cut ? lds_bytes - cut : 0; }   // (self-test of the guard)
     // everything beyond the dynamic LDS this launch asked for is a canary: a kernel writing past its allocation is caught below

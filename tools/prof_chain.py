@@ -10,7 +10,7 @@ M = {'smplh': 53, 'smpl': 41, 'smplx': 89, 'mano': 33}[mt]
 job = workload.make_job(mt, F, M, seed=1000, optimize_fingers=fingers)
 solver = workload.make_solver(job)
 lib = capi.load()
-buf = (C.c_longlong * 32)()
+buf = (C.c_longlong * 64)()
 lib.moshii_prof_read.argtypes = [C.POINTER(C.c_longlong), C.c_int]
 solver.solve(job['obs'][:8], job['vis'][:8])
 lib.moshii_prof_read(buf, 1)
@@ -19,7 +19,8 @@ lib.moshii_prof_read(buf, 1)
 p = np.array(list(buf), dtype=np.float64)
 names = {0: 'eval: fullpose/rodrigues/chain', 1: 'eval: posedirs', 2: 'eval: skin+markers', 3: 'eval: prior+reduce',
          4: 'asm: T0', 5: 'asm: T1 vertex jac', 6: 'asm: T2 marker rows', 7: 'asm: T3 JtJ', 8: 'asm: structured',
-         9: 'chol factor', 10: 'back-subst', 12: 'kernel total'}
+         9: 'chol factor', 10: 'back-subst', 12: 'kernel total',
+         40: 'eval: velocity / finger sums', 41: 'eval: prior setup (xb)', 42: 'eval: prior shortcut', 43: 'eval: prior full + argmin'}
 tot = p[12]
 print(f'{mt} F={F} fingers={fingers} wall {dt*1e3:.1f} ms  ({dt/F*1e6:.1f} us/frame)  launch {capi.last_launch_info()}')
 print(f'evals {p[20]:.0f} ({p[20]/F:.2f}/frame) assembles {p[21]:.0f} ({p[21]/F:.2f}/frame) chol {p[22]:.0f} ({p[22]/F:.2f}/frame)')
@@ -30,5 +31,11 @@ for k, nm in names.items():
     acc += p[k]
     print(f'  {nm:34s} {p[k]/tot*100:6.2f}%  {p[k]*us_per_tick/F:8.1f} us/frame')
 print(f'  {"other (dogleg control, copies)":34s} {(tot-acc)/tot*100:6.2f}%  {(tot-acc)*us_per_tick/F:8.1f} us/frame')
+ph = lambda ks: sum(p[k] for k in ks) * us_per_tick / F
+print(f'  calls (thread 0, wall): eval_forward_fn {p[15]*us_per_tick/F:.1f} (phases inside {ph([0,1,2,3]):.1f}) | assemble_fn {p[16]*us_per_tick/F:.1f} (inside {ph([4,5,6,7,8]):.1f})'
+      f' | ldl_solve {p[17]*us_per_tick/F:.1f} (inside {ph([9,10]):.1f}) | frame setup {p[18]*us_per_tick/F:.1f} | frame end {p[19]*us_per_tick/F:.1f} us/frame')
+print(f'  control (thread 0, wall): post-eval {p[23]*us_per_tick/F:.1f} | gradient max {p[24]*us_per_tick/F:.1f} | radius + start_iteration {p[25]*us_per_tick/F:.1f}'
+      f' | trial point {p[27]*us_per_tick/F:.1f} us/frame')
+print(f'  prior: shortcut taken {p[28]:.0f} times, full evaluation {p[29]:.0f} times')
 print(f'shader clock during the kernel: {p[12] / (p[30] / 100e6) / 1e6:.0f} MHz (s_memtime ticks / s_memrealtime @100 MHz)')
 print('iters/frame', out['iters'][:,0].mean(), 'status', np.unique(out['status'], return_counts=True))
