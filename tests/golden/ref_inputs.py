@@ -214,3 +214,35 @@ def layout_creation_inputs():
             'smplh_hands': (body + hands, 'smplh', {}),
             'smplx_face_wrist': (body + hands + face, 'smplx', dict(wrist_markers_on_stick=True)),
             'smpl_no_split': (body + hands, 'smpl', dict(separate_types=['body']))}
+
+
+def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_frames=(), dof_per_hand=12, use_hands_mean=True):
+    """One seeded Stage-II call as the reference reads it: model pickle, hand-prior npz, body-prior pickle and the mocap npz
+    written to `outdir`, plus the in-memory arguments of mosh_stageii.  The synthetic body is the triangulated capsule model
+    (synth.synth_mesh_model) at `n_verts` vertices: small enough for a finite-difference Jacobian of the reference's residuals.
+    Returns a dict with the file names, the arguments, and the synth sequence `s` (the same arrays helpers.oracle_case uses)."""
+    import pickle
+    import scipy.sparse as sp
+    from moshpp_amd import synth
+    dd = synth.synth_mesh_model(model_type, seed=seed, n_verts=n_verts)
+    s = synth.make_sequence(model_type, n_frames, n_markers, seed=seed, dd=dd, dof_per_hand=dof_per_hand,
+                            use_hands_mean=use_hands_mean, empty_frames=tuple(empty_frames), n_gaps=1, dropout=0.04)
+    model_fname = os.path.join(outdir, 'model.pkl')
+    pk = {k: v for k, v in dd.items() if not k.startswith('_') and k != 'model_type'}
+    pk['J_regressor'] = sp.csc_matrix(dd['J_regressor'])
+    with open(model_fname, 'wb') as fh:
+        pickle.dump(pk, fh, protocol=2)
+    hand_prior_fname = None
+    if s['hand_prior'] is not None:
+        hand_prior_fname = os.path.join(outdir, 'hand_prior.npz')
+        np.savez(hand_prior_fname, **s['hand_prior'])
+    body_prior_fname = None
+    if model_type != 'mano':
+        body_prior_fname = os.path.join(outdir, 'body_prior.pkl')
+        with open(body_prior_fname, 'wb') as fh:
+            pickle.dump(s['gmm'], fh, protocol=2)
+    mocap_fname = os.path.join(outdir, 'mocap.npz')
+    np.savez(mocap_fname, markers=s['markers'], labels=np.array(s['labels']), frame_rate=s['frame_rate'])
+    return dict(s=s, model_fname=model_fname, hand_prior_fname=hand_prior_fname, body_prior_fname=body_prior_fname,
+                mocap_fname=mocap_fname, markers_latent=s['markers_latent'], latent_labels=s['latent_labels'], betas=s['betas'],
+                marker_meta=s['marker_meta'], dof_per_hand=dof_per_hand, use_hands_mean=use_hands_mean, model_type=model_type)

@@ -486,3 +486,25 @@ def test_host_level_chunks_carry_the_free_shape_block(gpu_lib):
     print(info)
     assert info['n_chunks'] == 4
     assert np.abs(out['fullpose'] - seq['fullpose']).max() < 1e-6 and np.abs(out['shape'] - seq['shape']).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['smplh_body', 'smpl_body'])
+def test_chain_matches_the_executed_reference_stageii(gpu_lib, name, tmp_path):
+    """The kernel against tests/golden/ref_stageii.npz: the trajectory the REFERENCE's own mosh_stageii (chmosh.py:458-741,
+    executed by tests/golden/make_ref_stageii_golden.py under a lazy chumpy stand-in) produced on the same seeded files --
+    poses, translations, per-term errors, skipped frames and dogleg iterations per frame."""
+    from moshpp_amd import capi
+    from tests.test_ref_golden import _stageii_ref_case, _check_against_reference_run
+    c = _stageii_ref_case(name, tmp_path)
+    ref = c['ref']
+    dev = device_case(c)
+    out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                [dict(attach=dev['attach'], obs=c['obs'], vis=c['vis'], first=True)])[0]
+    solved = np.where(out['status'] == 0)[0]
+    errs = dict(data=out['errs'][solved, 0], poseB=out['errs'][solved, 1], velo=out['errs'][solved[2:], 2])
+    _check_against_reference_run(name, ref, out['fullpose'][solved], out['trans'][solved], errs, solved, c['vis'],
+                                 c['s']['latent_labels'])
+    calls = ref[f'{name}_minimize_calls']
+    per_frame = [int(calls[:5, 2].sum())] + [int(calls[5 + 2 * i:7 + 2 * i, 2].sum()) for i in range(len(solved) - 1)]
+    assert per_frame == [int(v) for v in out['iters'][solved, 0]]

@@ -248,3 +248,84 @@ def test_marker_layout_creation_matches_reference_functions(case, tmp_path):
     fn = str(tmp_path / 'layout.json')
     marker_labels_to_marker_layout(labels_in, fn, mtype, **kw)
     assert open(fn).read() == str(G[f'mklayout_{case}'])
+
+
+# ---- the Stage-II schedule itself: the reference's mosh_stageii EXECUTED (tests/golden/make_ref_stageii_golden.py) ------------
+STAGEII_REF_CASES = {'smplh_body': 'smplh', 'smpl_body': 'smpl'}
+
+
+def _stageii_ref_case(name, tmp_path):
+    """The seeded inputs of one fixture case, rebuilt (no reference needed), prepared for the oracle; + the fixture arrays."""
+    from tests.golden.ref_inputs import stageii_case
+    from tests.helpers import pose_layout
+    from moshpp_amd import synth
+    ref = np.load(os.path.join(GOLD, 'ref_stageii.npz'))
+    F, M, seed, V = [int(v) for v in ref[f'{name}_args'][:4]]
+    empty = tuple(int(v) for v in ref[f'{name}_args'][4:])
+    mt = STAGEII_REF_CASES[name]
+    c = stageii_case(mt, F, M, seed, V, str(tmp_path), empty_frames=empty)
+    s = c['s']
+    dd = s['model']
+    bd, hd, hm, comps = pose_layout(s)
+    model = dict(v_template=dd['v_template'], shapedirs=dd['shapedirs'], posedirs=dd['posedirs'], weights=dd['weights'],
+                 J_regressor=dd['J_regressor'], parents=synth.kintree_parents(mt), body_dof=bd, hand_dof=hd, hands_mean=hm,
+                 selected_components=comps)
+    m = so.prepare_model(model, s['betas'])
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
+    closest, coef = so.transformed_coeffs(can, s['markers_latent'])
+    prior = so.prepare_gmm_prior(s['gmm'], 63 if mt in ('smplh', 'smplx') else 69)
+    obs = np.nan_to_num(s['markers'])
+    vis = ~np.isnan(s['markers']).any(-1)
+    return dict(ref=ref, s=s, m=m, model=model, closest=closest, coef=coef, prior=prior, obs=obs, vis=vis, model_type=mt, F=F)
+
+
+def _check_against_reference_run(name, ref, fullpose, trans, errs, frame_ids, vis, labels):
+    # The fixture's solves used a central-difference Jacobian of the reference's residuals (h = 1e-6), ours the analytic one:
+    # the two dogleg runs agree to ~1e-8 per solve; a schedule difference (a weight, a free-variable set, the timing of
+    # pose_prev, a missing term) shows at 1e-3 and above.
+    assert len(fullpose) == len(ref[f'{name}_fullpose'])
+    assert [int(n) for n in ref[f'{name}_n_obs']] == [int(vis[t].sum()) for t in frame_ids]           # empty frames skipped
+    assert list(ref[f'{name}_labels_obs']) == ['|'.join(l for l, v in zip(labels, vis[t]) if v) for t in frame_ids]
+    assert np.abs(fullpose - ref[f'{name}_fullpose']).max() < 1e-6        # (measured: 5e-9 rad / 2e-12 m for the oracle)
+    assert np.abs(trans - ref[f'{name}_trans']).max() < 1e-8
+    assert list(ref[f'{name}_err_keys']) == ['data', 'poseB', 'velo']
+    # the velocity term exists from the THIRD solved frame on: pose_prev is refreshed (chmosh.py:656-657) only after the frame's
+    # objective was built (:624-626), so the second solved frame still sees pose_prev = None -- two entries fewer (:707-710)
+    assert len(ref[f'{name}_err_velo']) == len(fullpose) - 2
+    for k in ('data', 'poseB'):
+        np.testing.assert_allclose(errs[k], ref[f'{name}_err_{k}'], rtol=1e-6)
+    velo = np.asarray(errs['velo'])
+    np.testing.assert_allclose(velo[len(velo) - len(fullpose) + 2:], ref[f'{name}_err_velo'], rtol=1e-5, atol=1e-14)
+
+
+@pytest.mark.parametrize('name', sorted(STAGEII_REF_CASES))
+def test_stageii_schedule_matches_reference_function(name, tmp_path):
+    """oracle.stageii_chain against the trajectory the reference's own mosh_stageii produced on the same files."""
+    c = _stageii_ref_case(name, tmp_path)
+    ref = c['ref']
+    out = so.stageii_chain(c['m'], c['prior'], c['closest'], c['coef'], c['obs'], c['vis'], c['model_type'])
+    _check_against_reference_run(name, ref, out['fullpose'], out['trans'], out['errs'], out['frame_ids'], c['vis'], c['s']['latent_labels'])
+    # the simulated markers of the first solved frame, and the keys of the result dict the drop-in returns
+    assert np.abs(out['markers_sim'][0] - ref[f'{name}_markers_sim0']).max() < 1e-6
+    assert list(ref[f'{name}_keys']) == ['fullpose', 'stageii_debug_details', 'trans']          # (markers_* / labels_obs move into the details)
+    assert list(ref[f'{name}_debug_keys']) == ['labels_obs', 'labels_orig', 'markers_obs', 'markers_orig', 'markers_sim', 'mocap_fname',
+                                               'mocap_frame_rate', 'mocap_time_length', 'stageii_errs']
+    # 3 first-frame rounds + Step 1 + Step 2 per solved frame (chmosh.py:637-705)
+    calls = ref[f'{name}_minimize_calls']
+    assert len(calls) == 3 + 2 * len(out['fullpose'])
+    n1 = 3 + len(so.pose_id_sets(c['model_type'], c['m']['NP'])[3])
+    assert set(int(v) for v in calls[:, 0]) == {n1}                              # free variables of every solve (body-only: step 1 == step 2)
+    # dogleg iterations per solved frame: the reference-built problem and the oracle's take the same number of steps
+    per_frame = [int(calls[:5, 2].sum())] + [int(calls[5 + 2 * i:7 + 2 * i, 2].sum()) for i in range(len(out['fullpose']) - 1)]
+    assert per_frame == [int(v) for v in out['iters']]
+
+
+@pytest.mark.parametrize('name', sorted(STAGEII_REF_CASES))
+def test_host_mosh_stageii_keys_match_reference_function(name, tmp_path):
+    """The key sets of the dict our drop-in mosh_stageii builds, against the reference's (no GPU: the solver is not run)."""
+    ref = np.load(os.path.join(GOLD, 'ref_stageii.npz'))
+    from moshpp_amd import chmosh
+    import inspect
+    src = inspect.getsource(chmosh.mosh_stageii)
+    for k in list(ref[f'{name}_keys']) + list(ref[f'{name}_debug_keys']):
+        assert f"'{k}'" in src, k
