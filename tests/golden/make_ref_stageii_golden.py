@@ -407,7 +407,7 @@ def run_reference_stageii(model_type, n_frames, n_markers, seed, n_verts, empty_
     reference's mosh_stageii on it.  Returns (result dict, case)."""
     from tests.golden.ref_inputs import stageii_case
     tmp = tempfile.mkdtemp(prefix='ref_stageii_')
-    case = stageii_case(model_type, n_frames, n_markers, seed, n_verts, tmp, empty_frames=empty_frames)
+    case = stageii_case(model_type, n_frames, n_markers, seed, n_verts, tmp, empty_frames=empty_frames, finger_markers=optimize_fingers)
     # the reference modules, from their files
     _module('moshpp'); _module('moshpp.models'); _module('moshpp.prior'); _module('moshpp.tools'); _module('moshpp.marker_layout')
     sfd = load_ref('moshpp.models.smpl_fast_derivatives', 'models/smpl_fast_derivatives.py')
@@ -441,18 +441,20 @@ def run_reference_stageii(model_type, n_frames, n_markers, seed, n_verts, empty_
     return out, case
 
 
-CASES = {   # name: (model_type, frames, markers, seed, vertices, empty frames)
-    'smplh_body': ('smplh', 6, 53, 3, 1500, (3,)),       # BASELINE config 2's shape: SMPL-H, 53 markers, fixed betas; one empty frame
-    'smpl_body': ('smpl', 5, 41, 4, 1200, ()),           # BASELINE config 1's shape: SMPL, 41 markers; dropouts -> annealed weights
+CASES = {   # name: (model_type, frames, markers, seed, vertices, empty frames, optimize_fingers)
+    'smplh_body': ('smplh', 6, 53, 3, 1500, (3,), False),    # BASELINE config 2's shape: SMPL-H, 53 markers, fixed betas; one empty frame
+    'smpl_body': ('smpl', 5, 41, 4, 1200, (), False),        # BASELINE config 1's shape: SMPL, 41 markers; dropouts -> annealed weights
+    'smplh_fingers': ('smplh', 4, 66, 5, 1500, (), True),    # Step 2 frees the hand coefficients and adds the poseH term (chmosh.py:681-683)
 }
 
 
 def main():
     out = {}
-    for name, (mt, F, M, seed, V, empty) in CASES.items():
-        res, case = run_reference_stageii(mt, F, M, seed, V, empty_frames=empty)
+    for name, (mt, F, M, seed, V, empty, fingers) in CASES.items():
+        res, case = run_reference_stageii(mt, F, M, seed, V, empty_frames=empty, optimize_fingers=fingers)
         dbg = res['stageii_debug_details']
         out[f'{name}_args'] = np.array([F, M, seed, V] + list(empty), dtype=np.int64)
+        out[f'{name}_fingers'] = np.array(bool(fingers))
         out[f'{name}_fullpose'] = np.asarray(res['fullpose'])
         out[f'{name}_trans'] = np.asarray(res['trans'])
         out[f'{name}_keys'] = np.array(sorted(res.keys()))

@@ -216,7 +216,8 @@ def layout_creation_inputs():
             'smpl_no_split': (body + hands, 'smpl', dict(separate_types=['body']))}
 
 
-def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_frames=(), dof_per_hand=12, use_hands_mean=True):
+def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_frames=(), dof_per_hand=12, use_hands_mean=True,
+                 finger_markers=False):
     """One seeded Stage-II call as the reference reads it: model pickle, hand-prior npz, body-prior pickle and the mocap npz
     written to `outdir`, plus the in-memory arguments of mosh_stageii.  The synthetic body is the triangulated capsule model
     (synth.synth_mesh_model) at `n_verts` vertices: small enough for a finite-difference Jacobian of the reference's residuals.
@@ -226,7 +227,17 @@ def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_f
     from moshpp_amd import synth
     dd = synth.synth_mesh_model(model_type, seed=seed, n_verts=n_verts)
     s = synth.make_sequence(model_type, n_frames, n_markers, seed=seed, dd=dd, dof_per_hand=dof_per_hand,
-                            use_hands_mean=use_hands_mean, empty_frames=tuple(empty_frames), n_gaps=1, dropout=0.04)
+                            use_hands_mean=use_hands_mean, empty_frames=tuple(empty_frames), n_gaps=1, dropout=0.04,
+                            body_only_markers=not finger_markers)
+    if finger_markers:   # the reference switches optimize_fingers off unless the layout has 'finger' typed markers (chmosh.py:474-486)
+        K = dd['weights'].shape[1]
+        hand0 = (3 * K - 90) // 3
+        on_hand = np.array([int(np.argmax(dd['weights'][v])) >= hand0 for v in s['marker_meta']['marker_vids'].values()])
+        assert on_hand.any()
+        mm = s['marker_meta']
+        mm['marker_type'] = {l: ('finger' if h else 'body') for l, h in zip(s['latent_labels'], on_hand)}
+        mm['marker_type_mask'] = {'body': ~on_hand, 'finger': on_hand}
+        mm['m2b_distance'] = {'body': 0.0095, 'finger': 0.0095}
     model_fname = os.path.join(outdir, 'model.pkl')
     pk = {k: v for k, v in dd.items() if not k.startswith('_') and k != 'model_type'}
     pk['J_regressor'] = sp.csc_matrix(dd['J_regressor'])

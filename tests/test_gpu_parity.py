@@ -489,7 +489,7 @@ def test_host_level_chunks_carry_the_free_shape_block(gpu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['smplh_body', 'smpl_body'])
+@pytest.mark.parametrize('name', ['smplh_body', 'smpl_body', 'smplh_fingers'])
 def test_chain_matches_the_executed_reference_stageii(gpu_lib, name, tmp_path):
     """The kernel against tests/golden/ref_stageii.npz: the trajectory the REFERENCE's own mosh_stageii (chmosh.py:458-741,
     executed by tests/golden/make_ref_stageii_golden.py under a lazy chumpy stand-in) produced on the same seeded files --
@@ -498,11 +498,13 @@ def test_chain_matches_the_executed_reference_stageii(gpu_lib, name, tmp_path):
     from tests.test_ref_golden import _stageii_ref_case, _check_against_reference_run
     c = _stageii_ref_case(name, tmp_path)
     ref = c['ref']
-    dev = device_case(c)
+    dev = device_case(c, optimize_fingers=c['fingers'])
     out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
                                 [dict(attach=dev['attach'], obs=c['obs'], vis=c['vis'], first=True)])[0]
     solved = np.where(out['status'] == 0)[0]
     errs = dict(data=out['errs'][solved, 0], poseB=out['errs'][solved, 1], velo=out['errs'][solved[2:], 2])
+    if c['fingers']:
+        errs['poseH'] = out['errs'][solved, 3]
     _check_against_reference_run(name, ref, out['fullpose'][solved], out['trans'][solved], errs, solved, c['vis'],
                                  c['s']['latent_labels'])
     calls = ref[f'{name}_minimize_calls']

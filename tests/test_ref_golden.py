@@ -251,7 +251,7 @@ def test_marker_layout_creation_matches_reference_functions(case, tmp_path):
 
 
 # ---- the Stage-II schedule itself: the reference's mosh_stageii EXECUTED (tests/golden/make_ref_stageii_golden.py) ------------
-STAGEII_REF_CASES = {'smplh_body': 'smplh', 'smpl_body': 'smpl'}
+STAGEII_REF_CASES = {'smplh_body': 'smplh', 'smpl_body': 'smpl', 'smplh_fingers': 'smplh'}
 
 
 def _stageii_ref_case(name, tmp_path):
@@ -263,7 +263,8 @@ def _stageii_ref_case(name, tmp_path):
     F, M, seed, V = [int(v) for v in ref[f'{name}_args'][:4]]
     empty = tuple(int(v) for v in ref[f'{name}_args'][4:])
     mt = STAGEII_REF_CASES[name]
-    c = stageii_case(mt, F, M, seed, V, str(tmp_path), empty_frames=empty)
+    fingers = bool(ref[f'{name}_fingers'])
+    c = stageii_case(mt, F, M, seed, V, str(tmp_path), empty_frames=empty, finger_markers=fingers)
     s = c['s']
     dd = s['model']
     bd, hd, hm, comps = pose_layout(s)
@@ -276,7 +277,8 @@ def _stageii_ref_case(name, tmp_path):
     prior = so.prepare_gmm_prior(s['gmm'], 63 if mt in ('smplh', 'smplx') else 69)
     obs = np.nan_to_num(s['markers'])
     vis = ~np.isnan(s['markers']).any(-1)
-    return dict(ref=ref, s=s, m=m, model=model, closest=closest, coef=coef, prior=prior, obs=obs, vis=vis, model_type=mt, F=F)
+    return dict(ref=ref, s=s, m=m, model=model, closest=closest, coef=coef, prior=prior, obs=obs, vis=vis, model_type=mt, F=F,
+                fingers=fingers)
 
 
 def _check_against_reference_run(name, ref, fullpose, trans, errs, frame_ids, vis, labels):
@@ -288,7 +290,10 @@ def _check_against_reference_run(name, ref, fullpose, trans, errs, frame_ids, vi
     assert list(ref[f'{name}_labels_obs']) == ['|'.join(l for l, v in zip(labels, vis[t]) if v) for t in frame_ids]
     assert np.abs(fullpose - ref[f'{name}_fullpose']).max() < 1e-6        # (measured: 5e-9 rad / 2e-12 m for the oracle)
     assert np.abs(trans - ref[f'{name}_trans']).max() < 1e-8
-    assert list(ref[f'{name}_err_keys']) == ['data', 'poseB', 'velo']
+    fingers = 'poseH' in errs
+    assert list(ref[f'{name}_err_keys']) == (['data', 'poseB', 'poseH', 'velo'] if fingers else ['data', 'poseB', 'velo'])
+    if fingers:
+        np.testing.assert_allclose(errs['poseH'], ref[f'{name}_err_poseH'], rtol=1e-5)
     # the velocity term exists from the THIRD solved frame on: pose_prev is refreshed (chmosh.py:656-657) only after the frame's
     # objective was built (:624-626), so the second solved frame still sees pose_prev = None -- two entries fewer (:707-710)
     assert len(ref[f'{name}_err_velo']) == len(fullpose) - 2
@@ -303,7 +308,8 @@ def test_stageii_schedule_matches_reference_function(name, tmp_path):
     """oracle.stageii_chain against the trajectory the reference's own mosh_stageii produced on the same files."""
     c = _stageii_ref_case(name, tmp_path)
     ref = c['ref']
-    out = so.stageii_chain(c['m'], c['prior'], c['closest'], c['coef'], c['obs'], c['vis'], c['model_type'])
+    out = so.stageii_chain(c['m'], c['prior'], c['closest'], c['coef'], c['obs'], c['vis'], c['model_type'],
+                           optimize_fingers=c['fingers'])
     _check_against_reference_run(name, ref, out['fullpose'], out['trans'], out['errs'], out['frame_ids'], c['vis'], c['s']['latent_labels'])
     # the simulated markers of the first solved frame, and the keys of the result dict the drop-in returns
     assert np.abs(out['markers_sim'][0] - ref[f'{name}_markers_sim0']).max() < 1e-6
@@ -313,8 +319,9 @@ def test_stageii_schedule_matches_reference_function(name, tmp_path):
     # 3 first-frame rounds + Step 1 + Step 2 per solved frame (chmosh.py:637-705)
     calls = ref[f'{name}_minimize_calls']
     assert len(calls) == 3 + 2 * len(out['fullpose'])
-    n1 = 3 + len(so.pose_id_sets(c['model_type'], c['m']['NP'])[3])
-    assert set(int(v) for v in calls[:, 0]) == {n1}                              # free variables of every solve (body-only: step 1 == step 2)
+    ids = so.pose_id_sets(c['model_type'], c['m']['NP'], optimize_fingers=c['fingers'])
+    n1, n2 = 3 + len(ids[3]), 3 + len(ids[4])
+    assert [int(v) for v in calls[:, 0]] == [n1] * 4 + [n2] + [n1, n2] * (len(out['fullpose']) - 1)   # free variables of every solve
     # dogleg iterations per solved frame: the reference-built problem and the oracle's take the same number of steps
     per_frame = [int(calls[:5, 2].sum())] + [int(calls[5 + 2 * i:7 + 2 * i, 2].sum()) for i in range(len(out['fullpose']) - 1)]
     assert per_frame == [int(v) for v in out['iters']]
