@@ -3,26 +3,36 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full Stage-II pass over one synthetic sequence of BASELINE config[1] (4000-frame SMPL-H, 53 body
-markers, fixed betas) with observations and outputs resident in HBM: `moshii_sequence_solve` cuts the sequence into
-one chunk per CU, solves the chunks concurrently (each starts --chunk-warmup frames early), verifies every hand-off
-against its predecessor's end state on the device and re-solves the chunks that miss --verify-tol exactly -- all of
-that is inside the timed region.  `--mode sequential` times the reference's literal frame order instead (one chain =
-one workgroup).  With N > 1 (torch.distributed.run, one rank per GPU) every rank solves its own sequence of the same
-shape -- the path has no data-path collective -- and the job-level frames/s is reported ("scaling": "weak").
+A "step" = one full Stage-II pass over one synthetic sequence of BASELINE config[1] (4000-frame SMPL-H, 53 body markers,
+fixed betas) with observations and outputs resident in HBM: `moshii_sequence_solve` cuts the sequence into one chunk per CU,
+solves the chunks concurrently (each starts --chunk-warmup frames early), verifies every hand-off against its predecessor's
+end state on the device and re-solves the chunks that miss --verify-tol exactly -- all of that is inside the timed region.
+How long the repairs take depends on the motion, so the timed steps CYCLE through --seeds (six seeded sequences of the same
+shape; step k solves sequence k mod 6) and `value` is the MEDIAN over the seeds of frames / mean step time of that seed
+(`seeds` holds every seed's rate, min and max beside it; `aggregate_frames_per_s` is all timed frames / all timed seconds).
+`--mode sequential` times the reference's literal frame order instead (one chain = one workgroup).
+
+N > 1 (torch.distributed.run, one rank per GPU): every rank runs the same steps on its own copies -- the path has no
+data-path collective -- and the job-level frames/s is reported: "scaling": "weak" (replicas).  The partition north_star
+asks for is measured beside it at every N, on FIXED jobs (object `strong`): 32 sequences dealt to the ranks by
+parallel.partition_units (BASELINE config 3's shape; N = 1 is the `many_sequences` figure), and one 50 000-frame sequence cut
+into frame ranges with verified hand-offs (parallel.solve_sequence_sharded; config 5's shape).  `--scaling strong` makes the
+32-sequence job the headline (`value`, `scaling: "strong"`).
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline           dominant kernel k_chain_solve against the f64 vector peak (it is latency/ALU-bound, not HBM-bound)
   roofline_lbs       the full-mesh LBS export kernel against the HBM peak
-  cpu_baseline       the NumPy oracle ("port") on a bounded sample, host cores of this box
+  cpu_baseline       the NumPy oracle ("port") on bounded samples, host cores of this box: one core in its lean mode (`value`),
+                     one core doing the reference's own amount of work per iteration (`reference_cost`: full-mesh forward + dense
+                     3V x 3K Jacobian, smpl_fast_derivatives.py:250-256), and one sequence per core on `all_cores`
   parity             GPU result of the timed mode vs the oracle's sequential chain on that sample
-  sequential_chain   the literal frame order on the GPU (one workgroup) and the timed mode's deviation from it over
-                     ALL frames
-  many_sequences     32 copies of the sequence in one call: the dominant kernel with every CU busy
-  other_seeds        the same workload generated from two other seeds (the repair pattern depends on the motion)
-  stagei             Stage-I on 12 frames / 53 markers / 10 betas: GPU seconds (default dense solver and the opt-in
-                     arrow-structured one), iterations, and the NumPy oracle's seconds + differences on the same problem
-All extra legs except roofline / roofline_lbs run at N = 1 only.
+  sequential_chain   the literal frame order on the GPU (one workgroup) and the timed mode's deviation from it over ALL frames
+  incl_host_staging  the same solve through host buffers (observations in, results out over PCIe)
+  many_sequences     32 sequences in one call: the dominant kernel with every CU busy
+  strong             the fixed jobs above, at this N
+  stagei             Stage-I on 12 frames / 53 markers / 10 betas: GPU seconds (dense and arrow-structured solver), iterations, and
+                     the NumPy oracle's seconds + differences on the same problem
+The reference / CPU / Stage-I legs run at N = 1 only.
 """
 from __future__ import annotations
 
@@ -51,26 +61,67 @@ def solver_flops(K, Nv, n1, n2, NP, npose, nobs_mean, iters, fevals):
     return float(fevals) * fwd + float(iters) * per_iter
 
 
+def _cpu_chain_worker(a):
+    """One oracle chain on `frames` frames of the seeded workload (a process of the all-cores CPU leg)."""
+    seed, frames, markers = a
+    sys.path.insert(0, ROOT)
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(limits=1)
+    except Exception:
+        pass
+    from moshpp_amd import workload
+    from oracle import stageii_oracle as so
+    job = workload.make_job('smplh', n_frames=frames, n_markers=markers, seed=seed)
+    m, pr, closest, coef = oracle_setup(job)
+    t0 = time.perf_counter()
+    ref = so.stageii_chain(m, pr, closest, coef, job['obs'], job['vis'], 'smplh')
+    return len(ref['frame_ids']), time.perf_counter() - t0
+
+
+def oracle_setup(job):
+    from oracle import stageii_oracle as so
+    sm = job['sm']
+    m = so.prepare_model(dict(v_template=sm.v_template, shapedirs=sm.shapedirs, posedirs=sm.posedirs, weights=sm.weights,
+                              J_regressor=sm.J_regressor, parents=sm.parents, body_dof=sm.body_dof, hand_dof=sm.hand_dof,
+                              hands_mean=sm.hands_mean, selected_components=sm.selected_components), job['betas'])
+    pr = so.prepare_gmm_prior(job['seq']['gmm'], 63)
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
+    closest, coef = so.transformed_coeffs(can, job['markers_latent'])
+    return m, pr, closest, coef
+
+
+def strong_job_shares(n_sequences, frames, world):
+    """The fixed many-sequence job: which sequences (indices into the seed cycle) each rank solves (LPT by frame count)."""
+    from moshpp_amd.parallel import partition_units
+    return partition_units([float(frames)] * n_sequences, world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--frames', type=int, default=4000)
     ap.add_argument('--markers', type=int, default=53)
     ap.add_argument('--mode', choices=('chunked', 'sequential'), default='chunked')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: every rank its own copies of the workload (replicas); strong: the fixed 32-sequence job is the headline')
+    ap.add_argument('--seeds', default='1000,123,71,5,2024,7', help='the timed steps cycle through sequences generated from these seeds')
     ap.add_argument('--chunks', type=int, default=0, help='chunks per sequence (0 = one per CU)')
     ap.add_argument('--chunk-warmup', type=int, default=32)
     # hand-off tolerance: 1e-9 rad / m yields the same stitched result as 1e-11 (max deviation from the sequential chain 1.4e-9
     # rad on all 4000 frames, re-measured below every run) with fewer repairs of warm-ups that were converged to 1e-10
     ap.add_argument('--verify-tol', type=float, default=1e-9)
-    ap.add_argument('--cpu-sample', type=int, default=400, help='frames of the workload timed on the CPU oracle')
+    ap.add_argument('--cpu-sample', type=int, default=240, help='frames of the workload timed on the CPU oracle (one core, lean mode)')
+    ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the all-cores CPU leg (0 = min(host cores, 32))')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-stagei', action='store_true', help='skip the Stage-I leg')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
-    ap.add_argument('--spread-seeds', default='5,71', help='extra leg: the same workload generated from these seeds ("" to skip)')
+    ap.add_argument('--no-strong', action='store_true', help='skip the fixed-job (strong scaling) legs')
+    ap.add_argument('--strong-sequences', type=int, default=32)
+    ap.add_argument('--long-frames', type=int, default=50000)
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
-    ap.add_argument('--many', type=int, default=32, help='extra leg: this many copies of the sequence in one call (0: skip)')
     args = ap.parse_args()
 
     import torch
@@ -90,80 +141,207 @@ def main():
     from moshpp_amd import capi, workload
     lib = capi.load()
     capi.check(lib.moshii_set_device(local_rank))
+    dev = torch.device('cuda', local_rank)
+    seeds = [int(x) for x in args.seeds.split(',') if x.strip()]
 
-    # ---- workload: BASELINE config[1]; every rank solves its own copy of the same seeded sequence (identical work per
-    # GPU: the chunk-repair pattern depends on the motion, so different seeds would blur the weak-scaling figure)
-    job = workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=1000)
-    solver = workload.make_solver(job)
+    # ---- workload: BASELINE config[1], one resident sequence per seed (same model / betas layout, different motion)
+    jobs = {sd: workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=sd) for sd in seeds}
+    solvers = {sd: workload.make_solver(jobs[sd]) for sd in seeds}
+    seqs = {sd: workload.DeviceSequence(jobs[sd], solvers[sd], dev) for sd in seeds}
+    job, solver, ds = jobs[seeds[0]], solvers[seeds[0]], seqs[seeds[0]]
     sm = job['sm']
     F, M = job['vis'].shape
-    dev = torch.device('cuda', local_rank)
-    ds = workload.DeviceSequence(job, solver, dev)
-    reports = []
-
-    def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        if args.mode == 'chunked':
-            reports.append(ds.solve_chunked(stream, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol))
-        else:
-            ds.solve_sequential(stream)
+    reports = {sd: [] for sd in seeds}
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    reports.clear()
+    def allmax(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allsum(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    # ---- the fixed many-sequence job (strong scaling; also the headline with --scaling strong)
+    def strong_many():
+        """32 sequences dealt to the ranks; a rank solves its share in ONE moshii_sequence_solve call (copies of the seed-1000
+        sequence: sequences of one subject share the model / prior handles of a call).  Returns (frames solved here, seconds
+        here, sequences here)."""
+        share = strong_job_shares(args.strong_sequences, F, world)[rank]
+        copies = [workload.DeviceSequence(job, solver, dev) for _ in share]
+        stream = torch.cuda.current_stream().cuda_stream
+        n_local = len(copies)
+        per_seq_chunks = max(8, 256 // max(n_local, 1))      # keep every CU carrying a chain when a rank has few sequences
+        t_here, n_here = 0.0, 0
+        if n_local:
+            workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)   # untimed first pass (allocations inside the library)
+        barrier()
+        if n_local:
+            t0 = time.perf_counter()
+            workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)
+            torch.cuda.synchronize()
+            t_here = time.perf_counter() - t0
+            n_here = sum(int((c.results()['status'] != 1).sum()) for c in copies)
+        barrier()
+        return n_here, t_here, n_local
+
+    def strong_long():
+        """One long sequence over the ranks by frame ranges (host buffers: the boundary rows travel through the process group)."""
+        from moshpp_amd.parallel import solve_sequence_sharded
+        jl = workload.make_job('smplh', n_frames=args.long_frames, n_markers=args.markers, seed=seeds[0])
+        sl = workload.make_solver(jl)
+        calls = []
+
+        def solve_range(a, b, init):
+            calls.append((a, b))
+            return sl.solve(jl['obs'][a:b], jl['vis'][a:b], chain_mode='chunked', verify_tol=args.verify_tol, init=init)
+
+        gl = None
+        if dist is not None:
+            gl = dist.new_group(backend='gloo')   # object collectives of the hand-off check: host side
+        solve_range(0, min(600, args.long_frames), None); calls.clear()      # untimed first call
+        barrier()
+        t0 = time.perf_counter()
+        out, info = solve_sequence_sharded(solve_range, args.long_frames, dist=_GroupView(dist, gl) if dist is not None else None,
+                                           warmup=args.chunk_warmup, verify_tol=args.verify_tol)
+        torch.cuda.synchronize()
+        t_here = time.perf_counter() - t0
+        n_here = int((np.asarray(out['status']) != 1).sum())
+        barrier()
+        return n_here, t_here, info, len(calls)
+
+    class _GroupView:
+        """torch.distributed with the object collectives routed to a gloo group (parallel.solve_sequence_sharded's interface)."""
+        def __init__(self, d, g): self.d, self.g = d, g
+        def is_initialized(self): return True
+        def get_world_size(self): return self.d.get_world_size()
+        def get_rank(self): return self.d.get_rank()
+        def all_gather_object(self, out, obj): return self.d.all_gather_object(out, obj, group=self.g)
+        def gather_object(self, obj, out, dst=0): return self.d.gather_object(obj, out, dst=dst, group=self.g)
+
+    def step(k):
+        sd = seeds[k % len(seeds)]
+        stream = torch.cuda.current_stream().cuda_stream
+        if args.mode == 'chunked':
+            reports[sd].append(seqs[sd].solve_chunked(stream, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol))
+        else:
+            seqs[sd].solve_sequential(stream)
+
+    for k in range(max(args.warmup, 0)):
+        step(k)
+    for sd in seeds:
+        reports[sd].clear()
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        step()
+        step(k)
         ev[k][1].record()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     barrier()
-    step_ms = [a.elapsed_time(b) for a, b in ev]
-    t_max = t_local
-    if dist is not None:
-        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-    out = ds.results()
+    step_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    t_max = allmax(t_local)
+    used = [sd for i, sd in enumerate(seeds) if i < args.steps]
+    res = {sd: seqs[sd].results() for sd in used}
+    solved_of = {sd: int((res[sd]['status'] != 1).sum()) for sd in used}
+    frames_timed = sum(solved_of[seeds[k % len(seeds)]] for k in range(args.steps))
+    total_frames = allsum(frames_timed)
+    aggregate = total_frames / t_max
+    ms_per_step = 1e3 * t_max / args.steps
+    per_seed = {}
+    for i, sd in enumerate(used):
+        ms = step_ms[i::len(seeds)]
+        rp = reports[sd][-1] if reports[sd] else None
+        per_seed[str(sd)] = {'frames_per_s': round(world * solved_of[sd] / (float(ms.mean()) * 1e-3), 1), 'ms_per_step': round(float(ms.mean()), 3),
+                             'steps': int(len(ms)), **({'n_repaired': rp['n_repaired'], 'repair_rounds': rp['repair_rounds']} if rp else {})}
+    rates = np.array([v['frames_per_s'] for v in per_seed.values()])
+    value = float(np.median(rates))
+
+    out = res[seeds[0]]
     status, iters = out['status'], out['iters']
     solved_mask = status != 1
     solved = int(solved_mask.sum())
-    total_solved = solved
-    if dist is not None:
-        ts = torch.tensor([solved], dtype=torch.float64, device=dev)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        total_solved = int(ts.item())
-    value = total_solved * args.steps / t_max
-    ms_per_step = 1e3 * t_max / args.steps
-
     name, lds, thr = capi.last_launch_info()
-    rep = reports[-1] if reports else None
+    rep = reports[seeds[0]][-1] if reports[seeds[0]] else None
     how = (f'chunked: {rep["n_chunks"]} concurrent chunks (1 workgroup each), {rep["warmup"]}-frame warm-up overlap, hand-offs '
            f'verified to {rep["verify_tol"]:g} and repaired exactly' if rep else 'exact sequential chain (1 chain = 1 workgroup)')
     result = {
         'metric': 'solved mocap frames/sec (Stage-II)', 'value': round(value, 2), 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'BASELINE config[1]: {F}-frame SMPL-H sequence, {M} body markers, fixed betas; {how}',
+        'config': {'workload': f'BASELINE config[1]: {F}-frame SMPL-H sequence, {M} body markers, fixed betas; {how}; the steps cycle '
+                               f'through {len(used)} seeded sequences, value = median over the seeds'
+                               + ('' if world == 1 else f'; {world} replicas (every rank its own copies: no data-path collective)'),
                    'mode': args.mode, 'frames_per_gpu': F, 'markers': M, 'free_vars_step1': 3 + len(solver.ids['step1']),
                    'free_vars_step2': 3 + len(solver.ids['step2']), 'sequences_per_gpu': 1},
+        'value_is': 'median over seeds of (frames / mean step time of the seed)',
+        'seeds': per_seed, 'seed_min': round(float(rates.min()), 1), 'seed_max': round(float(rates.max()), 1),
+        'aggregate_frames_per_s': round(aggregate, 1),
     }
     if rep:
-        result['chunking'] = dict(rep, repaired_per_step=float(np.mean([r['n_repaired'] for r in reports])))
+        result['chunking'] = dict(rep, repaired_per_step=float(np.mean([r['n_repaired'] for sd in used for r in reports[sd]])))
+
+    # ---- fixed jobs at this N (all ranks take part)
+    strong = None
+    if not args.no_strong and args.mode == 'chunked':
+        strong = {}
+        try:
+            n_here, t_here, n_local = strong_many()
+            t_job = allmax(t_here)
+            n_job = allsum(n_here)
+            strong['many_sequences'] = {
+                'workload': f'{args.strong_sequences} x {F}-frame SMPL-H sequences (BASELINE config 3 shape with body markers; copies of the seed-{seeds[0]} capture), dealt to the ranks by '
+                            'longest-processing-time (parallel.partition_units); no collective on the data path',
+                'frames': int(n_job), 'frames_per_s': round(n_job / t_job, 1), 'ms': round(t_job * 1e3, 2),
+                'sequences_on_rank0': n_local, 'rank0_idle_ms': round((t_job - t_here) * 1e3, 2)}
+        except Exception as e:
+            strong['many_sequences'] = {'error': repr(e)}
+        try:
+            n_here, t_here, info, ncalls = strong_long()
+            t_job = allmax(t_here)
+            n_job = allsum(n_here)
+            strong['long_sequence'] = {
+                'workload': f'one {args.long_frames}-frame SMPL-H sequence (BASELINE config 5 shape) cut into {world} frame range(s), '
+                            f'{args.chunk_warmup}-frame warm-up overlap, hand-offs verified to {args.verify_tol:g} and repaired '
+                            '(parallel.solve_sequence_sharded); host buffers (PCIe staging inside the time)',
+                'frames': int(n_job), 'frames_per_s': round(n_job / t_job, 1), 'ms': round(t_job * 1e3, 2),
+                'handoff_repair_rounds': int(info['rounds']), 'ranks_repaired': info['repaired'],
+                'max_handoff_dev': float(info['max_handoff_dev']), 'rank0_idle_ms': round((t_job - t_here) * 1e3, 2),
+                'solves_on_rank0': ncalls}
+        except Exception as e:
+            strong['long_sequence'] = {'error': repr(e)}
+        result['strong'] = strong
+        if args.scaling == 'strong' and 'frames_per_s' in strong.get('many_sequences', {}):
+            sj = strong['many_sequences']
+            result.update(value=sj['frames_per_s'], scaling='strong', ms_per_step=sj['ms'], steps=1, warmup=1,
+                          value_is='job frames / max-over-ranks seconds of the fixed many-sequence job')
+            result['config'] = {'workload': sj['workload'], 'mode': args.mode, 'markers': M, 'parallelism': f'{world} rank(s), sequences sharded'}
+            result['replicas'] = {'value': round(value, 2), 'scaling': 'weak', 'seeds': per_seed}
+
     if rank == 0:
         nobs_mean = float(job['vis'].sum(1).mean())
-        fl = solver_flops(sm.K, 3 * M, len(solver.ids['step1']), len(solver.ids['step2']), sm.NP,
-                          len(solver.ids['body']), nobs_mean, iters[solved_mask, 0].sum(), iters[solved_mask, 1].sum())
-        kt = float(np.mean(step_ms)) * 1e-3
-        ach = fl / kt / 1e12
+        fl_seed = {}
+        for sd in used:
+            st = res[sd]['status'] != 1
+            it = res[sd]['iters']
+            fl_seed[sd] = solver_flops(sm.K, 3 * M, len(solver.ids['step1']), len(solver.ids['step2']), sm.NP, len(solver.ids['body']),
+                                       float(jobs[sd]['vis'].sum(1).mean()), it[st, 0].sum(), it[st, 1].sum())
+        fl = fl_seed[seeds[0]]
+        fl_timed = sum(fl_seed[seeds[k % len(seeds)]] for k in range(args.steps))
+        kt = float(step_ms.sum()) * 1e-3
+        ach = fl_timed / kt / 1e12
         result['roofline'] = {
             'kernel': name, 'bound': 'valu_f64',
             'bound_note': 'neither hbm nor mfma: float64 vector pipe, dependency/latency-bound small dense solves; HBM traffic ~44 KB/frame (PMC)',
@@ -172,15 +350,15 @@ def main():
             # (x2 wide-load correction of the guide -> 26.5 KB) + 17.7 KB written per solved frame, incl. the one-time read of
             # the 1.76 MB attachment slice and the kernel's scratch write-backs; scaled to the frames the timed mode solves
             'traffic': int(44.2e3 * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0))),
-            'traffic_source': 'rocprofv3 PMC per solved frame (profiles/r01_chain_pmc.txt) x frames solved in pass 1; not collected live',
-            'step_ms_hip_events': round(kt * 1e3, 3),
-            'algorithmic_gflop_per_step': round(fl / 1e9, 3),
-            'note': 'algorithmic = the sequential chain\'s work on the recorded frames; warm-up and repair work is overhead',
+            'traffic_source': 'rocprofv3 PMC per solved frame (profiles/r01_chain_pmc.txt) x frames solved in pass 1 of one step; not collected live',
+            'step_ms_hip_events': round(float(step_ms.mean()), 3), 'step_ms_hip_events_all': [round(float(x), 3) for x in step_ms],
+            'algorithmic_gflop_per_step': round(fl_timed / args.steps / 1e9, 3),
+            'note': 'algorithmic = the sequential chain\'s work on the recorded frames of the timed steps / their HIP-event time; warm-up and repair work is overhead',
             'dogleg_iters_per_frame': round(float(iters[solved_mask, 0].sum()) / max(solved, 1), 3),
             'residual_evals_per_frame': round(float(iters[solved_mask, 1].sum()) / max(solved, 1), 3), 'lds_bytes': lds,
         }
+        extras = world == 1     # the reference / CPU / Stage-I legs run at N = 1 only: at N > 1 the other ranks would idle at the barrier
         # ---- the literal frame order on one workgroup, and the timed mode's deviation from it over all frames
-        extras = world == 1     # the reference / spread / CPU / Stage-I legs run at N = 1 only: at N > 1 the other ranks would idle at the barrier
         if extras and args.mode == 'chunked' and not args.no_sequential:
             dsq = workload.DeviceSequence(job, solver, dev)
             stream = torch.cuda.current_stream().cuda_stream
@@ -193,61 +371,33 @@ def main():
             dp = np.abs(out['fullpose'] - sq['fullpose'])[solved_mask].max(1)
             dm = out['markers_sim'][solved_mask] - sq['markers_sim'][solved_mask]
             result['sequential_chain'] = {
-                'frames_per_s': round(solved / tsq, 1), 'ms': round(tsq * 1e3, 1), 'kernel': capi.last_launch_info()[0],
+                'frames_per_s': round(solved / tsq, 1), 'ms': round(tsq * 1e3, 1), 'us_per_frame': round(tsq * 1e6 / max(solved, 1), 1),
+                'kernel': capi.last_launch_info()[0], 'seed': seeds[0],
                 'timed_mode_vs_sequential': {'max_abs_pose_diff_rad': float(dp.max()), 'frames_over_1e-4_rad': int((dp > 1e-4).sum()),
                                              'frames_over_1e-6_rad': int((dp > 1e-6).sum()),
                                              'marker_rmse_m': float(np.sqrt((dm ** 2).sum(-1).mean())),
                                              'status_identical': bool((status == sq['status']).all())}}
-            result['speedup_vs_sequential_chain'] = round(value / max(solved / tsq, 1e-9) / world, 2)
+            result['speedup_vs_sequential_chain'] = round(value / max(solved / tsq, 1e-9), 2)
             del dsq
-        # ---- the same kernel with the chip full: 32 copies of the sequence in one call (BASELINE config[2] shape: many
-        # sequences per GPU).  8 chunks per sequence, so warm-up is 7 % of the work and every CU carries a chain.
-        if extras and args.many > 0:
+        # ---- the same solve through host buffers (PCIe staging of observations and results inside the time)
+        if extras and args.mode == 'chunked':
             try:
-                copies = [workload.DeviceSequence(job, solver, dev) for _ in range(args.many)]
-                stream = torch.cuda.current_stream().cuda_stream
-                workload.solve_many_chunked(copies, stream)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                mrep = workload.solve_many_chunked(copies, stream)
-                e1.record()
-                torch.cuda.synchronize()
-                mt = e0.elapsed_time(e1) * 1e-3
-                mout = copies[-1].results()
-                dpm = np.abs(mout['fullpose'] - out['fullpose'])[solved_mask].max()
-                mach = fl * args.many / mt / 1e12
-                result['many_sequences'] = {
-                    'sequences': args.many, 'frames': args.many * F, 'frames_per_s': round(args.many * solved / mt, 1), 'ms': round(mt * 1e3, 2),
-                    'chunking': mrep, 'max_abs_pose_diff_vs_single_run_rad': float(dpm),
-                    'roofline': {'kernel': name, 'bound': 'valu_f64', 'achieved': round(mach, 4), 'peak': F64_VALU_PEAK_TFLOPS,
-                                 'unit': 'TFLOP/s', 'frac': round(mach / F64_VALU_PEAK_TFLOPS, 5)}}
-                del copies
+                solver.solve(job['obs'][:64], job['vis'][:64], chain_mode='chunked', verify_tol=args.verify_tol)
+                th0 = time.perf_counter()
+                oh = solver.solve(job['obs'], job['vis'], chain_mode='chunked', verify_tol=args.verify_tol)
+                th = time.perf_counter() - th0
+                result['incl_host_staging'] = {'frames_per_s': round(int((oh['status'] != 1).sum()) / th, 1), 'ms': round(th * 1e3, 2), 'seed': seeds[0],
+                                               'note': 'moshii_sequence_solve with MOSHII_BUFFERS_HOST: pageable host arrays in and out'}
             except Exception as e:
-                result['many_sequences'] = {'error': repr(e)}
-        # ---- the same workload from other seeds: the chunk-repair pattern depends on the motion (how long the regions are in
-        # which a fresh start sits in another basin), so the headline seed is not the whole story
-        if extras and args.mode == 'chunked' and args.spread_seeds:
-            spread = {}
-            try:
-                for sd in [int(x) for x in args.spread_seeds.split(',') if x.strip()]:
-                    job2 = workload.make_job('smplh', n_frames=args.frames, n_markers=args.markers, seed=sd)
-                    solver2 = workload.make_solver(job2)
-                    ds2 = workload.DeviceSequence(job2, solver2, dev)
-                    stream2 = torch.cuda.current_stream().cuda_stream
-                    ds2.solve_chunked(stream2, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol)
-                    torch.cuda.synchronize()
-                    t2 = time.perf_counter()
-                    rep2 = ds2.solve_chunked(stream2, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol)
-                    torch.cuda.synchronize()
-                    dt2 = time.perf_counter() - t2
-                    n2 = int((ds2.results()['status'] != 1).sum())
-                    spread[str(sd)] = {'frames_per_s': round(n2 / dt2, 1), 'ms_per_step': round(dt2 * 1e3, 2),
-                                       'n_repaired': rep2['n_repaired'], 'repair_rounds': rep2['repair_rounds']}
-                    del ds2, solver2, job2
-                result['other_seeds'] = spread
-            except Exception as e:
-                result['other_seeds'] = {'error': repr(e)}
+                result['incl_host_staging'] = {'error': repr(e)}
+        # ---- the same kernel with the chip full = the N = 1 point of strong.many_sequences
+        if extras and strong and 'frames_per_s' in strong.get('many_sequences', {}):
+            sj = strong['many_sequences']
+            fl_many = fl * args.strong_sequences
+            mach = fl_many / (sj['ms'] * 1e-3) / 1e12
+            result['many_sequences'] = {'sequences': args.strong_sequences, 'frames': sj['frames'], 'frames_per_s': sj['frames_per_s'], 'ms': sj['ms'],
+                                        'roofline': {'kernel': name, 'bound': 'valu_f64', 'achieved': round(mach, 4), 'peak': F64_VALU_PEAK_TFLOPS,
+                                                     'unit': 'TFLOP/s', 'frac': round(mach / F64_VALU_PEAK_TFLOPS, 5)}}
         # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names)
         try:
             import ctypes as C
@@ -282,18 +432,11 @@ def main():
                                       'frames_per_s': round(Fl / lt, 1)}
         except Exception as e:   # the LBS leg must never take the headline number down
             result['roofline_lbs'] = {'error': repr(e)}
-        # ---- CPU baseline: the NumPy oracle ("port") on a bounded sample of the same workload; parity on that sample
+        # ---- CPU baseline: the NumPy oracle ("port") on bounded samples of the same workload; parity on the first sample
         if extras and not args.no_cpu:
             from oracle import stageii_oracle as so
             S = min(args.cpu_sample, F)
-            seq = job['seq']
-            m = so.prepare_model(dict(v_template=sm.v_template, shapedirs=sm.shapedirs, posedirs=sm.posedirs,
-                                      weights=sm.weights, J_regressor=sm.J_regressor, parents=sm.parents,
-                                      body_dof=sm.body_dof, hand_dof=sm.hand_dof, hands_mean=sm.hands_mean,
-                                      selected_components=sm.selected_components), job['betas'])
-            pr = so.prepare_gmm_prior(seq['gmm'], 63)
-            can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
-            closest, coef = so.transformed_coeffs(can, job['markers_latent'])
+            m, pr, closest, coef = oracle_setup(job)
             # one core: the chain is sequential and its matrices are small (<= 385 x 111) -- BLAS threading buys nothing
             # (measured: 23.8 vs 23.5 frames/s with 8 vs 1 threads), so the library is pinned to one thread and says so
             import contextlib
@@ -306,28 +449,52 @@ def main():
                 tc0 = time.perf_counter()
                 ref = so.stageii_chain(m, pr, closest, coef, job['obs'][:S], job['vis'][:S], 'smplh')
                 tc = time.perf_counter() - tc0
+                # the reference's own cost per iteration: full-mesh forward and the dense 3V x 3K vertex Jacobian, marker rows taken
+                # from it (smpl_fast_derivatives.py:250-256) -- same trajectory, a bounded number of frames
+                Sr = min(6, S)
+                tr0 = time.perf_counter()
+                refc = so.stageii_chain(m, pr, closest, coef, job['obs'][:Sr], job['vis'][:Sr], 'smplh', reference_cost=True)
+                trc = time.perf_counter() - tr0
             n_ref = len(ref['frame_ids'])
-            result['cpu_baseline'] = {'value': round(n_ref / tc, 2), 'unit': 'frames/s', 'cores': int(blas_threads),
-                                      'kind': 'port', 'host_cores_visible': os.cpu_count(),
-                                      'sample': f'first {S} frames of the same sequence, NumPy float64 oracle '
-                                                f'(lean marker-subset mode), single process, BLAS pinned to '
-                                                f'{blas_threads} thread(s), {tc:.1f} s'}
+            cb = {'value': round(n_ref / tc, 2), 'unit': 'frames/s', 'cores': int(blas_threads), 'kind': 'port',
+                  'host_cores_visible': os.cpu_count(),
+                  'sample': f'first {S} frames of the seed-{seeds[0]} sequence, NumPy float64 oracle (lean marker-subset mode), single '
+                            f'process, BLAS pinned to {blas_threads} thread(s), {tc:.1f} s',
+                  'reference_cost': {'value': round(len(refc['frame_ids']) / trc, 3), 'unit': 'frames/s', 'cores': int(blas_threads),
+                                     'sample': f'first {Sr} frames, full-mesh forward + dense 3V x 3K Jacobian per iteration as the '
+                                               f'reference computes them (smpl_fast_derivatives.py:250-256), {trc:.1f} s',
+                                     'max_abs_pose_diff_vs_lean_rad': float(np.abs(refc['fullpose'] - ref['fullpose'][:len(refc['fullpose'])]).max())}}
+            try:    # how the reference is deployed: one capture per OS process (mosh_head.py:584-589) -- one sequence per core
+                import multiprocessing as mp
+                P = args.cpu_procs or min(os.cpu_count() or 1, 32)
+                fr = 60
+                ctx = mp.get_context('spawn')
+                ta0 = time.perf_counter()
+                with ctx.Pool(P) as pool:
+                    rs = pool.map(_cpu_chain_worker, [(seeds[i % len(seeds)], fr, M) for i in range(P)])
+                ta = time.perf_counter() - ta0
+                cb['all_cores'] = {'value': round(sum(n for n, _ in rs) / max(t for _, t in rs), 1), 'unit': 'frames/s', 'cores': P,
+                                   'sample': f'{P} processes x {fr} frames (one sequence per core, lean mode), slowest chain '
+                                             f'{max(t for _, t in rs):.1f} s, {ta:.1f} s incl. process start-up'}
+            except Exception as e:
+                cb['all_cores'] = {'error': repr(e)}
+            result['cpu_baseline'] = cb
             gp = out['fullpose'][:S][status[:S] != 1]
             gm = out['markers_sim'][:S]
             sqd = []
             for i, t in enumerate(ref['frame_ids']):
                 sqd.append(((gm[t][job['vis'][t]] - ref['markers_sim'][i]) ** 2).sum(1))
             dpo = np.abs(gp - ref['fullpose']).max(1)
-            result['parity'] = {'against': 'oracle sequential chain', 'frames': int(n_ref),
+            result['parity'] = {'against': 'oracle sequential chain', 'frames': int(n_ref), 'seed': seeds[0],
                                 'max_abs_pose_diff_rad': float(dpo.max()), 'frames_over_1e-4_rad': int((dpo > 1e-4).sum()),
                                 'marker_rmse_m': float(np.sqrt(np.concatenate(sqd).mean())),
                                 'tolerance': {'pose_rad': 1e-4, 'marker_rmse_m': 1e-3}}
             result['speedup_vs_cpu_port'] = round(value / max(n_ref / tc, 1e-9), 1)
+            result['speedup_vs_cpu_reference_cost'] = round(value / max(len(refc['frame_ids']) / trc, 1e-9), 1)
         # ---- Stage-I leg (BASELINE config 4's calibration part): 12 picked frames, 53 markers, 10 betas on a
         #      triangulated SMPL-H-sized body; the joint solve on the GPU beside the NumPy oracle on the host
         if extras and not args.no_stagei:
             try:
-                from moshpp_amd import capi
                 pb1, dev1, pr1, kw1 = workload.make_stagei_job()
                 capi.stagei_solve_host(dev1, pr1, **kw1)
                 ts = []

@@ -35,7 +35,7 @@ __device__ long long g_prof[64];
 #define PROF_ACC(slot, var) do {} while (0)
 #endif
 
-enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6, S_PRIOR_REF = 7, S_PRIOR_KB0 = 8 };
+enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6, S_PRIOR_REF = 7, S_PRIOR_KB0 = 8, S_BATON = 9, S_ABORT = 10 };
 
 struct Ctx {
     double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
@@ -1883,16 +1883,65 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if (tid == 4) so[2 * NP + 4] = first ? 1.0 : 0.0;
             if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) so[2 * NP + 5 + e] = cx.pose[NP + e];
         }
-        if (bi_next < chp->nb && t == chp->bnd[bi_next]) {   // a chunk boundary inside a run-through repair chain
+        if (bi_next < chp->nb && t == chp->bnd[bi_next] - chp->bnd_off) {   // a chunk boundary inside a run-through repair chain
             const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
-            double* s1 = chp->run_final + (size_t)bi_next * S;
-            double* s2 = chp->run_entry + (size_t)(bi_next + 1) * S;
-            for (int i = tid; i < NP; i += MOSHII_TPB) { s1[i] = cx.pose[i]; s1[NP + i] = cx.pose_prev[i]; s2[i] = cx.pose[i]; s2[NP + i] = cx.pose_prev[i]; }
-            if (tid < 3) { s1[2 * NP + tid] = cx.trans[tid]; s2[2 * NP + tid] = cx.trans[tid]; }
-            if (tid == 3) { s1[2 * NP + 3] = has_prev ? 1.0 : 0.0; s2[2 * NP + 3] = has_prev ? 1.0 : 0.0; }
-            if (tid == 4) { s1[2 * NP + 4] = first ? 1.0 : 0.0; s2[2 * NP + 4] = first ? 1.0 : 0.0; }
-            if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) { s1[2 * NP + 5 + e] = cx.pose[NP + e]; s2[2 * NP + 5 + e] = cx.pose[NP + e]; }
+            double* s1 = chp->run_final + (size_t)bi_next * S;          // end state of the chunk just left ...
+            for (int i = tid; i < NP; i += MOSHII_TPB) { s1[i] = cx.pose[i]; s1[NP + i] = cx.pose_prev[i]; }
+            if (tid < 3) s1[2 * NP + tid] = cx.trans[tid];
+            if (tid == 3) s1[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+            if (tid == 4) s1[2 * NP + 4] = first ? 1.0 : 0.0;
+            if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) s1[2 * NP + 5 + e] = cx.pose[NP + e];
+            if (chp->baton != nullptr) {
+                // Did a chain of this round start at the chunk being entered?  Its start state came from rows this chain has
+                // just replaced, so it is told to stop and this chain goes on in its place once it has (it notices within one
+                // frame).  Should it not stop within the patience below (it is not resident yet: more chains than CUs), this
+                // chain ends here instead and the next round continues it -- what every chain did before there was a baton.
+                if (tid == 0) {
+                    int* st = chp->baton + 2 * (chp->chunk0 + 1 + bi_next);
+                    double go = 1.0;
+                    if (__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+                        __hip_atomic_store(st + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        int spins = 0;
+                        while (__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 2) {
+                            __builtin_amdgcn_s_sleep(64);
+                            if (++spins > 20000) { go = 0.0; break; }   // (~2 us per look: some tens of milliseconds)
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows that chain stored are compared against below
+                    cx.scal[S_BATON] = go;
+                }
+                __syncthreads();
+                if (cx.scal[S_BATON] == 0.0) { if (tid == 0 && chp->frames_done) *chp->frames_done = t; break; }
+            }
+            double* s2 = chp->run_entry + (size_t)(bi_next + 1) * S;    // ... is the state the next chunk is entered with
+            for (int i = tid; i < NP; i += MOSHII_TPB) { s2[i] = cx.pose[i]; s2[NP + i] = cx.pose_prev[i]; }
+            if (tid < 3) s2[2 * NP + tid] = cx.trans[tid];
+            if (tid == 3) s2[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+            if (tid == 4) s2[2 * NP + 4] = first ? 1.0 : 0.0;
+            if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) s2[2 * NP + 5 + e] = cx.pose[NP + e];
             ++bi_next;
+        }
+        if (chp->baton != nullptr && t < F) {
+            // Has an upstream chain of this round asked for this chain's territory (ChainDev::baton)?  Then stop here.  The rows
+            // of the chunk this chain is in now switch from its own to older ones at frame t -- in the middle of a chunk, where
+            // no hand-off check looks -- so the chunk's entry state is spoiled (an impossible flag value): unless the upstream
+            // chain sweeps it (it rewrites the entry state when it gets there), the next verification fails it and it is
+            // re-solved from its predecessor's end state, which this chain has just left behind.
+            // (a slot of its own: S_BATON above is written by thread 0, possibly before the others have read here)
+            if (tid == 0) cx.scal[S_ABORT] = (double)__hip_atomic_load(&chp->baton[2 * chp->chunk0 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (cx.scal[S_ABORT] != 0.0) {
+                if (tid == 0) {
+                    const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
+                    chp->run_entry[(size_t)bi_next * S + 2 * NP + 3] = -1.0;
+                    // ... and whoever re-solves this chunk starts by reproducing THIS chain's rows: it must not take that for
+                    // having re-joined before it is past frame t
+                    int* mark = chp->abort_at + chp->chunk0 + bi_next;
+                    if (*mark < chp->bnd_off + t) *mark = chp->bnd_off + t;
+                    if (chp->frames_done) *chp->frames_done = -t - 1;
+                }
+                break;
+            }
         }
         if (t == F) break;
         const bool record = t >= skip;
@@ -2004,9 +2053,22 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
         }
         __syncthreads();
+        if (rejoin_run > 0 && chp->abort_at != nullptr) {
+            // rows a stopped chain left in this chunk (ChainDev::abort_at) do not count: matching THEM says nothing about the
+            // older rows behind them -- only frames at or past the mark do
+            const int mark = __hip_atomic_load(chp->abort_at + chp->chunk0 + bi_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (chp->bnd_off + t < mark) rejoin_run = 0;
+        }
         if (rejoin_run >= 2 && t + 1 < F) { if (tid == 0 && chp->frames_done) *chp->frames_done = t + 1; break; }   // pose and pose_prev both match: the stored rows (and final state) stand
         if (t + 1 == F && tid == 0 && chp->frames_done) *chp->frames_done = F;
         PROF_ACC(19, _tr);
+    }
+    if (chp->baton != nullptr) {   // this chain is out of the way: everything it stored is visible before the flag is
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            __hip_atomic_store(&chp->baton[2 * chp->chunk0], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     PROF_LAP(12);
 #ifdef MOSHII_PROFILE

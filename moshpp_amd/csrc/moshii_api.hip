@@ -866,12 +866,20 @@ __global__ void k_verify_chunks(int n, int NP, int E, const int* __restrict__ pr
         const double* b = fin + (size_t)p * S;
         const bool flags_ok = (a[2 * NP + 3] == b[2 * NP + 3]) && (a[2 * NP + 4] == b[2 * NP + 4]);
         const bool hp = a[2 * NP + 3] != 0.0;
+        bool nan = false;   // (fmax drops a NaN operand: track it separately, a NaN hand-off must never pass as deviation 0)
         for (int i = threadIdx.x; i < 2 * NP + 3; i += blockDim.x) {
             if (i >= NP && i < 2 * NP && !hp) continue;
-            d = fmax(d, fabs(a[i] - b[i]));
+            const double v = fabs(a[i] - b[i]);
+            nan |= !(v == v);
+            d = fmax(d, v);
         }
-        for (int e = threadIdx.x; e < E; e += blockDim.x) d = fmax(d, fabs(a[2 * NP + 5 + e] - b[2 * NP + 5 + e]));   // free shape block
-        if (!flags_ok || !(d == d)) d = 1e300;
+        for (int e = threadIdx.x; e < E; e += blockDim.x) {   // free shape block
+            const double v = fabs(a[2 * NP + 5 + e] - b[2 * NP + 5 + e]);
+            nan |= !(v == v);
+            d = fmax(d, v);
+        }
+        if (nan) d = 2e300;          // a NaN state: reported as MOSHII_ERR_NUMERIC by the caller
+        else if (!flags_ok) d = 1e300;
     }
     red[threadIdx.x] = d;
     __syncthreads();
@@ -1024,7 +1032,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     }
     const int NC = (int)chunks.size();
     // ---- launch preparation + control block: [ChainDev x NC (pass 1)][ChainDev x NC (repairs)][pred x NC]
-    const size_t extra = 2 * sizeof(ChainDev) * NC + 3 * sizeof(int) * NC + 256;
+    const size_t extra = 2 * sizeof(ChainDev) * NC + 6 * sizeof(int) * NC + 256;
     LaunchCfg cfg;
     size_t ctl = 0;
     int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, NC, stream, extra, &cfg, &ctl);
@@ -1033,13 +1041,17 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     ChainDev* d_pass1 = (ChainDev*)dbase;
     ChainDev* d_repair = d_pass1 + NC;
     int* d_pred = (int*)(d_repair + NC);
-    int* d_bnd = d_pred + NC;   // chunk boundaries (relative frames) of run-through repair chains
+    int* d_bnd = d_pred + NC;   // first frame of every chunk (the boundaries a run-through repair chain crosses)
     int* d_done = d_bnd + NC;   // frames processed per repair chain (diagnostics)
+    int* d_baton = d_done + NC; // [2 NC] state / stop request per chunk (ChainDev::baton)
+    int* d_abort_at = d_baton + 2 * NC;   // [NC] ChainDev::abort_at (kept across the rounds of this call)
     const bool trace = getenv("MOSHII_TRACE_REPAIR") != nullptr;
+    // device buffers of this call: released on EVERY way out of the function (error returns included)
+    struct Owned { std::vector<void*> p; ~Owned() { for (void* q : p) if (q) hipFree(q); } } owned;
     double *d_entry = nullptr, *d_final = nullptr, *d_dev = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_entry, (size_t)NC * S * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&d_final, (size_t)NC * S * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&d_dev, (size_t)NC * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&d_entry, (size_t)NC * S * sizeof(double))); owned.p.push_back(d_entry);
+    HIP_TRY(hipMalloc((void**)&d_final, (size_t)NC * S * sizeof(double))); owned.p.push_back(d_final);
+    HIP_TRY(hipMalloc((void**)&d_dev, (size_t)NC * sizeof(double))); owned.p.push_back(d_dev);
     // start states of sequences that continue a chain (moshii_sequence_desc.init_*): [pose][pose_prev][trans][has_prev][first = 0]
     double* d_init = nullptr;
     {
@@ -1050,7 +1062,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             for (int q = 0; q < n_seq; ++q) {
                 const moshii_sequence_desc& sq = seqs[q];
                 if (!sq.init_pose) continue;
-                if (!sq.init_trans) { hipFree(d_entry); hipFree(d_final); hipFree(d_dev); return fail(MOSHII_ERR_ARG, "init_trans is required with init_pose"); }
+                if (!sq.init_trans) return fail(MOSHII_ERR_ARG, "init_trans is required with init_pose");
                 double* h = hinit.data() + (size_t)q * S;
                 memcpy(h, sq.init_pose, sizeof(double) * NP);
                 if (sq.init_pose_prev) memcpy(h + NP, sq.init_pose_prev, sizeof(double) * NP);
@@ -1059,11 +1071,11 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                 h[2 * NP + 4] = 0.0;
                 if (E > 0 && sq.init_shape) memcpy(h + 2 * NP + 5, sq.init_shape, sizeof(double) * E);
             }
-            HIP_TRY(hipMalloc((void**)&d_init, hinit.size() * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&d_init, hinit.size() * sizeof(double))); owned.p.push_back(d_init);
             HIP_TRY(hipMemcpy(d_init, hinit.data(), hinit.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
-    auto cleanup = [&]() { hipFree(d_entry); hipFree(d_final); hipFree(d_dev); if (d_init) hipFree(d_init); };
+    auto cleanup = [&]() {};   // (buffers are released by `owned`)
     std::vector<Staged> st(dev ? 0 : n_seq);
     std::vector<FrameBufs> fbs(n_seq), dbs(n_seq);
     for (int q = 0; q < n_seq; ++q) {
@@ -1081,7 +1093,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     std::vector<double*> shp(n_seq, nullptr);
     std::vector<char> shp_owned(n_seq, 0);
     size_t qbytes = 0;
-    auto cleanup_shape = [&]() { for (int q = 0; q < n_seq; ++q) if (shp_owned[q] && shp[q]) hipFree(shp[q]); };
+    auto cleanup_shape = [&]() {};   // (released by `owned`)
     if (E > 0) {
         const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;
         qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
@@ -1090,8 +1102,8 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         for (int q = 0; q < n_seq; ++q) {
             if (dev) { shp[q] = seqs[q].shape; continue; }
             if (seqs[q].F < 1) continue;
-            if (hipMalloc((void**)&shp[q], (size_t)seqs[q].F * E * sizeof(double)) != hipSuccess) { cleanup_shape(); cleanup(); return fail(MOSHII_ERR_HIP, "hipMalloc failed"); }
-            shp_owned[q] = 1;
+            if (hipMalloc((void**)&shp[q], (size_t)seqs[q].F * E * sizeof(double)) != hipSuccess) return fail(MOSHII_ERR_HIP, "hipMalloc failed");
+            shp_owned[q] = 1; owned.p.push_back(shp[q]);
             hipMemsetAsync(shp[q], 0, (size_t)seqs[q].F * E * sizeof(double), stream);
         }
     }
@@ -1133,6 +1145,13 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     for (int c = 0; c < NC; ++c) { cds[c] = make_chain(chunks[c], chunks[c].a, c, false); pred[c] = chunks[c].pred; }
     HIP_TRY(hipMemcpyAsync(d_pass1, cds.data(), sizeof(ChainDev) * NC, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_pred, pred.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
+    {
+        std::vector<int> cstart(NC);
+        for (int c = 0; c < NC; ++c) cstart[c] = chunks[c].s;
+        HIP_TRY(hipMemcpyAsync(d_bnd, cstart.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(d_abort_at, 0xff, sizeof(int) * NC, stream));   // -1: no mark
+        HIP_TRY(hipStreamSynchronize(stream));   // (cstart goes out of scope)
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     if ((rc = launch_chains(cfg, NC, d_pass1, stream))) { cleanup(); return rc; }
     // ---- verify the hand-offs; re-solve (exactly, from the predecessor's final state) the chunks that fail
@@ -1152,6 +1171,16 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         }
         std::vector<char> failing(NC, 0);
         for (int c = 0; c < NC; ++c) failing[c] = chunks[c].pred >= 0 && !(hdev[c] <= tol);
+        if (trace && NC <= 16) { fprintf(stderr, "[moshii] hand-off deviations:"); for (int c = 0; c < NC; ++c) fprintf(stderr, " %.1e", hdev[c]); fprintf(stderr, "\n"); }
+        for (int c = 0; c < NC; ++c)
+            if (chunks[c].pred >= 0 && hdev[c] >= 2e300) {   // NaN in a hand-off state: repairing cannot make it verify
+                cleanup_shape(); cleanup();
+                return fail(MOSHII_ERR_NUMERIC, "a chunk hand-off state is NaN");
+            }
+        if (rounds > NC + 1) {   // every round makes at least the first failing hand-off of a sequence exact: NC rounds is the worst case
+            cleanup_shape(); cleanup();
+            return fail(MOSHII_ERR_NUMERIC, "chunk hand-offs did not verify within the round limit");
+        }
         // Scheduling of the repair chains (any mistake here only costs time: whatever ends up inconsistent fails the next
         // verification).  A GROSS miss (> 1e-6) is a chunk whose fresh start sat in another basin: its repair chain may have
         // to run through several chunks before it re-joins, so it owns everything up to the next gross miss.  A SLIGHT
@@ -1178,28 +1207,34 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             }
         }
         if (todo.empty()) break;
-        // every repair chain starts at its failing chunk and runs on through the following chunks until it re-joins the
-        // stored trajectory, or reaches the next chain's start / the end of the sequence
+        // Every repair chain starts at its failing chunk and runs on through the following chunks of its sequence until it
+        // re-joins the stored trajectory.  Where it reaches the start of another chain of this round, it takes over from it
+        // (ChainDev::baton): a cascade of adjacent wrong regions is swept by ONE chain in one round, while regions that turn
+        // out to be independent are still repaired side by side.  (Before the baton each chain ended at the next chain's
+        // start: a cascade cost one round per region, each as long as the longest chain of that round.)
         std::vector<ChainDev> rep(todo.size());
-        std::vector<int> hbnd(NC, 0);
-        int nbnd = 0;
+        std::vector<int> hbaton(2 * (size_t)NC, 0);
+        for (size_t i = 0; i < todo.size(); ++i) hbaton[2 * (size_t)todo[i]] = 1;
         for (size_t i = 0; i < todo.size(); ++i) {
             const int c = todo[i];
-            int cl = c + 1;   // one past the last chunk this chain may cover
-            while (cl < NC && chunks[cl].seq == chunks[c].seq && !(i + 1 < todo.size() && todo[i + 1] == cl)) ++cl;   // (up to the next chain)
+            int cl = c + 1;   // one past the last chunk this chain may cover: the end of its sequence
+            while (cl < NC && chunks[cl].seq == chunks[c].seq) ++cl;
             ChainDev cd = make_chain(chunks[c], chunks[c].s, c, true);
             cd.F = chunks[cl - 1].e - chunks[c].s;
             cd.final_state = d_final + (size_t)(cl - 1) * S;
             cd.nb = cl - 1 - c;
-            cd.bnd = d_bnd + nbnd;
+            cd.bnd = d_bnd + c + 1;
+            cd.bnd_off = chunks[c].s;
             cd.run_final = d_final + (size_t)c * S;
             cd.run_entry = d_entry + (size_t)c * S;
-            for (int k = c + 1; k < cl; ++k) hbnd[nbnd++] = chunks[k].s - chunks[c].s;
-            if (!rejoin) { cd.F = chunks[c].e - chunks[c].s; cd.nb = 0; cd.final_state = d_final + (size_t)c * S; }   // (one chunk per chain)
+            cd.baton = d_baton;
+            cd.abort_at = d_abort_at;
+            cd.chunk0 = c;
+            if (!rejoin) { cd.F = chunks[c].e - chunks[c].s; cd.nb = 0; cd.final_state = d_final + (size_t)c * S; cd.baton = nullptr; cd.abort_at = nullptr; }   // (one chunk per chain)
             cd.frames_done = trace ? d_done + i : nullptr;
             rep[i] = cd;
         }
-        HIP_TRY(hipMemcpyAsync(d_bnd, hbnd.data(), sizeof(int) * std::max(nbnd, 1), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_baton, hbaton.data(), sizeof(int) * hbaton.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_repair, rep.data(), sizeof(ChainDev) * rep.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if ((rc = launch_chains(cfg, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }

@@ -111,6 +111,16 @@ struct ChainDev {
     double* run_final;          // final-state slot of this chain's first chunk (slots are contiguous by chunk)
     double* run_entry;          // entry-state slot of this chain's first chunk
     int* frames_done;           // device or null: number of frames this chain processed before it stopped
+    // Several repair chains of one round run concurrently, each started at a failing chunk and running on until it re-joins the
+    // stored trajectory.  When a chain reaches the chunk at which another chain of the round started, it takes that chain's
+    // territory over (the downstream chain's start state came from rows this chain is replacing): baton[2 c] = 1 while the
+    // chain started at chunk c runs, 2 once it has exited; baton[2 c + 1] = 1 asks it to stop at its next frame.
+    int* baton;                 // device [2 x chunks of the launch] or null
+    int* abort_at;              // device [chunks of the launch] or null: first frame (sequence numbering) a stopped chain did NOT re-solve
+                                // in that chunk -- the stored rows change hands there, so no chain may declare itself re-joined
+                                // before it has passed that frame
+    int chunk0;                 // index of this chain's first chunk
+    int bnd_off;                // bnd[] holds frame numbers of the sequence; this chain's frame 0 is frame bnd_off
     // free shape coefficients (extended kernel variant)
     const double* init_shape;   // device [nshape] or null
     double* shape;              // device [F][nshape] or null

@@ -123,6 +123,11 @@ inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
 inline void __builtin_amdgcn_fence(int, const char*) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
+// device-scope atomics / fences of the inter-workgroup baton: workgroups run one after another here, plain accesses do
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+inline void __threadfence() {}
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }

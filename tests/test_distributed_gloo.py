@@ -185,3 +185,31 @@ def test_stagei_sharded_schur_allreduces_only_the_shared_block(tmp_path):
             assert np.abs(o['pose'] - single['pose']).max() < 1e-9 and np.abs(o['trans'] - single['trans']).max() < 1e-10
         for o in outs[1:]:
             assert np.array_equal(o['betas'], outs[0]['betas']) and np.array_equal(o['pose'], outs[0]['pose'])
+
+
+# ---- bench.py's fixed (strong-scaling) job: which sequences a rank takes ---------------------------------------------------------
+def _bench_share_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    mine = bench.strong_job_shares(32, 4000, world)[rank]          # every rank computes the partition for itself
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    if rank == 0:
+        np.save(os.path.join(outdir, 'shares.npy'), np.array(got, dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_strong_job_is_partitioned_evenly_over_two_ranks(tmp_path):
+    mp.spawn(_bench_share_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    shares = np.load(tmp_path / 'shares.npy', allow_pickle=True)
+    flat = sorted(i for s in shares for i in s)
+    assert flat == list(range(32))                                  # every sequence solved exactly once
+    assert [len(s) for s in shares] == [16, 16]
+    import bench
+    assert [len(s) for s in bench.strong_job_shares(32, 4000, 8)] == [4] * 8
+    assert bench.strong_job_shares(32, 4000, 1) == [list(range(32))]          # N = 1: the many_sequences leg
