@@ -14,6 +14,15 @@
  *   - all floating-point data is IEEE double unless a name ends in _f32;
  *   - "host pointer" arguments are read during the call; handles own device copies;
  *   - thread-safe per handle (one host thread per handle at a time).
+ *
+ * Limits (one chain's whole solver state lives in the 160 KiB LDS of one CU; exceeding one gives MOSHII_ERR_UNSUPPORTED
+ * with a message, nothing is truncated silently; the reference has no such limits)
+ *   - joints K <= 64 (ancestor sets are 64-bit masks);
+ *   - latent markers M <= 128 per attachment (SMPL-X layouts with body + finger + face markers: 89 in BASELINE config 3);
+ *   - unknowns per solve (3 + free pose variables + free shape coefficients): <= 127 without, <= 207 with a jaw term or a
+ *     free shape block (n_face > 0 or n_shape > 0);
+ *   - mixture components of the prior x npose must fit beside the Jacobian tiles: G = 8, npose <= 69 as the reference
+ *     ships them; the marker-tile size adapts, a layout that cannot fit at all is reported as an error.
  */
 #ifndef MOSHII_H
 #define MOSHII_H
@@ -43,6 +52,7 @@ const char* moshii_last_error(void);
 int  moshii_version(void);
 int  moshii_device_count(void);
 int  moshii_set_device(int device);
+int  moshii_device_multiprocessors(void);   /* CUs of the current device (the chunk count moshii_sequence_solve picks by default) */
 
 /* ---------------------------------------------------------------------------------------------
  * Body model.  Replaces load_surface_model + SmplModelLBS construction

@@ -12,6 +12,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MOSHII_LIB', os.path.join(_HERE, 'libmoshii.so'))
+# limits of the chain kernel (include/moshii.h "Limits"): one chain's whole state lives in the 160 KiB LDS of a CU
+MAX_MARKERS = 128            # moshii_attach_create
+MAX_JOINTS = 64              # moshii_model_create (ancestor sets are 64-bit masks)
+MAX_UNKNOWNS = 127           # 3 + free pose variables per solve, plain kernel (8 register blocks of 16, one row for the right-hand side)
+MAX_UNKNOWNS_EXTENDED = 207  # ... with the jaw term / a free shape block (13 register blocks)
 
 BUFFERS_HOST = 0
 BUFFERS_DEVICE = 1
@@ -73,6 +78,7 @@ EXPORTS = {
     'moshii_version': (C.c_int, []),
     'moshii_device_count': (C.c_int, []),
     'moshii_set_device': (C.c_int, [C.c_int]),
+    'moshii_device_multiprocessors': (C.c_int, []),
     'moshii_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     'moshii_model_destroy': (C.c_int, [C.c_void_p]),
     'moshii_model_set_betas': (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
@@ -125,6 +131,11 @@ def check(rc):
 
 def device_count():
     return load().moshii_device_count()
+
+
+def device_cu_count():
+    """CUs of the current device (256 on MI355X); the default chunk count of the chunked chain modes."""
+    return max(int(load().moshii_device_multiprocessors()), 1)
 
 
 def require_device():

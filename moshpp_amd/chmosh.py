@@ -114,19 +114,31 @@ class StageIISolver:
                 raise ValueError(f'expression block [{self.shape_start}, {self.shape_start + self.n_shape}) exceeds the '
                                  f'{surface_model.num_total_betas} shape coefficients of the model')
         self.sm = surface_model
-        self.dev = surface_model.device()
+        # limits of the chain kernel's LDS layout (include/moshii.h), checked here with the numbers at hand
+        M = int(np.asarray(markers_latent).shape[0])
+        if M > capi.MAX_MARKERS:
+            raise ValueError(f'{M} latent markers: libmoshii solves layouts of at most {capi.MAX_MARKERS} markers per subject '
+                             f'(the per-frame Jacobian tiles and marker tables of a chain live in the 160 KiB LDS of one CU)')
+        if surface_model.K > capi.MAX_JOINTS:
+            raise ValueError(f'{surface_model.K} joints: libmoshii models have at most {capi.MAX_JOINTS} (ancestor sets are 64-bit masks)')
+        self.dev = surface_model.new_device()   # a handle of its own: betas / free shape block are state of the handle
         betas = np.asarray(betas, dtype=np.float64).ravel()
         nb = len(betas) if num_betas is None else int(num_betas)
         b = np.zeros(surface_model.num_total_betas)
         b[:nb] = betas[:nb]                               # chmosh.py:499-500
         self.betas = b
         self.dev.set_betas(b)
-        self.dev.set_free_shape(self.shape_start, self.n_shape)    # (0, 0) clears a block left by an earlier solver
+        self.dev.set_free_shape(self.shape_start, self.n_shape)
         can_body = self.dev.lbs_forward(np.zeros((1, surface_model.NP)), np.zeros((1, 3)))[0]   # can_model.r (:502)
         self.can_body = can_body
         self.tc = TransformedCoeffs(can_body, markers_latent)
         self.attach = capi.Attachment(self.dev, self.tc.closest, self.tc.coef)
         self.ids = stageii_pose_ids(self.model_type, surface_model.NP, optimize_fingers, optimize_toes, optimize_face)
+        n_unknowns = 3 + max(len(self.ids['step1']), len(self.ids['step2']) + self.n_shape)
+        cap = capi.MAX_UNKNOWNS_EXTENDED if (self.n_shape or len(self.ids['face'])) else capi.MAX_UNKNOWNS
+        if n_unknowns > cap:
+            raise ValueError(f'{n_unknowns} unknowns per solve (3 + free pose variables + free shape coefficients): libmoshii solves at most '
+                             f'{cap} for this configuration ({capi.MAX_UNKNOWNS} without / {capi.MAX_UNKNOWNS_EXTENDED} with jaw / free shape block)')
         self.prior = None
         if len(self.ids['body']):
             if prior is None:
@@ -177,7 +189,7 @@ class StageIISolver:
                     chains.append(ch)
                 return capi.chain_solve_host(self.dev, self.prior, self.opts, chains)
             keys = ('pose', 'trans', 'shape') if self.n_shape else ('pose', 'trans')
-            out, info = solve_sequence_chunked_host(solve_ranges, F, num_chunks or 64, warmup=chunk_warmup, verify_tol=verify_tol,
+            out, info = solve_sequence_chunked_host(solve_ranges, F, num_chunks or capi.device_cu_count(), warmup=chunk_warmup, verify_tol=verify_tol,
                                                     state_keys=keys)
             out['chunk_report'] = info
             return out
@@ -247,7 +259,11 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     obs, vis = mocap.markers_aslabeled_arrays(latent_labels, selected_frames)
 
     # 5. the frame loop (:584-724) on the GPU
-    out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', 'sequential'),
+    # chain mode: the chunk-parallel solve (same result as the reference's frame order to `verify_tol`) unless
+    # a variable with long memory is free -- finger, expression or DMPL coefficients: a chunk start then never reproduces the
+    # chain and the scheme degenerates to the sequential sweep it falls back on -- or the cfg asks for the literal order
+    default_mode = 'sequential' if (solver.optimize_fingers or solver.optimize_face or solver.optimize_dynamics) else 'chunked'
+    out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
                        verify_tol=float(_get(ext, 'verify_tol', 1e-11)))
     for fi in np.flatnonzero(out['status'] == 1):
@@ -417,6 +433,13 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
         if all(m in marker_meta['marker_vids'] for m in head_meta['mrk_labels']):
             head_corr = (np.array([lab_idx[str(m)] for m in head_meta['mrk_labels']], dtype=np.int32), np.asarray(head_meta['corr']))
             logger.info('Successfully took into account the correlation of the head markers')
+    if head_corr is not None and 'head' in marker_meta['marker_type_mask']:
+        # with the head correlation term the reference builds init_* for every type EXCEPT 'head' (`if k != 'head'`, :364): the
+        # whole type leaves the plain init terms, not only the markers listed in the correlation file
+        wt_init[np.asarray(marker_meta['marker_type_mask']['head'], dtype=bool)] = 0.0
+    # weight of init_head_corr: wt_init.get('body', stagei_wt_init) (:366-367) -- the body type's weight only if the layout has one
+    wt_init_head = float(_get(W, 'stagei_wt_init_body', W['stagei_wt_init'])) if 'body' in marker_meta['marker_type_mask'] \
+        else float(W['stagei_wt_init'])
     pose_ids, body_ids, finger_ids = stagei_pose_ids(sm.model_type, sm.NP, cfg.moshpp.optimize_fingers, cfg.moshpp.optimize_toes)
     face_kw = {}
     if cfg.moshpp.optimize_face and sm.model_type == 'smplx':       # jaw + per-frame expressions in the last two rounds (:300-305, 394-398)
@@ -436,7 +459,7 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
                                  exclude_vids=SMPLX_EYEBALL_VIDS if sm.V == 10475 else None,
                                  betas_init=all_betas[:nb] if nb else None, maxiter=int(cfg.opt_settings.maxiter),
                                  stagei_lr=float(cfg.opt_settings.stagei_lr), head_corr=head_corr,
-                                 wt_init_head=float(_get(W, 'stagei_wt_init_body', W['stagei_wt_init'])), **face_kw)
+                                 wt_init_head=wt_init_head, **face_kw)
     if nb:
         all_betas[:nb] = out['betas']
     errs = {k: v for k, v in out['errs'].items() if not (k == 'poseH' and not finger_ids) and not (k == 'beta' and not nb)
@@ -446,7 +469,10 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
     else:
         errs.pop('poseF', None)
     # markers_latent_all_vids (:424-430): nearest vertex of the LAST frame's posed body for every valid marker of that frame
-    dev.set_betas(all_betas if optimize_betas else np.zeros_like(all_betas))
+    b_last = (all_betas if optimize_betas else np.zeros_like(all_betas)).copy()
+    if face_kw:     # opt_models[-1].r carries the last frame's expression coefficients (:300-305)
+        b_last[face_kw['expr_start']:face_kw['expr_start'] + face_kw['n_expr']] += out['expression'][-1]
+    dev.set_betas(b_last)
     last_body = dev.lbs_forward(out['pose'][-1:], out['trans'][-1:])[0]
     last = stagei_frames[-1]
     keys = [k for k, v in last.items() if not np.any(np.isnan(v))]

@@ -340,6 +340,12 @@ int moshii_device_count(void) {
 }
 int moshii_set_device(int device) { HIP_TRY(hipSetDevice(device)); return MOSHII_OK; }
 
+int moshii_device_multiprocessors(void) {
+    int d = 0, n = 0;
+    if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) return 0;
+    return n;
+}
+
 int moshii_model_create(const moshii_model_desc* d, moshii_model_t* out) {
     if (!d || !out) return fail(MOSHII_ERR_ARG, "null argument");
     if (d->K < 1 || d->K > MOSHII_MAXK) return fail(MOSHII_ERR_UNSUPPORTED, "K must be in [1,64]");

@@ -143,6 +143,13 @@ class SurfaceModel:
                                       self.selected_components)
         return self._device
 
+    def new_device(self):
+        """A libmoshii model handle of its own: betas and the free shape block are STATE of the handle (moshii_model_set_betas /
+        set_free_shape), so every solver that sets them takes one for itself instead of sharing the cached `device()`."""
+        from . import capi
+        return capi.Model(self.v_template, self.shapedirs, self.posedirs, self.weights, self.J_regressor, self.parents,
+                          self.body_dof, self.hand_dof, self.hands_mean, self.selected_components)
+
 
 def load_surface_model(surface_model_fname, pose_hand_prior_fname=None, use_hands_mean=False, dof_per_hand=12,
                        v_template_fname=None, surface_model_type: str = None) -> SurfaceModel:

@@ -111,10 +111,13 @@ def solve_sequence_sharded(solve_range: Callable, F: int, dist=None, warmup: int
         finals = [None] * world
         dist.all_gather_object(finals, final)
         miss = False
+        # failures are decided from data every rank holds (`finals`, the gathered flags), so all ranks raise together: one rank
+        # raising alone would leave the others waiting in the next collective
+        starved = [r for r in range(world - 1) if finals[r] is None]
+        if starved:
+            raise RuntimeError('rank(s) %s solved fewer than two frames: no state to hand over' % starved)
         if rank > 0:
             left = finals[rank - 1]
-            if left is None:
-                raise RuntimeError('rank %d solved fewer than two frames: no state to hand over' % (rank - 1))
             dev = float('inf') if entry is None else float(np.max(np.abs(entry - left)))
             miss = not (dev <= verify_tol)
             if not miss:
@@ -123,7 +126,7 @@ def solve_sequence_sharded(solve_range: Callable, F: int, dist=None, warmup: int
         dist.all_gather_object(flags, bool(miss))
         if not any(flags):
             break
-        if rounds >= max_rounds:
+        if rounds >= max_rounds:    # (`flags` and `rounds` are the same on every rank)
             raise RuntimeError('sharded sequence solve did not converge: hand-offs still failing after %d rounds' % rounds)
         repaired.append([r for r, f in enumerate(flags) if f])
         if miss:   # re-solve the owned range from the left neighbour's end state
