@@ -25,12 +25,17 @@ __device__ long long g_prof[64];
 #define PROF_BEGIN() long long _pt = clock64()
 #define PROF_LAP(slot) do { __syncthreads(); if (threadIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - _pt; _pt = _n; } else { _pt = 0; } } while (0)
 #define PROF_COUNT(slot) do { if (threadIdx.x == 0) g_prof[slot] += 1; } while (0)
+// (laps inside helper functions: the running time stamp lives in g_prof[63]; PROF_MARK starts it -- one workgroup only)
+#define PROF_MARK() do { if (threadIdx.x == 0) g_prof[63] = clock64(); } while (0)
+#define PROF_LAP_EXT(slot) do { __syncthreads(); if (threadIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - g_prof[63]; g_prof[63] = _n; } } while (0)
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ACC(slot, var) do { if (threadIdx.x == 0) g_prof[slot] += clock64() - var; } while (0)   // thread 0's time since PROF_T
 #else
 #define PROF_BEGIN() do {} while (0)
 #define PROF_LAP(slot) do {} while (0)
 #define PROF_COUNT(slot) do {} while (0)
+#define PROF_MARK() do {} while (0)
+#define PROF_LAP_EXT(slot) do {} while (0)
 #define PROF_T(var) do {} while (0)
 #define PROF_ACC(slot, var) do {} while (0)
 #endif
@@ -311,10 +316,15 @@ __device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev&
 template <bool XT>
 __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                             const OptsDev& op, const double* pose, const double* trans, const FrameParams& fp,
-                            const uint8_t* visrow, const int* klist, int nk, const double* vbase) {
+                            const uint8_t* visrow, const int* klist, int nk, const double* vbase, const bool light) {
     const int tid = threadIdx.x;
     const int K = md.K, P = md.P, bd = md.body_dof, hd = md.hand_dof, nhf = md.nhand_full;
     PROF_BEGIN(); PROF_COUNT(20);
+    // `light` (wave-uniform): the forward state in LDS -- rotations, chain, vertices, simulated markers, the prior's argmin and
+    // value -- is that of THIS point already (the evaluation that ended the previous frame was at it, with the same joint
+    // lists); only what depends on the frame's data is redone: data residuals, velocity / finger / shape sums, the weights.
+    // Same arithmetic on the same stored values: the result has the bits of a full evaluation.
+    if (!light) {
     // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
     for (int d = tid; d < P; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, pose, d);
     if constexpr (XT) {
@@ -410,13 +420,18 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         cx.vpos[a * 3 + 2] = az + trans[2];
     }
     __syncthreads();
+    }   // (!light)
     // F6: simulated markers + weighted data residual
     double sd = 0.0;
     const int M = at.M;
     for (int m = tid; m < M; m += MOSHII_TPB) {
         double mk[3];
-        const double c[3] = {gptr(at.coef)[m * 3 + 0], gptr(at.coef)[m * 3 + 1], gptr(at.coef)[m * 3 + 2]};
-        marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, nullptr);
+        if (!light) {
+            const double c[3] = {gptr(at.coef)[m * 3 + 0], gptr(at.coef)[m * 3 + 1], gptr(at.coef)[m * 3 + 2]};
+            marker_eval(c, &cx.vpos[(3 * m + 0) * 3], &cx.vpos[(3 * m + 1) * 3], &cx.vpos[(3 * m + 2) * 3], mk, nullptr);
+        } else {
+            mk[0] = cx.msim[m * 3 + 0]; mk[1] = cx.msim[m * 3 + 1]; mk[2] = cx.msim[m * 3 + 2];
+        }
         const bool v = visrow != nullptr && gptr(visrow)[m] != 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -449,7 +464,8 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     // F7: prior: l_g = sqrt(.5) (x - mu_g) . L_g for every component, argmin of |l_g|^2 - log w_g
     const int np_ = op.nbody;
     double prior_ss = 0.0;
-    if (np_ > 0) {
+    if (np_ > 0 && light) prior_ss = cx.scal[S_PRIOR_SS];   // (stored by the evaluation that left this state; S_KBEST stands too)
+    if (np_ > 0 && !light) {
         for (int b = tid; b < np_; b += MOSHII_TPB) cx.xb[b] = pose[op.body[b]];
         __syncthreads();
         const int G = pr.G;
@@ -557,7 +573,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
             if (tid < G) cx.ps0[tid] = sqrt(cx.score[tid]);
             if (tid == 0) { cx.scal[S_PRIOR_REF] = 1.0; cx.scal[S_PRIOR_KB0] = (double)kb; }
         }
-        if (tid == 0) cx.scal[S_KBEST] = (double)kb;   // (read by assemble(), many barriers later)
+        if (tid == 0) { cx.scal[S_KBEST] = (double)kb; cx.scal[S_PRIOR_SS] = prior_ss; }   // (read by assemble() / a light evaluation, many barriers later)
         PROF_LAP(43);
     }
     block_sum3(sd, sv, sh, cx.red);
@@ -748,9 +764,48 @@ struct AReg {
 // allocated with nothing live but its arguments.
 // (Two functions, elimination and back-substitution: as one, hipcc's register allocator crashes on it under the
 // iterative-ILP scheduler the rest of this file is built with.)
+// How a matrix crosses a function boundary.  A struct of more than 64 bytes is passed and returned through the stack --
+// scratch memory, a store / load round trip at every call; a VECTOR of the same doubles travels in registers.  Up to 16
+// entries per thread (NBLK <= 5) go as a vector, larger matrices as the struct (the emulation build, compiled by g++, has
+// no such vector types: struct everywhere).
+#ifdef MOSHII_ASM_SRET
+#define MOSHII_ASM_RET_VEC(NBLK) false
+#else
+#define MOSHII_ASM_RET_VEC(NBLK) ((NBLK) * ((NBLK) + 1) / 2 <= 16)
+#endif
+template <int NBLK, bool VEC = (NBLK * (NBLK + 1) / 2 <= 16)>
+struct APass {
+    typedef AReg<NBLK> type;
+    static __device__ __forceinline__ type pack(const AReg<NBLK>& A) { return A; }
+    static __device__ __forceinline__ AReg<NBLK> unpack(const type& v) { return v; }
+};
+#if defined(__clang__)
 template <int NBLK>
-__device__ __noinline__ bool ldl_factor(const AReg<NBLK> A, int o_Lp, int o_g, int o_pinv, int n) {
+struct APass<NBLK, true> {
+    typedef double type __attribute__((ext_vector_type(NBLK * (NBLK + 1) / 2)));
+    static __device__ __forceinline__ type pack(const AReg<NBLK>& A) {
+        type v;
+#pragma unroll
+        for (int e = 0; e < AReg<NBLK>::NE; ++e) v[e] = A.a[e];
+        return v;
+    }
+    static __device__ __forceinline__ AReg<NBLK> unpack(const type v) {
+        AReg<NBLK> A;
+#pragma unroll
+        for (int e = 0; e < AReg<NBLK>::NE; ++e) A.a[e] = v[e];
+        return A;
+    }
+};
+#endif
+
+#ifdef MOSHII_LDL_PAIRWISE
+template <int NBLK>
+__device__ __noinline__ bool ldl_factor(const typename APass<NBLK>::type Av, int o_Lp_, int o_g_, int o_pinv_, int n_) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    const AReg<NBLK> A = APass<NBLK>::unpack(Av);
+    // (function arguments arrive in vector registers: as scalars the loop bounds and LDS offsets below are SALU work)
+    const int o_Lp = __builtin_amdgcn_readfirstlane(o_Lp_), o_g = __builtin_amdgcn_readfirstlane(o_g_);
+    const int o_pinv = __builtin_amdgcn_readfirstlane(o_pinv_), n = __builtin_amdgcn_readfirstlane(n_);
     double* const Lp = lds + o_Lp;
     const double* const g = lds + o_g;
     double* const pinv = lds + o_pinv;
@@ -861,10 +916,167 @@ __device__ __noinline__ bool ldl_factor(const AReg<NBLK> A, int o_Lp, int o_g, i
     PROF_LAP(9);
     return ok;
 }
+#else
+// Elimination by 16-column PANELS (same arithmetic, operation for operation, as the column-pair elimination kept above
+// under MOSHII_LDL_PAIRWISE -- every entry receives w_ik = fma(-c_ij, c_kj pin_j, w_ik) for j ascending -- so the factor,
+// the reciprocal pivots and the solver's trajectory have the same bits; what changes is who executes it).  The kernel's
+// time is instruction count (one wavefront per SIMD: ~5 cycles an instruction, measured -- tools/ubench_latency.hip); the
+// pair elimination spent ~150 instructions of EVERY wavefront and an LDS round trip per two columns.  Here, per panel:
+//   A  the owners publish the panel's current entries into the packed factor (where they end up anyway),
+//   B  wavefront 0 alone eliminates the 16 columns inside the panel: lane r holds row c0 + r (and row c0 + 64 + r when
+//      the matrix has more than 64 rows) in registers, the pivot and the normalised pivot-column entries travel by
+//      v_readlane -- no LDS, no barrier -- three instructions per (column, later column) pair,
+//   C  everyone applies the panel to the tiles to its right: 16 rank-1 updates per tile from LDS reads that are broadcasts
+//      (row entries) or spread over the banks (column entries), the next panel's entries included.
+// Two barriers per 16 columns instead of eight.
+template <int NBLK>
+struct LdlCtx {
+    double* Lp; double* pinv; double* Zr;
+    int n, trash, zero, ty, tx, lane;
+    int rS[NBLK], cS[NBLK];   // packed offsets of this thread's rows b 16 + ty / b 16 + tx (-1: beyond the border row)
+};
+// B: wavefront 0 eliminates the columns of panel P inside the panel.  FULL: all 16 columns exist (every panel but possibly
+// the last) -- no per-column test, one basic block, in which the scheduler overlaps a column's updates with the next
+// column's pivot chain.  Returns "a pivot was not positive".
+template <int NBLK, int P, bool FULL>
+__device__ __forceinline__ bool ldl_panel_eliminate(const LdlCtx<NBLK>& c) {
+    constexpr int NS = (NBLK * 16 + 63) / 64;      // rows per lane of wavefront 0
+    constexpr int c0 = 16 * P;
+    double a[NS][16];
+    int off[NS];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const int row = c0 + 64 * s_ + c.lane;
+        off[s_] = (row <= c.n) ? row * (row + 1) / 2 + c0 : -1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[s_][k] = c.Lp[(off[s_] >= 0 && c0 + k <= row) ? off[s_] + k : c.zero];
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (FULL || c0 + j < c.n) {   // (uniform: the border row's own "column" is not eliminated)
+            const double pj = readlane_f64(a[0][j], j);
+            bad = bad || !(pj > 0.0);
+            // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
+            double pin = __builtin_amdgcn_rcp(pj);
+            pin = fma(fma(-pj, pin, 1.0), pin, pin);
+            pin = fma(fma(-pj, pin, 1.0), pin, pin);
+            *((c.lane == 0) ? c.pinv + c0 + j : c.Lp + c.trash) = pin;
+            const double lj = a[0][j] * pin;   // lane k: c_kj pin_j of row c0 + k
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) {
+                const double lk = readlane_f64(lj, k);
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) a[s_][k] = fma(-a[s_][j], lk, a[s_][k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const int row = c0 + 64 * s_ + c.lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c.Lp[(off[s_] >= 0 && c0 + k <= row) ? off[s_] + k : c.trash] = a[s_][k];
+    }
+    return bad;
+}
+// C: panel P applied to every tile to its right
+template <int NBLK, int P, bool FULL>
+__device__ __forceinline__ void ldl_panel_apply(const LdlCtx<NBLK>& c, double (&w)[NBLK * (NBLK + 1) / 2]) {
+    constexpr int c0 = 16 * P;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (FULL || c0 + j < c.n) {
+            const double pin = c.pinv[c0 + j];
+            double ci[NBLK], ck[NBLK];
+#pragma unroll
+            for (int b = P + 1; b < NBLK; ++b) {
+                ci[b] = c.Lp[(c.rS[b] >= 0) ? c.rS[b] + c0 + j : c.zero];
+                ck[b] = c.Lp[(c.cS[b] >= 0) ? c.cS[b] + c0 + j : c.zero] * pin;
+            }
+#pragma unroll
+            for (int bi = P + 1; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = P + 1; bj <= bi; ++bj) w[bi * (bi + 1) / 2 + bj] = fma(-ci[bi], ck[bj], w[bi * (bi + 1) / 2 + bj]);
+        }
+    }
+}
+template <int NBLK, int P>
+__device__ __forceinline__ bool ldl_panels(const LdlCtx<NBLK>& c, double (&w)[NBLK * (NBLK + 1) / 2]) {
+    constexpr int c0 = 16 * P;
+    if (c0 >= c.n) return true;   // (uniform)
+    // A: the panel's entries as they stand (lower triangle of the diagonal tile, the tiles below it whole)
+#pragma unroll
+    for (int bi = P; bi < NBLK; ++bi) {
+        const int q1 = bi * 16 + c.ty, q2 = c0 + c.tx;
+        c.Lp[(c.rS[bi] >= 0 && q2 <= q1) ? c.rS[bi] + q2 : c.trash] = w[bi * (bi + 1) / 2 + P];
+    }
+    __syncthreads();
+    PROF_LAP_EXT(46);
+    if (threadIdx.x < 64) {
+        const bool bad = (c0 + 16 <= c.n) ? ldl_panel_eliminate<NBLK, P, true>(c) : ldl_panel_eliminate<NBLK, P, false>(c);
+        if (c.lane == 0 && bad) c.Zr[1] = 1.0;
+    }
+    __syncthreads();
+    PROF_LAP_EXT(44);
+    if (c.Zr[1] != 0.0) return false;   // a non-positive pivot (every thread sees it): the caller takes the Cauchy step
+    if constexpr (P + 1 < NBLK) {
+        if (c0 + 16 <= c.n) ldl_panel_apply<NBLK, P, true>(c, w); else ldl_panel_apply<NBLK, P, false>(c, w);
+        PROF_LAP_EXT(45);
+        return ldl_panels<NBLK, P + 1>(c, w);
+    }
+    return true;
+}
 
 template <int NBLK>
-__device__ __noinline__ void ldl_backsub(int o_Lp, int o_d, int o_pinv, int n) {
+__device__ __noinline__ bool ldl_factor(const typename APass<NBLK>::type Av, int o_Lp_, int o_g_, int o_pinv_, int n_) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    const AReg<NBLK> A = APass<NBLK>::unpack(Av);
+    // (function arguments arrive in vector registers: as scalars the loop bounds and LDS offsets below are SALU work)
+    const int o_Lp = __builtin_amdgcn_readfirstlane(o_Lp_), o_g = __builtin_amdgcn_readfirstlane(o_g_);
+    const int o_pinv = __builtin_amdgcn_readfirstlane(o_pinv_), n = __builtin_amdgcn_readfirstlane(n_);
+    const double* const g = lds + o_g;
+    const int tid = threadIdx.x;
+    PROF_BEGIN(); PROF_COUNT(22);
+    LdlCtx<NBLK> c;
+    c.Lp = lds + o_Lp; c.pinv = lds + o_pinv; c.n = n;
+    c.ty = tid >> 4; c.tx = tid & 15; c.lane = tid & 63;
+    double w[AReg<NBLK>::NE];
+    {
+        int e = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                const int q1 = bi * 16 + c.ty, q2 = bj * 16 + c.tx;
+                const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);   // (unconditional read)
+                w[e] = (q1 == n) ? gq : A.a[e];
+                ++e;
+            }
+    }
+    // Lp: the packed factor, entry (i, j), j <= i, at i (i + 1) / 2 + j; row n is the right-hand side.  Behind it: 64 per-lane
+    // trash words (stores that do not apply), a zero word (loads that do not apply), the panels' verdict.
+    c.trash = (n + 1) * (n + 2) / 2 + c.lane; c.zero = (n + 1) * (n + 2) / 2 + 64;
+    c.Zr = c.Lp + c.zero;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int q1 = b * 16 + c.ty, q2 = b * 16 + c.tx;
+        c.rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
+        c.cS[b] = (q2 <= n) ? q2 * (q2 + 1) / 2 : -1;
+    }
+    if (tid == 0) { c.Zr[0] = 0.0; c.Zr[1] = 0.0; }
+    PROF_MARK();
+    const bool ok = ldl_panels<NBLK, 0>(c, w);
+    __syncthreads();
+    PROF_LAP(9);
+    return ok;
+}
+#endif
+
+template <int NBLK>
+__device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n_) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int o_Lp = __builtin_amdgcn_readfirstlane(o_Lp_), o_d = __builtin_amdgcn_readfirstlane(o_d_);
+    const int o_pinv = __builtin_amdgcn_readfirstlane(o_pinv_), n = __builtin_amdgcn_readfirstlane(n_);
     const double* const Lp = lds + o_Lp;
     double* const d = lds + o_d;
     const double* const pinv = lds + o_pinv;
@@ -915,7 +1127,7 @@ __device__ __noinline__ void ldl_backsub(int o_Lp, int o_d, int o_pinv, int n) {
 
 template <int NBLK>
 __device__ __forceinline__ bool ldl_solve(const AReg<NBLK>& A, int o_Lp, int o_g, int o_d, int o_pinv, int n) {
-    if (!ldl_factor<NBLK>(A, o_Lp, o_g, o_pinv, n)) return false;
+    if (!ldl_factor<NBLK>(APass<NBLK>::pack(A), o_Lp, o_g, o_pinv, n)) return false;
     ldl_backsub<NBLK>(o_Lp, o_d, o_pinv, n);
     return true;
 }
@@ -1474,8 +1686,8 @@ __device__ __forceinline__ T uniform_load(const T* p) {
 }
 
 template <bool XT>
-__device__ __noinline__ Sse eval_forward_fn(const FrameParams fp_, const uint8_t* visrow, int o_pose, int o_trans, int i_klist, int nk,
-                                            int o_vbase) {
+__device__ __noinline__ Sse eval_forward_fn(const uint8_t* visrow, int o_pose, int o_trans, int i_klist, int nk,
+                                            int o_vbase, int light) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
     const ChainLayout ly = uniform_load(&kc->ly);
@@ -1483,16 +1695,16 @@ __device__ __noinline__ Sse eval_forward_fn(const FrameParams fp_, const uint8_t
     const PriorDev pr = uniform_load(&kc->pr);
     const OptsDev op = uniform_load(&kc->op);
     const AttachDev at = uniform_load(&kc->at);
-    const FrameParams fp = uniform_load(&fp_);
+    const FrameParams fp = uniform_load(reinterpret_cast<const FrameParams*>(kc->fp_raw));
     const Ctx cx = make_ctx(lds, ly);
     const int* ints = reinterpret_cast<const int*>(lds + ly.o_ints);
     return eval_forward<XT>(cx, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), lds + __builtin_amdgcn_readfirstlane(o_trans),
                             fp, visrow, ints + __builtin_amdgcn_readfirstlane(i_klist), __builtin_amdgcn_readfirstlane(nk),
-                            lds + __builtin_amdgcn_readfirstlane(o_vbase));
+                            lds + __builtin_amdgcn_readfirstlane(o_vbase), __builtin_amdgcn_readfirstlane(light) != 0);
 }
 
 template <int NBLK, bool XT>
-__device__ __noinline__ AReg<NBLK> assemble_fn(const FrameParams fp_, int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
+__device__ __noinline__ typename APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::type assemble_fn(int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
     const ChainLayout ly = uniform_load(&kc->ly);
@@ -1500,12 +1712,12 @@ __device__ __noinline__ AReg<NBLK> assemble_fn(const FrameParams fp_, int o_pose
     const PriorDev pr = uniform_load(&kc->pr);
     const OptsDev op = uniform_load(&kc->op);
     const AttachDev at = uniform_load(&kc->at);
-    const FrameParams fp = uniform_load(&fp_);
+    const FrameParams fp = uniform_load(reinterpret_cast<const FrameParams*>(kc->fp_raw));
     const Ctx cx = make_ctx(lds, ly);
     AReg<NBLK> A;
     assemble<NBLK, XT>(cx, ly, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), fp, __builtin_amdgcn_readfirstlane(n),
                        __builtin_amdgcn_readfirstlane(ncp), __builtin_amdgcn_readfirstlane(nkf), __builtin_amdgcn_readfirstlane(nfree_hand), qs, A);
-    return A;
+    return APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::pack(A);
 }
 
 // Arun/Procrustes rigid init (rigid_transformations.py:39-83), serial on one thread (first solved frame only).
@@ -1601,7 +1813,7 @@ template <int NBLK, bool XT>
 __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                          const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, MOSHII_GP(const int) ids, int nids, int nshp,
                          double* qs, double e3,
-                         bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int set_id, int& vc_key,
+                         bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int& fwd_set, int set_id, int& vc_key,
                          int& tab_key, int& n_iter, int& n_fev, int& fail) {
     const int tid = threadIdx.x;
     const int ncp = 3 + nids;
@@ -1661,6 +1873,13 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     }
     AReg<NBLK> A;
     A.zero();
+    // the phase's parameters go to the context block at the head of the LDS, where eval_forward_fn / assemble_fn pick them up
+    // (as a by-value argument they travelled through the stack in scratch memory at every call)
+    if (tid == 0) {
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        static_assert(sizeof(FrameParams) <= sizeof(KernelCtx::fp_raw), "KernelCtx::fp_raw too small");
+        *reinterpret_cast<FrameParams*>(reinterpret_cast<KernelCtx*>(lds)->fp_raw) = fp;
+    }
     for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
     if (tid < 3) cx.trans_t[tid] = cx.trans[tid];
     __syncthreads();
@@ -1671,10 +1890,16 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     // `reuse`: the previous phase of this frame ended with the forward state of the CURRENT point in LDS and the same
     // residual weights, so its evaluation (what ch.minimize recomputes on entry) is carried over instead of redone.
     bool skip_eval = reuse && !rigid;
+    // at_pose && fwd_set == set_id: the forward state in LDS is that of the current point, left by an evaluation with this
+    // free set's joint lists -- the previous frame's last one, or the previous phase's under other weights.  The entry
+    // evaluation then only redoes what depends on the frame's data and weights (eval_forward's `light`).
+    int light = (!rigid && at_pose && fwd_set == set_id) ? 1 : 0;
     while (true) {
         if (skip_eval) { last = carried; skip_eval = false; }
-        else { PROF_T(_te); last = eval_forward_fn<XT>(fp, visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst); PROF_ACC(15, _te); }
+        else { PROF_T(_te); last = eval_forward_fn<XT>(visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst, light); PROF_ACC(15, _te); }
+        light = 0;
         at_pose = true;   // cleared below when a trial point is rejected
+        fwd_set = set_id;
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
             __syncthreads();
@@ -1710,7 +1935,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         }
         PROF_ACC(23, _t1);
         if (do_assemble) {
-            { PROF_T(_ta); A = assemble_fn<NBLK, XT>(fp, ly.o_pose, n, ncp, nkf, nfree_hand, qs); PROF_ACC(16, _ta); }
+            { PROF_T(_ta); A = APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::unpack(assemble_fn<NBLK, XT>(ly.o_pose, n, ncp, nkf, nfree_hand, qs)); PROF_ACC(16, _ta); }
             PROF_T(_t2);
             double gm = 0.0;
             for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
@@ -1866,6 +2091,8 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)
     int rejoin_run = 0;            // consecutive frames that reproduced the stored trajectory (repair chains)
     int bi_next = 0;               // next chunk boundary of a run-through repair chain
+    bool at_pose = false;          // the forward state in LDS is that of (cx.pose, cx.trans) ...
+    int fwd_set = 0;               // ... evaluated with the joint lists of this free set (run_phase)
     PROF_BEGIN();
 #ifdef MOSHII_PROFILE
     const long long _wall0 = wall_clock64();
@@ -1999,7 +2226,6 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         // phases: [rigid + annealed rounds x10 x5 x1 (first solved frame only, :629-655)] step 1 (:665-671),
         //         step 2 (:676-705), record (:712-724)
         Sse fin, carried;
-        bool at_pose = false;
         const bool same_sets = op.same_sets != 0;
         double prev_wt_pose = -1.0;
         int prev_terms = -1;
@@ -2016,7 +2242,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_terms == terms;
             fin = run_phase<NBLK, XT>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
                                   (XT && step2) ? op.nshape : 0, XT ? chp->qscratch : nullptr,
-                                  round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose,
+                                  round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose, fwd_set,
                                   /*set_id=*/(kind >= 4 && !same_sets) ? 2 : 1, vc_key, tab_key, n_iter, n_fev, fail);
             prev_wt_pose = fp.wt_pose; prev_terms = terms;
         }
@@ -2124,7 +2350,7 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restr
     for (int k = 1 + tid; k < md.K; k += MOSHII_TPB) cx.ksum[k - 1] = k;   // every joint's correctives, on top of v_shaped
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];
     __syncthreads();
-    eval_forward<false>(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh);
+    eval_forward<false>(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh, false);
     for (int i = tid; i < 3 * at.M; i += MOSHII_TPB) out[(size_t)f * 3 * at.M + i] = cx.msim[i];
 }
 

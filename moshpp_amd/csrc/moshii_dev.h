@@ -161,6 +161,7 @@ struct KernelCtx {
     PriorDev pr;
     OptsDev op;
     AttachDev at;
+    double fp_raw[12];   // the running phase's per-frame parameters (chain_solve.hip: FrameParams), rewritten at every phase start
 };
 #define MOSHII_KC_DOUBLES ((int)((sizeof(KernelCtx) + 15) / 16 * 2))
 
