@@ -768,10 +768,14 @@ struct AReg {
 // scratch memory, a store / load round trip at every call; a VECTOR of the same doubles travels in registers.  Up to 16
 // entries per thread (NBLK <= 5) go as a vector, larger matrices as the struct (the emulation build, compiled by g++, has
 // no such vector types: struct everywhere).
-#ifdef MOSHII_ASM_SRET
-#define MOSHII_ASM_RET_VEC(NBLK) false
-#else
+// assemble_fn's RESULT nevertheless goes back as the struct.  Returned as a vector, the callee keeps more of its state in the
+// callee-saved half of the register file and saves / restores ~110 registers per lane to scratch at every call: alone on the
+// GPU a chain is 1.5 % faster that way, but with a chain on every CU the extra scratch footprint (32 CUs share 4 MB of L2)
+// costs 8 % (32-sequence leg 635 k -> 685 k frames/s with the struct return; the single-sequence bench is unchanged).
+#ifdef MOSHII_ASM_VECRET
 #define MOSHII_ASM_RET_VEC(NBLK) ((NBLK) * ((NBLK) + 1) / 2 <= 16)
+#else
+#define MOSHII_ASM_RET_VEC(NBLK) false
 #endif
 template <int NBLK, bool VEC = (NBLK * (NBLK + 1) / 2 <= 16)>
 struct APass {
@@ -1703,8 +1707,13 @@ __device__ __noinline__ Sse eval_forward_fn(const uint8_t* visrow, int o_pose, i
                             lds + __builtin_amdgcn_readfirstlane(o_vbase), __builtin_amdgcn_readfirstlane(light) != 0);
 }
 
+#ifdef MOSHII_ASM_INLINE
+#define MOSHII_ASM_LINKAGE __forceinline__
+#else
+#define MOSHII_ASM_LINKAGE __noinline__
+#endif
 template <int NBLK, bool XT>
-__device__ __noinline__ typename APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::type assemble_fn(int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
+__device__ MOSHII_ASM_LINKAGE typename APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::type assemble_fn(int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
     const ChainLayout ly = uniform_load(&kc->ly);

@@ -19,10 +19,15 @@ scripts under tests/golden/, checked by tests/test_ref_golden.py and tests/test_
   * (host package) C3D reader / writer       <- the reference's vendored py-c3d writer and reader (tools/c3d.py)
   * (host package) MocapSession, load_surface_model, AMASS part split <- the reference's own class / functions
     (tools/mocap_interface.py:87-279, models/smpl_fast_derivatives.py:52-150, tools/run_tools.py:70-85)
-UNPINNED (third-party code absent): the SMPL forward + its pose Jacobian, the node Jacobians, and
-`minimize_dogleg`.  These restate the *published* algorithms (SMPL's public `lbs.py`/`posemapper.py`/
-`verts.py`, chumpy's `optimization_internal.py`), anchored on the reference's call sites and validated by
-internal self-checks only (finite differences, scipy least-squares minimum, ground-truth recovery) --
+  * stageii_chain (the Stage-II schedule: first-frame rigid init and annealed rounds, Step 1 / Step 2 free sets, weights,
+    velocity target, empty frames, result terms) and the way `minimize_dogleg` is driven  <- the reference's own
+    `mosh_stageii` function (chmosh.py:468-741) EXECUTED under a lazy chumpy stand-in with the reference's node classes
+    (tests/golden/make_ref_stageii_golden.py -> tests/golden/ref_stageii.npz; 3 cases incl. fingers): <= 5e-9 rad, equal
+    dogleg iteration counts on every solve
+UNPINNED (third-party code absent): the LBS arithmetic of psbody.smpl (forward + pose Jacobian) and the internals of
+chumpy's `minimize_dogleg` (radius rules, stops, the solve).  These restate the *published* algorithms (SMPL's public
+`lbs.py`/`posemapper.py`/`verts.py`, chumpy's `optimization_internal.py`), anchored on the reference's call sites and
+validated by internal self-checks only (finite differences, scipy least-squares minimum, ground-truth recovery) --
 see tests/test_oracle.py.
 
 Reference anchors (all relative to /root/reference/src/moshpp):

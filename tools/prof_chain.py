@@ -19,9 +19,10 @@ lib.moshii_prof_read(buf, 1)
 p = np.array(list(buf), dtype=np.float64)
 names = {0: 'eval: fullpose/rodrigues/chain', 1: 'eval: posedirs', 2: 'eval: skin+markers', 3: 'eval: prior+reduce',
          4: 'asm: T0', 5: 'asm: T1 vertex jac', 6: 'asm: T2 marker rows', 7: 'asm: T3 JtJ', 8: 'asm: structured',
-         9: 'chol factor', 10: 'back-subst', 12: 'kernel total',
+         9: 'chol: set-up + verdicts', 10: 'back-subst', 12: 'kernel total',
          46: 'chol: publish', 44: 'chol: panel (wave 0)', 45: 'chol: trailing update',
          40: 'eval: velocity / finger sums', 41: 'eval: prior setup (xb)', 42: 'eval: prior shortcut', 43: 'eval: prior full + argmin'}
+p[9] -= p[44] + p[45] + p[46]   # (slot 9 laps the whole factorisation; 44-46 are laps inside it)
 tot = p[12]
 print(f'{mt} F={F} fingers={fingers} wall {dt*1e3:.1f} ms  ({dt/F*1e6:.1f} us/frame)  launch {capi.last_launch_info()}')
 print(f'evals {p[20]:.0f} ({p[20]/F:.2f}/frame) assembles {p[21]:.0f} ({p[21]/F:.2f}/frame) chol {p[22]:.0f} ({p[22]/F:.2f}/frame)')
