@@ -314,6 +314,10 @@ typedef struct moshii_stagei_desc {
     double*  expression;                    /* [n_frames][n_expr] or NULL                                        */
     double*  errs;                          /* [8] SSE of data, poseB, init, beta (expr when n_expr > 0), surf, poseH, init_head_corr, poseF */
     int32_t* iters;                         /* [1] dogleg outer iterations over all rounds                       */
+    /* options added later (behind the outputs: a caller that zeroes the struct and knows nothing of them gets the old behaviour) */
+    int32_t  extra_initial_rigid_adjustment;   /* cfg.opt_settings.extra_initial_rigid_adjustment (chmosh.py:230-232): before the annealing
+                                                * rounds, one dogleg over every frame's root orientation + translation on the unweighted
+                                                * marker residuals (e_3 = .001, delta_0 = .5, maxiter)                                   */
 } moshii_stagei_desc;
 
 int moshii_stagei_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL */, const moshii_stagei_desc* desc, void* stream);

@@ -426,7 +426,7 @@ class StageIDesc(C.Structure):
                 ('allreduce_sum', C.c_void_p), ('allreduce_user', C.c_void_p),
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
                 ('pose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('expression', C.c_void_p),
-                ('errs', C.c_void_p), ('iters', C.c_void_p)]
+                ('errs', C.c_void_p), ('iters', C.c_void_p), ('extra_initial_rigid_adjustment', C.c_int32)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
@@ -435,7 +435,7 @@ STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH', 'init_head
 
 def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_ids, body_ids, finger_ids=(), exclude_vids=None,
                 betas_init=None, maxiter=100, stagei_lr=1e-3, head_corr=None, wt_init_head=None, frame_range=None,
-                owns_shared_rows=True, allreduce=None, n_expr=0, expr_start=0, face_ids=()):
+                owns_shared_rows=True, allreduce=None, n_expr=0, expr_start=0, face_ids=(), extra_initial_rigid_adjustment=False):
     """Fill a StageIDesc from NumPy data.  `frames`: list of (latent ids, obs[n,3]).  Returns (desc, outputs dict, keep-alive list)."""
     keep = []
 
@@ -461,6 +461,7 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
     d.body_ids = ptr(body_ids, np.int32); d.n_body = len(body_ids)
     d.finger_ids = ptr(list(finger_ids), np.int32); d.n_finger = len(finger_ids)
     d.maxiter, d.stagei_lr = int(maxiter), float(stagei_lr)
+    d.extra_initial_rigid_adjustment = 1 if extra_initial_rigid_adjustment else 0
     d.n_expr, d.expr_start = int(n_expr), int(expr_start)
     d.face_ids = ptr(list(face_ids), np.int32); d.n_face = len(face_ids)
     d.wt_expr, d.wt_poseF = float(weights.get('stagei_wt_expr', 0.0)), float(weights.get('stagei_wt_poseF', 0.0))

@@ -424,8 +424,7 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
         markers_obs.append(obf); labels_obs.append(common)
     logger.debug('Number of available markers in each stagei selected frames: {}'.format(
         ', '.join([f'(F{fi:02d}, {len(fr)})' for fi, fr in enumerate(markers_obs)])))
-    if _get(cfg.opt_settings, 'extra_initial_rigid_adjustment', False):
-        raise NotImplementedError('opt_settings.extra_initial_rigid_adjustment')
+    extra_rigid = bool(_get(cfg.opt_settings, 'extra_initial_rigid_adjustment', False))   # :230-232, done by the solver before round 1
     head_corr = None
     hfn = _get(cfg.moshpp, 'head_marker_corr_fname')
     if hfn is not None:                                                                # :252-266
@@ -459,7 +458,7 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
                                  exclude_vids=SMPLX_EYEBALL_VIDS if sm.V == 10475 else None,
                                  betas_init=all_betas[:nb] if nb else None, maxiter=int(cfg.opt_settings.maxiter),
                                  stagei_lr=float(cfg.opt_settings.stagei_lr), head_corr=head_corr,
-                                 wt_init_head=wt_init_head, **face_kw)
+                                 wt_init_head=wt_init_head, extra_initial_rigid_adjustment=extra_rigid, **face_kw)
     if nb:
         all_betas[:nb] = out['betas']
     errs = {k: v for k, v in out['errs'].items() if not (k == 'poseH' and not finger_ids) and not (k == 'beta' and not nb)

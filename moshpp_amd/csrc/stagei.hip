@@ -1443,6 +1443,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         LAUNCH(k_s1_verts, (d.V * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.V, 0, p.can, 1);
     };
     // evaluation of residual (and Jacobian) at the uploaded point
+    int shared_rows_on = 1;   // 0 during the extra rigid adjustment: the init / beta / surf / head rows are not part of its objective
     auto evaluate = [&](int want_J) {
         canonical();
         LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl);
@@ -1452,9 +1453,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         if (nown > 0) LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
         if (want_J && nown > 0) LAUNCH(k_s1_vjac, (3 * M * K + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo);
         if (want_J) hipMemsetAsync(p.Jm, 0, (size_t)d.R * d.ldn * 8, st);
-        if (shard) hipMemsetAsync(p.r, 0, (size_t)d.R * 8, st);          // rows of frames other ranks own stay zero here
-        LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J, own_shared);
-        if (d.nhead_rows && own_shared) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
+        if (shard || !shared_rows_on) hipMemsetAsync(p.r, 0, (size_t)d.R * 8, st);          // rows of frames other ranks own (or switched off) stay zero here
+        LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J, own_shared && shared_rows_on);
+        if (d.nhead_rows && own_shared && shared_rows_on) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
         if (nown > 0) LAUNCH(k_s1_rows, nown, 1, S1_TPB, st, d, p, want_J, f_lo);
     };
     auto fetch = [&](std::vector<double>& h, const double* dev, size_t count) {
@@ -1515,10 +1516,19 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     // ---- annealing rounds
     int total_iters = 0;
     std::vector<double> r, rnew, g, x, dsd, dgn, ddl, tmp, hbuf;
-    for (int round = 0; round < ds->n_anneal; ++round) {
-        const double a = ds->annealing[round];
-        const bool detailed = round > ds->n_anneal - 3;
+    // round -1 (opt_settings.extra_initial_rigid_adjustment, chmosh.py:230-232): the unweighted marker residuals of all frames
+    // as a function of every frame's root orientation and translation only, e_3 = .001.  It runs through the same machinery:
+    // the only pose columns are the root's, the latent-marker and shape columns are parked behind column n (written, never
+    // read: the products take n columns of a row of ldn), the prior / init / beta / surf / head rows are off.
+    const int Gall = d.G;
+    for (int round = ds->extra_initial_rigid_adjustment ? -1 : 0; round < ds->n_anneal; ++round) {
+        const bool rigid_round = round < 0;
+        const double a = rigid_round ? 1.0 : ds->annealing[round];
+        const bool detailed = !rigid_round && round > ds->n_anneal - 3;
+        shared_rows_on = rigid_round ? 0 : 1;
+        d.G = rigid_round ? 0 : Gall;
         pose_ids.assign(ds->pose_ids, ds->pose_ids + ds->n_pose_ids);
+        if (rigid_round) { pose_ids.clear(); pose_ids.push_back(0); pose_ids.push_back(1); pose_ids.push_back(2); }
         finger_ids.clear();
         if (detailed) finger_ids.assign(ds->finger_ids, ds->finger_ids + ds->n_finger);
         pose_ids.insert(pose_ids.end(), finger_ids.begin(), finger_ids.end());
@@ -1534,16 +1544,17 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         d.npid = (int)pose_ids.size(); d.nfinger = (int)finger_ids.size();
         d.n = 3 * F + 3 * M + F * d.npid + nsh; d.ldn = (d.n + 15) & ~15;
         d.o_ml = 3 * F; d.o_pose = 3 * F + 3 * M; d.o_b = d.o_pose + F * d.npid;
+        if (rigid_round) { d.n = 6 * F; d.ldn = ld_max; d.o_pose = 3 * F; d.o_ml = 6 * F; d.o_b = 6 * F + 3 * M; }
         d.r_data = 0; d.r_prior = 3 * ntot_obs; d.r_init = d.r_prior + F * (d.G ? d.npose_prior + 1 : 0);
         d.r_beta = d.r_init + 3 * M; d.r_surf = d.r_beta + nsh; d.r_poseH = d.r_surf + M; d.r_head = d.r_poseH + F * d.nfinger;
         d.r_poseF = d.r_head + 3 * d.nhead_rows; d.R = d.r_poseF + F * d.nface;
-        p.w_anneal = a; p.w_data = (ds->wt_data / a) * (46.0 / M); p.w_poseB = ds->wt_poseB * a; p.w_poseH = ds->wt_poseH * a;
+        p.w_anneal = a; p.w_data = rigid_round ? 1.0 : (ds->wt_data / a) * (46.0 / M); p.w_poseB = ds->wt_poseB * a; p.w_poseH = ds->wt_poseH * a;
         p.w_beta = (d.per_frame ? ds->wt_expr : ds->wt_betas) * a; p.w_surf = ds->wt_surf; p.w_init_head = ds->wt_init_head * a;
         p.w_poseF = ds->wt_poseF * a;
         hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
         if (d.nfinger) hipMemcpyAsync(d_finger, finger_ids.data(), d.nfinger * sizeof(int), hipMemcpyHostToDevice, st);
         const int fs = 3 + d.npid + ((d.per_frame && d.shape_free) ? nb : 0), ns = 3 * M + (d.per_frame ? 0 : nb), nsp = (ns + 15) & ~15;
-        const bool schur = want_schur && fs <= S1_FSMAX;
+        const bool schur = want_schur && fs <= S1_FSMAX && !rigid_round;
         if (schur) {
             std::vector<int> fcols((size_t)F * fs), scols(ns), ones((size_t)((F * fs + S1_T - 1) / S1_T) * ((ns + S1_T - 1) / S1_T), 1);
             for (int f = 0; f < F; ++f) {
@@ -1563,15 +1574,15 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         auto pack = [&](std::vector<double>& xx) {
             xx.resize(n);
             for (int f = 0; f < F; ++f) for (int c = 0; c < 3; ++c) xx[3 * f + c] = trans[3 * f + c];
-            for (int i = 0; i < 3 * M; ++i) xx[d.o_ml + i] = ml[i];
+            if (!rigid_round) for (int i = 0; i < 3 * M; ++i) xx[d.o_ml + i] = ml[i];
             for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) xx[d.o_pose + f * d.npid + c] = pose[(size_t)f * NP + pose_ids[c]];
-            for (int e = 0; e < nsh; ++e) xx[d.o_b + e] = betas[e];          // per-frame mode: [frame][coefficient], canonical row last
+            if (!rigid_round) for (int e = 0; e < nsh; ++e) xx[d.o_b + e] = betas[e];          // per-frame mode: [frame][coefficient], canonical row last
         };
         auto unpack = [&](const std::vector<double>& xx) {
             for (int f = 0; f < F; ++f) for (int c = 0; c < 3; ++c) trans[3 * f + c] = xx[3 * f + c];
-            for (int i = 0; i < 3 * M; ++i) ml[i] = xx[d.o_ml + i];
+            if (!rigid_round) for (int i = 0; i < 3 * M; ++i) ml[i] = xx[d.o_ml + i];
             for (int f = 0; f < F; ++f) for (int c = 0; c < d.npid; ++c) pose[(size_t)f * NP + pose_ids[c]] = xx[d.o_pose + f * d.npid + c];
-            for (int e = 0; e < nsh; ++e) betas[e] = xx[d.o_b + e];
+            if (!rigid_round) for (int e = 0; e < nsh; ++e) betas[e] = xx[d.o_b + e];
         };
         auto eval_at = [&](const std::vector<double>& xx, int want_J, std::vector<double>& rr) -> double {
             unpack(xx); upload_point(); evaluate(want_J); fetch(rr, p.r, R);
@@ -1609,7 +1620,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
             if (shard && schur) reduce(out.data(), n);          // A is rank-local there: sum the products
         };
         // ---- Powell dogleg (chumpy minimize_dogleg as restated in oracle/stageii_oracle.py:minimize_dogleg)
-        const double e1 = 1e-15, e2 = 1e-15, e3 = ds->stagei_lr;
+        const double e1 = 1e-15, e2 = 1e-15, e3 = rigid_round ? .001 : ds->stagei_lr;
         pack(x);
         double sse = eval_at(x, 1, r);
         normal_eq();

@@ -462,9 +462,39 @@ class StageIObjective:
         return np.vstack([jac[k] for k in sorted(res)])
 
 
+class _RigidAdjustment:
+    """`ch.minimize(fun=data_obj, x0=[p[:3] for p in poses] + trans, ...)` (chmosh.py:230-232): the unweighted marker residuals
+    of all picked frames as a function of every frame's root orientation and translation; everything else stays where it is.
+    x = [trans_f (3 each), root_f (3 each)] -- the order does not matter to the dogleg (all its norms are permutation invariant)."""
+
+    def __init__(self, obj):
+        self.obj = obj
+        obj.set_round([0, 1, 2], [], dict(anneal=1.0, data=1.0, poseB=0.0, poseH=0.0, beta=0.0, surf=0.0, init_head=0.0,
+                                          poseF=0.0, expr=0.0))
+        self.full = obj.x()
+        F, M = obj.F, obj.M
+        self.cols = np.concatenate([np.arange(3 * F), 3 * F + 3 * M + np.arange(3 * F)])
+
+    def x(self):
+        return self.full[self.cols].copy()
+
+    def _full(self, x):
+        full = self.full.copy()
+        full[self.cols] = x
+        return full
+
+    def r(self, x):
+        return self.obj.evaluate(self._full(x))['data']
+
+    def J(self, x):
+        _, jac = self.obj.evaluate(self._full(x), want_J=True)
+        return jac['data'][:, self.cols]
+
+
 def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_mask, m2b_distance, nb, weights=None,
                  optimize_fingers=False, optimize_toes=False, betas_init=None, maxiter=100, stagei_lr=1e-3, exclude_vids=None,
-                 head_corr=None, stats=None, optimize_face=False, expr_start=None, n_expr=0):
+                 head_corr=None, stats=None, optimize_face=False, expr_start=None, n_expr=0,
+                 extra_initial_rigid_adjustment=False):
     """mosh_stagei's numeric core (chmosh.py:177-447).  `frames`: list of (latent marker ids, obs[n,3]) -- the `common_labels`
     selection of :199-206 already applied; `marker_vids`[M]; `marker_type_mask`: {type: bool[M]}; `m2b_distance`: {type: metres}.
     Returns betas, markers_latent, markers_latent_vids, per-frame pose / trans, per-term SSE of the last round."""
@@ -497,6 +527,10 @@ def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_m
         R, T = o2.rigid_landmark_transform(sim.T, obs.T)
         obj.pose[f, :3] = o2.rotmat_to_rotvec(R)
         obj.trans[f] = np.asarray(T).ravel()
+    if extra_initial_rigid_adjustment:   # chmosh.py:230-232
+        adj = _RigidAdjustment(obj)
+        xa = o2.minimize_dogleg(adj, adj.x(), e_3=.001, delta_0=0.5, maxiter=maxiter, stats=stats)
+        obj.set_x(adj._full(xa))
     anneal = list(W['stagei_wt_annealing'])
     res = None
     for tidx, a in enumerate(anneal):

@@ -128,13 +128,14 @@ def stagei_case(model_type='smplh', n_verts=2500, nb=6, M=30, F=6, seed=0, dof_p
 
 def stagei_oracle_extra(extra):
     """The oracle's spelling of the optional Stage-I arguments (n_expr / expr_start / face_ids -> optimize_face ...)."""
-    e = {k: v for k, v in extra.items() if k in ('exclude_vids', 'head_corr', 'betas_init')}
+    e = {k: v for k, v in extra.items() if k in ('exclude_vids', 'head_corr', 'betas_init', 'extra_initial_rigid_adjustment')}
     if extra.get('n_expr'):
         e.update(optimize_face=True, expr_start=extra['expr_start'], n_expr=extra['n_expr'])
     return e
 
 
-def stagei_kwargs(case, optimize_fingers=False, exclude_vids=None, head_corr=None, betas_init=None, n_expr=0, expr_start=0, face_ids=()):
+def stagei_kwargs(case, optimize_fingers=False, exclude_vids=None, head_corr=None, betas_init=None, n_expr=0, expr_start=0, face_ids=(),
+                  extra_initial_rigid_adjustment=False):
     """The arguments of capi.stagei_desc for a stagei_case (reference default weights)."""
     from oracle import stagei_oracle as s1
     m = case['m']
@@ -146,4 +147,4 @@ def stagei_kwargs(case, optimize_fingers=False, exclude_vids=None, head_corr=Non
     return dict(faces=case['faces'], marker_vids=case['vids'], m2b=np.ones(M) * case['m2b']['body'], wt_init=np.ones(M) * W['stagei_wt_init'],
                 frames=case['frames'], nb=case['nb'], weights=W, pose_ids=step1, body_ids=body if case['prior'] is not None else [],
                 finger_ids=finger, exclude_vids=exclude_vids, head_corr=head_corr, betas_init=betas_init, n_expr=n_expr,
-                expr_start=expr_start, face_ids=face_ids)
+                expr_start=expr_start, face_ids=face_ids, extra_initial_rigid_adjustment=extra_initial_rigid_adjustment)

@@ -67,10 +67,12 @@ def _variant(name):
         return helpers.stagei_case(), False, dict(head_corr=(np.array([3, 7, 11, 20]), rng.normal(0, 1, (3, 4))))
     if name == 'face':               # SMPL-X, fixed betas, jaw + per-frame expression coefficients free in the last two rounds
         return helpers.stagei_case('smplx', seed=3, nb=0), False, dict(n_expr=5, expr_start=4, face_ids=[66, 67, 68])
+    if name == 'extra_rigid':        # opt_settings.extra_initial_rigid_adjustment (chmosh.py:230-232)
+        return helpers.stagei_case('smplh', seed=8), False, dict(extra_initial_rigid_adjustment=True)
     raise KeyError(name)
 
 
-@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr', 'face'])
+@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr', 'face', 'extra_rigid'])
 def test_stagei_variants_match_oracle(name):
     from moshpp_amd import capi
     from oracle import stagei_oracle as s1
