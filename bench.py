@@ -503,13 +503,14 @@ def main():
                 leg = {'workload': f"12 frames, 53 markers, 10 betas, V={pb1['model']['v_template'].shape[0]}, {len(pb1['faces'])} triangles",
                        'unknowns': int(3 * 12 + 3 * 53 + 12 * len(kw1['pose_ids']) + 10), 'seconds': round(float(np.median(ts)), 4),
                        'dogleg_iterations': o1['iters']}
-                try:    # the arrow-structured solver (per-frame elimination + Schur complement), still opt-in: MOSHII_S1_SOLVER=schur
-                    os.environ['MOSHII_S1_SOLVER'] = 'schur'
+                leg['solver'] = 'arrow-structured (per-frame elimination + Schur complement on the shared block): the default'
+                try:    # the dense blocked Cholesky of the whole system beside it (MOSHII_S1_SOLVER=dense)
+                    os.environ['MOSHII_S1_SOLVER'] = 'dense'
                     capi.stagei_solve_host(dev1, pr1, **kw1)
-                    t1 = time.perf_counter(); o2 = capi.stagei_solve_host(dev1, pr1, **kw1); leg['seconds_schur_solver'] = round(time.perf_counter() - t1, 4)
+                    t1 = time.perf_counter(); o2 = capi.stagei_solve_host(dev1, pr1, **kw1); leg['seconds_dense_solver'] = round(time.perf_counter() - t1, 4)
                     leg['schur_vs_dense_max_abs_betas_diff'] = float(np.abs(o2['betas'] - o1['betas']).max())
                 except Exception as e:
-                    leg['seconds_schur_solver'] = repr(e)
+                    leg['seconds_dense_solver'] = repr(e)
                 finally:
                     os.environ.pop('MOSHII_S1_SOLVER', None)
                 if not args.no_cpu:     # the CPU side of this leg: the NumPy oracle on the same problem (checker + timing)

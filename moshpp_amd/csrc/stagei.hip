@@ -1180,7 +1180,7 @@ KERNEL k_s1_tri_solve(const double* L, int n, const double* dinv, const double* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Arrow structure of the Stage-I normal equations (experimental solver, MOSHII_S1_SOLVER=schur): a frame's unknowns (trans, pose,
+// Arrow structure of the Stage-I normal equations (the default solver; MOSHII_S1_SOLVER=dense switches it off): a frame's unknowns (trans, pose,
 // per-frame expressions) are coupled to other frames only through the shared block (latent markers, betas).  Per frame one
 // workgroup factors its diagonal block in LDS, inverts the factor in place and forms Y_f = L_f^{-1} A_fs, z_f = L_f^{-1} g_f; the
 // shared block is then solved on the Schur complement S = A_ss - sum_f Y_f^T Y_f (a few panels of the blocked Cholesky instead of
@@ -1409,9 +1409,12 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.r = pool.get<double>(R_max); p.Jm = pool.get<double>((size_t)R_max * ld_max);
     if (n_max > S1_NMAX) return fail(MOSHII_ERR_ARG, "stagei: more than 4096 unknowns");
     double* d_A = pool.get<double>((size_t)n_max * n_max); double* d_L = pool.get<double>((size_t)n_max * n_max);
-    // experimental arrow-structured solver (off unless MOSHII_S1_SOLVER=schur)
+    // arrow-structured solver (per-frame elimination + Schur complement on the shared block) unless MOSHII_S1_SOLVER=dense asks for
+    // the dense blocked Cholesky of the whole system.  Default since round 2: ten seeded problems (six SMPL-H seeds, fingers, SMPL-X,
+    // SMPL, fixed betas) take the same dogleg iterations with both and end within 1.3e-10 (profiles/r02_stagei_schur_seeds.txt), the
+    // arrow form 1.35-1.5x faster; sharded, it sums the 169 x 169 shared block instead of the 925 x 925 system.
     const char* solver_env = getenv("MOSHII_S1_SOLVER");
-    const bool want_schur = solver_env && strcmp(solver_env, "schur") == 0;
+    const bool want_schur = !(solver_env && strcmp(solver_env, "dense") == 0);
     const int fs_max = 3 + npid_max + (d.per_frame ? nb : 0), ns_max = 3 * M + (d.per_frame ? 0 : nb), nsp_max = (ns_max + 15) & ~15;
     int *d_fcols = nullptr, *d_scols = nullptr, *d_ones = nullptr;
     double *d_Linv = nullptr, *d_Y = nullptr, *d_z = nullptr, *d_T = nullptr, *d_S = nullptr, *d_h = nullptr, *d_ds = nullptr;

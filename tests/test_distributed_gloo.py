@@ -152,7 +152,7 @@ def test_stagei_frames_sharded_over_ranks_gloo(tmp_path):
     for world in (2, 3):
         d = tmp_path / f'w{world}'
         os.makedirs(d)
-        mp.spawn(_stagei_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        mp.spawn(_stagei_worker, args=(world, _free_port(), str(d), 'dense'), nprocs=world, join=True)
         outs = [np.load(d / f'rank{r}.npz') for r in range(world)]
         for o in outs:
             assert int(o['iters'][0]) == int(single['iters'][0])

@@ -303,12 +303,12 @@ def test_stagei_dogleg_keeps_descending_and_scipy_agrees_on_descent(case):
 
 @pytest.mark.parametrize('fingers', [False, True])
 def test_schur_solver_equals_dense_solver_in_emulation(case, fingers, monkeypatch):
-    """MOSHII_S1_SOLVER=schur (per-frame elimination + Schur complement on the shared block; off by default, not yet validated on a GPU)
-    takes the same Gauss-Newton steps as the dense blocked Cholesky."""
+    """The arrow-structured solver (per-frame elimination + Schur complement on the shared block; the default) takes the same
+    Gauss-Newton steps as the dense blocked Cholesky (MOSHII_S1_SOLVER=dense)."""
     from tests.emu import emu_stagei
     c = case if not fingers else helpers.stagei_case(finger_markers=True, M=36, seed=2)
     kw = helpers.stagei_kwargs(c, optimize_fingers=fingers)
-    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
+    monkeypatch.setenv('MOSHII_S1_SOLVER', 'dense')
     a = emu_stagei.solve(c['m'], c['prior'], **kw)
     monkeypatch.setenv('MOSHII_S1_SOLVER', 'schur')
     b = emu_stagei.solve(c['m'], c['prior'], **kw)
@@ -325,7 +325,7 @@ def test_schur_solver_variants_in_emulation(name, monkeypatch):
     from tests.test_gpu_stagei import _variant
     c, fingers, extra = _variant(name)
     kw = helpers.stagei_kwargs(c, optimize_fingers=fingers, **extra)
-    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
+    monkeypatch.setenv('MOSHII_S1_SOLVER', 'dense')
     a = emu_stagei.solve(c['m'], c['prior'], **kw)
     monkeypatch.setenv('MOSHII_S1_SOLVER', 'schur')
     b = emu_stagei.solve(c['m'], c['prior'], **kw)
