@@ -318,6 +318,11 @@ typedef struct moshii_stagei_desc {
     int32_t  extra_initial_rigid_adjustment;   /* cfg.opt_settings.extra_initial_rigid_adjustment (chmosh.py:230-232): before the annealing
                                                 * rounds, one dogleg over every frame's root orientation + translation on the unweighted
                                                 * marker residuals (e_3 = .001, delta_0 = .5, maxiter)                                   */
+    int32_t  allreduce_on_device;              /* sharded only: allreduce_sum is handed DEVICE pointers (the solver's own buffers: the
+                                                * Schur block / normal equations never visit the host; the few n-vectors and scalars are
+                                                * staged through a device scratch).  The stream has been synchronised when the callback
+                                                * runs and the callback returns after its collective has completed -- e.g. RCCL
+                                                * (torch.distributed backend "nccl") on a tensor wrapped around the pointer.            */
 } moshii_stagei_desc;
 
 int moshii_stagei_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL */, const moshii_stagei_desc* desc, void* stream);

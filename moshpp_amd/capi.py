@@ -426,7 +426,8 @@ class StageIDesc(C.Structure):
                 ('allreduce_sum', C.c_void_p), ('allreduce_user', C.c_void_p),
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
                 ('pose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('expression', C.c_void_p),
-                ('errs', C.c_void_p), ('iters', C.c_void_p), ('extra_initial_rigid_adjustment', C.c_int32)]
+                ('errs', C.c_void_p), ('iters', C.c_void_p), ('extra_initial_rigid_adjustment', C.c_int32),
+                ('allreduce_on_device', C.c_int32)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
@@ -435,7 +436,8 @@ STAGEI_ERR_NAMES = ('data', 'poseB', 'init', 'beta', 'surf', 'poseH', 'init_head
 
 def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_ids, body_ids, finger_ids=(), exclude_vids=None,
                 betas_init=None, maxiter=100, stagei_lr=1e-3, head_corr=None, wt_init_head=None, frame_range=None,
-                owns_shared_rows=True, allreduce=None, n_expr=0, expr_start=0, face_ids=(), extra_initial_rigid_adjustment=False):
+                owns_shared_rows=True, allreduce=None, n_expr=0, expr_start=0, face_ids=(), extra_initial_rigid_adjustment=False,
+                allreduce_on_device=False):
     """Fill a StageIDesc from NumPy data.  `frames`: list of (latent ids, obs[n,3]).  Returns (desc, outputs dict, keep-alive list)."""
     keep = []
 
@@ -472,10 +474,15 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
         d.head_ids = ptr(hid, np.int32); d.head_corr = ptr(Cm, np.float64); d.n_head, d.n_head_rows = Cm.shape[1], Cm.shape[0]
     d.wt_init_head = float(weights['stagei_wt_init'] if wt_init_head is None else wt_init_head)
     if allreduce is not None:
-        # allreduce(array) sums a 1-D float64 NumPy array in place over the ranks (moshpp_amd.parallel.make_allreduce)
+        # allreduce(array) sums a 1-D float64 NumPy array in place over the ranks (moshpp_amd.parallel.make_allreduce); with
+        # allreduce_on_device it is allreduce(device_pointer, count) instead (parallel.make_allreduce_device: RCCL on the solver's
+        # own buffers)
         def _cb(buf, count, _user):
             try:
-                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                if allreduce_on_device:
+                    allreduce(C.cast(buf, C.c_void_p).value, int(count))
+                else:
+                    allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
                 return 0
             except Exception:          # never let an exception cross the C boundary
                 import traceback
@@ -484,6 +491,7 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
         cb = ALLREDUCE_CB(_cb)
         keep.append(cb)
         d.sharded = 1
+        d.allreduce_on_device = 1 if allreduce_on_device else 0
         d.frame_lo, d.frame_hi = (0, F) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
         d.owns_shared_rows = 1 if owns_shared_rows else 0
         d.allreduce_sum = C.cast(cb, C.c_void_p)

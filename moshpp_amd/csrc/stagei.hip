@@ -1338,8 +1338,34 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     const int own_shared = shard ? (ds->owns_shared_rows ? 1 : 0) : 1;
     if (shard && (f_lo < 0 || f_hi > F || nown < 0)) return fail(MOSHII_ERR_ARG, "stagei: frame range of this rank out of bounds");
     int reduce_rc = 0;
-    auto reduce = [&](double* buf, long long count) { if (shard && ds->allreduce_sum(buf, count, ds->allreduce_user) != 0) reduce_rc = 1; };
     DevPool pool;
+    // sums over the ranks.  reduce(): a host vector; reduce_dev(): one of the solver's device buffers.  With allreduce_on_device the
+    // callback works on device memory (RCCL): device buffers are summed in place, host vectors are staged through d_red; without it
+    // the callback works on host memory (gloo, or nccl behind a copy) and device buffers take the round trip through `hred`.
+    const bool red_dev = shard && ds->allreduce_on_device;
+    double* d_red = nullptr; long long d_red_cap = 0;
+    std::vector<double> hred;
+    auto reduce = [&](double* buf, long long count) {
+        if (!shard || count <= 0) return;
+        if (!red_dev) { if (ds->allreduce_sum(buf, count, ds->allreduce_user) != 0) reduce_rc = 1; return; }
+        if (count > d_red_cap) { d_red = pool.get<double>((size_t)count); d_red_cap = count; if (!pool.ok) { reduce_rc = 1; return; } }
+        hipMemcpyAsync(d_red, buf, (size_t)count * 8, hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
+        if (ds->allreduce_sum(d_red, count, ds->allreduce_user) != 0) reduce_rc = 1;
+        hipMemcpyAsync(buf, d_red, (size_t)count * 8, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+    };
+    auto reduce_dev = [&](double* dbuf, long long count) {
+        if (!shard || count <= 0) return;
+        hipStreamSynchronize(st);
+        if (red_dev) { if (ds->allreduce_sum(dbuf, count, ds->allreduce_user) != 0) reduce_rc = 1; return; }
+        hred.resize((size_t)count);
+        hipMemcpyAsync(hred.data(), dbuf, (size_t)count * 8, hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        if (ds->allreduce_sum(hred.data(), count, ds->allreduce_user) != 0) reduce_rc = 1;
+        hipMemcpyAsync(dbuf, hred.data(), (size_t)count * 8, hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
+    };
     // ---- constants
     p.parents = mv->parents; p.vt = mv->vt; p.shapedirs = mv->shapedirs; p.posedirs = mv->posedirs; p.weights = mv->weights;
     p.Jreg = mv->Jreg; p.hands_mean = mv->hands_mean; p.comps = mv->comps; p.anc = mv->anc;
@@ -1604,15 +1630,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                 reduce(g.data(), n);
                 return;
             }
-            if (shard) {        // sum the ranks' normal equations: [A | g] through the host (a few MB per iteration)
-                hbuf.resize((size_t)n * n + n);
-                hipMemcpyAsync(hbuf.data(), d_A, (size_t)n * n * 8, hipMemcpyDeviceToHost, st);
-                hipMemcpyAsync(hbuf.data() + (size_t)n * n, d_g, (size_t)n * 8, hipMemcpyDeviceToHost, st);
-                hipStreamSynchronize(st);
-                reduce(hbuf.data(), (long long)n * n + n);
-                hipMemcpyAsync(d_A, hbuf.data(), (size_t)n * n * 8, hipMemcpyHostToDevice, st);
-                hipMemcpyAsync(d_g, hbuf.data() + (size_t)n * n, (size_t)n * 8, hipMemcpyHostToDevice, st);
-                hipStreamSynchronize(st);
+            if (shard) {        // sum the ranks' normal equations A and g (MOSHII_S1_SOLVER=dense: a few MB per iteration)
+                reduce_dev(d_A, (long long)n * n);
+                reduce_dev(d_g, n);
             }
             fetch(g, d_g, n);
         };
@@ -1657,15 +1677,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                         if (nown > 0) LAUNCH_LDS(k_s1_elim, nown, 1, S1_TPB, lds_bytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, p.status, f_lo);
                         { int nt = (ns + S1_T - 1) / S1_T; LAUNCH(k_s1_syrk, nt, nt, 256, st, d_Y, F * fs, ns, nsp, d_T, d_ones); }
                         LAUNCH(k_s1_schur_sub, (ns + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_A, n, d_g, d_scols, ns, d_T, d_Y, nsp, d_z, F * fs, d_S, d_h);
-                        if (shard) {
-                            hbuf.resize((size_t)ns * ns + ns);
-                            hipMemcpyAsync(hbuf.data(), d_S, (size_t)ns * ns * 8, hipMemcpyDeviceToHost, st);
-                            hipMemcpyAsync(hbuf.data() + (size_t)ns * ns, d_h, (size_t)ns * 8, hipMemcpyDeviceToHost, st);
-                            hipStreamSynchronize(st);
-                            reduce(hbuf.data(), (long long)ns * ns + ns);
-                            hipMemcpyAsync(d_S, hbuf.data(), (size_t)ns * ns * 8, hipMemcpyHostToDevice, st);
-                            hipMemcpyAsync(d_h, hbuf.data() + (size_t)ns * ns, (size_t)ns * 8, hipMemcpyHostToDevice, st);
-                            hipStreamSynchronize(st);
+                        if (shard) {   // the only matrix that crosses ranks: the Schur system of the shared block, in place on the device
+                            reduce_dev(d_S, (long long)ns * ns);
+                            reduce_dev(d_h, ns);
                         }
                         for (int j0 = 0; j0 < ns; j0 += S1_PB) {
                             const int jb = std::min(S1_PB, ns - j0), rem = ns - j0 - jb;

@@ -157,12 +157,40 @@ def make_allreduce(dist, device=None):
     return allreduce
 
 
-def stagei_solve_sharded(solve, n_frames, dist):
+def make_allreduce_device(dist):
+    """In-place sum of `count` float64 values at a DEVICE address over the ranks: torch.distributed (backend nccl = RCCL over xGMI)
+    on a tensor wrapped around the pointer -- nothing is copied, nothing visits the host (moshii_stagei_desc.allreduce_on_device).
+    With another backend (gloo on a CPU build, where "device" memory is host memory) the same address is wrapped as a NumPy view."""
+    import numpy as np
+    import torch
+
+    class _DevArray:                      # the CUDA array interface is how torch adopts foreign device memory (HIP included)
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {'shape': (count,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2}
+
+    def allreduce(ptr, count):
+        if dist.get_backend() == 'nccl':
+            t = torch.as_tensor(_DevArray(ptr, count), device='cuda')
+            dist.all_reduce(t)
+            torch.cuda.current_stream().synchronize()
+        else:
+            import ctypes
+            arr = np.ctypeslib.as_array((ctypes.c_double * count).from_address(ptr))
+            dist.all_reduce(torch.from_numpy(arr))
+    return allreduce
+
+
+def stagei_solve_sharded(solve, n_frames, dist, on_device=None):
     """One Stage-I problem over the ranks: rank r evaluates frames frame_ranges(n_frames, world)[r], rank 0 the shared rows; the
     normal equations are summed with an all-reduce per dogleg iteration (moshii_stagei_desc.sharded) and every rank returns the
-    same solution.  `solve(frame_range=..., owns_shared_rows=..., allreduce=...)` is capi.stagei_solve_host with the problem bound."""
+    same solution.  `solve(frame_range=..., owns_shared_rows=..., allreduce=...)` is capi.stagei_solve_host with the problem bound.
+    on_device (default: with the nccl backend): the reduction runs on the solver's device buffers (make_allreduce_device)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = frame_ranges(n_frames, world)[rank]
+    if on_device is None:                 # RCCL works on device memory: hand it the solver's buffers
+        on_device = dist.get_backend() == 'nccl'
+    if on_device:
+        return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce_device(dist), allreduce_on_device=True)
     return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce(dist))
 
 

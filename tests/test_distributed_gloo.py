@@ -4,6 +4,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -119,7 +120,7 @@ def test_three_rank_gloo_one_sequence_by_frame_ranges(tmp_path):
 
 
 # ---- Stage-I: frames of one subject over ranks, normal equations all-reduced (moshii_stagei_desc.sharded) --------------------
-def _stagei_worker(rank, world, port, outdir, solver=''):
+def _stagei_worker(rank, world, port, outdir, solver='', on_device=None):
     """The Stage-I solver with its frames split over `world` ranks and gloo as the all-reduce.  On this CPU-only box the kernels run
     through the g++ emulation build of stagei.hip (tests/emu): same source, same host code, same sharding logic as the GPU library."""
     sys.path.insert(0, ROOT)
@@ -134,7 +135,7 @@ def _stagei_worker(rank, world, port, outdir, solver=''):
         os.environ['MOSHII_S1_SOLVER'] = solver
     c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
     kw = helpers.stagei_kwargs(c)
-    out = stagei_solve_sharded(lambda **sh: emu_stagei.solve(c['m'], c['prior'], **kw, **sh), len(c['frames']), dist)
+    out = stagei_solve_sharded(lambda **sh: emu_stagei.solve(c['m'], c['prior'], **kw, **sh), len(c['frames']), dist, on_device=on_device)
     np.savez(os.path.join(outdir, f'rank{rank}.npz'), **{k: np.asarray(v) for k, v in out.items()})
     dist.barrier()
     dist.destroy_process_group()
@@ -185,6 +186,28 @@ def test_stagei_sharded_schur_allreduces_only_the_shared_block(tmp_path):
             assert np.abs(o['pose'] - single['pose']).max() < 1e-9 and np.abs(o['trans'] - single['trans']).max() < 1e-10
         for o in outs[1:]:
             assert np.array_equal(o['betas'], outs[0]['betas']) and np.array_equal(o['pose'], outs[0]['pose'])
+
+
+@pytest.mark.parametrize('solver', ['schur', 'dense'])
+def test_stagei_sharded_reduces_on_the_solvers_own_buffers(tmp_path, solver):
+    """moshii_stagei_desc.allreduce_on_device: the callback is handed the solver's device buffers (the Schur block / the normal
+    equations in place, vectors and scalars through a device scratch) -- what RCCL needs.  Here the "device" is the emulation's host
+    memory and gloo sums it through the same pointers: the protocol, the buffer sizes and the result are what the GPU path uses."""
+    sys.path.insert(0, ROOT)
+    from tests import helpers
+    from tests.emu import emu_stagei
+    emu_stagei.build_emu.build()
+    c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
+    single = emu_stagei.solve(c['m'], c['prior'], **helpers.stagei_kwargs(c))
+    d = tmp_path / 'w2'
+    os.makedirs(d)
+    mp.spawn(_stagei_worker, args=(2, _free_port(), str(d), solver, True), nprocs=2, join=True)
+    outs = [np.load(d / f'rank{r}.npz') for r in range(2)]
+    for o in outs:
+        assert int(o['iters'][0]) == int(single['iters'][0])
+        assert np.abs(o['betas'] - single['betas']).max() < 1e-9 and np.abs(o['markers_latent'] - single['markers_latent']).max() < 1e-10
+        assert np.abs(o['pose'] - single['pose']).max() < 1e-9 and np.abs(o['trans'] - single['trans']).max() < 1e-10
+    assert np.array_equal(outs[0]['betas'], outs[1]['betas']) and np.array_equal(outs[0]['pose'], outs[1]['pose'])
 
 
 # ---- bench.py's fixed (strong-scaling) job: which sequences a rank takes ---------------------------------------------------------

@@ -1,4 +1,5 @@
 """Stage-I on the GPU (moshii_stagei_solve) against the f64 oracle (oracle/stagei_oracle.py) on the same seeded problems."""
+import os
 import time
 
 import numpy as np
@@ -178,17 +179,55 @@ def test_mosh_stagei_then_stageii_end_to_end(tmp_path):
     assert rm < 5e-3        # the solved subject + layout reproduce the capture to a few millimetres
 
 
-def test_stagei_schur_solver_matches_dense(monkeypatch):
-    """MOSHII_S1_SOLVER=schur (per-frame elimination + Schur complement of the shared block; opt-in) takes the same Gauss-Newton steps
-    as the default dense blocked Cholesky."""
+@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5])
+def test_stagei_schur_solver_matches_dense(monkeypatch, seed):
+    """The default arrow-structured solver (per-frame elimination + Schur complement of the shared block) takes the same Gauss-Newton
+    steps as the dense blocked Cholesky (MOSHII_S1_SOLVER=dense), on five seeded problems (the bench-sized ones:
+    profiles/r02_stagei_schur_seeds.txt)."""
     from moshpp_amd import capi
-    c = helpers.stagei_case()
+    c = helpers.stagei_case(seed=seed)
     dev, pr = _device(c)
     kw = helpers.stagei_kwargs(c)
-    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
+    monkeypatch.setenv('MOSHII_S1_SOLVER', 'dense')
     a = capi.stagei_solve_host(dev, pr, **kw)
-    monkeypatch.setenv('MOSHII_S1_SOLVER', 'schur')
+    monkeypatch.delenv('MOSHII_S1_SOLVER', raising=False)
     b = capi.stagei_solve_host(dev, pr, **kw)
     assert a['iters'] == b['iters']
     assert np.abs(a['betas'] - b['betas']).max() < 1e-6 and np.abs(a['markers_latent'] - b['markers_latent']).max() < 1e-7
     assert np.abs(a['pose'] - b['pose']).max() < 1e-6
+
+
+def _nccl_stagei_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world)
+    from moshpp_amd import capi
+    from moshpp_amd.parallel import stagei_solve_sharded
+    c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
+    dev, pr = _device(c)
+    kw = helpers.stagei_kwargs(c)
+    single = capi.stagei_solve_host(dev, pr, **kw)
+    out = stagei_solve_sharded(lambda **sh: capi.stagei_solve_host(dev, pr, **kw, **sh), len(c['frames']), dist)   # nccl -> on device
+    np.savez(os.path.join(outdir, f'rank{rank}.npz'), iters=[out['iters'], single['iters']], betas=out['betas'], betas1=single['betas'],
+             ml=out['markers_latent'], ml1=single['markers_latent'], pose=out['pose'], pose1=single['pose'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stagei_allreduce_on_device_through_rccl(tmp_path):
+    """moshii_stagei_desc.allreduce_on_device with torch.distributed's nccl backend (= RCCL): the callback wraps the solver's device
+    buffers as tensors and all-reduces them in place.  One rank (this box has one GPU): the collective is the identity, what is
+    tested is that RCCL accepts the foreign pointers, the stream hand-over and that the sharded code path returns the plain result;
+    the multi-rank arithmetic is covered with gloo in tests/test_distributed_gloo.py."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_nccl_stagei_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    o = np.load(tmp_path / 'rank0.npz')
+    assert int(o['iters'][0]) == int(o['iters'][1])
+    assert np.abs(o['betas'] - o['betas1']).max() < 1e-9 and np.abs(o['ml'] - o['ml1']).max() < 1e-10
+    assert np.abs(o['pose'] - o['pose1']).max() < 1e-9
