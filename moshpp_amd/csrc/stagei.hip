@@ -899,6 +899,10 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
 // dense linear algebra on the row-major Jacobian Jm[R][ldn]
 // ---------------------------------------------------------------------------------------------------------------------------
 #define S1_T 32
+#define S1_PB 32     // panel width of the blocked Cholesky further down
+#ifdef S1_EMU
+#include "stagei_emu_twins.h"   // tests/emu (test infrastructure): sequential restatements of k_s1_syrk / k_s1_chol_diag / k_s1_chol_update tiles
+#endif
 // flags[row chunk][column block] = 1 iff that 32 x 32 block of J holds a non-zero (most do not: a frame's pose columns appear only
 // in that frame's rows)                                                    grid (ceil(R / 32), ceil(n / 32))
 KERNEL k_s1_nzflags(const double* Jm, int R, int n, int ldn, int* flags) {
@@ -918,11 +922,7 @@ KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A, const int* 
     int ti = BX, tj = BY;
     if (tj > ti) return;
 #ifdef S1_EMU
-    for (int i = ti * S1_T; i < std::min(n, (ti + 1) * S1_T); ++i) for (int j = tj * S1_T; j < std::min(n, (tj + 1) * S1_T); ++j) {
-        double s = 0;
-        for (int r = 0; r < R; ++r) s += Jm[(size_t)r * ldn + i] * Jm[(size_t)r * ldn + j];
-        A[(size_t)i * n + j] = s; A[(size_t)j * n + i] = s;
-    }
+    s1_emu_syrk_tile(Jm, R, n, ldn, A, ti, tj);   // (tests/emu/stagei_emu_twins.h)
 #else
     __shared__ double Si[S1_T][S1_T + 1], Sj[S1_T][S1_T + 1];
     int tx = TID % 16, ty = TID / 16;
@@ -984,52 +984,7 @@ KERNEL k_s1_gemv(const double* Mx, const double* x, int n, int ld, double* y) {
 // Blocked right-looking Cholesky of A[n][n] (lower), panel width S1_PB.  Per panel: k_s1_chol_diag (one workgroup: the diagonal
 // block is factored and inverted in LDS), k_s1_chol_trsm (every row below: its 32 entries times the inverse) and k_s1_chol_update (one 32 x 32 tile of the
 // trailing matrix per workgroup: A_ik -= L_i L_k^T).  status[1] = 1 if a pivot is not positive.
-#define S1_PB 32
-#ifdef S1_EMU
-KERNEL_LB(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status) {
-    SHARED double D[S1_PB][S1_PB + 1];
-    const int jb = (n - j0) < S1_PB ? (n - j0) : S1_PB;
-    for (int e = TID; e < S1_PB * S1_PB; e += NT) { int r = e / S1_PB, c = e % S1_PB; D[r][c] = (r < jb && c <= r) ? A[(size_t)(j0 + r) * n + j0 + c] : (r == c ? 1.0 : 0.0); }
-    SYNC();
-    for (int c = 0; c < jb; ++c) {
-        if (TID == 0) {
-            double v = D[c][c];
-            if (!(v > 0)) { status[1] = 1; v = 1.0; }
-            D[c][c] = sqrt(v);
-        }
-        SYNC();
-        const double ip = 1.0 / D[c][c];
-        for (int r = c + 1 + TID; r < jb; r += NT) D[r][c] *= ip;
-        SYNC();
-        // rank-1 update of the rows below: lane -> (row, column parity), no integer division
-        for (int t = TID; t < 2 * S1_PB; t += NT) {
-            const int r = t % S1_PB, h = t / S1_PB;
-            if (r > c && r < jb) {
-                const double lrc = D[r][c];
-                for (int k = c + 1 + h; k <= r; k += 2) D[r][k] -= lrc * D[k][c];
-            }
-        }
-        SYNC();
-    }
-    for (int e = TID; e < jb * jb; e += NT) { int r = e / jb, c = e % jb; if (c <= r) A[(size_t)(j0 + r) * n + j0 + c] = D[r][c]; }
-    // inverse of the (padded, unit-extended) 32 x 32 factor, one column per thread: L x = e_c
-    double* Di = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
-    SHARED double X[S1_PB][S1_PB + 1];
-    for (int c = TID; c < S1_PB; c += NT) {
-        for (int r = 0; r < S1_PB; ++r) {
-            double s0 = (r == c) ? 1.0 : 0.0, s1 = 0, s2 = 0, s3 = 0;        // four independent chains hide the LDS latency
-            int k = c;
-            for (; k + 3 < r; k += 4) {
-                s0 -= D[r][k] * X[k][c]; s1 -= D[r][k + 1] * X[k + 1][c]; s2 -= D[r][k + 2] * X[k + 2][c]; s3 -= D[r][k + 3] * X[k + 3][c];
-            }
-            for (; k < r; ++k) s0 -= D[r][k] * X[k][c];
-            X[r][c] = (r < c) ? 0.0 : ((s0 + s1) + (s2 + s3)) / D[r][r];
-        }
-        for (int r = 0; r < S1_PB; ++r) Di[r * S1_PB + c] = X[r][c];
-    }
-}
-
-#else
+#ifndef S1_EMU
 // GPU version: one wavefront, lane r keeps row r of the block in registers; pivots and columns travel by lane shuffles.
 // Then lane c solves L x = e_c for column c of the inverse with the factor's entries broadcast the same way.
 __global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status) {
@@ -1101,12 +1056,7 @@ KERNEL k_s1_chol_update(double* A, int n, int j0, int jb) {
     if (tj > ti) return;
     const int s0 = j0 + jb;
 #ifdef S1_EMU
-    for (int i = s0 + ti * S1_PB; i < std::min(n, s0 + (ti + 1) * S1_PB); ++i) for (int k = s0 + tj * S1_PB; k < std::min(n, s0 + (tj + 1) * S1_PB); ++k) {
-        if (k > i) continue;
-        double sacc = 0;
-        for (int c = 0; c < jb; ++c) sacc += A[(size_t)i * n + j0 + c] * A[(size_t)k * n + j0 + c];
-        A[(size_t)i * n + k] -= sacc;
-    }
+    s1_emu_chol_update_tile(A, n, j0, jb, ti, tj);   // (tests/emu/stagei_emu_twins.h)
 #else
     __shared__ double Li[S1_PB][S1_PB + 1], Lk[S1_PB][S1_PB + 1];
     for (int e = TID; e < S1_PB * S1_PB; e += NT) {

@@ -12,11 +12,11 @@ OUT = os.path.join(HERE, 'libstagei_emu.so')
 
 def build(force=False):
     deps = [SRC, os.path.join(ROOT, 'moshpp_amd', 'csrc', 'stagei_views.h'), os.path.join(ROOT, 'include', 'moshii.h'),
-            os.path.join(HERE, 'emu_entry.cpp')]
+            os.path.join(HERE, 'emu_entry.cpp'), os.path.join(HERE, 'stagei_emu_twins.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT
     subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-DS1_EMU', '-x', 'c++', SRC,
-                           os.path.join(HERE, 'emu_entry.cpp'), '-o', OUT, '-I', os.path.join(ROOT, 'include')])
+                           os.path.join(HERE, 'emu_entry.cpp'), '-o', OUT, '-I', os.path.join(ROOT, 'include'), '-I', HERE])
     return OUT
 
 
