@@ -1286,7 +1286,10 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     const bool shard = ds->sharded && ds->allreduce_sum;
     const int f_lo = shard ? ds->frame_lo : 0, f_hi = shard ? ds->frame_hi : F, nown = f_hi - f_lo;
     const int own_shared = shard ? (ds->owns_shared_rows ? 1 : 0) : 1;
-    if (shard && (f_lo < 0 || f_hi > F || nown < 0)) return fail(MOSHII_ERR_ARG, "stagei: frame range of this rank out of bounds");
+    // (a rank whose arguments are wrong must not just return: the others would wait in the first all-reduce.  Its verdict is summed
+    //  over the ranks below, as soon as reduce() exists, and every rank fails together.)
+    const bool bad_range = shard && (f_lo < 0 || f_hi > F || nown < 0);
+    const bool bad_owner = shard && own_shared && nown <= 0;   // the arrow solver back-substitutes the shared block on a rank with frames
     int reduce_rc = 0;
     DevPool pool;
     // sums over the ranks.  reduce(): a host vector; reduce_dev(): one of the solver's device buffers.  With allreduce_on_device the
@@ -1316,6 +1319,14 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         hipMemcpyAsync(dbuf, hred.data(), (size_t)count * 8, hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
     };
+    if (shard) {
+        double verdict[2] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0};
+        if (!red_dev) reduce(verdict, 2);      // (the device path needs the pool: its first allocation may fail on its own)
+        else { reduce(verdict, 2); if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed"); }
+        if (reduce_rc) return fail(MOSHII_ERR_ARG, "stagei: the all-reduce callback failed");
+        if (verdict[0] > 0) return fail(MOSHII_ERR_ARG, "stagei: frame range of a rank out of bounds");
+        if (verdict[1] > 0) return fail(MOSHII_ERR_ARG, "stagei: the rank that owns the shared rows must own at least one frame");
+    }
     // ---- constants
     p.parents = mv->parents; p.vt = mv->vt; p.shapedirs = mv->shapedirs; p.posedirs = mv->posedirs; p.weights = mv->weights;
     p.Jreg = mv->Jreg; p.hands_mean = mv->hands_mean; p.comps = mv->comps; p.anc = mv->anc;

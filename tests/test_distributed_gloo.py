@@ -188,6 +188,40 @@ def test_stagei_sharded_schur_allreduces_only_the_shared_block(tmp_path):
             assert np.array_equal(o['betas'], outs[0]['betas']) and np.array_equal(o['pose'], outs[0]['pose'])
 
 
+def _stagei_bad_owner_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from moshpp_amd.parallel import make_allreduce
+    from tests import helpers
+    from tests.emu import emu_stagei
+    c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
+    kw = helpers.stagei_kwargs(c)
+    rng = (0, 5) if rank == 0 else (5, 5)                       # rank 1 owns no frame, yet claims the shared rows
+    try:
+        emu_stagei.solve(c['m'], c['prior'], **kw, frame_range=rng, owns_shared_rows=(rank == 1), allreduce=make_allreduce(dist))
+        msg = 'no error'
+    except RuntimeError as e:
+        msg = str(e)
+    with open(os.path.join(outdir, f'rank{rank}.txt'), 'w') as f:
+        f.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stagei_sharded_argument_errors_fail_on_every_rank_together(tmp_path):
+    """A rank with bad sharding arguments does not return alone (the others would wait for it in the first all-reduce): the verdict is
+    summed over the ranks and all of them fail with the same message."""
+    sys.path.insert(0, ROOT)
+    from tests.emu import emu_stagei
+    emu_stagei.build_emu.build()
+    mp.spawn(_stagei_bad_owner_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(tmp_path / f'rank{r}.txt').read() for r in range(2)]
+    assert all('owns the shared rows must own at least one frame' in m for m in msgs), msgs
+
+
 @pytest.mark.parametrize('solver', ['schur', 'dense'])
 def test_stagei_sharded_reduces_on_the_solvers_own_buffers(tmp_path, solver):
     """moshii_stagei_desc.allreduce_on_device: the callback is handed the solver's device buffers (the Schur block / the normal
