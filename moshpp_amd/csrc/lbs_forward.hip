@@ -563,11 +563,14 @@ __global__ __launch_bounds__(256, (NT == 2) ? 2 : 1) void k_lbs_mfma(Lbs32Model 
                     const char* ar = Ab + ((r * 2) * 32 + (lane & 31)) * PA + (ks * 16 + 8 * h) * 2;
                     const half8 ah = *reinterpret_cast<const half8*>(ar);
                     const half8 al = *reinterpret_cast<const half8*>(ar + 32 * PA);
-                    // (each MFMA is followed by 8 idle issue slots: its four-register A / B operands come straight from LDS reads
-                    //  and hipcc reuses those registers at once -- a VALU write landing one instruction behind the MFMA was seen to
-                    //  corrupt the operand for the later-read part of the tile: wrong columns 16..31, timing dependent)
+                    // (Round 1 put 8 idle issue slots behind each of these MFMAs, blaming a wrong tile on the matrix pipe still reading
+                    //  its four-register A / B operands when a later write lands on them.  tools/mfma_war_hazard.hip tests exactly that
+                    //  on the hardware -- VALU writes and ds_read_b128 returns into the operand registers 0..16 slots after issue, with
+                    //  the pipe idle or busy: the product never changes, the hardware interlocks it -- and this variant passes its
+                    //  parity test 60 times in a row without the slots.  The slots are gone; whatever corrupted that tile once was not
+                    //  an operand hazard.  The issue order stays pinned.)
 #define LBS_MFMA_SAFE(A_, B_) { D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, D, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); \
-                                asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+                                }
                     LBS_MFMA_SAFE(ah, Wh[ks]) LBS_MFMA_SAFE(al, Wh[ks]) LBS_MFMA_SAFE(ah, Wl[ks])
 #undef LBS_MFMA_SAFE
                 }
