@@ -16,13 +16,13 @@ UNITS = [(os.path.join(CSRC, 'moshii_api.hip'), []), (os.path.join(CSRC, 'chain_
 
 def build(force=False, opt='-O1'):
     deps = [u for u, _ in UNITS] + [os.path.join(HERE, 'fakehip', 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'moshii_dev.h'),
-                                    os.path.join(ROOT, 'include', 'moshii.h')]
+                                    os.path.join(ROOT, 'include', 'moshii.h'), os.path.join(HERE, 'stagei_emu_twins.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT
     objs, procs = [], []
     for src, extra in UNITS:
         obj = os.path.join(HERE, '_' + os.path.basename(src).replace('.', '_') + '.o')
-        cmd = ['g++', opt, '-std=c++17', '-fPIC', '-w', '-I', os.path.join(HERE, 'fakehip'), '-I', os.path.join(ROOT, 'include'),
+        cmd = ['g++', opt, '-std=c++17', '-fPIC', '-w', '-I', os.path.join(HERE, 'fakehip'), '-I', os.path.join(ROOT, 'include'), '-I', HERE,
                '-x', 'c++', '-c', src, '-o', obj] + extra
         procs.append((src, subprocess.Popen(cmd)))
         objs.append(obj)
