@@ -344,13 +344,14 @@ def main():
         ach = fl_timed / kt / 1e12
         result['roofline'] = {
             'kernel': name, 'bound': 'valu_f64',
-            'bound_note': 'neither hbm nor mfma: float64 vector pipe, dependency/latency-bound small dense solves; HBM traffic ~44 KB/frame (PMC)',
+            'bound_note': 'neither hbm nor mfma: float64 vector pipe, instruction-count / latency-bound small dense solves with one wave per SIMD; memory side 44 KB/frame for a chain alone, ~410 KB/frame (mostly scratch write-back) with a chain on every CU (PMC)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
-            # PMC (separate FETCH_SIZE / WRITE_SIZE passes on a 120-frame chain, profiles/r01_chain_pmc.txt): 13.3 KB fetched
-            # (x2 wide-load correction of the guide -> 26.5 KB) + 17.7 KB written per solved frame, incl. the one-time read of
-            # the 1.76 MB attachment slice and the kernel's scratch write-backs; scaled to the frames the timed mode solves
-            'traffic': int(44.2e3 * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0))),
-            'traffic_source': 'rocprofv3 PMC per solved frame (profiles/r01_chain_pmc.txt) x frames solved in pass 1 of one step; not collected live',
+            # PMC (separate FETCH_SIZE / WRITE_SIZE passes over a seed-1000 bench step, profiles/r02_chain_pmc.txt): the pass-1 launch
+            # moves 2 x 1.27 GB fetched (wide-load correction of the guide) + 2.89 GB written for its 13 250 solved frames = 410 KB per
+            # solved frame (a chain alone on the GPU: 44 KB, profiles/r01_chain_pmc.txt), the repair launches < 0.1 GB; scaled to
+            # the frames pass 1 of the timed mode solves
+            'traffic': int(410e3 * (F + (rep['n_chunks'] * (rep['warmup'] + 5) if rep else 0))),
+            'traffic_source': 'rocprofv3 PMC per solved frame of the pass-1 launch (profiles/r02_chain_pmc.txt) x frames solved in pass 1 of one step; not collected live',
             'step_ms_hip_events': round(float(step_ms.mean()), 3), 'step_ms_hip_events_all': [round(float(x), 3) for x in step_ms],
             'algorithmic_gflop_per_step': round(fl_timed / args.steps / 1e9, 3),
             'note': 'algorithmic = the sequential chain\'s work on the recorded frames of the timed steps / their HIP-event time; warm-up and repair work is overhead',
