@@ -463,6 +463,14 @@ KERNEL k_s1_vjac(S1Dims d, S1Ptr p, int zbase) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // attachment: the three nearest canonical vertices of every latent marker (grid M); ties go to the lower vertex id
 // ---------------------------------------------------------------------------------------------------------------------------
+// (value, index) minimum over the workgroup, lowest index on ties, left in bd[0] / bi[0]: a halving tree (NT is a power of two; the
+// emulation build has NT = 1) -- thread 0 walking all 256 entries cost more than the search it finished
+#define S1_BLOCK_ARGMIN(bd, bi) \
+    for (int s_ = NT >> 1; s_ > 0; s_ >>= 1) { \
+        if (TID < s_ && (bd[TID + s_] < bd[TID] || (bd[TID + s_] == bd[TID] && bi[TID + s_] < bi[TID]))) { bd[TID] = bd[TID + s_]; bi[TID] = bi[TID + s_]; } \
+        SYNC(); \
+    }
+
 KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl_out) {
     SHARED double bd[256]; SHARED int bi[256];
     int m = BX;
@@ -478,10 +486,7 @@ KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl_out) {
         }
         bd[TID] = best; bi[TID] = besti;
         SYNC();
-        if (TID == 0) {
-            for (int t = 1; t < NT; ++t) if (bd[t] < bd[0] || (bd[t] == bd[0] && bi[t] < bi[0])) { bd[0] = bd[t]; bi[0] = bi[t]; }
-        }
-        SYNC();
+        S1_BLOCK_ARGMIN(bd, bi)
         found[pass] = bi[0];
         SYNC();
     }
@@ -522,8 +527,8 @@ KERNEL k_s1_surface(S1Dims d, S1Ptr p) {
     }
     bd[TID] = best; bi[TID] = besti;
     SYNC();
+    S1_BLOCK_ARGMIN(bd, bi)
     if (TID == 0) {
-        for (int t = 1; t < NT; ++t) if (bd[t] < bd[0] || (bd[t] == bd[0] && bi[t] < bi[0])) { bd[0] = bd[t]; bi[0] = bi[t]; }
         const int* fv = p.faces + 3 * bi[0];
         const double *A = p.can + 3 * fv[0], *B = p.can + 3 * fv[1], *C = p.can + 3 * fv[2];
         double q[3], diff[3], e1[3], e2[3], nrm[3], nh[3], nn[3];
