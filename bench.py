@@ -124,19 +124,33 @@ def main():
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result: whatever native libraries print on the way (gloo announces its connections on
+    # stdout when the hand-off group of the strong-scaling leg is created) goes to stderr
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the Stage-II path has no CPU fallback')
+    # development aid: MOSHII_BENCH_ONE_GPU=1 runs every rank on cuda:0 with gloo as the process group -- the N > 1 code paths
+    # (partition of the fixed job, sharded long sequence, max-over-ranks timing) on a one-GPU box; the numbers mean nothing
+    one_gpu = os.environ.get('MOSHII_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from moshpp_amd import capi, workload
     lib = capi.load()
@@ -161,14 +175,14 @@ def main():
     def allmax(x):
         if dist is None:
             return float(x)
-        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(x)], dtype=torch.float64, device='cpu' if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def allsum(x):
         if dist is None:
             return float(x)
-        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(x)], dtype=torch.float64, device='cpu' if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
@@ -527,6 +541,8 @@ def main():
                 result['stagei'] = leg
             except Exception as e:
                 result['stagei'] = {'error': repr(e)}
+        sys.stdout.flush()
+        os.dup2(_real_stdout, 1)           # the ONE line on stdout
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
