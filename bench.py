@@ -366,6 +366,11 @@ def main():
             # the frames pass 1 of the timed mode solves
             'traffic': int(410e3 * (F + (rep['n_chunks'] * (rep['warmup'] + 5) if rep else 0))),
             'traffic_source': 'rocprofv3 PMC per solved frame of the pass-1 launch (profiles/r02_chain_pmc.txt) x frames solved in pass 1 of one step; not collected live',
+            # the same fraction seed by seed (round 1 quoted seed 1000 alone: 0.0058; `frac` above is over all timed steps)
+            'frac_by_seed': {str(sd): round(sum(fl_seed[sd] for k in range(args.steps) if seeds[k % len(seeds)] == sd)
+                                            / max(sum(float(step_ms[k]) for k in range(args.steps) if seeds[k % len(seeds)] == sd) * 1e-3, 1e-12)
+                                            / 1e12 / F64_VALU_PEAK_TFLOPS, 6)
+                             for sd in seeds if any(seeds[k % len(seeds)] == sd for k in range(args.steps))},
             'step_ms_hip_events': round(float(step_ms.mean()), 3), 'step_ms_hip_events_all': [round(float(x), 3) for x in step_ms],
             'algorithmic_gflop_per_step': round(fl_timed / args.steps / 1e9, 3),
             'note': 'algorithmic = the sequential chain\'s work on the recorded frames of the timed steps / their HIP-event time; warm-up and repair work is overhead',
