@@ -2100,6 +2100,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)
     int rejoin_run = 0;            // consecutive frames that reproduced the stored trajectory (repair chains)
     int bi_next = 0;               // next chunk boundary of a run-through repair chain
+    bool fuse_on = false;          // a pass-1 chain that has carried on as the repair chain of the next chunk (ChainDev::fuse_F)
     bool at_pose = false;          // the forward state in LDS is that of (cx.pose, cx.trans) ...
     int fwd_set = 0;               // ... evaluated with the joint lists of this free set (run_phase)
     PROF_BEGIN();
@@ -2119,6 +2120,104 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if (tid == 4) so[2 * NP + 4] = first ? 1.0 : 0.0;
             if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) so[2 * NP + 5 + e] = cx.pose[NP + e];
         }
+        if (chp->fuse_flags != nullptr) {
+            const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
+            if (t == skip && chp->entry_state != nullptr) {   // the entry state is out: the left neighbour may compare with it
+                __syncthreads();
+                if (tid == 0) { __threadfence(); __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            if (chp->fuse_F == 0 && t == F) {                  // (a chain without a right neighbour: its rows are complete)
+                __syncthreads();
+                if (tid == 0) { __threadfence(); __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            if (chp->fuse_F > 0 && t == chp->fuse_F) {
+                // The end of this chain's own chunk (ChainDev::fuse_F): its end state ...
+                double* sf = chp->run_final - S;
+                for (int i = tid; i < NP; i += MOSHII_TPB) { sf[i] = cx.pose[i]; sf[NP + i] = cx.pose_prev[i]; }
+                if (tid < 3) sf[2 * NP + tid] = cx.trans[tid];
+                if (tid == 3) sf[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+                if (tid == 4) sf[2 * NP + 4] = first ? 1.0 : 0.0;
+                if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) sf[2 * NP + 5 + e] = cx.pose[NP + e];
+                __syncthreads();
+                if (tid == 0) { __threadfence(); __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }   // this chunk's rows are complete
+                // ... against the entry state the next chunk's chain recorded a chunk ago (it only has to be waited for when the
+                // chunks are not all resident -- then this chain gives up quickly and the host's rounds do the rest)
+                bool carry = false;
+                auto state_dev = [&](const double* en) {   // max |this chain's state - en| (flags must be equal; NaN counts as a miss)
+                    double dv = 0.0, nn = 0.0;
+                    for (int i = tid; i < NP; i += MOSHII_TPB) { dv = fmax(dv, fmax(fabs(cx.pose[i] - en[i]), fabs(cx.pose_prev[i] - en[NP + i]))); nn += en[i] + en[NP + i]; }
+                    if (tid < 3) dv = fmax(dv, fabs(cx.trans[tid] - en[2 * NP + tid]));
+                    if (tid == 3 && (has_prev ? 1.0 : 0.0) != en[2 * NP + 3]) dv = 1e300;
+                    if (tid == 4 && (first ? 1.0 : 0.0) != en[2 * NP + 4]) dv = 1e300;
+                    if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) dv = fmax(dv, fabs(cx.pose[NP + e] - en[2 * NP + 5 + e]));
+                    if (!(nn == nn)) dv = 1e300;
+                    return block_max(dv, cx.red);
+                };
+                auto wait_flag = [&](int* fl, int patience) {   // thread 0 waits (bounded) for *fl == 1; every thread gets the outcome
+                    if (tid == 0) {
+                        double go = 1.0;
+                        int spins = 0;
+                        while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                            __builtin_amdgcn_s_sleep(64);
+                            if (++spins > patience) { go = 0.0; break; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        cx.scal[S_BATON] = go;
+                    }
+                    __syncthreads();
+                    const bool ok_ = cx.scal[S_BATON] != 0.0;
+                    __syncthreads();
+                    return ok_;
+                };
+                if (chp->fuse_has_next && wait_flag(chp->fuse_flags + 3 * (chp->fuse_c + 1), 2000)) {
+                    const double dv = state_dev(chp->run_entry);
+                    carry = !(dv <= chp->fuse_tol);
+                    // A gross miss (another basin) is only this chain's to repair if its OWN chunk stands on firm ground: if the hand-off
+                    // INTO this chunk missed grossly too, this chain's state is the suspect one and the sweep that repairs this chunk
+                    // will deal with the next boundary when it gets there (the rule the host applies to its repair rounds).  The left
+                    // neighbour finishes at about the same time; if it has not, the chain goes ahead.
+                    if (carry && dv > 1e-6 && chp->fuse_has_prev && wait_flag(chp->fuse_flags + 3 * (chp->fuse_c - 1) + 1, 150)) {
+                        const double* lf = chp->run_final - 2 * S;   // end state of the left neighbour
+                        const double* oe = chp->run_entry - S;       // the entry state this chain recorded
+                        double dl = 0.0;
+                        for (int i = tid; i < 2 * NP + 3; i += MOSHII_TPB) dl = fmax(dl, fabs(lf[i] - oe[i]));
+                        dl = block_max(dl, cx.red);
+                        if (!(dl <= 1e-6)) carry = false;
+                    }
+                }
+                // The verdict (a chain will start at the next chunk, or not) is in place before it is declared final: a sweep
+                // arriving at the next boundary waits for that declaration before it looks.
+                if (carry && tid == 0) __hip_atomic_store(&chp->baton[2 * chp->chunk0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (tid == 0) { __threadfence(); __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+                if (!carry) { if (tid == 0 && chp->frames_done) *chp->frames_done = t; break; }
+                // Carry on as the repair chain of the next chunk -- once that chunk's own chain has written its last row (from here on
+                // its rows are compared against and replaced), unless an upstream sweep asks for this territory meanwhile.
+                if (tid == 0) {
+                    int* fl = chp->fuse_flags + 3 * (chp->fuse_c + 1) + 1;
+                    double go = 1.0;
+                    int spins = 0;
+                    while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                        if (__hip_atomic_load(&chp->baton[2 * chp->chunk0 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { go = 0.0; break; }
+                        __builtin_amdgcn_s_sleep(64);
+                        if (++spins > 20000) { go = 0.0; break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (go != 0.0 && chp->fuse_count != nullptr) atomicAdd(chp->fuse_count, 1);
+                    cx.scal[S_BATON] = go;
+                }
+                __syncthreads();
+                if (cx.scal[S_BATON] == 0.0) { if (tid == 0 && chp->frames_done) *chp->frames_done = t; break; }
+                double* s2 = chp->run_entry;   // the next chunk is entered with this state
+                for (int i = tid; i < NP; i += MOSHII_TPB) { s2[i] = cx.pose[i]; s2[NP + i] = cx.pose_prev[i]; }
+                if (tid < 3) s2[2 * NP + tid] = cx.trans[tid];
+                if (tid == 3) s2[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+                if (tid == 4) s2[2 * NP + 4] = first ? 1.0 : 0.0;
+                if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) s2[2 * NP + 5 + e] = cx.pose[NP + e];
+                fuse_on = true;
+            }
+        }
+        const bool sweeping = chp->fuse_F == 0 || fuse_on;   // (a pass-1 chain inside its own chunk is not a repair chain yet)
         if (bi_next < chp->nb && t == chp->bnd[bi_next] - chp->bnd_off) {   // a chunk boundary inside a run-through repair chain
             const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
             double* s1 = chp->run_final + (size_t)bi_next * S;          // end state of the chunk just left ...
@@ -2135,12 +2234,28 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
                 if (tid == 0) {
                     int* st = chp->baton + 2 * (chp->chunk0 + 1 + bi_next);
                     double go = 1.0;
-                    if (__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+                    if (chp->fuse_flags != nullptr) {   // (first launch) has the chain of the chunk just left decided whether it carries on?
+                        int* vd = chp->fuse_flags + 3 * (chp->chunk0 + bi_next) + 2;
+                        int spins = 0;
+                        while (__hip_atomic_load(vd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                            __builtin_amdgcn_s_sleep(64);
+                            if (++spins > 20000) { go = 0.0; break; }
+                        }
+                    }
+                    if (go != 0.0 && __hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1) {
                         __hip_atomic_store(st + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         int spins = 0;
                         while (__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 2) {
                             __builtin_amdgcn_s_sleep(64);
                             if (++spins > 20000) { go = 0.0; break; }   // (~2 us per look: some tens of milliseconds)
+                        }
+                    }
+                    if (go != 0.0 && chp->fuse_flags != nullptr) {   // ... and has that chunk's own pass-1 chain written its last row?
+                        int* od = chp->fuse_flags + 3 * (chp->chunk0 + 1 + bi_next) + 1;
+                        int spins = 0;
+                        while (__hip_atomic_load(od, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                            __builtin_amdgcn_s_sleep(64);
+                            if (++spins > 20000) { go = 0.0; break; }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows that chain stored are compared against below
@@ -2157,7 +2272,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) s2[2 * NP + 5 + e] = cx.pose[NP + e];
             ++bi_next;
         }
-        if (chp->baton != nullptr && t < F) {
+        if (chp->baton != nullptr && sweeping && t < F) {
             // Has an upstream chain of this round asked for this chain's territory (ChainDev::baton)?  Then stop here.  The rows
             // of the chunk this chain is in now switch from its own to older ones at frame t -- in the middle of a chunk, where
             // no hand-off check looks -- so the chunk's entry state is spoiled (an impossible flag value): unless the upstream
@@ -2257,7 +2372,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         }
         first = false;
         PROF_T(_tr);
-        if (record && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
+        if (record && sweeping && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
             // repair chains: has this chain re-joined the trajectory already stored for this chunk?
             double dv = 0.0;
             const double* po = chp->pose + (size_t)t * NP;

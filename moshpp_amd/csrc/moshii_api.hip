@@ -1038,7 +1038,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     }
     const int NC = (int)chunks.size();
     // ---- launch preparation + control block: [ChainDev x NC (pass 1)][ChainDev x NC (repairs)][pred x NC]
-    const size_t extra = 2 * sizeof(ChainDev) * NC + 6 * sizeof(int) * NC + 256;
+    const size_t extra = 2 * sizeof(ChainDev) * NC + 10 * sizeof(int) * NC + 256;
     LaunchCfg cfg;
     size_t ctl = 0;
     int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, NC, stream, extra, &cfg, &ctl);
@@ -1051,6 +1051,11 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     int* d_done = d_bnd + NC;   // frames processed per repair chain (diagnostics)
     int* d_baton = d_done + NC; // [2 NC] state / stop request per chunk (ChainDev::baton)
     int* d_abort_at = d_baton + 2 * NC;   // [NC] ChainDev::abort_at (kept across the rounds of this call)
+    int* d_fuse = d_abort_at + NC;        // [3 NC] ChainDev::fuse_flags, then [1] ChainDev::fuse_count
+    int* d_fuse_count = d_fuse + 3 * NC;
+    // Pass-1 chains check their own right-hand hand-off and carry on as the repair chain of the next chunk when it misses
+    // (ChainDev::fuse_F): possible when every chunk has a CU of its own for the whole launch, so that the flags they wait on are set.
+    const bool fuse = rejoin && NC <= n_cu && getenv("MOSHII_NO_FUSE") == nullptr;
     const bool trace = getenv("MOSHII_TRACE_REPAIR") != nullptr;
     // device buffers of this call: released on EVERY way out of the function (error returns included)
     struct Owned { std::vector<void*> p; ~Owned() { for (void* q : p) if (q) hipFree(q); } } owned;
@@ -1149,6 +1154,30 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     std::vector<ChainDev> cds(NC);
     std::vector<int> pred(NC);
     for (int c = 0; c < NC; ++c) { cds[c] = make_chain(chunks[c], chunks[c].a, c, false); pred[c] = chunks[c].pred; }
+    if (fuse)
+        for (int c = 0; c < NC; ++c) {
+            ChainDev& cd = cds[c];
+            cd.fuse_flags = d_fuse; cd.fuse_c = c; cd.fuse_count = d_fuse_count; cd.fuse_tol = tol;
+            cd.fuse_has_prev = (chunks[c].pred >= 0) ? 1 : 0;
+            const bool has_next = c + 1 < NC && chunks[c + 1].seq == chunks[c].seq;
+            if (!has_next) continue;
+            int cl = c + 1;   // one past the last chunk of the sequence
+            while (cl < NC && chunks[cl].seq == chunks[c].seq) ++cl;
+            // its own chunk as before, then -- if the hand-off to chunk c + 1 misses -- the repair chain that starts at chunk c + 1
+            cd.fuse_F = chunks[c].e - chunks[c].a;
+            cd.fuse_has_next = 1;
+            cd.F = chunks[cl - 1].e - chunks[c].a;
+            cd.final_state = d_final + (size_t)(cl - 1) * S;
+            cd.nb = cl - 1 - (c + 1);
+            cd.bnd = d_bnd + c + 2;
+            cd.bnd_off = chunks[c].a;
+            cd.run_final = d_final + (size_t)(c + 1) * S;
+            cd.run_entry = d_entry + (size_t)(c + 1) * S;
+            cd.baton = d_baton;
+            cd.abort_at = d_abort_at;
+            cd.chunk0 = c + 1;
+            cd.rejoin_tol = tol;
+        }
     HIP_TRY(hipMemcpyAsync(d_pass1, cds.data(), sizeof(ChainDev) * NC, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_pred, pred.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
     {
@@ -1156,6 +1185,8 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         for (int c = 0; c < NC; ++c) cstart[c] = chunks[c].s;
         HIP_TRY(hipMemcpyAsync(d_bnd, cstart.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(d_abort_at, 0xff, sizeof(int) * NC, stream));   // -1: no mark
+        HIP_TRY(hipMemsetAsync(d_baton, 0, sizeof(int) * 2 * NC, stream));
+        HIP_TRY(hipMemsetAsync(d_fuse, 0, sizeof(int) * (3 * NC + 1), stream));
         HIP_TRY(hipStreamSynchronize(stream));   // (cstart goes out of scope)
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1163,6 +1194,11 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     // ---- verify the hand-offs; re-solve (exactly, from the predecessor's final state) the chunks that fail
     std::vector<double> hdev(NC, 0.0);
     int n_repaired = 0, rounds = 0;
+    if (fuse) {   // chains that carried on inside the first launch count as repairs (they did a repair chain's work)
+        HIP_TRY(hipMemcpyAsync(&n_repaired, d_fuse_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (trace) fprintf(stderr, "[moshii] pass 1: %d chains carried on into the next chunk\n", n_repaired);
+    }
     double max_dev = 0.0;
     while (true) {
         hipLaunchKernelGGL(k_verify_chunks, dim3(NC), dim3(64), 0, stream, NC, NP, E, d_pred, d_entry, d_final, d_dev);

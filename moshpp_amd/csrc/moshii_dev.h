@@ -127,6 +127,21 @@ struct ChainDev {
     double* qscratch;           // device [2][K][nshape][3]: d(joint world position)/ds and q = dt - Rw . dJ/ds of the current point
     double rejoin_tol;          // > 0 (repair chains): stop once two consecutive solved frames reproduce the rows already in
                                 // `pose`/`trans` to this tolerance -- the rest of the chunk is then the continuation within tol
+    // Pass-1 chains that check their own right-hand hand-off (moshii_sequence_solve, all chunks resident): at frame fuse_F -- the
+    // end of its own chunk -- the chain compares its state with the entry state the NEXT chunk's chain recorded (fuse_tol).  Equal:
+    // it stops, as a pass-1 chain always did.  Different: it IS the sequential continuation the next chunk needs, so it carries on
+    // as the repair chain of that chunk (the fields above -- nb, bnd, run_*, baton, abort_at, chunk0, rejoin_tol -- are set up for a
+    // repair chain that starts at chunk fuse_c + 1) instead of leaving that to a later launch that waits for the slowest chunk of
+    // pass 1.  fuse_flags[3 c] = 1 once chunk c's chain has recorded its entry state, fuse_flags[3 c + 1] = 1 once it has written
+    // the last row of its own chunk (rows of a chunk are never compared against or overwritten before that), fuse_flags[3 c + 2] = 1
+    // once it has decided whether it carries on (a sweep arriving at chunk c + 1 waits for that before it looks for a chain there).
+    int fuse_F;                 // 0: plain chain
+    int fuse_c;                 // index of this chain's own chunk
+    int fuse_has_next;          // the next chunk belongs to the same sequence
+    int fuse_has_prev;          // so does the previous one
+    int* fuse_flags;            // device [3 x chunks of the launch]
+    int* fuse_count;            // device: number of chains that carried on
+    double fuse_tol;
 };
 
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).

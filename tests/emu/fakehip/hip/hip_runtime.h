@@ -79,6 +79,7 @@ template <class T> inline T __shfl_down(T v, int delta, int width = 64) {
     double got = hipemu::wave_exchange((double)v, (src < width && src < 64) ? src : lane);
     return (T)got;
 }
+inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }   // (blocks and fibers run one at a time)
 inline int __double2loint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b & 0xffffffff); }
 inline int __double2hiint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) { int64_t b = ((int64_t)hi << 32) | (uint32_t)lo; double v; memcpy(&v, &b, 8); return v; }

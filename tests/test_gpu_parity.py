@@ -288,29 +288,34 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
 
 
-@pytest.mark.parametrize('rejoin', [True, False])
-def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib, rejoin):
-    """Short warm-up + tight tolerance makes most hand-offs fail, in runs.  Two repair strategies must both end on the
-    sequential chain: run-through chains that stop where they re-join the stored rows (default), and one chain per chunk
-    over many rounds (MOSHII_NO_REJOIN=1) -- there a chunk repaired early must be repaired AGAIN when its predecessor is
-    re-solved in a later round (regression: a chunk once repaired used to be trusted for good, leaving it stitched to a
-    stale predecessor state)."""
+@pytest.mark.parametrize('strategy', ['carry_on', 'rounds', 'one_chunk_per_chain'])
+def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib, strategy):
+    """Short warm-up + tight tolerance makes most hand-offs fail, in runs.  Every repair strategy must end on the sequential
+    chain: pass-1 chains that check their own hand-off and carry on into the next chunk inside the first launch (default);
+    run-through repair chains launched by the host in rounds, stopping where they re-join the stored rows (MOSHII_NO_FUSE=1);
+    and one chain per chunk over many rounds (MOSHII_NO_REJOIN=1) -- there a chunk repaired early must be repaired AGAIN when
+    its predecessor is re-solved in a later round (regression: a chunk once repaired used to be trusted for good, leaving it
+    stitched to a stale predecessor state)."""
     from moshpp_amd import capi
     F = 480
     case = oracle_case('smplh', F=F, M=53, seed=71)
     dev = device_case(case)
     seq = _sequential(dev, case)
-    if not rejoin:
-        os.environ['MOSHII_NO_REJOIN'] = '1'
+    env = {'carry_on': None, 'rounds': 'MOSHII_NO_FUSE', 'one_chunk_per_chain': 'MOSHII_NO_REJOIN'}[strategy]
+    if env:
+        os.environ[env] = '1'
     try:
         outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
                                              [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
                                              num_chunks=40, warmup=6, verify_tol=1e-12)
     finally:
-        os.environ.pop('MOSHII_NO_REJOIN', None)
+        if env:
+            os.environ.pop(env, None)
     print('chunk report', rep)
-    assert rep['n_repaired'] >= 1 and rep['repair_rounds'] >= 1
-    if not rejoin:
+    assert rep['n_repaired'] >= 1
+    if strategy != 'carry_on':
+        assert rep['repair_rounds'] >= 1
+    if strategy == 'one_chunk_per_chain':
         assert rep['n_repaired'] >= 10 and rep['repair_rounds'] >= 2
     solved = seq['status'] == 0
     dp = np.abs(outs[0]['fullpose'] - seq['fullpose'])[solved].max(1)
