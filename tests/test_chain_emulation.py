@@ -46,7 +46,7 @@ def test_extended_kernel_matches_oracle_in_emulation():
 
 def test_chunked_sequence_solve_equals_sequential_chain_in_emulation():
     """moshii_sequence_solve (chunks, on-device hand-off verification, repairs) against moshii_chain_solve on the same sequence."""
-    case = oracle_case('smplh', F=40, M=53, seed=2)
+    case = oracle_case('smplh', F=32, M=53, seed=2)
     with emulated_libmoshii() as capi:
         dev = device_case(case)
         seq = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
@@ -63,7 +63,7 @@ def test_chunked_sequence_solve_carries_the_free_shape_block_in_emulation(kind, 
     """moshii_sequence_solve with n_shape > 0: the expression / DMPL coefficients travel in the chunk hand-off states (verified with
     pose and trans, re-solved from the predecessor's end state, rejoin test on the shape rows too) -- equal to the sequential chain."""
     from tests.helpers import shape_case
-    F = 30
+    F = 24
     case = shape_case(model_type, F=F, M=40, E=4, seed=9, kind=kind)
     with emulated_libmoshii() as capi:
         dev = device_case(case, optimize_face=(kind == 'expr'), shape_kind=kind)
@@ -101,7 +101,7 @@ def test_bench_call_path_in_emulation():
     CPU tensors standing in for HBM: chunked == sequential, struct layouts of the ctypes descriptors match the header."""
     from moshpp_amd import workload
     with emulated_libmoshii():
-        job = workload.make_job('smplh', n_frames=24, n_markers=53, seed=3)
+        job = workload.make_job('smplh', n_frames=20, n_markers=53, seed=3)
         solver = workload.make_solver(job)
         ds = workload.DeviceSequence(job, solver, 'cpu')
         rep = ds.solve_chunked(None, num_chunks=3, warmup=5, verify_tol=1e-9)
@@ -119,7 +119,7 @@ def test_bench_call_path_in_emulation():
 
 def test_sequence_solve_continues_a_chain_in_emulation():
     """moshii_sequence_desc.init_*: a chunked solve that starts from another chain's end state (how one sequence is spread over ranks)."""
-    case = oracle_case('smplh', F=36, M=53, seed=6)
+    case = oracle_case('smplh', F=30, M=53, seed=6)
     with emulated_libmoshii() as capi:
         dev = device_case(case)
         args = (dev['model'], dev['prior'], dev['opts'])
