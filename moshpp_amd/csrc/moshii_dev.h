@@ -188,20 +188,17 @@ struct Lbs32Model {
     float* weights;        // [K][Vp64]
     float* J;              // [K][3]
     int Vp;                // V padded to 64
-    // MFMA path
-    _Float16* Pfrag;       // [Vp128/32][3][KS][64 lanes][8]  posedirs * pscale, fragment-major
+    // MFMA path (lbs_forward.hip: k_lbs_prep + k_lbs_tile)
+    _Float16* Pfrag;       // [Vp128/16][3][KS][64 lanes][8]  posedirs * pscale, A-operand fragments of v_mfma_f32_16x16x32_f16
     float* vsh_pad;        // [Vp128][3]
-    int2* sjw;             // [Vp128][NW]  skinning influences per vertex: {byte offset of the joint's transform block, weight bits}
+    int2* sjw;             // [Vp128][NW]  skinning influences per vertex: {byte offset of the joint's block in a half tile's transforms, weight bits}
     int K, NW;
     float inv_pscale;
-    int Vp128, KP, KS;
+    int Vp128, KS;         // vertices padded to whole tiles; k-steps of 32 pose features
+    int KJ;                // joints padded to a multiple of 4 (a half tile's transforms are whole 1 KiB pieces)
     int mfma_ok;
-    // per-call scratch
-    // dense blend on the matrix pipe (k_lbs_mfma<.., .., KSJ > 0>): skinning weights and joint transforms as f16 hi + lo
-    _Float16* Wfrag;       // [Vp128/32][KJ/16][2 hi,lo][64 lanes][8]  weights, B-operand fragment-major
-    _Float16* Ah;          // per call: [ceil(Fcap/8)][3 rows][2 hi,lo][32 = 4 slot + comp][KJ]  joint transforms, A-operand order
-    int KJ;                // joints padded to a multiple of 16
-    float* Atr;            // [K][Fcap][12]
-    _Float16* featT;       // [Fcap][KP]
+    // per-call scratch, grown to the largest frame count seen (padded to whole 128-frame tiles)
+    float* Atr;            // [Fcap/16][KJ][16][12]  joint transforms, one contiguous block per 16 frames
+    _Float16* featF;       // [Fcap/128][KS][8][64 lanes][8]  pose features, B-operand fragments
     int Fcap;
 };

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE.  A stand-in for <hip/hip_runtime.h> that lets g++ compile moshpp_amd/csrc/{moshii_api,chain_solve}.hip UNCHANGED
+// TEST INFRASTRUCTURE.  A stand-in for <hip/hip_runtime.h> that lets g++ compile moshpp_amd/csrc/{moshii_api,chain_solve,lbs_forward}.hip UNCHANGED
 // and run their kernels on the CPU: every workgroup is executed as one fiber per thread (ucontext), with real barrier semantics for
 // __syncthreads / s_barrier and wave-level rendezvous for the cross-lane operations the kernels use (__shfl_down, readlane,
 // wave_barrier).  "Device" memory is host memory.  Used only by tests/emu (build_chain_emu.py); the product is built by hipcc.
@@ -26,6 +26,7 @@ void barrier();                                     // workgroup barrier
 void wave_sync();                                   // all lanes of the caller's wavefront rendezvous
 double wave_exchange(double v, int src_lane);       // value of `v` in lane `src_lane` of the caller's wavefront (all lanes call)
 void wave_gather2(double a, double b, const double** all);   // every lane's (a, b) of the caller's wavefront: all[0][2*lane], all[0][2*lane+1]
+const char* wave_allgather(const void* mine, int nbytes);    // every lane's `nbytes` (<= 64) of the caller's wavefront, lane-major, 64 bytes apart
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
 void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `extern __shared__`: guarded beyond the launch's lds_bytes
 }
@@ -39,7 +40,10 @@ void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `exter
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define MOSHII_AS_GLOBAL                             // (address spaces: nothing to say on the CPU)
-#define _Float16 unsigned short                      // only pointer members of Lbs32Model (the f16 LBS path is not emulated)
+#ifndef HIPEMU_NATIVE_F16                            // lbs_forward.hip is compiled by clang++ (ext_vector_type, _Float16 arithmetic)
+#define _Float16 unsigned short                      // g++ 11 translation units: only pointer members of Lbs32Model
+#endif
+#define address_space(n)                             // __attribute__((address_space(1))) -> __attribute__(())
 #define HIP_SYMBOL(x) (&(x))
 #define threadIdx (hipemu::cur().tid)
 #define blockIdx (hipemu::cur().bid)
@@ -119,6 +123,38 @@ inline hipemu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipem
     }
     return d;
 }
+#ifdef HIPEMU_NATIVE_F16
+// v_mfma_f32_16x16x32_f16: D = A (16x32) . B (32x16) + C; lane l supplies A[l & 15][8 (l >> 4) + e] and B[8 (l >> 4) + e][l & 15],
+// register r of lane l holds C/D[4 (l >> 4) + r][l & 15]; products are exact in f32, the sum is taken in double and rounded once
+typedef _Float16 hipemu_h8 __attribute__((ext_vector_type(8)));
+typedef float hipemu_f4 __attribute__((ext_vector_type(4)));
+inline hipemu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_h8 a, hipemu_h8 b, hipemu_f4 c, int, int, int) {
+    struct { hipemu_h8 a, b; } mine = {a, b};
+    const char* all = hipemu::wave_allgather(&mine, 32);
+    const int lane = (int)(hipemu::cur().tid.x % 64), n = lane & 15;
+    hipemu_f4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (lane >> 4) + r;
+        double acc = c[r];
+        for (int kq = 0; kq < 4; ++kq) {
+            const _Float16* pa = reinterpret_cast<const _Float16*>(all + (size_t)(m + 16 * kq) * 64);
+            const _Float16* pb = reinterpret_cast<const _Float16*>(all + (size_t)(n + 16 * kq) * 64 + 16);
+            for (int e = 0; e < 8; ++e) acc += (double)((float)pa[e] * (float)pb[e]);
+        }
+        d[r] = (float)acc;
+    }
+    return d;
+}
+// LDS-DMA: every lane's `size` bytes land at the wave-uniform LDS address + lane * size (immediately here; the kernels' waits and
+// barriers are what the device build relies on)
+inline void __builtin_amdgcn_global_load_lds(const void* g, void* l, int size, int offset, int) {
+    const int lane = (int)(hipemu::cur().tid.x % 64);
+    memcpy((char*)l + offset + (size_t)lane * size, (const char*)g + offset, size);
+}
+#endif
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
@@ -141,9 +177,14 @@ inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
 
 // dynamic LDS: the kernels declare `extern __shared__ double lds[]` (namespace moshii, chain_solve.hip) and `... sm[]` (unnamed
 // namespace, moshii_api.hip); with __shared__ = thread_local these block-scope externs need a definition in their namespace
-namespace moshii { inline alignas(16) thread_local double lds[160 * 1024 / 8]; }
+namespace moshii { alignas(16) inline thread_local double lds[160 * 1024 / 8]; }
 namespace { alignas(16) thread_local double sm[160 * 1024 / 8]; }
+#ifdef HIPEMU_NATIVE_F16   // lbs_forward.hip: `extern __shared__ char lds_raw[]` (export kernel), `... float smf[]` (plain kernel)
+namespace { alignas(16) thread_local char lds_raw[160 * 1024]; alignas(16) thread_local float smf[160 * 1024 / 4]; }
+namespace { struct HipEmuLdsRegistration { HipEmuLdsRegistration() { hipemu::register_dynamic_lds((double*)lds_raw, sizeof(lds_raw)); hipemu::register_dynamic_lds((double*)smf, sizeof(smf)); } } hipemu_lds_registration; }
+#else
 namespace { struct HipEmuLdsRegistration { HipEmuLdsRegistration() { hipemu::register_dynamic_lds(moshii::lds, sizeof(moshii::lds)); hipemu::register_dynamic_lds(sm, sizeof(sm)); } } hipemu_lds_registration; }
+#endif
 
 // the one inline-assembly statement of the chain kernel is a workgroup barrier ("s_waitcnt ...; s_barrier"):
 //   asm volatile("..." ::: "memory")  ->  hipemu::barrier()

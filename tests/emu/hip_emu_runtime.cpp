@@ -17,7 +17,8 @@ struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
 
 namespace {
 enum State { RUN, AT_BARRIER, AT_WAVE, DONE };
-struct Fiber { ucontext_t ctx; char* stack; State st; ThreadCtx tc; double xval; int xsrc; double xgot; double xval2; };
+struct Fiber { ucontext_t ctx; char* stack; State st; ThreadCtx tc; double xval; int xsrc; double xgot; double xval2; const void* xptr; int xbytes; };
+std::vector<char> gatherb_buf;   // [wave][64][64 bytes]: the operands of the wave's last byte gather
 std::vector<double> gather_buf;   // [wave][64][2]: the operands of the wave's last gather, filled when the wave is released
 const size_t STACK = 1 << 20;
 std::vector<Fiber> fibers;
@@ -63,6 +64,13 @@ void wave_gather2(double a, double b, const double** all) {
     *all = &gather_buf[(size_t)(cur_fiber / 64) * 128];
 }
 
+const char* wave_allgather(const void* mine, int nbytes) {
+    Fiber& f = fibers[cur_fiber];
+    f.xptr = mine; f.xbytes = nbytes; f.xsrc = -3;
+    yield_as(AT_WAVE);
+    return &gatherb_buf[(size_t)(cur_fiber / 64) * 4096];
+}
+
 static void segv_backtrace(int) {   // a kernel bug on the CPU: say where (symbols: build with -g, resolve with addr2line)
     void* frames[48];
     const int n = backtrace(frames, 48);
@@ -84,6 +92,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
         handler_installed = true;
     }
     gather_buf.assign((size_t)((nt + 63) / 64) * 128, 0.0);
+    gatherb_buf.assign((size_t)((nt + 63) / 64) * 4096, 0);
     if (const char* e = getenv("HIPEMU_LDS_SHRINK")) { size_t cut = (size_t)atol(e); lds_bytes = lds_bytes > cut ? lds_bytes - cut : 0; }   // (self-test of the guard)
     // everything beyond the dynamic LDS this launch asked for is a canary: a kernel writing past its allocation is caught below
     for (auto& a : lds_arrays()) for (size_t i = (lds_bytes + 7) / 8; i < a.bytes / 8; ++i) a.base[i] = CANARY;
@@ -116,6 +125,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
                     for (int t = lo; t < hi; ++t) if (fibers[t].st == AT_WAVE) {
                         int s = fibers[t].xsrc;
                         fibers[t].xgot = (s >= 0 && lo + s < hi) ? fibers[lo + s].xval : 0.0;
+                        if (s == -3) memcpy(&gatherb_buf[(size_t)w * 4096 + (size_t)(t - lo) * 64], fibers[t].xptr, (size_t)fibers[t].xbytes);
                         if (s == -2) { gather_buf[(size_t)w * 128 + 2 * (t - lo)] = fibers[t].xval; gather_buf[(size_t)w * 128 + 2 * (t - lo) + 1] = fibers[t].xval2; }
                     }
                     for (int t = lo; t < hi; ++t) if (fibers[t].st == AT_WAVE) fibers[t].st = RUN;

@@ -153,3 +153,27 @@ def test_underdetermined_frames_are_flagged_and_still_fit_their_data_in_emulatio
     assert np.abs(out['fullpose'][:2] - ref['fullpose'][:2]).max() > 0.1                                     # ... at different poses
     assert np.abs(out['fullpose'][2:] - ref['fullpose'][2:]).max() < 1e-2                                    # and meet again afterwards
     assert np.allclose(out['errs'][2:, 0], np.asarray(ref['errs']['data'])[2:], rtol=1e-2)
+
+
+@pytest.mark.parametrize('model_type,F', [('mano', 20), ('smpl', 17)])
+def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F):
+    """The f16-MFMA full-mesh export (lbs_forward.hip: k_lbs_prep + k_lbs_tile, compiled unchanged by the host clang++) against the
+    f64 kernel of the same emulated library: 16x16x32 MFMA fragment layouts, the feature ring, the lane = frame blend, the result
+    exchange and the partial vertex / frame tiles; the register-staged and the LDS-DMA form of the transform copy give the same bits."""
+    import os
+    M = {'mano': 24, 'smpl': 41}[model_type]
+    case = oracle_case(model_type, F=4, M=M, seed=61)
+    rng = np.random.default_rng(5)
+    pose = rng.normal(0, 0.35, (F, case['m']['NP']))
+    trans = rng.normal(0, 1, (F, 3))
+    with emulated_libmoshii():
+        dev = device_case(case)
+        ref = dev['model'].lbs_forward(pose, trans)
+        got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+        os.environ['MOSHII_LBS_NO_DMA'] = '1'
+        try:
+            got2 = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+        finally:
+            del os.environ['MOSHII_LBS_NO_DMA']
+    assert np.abs(got - ref).max() < 2e-5
+    np.testing.assert_array_equal(got, got2)

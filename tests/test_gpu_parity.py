@@ -262,9 +262,10 @@ def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
 
 @pytest.mark.parametrize('model_type,F', [('smplh', 300), ('smplx', 150), ('mano', 200), ('smpl', 129)])
 def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
-    """The MFMA export kernel (f16-operand correctives, sparse in-register blend, row stores through LDS) against the
-    reference-precision kernel and against the plain f32 kernel, on frame counts and vertex counts that leave
-    partial frame tiles and partial vertex tiles."""
+    """The MFMA export kernel (f16-operand correctives, lane = frame blend from LDS-DMA-staged transforms, row stores through
+    LDS) against the reference-precision kernel and against the plain f32 kernel, on frame counts and vertex counts that
+    leave partial frame tiles and partial vertex tiles; the register-staged form of the transform copy must give the same
+    bits as the DMA form (same arithmetic, different route into LDS); repeated calls must too (the DMA waits are counted)."""
     M = {'smplh': 53, 'smplx': 60, 'mano': 24, 'smpl': 41}[model_type]
     case = oracle_case(model_type, F=4, M=M, seed=61)
     dev = device_case(case)
@@ -283,6 +284,13 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     finally:
         del os.environ['MOSHII_LBS_PLAIN']
     assert np.abs(plain - ref).max() < 5e-6
+    for _ in range(3):
+        np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
+    os.environ['MOSHII_LBS_NO_DMA'] = '1'
+    try:
+        np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
+    finally:
+        del os.environ['MOSHII_LBS_NO_DMA']
     # linearity in trans (size-independent property): shifting trans shifts every vertex by the same amount
     got2 = dev['model'].lbs_forward(pose, trans + 0.25, dtype=np.float32)
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
@@ -422,28 +430,6 @@ def test_mosh_stageii_face_and_dynamics_end_to_end(gpu_lib, tmp_path, model_type
     assert np.abs(out['fullpose'] - ref['fullpose']).max() < 1e-6
     assert np.abs(out['trans'] - ref['trans']).max() < TIGHT
     np.testing.assert_allclose(errs['expr' if kind == 'expr' else 'dmpl'], ref['errs']['shape'], rtol=1e-5)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('model_type,F', [('smplh', 300), ('smplx', 150), ('mano', 200), ('smpl', 129)])
-def test_lbs_f32_dense_blend_variant_matches_f64(gpu_lib, model_type, F):
-    """MOSHII_LBS_BLEND=mfma: the skinning blend as a dense W x A product on the matrix pipe (f16 hi + lo operands) instead of
-    the LDS gather -- an opt-in variant (slower as of round 1); must agree with the f64 kernel for every
-    joint-count class (KJ = 64, 64, 16, 32), repeatedly (the path once showed a timing-dependent MFMA operand hazard)."""
-    M = {'smplh': 53, 'smplx': 60, 'mano': 24, 'smpl': 41}[model_type]
-    case = oracle_case(model_type, F=4, M=M, seed=61)
-    dev = device_case(case)
-    rng = np.random.default_rng(5)
-    pose = rng.normal(0, 0.35, (F, case['m']['NP']))
-    trans = rng.normal(0, 1, (F, 3))
-    ref = dev['model'].lbs_forward(pose, trans)
-    os.environ['MOSHII_LBS_BLEND'] = 'mfma'
-    try:
-        for _ in range(3):
-            got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
-            assert np.abs(got - ref).max() < 2e-5
-    finally:
-        del os.environ['MOSHII_LBS_BLEND']
 
 
 @pytest.mark.gpu
