@@ -124,6 +124,17 @@ def main():
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     # stdout carries exactly one line, the result: whatever native libraries print on the way (gloo announces its connections on
     # stdout when the hand-off group of the strong-scaling leg is created) goes to stderr
     sys.stdout.flush()
@@ -134,6 +145,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the Stage-II path has no CPU fallback')
     # development aid: MOSHII_BENCH_ONE_GPU=1 runs every rank on cuda:0 with gloo as the process group -- the N > 1 code paths
@@ -188,11 +201,12 @@ def main():
 
     # ---- the fixed many-sequence job (strong scaling; also the headline with --scaling strong)
     def strong_many():
-        """32 sequences dealt to the ranks; a rank solves its share in ONE moshii_sequence_solve call (copies of the seed-1000
-        sequence: sequences of one subject share the model / prior handles of a call).  Returns (frames solved here, seconds
-        here, sequences here)."""
+        """32 sequences dealt to the ranks; a rank solves its share in ONE moshii_sequence_solve call.  The sequences are 32
+        DISTINCT captures of the seed-1000 subject (sequences of one subject share the model / prior handles of a call):
+        capture i is motion seed 5000 + i through workload.make_capture -- the job waits for its hardest sequence, as a real
+        batch does.  Returns (frames solved here, seconds here, sequences here)."""
         share = strong_job_shares(args.strong_sequences, F, world)[rank]
-        copies = [workload.DeviceSequence(job, solver, dev) for _ in share]
+        copies = [workload.DeviceSequence(workload.make_capture(job, solver, 5000 + i), solver, dev) for i in share]
         stream = torch.cuda.current_stream().cuda_stream
         n_local = len(copies)
         per_seq_chunks = max(8, 256 // max(n_local, 1))      # keep every CU carrying a chain when a rank has few sequences
@@ -316,7 +330,7 @@ def main():
             t_job = allmax(t_here)
             n_job = allsum(n_here)
             strong['many_sequences'] = {
-                'workload': f'{args.strong_sequences} x {F}-frame SMPL-H sequences (BASELINE config 3 shape with body markers; copies of the seed-{seeds[0]} capture), dealt to the ranks by '
+                'workload': f'{args.strong_sequences} DISTINCT {F}-frame SMPL-H captures of the seed-{seeds[0]} subject (BASELINE config 3 shape with body markers; motion seeds 5000..), dealt to the ranks by '
                             'longest-processing-time (parallel.partition_units); no collective on the data path',
                 'frames': int(n_job), 'frames_per_s': round(n_job / t_job, 1), 'ms': round(t_job * 1e3, 2),
                 'sequences_on_rank0': n_local, 'rank0_idle_ms': round((t_job - t_here) * 1e3, 2)}

@@ -10,8 +10,11 @@ CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['moshii_api.hip', 'chain_solve.hip', 'lbs_forward.hip', 'stagei.hip']
 # per-file extras.  chain_solve: the iterative-ILP machine scheduler orders the long dependent f64 chains of the solver better than the
 # default (measured 393 vs 414 us/frame on the bench sequence, same results); the LBS kernel pins its own order with sched_barriers
-# and is 4 % slower with it, so it keeps the default.
-EXTRA_FLAGS = {'chain_solve.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
+# and keeps the default scheduler.
+EXTRA_FLAGS = {'chain_solve.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'],
+               # lbs_forward: the SLP vectoriser packs the blend's scalar FMAs into v_pk_fma_f32 and pays for it with a v_mov per operand
+               # pair (a third of the epilogue's VALU instructions were moves)
+               'lbs_forward.hip': ['-fno-slp-vectorize']}
 if os.environ.get('MOSHII_NO_ILP'):
     EXTRA_FLAGS = {}
 HEADERS = ['moshii_dev.h', 'stagei_views.h', os.path.join('..', '..', 'include', 'moshii.h')]

@@ -303,24 +303,31 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 }
 
 // ---- the export kernel ------------------------------------------------------------------------------------
-__host__ __device__ inline size_t lbs_lds_bytes(int KJ) { return (size_t)LBS_RING * LBS_CHUNK + 2 * (size_t)KJ * LBS_JBYTES + (size_t)16 * LBS_SXP * 4; }
+// LDS map (bytes; every offset is a compile-time constant so that the epilogue's reads carry their buffer base as an immediate):
+//   [0, 43008)        transforms of the half tile in work, buffer 0   (KJ <= 56 joints x 768 B)
+//   [43008, 86016)    buffer 1
+//   [86016, 110592)   feature ring, 3 slots of 8 KiB
+//   [110592, 135296)  result exchange, 16 rows of LBS_SXP dwords
+#define LBS_TLMAX 43008
+#define LBS_KJMAX 56
+#define LBS_OFF_RING (2 * LBS_TLMAX)
+#define LBS_OFF_SX (LBS_OFF_RING + LBS_RING * LBS_CHUNK)
+#define LBS_LDS_BYTES (LBS_OFF_SX + 16 * LBS_SXP * 4)
 
 #define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their "no wait" values): the LDS-DMA pieces are older than the N stores
-// issued behind them, which stay in flight
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their "no wait" values): the LDS-DMA pieces are older than the N memory
+// instructions issued behind them, which stay in flight
 #define LBS_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
 
-// NWT: skinning influences per vertex (padded).  DMA = 1: half-tile transforms by LDS-DMA, double buffered; DMA = 0: through
-// registers at the point of use (the fallback the DMA path is checked against).
-template <int NWT, int DMA>
+// NWT: skinning influences per vertex (padded).
+template <int NWT>
 __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, KJ = lm.KJ;
     const int tlb = KJ * LBS_JBYTES;                       // bytes of one half tile's transforms (a multiple of 1024)
-    char* ring = lds_raw;                                  // [LBS_RING][8 frame blocks][64 lanes][16 B]
-    char* Tl = lds_raw + LBS_RING * LBS_CHUNK;             // [2][KJ][16 frames][12] f32
-    char* Sx = Tl + 2 * tlb;                               // [16 frames][LBS_SXP] f32
+    char* ring = lds_raw + LBS_OFF_RING;                   // [LBS_RING][8 frame blocks][64 lanes][16 B]
+    char* Sx = lds_raw + LBS_OFF_SX;                       // [16 frames][LBS_SXP] f32
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...}, whose posedirs
     // fragments (356 KB each) stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side, so the
     // transforms and features of a few frame tiles are what else the L2 has to hold.
@@ -330,8 +337,32 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
     const float isc = lm.inv_pscale;
     const int q4 = lane >> 4, fl = lane & 15;
     const int sxw = fl * (LBS_SXP * 4) + (wv * 32 + 4 * q4) * 12;   // this lane's row / first vertex in the exchange (bytes)
+    // Four rotating A-fragment sets (k-steps t .. t+3), two B-fragment sets (t, t+1), two feature-chunk register pairs and the
+    // three ring slots are addressed by NAME (the loop is unrolled twelve-fold) so that no register copy ever waits on a load.
+    // Step t: barrier (chunk t + 1 is visible, every wave has left chunk t - 1), drop chunk t + 2 (fetched two steps ago) into
+    // the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs fragments of step t + 3, read the B fragments of step
+    // t + 1 from LDS, issue the 48 MFMAs of step t.  Global loads therefore have two (features) / three (posedirs) k-steps of
+    // ~800 cycles to arrive -- the first version gave the features one, and ran at the L2-miss latency per step.
+    half8 aS[4][2][3], bS[2][8];
+    f32x4 gS[2][2];
+#define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+        aS[SET][vg][c] = ap[((size_t)(vg * 3 + c) * KS + kk_) * 64]; }
+#define LBS_LD_G(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); gS[SET][0] = fp[(size_t)kk_ * 512]; gS[SET][1] = fp[(size_t)kk_ * 512 + 256]; }
+#define LBS_ST_G(SET, SLOT) { *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + tid * 16) = gS[SET][0]; *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + 4096 + tid * 16) = gS[SET][1]; }
+#define LBS_LD_B(SET, SLOT) { _Pragma("unroll") for (int t = 0; t < 8; ++t) bS[SET][t] = *reinterpret_cast<const half8*>(ring + (SLOT) * LBS_CHUNK + t * 1024 + lane * 16); }
+    // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use)
+#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+        acc[vg][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][vg][c], bS[BSET][t], acc[vg][t][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+#define LBS_STEP(S, KSTEP) { LBS_LDS_BARRIER(); LBS_ST_G((S) % 2, ((S) + 2) % 3) LBS_LD_G((S) % 2, (KSTEP) + 4) LBS_LD_A(((S) + 3) % 4, (KSTEP) + 3) LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) LBS_MMA((S) % 4, (S) % 2) }
+    // first global loads of a tile (feature chunks 0, 1 and the posedirs fragments of steps 0 .. 2).  (Issuing them for the NEXT
+    // tile ahead of the current tile's last row stores keeps 80 more registers live through the epilogue: hipcc then spills 230.)
+#define LBS_TILE_OF(IDX, FT, VT) const int FT = (IDX) / NVX, VT = xcd + 8 * ((IDX) - FT * NVX);
+#define LBS_HEAD_LOADS(IDX) { LBS_TILE_OF(IDX, ft_, vt_) \
+        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt_ * 8 + wv * 2) * 3 * KS) * 64 + lane; \
+        const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft_ * KS * 512 + tid; \
+        LBS_LD_G(0, 0) LBS_LD_G(1, 1) LBS_LD_A(0, 0) LBS_LD_A(1, 1) LBS_LD_A(2, 2) }
     for (int idx = slot; idx < ntiles; idx += nslots) {
-        const int ft = idx / NVX, vt = xcd + 8 * (idx - ft * NVX);
+        LBS_TILE_OF(idx, ft, vt)
         const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
         // ---- main loop: acc[vg][t][c] (16 vertices x 16 frames) += Pfrag(vg, c, ks) x featF(t, ks)
         f32x4 acc[2][8][3];
@@ -343,36 +374,43 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
                 for (int c = 0; c < 3; ++c) acc[vg][t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt * 8 + wv * 2) * 3 * KS) * 64 + lane;
         const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft * KS * 512 + tid;
-        // Three rotating A-fragment sets (k-steps t .. t+2), two B-fragment sets (t, t+1) and the ring slots are addressed by
-        // NAME (the loop is unrolled six-fold) so that no register copy ever waits on a load.  Step t: barrier (chunk t + 1 is
-        // visible, every wave has left chunk t - 1), drop chunk t + 2 into the slot chunk t - 1 occupied, fetch chunk t + 3 and
-        // the posedirs fragments of step t + 2 (one k-step = 48 MFMAs = ~800 cycles ahead each), read the B fragments of step
-        // t + 1 from LDS, and issue the 48 MFMAs of step t.
-        half8 aS[3][2][3], bS[2][8];
-        f32x4 g0, g1;
-#define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        aS[SET][vg][c] = ap[((size_t)(vg * 3 + c) * KS + kk_) * 64]; }
-#define LBS_LD_G(KSTEP) { const int kk_ = min((KSTEP), KS - 1); g0 = fp[(size_t)kk_ * 512]; g1 = fp[(size_t)kk_ * 512 + 256]; }
-#define LBS_ST_G(SLOT) { *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + tid * 16) = g0; *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + 4096 + tid * 16) = g1; }
-#define LBS_LD_B(SET, SLOT) { _Pragma("unroll") for (int t = 0; t < 8; ++t) bS[SET][t] = *reinterpret_cast<const half8*>(ring + (SLOT) * LBS_CHUNK + t * 1024 + lane * 16); }
-        // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use)
-#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        acc[vg][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][vg][c], bS[BSET][t], acc[vg][t][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
-#define LBS_STEP(S6, KSTEP) { LBS_LDS_BARRIER(); LBS_ST_G(((S6) + 2) % 3) LBS_LD_G((KSTEP) + 3) LBS_LD_A(((S6) + 2) % 3, (KSTEP) + 2) LBS_LD_B(((S6) + 1) % 2, ((S6) + 1) % 3) LBS_MMA((S6) % 3, (S6) % 2) }
-        LBS_LD_G(0) LBS_LD_A(0, 0) LBS_LD_A(1, 1)
-        LBS_ST_G(0)
-        LBS_LD_G(1)
-        LBS_ST_G(1)
-        LBS_LD_G(2)
+        LBS_HEAD_LOADS(idx)
+        LBS_ST_G(0, 0) LBS_ST_G(1, 1)
+        LBS_LD_G(0, 2) LBS_LD_G(1, 3)
         LBS_LDS_BARRIER();
         LBS_LD_B(0, 0)
         int ks = 0;
-        for (; ks + 6 <= KS; ks += 6) {
+        for (; ks + 12 <= KS; ks += 12) {
             LBS_STEP(0, ks) LBS_STEP(1, ks + 1) LBS_STEP(2, ks + 2) LBS_STEP(3, ks + 3) LBS_STEP(4, ks + 4) LBS_STEP(5, ks + 5)
+            LBS_STEP(6, ks + 6) LBS_STEP(7, ks + 7) LBS_STEP(8, ks + 8) LBS_STEP(9, ks + 9) LBS_STEP(10, ks + 10) LBS_STEP(11, ks + 11)
         }
+        if (ks < KS) { LBS_STEP(0, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(1, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(2, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(3, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(4, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(5, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(6, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(7, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(8, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(9, ks) ++ks; }
+        if (ks < KS) { LBS_STEP(10, ks) ++ks; }
+        // ---- epilogue: eight half tiles of 16 frames.  Per half tile: transforms in LDS (barrier), every lane blends and
+        // applies its 8 (vertex, frame) pairs and drops the results into the exchange (barrier), the workgroup writes 16 whole
+        // tile rows.  The transforms of half tile h + 1 are on their way (LDS-DMA) while h is worked on.
+        const char* asrc = reinterpret_cast<const char*>(lm.Atr) + (size_t)ft * 8 * tlb;
+        const int npieces = tlb >> 10;
+        auto stage_dma = [&](int h, int buf) {
+            const char* s = asrc + (size_t)h * tlb + lane * 16;
+            char* d = lds_raw + buf * LBS_TLMAX;
+            for (int p = wv; p < npieces; p += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)p * 1024),
+                                                 (__attribute__((address_space(3))) void*)(d + p * 1024), 16, 0, 0);
+        };
+        stage_dma(0, 0);
         // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + 32 wv + 16 vg + 4 (lane / 16) + r.
-        // Their rest positions, joint addresses and weights (88 registers) are fetched HERE, behind the unrolled part of the k-loop:
-        // fetched at the top of the tile they are live across the whole loop and hipcc parks them in scratch.
+        // Their rest positions, joint addresses and weights (88 registers) are fetched behind the k-loop (fetched before it they
+        // are live across it, on top of its 176 operand registers, and hipcc parks them in scratch / AGPRs).
         float vs[2][4][3], ww[2][4][NWT];
         int ja[2][4][NWT];
 #pragma unroll
@@ -389,17 +427,6 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
                     ww[vg][r][i] = __int_as_float(jw.y);
                 }
             }
-        if (ks < KS) { LBS_STEP(0, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(1, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(2, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(3, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(4, ks) ++ks; }
-#undef LBS_LD_A
-#undef LBS_LD_G
-#undef LBS_ST_G
-#undef LBS_LD_B
-#undef LBS_MMA
-#undef LBS_STEP
         // (MOSHII_LBS_STOP=1|2: phase timing by truncation -- 1: stop after the k-loop, 2: everything but the global stores)
         if (dbg & 1) {
             float sacc = 0.0f;
@@ -410,67 +437,42 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
 #pragma unroll
                     for (int c = 0; c < 3; ++c) sacc += acc[vg][t][c][0] + acc[vg][t][c][1] + acc[vg][t][c][2] + acc[vg][t][c][3];
             if (sacc == 123.456f) out[0] = vs[0][0][0] + ww[1][3][0] + (float)ja[0][2][1];
+            LBS_WAIT_VM(0);
             LBS_LDS_BARRIER();
             continue;
         }
-        // ---- epilogue: eight half tiles of 16 frames.  Per half tile: transforms in LDS (barrier), every lane blends and
-        // applies its 8 (vertex, frame) pairs and drops the results into the exchange (barrier), the workgroup writes 16 whole
-        // tile rows.  The transforms of half tile h + 1 are on their way (DMA) while h is worked on.
-        const char* asrc = reinterpret_cast<const char*>(lm.Atr) + (size_t)ft * 8 * tlb;
-        const int npieces = tlb >> 10;
-        auto stage_dma = [&](int h, int buf) {
-            const char* s = asrc + (size_t)h * tlb + lane * 16;
-            char* d = Tl + buf * tlb;
-            for (int p = wv; p < npieces; p += 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)p * 1024),
-                                                 (__attribute__((address_space(3))) void*)(d + p * 1024), 16, 0, 0);
-        };
-        auto stage_regs = [&](int h, int buf) {
-            const f32x4* s = reinterpret_cast<const f32x4*>(asrc + (size_t)h * tlb);
-            f32x4* d = reinterpret_cast<f32x4*>(Tl + buf * tlb);
-            const int n16 = tlb >> 4;
-            for (int c = tid; c < n16; c += 256) d[c] = s[c];
-        };
         const int nfl = min(LBS_TV, V - v0) * 3;   // valid floats of a tile row
         // interior tile: every wave issues exactly eight store instructions per half tile, which is what the counted wait below relies on
         const bool full = (f0 + LBS_TF <= F) && (nfl == LBS_TV * 3);
-        if (DMA) stage_dma(0, 0);
+        // two (vertex, frame) items in flight per lane: the 12 transform reads of item k + 1 are issued before item k is computed
+        f32x4 A0[2][NWT], A1[2][NWT], A2[2][NWT];
+#define LBS_GATHER(SET, VG, R, BOFF) { _Pragma("unroll") for (int i = 0; i < NWT; ++i) { const char* tp = lds_raw + (BOFF) + ja[VG][R][i]; \
+        A0[SET][i] = *reinterpret_cast<const f32x4*>(tp); A1[SET][i] = *reinterpret_cast<const f32x4*>(tp + 16); A2[SET][i] = *reinterpret_cast<const f32x4*>(tp + 32); } }
+#define LBS_APPLY(SET, VG, R, H) { \
+        const float px = fmaf(isc, acc[VG][H][0][R], vs[VG][R][0]), py = fmaf(isc, acc[VG][H][1][R], vs[VG][R][1]), pz = fmaf(isc, acc[VG][H][2][R], vs[VG][R][2]); \
+        float ox = 0.0f, oy = 0.0f, oz = 0.0f; \
+        _Pragma("unroll") for (int i = 0; i < NWT; ++i) { const float w = ww[VG][R][i]; \
+            ox = fmaf(w, fmaf(A0[SET][i].x, px, fmaf(A0[SET][i].y, py, fmaf(A0[SET][i].z, pz, A0[SET][i].w))), ox); \
+            oy = fmaf(w, fmaf(A1[SET][i].x, px, fmaf(A1[SET][i].y, py, fmaf(A1[SET][i].z, pz, A1[SET][i].w))), oy); \
+            oz = fmaf(w, fmaf(A2[SET][i].x, px, fmaf(A2[SET][i].y, py, fmaf(A2[SET][i].z, pz, A2[SET][i].w))), oz); } \
+        float* so = reinterpret_cast<float*>(Sx + sxw + ((VG) * 16 + (R)) * 12); so[0] = ox; so[1] = oy; so[2] = oz; }
+#define LBS_ITEM(K, H, BOFF) { if ((K) < 7) LBS_GATHER(((K) + 1) & 1, ((K) + 1) >> 2, ((K) + 1) & 3, BOFF) \
+        LBS_APPLY((K) & 1, (K) >> 2, (K) & 3, H) }
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
-            const int buf = DMA ? (h & 1) : 0;
-            if (DMA) {
-                if (h > 0 && full && dbg == 0) LBS_WAIT_VM(8);   // the eight row stores of half tile h - 1 are younger than the DMA pieces: they stay in flight
-                else LBS_WAIT_VM(0);
-            } else {
-                LBS_LDS_BARRIER();   // every wave is done with the previous half tile's transforms and rows
-                stage_regs(h, 0);
-            }
+            if (h > 0 && full && dbg == 0) LBS_WAIT_VM(8);   // the eight row stores of half tile h - 1 are younger than the DMA pieces: they stay in flight
+            else LBS_WAIT_VM(0);
             LBS_LDS_BARRIER();
-            if (DMA && h + 1 < 8) stage_dma(h + 1, (h + 1) & 1);
-            const char* Tb = Tl + buf * tlb;
-#pragma unroll
-            for (int vg = 0; vg < 2; ++vg)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float px = vs[vg][r][0] + isc * acc[vg][h][0][r], py = vs[vg][r][1] + isc * acc[vg][h][1][r],
-                                pz = vs[vg][r][2] + isc * acc[vg][h][2][r];
-                    f32x4 A0[NWT], A1[NWT], A2[NWT];
-#pragma unroll
-                    for (int i = 0; i < NWT; ++i) {
-                        const f32x4* tp = reinterpret_cast<const f32x4*>(Tb + ja[vg][r][i]);
-                        A0[i] = tp[0]; A1[i] = tp[1]; A2[i] = tp[2];
-                    }
-                    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < NWT; ++i) {
-                        const float w = ww[vg][r][i];
-                        ox += w * (A0[i].x * px + A0[i].y * py + A0[i].z * pz + A0[i].w);
-                        oy += w * (A1[i].x * px + A1[i].y * py + A1[i].z * pz + A1[i].w);
-                        oz += w * (A2[i].x * px + A2[i].y * py + A2[i].z * pz + A2[i].w);
-                    }
-                    float* so = reinterpret_cast<float*>(Sx + sxw + (vg * 16 + r) * 12);
-                    so[0] = ox; so[1] = oy; so[2] = oz;
-                }
+            if (h + 1 < 8) stage_dma(h + 1, (h + 1) & 1);
+            if (h & 1) {
+                LBS_GATHER(0, 0, 0, LBS_TLMAX)
+                LBS_ITEM(0, h, LBS_TLMAX) LBS_ITEM(1, h, LBS_TLMAX) LBS_ITEM(2, h, LBS_TLMAX) LBS_ITEM(3, h, LBS_TLMAX)
+                LBS_ITEM(4, h, LBS_TLMAX) LBS_ITEM(5, h, LBS_TLMAX) LBS_ITEM(6, h, LBS_TLMAX) LBS_ITEM(7, h, LBS_TLMAX)
+            } else {
+                LBS_GATHER(0, 0, 0, 0)
+                LBS_ITEM(0, h, 0) LBS_ITEM(1, h, 0) LBS_ITEM(2, h, 0) LBS_ITEM(3, h, 0)
+                LBS_ITEM(4, h, 0) LBS_ITEM(5, h, 0) LBS_ITEM(6, h, 0) LBS_ITEM(7, h, 0)
+            }
             LBS_LDS_BARRIER();   // the exchange is complete
             // wave w writes rows w, w + 4, w + 8, w + 12 of the half tile: 96 16-byte chunks per row = one full wave store + one
             // half-wave store (all addressing is a wave-uniform base + 16 lane)
@@ -497,8 +499,17 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
                 }
             }
         }
-        LBS_LDS_BARRIER();   // the last rows are out of the exchange (the next tile's prologue leaves it alone, the next half tile 0 does not)
+        LBS_LDS_BARRIER();   // the last rows are out of the exchange before the next tile's first half tile writes it
     }
+#undef LBS_LD_A
+#undef LBS_LD_G
+#undef LBS_ST_G
+#undef LBS_LD_B
+#undef LBS_MMA
+#undef LBS_STEP
+#undef LBS_GATHER
+#undef LBS_APPLY
+#undef LBS_ITEM
 }
 
 }  // namespace
@@ -578,7 +589,7 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
             if (hipMalloc((void**)&lm->sjw, sjw.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
             hipMemcpy(lm->sjw, sjw.data(), sjw.size() * sizeof(int), hipMemcpyHostToDevice);
             hipLaunchKernelGGL(k_pack_pfrag, dim3(4096), dim3(256), 0, 0, V, nfeat, KS, nvg, pscale, moshii_internal_posedirs(m), lm->Pfrag);
-            lm->mfma_ok = lbs_lds_bytes(lm->KJ) <= 160 * 1024;
+            lm->mfma_ok = lm->KJ <= LBS_KJMAX;
         }
     }
     hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->v_shaped);
@@ -627,13 +638,11 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid);
     // one workgroup per CU (the kernel takes the whole register file and most of the LDS), 8 XCDs
     const int nslots = std::max(1, std::min((ncu > 0 ? ncu : 256) / 8, ((NVT + 7) / 8) * NFT));
-    const size_t lds = lbs_lds_bytes(lm.KJ);
-    const bool dma = getenv("MOSHII_LBS_NO_DMA") == nullptr;   // (development switch: transforms staged through registers)
-    auto kern = (lm.NW == 4) ? (dma ? k_lbs_tile<4, 1> : k_lbs_tile<4, 0>) : (dma ? k_lbs_tile<8, 1> : k_lbs_tile<8, 0>);
+    auto kern = (lm.NW == 4) ? k_lbs_tile<4> : k_lbs_tile<8>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 3;   // (development: phase timing by truncation; incomplete output)
-    hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(256), lds, stream, lm, md->V, F, NVT, NFT, verts, dbg);
+    hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(256), LBS_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, dbg);
     return hipGetLastError();
 }

@@ -442,8 +442,9 @@ def synth_motion(NP, body_dof, n_frames, seed=0, fps=120.0, amp_body=0.45, amp_h
 
 def make_sequence(model_type='smplh', n_frames=120, n_markers=53, seed=0, noise=0.0005, dropout=0.02,
                   n_gaps=2, num_betas=16, dof_per_hand=24, use_hands_mean=True, body_only_markers=True,
-                  empty_frames=(), dd=None):
-    """Everything one Stage-II call needs, generated from seeds:
+                  empty_frames=(), dd=None, motion_seed=None):
+    """Everything one Stage-II call needs, generated from seeds (`motion_seed`: another capture -- motion, noise, dropouts -- of
+    the SAME subject, i.e. the same model, betas, priors and marker placement as `seed` gives):
     model pickle dict, hand prior, GMM prior, betas, latent markers + labels, marker_meta,
     mocap markers[F,N,3] in metres (NaN where dropped) + labels, and the ground truth."""
     rng = np.random.default_rng(seed + 5)
@@ -485,7 +486,9 @@ def make_sequence(model_type='smplh', n_frames=120, n_markers=53, seed=0, noise=
     markers_latent = can_body[vids] + dd['_outward'][vids] * 0.0095
     labels = [f'MK{idx:02d}' for idx in range(n_markers)]
     closest, coef = attach_markers(can_body, markers_latent)
-    pose_gt, trans_gt = synth_motion(NP, body_dof, n_frames, seed=seed)
+    pose_gt, trans_gt = synth_motion(NP, body_dof, n_frames, seed=seed if motion_seed is None else motion_seed)
+    if motion_seed is not None:
+        rng = np.random.default_rng(motion_seed + 5)
     if not (model_type in ('smplh', 'smplx') and not body_only_markers) and model_type != 'mano':
         pose_gt[:, body_dof:] = 0.0  # body-only layouts cannot observe the fingers
     if model_type == 'smplx':

@@ -39,6 +39,33 @@ def make_job(model_type='smplh', n_frames=4000, n_markers=53, seed=0, optimize_f
                 optimize_fingers=optimize_fingers)
 
 
+def make_capture(job, solver, motion_seed, noise=0.0005, dropout=0.02, n_gaps=2):
+    """Another capture of the SAME subject as `job` (same model, betas, priors, marker placement): a new seeded motion pushed
+    through the solver's own attachment on the device (moshii_attach_markers, f64), plus the generator's noise / dropout model.
+    Returns a job dict sharing everything but obs / vis with `job` -- seconds for 32 x 4000 frames, where the NumPy generator
+    (synth.make_sequence) takes minutes."""
+    seq, sm = job['seq'], job['sm']
+    F, M = job['vis'].shape
+    pose_gt, trans_gt = synth.synth_motion(sm.NP, sm.body_dof, F, seed=motion_seed)
+    if not job['optimize_fingers'] and job['model_type'] != 'mano':
+        pose_gt[:, sm.body_dof:] = 0.0
+    if job['model_type'] == 'smplx':
+        pose_gt[:, 66:75] = 0.0
+    markers = solver.attach.markers(pose_gt, trans_gt)
+    rng = np.random.default_rng(motion_seed + 5)
+    markers += rng.normal(0, noise, markers.shape)
+    drop = rng.random((F, M)) < dropout
+    for _ in range(n_gaps):
+        mk = rng.integers(M)
+        s0 = rng.integers(max(1, F - 10))
+        drop[s0:s0 + rng.integers(10, 50), mk] = True
+    drop[0, :] = False
+    markers[drop] = 0.0
+    out = dict(job)
+    out.update(obs=markers, vis=~drop, pose_gt=pose_gt, trans_gt=trans_gt, motion_seed=motion_seed)
+    return out
+
+
 def make_solver(job, maxiter=100):
     from .chmosh import StageIISolver
     return StageIISolver(job['sm'], job['betas'], job['markers_latent'], job['prior'], job['weights'],
