@@ -2091,7 +2091,9 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         first = is ? (is[2 * NP + 4] != 0.0) : (chp->first != 0);
     }
     if (tid == 0) cx.scal[S_PRIOR_REF] = 0.0;   // no prior reference point yet (eval_forward)
-    if (tid < 16) cx.ell[8 * pr.npose + tid] = 0.0;   // the slack behind the prior's partial-sum slices is read (times 0): keep it finite
+    // the prior's partial-sum slices and the slack behind them are read past a wave's own entries (times 0) before the neighbouring
+    // wave has necessarily written them on the first evaluation: keep every word finite from the start (stale LDS bits could be NaN)
+    for (int i = tid; i < 8 * pr.npose + 16; i += MOSHII_TPB) cx.ell[i] = 0.0;
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];   // regressed joints: read in every phase, keep them in LDS
     __syncthreads();
@@ -2197,7 +2199,11 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
                     int* fl = chp->fuse_flags + 3 * (chp->fuse_c + 1) + 1;
                     double go = 1.0;
                     int spins = 0;
-                    while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                    // (... AND has given its own verdict: until then it may still read the entry state it recorded -- the slot written
+                    //  below -- for its "is my own chunk on firm ground" test; overwriting it earlier made that test compare this
+                    //  chain's end state with itself)
+                    while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1 ||
+                           __hip_atomic_load(fl + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
                         if (__hip_atomic_load(&chp->baton[2 * chp->chunk0 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { go = 0.0; break; }
                         __builtin_amdgcn_s_sleep(64);
                         if (++spins > 20000) { go = 0.0; break; }

@@ -319,9 +319,15 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 // instructions issued behind them, which stay in flight
 #define LBS_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
 
-// NWT: skinning influences per vertex (padded).
-template <int NWT>
-__global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, int dbg) {
+// NWT: skinning influences per vertex (padded).  NVG: 16-vertex groups per wave -- 2: four waves per workgroup, one per SIMD, the
+// whole register file each; 1: eight waves, two per SIMD with 256 registers each, so that one wave's LDS / memory latency is
+// covered by the other's arithmetic (the workgroup tile is 128 vertices x 128 frames either way).
+template <int NWT, int NVG>
+__global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, int dbg) {
+    constexpr int TPB = 512 / NVG, NWAVE = TPB / 64, WV = 16 * NVG;   // threads, waves, vertices per wave
+    constexpr int RPW = 16 / NWAVE;                                  // exchange rows a wave stores per half tile
+    constexpr int NB = NVG;                                          // B-fragment sets / gather sets in flight per wave: with two waves per SIMD the
+                                                                     // partner covers a wave's LDS latency and the second set only costs registers
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, KJ = lm.KJ;
@@ -336,88 +342,74 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
     const int ntiles = NVX * NFT;
     const float isc = lm.inv_pscale;
     const int q4 = lane >> 4, fl = lane & 15;
-    const int sxw = fl * (LBS_SXP * 4) + (wv * 32 + 4 * q4) * 12;   // this lane's row / first vertex in the exchange (bytes)
-    // Four rotating A-fragment sets (k-steps t .. t+3), two B-fragment sets (t, t+1), two feature-chunk register pairs and the
-    // three ring slots are addressed by NAME (the loop is unrolled twelve-fold) so that no register copy ever waits on a load.
+    const int sxw = fl * (LBS_SXP * 4) + (wv * WV + 4 * q4) * 12;   // this lane's row / first vertex in the exchange (bytes)
+    // Three rotating A-fragment sets (k-steps t .. t+2), two B-fragment sets (t, t+1), two feature-chunk register sets and the
+    // three ring slots are addressed by NAME (the loop is unrolled six-fold) so that no register copy ever waits on a load.
     // Step t: barrier (chunk t + 1 is visible, every wave has left chunk t - 1), drop chunk t + 2 (fetched two steps ago) into
-    // the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs fragments of step t + 3, read the B fragments of step
-    // t + 1 from LDS, issue the 48 MFMAs of step t.  Global loads therefore have two (features) / three (posedirs) k-steps of
-    // ~800 cycles to arrive -- the first version gave the features one, and ran at the L2-miss latency per step.
-    half8 aS[4][2][3], bS[2][8];
-    f32x4 gS[2][2];
-#define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+    // the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs fragments of step t + 2, read the B fragments of step
+    // t + 1 from LDS, issue the 24 NVG MFMAs of step t.
+    half8 aS[3][NVG][3], bS[NB][8];
+    f32x4 gS[2][NVG];
+#define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
         aS[SET][vg][c] = ap[((size_t)(vg * 3 + c) * KS + kk_) * 64]; }
-#define LBS_LD_G(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); gS[SET][0] = fp[(size_t)kk_ * 512]; gS[SET][1] = fp[(size_t)kk_ * 512 + 256]; }
-#define LBS_ST_G(SET, SLOT) { *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + tid * 16) = gS[SET][0]; *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + 4096 + tid * 16) = gS[SET][1]; }
+#define LBS_LD_G(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int u = 0; u < NVG; ++u) gS[SET][u] = fp[(size_t)kk_ * 512 + u * TPB]; }
+#define LBS_ST_G(SET, SLOT) { _Pragma("unroll") for (int u = 0; u < NVG; ++u) *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + (tid + u * TPB) * 16) = gS[SET][u]; }
 #define LBS_LD_B(SET, SLOT) { _Pragma("unroll") for (int t = 0; t < 8; ++t) bS[SET][t] = *reinterpret_cast<const half8*>(ring + (SLOT) * LBS_CHUNK + t * 1024 + lane * 16); }
     // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use)
-#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
         acc[vg][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][vg][c], bS[BSET][t], acc[vg][t][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
-#define LBS_STEP(S, KSTEP) { LBS_LDS_BARRIER(); LBS_ST_G((S) % 2, ((S) + 2) % 3) LBS_LD_G((S) % 2, (KSTEP) + 4) LBS_LD_A(((S) + 3) % 4, (KSTEP) + 3) LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) LBS_MMA((S) % 4, (S) % 2) }
-    // first global loads of a tile (feature chunks 0, 1 and the posedirs fragments of steps 0 .. 2).  (Issuing them for the NEXT
-    // tile ahead of the current tile's last row stores keeps 80 more registers live through the epilogue: hipcc then spills 230.)
-#define LBS_TILE_OF(IDX, FT, VT) const int FT = (IDX) / NVX, VT = xcd + 8 * ((IDX) - FT * NVX);
-#define LBS_HEAD_LOADS(IDX) { LBS_TILE_OF(IDX, ft_, vt_) \
-        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt_ * 8 + wv * 2) * 3 * KS) * 64 + lane; \
-        const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft_ * KS * 512 + tid; \
-        LBS_LD_G(0, 0) LBS_LD_G(1, 1) LBS_LD_A(0, 0) LBS_LD_A(1, 1) LBS_LD_A(2, 2) }
+#define LBS_STEP(S, KSTEP) { LBS_LDS_BARRIER(); LBS_ST_G((S) % 2, ((S) + 2) % 3) LBS_LD_G((S) % 2, (KSTEP) + 4) LBS_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
+        if constexpr (NB == 2) { LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) LBS_MMA((S) % 3, (S) % 2) } else { LBS_LD_B(0, (S) % 3) LBS_MMA((S) % 3, 0) } }
     for (int idx = slot; idx < ntiles; idx += nslots) {
-        LBS_TILE_OF(idx, ft, vt)
+        const int ft = idx / NVX, vt = xcd + 8 * (idx - ft * NVX);
         const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
         // ---- main loop: acc[vg][t][c] (16 vertices x 16 frames) += Pfrag(vg, c, ks) x featF(t, ks)
-        f32x4 acc[2][8][3];
+        f32x4 acc[NVG][8][3];
 #pragma unroll
-        for (int vg = 0; vg < 2; ++vg)
+        for (int vg = 0; vg < NVG; ++vg)
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[vg][t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt * 8 + wv * 2) * 3 * KS) * 64 + lane;
+        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt * 8 + wv * NVG) * 3 * KS) * 64 + lane;
         const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft * KS * 512 + tid;
-        LBS_HEAD_LOADS(idx)
+        LBS_LD_G(0, 0) LBS_LD_G(1, 1) LBS_LD_A(0, 0) LBS_LD_A(1, 1)
         LBS_ST_G(0, 0) LBS_ST_G(1, 1)
         LBS_LD_G(0, 2) LBS_LD_G(1, 3)
         LBS_LDS_BARRIER();
-        LBS_LD_B(0, 0)
+        if constexpr (NB == 2) LBS_LD_B(0, 0)
         int ks = 0;
-        for (; ks + 12 <= KS; ks += 12) {
+        for (; ks + 6 <= KS; ks += 6) {
             LBS_STEP(0, ks) LBS_STEP(1, ks + 1) LBS_STEP(2, ks + 2) LBS_STEP(3, ks + 3) LBS_STEP(4, ks + 4) LBS_STEP(5, ks + 5)
-            LBS_STEP(6, ks + 6) LBS_STEP(7, ks + 7) LBS_STEP(8, ks + 8) LBS_STEP(9, ks + 9) LBS_STEP(10, ks + 10) LBS_STEP(11, ks + 11)
         }
         if (ks < KS) { LBS_STEP(0, ks) ++ks; }
         if (ks < KS) { LBS_STEP(1, ks) ++ks; }
         if (ks < KS) { LBS_STEP(2, ks) ++ks; }
         if (ks < KS) { LBS_STEP(3, ks) ++ks; }
         if (ks < KS) { LBS_STEP(4, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(5, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(6, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(7, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(8, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(9, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(10, ks) ++ks; }
         // ---- epilogue: eight half tiles of 16 frames.  Per half tile: transforms in LDS (barrier), every lane blends and
-        // applies its 8 (vertex, frame) pairs and drops the results into the exchange (barrier), the workgroup writes 16 whole
+        // applies its 4 NVG (vertex, frame) pairs and drops the results into the exchange (barrier), the workgroup writes 16 whole
         // tile rows.  The transforms of half tile h + 1 are on their way (LDS-DMA) while h is worked on.
         const char* asrc = reinterpret_cast<const char*>(lm.Atr) + (size_t)ft * 8 * tlb;
         const int npieces = tlb >> 10;
         auto stage_dma = [&](int h, int buf) {
             const char* s = asrc + (size_t)h * tlb + lane * 16;
             char* d = lds_raw + buf * LBS_TLMAX;
-            for (int p = wv; p < npieces; p += 4)
+            for (int p = wv; p < npieces; p += NWAVE)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)p * 1024),
                                                  (__attribute__((address_space(3))) void*)(d + p * 1024), 16, 0, 0);
         };
         stage_dma(0, 0);
-        // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + 32 wv + 16 vg + 4 (lane / 16) + r.
-        // Their rest positions, joint addresses and weights (88 registers) are fetched behind the k-loop (fetched before it they
-        // are live across it, on top of its 176 operand registers, and hipcc parks them in scratch / AGPRs).
-        float vs[2][4][3], ww[2][4][NWT];
-        int ja[2][4][NWT];
+        // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + WV wv + 16 vg + 4 (lane / 16) + r.
+        // Their rest positions, joint addresses and weights are fetched behind the k-loop (fetched before it they are live across
+        // it, on top of its operand registers, and hipcc parks them in scratch / AGPRs).
+        float vs[NVG][4][3], ww[NVG][4][NWT];
+        int ja[NVG][4][NWT];
 #pragma unroll
-        for (int vg = 0; vg < 2; ++vg)
+        for (int vg = 0; vg < NVG; ++vg)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int v = v0 + wv * 32 + vg * 16 + 4 * q4 + r;
+                const int v = v0 + wv * WV + vg * 16 + 4 * q4 + r;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) vs[vg][r][c] = lm.vsh_pad[(size_t)v * 3 + c];
 #pragma unroll
@@ -431,73 +423,75 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
         if (dbg & 1) {
             float sacc = 0.0f;
 #pragma unroll
-            for (int vg = 0; vg < 2; ++vg)
+            for (int vg = 0; vg < NVG; ++vg)
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) sacc += acc[vg][t][c][0] + acc[vg][t][c][1] + acc[vg][t][c][2] + acc[vg][t][c][3];
-            if (sacc == 123.456f) out[0] = vs[0][0][0] + ww[1][3][0] + (float)ja[0][2][1];
+            if (sacc == 123.456f) out[0] = vs[0][0][0] + ww[NVG - 1][3][0] + (float)ja[0][2][1];
             LBS_WAIT_VM(0);
             LBS_LDS_BARRIER();
             continue;
         }
         const int nfl = min(LBS_TV, V - v0) * 3;   // valid floats of a tile row
-        // interior tile: every wave issues exactly eight store instructions per half tile, which is what the counted wait below relies on
+        // interior tile: every wave issues exactly 2 RPW store instructions per half tile, which is what the counted wait below relies on
         const bool full = (f0 + LBS_TF <= F) && (nfl == LBS_TV * 3);
-        // two (vertex, frame) items in flight per lane: the 12 transform reads of item k + 1 are issued before item k is computed
-        f32x4 A0[2][NWT], A1[2][NWT], A2[2][NWT];
+        // The half tiles run as a LOOP (two per trip: the transform buffers alternate, and their base is an immediate of the reads):
+        // unrolled eight-fold, the epilogue alone was 48 KB of straight-line code executed once per tile.  The accumulators are
+        // registers and cannot be indexed by the trip count: a wave-uniform switch moves the half tile's 12 NVG values out first
+        // (as rest position + corrective).
+        f32x4 A0[NB][NWT], A1[NB][NWT], A2[NB][NWT];
+        float pp[NVG][4][3];
 #define LBS_GATHER(SET, VG, R, BOFF) { _Pragma("unroll") for (int i = 0; i < NWT; ++i) { const char* tp = lds_raw + (BOFF) + ja[VG][R][i]; \
         A0[SET][i] = *reinterpret_cast<const f32x4*>(tp); A1[SET][i] = *reinterpret_cast<const f32x4*>(tp + 16); A2[SET][i] = *reinterpret_cast<const f32x4*>(tp + 32); } }
-#define LBS_APPLY(SET, VG, R, H) { \
-        const float px = fmaf(isc, acc[VG][H][0][R], vs[VG][R][0]), py = fmaf(isc, acc[VG][H][1][R], vs[VG][R][1]), pz = fmaf(isc, acc[VG][H][2][R], vs[VG][R][2]); \
+#define LBS_APPLY(SET, VG, R) { \
+        const float px = pp[VG][R][0], py = pp[VG][R][1], pz = pp[VG][R][2]; \
         float ox = 0.0f, oy = 0.0f, oz = 0.0f; \
         _Pragma("unroll") for (int i = 0; i < NWT; ++i) { const float w = ww[VG][R][i]; \
             ox = fmaf(w, fmaf(A0[SET][i].x, px, fmaf(A0[SET][i].y, py, fmaf(A0[SET][i].z, pz, A0[SET][i].w))), ox); \
             oy = fmaf(w, fmaf(A1[SET][i].x, px, fmaf(A1[SET][i].y, py, fmaf(A1[SET][i].z, pz, A1[SET][i].w))), oy); \
             oz = fmaf(w, fmaf(A2[SET][i].x, px, fmaf(A2[SET][i].y, py, fmaf(A2[SET][i].z, pz, A2[SET][i].w))), oz); } \
         float* so = reinterpret_cast<float*>(Sx + sxw + ((VG) * 16 + (R)) * 12); so[0] = ox; so[1] = oy; so[2] = oz; }
-#define LBS_ITEM(K, H, BOFF) { if ((K) < 7) LBS_GATHER(((K) + 1) & 1, ((K) + 1) >> 2, ((K) + 1) & 3, BOFF) \
-        LBS_APPLY((K) & 1, (K) >> 2, (K) & 3, H) }
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            if (h > 0 && full && dbg == 0) LBS_WAIT_VM(8);   // the eight row stores of half tile h - 1 are younger than the DMA pieces: they stay in flight
-            else LBS_WAIT_VM(0);
-            LBS_LDS_BARRIER();
-            if (h + 1 < 8) stage_dma(h + 1, (h + 1) & 1);
-            if (h & 1) {
-                LBS_GATHER(0, 0, 0, LBS_TLMAX)
-                LBS_ITEM(0, h, LBS_TLMAX) LBS_ITEM(1, h, LBS_TLMAX) LBS_ITEM(2, h, LBS_TLMAX) LBS_ITEM(3, h, LBS_TLMAX)
-                LBS_ITEM(4, h, LBS_TLMAX) LBS_ITEM(5, h, LBS_TLMAX) LBS_ITEM(6, h, LBS_TLMAX) LBS_ITEM(7, h, LBS_TLMAX)
-            } else {
-                LBS_GATHER(0, 0, 0, 0)
-                LBS_ITEM(0, h, 0) LBS_ITEM(1, h, 0) LBS_ITEM(2, h, 0) LBS_ITEM(3, h, 0)
-                LBS_ITEM(4, h, 0) LBS_ITEM(5, h, 0) LBS_ITEM(6, h, 0) LBS_ITEM(7, h, 0)
-            }
-            LBS_LDS_BARRIER();   // the exchange is complete
-            // wave w writes rows w, w + 4, w + 8, w + 12 of the half tile: 96 16-byte chunks per row = one full wave store + one
-            // half-wave store (all addressing is a wave-uniform base + 16 lane)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wv + 4 * i, f = f0 + 16 * h + row;
-                const char* srow = Sx + row * (LBS_SXP * 4) + lane * 16;
-                float* orow = out + ((size_t)f * V + v0) * 3 + lane * 4;
-#pragma unroll
-                for (int part = 0; part < 2; ++part) {
-                    if (part == 1 && lane >= 32) continue;
-                    const f32x2* sp = reinterpret_cast<const f32x2*>(srow + part * 1024);
-                    const f32x2 lo = sp[0], hi = sp[1];
-                    const f32x4u val = {lo.x, lo.y, hi.x, hi.y};
-                    float* o = orow + part * 256;
-                    const int c = (lane + 64 * part) * 4;
-                    // (streaming stores: the output must not evict the posedirs fragments the k-loop re-reads from L2)
-                    if (dbg & 2) continue;
-                    if (full) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
-                    else if (f < F) {
-                        if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
-                        else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e];
-                    }
-                }
-            }
+        // item k = 4 vg + r; the 12 transform reads of item k + 1 are issued before item k is computed
+#define LBS_ITEM(K, BOFF) { if constexpr (NB == 2) { if ((K) + 1 < 4 * NVG) LBS_GATHER(((K) + 1) & 1, ((K) + 1) >> 2, ((K) + 1) & 3, BOFF) LBS_APPLY((K) & 1, (K) >> 2, (K) & 3) } \
+        else { LBS_GATHER(0, (K) >> 2, (K) & 3, BOFF) LBS_APPLY(0, (K) >> 2, (K) & 3) } }
+#define LBS_TAKE(H) { _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int r = 0; r < 4; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+        pp[vg][r][c] = fmaf(isc, acc[vg][H][c][r], vs[vg][r][c]); }
+#define LBS_HALF(H, BOFF) { \
+        if ((H) > 0 && full && dbg == 0) LBS_WAIT_VM(2 * RPW); else LBS_WAIT_VM(0);   /* the row stores of half tile h - 1 are younger than the DMA pieces: they stay in flight */ \
+        LBS_LDS_BARRIER(); \
+        if ((H) + 1 < 8) stage_dma((H) + 1, ((H) + 1) & 1); \
+        switch (H) { case 0: LBS_TAKE(0) break; case 1: LBS_TAKE(1) break; case 2: LBS_TAKE(2) break; case 3: LBS_TAKE(3) break; \
+                     case 4: LBS_TAKE(4) break; case 5: LBS_TAKE(5) break; case 6: LBS_TAKE(6) break; default: LBS_TAKE(7) break; } \
+        if constexpr (NB == 2) LBS_GATHER(0, 0, 0, BOFF) \
+        LBS_ITEM(0, BOFF) LBS_ITEM(1, BOFF) LBS_ITEM(2, BOFF) LBS_ITEM(3, BOFF) \
+        if constexpr (NVG == 2) { LBS_ITEM(4, BOFF) LBS_ITEM(5, BOFF) LBS_ITEM(6, BOFF) LBS_ITEM(7, BOFF) } \
+        LBS_LDS_BARRIER();   /* the exchange is complete */ \
+        /* wave w writes rows w, w + NWAVE, ... of the half tile: 96 16-byte chunks per row = one full wave store + one half-wave store */ \
+        _Pragma("unroll") for (int i = 0; i < RPW; ++i) { \
+            const int row = wv + NWAVE * i, f = f0 + 16 * (H) + row; \
+            const char* srow = Sx + row * (LBS_SXP * 4) + lane * 16; \
+            float* orow = out + ((size_t)f * V + v0) * 3 + lane * 4; \
+            _Pragma("unroll") for (int part = 0; part < 2; ++part) { \
+                if (part == 1 && lane >= 32) continue; \
+                const f32x2* sp = reinterpret_cast<const f32x2*>(srow + part * 1024); \
+                const f32x2 lo = sp[0], hi = sp[1]; \
+                const f32x4u val = {lo.x, lo.y, hi.x, hi.y}; \
+                float* o = orow + part * 256; \
+                const int c = (lane + 64 * part) * 4; \
+                if (dbg & 2) continue; \
+                /* (streaming stores: the output must not evict the posedirs fragments the k-loop re-reads from L2) */ \
+                if (full) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o)); \
+                else if (f < F) { \
+                    if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o)); \
+                    else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e]; \
+                } \
+            } \
+        } }
+#pragma unroll 1
+        for (int h2 = 0; h2 < 8; h2 += 2) {
+            LBS_HALF(h2, 0)
+            LBS_HALF(h2 + 1, LBS_TLMAX)
         }
         LBS_LDS_BARRIER();   // the last rows are out of the exchange before the next tile's first half tile writes it
     }
@@ -510,6 +504,8 @@ __global__ __launch_bounds__(256, 1) void k_lbs_tile(Lbs32Model lm, int V, int F
 #undef LBS_GATHER
 #undef LBS_APPLY
 #undef LBS_ITEM
+#undef LBS_TAKE
+#undef LBS_HALF
 }
 
 }  // namespace
@@ -638,11 +634,15 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid);
     // one workgroup per CU (the kernel takes the whole register file and most of the LDS), 8 XCDs
     const int nslots = std::max(1, std::min((ncu > 0 ? ncu : 256) / 8, ((NVT + 7) / 8) * NFT));
-    auto kern = (lm.NW == 4) ? k_lbs_tile<4> : k_lbs_tile<8>;
+    // waves per workgroup: 8 (two per SIMD, the default) or 4 (MOSHII_LBS_WAVES=4: one per SIMD with twice the registers)
+    int nwave = 8;
+    if (const char* es = getenv("MOSHII_LBS_WAVES")) nwave = (atoi(es) == 4) ? 4 : 8;
+    if (lm.NW != 4) nwave = 4;   // (eight influences per vertex: the register budget of the one-wave-per-SIMD form)
+    auto kern = (lm.NW == 4) ? (nwave == 8 ? k_lbs_tile<4, 1> : k_lbs_tile<4, 2>) : k_lbs_tile<8, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 3;   // (development: phase timing by truncation; incomplete output)
-    hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(256), LBS_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, dbg);
+    hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(nwave * 64), LBS_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, dbg);
     return hipGetLastError();
 }

@@ -159,7 +159,7 @@ def test_underdetermined_frames_are_flagged_and_still_fit_their_data_in_emulatio
 def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F):
     """The f16-MFMA full-mesh export (lbs_forward.hip: k_lbs_prep + k_lbs_tile, compiled unchanged by the host clang++) against the
     f64 kernel of the same emulated library: 16x16x32 MFMA fragment layouts, the feature ring, the lane = frame blend, the result
-    exchange and the partial vertex / frame tiles; the register-staged and the LDS-DMA form of the transform copy give the same bits."""
+    exchange and the partial vertex / frame tiles; the eight-wave (two per SIMD) and the four-wave form of the kernel give the same bits."""
     import os
     M = {'mano': 24, 'smpl': 41}[model_type]
     case = oracle_case(model_type, F=4, M=M, seed=61)
@@ -170,10 +170,10 @@ def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F):
         dev = device_case(case)
         ref = dev['model'].lbs_forward(pose, trans)
         got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
-        os.environ['MOSHII_LBS_NO_DMA'] = '1'
+        os.environ['MOSHII_LBS_WAVES'] = '4'
         try:
             got2 = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
         finally:
-            del os.environ['MOSHII_LBS_NO_DMA']
+            del os.environ['MOSHII_LBS_WAVES']
     assert np.abs(got - ref).max() < 2e-5
     np.testing.assert_array_equal(got, got2)

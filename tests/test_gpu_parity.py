@@ -264,8 +264,8 @@ def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
 def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     """The MFMA export kernel (f16-operand correctives, lane = frame blend from LDS-DMA-staged transforms, row stores through
     LDS) against the reference-precision kernel and against the plain f32 kernel, on frame counts and vertex counts that
-    leave partial frame tiles and partial vertex tiles; the register-staged form of the transform copy must give the same
-    bits as the DMA form (same arithmetic, different route into LDS); repeated calls must too (the DMA waits are counted)."""
+    leave partial frame tiles and partial vertex tiles; the four-wave form of the kernel (one wave per SIMD) must give the same
+    bits as the default eight-wave form (same arithmetic per vertex and frame); repeated calls must too (the DMA waits are counted)."""
     M = {'smplh': 53, 'smplx': 60, 'mano': 24, 'smpl': 41}[model_type]
     case = oracle_case(model_type, F=4, M=M, seed=61)
     dev = device_case(case)
@@ -286,11 +286,11 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     assert np.abs(plain - ref).max() < 5e-6
     for _ in range(3):
         np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
-    os.environ['MOSHII_LBS_NO_DMA'] = '1'
+    os.environ['MOSHII_LBS_WAVES'] = '4'
     try:
         np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
     finally:
-        del os.environ['MOSHII_LBS_NO_DMA']
+        del os.environ['MOSHII_LBS_WAVES']
     # linearity in trans (size-independent property): shifting trans shifts every vertex by the same amount
     got2 = dev['model'].lbs_forward(pose, trans + 0.25, dtype=np.float32)
     assert np.abs((got2 - got) - 0.25).max() < 1e-5

@@ -10,12 +10,16 @@ python tools/lbs_bench.py 2000 10 smplh
 python tools/lbs_bench.py 50000 3 smplh
 echo "# stop=1 (prep + k-loop)"; MOSHII_LBS_STOP=1 python tools/lbs_bench.py 4000 10 smplh
 echo "# stop=2 (no stores)"; MOSHII_LBS_STOP=2 python tools/lbs_bench.py 4000 10 smplh
+echo "# four waves per workgroup"; MOSHII_LBS_WAVES=4 python tools/lbs_bench.py 4000 10 smplh
+echo "# four waves, stop=1"; MOSHII_LBS_WAVES=4 MOSHII_LBS_STOP=1 python tools/lbs_bench.py 4000 10 smplh
+echo "# four waves, stop=2"; MOSHII_LBS_WAVES=4 MOSHII_LBS_STOP=2 python tools/lbs_bench.py 4000 10 smplh
 } > $O/timings.txt 2>&1
 grep -v amdgpu.ids $O/timings.txt
 export PYTHONPATH=/root/repo
 (cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/$O/trace -o lbs -- python /root/repo/tools/lbs_bench.py 4000 10 smplh > /root/repo/$O/rocprof_stdout.txt 2>&1)
-for f in $(find $O/trace -name "*kernel_stats.csv"); do cp $f $O/kernel_stats.csv; head -8 $f; done
+find $O/trace -type f | head; for f in $(find $O/trace -name "*stats*.csv"); do cp $f $O/; head -8 $f; done
 rm -rf $O/trace
+rocprofv3 -L 2>/dev/null | grep -i "icache\|ifetch\|SQC_" | head -40 > $O/counters_icache.txt; cat $O/counters_icache.txt
 [ "$1" = "nopmc" ] && exit 0
 i=0
 for set in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
