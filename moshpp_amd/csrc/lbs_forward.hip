@@ -216,9 +216,11 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
     // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own
     __shared__ float s_fullpose[4][3 * MOSHII_MAXK];
     __shared__ float s_Rl[4][MOSHII_MAXK * 9], s_Rw[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];
+    __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
     const int K = md.K, P = md.P, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
-    const int f = blockIdx.x * 4 + wv;
-    if (f >= F) return;   // (whole wavefront; no workgroup barrier below)
+    const int fw = blockIdx.x * 4 + wv;          // this wave's frame; the last workgroup's spare waves redo frame F - 1 and write nothing
+    const int f = min(fw, F - 1);
+    for (int q = tid; q < 16 * 32; q += 64) s_feat[wv][q] = (_Float16)0.0f;
     float* fullpose = s_fullpose[wv]; float* Rl = s_Rl[wv]; float* Rw = s_Rw[wv]; float* tw = s_tw[wv];
     const float* ps = pose + (size_t)f * md.NP;
     const int bd = md.body_dof, nhf = md.nhand_full;
@@ -243,9 +245,6 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // B fragments of v_mfma_f32_16x16x32_f16: feature q of frame f sits in record (f / 128, q / 32, (f / 16) % 8), lane
-    // (f % 16) + 16 ((q / 8) % 4), element q % 8.  Feature columns beyond 9 (K - 1) were zeroed when the buffer was allocated.
-    _Float16* frec = featF + ((size_t)(f >> 7) * KS * 8 + ((f >> 4) & 7)) * 512 + (size_t)(f & 15) * 8;
     if (tid < K) {
         const float x = fullpose[3 * tid], y = fullpose[3 * tid + 1], z = fullpose[3 * tid + 2];
         const float t2 = x * x + y * y + z * z;
@@ -259,10 +258,7 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
             const float id = (e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f;
             const float r = id + a * Km[e] + b * K2[e];
             Rl[tid * 9 + e] = r;
-            if (tid >= 1) {
-                const int q = (tid - 1) * 9 + e;
-                frec[(size_t)(q >> 5) * 4096 + ((q >> 3) & 3) * 128 + (q & 7)] = (_Float16)(a * Km[e] + b * K2[e]);   // R - I without the cancellation
-            }
+            if (tid >= 1) s_feat[wv][(tid - 1) * 9 + e] = (_Float16)(a * Km[e] + b * K2[e]);   // R - I without the cancellation
         }
     }
     // kinematic chain inside the wavefront (in-order LDS), one tree level per step
@@ -289,7 +285,7 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (tid < K) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint)
+    if (tid < K && fw < F) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint)
         f32x4* o = reinterpret_cast<f32x4*>(Atr + (((size_t)(f >> 4) * KJ + tid) * 16 + (f & 15)) * 12);
         const float* tr = trans + (size_t)f * 3;
 #pragma unroll
@@ -300,6 +296,19 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
             o[i] = row;
         }
     }
+    // B fragments of v_mfma_f32_16x16x32_f16: features 8 g .. 8 g + 7 of frame f are the 16 bytes of record (f / 128, g / 4,
+    // (f / 16) % 8), lane (f % 16) + 16 (g % 4).  The workgroup's four frames are four consecutive lanes: thread (g, frame) writes
+    // one 16-byte piece, four threads a 64-byte run (the first version wrote every feature as a 2-byte store of its own: 2.4 M write
+    // requests per call, the waves a third of their time at the issue stage behind them).
+    __syncthreads();
+    {
+        const int fi = threadIdx.x & 3, g = threadIdx.x >> 2, fo = blockIdx.x * 4 + fi;
+        if (g < KS * 4 && fo < F) {
+            const f32x4 piece = *reinterpret_cast<const f32x4*>(&s_feat[fi][g * 8]);
+            _Float16* dst = featF + ((((size_t)(fo >> 7) * KS + (g >> 2)) * 8 + ((fo >> 4) & 7)) * 64 + (fo & 15) + 16 * (g & 3)) * 8;
+            *reinterpret_cast<f32x4*>(dst) = piece;
+        }
+    }
 }
 
 // ---- the export kernel ------------------------------------------------------------------------------------
@@ -307,12 +316,13 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 //   [0, 43008)        transforms of the half tile in work, buffer 0   (KJ <= 56 joints x 768 B)
 //   [43008, 86016)    buffer 1
 //   [86016, 110592)   feature ring, 3 slots of 8 KiB
-//   [110592, 135296)  result exchange, 16 rows of LBS_SXP dwords
+//   [110592, 160000)  result exchange, two buffers of 16 rows of LBS_SXP dwords
 #define LBS_TLMAX 43008
 #define LBS_KJMAX 56
 #define LBS_OFF_RING (2 * LBS_TLMAX)
 #define LBS_OFF_SX (LBS_OFF_RING + LBS_RING * LBS_CHUNK)
-#define LBS_LDS_BYTES (LBS_OFF_SX + 16 * LBS_SXP * 4)
+#define LBS_SXBYTES (16 * LBS_SXP * 4)
+#define LBS_LDS_BYTES (LBS_OFF_SX + 2 * LBS_SXBYTES)
 
 #define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their "no wait" values): the LDS-DMA pieces are older than the N memory
@@ -326,14 +336,14 @@ template <int NWT, int NVG>
 __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, int dbg) {
     constexpr int TPB = 512 / NVG, NWAVE = TPB / 64, WV = 16 * NVG;   // threads, waves, vertices per wave
     constexpr int RPW = 16 / NWAVE;                                  // exchange rows a wave stores per half tile
-    constexpr int NB = NVG;                                          // B-fragment sets / gather sets in flight per wave: with two waves per SIMD the
-                                                                     // partner covers a wave's LDS latency and the second set only costs registers
+    constexpr int NB = NVG;                                          // B-fragment sets: two (the fragments of step t + 1 are read while step t multiplies) where
+                                                                     // the registers allow it; with eight waves the partner wave of the SIMD covers the read
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, KJ = lm.KJ;
     const int tlb = KJ * LBS_JBYTES;                       // bytes of one half tile's transforms (a multiple of 1024)
     char* ring = lds_raw + LBS_OFF_RING;                   // [LBS_RING][8 frame blocks][64 lanes][16 B]
-    char* Sx = lds_raw + LBS_OFF_SX;                       // [16 frames][LBS_SXP] f32
+    char* Sx = lds_raw + LBS_OFF_SX;                       // [2][16 frames][LBS_SXP] f32
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...}, whose posedirs
     // fragments (356 KB each) stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side, so the
     // transforms and features of a few frame tiles are what else the L2 has to hold.
@@ -351,15 +361,44 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
     half8 aS[3][NVG][3], bS[NB][8];
     f32x4 gS[2][NVG];
 #define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        aS[SET][vg][c] = ap[((size_t)(vg * 3 + c) * KS + kk_) * 64]; }
-#define LBS_LD_G(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int u = 0; u < NVG; ++u) gS[SET][u] = fp[(size_t)kk_ * 512 + u * TPB]; }
+        aS[SET][vg][c] = (ap + ((size_t)(vg * 3 + c) * KS + kk_) * 64)[lane]; }
+#define LBS_LD_G(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int u = 0; u < NVG; ++u) gS[SET][u] = (fp + (size_t)kk_ * 512 + u * TPB)[tid]; }
 #define LBS_ST_G(SET, SLOT) { _Pragma("unroll") for (int u = 0; u < NVG; ++u) *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + (tid + u * TPB) * 16) = gS[SET][u]; }
 #define LBS_LD_B(SET, SLOT) { _Pragma("unroll") for (int t = 0; t < 8; ++t) bS[SET][t] = *reinterpret_cast<const half8*>(ring + (SLOT) * LBS_CHUNK + t * 1024 + lane * 16); }
-    // (sched_barrier pins the issue order: without it hipcc sinks the prefetch loads down to their first use)
-#define LBS_MMA(ASET, BSET) { __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        acc[vg][t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][vg][c], bS[BSET][t], acc[vg][t][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
-#define LBS_STEP(S, KSTEP) { LBS_LDS_BARRIER(); LBS_ST_G((S) % 2, ((S) + 2) % 3) LBS_LD_G((S) % 2, (KSTEP) + 4) LBS_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
-        if constexpr (NB == 2) { LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) LBS_MMA((S) % 3, (S) % 2) } else { LBS_LD_B(0, (S) % 3) LBS_MMA((S) % 3, 0) } }
+    // The memory instructions of a step are spread BETWEEN its MFMAs (sched_barrier pins the order): a wave issues in order, and
+    // a global load does not leave the issue stage while the CU's address unit is busy with the other waves' loads -- with all
+    // loads of a step ahead of its MFMAs (the first version), every wave sat ~500 cycles behind the other seven's 1 KB loads
+    // before its first MFMA (measured: 1 420 cycles per step against 768 of MFMA; 800 with the loads ablated).
+#define LBS_MMA_T(ASET, BSET, T) { _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+        acc[vg][T][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][vg][c], bS[BSET][T], acc[vg][T][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+#define LBS_LD_A1(SET, KSTEP, VG) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+        aS[SET][VG][c] = (ap + ((size_t)((VG) * 3 + c) * KS + kk_) * 64)[lane]; __builtin_amdgcn_sched_barrier(0); }
+#define LBS_STEP(S, KSTEP) { const bool ring_ = !(dbg & 8), lda_ = !(dbg & 4); \
+        if (ring_) LBS_LDS_BARRIER(); \
+        if constexpr (NB == 1) { LBS_LD_B(0, (S) % 3) } \
+        __builtin_amdgcn_sched_barrier(0); \
+        LBS_MMA_T((S) % 3, (S) % NB, 0) \
+        if (ring_) { LBS_ST_G((S) % 2, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
+        LBS_MMA_T((S) % 3, (S) % NB, 1) \
+        if (ring_ && (KSTEP) + 4 < KS) { LBS_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0);   /* (nothing is fetched past the last k-step: the first half tile would wait for it) */ \
+        LBS_MMA_T((S) % 3, (S) % NB, 2) \
+        if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, 0) \
+        LBS_MMA_T((S) % 3, (S) % NB, 3) \
+        if constexpr (NVG == 2) { if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, NVG - 1) } \
+        LBS_MMA_T((S) % 3, (S) % NB, 4) \
+        LBS_MMA_T((S) % 3, (S) % NB, 5) \
+        if constexpr (NB == 2) { LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) } __builtin_amdgcn_sched_barrier(0); \
+        LBS_MMA_T((S) % 3, (S) % NB, 6) \
+        LBS_MMA_T((S) % 3, (S) % NB, 7) }
+    // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in the output buffer instead of vertices -- tools/lbs_bench.py prints them)
+#define LBS_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 32 + (K)] = clock64(); }
+    const int npieces = tlb >> 10;
+    auto dma_piece = [&](const char* src, int buf, int p) {   // 1 KiB piece p of a half tile's transforms -> LDS buffer buf, by LDS-DMA
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(lds_raw + buf * LBS_TLMAX + p * 1024), 16, 0, 0);
+    };
+    auto stage_dma = [&](const char* asrc, int h, int buf) { for (int p = wv; p < npieces; p += NWAVE) dma_piece(asrc + (size_t)h * tlb, buf, p); };
+    if (slot < ntiles) stage_dma(reinterpret_cast<const char*>(lm.Atr) + (size_t)(slot / NVX) * 8 * tlb, 0, 0);
     for (int idx = slot; idx < ntiles; idx += nslots) {
         const int ft = idx / NVX, vt = xcd + 8 * (idx - ft * NVX);
         const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
@@ -371,13 +410,28 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[vg][t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt * 8 + wv * NVG) * 3 * KS) * 64 + lane;
-        const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft * KS * 512 + tid;
+        // (wave-uniform bases: the loads take them as scalar pairs plus ONE lane-offset register instead of a 64-bit address each)
+        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt * 8 + wv * NVG) * 3 * KS) * 64;
+        const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft * KS * 512;
+        LBS_STAMP(0)
+        // the tile's 128 vertex records {rest position, NWT x (joint address, weight)}: threads 0 .. 127 fetch one each now and hold it
+        // across the k-loop (3 + 2 NWT registers in two waves); behind the loop the records go through the (then idle) feature ring,
+        // from where every lane picks up the 4 NVG vertices of its accumulator registers.  (Every lane fetching its own vertices
+        // here kept 44 registers live across the loop -- spilled; fetching them behind the loop left the first half tile waiting
+        // 4 000 cycles for memory.)
+        float vrec[3]; int2 jrec[NWT];
+        if (tid < LBS_TV) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vrec[c] = lm.vsh_pad[(size_t)(v0 + tid) * 3 + c];
+#pragma unroll
+            for (int i = 0; i < NWT; ++i) jrec[i] = lm.sjw[(size_t)(v0 + tid) * NWT + i];
+        }
         LBS_LD_G(0, 0) LBS_LD_G(1, 1) LBS_LD_A(0, 0) LBS_LD_A(1, 1)
         LBS_ST_G(0, 0) LBS_ST_G(1, 1)
         LBS_LD_G(0, 2) LBS_LD_G(1, 3)
         LBS_LDS_BARRIER();
         if constexpr (NB == 2) LBS_LD_B(0, 0)
+        LBS_STAMP(1)
         int ks = 0;
         for (; ks + 6 <= KS; ks += 6) {
             LBS_STEP(0, ks) LBS_STEP(1, ks + 1) LBS_STEP(2, ks + 2) LBS_STEP(3, ks + 3) LBS_STEP(4, ks + 4) LBS_STEP(5, ks + 5)
@@ -390,36 +444,40 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
         // ---- epilogue: eight half tiles of 16 frames.  Per half tile: transforms in LDS (barrier), every lane blends and
         // applies its 4 NVG (vertex, frame) pairs and drops the results into the exchange (barrier), the workgroup writes 16 whole
         // tile rows.  The transforms of half tile h + 1 are on their way (LDS-DMA) while h is worked on.
+        LBS_STAMP(2)
+        // transforms of this tile / of this workgroup's next tile (whose first half tile is fetched during the last one of this tile:
+        // issued behind the k-loop it kept the first half tile waiting 3 000 cycles)
         const char* asrc = reinterpret_cast<const char*>(lm.Atr) + (size_t)ft * 8 * tlb;
-        const int npieces = tlb >> 10;
-        auto stage_dma = [&](int h, int buf) {
-            const char* s = asrc + (size_t)h * tlb + lane * 16;
-            char* d = lds_raw + buf * LBS_TLMAX;
-            for (int p = wv; p < npieces; p += NWAVE)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)p * 1024),
-                                                 (__attribute__((address_space(3))) void*)(d + p * 1024), 16, 0, 0);
-        };
-        stage_dma(0, 0);
-        // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + WV wv + 16 vg + 4 (lane / 16) + r.
-        // Their rest positions, joint addresses and weights are fetched behind the k-loop (fetched before it they are live across
-        // it, on top of its operand registers, and hipcc parks them in scratch / AGPRs).
+        const char* asrc_next = reinterpret_cast<const char*>(lm.Atr) + (size_t)((idx + nslots) / NVX) * 8 * tlb;
+        constexpr int RECW = 4 + 2 * NWT;   // dwords per vertex record in LDS: x y z - | weights | joint addresses
+        {
+            LBS_LDS_BARRIER();   // every wave has read its last B fragments: the ring is free
+            if (tid < LBS_TV) {
+                float* rec = reinterpret_cast<float*>(ring) + tid * RECW;
+                rec[0] = vrec[0]; rec[1] = vrec[1]; rec[2] = vrec[2];
+#pragma unroll
+                for (int i = 0; i < NWT; ++i) { rec[4 + i] = __int_as_float(jrec[i].y); reinterpret_cast<int*>(rec)[4 + NWT + i] = jrec[i].x; }
+            }
+            LBS_LDS_BARRIER();
+        }
+        // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + WV wv + 16 vg + 4 (lane / 16) + r
         float vs[NVG][4][3], ww[NVG][4][NWT];
         int ja[NVG][4][NWT];
 #pragma unroll
         for (int vg = 0; vg < NVG; ++vg)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int v = v0 + wv * WV + vg * 16 + 4 * q4 + r;
+                const float* rec = reinterpret_cast<const float*>(ring) + (wv * WV + vg * 16 + 4 * q4 + r) * RECW;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) vs[vg][r][c] = lm.vsh_pad[(size_t)v * 3 + c];
+                for (int c = 0; c < 3; ++c) vs[vg][r][c] = rec[c];
 #pragma unroll
                 for (int i = 0; i < NWT; ++i) {
-                    const int2 jw = lm.sjw[(size_t)v * NWT + i];
-                    ja[vg][r][i] = jw.x + fl * 48;   // byte offset inside a half tile's transform block
-                    ww[vg][r][i] = __int_as_float(jw.y);
+                    ww[vg][r][i] = rec[4 + i];
+                    ja[vg][r][i] = reinterpret_cast<const int*>(rec)[4 + NWT + i] + fl * 48;   // byte offset inside a half tile's transform block
                 }
             }
-        // (MOSHII_LBS_STOP=1|2: phase timing by truncation -- 1: stop after the k-loop, 2: everything but the global stores)
+        // (MOSHII_LBS_STOP: phase timing by truncation / ablation -- 1: stop after the k-loop, 2: everything but the global stores,
+        //  +4: the k-loop re-uses its first posedirs fragments, +8: ... and its first feature chunks, without the ring and its barriers)
         if (dbg & 1) {
             float sacc = 0.0f;
 #pragma unroll
@@ -436,76 +494,89 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
         const int nfl = min(LBS_TV, V - v0) * 3;   // valid floats of a tile row
         // interior tile: every wave issues exactly 2 RPW store instructions per half tile, which is what the counted wait below relies on
         const bool full = (f0 + LBS_TF <= F) && (nfl == LBS_TV * 3);
-        // The half tiles run as a LOOP (two per trip: the transform buffers alternate, and their base is an immediate of the reads):
-        // unrolled eight-fold, the epilogue alone was 48 KB of straight-line code executed once per tile.  The accumulators are
-        // registers and cannot be indexed by the trip count: a wave-uniform switch moves the half tile's 12 NVG values out first
-        // (as rest position + corrective).
-        f32x4 A0[NB][NWT], A1[NB][NWT], A2[NB][NWT];
+        // The half tiles run as a LOOP (two per trip: the transform and exchange buffers alternate, and their bases are immediates
+        // of the reads): unrolled eight-fold, the epilogue alone was 48 KB of straight-line code executed once per tile.  The
+        // accumulators are registers and cannot be indexed by the trip count: a wave-uniform switch moves the half tile's 12 NVG
+        // values out first (as rest position + corrective).  ONE barrier per half tile: with two exchange buffers, "transforms of
+        // h visible" and "exchange of h - 1 complete" are the same barrier, and the rows of h - 1 are stored while the first
+        // transform reads of h are in flight.
+        constexpr int NPAIR = NWT / 2, NST = 4 * NVG * NPAIR;   // a stage = two influences of one (vertex, frame) item
+        f32x4 A0[2][2], A1[2][2], A2[2][2];
         float pp[NVG][4][3];
-#define LBS_GATHER(SET, VG, R, BOFF) { _Pragma("unroll") for (int i = 0; i < NWT; ++i) { const char* tp = lds_raw + (BOFF) + ja[VG][R][i]; \
+#define LBS_GATHER(SET, ST, TOFF) { const int k_ = (ST) / NPAIR, p_ = (ST) % NPAIR; _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+        const char* tp = lds_raw + (TOFF) + ja[k_ >> 2][k_ & 3][2 * p_ + i]; \
         A0[SET][i] = *reinterpret_cast<const f32x4*>(tp); A1[SET][i] = *reinterpret_cast<const f32x4*>(tp + 16); A2[SET][i] = *reinterpret_cast<const f32x4*>(tp + 32); } }
-#define LBS_APPLY(SET, VG, R) { \
-        const float px = pp[VG][R][0], py = pp[VG][R][1], pz = pp[VG][R][2]; \
-        float ox = 0.0f, oy = 0.0f, oz = 0.0f; \
-        _Pragma("unroll") for (int i = 0; i < NWT; ++i) { const float w = ww[VG][R][i]; \
-            ox = fmaf(w, fmaf(A0[SET][i].x, px, fmaf(A0[SET][i].y, py, fmaf(A0[SET][i].z, pz, A0[SET][i].w))), ox); \
-            oy = fmaf(w, fmaf(A1[SET][i].x, px, fmaf(A1[SET][i].y, py, fmaf(A1[SET][i].z, pz, A1[SET][i].w))), oy); \
-            oz = fmaf(w, fmaf(A2[SET][i].x, px, fmaf(A2[SET][i].y, py, fmaf(A2[SET][i].z, pz, A2[SET][i].w))), oz); } \
-        float* so = reinterpret_cast<float*>(Sx + sxw + ((VG) * 16 + (R)) * 12); so[0] = ox; so[1] = oy; so[2] = oz; }
-        // item k = 4 vg + r; the 12 transform reads of item k + 1 are issued before item k is computed
-#define LBS_ITEM(K, BOFF) { if constexpr (NB == 2) { if ((K) + 1 < 4 * NVG) LBS_GATHER(((K) + 1) & 1, ((K) + 1) >> 2, ((K) + 1) & 3, BOFF) LBS_APPLY((K) & 1, (K) >> 2, (K) & 3) } \
-        else { LBS_GATHER(0, (K) >> 2, (K) & 3, BOFF) LBS_APPLY(0, (K) >> 2, (K) & 3) } }
 #define LBS_TAKE(H) { _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int r = 0; r < 4; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
         pp[vg][r][c] = fmaf(isc, acc[vg][H][c][r], vs[vg][r][c]); }
-#define LBS_HALF(H, BOFF) { \
-        if ((H) > 0 && full && dbg == 0) LBS_WAIT_VM(2 * RPW); else LBS_WAIT_VM(0);   /* the row stores of half tile h - 1 are younger than the DMA pieces: they stay in flight */ \
+        // wave w writes rows w, w + NWAVE, ... of a half tile: 96 16-byte chunks per row = one full wave store + one half-wave store.
+        // The stores of half tile h - 1 are issued one at a time between the stages of h: back to back, a wave's second store
+        // waits at the issue stage while the address unit works through the other waves' (24 KB per half tile at 64 B/clk).
+        auto row_store_part = [&](int h, int soff, int idx) {   // store instruction idx (0 .. 2 RPW - 1) of half tile h's rows
+            const int i = idx >> 1, part = idx & 1;
+            if (part == 1 && lane >= 32) return;
+            const int row = wv + NWAVE * i, f = f0 + 16 * h + row;
+            const f32x2* sp = reinterpret_cast<const f32x2*>(Sx + soff + row * (LBS_SXP * 4) + lane * 16 + part * 1024);
+            const f32x2 lo = sp[0], hi = sp[1];
+            const f32x4u val = {lo.x, lo.y, hi.x, hi.y};
+            float* o = out + ((size_t)f * V + v0) * 3 + lane * 4 + part * 256;
+            const int c = (lane + 64 * part) * 4;
+            if (dbg & 18) return;
+            // (streaming stores: the output must not evict the posedirs fragments the k-loop re-reads from L2)
+            if (full) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
+            else if (f < F) {
+                if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
+                else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e];
+            }
+        };
+#define LBS_HALF(H, TOFF, SOFF) { \
+        /* the transforms of this half tile: its DMA pieces are older than the row stores of half tile H - 2, which stay in flight */ \
+        if ((H) >= 2 && full && (dbg & ~16) == 0) LBS_WAIT_VM(2 * RPW); else LBS_WAIT_VM(0); \
         LBS_LDS_BARRIER(); \
-        if ((H) + 1 < 8) stage_dma((H) + 1, ((H) + 1) & 1); \
+        LBS_STAMP(3 + 3 * ((H) & 7)) \
+        const char* dsrc_ = ((H) + 1 < 8) ? asrc + (size_t)((H) + 1) * tlb : asrc_next;   /* next half tile's transforms (the next tile's first) */ \
+        const bool dgo_ = ((H) + 1 < 8) || (idx + nslots < ntiles); \
+        for (int q = NST / 2; dgo_ && q * NWAVE + wv < npieces; ++q) dma_piece(dsrc_, ((H) + 1) & 1, q * NWAVE + wv); \
         switch (H) { case 0: LBS_TAKE(0) break; case 1: LBS_TAKE(1) break; case 2: LBS_TAKE(2) break; case 3: LBS_TAKE(3) break; \
                      case 4: LBS_TAKE(4) break; case 5: LBS_TAKE(5) break; case 6: LBS_TAKE(6) break; default: LBS_TAKE(7) break; } \
-        if constexpr (NB == 2) LBS_GATHER(0, 0, 0, BOFF) \
-        LBS_ITEM(0, BOFF) LBS_ITEM(1, BOFF) LBS_ITEM(2, BOFF) LBS_ITEM(3, BOFF) \
-        if constexpr (NVG == 2) { LBS_ITEM(4, BOFF) LBS_ITEM(5, BOFF) LBS_ITEM(6, BOFF) LBS_ITEM(7, BOFF) } \
-        LBS_LDS_BARRIER();   /* the exchange is complete */ \
-        /* wave w writes rows w, w + NWAVE, ... of the half tile: 96 16-byte chunks per row = one full wave store + one half-wave store */ \
-        _Pragma("unroll") for (int i = 0; i < RPW; ++i) { \
-            const int row = wv + NWAVE * i, f = f0 + 16 * (H) + row; \
-            const char* srow = Sx + row * (LBS_SXP * 4) + lane * 16; \
-            float* orow = out + ((size_t)f * V + v0) * 3 + lane * 4; \
-            _Pragma("unroll") for (int part = 0; part < 2; ++part) { \
-                if (part == 1 && lane >= 32) continue; \
-                const f32x2* sp = reinterpret_cast<const f32x2*>(srow + part * 1024); \
-                const f32x2 lo = sp[0], hi = sp[1]; \
-                const f32x4u val = {lo.x, lo.y, hi.x, hi.y}; \
-                float* o = orow + part * 256; \
-                const int c = (lane + 64 * part) * 4; \
-                if (dbg & 2) continue; \
-                /* (streaming stores: the output must not evict the posedirs fragments the k-loop re-reads from L2) */ \
-                if (full) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o)); \
-                else if (f < F) { \
-                    if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o)); \
-                    else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e]; \
-                } \
-            } \
-        } }
+        LBS_GATHER(0, 0, TOFF) \
+        LBS_STAMP(4 + 3 * ((H) & 7)) \
+        float ox = 0.0f, oy = 0.0f, oz = 0.0f; \
+        _Pragma("unroll") for (int st = 0; st < NST; ++st) { \
+            if (st + 1 < NST) { if (st & 1) LBS_GATHER(0, st + 1, TOFF) else LBS_GATHER(1, st + 1, TOFF) } \
+            /* memory instructions one at a time between the stages (the address unit serialises them): first the DMA pieces of the next \
+               half tile, then the row stores of the previous one -- all stores younger than all pieces, which the counted wait relies on */ \
+            if (st < NST / 2) { if (dgo_ && st * NWAVE + wv < npieces) dma_piece(dsrc_, ((H) + 1) & 1, st * NWAVE + wv); } \
+            else if ((H) >= 1 && st - NST / 2 < 2 * RPW) row_store_part((H) - 1, LBS_SXBYTES - (SOFF), st - NST / 2); \
+            const int k_ = st / NPAIR, p_ = st % NPAIR, set_ = st & 1; \
+            const float px = pp[k_ >> 2][k_ & 3][0], py = pp[k_ >> 2][k_ & 3][1], pz = pp[k_ >> 2][k_ & 3][2]; \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) { const float w = ww[k_ >> 2][k_ & 3][2 * p_ + i]; \
+                ox = fmaf(w, fmaf(A0[set_][i].x, px, fmaf(A0[set_][i].y, py, fmaf(A0[set_][i].z, pz, A0[set_][i].w))), ox); \
+                oy = fmaf(w, fmaf(A1[set_][i].x, px, fmaf(A1[set_][i].y, py, fmaf(A1[set_][i].z, pz, A1[set_][i].w))), oy); \
+                oz = fmaf(w, fmaf(A2[set_][i].x, px, fmaf(A2[set_][i].y, py, fmaf(A2[set_][i].z, pz, A2[set_][i].w))), oz); } \
+            if (p_ == NPAIR - 1) { float* so = reinterpret_cast<float*>(Sx + (SOFF) + sxw + ((k_ >> 2) * 16 + (k_ & 3)) * 12); so[0] = ox; so[1] = oy; so[2] = oz; ox = 0.0f; oy = 0.0f; oz = 0.0f; } \
+        } \
+        LBS_STAMP(5 + 3 * ((H) & 7)) }
 #pragma unroll 1
         for (int h2 = 0; h2 < 8; h2 += 2) {
-            LBS_HALF(h2, 0)
-            LBS_HALF(h2 + 1, LBS_TLMAX)
+            LBS_HALF(h2, 0, 0)
+            LBS_HALF(h2 + 1, LBS_TLMAX, LBS_SXBYTES)
         }
-        LBS_LDS_BARRIER();   // the last rows are out of the exchange before the next tile's first half tile writes it
+        LBS_LDS_BARRIER();   // the last exchange is complete
+#pragma unroll
+        for (int q = 0; q < 2 * RPW; ++q) row_store_part(7, LBS_SXBYTES, q);
+        LBS_STAMP(27)
     }
 #undef LBS_LD_A
 #undef LBS_LD_G
 #undef LBS_ST_G
 #undef LBS_LD_B
-#undef LBS_MMA
+#undef LBS_MMA_T
+#undef LBS_LD_A1
 #undef LBS_STEP
 #undef LBS_GATHER
-#undef LBS_APPLY
-#undef LBS_ITEM
 #undef LBS_TAKE
 #undef LBS_HALF
+#undef LBS_STAMP
 }
 
 }  // namespace
@@ -642,7 +713,7 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     int dbg = 0;
-    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 3;   // (development: phase timing by truncation; incomplete output)
+    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 31;   // (development: phase timing by truncation; incomplete output)
     hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(nwave * 64), LBS_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, dbg);
     return hipGetLastError();
 }

@@ -1294,7 +1294,9 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     // (a rank whose arguments are wrong must not just return: the others would wait in the first all-reduce.  Its verdict is summed
     //  over the ranks below, as soon as reduce() exists, and every rank fails together.)
     const bool bad_range = shard && (f_lo < 0 || f_hi > F || nown < 0);
-    const bool bad_owner = shard && own_shared && nown <= 0;   // the arrow solver back-substitutes the shared block on a rank with frames
+    // the arrow solver back-substitutes the shared block on a rank with frames (the dense solver, MOSHII_S1_SOLVER=dense, has no such need)
+    const char* solver_env0 = getenv("MOSHII_S1_SOLVER");
+    const bool bad_owner = shard && own_shared && nown <= 0 && !(solver_env0 && strcmp(solver_env0, "dense") == 0);
     int reduce_rc = 0;
     DevPool pool;
     // sums over the ranks.  reduce(): a host vector; reduce_dev(): one of the solver's device buffers.  With allreduce_on_device the
@@ -1325,10 +1327,20 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         hipStreamSynchronize(st);
     };
     if (shard) {
-        double verdict[2] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0};
-        if (!red_dev) reduce(verdict, 2);      // (the device path needs the pool: its first allocation may fail on its own)
-        else { reduce(verdict, 2); if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed"); }
+        // The device path stages host vectors through d_red: that buffer is sized HERE for the largest vector the solve will ever
+        // stage (the n unknowns; 3 F M marker coordinates) and its allocation status rides in the verdict, so that no rank can drop out of a later all-reduce
+        // because of it.  (A rank that cannot even get these few KB still enters the verdict sum: with the callback's host fallback
+        // if there is one, else it fails alone -- there is nothing to sum on.)
+        double verdict[3] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0, 0.0};
+        if (red_dev) {
+            const long long cap0 = 3LL * M + (long long)F * (3 + NP) + (long long)nb * (d.per_frame ? F : 1) + 3LL * F * M + 6LL * F + 64;   // >= n, 3 F M, 6 F
+            d_red = pool.get<double>((size_t)cap0);
+            d_red_cap = pool.ok ? cap0 : 0;
+            if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed before the first all-reduce (the other ranks were not joined)");
+        }
+        reduce(verdict, 3);
         if (reduce_rc) return fail(MOSHII_ERR_ARG, "stagei: the all-reduce callback failed");
+        if (verdict[2] > 0) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed on a rank");
         if (verdict[0] > 0) return fail(MOSHII_ERR_ARG, "stagei: frame range of a rank out of bounds");
         if (verdict[1] > 0) return fail(MOSHII_ERR_ARG, "stagei: the rank that owns the shared rows must own at least one frame");
     }

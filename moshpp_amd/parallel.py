@@ -175,6 +175,9 @@ def make_allreduce_device(dist):
             torch.cuda.current_stream().synchronize()
         else:
             import ctypes
+            from . import capi
+            if not str(capi.LIB_PATH).endswith('_emu.so'):   # a real GPU build: the pointer is device memory, gloo would read it on the host
+                raise RuntimeError('make_allreduce_device needs the nccl (RCCL) backend on a GPU build; use make_allreduce for ' + str(dist.get_backend()))
             arr = np.ctypeslib.as_array((ctypes.c_double * count).from_address(ptr))
             dist.all_reduce(torch.from_numpy(arr))
     return allreduce

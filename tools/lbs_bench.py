@@ -30,3 +30,12 @@ torch.cuda.synchronize()
 t = e0.elapsed_time(e1) * 1e-3 / reps
 out_bytes = F * sm.V * 12
 print(f'{mt} F={F}: {t*1e6:.1f} us per call, output {out_bytes/1e6:.1f} MB -> {out_bytes/t/1e9:.0f} GB/s ({out_bytes/t/8e12*100:.1f}% of 8 TB/s), {F/t:.0f} frames/s')
+
+import os
+if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
+    torch.cuda.synchronize()
+    st = verts.view(-1)[:2 * 32 * 8].cpu().numpy().view(np.int64).reshape(8, 32)
+    names = ['start', 'prologue done', 'k-loop done'] + [f'h{h} {w}' for h in range(8) for w in ('transforms in', 'blend done', 'exchange ready')] + ['rows out']
+    for ti in range(7):
+        row = st[ti]
+        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(28)) + f' | total {int(row[27] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[27])}' if ti < 6 else ''))

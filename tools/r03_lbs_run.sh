@@ -10,13 +10,12 @@ python tools/lbs_bench.py 2000 10 smplh
 python tools/lbs_bench.py 50000 3 smplh
 echo "# stop=1 (prep + k-loop)"; MOSHII_LBS_STOP=1 python tools/lbs_bench.py 4000 10 smplh
 echo "# stop=2 (no stores)"; MOSHII_LBS_STOP=2 python tools/lbs_bench.py 4000 10 smplh
-echo "# four waves per workgroup"; MOSHII_LBS_WAVES=4 python tools/lbs_bench.py 4000 10 smplh
-echo "# four waves, stop=1"; MOSHII_LBS_WAVES=4 MOSHII_LBS_STOP=1 python tools/lbs_bench.py 4000 10 smplh
-echo "# four waves, stop=2"; MOSHII_LBS_WAVES=4 MOSHII_LBS_STOP=2 python tools/lbs_bench.py 4000 10 smplh
+echo "# stamps (clock64 ticks of workgroup 0, wave 0)"; MOSHII_LBS_STOP=16 python tools/lbs_bench.py 4000 2 smplh
+echo "# stamps, four waves"; MOSHII_LBS_WAVES=4 MOSHII_LBS_STOP=16 python tools/lbs_bench.py 4000 2 smplh
 } > $O/timings.txt 2>&1
 grep -v amdgpu.ids $O/timings.txt
 export PYTHONPATH=/root/repo
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/$O/trace -o lbs -- python /root/repo/tools/lbs_bench.py 4000 10 smplh > /root/repo/$O/rocprof_stdout.txt 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/trace -o lbs -- python /root/repo/tools/lbs_bench.py 4000 10 smplh > /root/repo/$O/rocprof_stdout.txt 2>&1)
 find $O/trace -type f | head; for f in $(find $O/trace -name "*stats*.csv"); do cp $f $O/; head -8 $f; done
 rm -rf $O/trace
 rocprofv3 -L 2>/dev/null | grep -i "icache\|ifetch\|SQC_" | head -40 > $O/counters_icache.txt; cat $O/counters_icache.txt
