@@ -456,12 +456,13 @@ def main():
             # consumes it (f16 posedirs, f32 rest vertices, sparse skinning weights as (joint, weight) pairs)
             model_bytes = 2 * 3 * sm.V * 9 * (Kj - 1) + 12 * sm.V + 8 * 4 * sm.V
             bytes_alg = Fl * (12 * sm.V + 4 * sm.NP + 12) + model_bytes
-            result['roofline_lbs'] = {'kernel': 'k_lbs_mfma (+ k_lbs_prep)', 'bound': 'hbm', 'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives', 'achieved': round(bytes_alg / lt / 1e9, 1),
+            result['roofline_lbs'] = {'kernel': 'k_lbs_tile (+ k_lbs_prep)', 'bound': 'hbm', 'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives (max error vs the f64 kernel 7e-6 m)',
+                                      'achieved': round(bytes_alg / lt / 1e9, 1),
                                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
-                                      # PMC at F=4000 (profiles/r01_lbs_pmc.txt): FETCH_SIZE 234.8 MB (x2 -> 469.6 MB), WRITE_SIZE 430.7 MB
-                                      # (+ k_lbs_prep 2 x 1.2 + 13.4 MB)
-                                      'traffic': int((2 * 234.794e6 + 430.65e6 + 2 * 1.175e6 + 13.376e6) * Fl / 4000.0),
-                                      'traffic_source': 'rocprofv3 PMC at F=4000 (profiles/r01_lbs_pmc.txt), scaled by frames; not collected live',
+                                      # PMC at F=4000 (profiles/r03_lbs_pmc.txt): k_lbs_tile FETCH_SIZE 145.3 MB (x2 -> 290.5 MB), WRITE_SIZE 349.6 MB;
+                                      # k_lbs_prep FETCH 1.2 MB (x2), WRITE 13.5 MB
+                                      'traffic': int((2 * 145.274e6 + 349.589e6 + 2 * 1.165e6 + 13.5e6) * Fl / 4000.0),
+                                      'traffic_source': 'rocprofv3 PMC at F=4000 (profiles/r03_lbs_pmc.txt), scaled by frames; not collected live',
                                       'frames': Fl, 'kernel_ms': round(lt * 1e3, 3),
                                       'frames_per_s': round(Fl / lt, 1)}
         except Exception as e:   # the LBS leg must never take the headline number down
