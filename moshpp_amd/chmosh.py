@@ -259,10 +259,14 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     obs, vis = mocap.markers_aslabeled_arrays(latent_labels, selected_frames)
 
     # 5. the frame loop (:584-724) on the GPU
-    # chain mode: the chunk-parallel solve (same result as the reference's frame order to `verify_tol`) unless
-    # a variable with long memory is free -- finger, expression or DMPL coefficients: a chunk start then never reproduces the
-    # chain and the scheme degenerates to the sequential sweep it falls back on -- or the cfg asks for the literal order
-    default_mode = 'sequential' if (solver.optimize_fingers or solver.optimize_face or solver.optimize_dynamics) else 'chunked'
+    # chain mode.  DEFAULT: 'sequential' -- the reference's literal frame order on one workgroup, bit-reproducible from run to run.
+    # 'chunked' (cfg.moshpp_amd.chain_mode) is an explicit opt-in: the same chain cut into concurrently solved chunks whose hand-offs
+    # are verified to `verify_tol` and repaired (12x faster on the bench sequence).  It ends on the sequential
+    # chain to `verify_tol` -- except on ill-conditioned stretches, where a 1e-13 difference in a hand-off state is amplified to
+    # another, equally valid local solution (2 of 13 seeded sequences: up to 5e-2 rad over a few hundred frames, markers < 1 mm
+    # apart; tests/test_gpu_fullsize.py) -- and which chunk is repaired by which chain depends on timing, so the last digits of a
+    # result can differ between runs.  A drop-in default must not have either property.
+    default_mode = 'sequential'
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
                        verify_tol=float(_get(ext, 'verify_tol', 1e-11)))
