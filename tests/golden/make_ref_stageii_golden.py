@@ -235,8 +235,22 @@ class Select(Ch):
         out = self.__dict__['parent'].r[self.__dict__['idx']]
         return np.atleast_1d(out) if np.ndim(out) == 0 else out   # chumpy: x[i] of a vector is a 1-element Ch
 
-    def __setitem__(self, idx, value):       # e.g. can_model.betas[:n][...]: not used by the path; kept explicit
-        raise NotImplementedError('assignment through a view of a view')
+    def _base_and_map(self):
+        """(base Array, flat indices of this view's elements in it): chumpy's Select is a Permute, and item assignment on a
+        Permute of a leaf writes through to the leaf (ch.py: Ch.__setitem__)."""
+        p = self.__dict__['parent']
+        if isinstance(p, Array):
+            base, pmap = p, np.arange(p.r.size).reshape(p.r.shape)
+        else:
+            assert isinstance(p, Select), 'assignment through a view: only views of arrays'
+            base, pmap = p._base_and_map()
+        return base, pmap[self.__dict__['idx']]
+
+    def __setitem__(self, idx, value):       # can_model.shapedirs[:, :, nb:nb + nd] = dmpl_pcs (chmosh.py:512): a view of the loaded model's array
+        base, fmap = self._base_and_map()
+        x = base.__dict__['x']
+        x.reshape(-1)[np.asarray(fmap[idx]).ravel()] = np.broadcast_to(_val(value), np.shape(fmap[idx])).ravel()
+        base.__dict__['_own_ver'] = _tick()
 
     def set_value(self, v):
         p = self.__dict__['parent']
@@ -365,14 +379,15 @@ class VertsDecorated(Ch):
     def _model(self):
         d = self.__dict__
         b = np.asarray(self.betas.r, dtype=np.float64)
-        if d['_prepared'] is None or not np.array_equal(d['_prepared'][0], b):
+        sv = d['shapedirs']._version() if _is_ch(d['shapedirs']) else 0     # (the DMPL branch rewrites shapedirs columns after construction)
+        if d['_prepared'] is None or not np.array_equal(d['_prepared'][0], b) or d['_prepared'][2] != sv:
             kt = np.asarray(d['kintree_table'])
             parents = [-1] + [int(p) for p in kt[0, 1:]]
             nb = len(b)
             model = dict(v_template=_val(d['v_template']), shapedirs=_val(d['shapedirs'])[:, :, :nb], posedirs=_val(d['posedirs']),
                          weights=_val(d['weights']), J_regressor=d['J_regressor'], parents=parents,
                          body_dof=3 * kt.shape[1], hand_dof=0, hands_mean=None, selected_components=None)
-            d['_prepared'] = (b.copy(), so.prepare_model(model, b))
+            d['_prepared'] = (b.copy(), so.prepare_model(model, b), sv)
         return d['_prepared'][1]
 
     def compute_r(self):
@@ -402,12 +417,14 @@ class Cfg(dict):
 
 
 def run_reference_stageii(model_type, n_frames, n_markers, seed, n_verts, empty_frames=(), optimize_fingers=False,
-                          optimize_toes=False):
+                          optimize_toes=False, optimize_face=False, optimize_dynamics=False, n_free_shape=0):
     """Builds the seeded case (tests/golden/ref_inputs.stageii_case: files on disk, as the reference reads them) and runs the
     reference's mosh_stageii on it.  Returns (result dict, case)."""
     from tests.golden.ref_inputs import stageii_case
     tmp = tempfile.mkdtemp(prefix='ref_stageii_')
-    case = stageii_case(model_type, n_frames, n_markers, seed, n_verts, tmp, empty_frames=empty_frames, finger_markers=optimize_fingers)
+    case = stageii_case(model_type, n_frames, n_markers, seed, n_verts, tmp, empty_frames=empty_frames, finger_markers=optimize_fingers,
+                        face_markers=optimize_face, n_free_shape=n_free_shape,
+                        shape_kind='expr' if optimize_face else ('dmpl' if optimize_dynamics else None))
     # the reference modules, from their files
     _module('moshpp'); _module('moshpp.models'); _module('moshpp.prior'); _module('moshpp.tools'); _module('moshpp.marker_layout')
     sfd = load_ref('moshpp.models.smpl_fast_derivatives', 'models/smpl_fast_derivatives.py')
@@ -424,16 +441,18 @@ def run_reference_stageii(model_type, n_frames, n_markers, seed, n_verts, empty_
     ns = {'np': np, 'ch': ch, 'pickle': pickle, 'DictConfig': dict, 'logger': _quiet, 'MocapSession': mi.MocapSession,
           'general_labels_map': lm.general_labels_map, 'load_moshpp_models': bml.load_moshpp_models,
           'TransformedCoeffs': tlm.TransformedCoeffs, 'TransformedLms': tlm.TransformedLms,
-          'perform_rigid_adjustment': rig.perform_rigid_adjustment, 'visualize_pose_estimate': None}
+          'perform_rigid_adjustment': rig.perform_rigid_adjustment, 'visualize_pose_estimate': None,
+          # the DMPL branch reads its pickle through a TEXT-mode open() (chmosh.py:511, Python-2 era): pickle.load needs bytes
+          'open': lambda fname, *a: open(fname, 'rb')}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), 'chmosh.py', 'exec'), ns)
     cfg = Cfg.of(dict(
         mocap=dict(unit='m', rotate=None, subject_name=None, multi_subject=False, start_fidx=0, end_fidx=-1, ds_rate=1),
-        moshpp=dict(optimize_fingers=optimize_fingers, optimize_face=False, optimize_toes=optimize_toes, optimize_dynamics=False,
+        moshpp=dict(optimize_fingers=optimize_fingers, optimize_face=optimize_face, optimize_toes=optimize_toes, optimize_dynamics=optimize_dynamics,
                     pose_hand_prior_fname=case['hand_prior_fname'], pose_body_prior_fname=case['body_prior_fname'], verbosity=0,
                     visualization=dict(marker_radius=dict(body=0.009))),
         surface_model=dict(fname=case['model_fname'], type=model_type, use_hands_mean=case['use_hands_mean'],
-                           dof_per_hand=case['dof_per_hand'], num_betas=len(case['betas']), num_dmpls=0, num_expressions=0,
-                           betas_expr_start_id=300),
+                           dof_per_hand=case['dof_per_hand'], num_betas=16, num_dmpls=n_free_shape if optimize_dynamics else 0,
+                           num_expressions=n_free_shape if optimize_face else 0, betas_expr_start_id=16, dmpl_fname=case['dmpl_fname']),
         opt_settings=dict(maxiter=100, weights=dict(so.stageii_weights_default()))))
     del N_MINIMIZE[:]
     out = ns['mosh_stageii'](case['mocap_fname'], cfg, case['markers_latent'], case['latent_labels'], case['betas'],
@@ -441,20 +460,33 @@ def run_reference_stageii(model_type, n_frames, n_markers, seed, n_verts, empty_
     return out, case
 
 
-CASES = {   # name: (model_type, frames, markers, seed, vertices, empty frames, optimize_fingers)
-    'smplh_body': ('smplh', 6, 53, 3, 1500, (3,), False),    # BASELINE config 2's shape: SMPL-H, 53 markers, fixed betas; one empty frame
-    'smpl_body': ('smpl', 5, 41, 4, 1200, (), False),        # BASELINE config 1's shape: SMPL, 41 markers; dropouts -> annealed weights
-    'smplh_fingers': ('smplh', 4, 66, 5, 1500, (), True),    # Step 2 frees the hand coefficients and adds the poseH term (chmosh.py:681-683)
+CASES = {   # name: dict(model_type, frames, markers, seed, vertices, + switches)
+    'smplh_body': dict(mt='smplh', F=6, M=53, seed=3, V=1500, empty=(3,)),   # BASELINE config 2's shape: SMPL-H, 53 markers, fixed betas; one empty frame
+    'smpl_body': dict(mt='smpl', F=5, M=41, seed=4, V=1200),                 # BASELINE config 1's shape: SMPL, 41 markers; dropouts -> annealed weights
+    'smplh_fingers': dict(mt='smplh', F=4, M=66, seed=5, V=1500, fingers=True),   # Step 2 frees the hand coefficients and adds the poseH term (chmosh.py:681-683)
+    # round 3: the remaining branches of the schedule
+    'smplh_toes': dict(mt='smplh', F=4, M=53, seed=6, V=1500, toes=True),    # optimize_toes: pose ids 30:36 stay free (:646-647, 666-667, 678-679)
+    'mano_fingers': dict(mt='mano', F=4, M=24, seed=7, V=700, fingers=True),  # MANO: no body ids, no poseB term, pose_finger_ids = all_pose_ids[3:] (:569-570)
+    'smplx_face': dict(mt='smplx', F=4, M=60, seed=8, V=1600, face=True, E=4),   # jaw ids 66:69 + poseF + expr terms, expression block free (:562-567, 685-689, 721-724)
+    'smplh_dmpl': dict(mt='smplh', F=5, M=53, seed=9, V=1500, dynamics=True, E=3),   # DMPL block free, dmpl / extrap_dmpl terms, dmpl_prev refresh order (:507-514, 658-659, 694-699, 719-720)
 }
 
 
 def main():
     out = {}
-    for name, (mt, F, M, seed, V, empty, fingers) in CASES.items():
-        res, case = run_reference_stageii(mt, F, M, seed, V, empty_frames=empty, optimize_fingers=fingers)
+    for name, cs in CASES.items():
+        mt, F, M, seed, V = cs['mt'], cs['F'], cs['M'], cs['seed'], cs['V']
+        empty, fingers = cs.get('empty', ()), cs.get('fingers', False)
+        res, case = run_reference_stageii(mt, F, M, seed, V, empty_frames=empty, optimize_fingers=fingers, optimize_toes=cs.get('toes', False),
+                                          optimize_face=cs.get('face', False), optimize_dynamics=cs.get('dynamics', False),
+                                          n_free_shape=cs.get('E', 0))
         dbg = res['stageii_debug_details']
         out[f'{name}_args'] = np.array([F, M, seed, V] + list(empty), dtype=np.int64)
         out[f'{name}_fingers'] = np.array(bool(fingers))
+        out[f'{name}_switches'] = np.array([int(cs.get('toes', False)), int(cs.get('face', False)), int(cs.get('dynamics', False)), int(cs.get('E', 0))])
+        for k in ('expression', 'dmpls'):
+            if k in res:
+                out[f'{name}_{k}'] = np.asarray(res[k])
         out[f'{name}_fullpose'] = np.asarray(res['fullpose'])
         out[f'{name}_trans'] = np.asarray(res['trans'])
         out[f'{name}_keys'] = np.array(sorted(res.keys()))

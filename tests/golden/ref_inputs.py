@@ -217,7 +217,7 @@ def layout_creation_inputs():
 
 
 def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_frames=(), dof_per_hand=12, use_hands_mean=True,
-                 finger_markers=False):
+                 finger_markers=False, face_markers=False, n_free_shape=0, shape_kind=None):
     """One seeded Stage-II call as the reference reads it: model pickle, hand-prior npz, body-prior pickle and the mocap npz
     written to `outdir`, plus the in-memory arguments of mosh_stageii.  The synthetic body is the triangulated capsule model
     (synth.synth_mesh_model) at `n_verts` vertices: small enough for a finite-difference Jacobian of the reference's residuals.
@@ -225,10 +225,36 @@ def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_f
     import pickle
     import scipy.sparse as sp
     from moshpp_amd import synth
-    dd = synth.synth_mesh_model(model_type, seed=seed, n_verts=n_verts)
+    # free shape block of Step 2 (chmosh.py:507-514, 562-567, 685-699): `n_free_shape` extra shapedirs columns [16, 16 + E), boosted
+    # so that half a millimetre of marker noise moves the coefficients visibly.  shape_kind 'expr': the model file carries them
+    # (betas_expr_start_id = 16); 'dmpl': the model file carries zeros there and the directions come from a DMPL pickle
+    # ({'eigvec': [V, 3, E]}), which the reference writes over can_model.shapedirs[:, :, 16:16 + E] (:511-512).
+    NB = 16 + int(n_free_shape)
+    dd = synth.synth_mesh_model(model_type, seed=seed, n_verts=n_verts, num_betas=NB)
+    free_dirs = None
+    if n_free_shape:
+        dd = dict(dd)
+        sd = np.array(dd['shapedirs'], dtype=np.float64)
+        sd[:, :, 16:] *= 6.0 / np.maximum(np.abs(sd[:, :, 16:]).max(axis=(0, 1), keepdims=True) / 0.005, 1e-12)
+        free_dirs = sd[:, :, 16:].copy()
+        if shape_kind == 'dmpl':
+            sd[:, :, 16:] = 0.0
+        dd['shapedirs'] = sd
     s = synth.make_sequence(model_type, n_frames, n_markers, seed=seed, dd=dd, dof_per_hand=dof_per_hand,
                             use_hands_mean=use_hands_mean, empty_frames=tuple(empty_frames), n_gaps=1, dropout=0.04,
-                            body_only_markers=not finger_markers)
+                            body_only_markers=not finger_markers, num_betas=NB)
+    if n_free_shape:
+        s['betas'] = s['betas'].copy()
+        s['betas'][16:] = 0.0
+    if face_markers:     # optimize_face stays on only with 'face' typed markers in the layout (chmosh.py:474-486): the head's
+        K = dd['weights'].shape[1]
+        head = {'smplx': 15}[model_type]
+        on_head = np.array([int(np.argmax(dd['weights'][v])) == head for v in s['marker_meta']['marker_vids'].values()])
+        assert on_head.any()
+        mm = s['marker_meta']
+        mm['marker_type'] = {l: ('face' if h else 'body') for l, h in zip(s['latent_labels'], on_head)}
+        mm['marker_type_mask'] = {'body': ~on_head, 'face': on_head}
+        mm['m2b_distance'] = {'body': 0.0095, 'face': 0.0095}
     if finger_markers:   # the reference switches optimize_fingers off unless the layout has 'finger' typed markers (chmosh.py:474-486)
         K = dd['weights'].shape[1]
         hand0 = (3 * K - 90) // 3
@@ -252,8 +278,14 @@ def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_f
         body_prior_fname = os.path.join(outdir, 'body_prior.pkl')
         with open(body_prior_fname, 'wb') as fh:
             pickle.dump(s['gmm'], fh, protocol=2)
+    dmpl_fname = None
+    if shape_kind == 'dmpl':
+        dmpl_fname = os.path.join(outdir, 'dmpl.pkl')
+        with open(dmpl_fname, 'wb') as fh:
+            pickle.dump({'eigvec': free_dirs}, fh, protocol=2)
     mocap_fname = os.path.join(outdir, 'mocap.npz')
     np.savez(mocap_fname, markers=s['markers'], labels=np.array(s['labels']), frame_rate=s['frame_rate'])
     return dict(s=s, model_fname=model_fname, hand_prior_fname=hand_prior_fname, body_prior_fname=body_prior_fname,
                 mocap_fname=mocap_fname, markers_latent=s['markers_latent'], latent_labels=s['latent_labels'], betas=s['betas'],
-                marker_meta=s['marker_meta'], dof_per_hand=dof_per_hand, use_hands_mean=use_hands_mean, model_type=model_type)
+                marker_meta=s['marker_meta'], dof_per_hand=dof_per_hand, use_hands_mean=use_hands_mean, model_type=model_type,
+                dmpl_fname=dmpl_fname, free_dirs=free_dirs, n_free_shape=int(n_free_shape), shape_kind=shape_kind)

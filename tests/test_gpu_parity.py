@@ -480,24 +480,43 @@ def test_host_level_chunks_carry_the_free_shape_block(gpu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['smplh_body', 'smpl_body', 'smplh_fingers'])
+@pytest.mark.parametrize('name', ['smplh_body', 'smpl_body', 'smplh_fingers', 'smplh_toes', 'mano_fingers', 'smplx_face', 'smplh_dmpl'])
 def test_chain_matches_the_executed_reference_stageii(gpu_lib, name, tmp_path):
     """The kernel against tests/golden/ref_stageii.npz: the trajectory the REFERENCE's own mosh_stageii (chmosh.py:458-741,
     executed by tests/golden/make_ref_stageii_golden.py under a lazy chumpy stand-in) produced on the same seeded files --
-    poses, translations, per-term errors, skipped frames and dogleg iterations per frame."""
+    poses, translations, per-term errors, skipped frames and dogleg iterations per frame; since round 3 over every branch of the
+    schedule the kernels implement: optimize_toes, MANO (no body prior), optimize_face (jaw + expression block, extended kernel),
+    optimize_dynamics (DMPL block with its stay term)."""
     from moshpp_amd import capi
     from tests.test_ref_golden import _stageii_ref_case, _check_against_reference_run
     c = _stageii_ref_case(name, tmp_path)
     ref = c['ref']
-    dev = device_case(c, optimize_fingers=c['fingers'])
+    c['start'] = 16
+    dev = device_case(c, optimize_fingers=c['fingers'], optimize_toes=c['toes'], optimize_face=c['face'], shape_kind=c['free_shape'])
     out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
                                 [dict(attach=dev['attach'], obs=c['obs'], vis=c['vis'], first=True)])[0]
     solved = np.where(out['status'] == 0)[0]
-    errs = dict(data=out['errs'][solved, 0], poseB=out['errs'][solved, 1], velo=out['errs'][solved[2:], 2])
+    errs = dict(data=out['errs'][solved, 0], velo=out['errs'][solved[2:], 2])
+    if c['prior'] is not None:
+        errs['poseB'] = out['errs'][solved, 1]
     if c['fingers']:
         errs['poseH'] = out['errs'][solved, 3]
+    if c['face']:
+        errs['poseF'] = out['errs'][solved, 4]
+    if c['free_shape']:
+        errs['shape'] = out['errs'][solved, 5]
+        errs['_shape_kind'] = c['free_shape']
+        if c['free_shape'] == 'dmpl':
+            errs['shape_stay'] = out['errs'][solved[1:], 6]
     _check_against_reference_run(name, ref, out['fullpose'][solved], out['trans'][solved], errs, solved, c['vis'],
                                  c['s']['latent_labels'])
+    if c['free_shape'] == 'expr':
+        assert np.abs(out['shape'][solved] - ref[f'{name}_expression'][:, :c['E']]).max() < 1e-6
+        np.testing.assert_allclose(errs['shape'], ref[f'{name}_err_expr'], rtol=1e-4)
+    if c['free_shape'] == 'dmpl':
+        assert np.abs(out['shape'][solved] - ref[f'{name}_dmpls']).max() < 1e-6
+        np.testing.assert_allclose(errs['shape'], ref[f'{name}_err_dmpl'], rtol=1e-4)
+        np.testing.assert_allclose(errs['shape_stay'], ref[f'{name}_err_extrap_dmpl'], rtol=1e-4, atol=1e-14)
     calls = ref[f'{name}_minimize_calls']
     per_frame = [int(calls[:5, 2].sum())] + [int(calls[5 + 2 * i:7 + 2 * i, 2].sum()) for i in range(len(solved) - 1)]
     assert per_frame == [int(v) for v in out['iters'][solved, 0]]

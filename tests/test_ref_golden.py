@@ -251,7 +251,9 @@ def test_marker_layout_creation_matches_reference_functions(case, tmp_path):
 
 
 # ---- the Stage-II schedule itself: the reference's mosh_stageii EXECUTED (tests/golden/make_ref_stageii_golden.py) ------------
-STAGEII_REF_CASES = {'smplh_body': 'smplh', 'smpl_body': 'smpl', 'smplh_fingers': 'smplh'}
+STAGEII_REF_CASES = {'smplh_body': 'smplh', 'smpl_body': 'smpl', 'smplh_fingers': 'smplh',
+                     # round 3: optimize_toes, MANO (no body prior), optimize_face (jaw + expressions), optimize_dynamics (DMPL)
+                     'smplh_toes': 'smplh', 'mano_fingers': 'mano', 'smplx_face': 'smplx', 'smplh_dmpl': 'smplh'}
 
 
 def _stageii_ref_case(name, tmp_path):
@@ -264,21 +266,39 @@ def _stageii_ref_case(name, tmp_path):
     empty = tuple(int(v) for v in ref[f'{name}_args'][4:])
     mt = STAGEII_REF_CASES[name]
     fingers = bool(ref[f'{name}_fingers'])
-    c = stageii_case(mt, F, M, seed, V, str(tmp_path), empty_frames=empty, finger_markers=fingers)
+    toes, face, dynamics, E = [int(v) for v in ref[f'{name}_switches']] if f'{name}_switches' in ref.files else (0, 0, 0, 0)
+    kind = 'expr' if face else ('dmpl' if dynamics else None)
+    c = stageii_case(mt, F, M, seed, V, str(tmp_path), empty_frames=empty, finger_markers=fingers, face_markers=bool(face),
+                     n_free_shape=E, shape_kind=kind)
     s = c['s']
     dd = s['model']
     bd, hd, hm, comps = pose_layout(s)
-    model = dict(v_template=dd['v_template'], shapedirs=dd['shapedirs'], posedirs=dd['posedirs'], weights=dd['weights'],
+    shapedirs = np.array(dd['shapedirs'], dtype=np.float64)
+    if kind == 'dmpl':      # what the reference does with the DMPL pickle (chmosh.py:511-512): the directions overwrite columns 16 .. 16 + E
+        shapedirs[:, :, 16:16 + E] = c['free_dirs']
+    model = dict(v_template=dd['v_template'], shapedirs=shapedirs, posedirs=dd['posedirs'], weights=dd['weights'],
                  J_regressor=dd['J_regressor'], parents=synth.kintree_parents(mt), body_dof=bd, hand_dof=hd, hands_mean=hm,
                  selected_components=comps)
     m = so.prepare_model(model, s['betas'])
+    if E:
+        so.set_free_shape(m, 16, E)
     can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
     closest, coef = so.transformed_coeffs(can, s['markers_latent'])
-    prior = so.prepare_gmm_prior(s['gmm'], 63 if mt in ('smplh', 'smplx') else 69)
+    prior = None if mt == 'mano' else so.prepare_gmm_prior(s['gmm'], 63 if mt in ('smplh', 'smplx') else 69)
     obs = np.nan_to_num(s['markers'])
     vis = ~np.isnan(s['markers']).any(-1)
     return dict(ref=ref, s=s, m=m, model=model, closest=closest, coef=coef, prior=prior, obs=obs, vis=vis, model_type=mt, F=F,
-                fingers=fingers)
+                fingers=fingers, toes=bool(toes), face=bool(face), free_shape=kind, E=E)
+
+
+def ref_term_names(errs):
+    """Our term names -> the reference's: the free shape block's regulariser is 'expr' or 'dmpl' there, its stay term 'extrap_dmpl'."""
+    out = set(errs)
+    if 'shape' in errs:
+        out.add(errs.get('_shape_kind', 'expr'))
+    if 'shape_stay' in errs:
+        out.add('extrap_dmpl')
+    return out
 
 
 def _check_against_reference_run(name, ref, fullpose, trans, errs, frame_ids, vis, labels):
@@ -290,15 +310,19 @@ def _check_against_reference_run(name, ref, fullpose, trans, errs, frame_ids, vi
     assert list(ref[f'{name}_labels_obs']) == ['|'.join(l for l, v in zip(labels, vis[t]) if v) for t in frame_ids]
     assert np.abs(fullpose - ref[f'{name}_fullpose']).max() < 1e-6        # (measured: 5e-9 rad / 2e-12 m for the oracle)
     assert np.abs(trans - ref[f'{name}_trans']).max() < 1e-8
-    fingers = 'poseH' in errs
-    assert list(ref[f'{name}_err_keys']) == (['data', 'poseB', 'poseH', 'velo'] if fingers else ['data', 'poseB', 'velo'])
-    if fingers:
+    # the terms of the objective, in the order the reference's dict first meets them (chmosh.py:612-626, 681-699, 707-710)
+    want = ['data'] + (['poseB'] if 'poseB' in errs else []) + [k for k in ('poseH', 'poseF', 'expr', 'dmpl', 'extrap_dmpl') if k in ref_term_names(errs)] + ['velo']
+    assert list(ref[f'{name}_err_keys']) == want, (list(ref[f'{name}_err_keys']), want)
+    if 'poseH' in errs:
         np.testing.assert_allclose(errs['poseH'], ref[f'{name}_err_poseH'], rtol=1e-5)
+    if 'poseF' in errs:
+        np.testing.assert_allclose(errs['poseF'], ref[f'{name}_err_poseF'], rtol=1e-4, atol=1e-12)
     # the velocity term exists from the THIRD solved frame on: pose_prev is refreshed (chmosh.py:656-657) only after the frame's
     # objective was built (:624-626), so the second solved frame still sees pose_prev = None -- two entries fewer (:707-710)
     assert len(ref[f'{name}_err_velo']) == len(fullpose) - 2
     for k in ('data', 'poseB'):
-        np.testing.assert_allclose(errs[k], ref[f'{name}_err_{k}'], rtol=1e-6)
+        if k in errs:
+            np.testing.assert_allclose(errs[k], ref[f'{name}_err_{k}'], rtol=1e-6)
     velo = np.asarray(errs['velo'])
     np.testing.assert_allclose(velo[len(velo) - len(fullpose) + 2:], ref[f'{name}_err_velo'], rtol=1e-5, atol=1e-14)
 
@@ -309,18 +333,31 @@ def test_stageii_schedule_matches_reference_function(name, tmp_path):
     c = _stageii_ref_case(name, tmp_path)
     ref = c['ref']
     out = so.stageii_chain(c['m'], c['prior'], c['closest'], c['coef'], c['obs'], c['vis'], c['model_type'],
-                           optimize_fingers=c['fingers'])
-    _check_against_reference_run(name, ref, out['fullpose'], out['trans'], out['errs'], out['frame_ids'], c['vis'], c['s']['latent_labels'])
+                           optimize_fingers=c['fingers'], optimize_toes=c['toes'], optimize_face=c['face'], free_shape=c['free_shape'])
+    errs = dict(out['errs'])
+    if c['free_shape']:
+        errs['_shape_kind'] = c['free_shape']
+    _check_against_reference_run(name, ref, out['fullpose'], out['trans'], errs, out['frame_ids'], c['vis'], c['s']['latent_labels'])
+    if c['free_shape'] == 'expr':      # the recorded expression block: all betas from betas_expr_start_id on (chmosh.py:724)
+        assert np.abs(out['shape'] - ref[f'{name}_expression'][:, :c['E']]).max() < 1e-6 and np.abs(out['shape']).max() > 1e-3
+        np.testing.assert_allclose(errs['shape'], ref[f'{name}_err_expr'], rtol=1e-4)
+    if c['free_shape'] == 'dmpl':      # (chmosh.py:719-720), the regulariser, and the "stay" term from the second solved frame on (:694-697)
+        assert np.abs(out['shape'] - ref[f'{name}_dmpls']).max() < 1e-6 and np.abs(out['shape']).max() > 1e-3
+        np.testing.assert_allclose(errs['shape'], ref[f'{name}_err_dmpl'], rtol=1e-4)
+        stay = np.asarray(errs['shape_stay'])
+        np.testing.assert_allclose(stay[len(stay) - len(ref[f'{name}_err_extrap_dmpl']):], ref[f'{name}_err_extrap_dmpl'], rtol=1e-4, atol=1e-14)
+        assert len(ref[f'{name}_err_extrap_dmpl']) == len(out['fullpose']) - 1
     # the simulated markers of the first solved frame, and the keys of the result dict the drop-in returns
     assert np.abs(out['markers_sim'][0] - ref[f'{name}_markers_sim0']).max() < 1e-6
-    assert list(ref[f'{name}_keys']) == ['fullpose', 'stageii_debug_details', 'trans']          # (markers_* / labels_obs move into the details)
+    extra = {'expr': ['expression'], 'dmpl': ['dmpls'], None: []}[c['free_shape']]
+    assert list(ref[f'{name}_keys']) == sorted(['fullpose', 'stageii_debug_details', 'trans'] + extra)          # (markers_* / labels_obs move into the details)
     assert list(ref[f'{name}_debug_keys']) == ['labels_obs', 'labels_orig', 'markers_obs', 'markers_orig', 'markers_sim', 'mocap_fname',
                                                'mocap_frame_rate', 'mocap_time_length', 'stageii_errs']
     # 3 first-frame rounds + Step 1 + Step 2 per solved frame (chmosh.py:637-705)
     calls = ref[f'{name}_minimize_calls']
     assert len(calls) == 3 + 2 * len(out['fullpose'])
-    ids = so.pose_id_sets(c['model_type'], c['m']['NP'], optimize_fingers=c['fingers'])
-    n1, n2 = 3 + len(ids[3]), 3 + len(ids[4])
+    ids = so.pose_id_sets(c['model_type'], c['m']['NP'], optimize_fingers=c['fingers'], optimize_toes=c['toes'], optimize_face=c['face'])
+    n1, n2 = 3 + len(ids[3]), 3 + len(ids[4]) + c['E']
     assert [int(v) for v in calls[:, 0]] == [n1] * 4 + [n2] + [n1, n2] * (len(out['fullpose']) - 1)   # free variables of every solve
     # dogleg iterations per solved frame: the reference-built problem and the oracle's take the same number of steps
     per_frame = [int(calls[:5, 2].sum())] + [int(calls[5 + 2 * i:7 + 2 * i, 2].sum()) for i in range(len(out['fullpose']) - 1)]
