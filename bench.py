@@ -29,6 +29,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   sequential_chain   the literal frame order on the GPU (one workgroup) and the timed mode's deviation from it over ALL frames
   incl_host_staging  the same solve through host buffers (observations in, results out over PCIe)
   many_sequences     32 sequences in one call: the dominant kernel with every CU busy
+  config3            BASELINE config 3 as stated (32 x 4000 SMPL-X frames, 89 markers, fingers + jaw + 80 expressions free: 194 unknowns)
   strong             the fixed jobs above, at this N
   stagei             Stage-I on 12 frames / 53 markers / 10 betas: GPU seconds (dense and arrow-structured solver), iterations, and
                      the NumPy oracle's seconds + differences on the same problem
@@ -121,6 +122,9 @@ def main():
     ap.add_argument('--no-strong', action='store_true', help='skip the fixed-job (strong scaling) legs')
     ap.add_argument('--strong-sequences', type=int, default=32)
     ap.add_argument('--long-frames', type=int, default=50000)
+    ap.add_argument('--no-config3', action='store_true', help='skip the BASELINE config 3 leg (32 x 4000 SMPL-X frames, 194 unknowns: ~30 s)')
+    ap.add_argument('--config3-sequences', type=int, default=32)
+    ap.add_argument('--config3-frames', type=int, default=4000)
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
     args = ap.parse_args()
 
@@ -432,6 +436,41 @@ def main():
             result['many_sequences'] = {'sequences': args.strong_sequences, 'frames': sj['frames'], 'frames_per_s': sj['frames_per_s'], 'ms': sj['ms'],
                                         'roofline': {'kernel': name, 'bound': 'valu_f64', 'achieved': round(mach, 4), 'peak': F64_VALU_PEAK_TFLOPS,
                                                      'unit': 'TFLOP/s', 'frac': round(mach / F64_VALU_PEAK_TFLOPS, 5)}}
+        # ---- BASELINE config 3 as stated: 32 x 4000-frame SMPL-X captures, 89 markers incl. face / hands, fingers + jaw + 80 expression
+        # coefficients free (194 unknowns per Step-2 solve; chmosh.py:560-567, 681-689).  With a free expression block a chunk start
+        # never reproduces the chain's coefficients, so this size class runs one sequential chain per sequence:
+        # 32 of the 256 CUs carry a chain.  Host arrays in and out (the extended kernel's buffers), staging included.
+        if extras and not args.no_config3:
+            try:
+                fj = workload.make_face_job()
+                fsol = workload.make_solver(fj)
+                caps = [workload.make_face_capture(fj, fsol, 7000 + i, n_frames=args.config3_frames) for i in range(args.config3_sequences)]
+                chains = [dict(attach=fsol.attach, obs=c['obs'], vis=c['vis'], first=True) for c in caps]
+                capi.chain_solve_host(fsol.dev, fsol.prior, fsol.opts, [dict(attach=fsol.attach, obs=caps[0]['obs'][:8], vis=caps[0]['vis'][:8], first=True)])
+                t0 = time.perf_counter()
+                fouts = capi.chain_solve_host(fsol.dev, fsol.prior, fsol.opts, chains)
+                dt3 = time.perf_counter() - t0
+                kname3 = capi.last_launch_info()[0]
+                nfr = sum(int((o['status'] != 1).sum()) for o in fouts)
+                it3 = np.concatenate([o['iters'][o['status'] != 1] for o in fouts])
+                d3 = np.concatenate([(o['markers_sim'] - c['obs'])[c['vis']] for o, c in zip(fouts, caps)])
+                ex3 = max(float(np.abs(o['shape'][-1] - c['expr_gt']).max()) for o, c in zip(fouts, caps))
+                smx = fj['sm']
+                fl3 = solver_flops(smx.K, 3 * caps[0]['vis'].shape[1], len(fsol.ids['step1']), len(fsol.ids['step2']) + fsol.n_shape, smx.NP,
+                                   len(fsol.ids['body']), float(np.mean([c['vis'].sum(1).mean() for c in caps])), it3[:, 0].sum(), it3[:, 1].sum())
+                result['config3'] = {
+                    'workload': f'BASELINE config[2] as stated: {args.config3_sequences} distinct {args.config3_frames}-frame SMPL-X captures of one subject, '
+                                f'{caps[0]["vis"].shape[1]} markers incl. face / hand vertices, fingers + jaw + {fsol.n_shape} expression coefficients free '
+                                f'({3 + len(fsol.ids["step2"]) + fsol.n_shape} unknowns per Step-2 solve); one sequential chain per sequence in ONE launch '
+                                f'({args.config3_sequences} of the CUs busy); host arrays in and out',
+                    'kernel': kname3, 'frames': nfr, 'frames_per_s': round(nfr / dt3, 1), 'seconds': round(dt3, 2),
+                    'us_per_frame_per_chain': round(1e6 * dt3 / args.config3_frames, 1),
+                    'dogleg_iterations_per_frame': round(float(it3[:, 0].mean()), 2),
+                    'marker_rmse_m': float(np.sqrt((d3 ** 2).sum(1).mean())), 'final_expression_max_err': ex3,
+                    'roofline': {'kernel': kname3, 'bound': 'valu_f64', 'achieved': round(fl3 / dt3 / 1e12, 4), 'peak': F64_VALU_PEAK_TFLOPS,
+                                 'unit': 'TFLOP/s', 'frac': round(fl3 / dt3 / 1e12 / F64_VALU_PEAK_TFLOPS, 5)}}
+            except Exception as e:
+                result['config3'] = {'error': repr(e)}
         # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names)
         try:
             import ctypes as C

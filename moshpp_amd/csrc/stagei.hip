@@ -98,7 +98,7 @@ struct S1Ptr {
     // per pose
     double *fp, *Rl, *Jl, *Rw, *tw, *feat, *om, *Bm, *Jb, *q; int* featzero;
     // canonical body + attachment + surface
-    double* can; int* cl; double *coef, *Fc, *dcdb; int* tv; double *sdist, *sdp, *sdabc; int* status;
+    double* can; int* cl; int* cl8; double *coef, *Fc, *dcdb; int* tv; double *sdist, *sdp, *sdabc; int* status;
     // vertex evaluations
     int* vlist;               // [NPZ][ncan] global vertex ids (frames use the first 3M entries of the canonical list)
     double *vv, *dvs, *dv, *Lb;
@@ -471,15 +471,20 @@ KERNEL k_s1_vjac(S1Dims d, S1Ptr p, int zbase) {
         SYNC(); \
     }
 
-KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl_out) {
+#define S1_NNK 8          // neighbours kept per marker (transformed_lm.py:73: the kd-tree query asks for 8)
+KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl8_out) {
     SHARED double bd[256]; SHARED int bi[256];
     int m = BX;
     const double* x = p.ml + 3 * m;
-    int found[3] = {-1, -1, -1};
-    for (int pass = 0; pass < 3; ++pass) {
+    int found[S1_NNK];
+    for (int s = 0; s < S1_NNK; ++s) found[s] = -1;
+    for (int pass = 0; pass < S1_NNK; ++pass) {
         double best = 1e300; int besti = 0x7fffffff;
         for (int v = TID; v < d.V; v += NT) {
-            if (p.excl[v] || v == found[0] || v == found[1]) continue;
+            if (p.excl[v]) continue;
+            bool taken = false;
+            for (int s = 0; s < pass; ++s) taken = taken || v == found[s];
+            if (taken) continue;
             double dx = x[0] - p.can[3 * v], dy = x[1] - p.can[3 * v + 1], dz = x[2] - p.can[3 * v + 2];
             double d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < best || (d2 == best && v < besti)) { best = d2; besti = v; }
@@ -490,7 +495,36 @@ KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl_out) {
         found[pass] = bi[0];
         SYNC();
     }
-    if (TID == 0) for (int s = 0; s < 3; ++s) cl_out[3 * m + s] = found[s];
+    if (TID == 0) for (int s = 0; s < S1_NNK; ++s) cl8_out[S1_NNK * m + s] = found[s];
+}
+
+// The attachment's three vertices per marker out of its 8 nearest (transformed_lm.py:88-101): the two nearest and, normally, the
+// third -- but while ANY marker's e1 x e2 vanishes (three collinear neighbours: the reference's nrm() turns 0 / 0 into a NaN and
+// tests for it) the third neighbour of EVERY marker moves on to the next nearest.  One workgroup; status[2] is raised only if the
+// eighth neighbour still leaves a collinear triple.
+KERNEL k_s1_pick3(S1Dims d, S1Ptr p, const int* cl8, int* cl_out) {
+    SHARED int any_bad;
+    int nn = 3;
+    for (;;) {
+        if (TID == 0) any_bad = 0;
+        SYNC();
+        for (int m = TID; m < d.M; m += NT) {
+            const int* c8 = cl8 + S1_NNK * m;
+            const double* v0 = p.can + 3 * c8[0]; const double* v1 = p.can + 3 * c8[1]; const double* v2 = p.can + 3 * c8[nn - 1];
+            double e1[3], e2[3], cr[3];
+            for (int a = 0; a < 3; ++a) { e1[a] = v1[a] - v0[a]; e2[a] = v2[a] - v0[a]; }
+            cross3(e1, e2, cr);
+            if (dot3(cr, cr) == 0.0) any_bad = 1;
+        }
+        SYNC();
+        const int bad = any_bad;
+        SYNC();
+        if (!bad || nn >= S1_NNK || nn >= d.M) { if (bad && TID == 0) p.status[2] = 1; break; }   // (the reference's loop bound is the marker count)
+        ++nn;
+    }
+    for (int m = TID; m < d.M; m += NT) {
+        cl_out[3 * m + 0] = cl8[S1_NNK * m + 0]; cl_out[3 * m + 1] = cl8[S1_NNK * m + 1]; cl_out[3 * m + 2] = cl8[S1_NNK * m + nn - 1];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1396,7 +1430,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     p.Rw = pool.get<double>((size_t)d.NPZ * K * 9); p.tw = pool.get<double>((size_t)d.NPZ * K * 3); p.feat = pool.get<double>((size_t)d.NPZ * d.nfeat);
     p.om = pool.get<double>((size_t)d.NPZ * K * 9); p.Bm = pool.get<double>((size_t)d.NPZ * K * 27); p.Jb = pool.get<double>((size_t)d.NPZ * K * 3);
     p.q = pool.get<double>((size_t)d.NPZ * K * std::max(1, nb) * 3); p.featzero = pool.get<int>(d.NPZ);
-    p.can = pool.get<double>((size_t)3 * d.V); p.cl = pool.get<int>(3 * M); p.coef = pool.get<double>(3 * M); p.Fc = pool.get<double>(9 * M);
+    p.can = pool.get<double>((size_t)3 * d.V); p.cl = pool.get<int>(3 * M); p.cl8 = pool.get<int>(S1_NNK * M); p.coef = pool.get<double>(3 * M); p.Fc = pool.get<double>(9 * M);
     p.dcdb = pool.get<double>((size_t)M * 3 * std::max(1, nb)); p.tv = pool.get<int>(3 * M); p.sdist = pool.get<double>(M);
     p.sdp = pool.get<double>(3 * M); p.sdabc = pool.get<double>(9 * M); p.status = pool.get<int>(4);
     p.vlist = pool.get<int>((size_t)d.NPZ * d.ncan); p.vv = pool.get<double>((size_t)d.NPZ * d.ncan * 3);
@@ -1453,7 +1487,8 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     int shared_rows_on = 1;   // 0 during the extra rigid adjustment: the init / beta / surf / head rows are not part of its objective
     auto evaluate = [&](int want_J) {
         canonical();
-        LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl);
+        LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl8);
+        LAUNCH(k_s1_pick3, 1, 1, S1_TPB, st, d, p, p.cl8, p.cl);
         LAUNCH(k_s1_surface, M, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_lists, (3 * M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_verts, (d.ncan * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0);
@@ -1504,7 +1539,8 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     {
         int Gkeep = d.G; d.G = 0;                      // no prior rows while the column map is empty
         hipMemcpyAsync(d_colmap, colmap.data(), NP * sizeof(int), hipMemcpyHostToDevice, st);
-        LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl0);
+        LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl8);
+        LAUNCH(k_s1_pick3, 1, 1, S1_TPB, st, d, p, p.cl8, p.cl0);
         evaluate(0);                                    // fills coef (== coef0 here) and the posed markers of every frame
         hipMemcpyAsync(p.coef0, p.coef, 3 * M * 8, hipMemcpyDeviceToDevice, st);
         d.G = Gkeep;
@@ -1755,7 +1791,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         if (reduce_rc) return fail(MOSHII_ERR_ARG, "stagei: the all-reduce callback failed");
         if (hstat[0] == 3) return fail(MOSHII_ERR_ARG, "stagei: a vertex has more than 16 non-zero skinning weights");
         if (hstat[1]) return fail(MOSHII_ERR_NUMERIC, "stagei: normal equations not positive definite");
-        if (hstat[2]) return fail(MOSHII_ERR_NUMERIC, "stagei: the three nearest vertices of a marker are collinear (the reference falls back to the next neighbour, transformed_lm.py:94-101; not implemented)");
+        if (hstat[2]) return fail(MOSHII_ERR_NUMERIC, "stagei: a marker's nearest vertices are collinear for every one of its 8 neighbours (transformed_lm.py:94-101 runs out of candidates)");
     }
     if (hipGetLastError() != hipSuccess) return fail(MOSHII_ERR_HIP, "stagei: kernel launch failed");
     // ---- outputs; nearest canonical vertex of every latent marker (chmosh.py:420-422)

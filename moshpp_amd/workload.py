@@ -66,10 +66,55 @@ def make_capture(job, solver, motion_seed, noise=0.0005, dropout=0.02, n_gaps=2)
     return out
 
 
+def make_face_job(seed=26, n_markers=89, num_expressions=80, expr_boost=6.0):
+    """The subject of BASELINE config 3: SMPL-X, 89 markers incl. face / hand vertices, fingers + jaw + `num_expressions` expression
+    coefficients free in Step 2 (chmosh.py:560-567, 681-689) -- 194 unknowns per solve at the yaml default of 80.  The synthetic model
+    carries the expression directions as shapedirs columns [16, 16 + E) (betas_expr_start_id = 16), boosted to centimetre scale so that
+    the block is observable through the face markers.  Captures: make_face_capture."""
+    E = int(num_expressions)
+    dd = dict(synth.synth_model('smplx', seed=seed, num_betas=16 + E))
+    sd = np.array(dd['shapedirs'], dtype=np.float64)
+    sd[:, :, 16:] *= expr_boost / np.maximum(np.abs(sd[:, :, 16:]).max(axis=(0, 1), keepdims=True) / 0.005, 1e-12)
+    dd['shapedirs'] = sd
+    job = make_job('smplx', n_frames=4, n_markers=n_markers, seed=seed, optimize_fingers=True, dd=dd, num_betas=16 + E)
+    job['betas'] = job['betas'].copy()
+    job['betas'][16:] = 0.0                       # the subject's shape: the expression block belongs to the frames
+    job.update(optimize_face=True, num_expressions=E, betas_expr_start_id=16)
+    return job
+
+
+def make_face_capture(job, solver, motion_seed, n_frames=4000, expr_amp=0.6, noise=0.0005, dropout=0.02):
+    """One capture of the config-3 subject: seeded body + finger motion, a jaw motion and a per-capture expression (a constant offset
+    of the free block: every frame has to find it, warm-started from its predecessor), generated on the device through a second
+    model handle that carries the expression in its betas; the generator's noise / dropout model on top."""
+    from . import capi
+    sm = job['sm']
+    E = job['num_expressions']
+    rng = np.random.default_rng(motion_seed + 5)
+    pose_gt, trans_gt = synth.synth_motion(sm.NP, sm.body_dof, n_frames, seed=motion_seed)
+    t = np.arange(n_frames)[:, None] / 30.0
+    pose_gt[:, 66:69] = 0.15 * np.sin(2 * np.pi * 1.1 * t + np.array([0.0, 1.0, 2.0]))   # jaw
+    pose_gt[:, 69:75] = 0.0                                                               # eyes: never free
+    gen = sm.new_device()
+    b = solver.betas.copy()
+    b[16:16 + E] = expr_amp * rng.standard_normal(E)
+    gen.set_betas(b)
+    att = capi.Attachment(gen, solver.tc.closest, solver.tc.coef)
+    markers = att.markers(pose_gt, trans_gt)
+    att.close(); gen.close()
+    markers += rng.normal(0, noise, markers.shape)
+    drop = rng.random(markers.shape[:2]) < dropout
+    drop[0, :] = False
+    markers[drop] = 0.0
+    return dict(obs=markers, vis=~drop, pose_gt=pose_gt, trans_gt=trans_gt, expr_gt=b[16:16 + E])
+
+
 def make_solver(job, maxiter=100):
     from .chmosh import StageIISolver
     return StageIISolver(job['sm'], job['betas'], job['markers_latent'], job['prior'], job['weights'],
-                         surface_model_type=job['model_type'], optimize_fingers=job['optimize_fingers'], maxiter=maxiter)
+                         surface_model_type=job['model_type'], optimize_fingers=job['optimize_fingers'], maxiter=maxiter,
+                         optimize_face=job.get('optimize_face', False), betas_expr_start_id=job.get('betas_expr_start_id', 300),
+                         num_expressions=job.get('num_expressions', 80))
 
 
 class DeviceSequence:

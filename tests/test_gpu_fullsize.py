@@ -361,7 +361,7 @@ def test_bench_launches_its_own_ranks(gpu_lib):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--frames', '600',
                         '--seeds', '1000,123', '--no-cpu', '--no-stagei', '--no-sequential', '--strong-sequences', '4', '--long-frames', '1500',
-                        '--lbs-frames', '200'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+                        '--lbs-frames', '200', '--no-config3'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]

@@ -83,7 +83,12 @@ def _stagei_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_stagei_frames_over_two_ranks_equals_single_process(gpu_lib, tmp_path):
+@pytest.mark.parametrize('solver', ['schur', 'dense'])
+def test_stagei_frames_over_two_ranks_equals_single_process(gpu_lib, tmp_path, solver, monkeypatch):
+    """Two processes on the GPU, the picked frames split between them.  'schur' (the default arrow-structured solver): every rank
+    eliminates its own frames and only the Schur system of the shared block (+ a few n-vectors) is all-reduced; 'dense'
+    (MOSHII_S1_SOLVER=dense): the whole normal equations are.  Both must reproduce the single-process solve."""
+    monkeypatch.setenv('MOSHII_S1_SOLVER', solver)      # (inherited by the spawned ranks)
     from moshpp_amd import capi
     from tests import helpers
     mp.spawn(_stagei_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

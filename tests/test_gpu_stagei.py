@@ -70,10 +70,35 @@ def _variant(name):
         return helpers.stagei_case('smplx', seed=3, nb=0), False, dict(n_expr=5, expr_start=4, face_ids=[66, 67, 68])
     if name == 'extra_rigid':        # opt_settings.extra_initial_rigid_adjustment (chmosh.py:230-232)
         return helpers.stagei_case('smplh', seed=8), False, dict(extra_initial_rigid_adjustment=True)
+    if name == 'collinear':
+        # The collinear-neighbour fallback of the live attachment (transformed_lm.py:94-101): one marker's three nearest canonical
+        # vertices are made EXACTLY collinear -- the layout vertex and two vertices moved next to it along x, all three with the same
+        # y / z template coordinates, blend-shape rows, pose-corrective rows and skinning weights, so that their canonical y / z stay
+        # bit-identical for every betas in every implementation (at zero pose the skinning transforms are exact identities) and
+        # e1 x e2 is an exact zero.  The reference then moves the third neighbour of EVERY marker to the fourth nearest.
+        import copy
+        from oracle import stageii_oracle as so_
+        c = copy.deepcopy(helpers.stagei_case('smplh', seed=9))
+        mdl = c['model']
+        v = mdl['v_template']
+        v0 = int(c['vids'][0])
+        d = np.linalg.norm(v - v[v0], axis=1)
+        near = np.argsort(d)[1:3]
+        delta = 0.25 * d[near[0]]
+        for k, vi in enumerate(near):
+            v[vi] = v[v0] + np.array([(1.0, -1.3)[k] * delta, 0.0, 0.0])
+            for key in ('shapedirs', 'posedirs', 'weights'):
+                mdl[key][vi] = mdl[key][v0]
+        c['m'] = so_.prepare_model(mdl)
+        so_.set_free_shape(c['m'], 0, c['nb'])
+        can = so_.verts_forward(c['m'], so_.fullpose_from_pose(c['m'], np.zeros(c['m']['NP'])), np.zeros(3))
+        e1, e2 = can[near[0]] - can[v0], can[near[1]] - can[v0]
+        assert np.all(np.cross(e1, e2) == 0.0)
+        return c, False, {}
     raise KeyError(name)
 
 
-@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr', 'face', 'extra_rigid'])
+@pytest.mark.parametrize('name', ['smplx_exclude', 'smpl', 'mano', 'fixed_betas', 'betas_init', 'head_corr', 'face', 'extra_rigid', 'collinear'])
 def test_stagei_variants_match_oracle(name):
     from moshpp_amd import capi
     from oracle import stagei_oracle as s1

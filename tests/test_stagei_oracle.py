@@ -104,7 +104,7 @@ def test_kernel_arithmetic_matches_oracle_in_emulation(case, fingers):
     assert np.allclose(out['errs'][:6], want, rtol=1e-7, atol=1e-12) and out['errs'][6] == 0.0
 
 
-@pytest.mark.parametrize('name', ['mano', 'fixed_betas', 'head_corr', 'face', 'extra_rigid'])
+@pytest.mark.parametrize('name', ['mano', 'fixed_betas', 'head_corr', 'face', 'extra_rigid', 'collinear'])
 def test_kernel_arithmetic_variants_in_emulation(name):
     """Other model families / options through the emulated kernels (the GPU tests run the full list)."""
     from tests.emu import emu_stagei
