@@ -50,6 +50,9 @@ typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact 
 
 const char* moshii_last_error(void);
 int  moshii_version(void);
+/* first 16 hex digits of the SHA-256 over the sources this binary was compiled from (python -m moshpp_amd.build computes the same
+ * over the tree: a stale binary is detectable); "unknown" for a build outside build.py */
+const char* moshii_source_hash(void);
 int  moshii_device_count(void);
 int  moshii_set_device(int device);
 int  moshii_device_multiprocessors(void);   /* CUs of the current device (the chunk count moshii_sequence_solve picks by default) */

@@ -19,6 +19,7 @@ if os.environ.get('MOSHII_NO_ILP'):
     EXTRA_FLAGS = {}
 HEADERS = ['moshii_dev.h', 'stagei_views.h', os.path.join('..', '..', 'include', 'moshii.h')]
 OUT = os.path.join(HERE, 'libmoshii.so')
+LAST_BUILD_RAN_HIPCC = False   # set by build(): did this call compile anything?
 
 
 def _hipcc():
@@ -28,8 +29,28 @@ def _hipcc():
     return 'hipcc'
 
 
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the native sources and headers (names and bytes).  Compiled into the library
+    (moshii_source_hash(), -DMOSHII_SRC_HASH) and written beside it, so that a stale binary -- one that was not built from this
+    tree, whatever its time stamp says -- is noticed (needs_build below, tests/test_gpu_parity.py::test_loaded_library_was_built_from_this_tree)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES) + sorted(HEADERS):
+        fn = os.path.normpath(os.path.join(CSRC, rel))
+        h.update(os.path.basename(fn).encode())
+        with open(fn, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(OUT):
+        return True
+    try:
+        with open(OUT + '.srchash') as fh:
+            if fh.read().strip() != source_hash():
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
@@ -42,14 +63,18 @@ def build(force=False, verbose=True, profile=False, variant=None, defines=()):
     time with MOSHII_LIB)."""
     tag = ('_' + variant if variant else '') + ('_prof' if profile else '')
     out = OUT.replace('libmoshii.so', f'libmoshii{tag}.so')
+    global LAST_BUILD_RAN_HIPCC
+    LAST_BUILD_RAN_HIPCC = False
     if not force and not tag and not needs_build():
         return OUT
+    LAST_BUILD_RAN_HIPCC = True
+    shash = source_hash()
     objs = []
     procs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, s.replace('.hip', f'{tag}.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-value',
-               '-c', os.path.join(CSRC, s), '-o', obj] + (['-DMOSHII_PROFILE'] if profile else []) + list(defines) + EXTRA_FLAGS.get(s, [])
+               '-c', os.path.join(CSRC, s), '-o', obj] + (['-DMOSHII_PROFILE'] if profile else []) + list(defines) + EXTRA_FLAGS.get(s, []) + [f'-DMOSHII_SRC_HASH="{shash}"']
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -61,6 +86,8 @@ def build(force=False, verbose=True, profile=False, variant=None, defines=()):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(out + '.srchash', 'w') as fh:
+        fh.write(shash + '\n')
     return out
 
 

@@ -76,6 +76,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     'moshii_last_error': (C.c_char_p, []),
     'moshii_version': (C.c_int, []),
+    'moshii_source_hash': (C.c_char_p, []),
     'moshii_device_count': (C.c_int, []),
     'moshii_set_device': (C.c_int, [C.c_int]),
     'moshii_device_multiprocessors': (C.c_int, []),

@@ -332,6 +332,10 @@ extern "C" {
 
 const char* moshii_last_error(void) { return g_err.c_str(); }
 int moshii_version(void) { return 100; }
+#ifndef MOSHII_SRC_HASH
+#define MOSHII_SRC_HASH "unknown"
+#endif
+const char* moshii_source_hash(void) { return MOSHII_SRC_HASH; }
 
 int moshii_device_count(void) {
     int n = 0;

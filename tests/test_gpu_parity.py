@@ -520,3 +520,11 @@ def test_chain_matches_the_executed_reference_stageii(gpu_lib, name, tmp_path):
     calls = ref[f'{name}_minimize_calls']
     per_frame = [int(calls[:5, 2].sum())] + [int(calls[5 + 2 * i:7 + 2 * i, 2].sum()) for i in range(len(solved) - 1)]
     assert per_frame == [int(v) for v in out['iters'][solved, 0]]
+
+
+@pytest.mark.gpu
+def test_loaded_library_was_built_from_this_tree(gpu_lib):
+    """The binary the GPU tests run is the one this tree's sources produce: the source hash compiled into it
+    (moshii_source_hash) equals the hash of moshpp_amd/csrc + include/moshii.h as they are on disk."""
+    from moshpp_amd import build, capi
+    assert capi.load().moshii_source_hash().decode() == build.source_hash()
