@@ -802,127 +802,8 @@ struct APass<NBLK, true> {
 };
 #endif
 
-#ifdef MOSHII_LDL_PAIRWISE
-template <int NBLK>
-__device__ __noinline__ bool ldl_factor(const typename APass<NBLK>::type Av, int o_Lp_, int o_g_, int o_pinv_, int n_) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const AReg<NBLK> A = APass<NBLK>::unpack(Av);
-    // (function arguments arrive in vector registers: as scalars the loop bounds and LDS offsets below are SALU work)
-    const int o_Lp = __builtin_amdgcn_readfirstlane(o_Lp_), o_g = __builtin_amdgcn_readfirstlane(o_g_);
-    const int o_pinv = __builtin_amdgcn_readfirstlane(o_pinv_), n = __builtin_amdgcn_readfirstlane(n_);
-    double* const Lp = lds + o_Lp;
-    const double* const g = lds + o_g;
-    double* const pinv = lds + o_pinv;
-    const int tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;
-    PROF_BEGIN(); PROF_COUNT(22);
-    double w[AReg<NBLK>::NE];
-    {
-        int e = 0;
-#pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi)
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) {
-                const int q1 = bi * 16 + ty, q2 = bj * 16 + tx;
-                const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);   // (unconditional read)
-                w[e] = (q1 == n) ? gq : A.a[e];
-                ++e;
-            }
-    }
-    // LDS views.  Lp: the packed factor (what the back-substitution reads); entry (i, j), i > j, is written once, by its
-    // owner, and never read inside the elimination loop.  Cv: the column broadcast buffer [2 parities][2 columns][rows],
-    // rewritten every step -- parity double-buffering makes one barrier per step sufficient (a thread can only be two
-    // steps ahead of another after both passed the barrier in between).  Two columns are eliminated per step: one
-    // barrier and one LDS round trip per PAIR; the second column's entries are corrected by the first on the fly,
-    //   c'_{i,j+1} = c_{i,j+1} - c_{ij} a / d_j ,   d'_{j+1} = d_{j+1} - a^2 / d_j ,   a = A[j+1][j].
-    // Stores that do not apply go to a per-lane `trash` word (64 of them: a shared one made every such store a many-way
-    // same-bank write), loads that do not apply read `zero` (= 0.0): straight-line LDS traffic.
-    const int trash = (n + 1) * (n + 2) / 2 + (tid & 63), zero = (n + 1) * (n + 2) / 2 + 64;
-    constexpr int CVR = NBLK * 16;                 // rows of one broadcast column
-    double* const Sl = Lp + trash;                 // this lane's trash word
-    double* const Zr = Lp + zero;                  // the zero word
-    double* Cv = Zr + 2;                           // [2][2][CVR]
-    int rS[NBLK];                                  // packed offset of this thread's row q1 (or -1 beyond the border row)
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-        const int q1 = b * 16 + ty;
-        rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
-    }
-    if (tid == 0) Zr[0] = 0.0;
-    bool ok = true;
-    int step = 0;
-    // outer loop over 16-column blocks is unrolled, so every register index below is a compile-time constant
-#pragma unroll
-    for (int bj0 = 0; bj0 < NBLK; ++bj0) {
-        if (!ok) break;
-        for (int jl = 0; jl < 16; jl += 2) {
-            const int j = bj0 * 16 + jl;
-            if (j >= n) break;
-            const bool pair = j + 1 < n;   // (n odd: the last column goes alone)
-            double* cv = Cv + (step & 1) * 2 * CVR;
-            ++step;
-            const bool ownA = tx == jl, ownB = tx == jl + 1;
-#pragma unroll
-            for (int bi = bj0; bi < NBLK; ++bi) {   // publish columns j, j+1 as they stand (rows of this thread), and column j's final entries
-                const int q1 = bi * 16 + ty;
-                const double v = w[bi * (bi + 1) / 2 + bj0];
-                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl;
-                *dst = v;
-                Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;
-            }
-            __syncthreads();
-            const double p0 = cv[j], a10 = cv[j + 1], p1r = cv[CVR + j + 1];
-            // Row / column entries of the two pivot columns, read WITHOUT a validity mask: the entries this leaves wrong are
-            // dead ones -- rows or columns <= j + 1 are final and published, rows beyond the border row n are zero and stay
-            // zero, and the corner (n, n) is never read -- so nothing that is used later sees them.
-            double ci0[NBLK], ci1[NBLK], ck0[NBLK], ck1[NBLK];
-#pragma unroll
-            for (int b = bj0; b < NBLK; ++b) {
-                const int q1 = b * 16 + ty, q2 = b * 16 + tx;
-                ci0[b] = cv[q1]; ci1[b] = cv[CVR + q1]; ck0[b] = cv[q2]; ck1[b] = cv[CVR + q2];
-            }
-            // (no exit between the barrier and the arithmetic: all LDS reads of the step are issued together, ONE round trip;
-            //  a non-positive pivot -- every thread sees the same two -- ends the elimination after this step's (then
-            //  meaningless) update)
-            const bool bad0 = !(p0 > 0.0);
-            // 1 / pivot: hardware reciprocal + two Newton steps (pivot is positive and normal), shorter than the IEEE divide
-            double pin0 = __builtin_amdgcn_rcp(p0);
-            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
-            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
-            const double l10 = a10 * pin0;
-            const double p1 = pair ? fma(-a10, l10, p1r) : 1.0;
-            const bool bad = bad0 || !(p1 > 0.0);
-            double pin1 = __builtin_amdgcn_rcp(p1);
-            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
-            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
-            if (!pair) pin1 = 0.0;
-            *((tid == 0) ? pinv + j : Sl) = pin0;              // (branch-free: the other threads write their trash word)
-            *((tid == 0 && pair) ? pinv + j + 1 : Sl) = pin1;
-#pragma unroll
-            for (int b = bj0; b < NBLK; ++b) {
-                ci1[b] = fma(-ci0[b], l10, ci1[b]);          // column j+1 corrected by column j
-                ck1[b] = fma(-ck0[b], l10, ck1[b]);
-                const int q1 = b * 16 + ty;
-                Lp[(ownB && pair && q1 > j + 1 && rS[b] >= 0) ? rS[b] + j + 1 : trash] = ci1[b];   // ... and stored, final
-                ck0[b] *= pin0; ck1[b] *= pin1;
-            }
-#pragma unroll
-            for (int bi = bj0; bi < NBLK; ++bi)
-#pragma unroll
-                for (int bj = bj0; bj <= bi; ++bj) {
-                    const int e = bi * (bi + 1) / 2 + bj;
-                    w[e] = fma(-ci1[bi], ck1[bj], fma(-ci0[bi], ck0[bj], w[e]));
-                }
-            if (bad) { ok = false; break; }
-        }
-    }
-    __syncthreads();
-    PROF_LAP(9);
-    return ok;
-}
-#else
-// Elimination by 16-column PANELS (same arithmetic, operation for operation, as the column-pair elimination kept above
-// under MOSHII_LDL_PAIRWISE -- every entry receives w_ik = fma(-c_ij, c_kj pin_j, w_ik) for j ascending -- so the factor,
+// Elimination by 16-column PANELS (same arithmetic, operation for operation, as the round-1 column-pair elimination it replaced
+// -- every entry receives w_ik = fma(-c_ij, c_kj pin_j, w_ik) for j ascending -- so the factor,
 // the reciprocal pivots and the solver's trajectory have the same bits; what changes is who executes it).  The kernel's
 // time is instruction count (one wavefront per SIMD: ~5 cycles an instruction, measured -- tools/ubench_latency.hip); the
 // pair elimination spent ~150 instructions of EVERY wavefront and an LDS round trip per two columns.  Here, per panel:
@@ -1074,7 +955,7 @@ __device__ __noinline__ bool ldl_factor(const typename APass<NBLK>::type Av, int
     PROF_LAP(9);
     return ok;
 }
-#endif
+
 
 template <int NBLK>
 __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n_) {
@@ -2503,18 +2384,18 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
             case 13: kern = k_chain_solve<13, 1, true>; break;
             default: return hipErrorInvalidValue;
         }
-    } else switch (nblk * 2 + (two_per_cu ? 1 : 0)) {
-        case 4: kern = k_chain_solve<2, 1, false>; break;
-        case 5: kern = k_chain_solve<2, 2, false>; break;
-        case 8: kern = k_chain_solve<4, 1, false>; break;
-        case 9: kern = k_chain_solve<4, 2, false>; break;
-        case 10: kern = k_chain_solve<5, 1, false>; break;
-        case 11: kern = k_chain_solve<5, 2, false>; break;
-        case 14: kern = k_chain_solve<7, 1, false>; break;
-        case 15: kern = k_chain_solve<7, 2, false>; break;
-        case 16: kern = k_chain_solve<8, 1, false>; break;
-        case 17: kern = k_chain_solve<8, 2, false>; break;
-        default: return hipErrorInvalidValue;
+    } else {
+        // (a 256-register variant for two workgroups per CU existed through round 2: 1.9x slower per chain for +6 % aggregate
+        //  throughput -- the register cap alone cost 36 % -- and was never the default; removed)
+        if (two_per_cu) return hipErrorInvalidValue;
+        switch (nblk) {
+            case 2: kern = k_chain_solve<2, 1, false>; break;
+            case 4: kern = k_chain_solve<4, 1, false>; break;
+            case 5: kern = k_chain_solve<5, 1, false>; break;
+            case 7: kern = k_chain_solve<7, 1, false>; break;
+            case 8: kern = k_chain_solve<8, 1, false>; break;
+            default: return hipErrorInvalidValue;
+        }
     }
 #endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -723,11 +723,10 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     // room for two workgroups per CU so that one chain's dependency stalls are covered by the other's work.
     int n_cu = 256;
     { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 1) n_cu = 256; }
-    // One workgroup per CU by default: the 256-register variant (two per CU) spills and was measured slower per chain
-    // by 1.9x for +6 % aggregate throughput (tools/gpu_occupancy.py); MOSHII_TWO_PER_CU=1 selects it for experiments.
-    int two_per_cu = 0;
+    // One workgroup per CU: a 256-register variant (two per CU) spilled and was measured slower per chain by 1.9x for +6 %
+    // aggregate throughput (round 1, tools/gpu_occupancy.py); it was removed in round 3.
+    const int two_per_cu = 0;
     (void)n_workgroups;
-    if (const char* e = getenv("MOSHII_TWO_PER_CU")) two_per_cu = atoi(e) != 0;
     int budget = two_per_cu ? 80 * 1024 : 160 * 1024;
     if (const char* e = getenv("MOSHII_LDS_BUDGET")) budget = atoi(e);
     // hand joints whose d marker / d fullpose must be parked for the PCA contraction (only when hand coefficients are free)
