@@ -157,10 +157,11 @@ def make_allreduce(dist, device=None):
     return allreduce
 
 
-def make_allreduce_device(dist):
+def make_allreduce_device(dist, device_memory_is_host=False):
     """In-place sum of `count` float64 values at a DEVICE address over the ranks: torch.distributed (backend nccl = RCCL over xGMI)
     on a tensor wrapped around the pointer -- nothing is copied, nothing visits the host (moshii_stagei_desc.allreduce_on_device).
-    With another backend (gloo on a CPU build, where "device" memory is host memory) the same address is wrapped as a NumPy view."""
+    With another backend the call is refused unless `device_memory_is_host` says the "device" pointers are host memory (the CPU
+    emulation of the kernels, tests only): the address is then wrapped as a NumPy view."""
     import numpy as np
     import torch
 
@@ -175,15 +176,15 @@ def make_allreduce_device(dist):
             torch.cuda.current_stream().synchronize()
         else:
             import ctypes
-            from . import capi
-            if not str(capi.LIB_PATH).endswith('_emu.so'):   # a real GPU build: the pointer is device memory, gloo would read it on the host
-                raise RuntimeError('make_allreduce_device needs the nccl (RCCL) backend on a GPU build; use make_allreduce for ' + str(dist.get_backend()))
+            if not device_memory_is_host:   # a real GPU build: the pointer is device memory, gloo would read it on the host
+                raise RuntimeError('make_allreduce_device needs the nccl (RCCL) backend on a GPU build (device_memory_is_host=True only '
+                                   'for the CPU emulation of the kernels); use make_allreduce for ' + str(dist.get_backend()))
             arr = np.ctypeslib.as_array((ctypes.c_double * count).from_address(ptr))
             dist.all_reduce(torch.from_numpy(arr))
     return allreduce
 
 
-def stagei_solve_sharded(solve, n_frames, dist, on_device=None):
+def stagei_solve_sharded(solve, n_frames, dist, on_device=None, device_memory_is_host=False):
     """One Stage-I problem over the ranks: rank r evaluates frames frame_ranges(n_frames, world)[r], rank 0 the shared rows; the
     normal equations are summed with an all-reduce per dogleg iteration (moshii_stagei_desc.sharded) and every rank returns the
     same solution.  `solve(frame_range=..., owns_shared_rows=..., allreduce=...)` is capi.stagei_solve_host with the problem bound.
@@ -193,7 +194,7 @@ def stagei_solve_sharded(solve, n_frames, dist, on_device=None):
     if on_device is None:                 # RCCL works on device memory: hand it the solver's buffers
         on_device = dist.get_backend() == 'nccl'
     if on_device:
-        return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce_device(dist), allreduce_on_device=True)
+        return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce_device(dist, device_memory_is_host), allreduce_on_device=True)
     return solve(frame_range=(lo, hi), owns_shared_rows=(rank == 0), allreduce=make_allreduce(dist))
 
 

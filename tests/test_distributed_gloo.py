@@ -135,7 +135,7 @@ def _stagei_worker(rank, world, port, outdir, solver='', on_device=None):
         os.environ['MOSHII_S1_SOLVER'] = solver
     c = helpers.stagei_case(M=24, F=5, n_verts=1500, seed=11)
     kw = helpers.stagei_kwargs(c)
-    out = stagei_solve_sharded(lambda **sh: emu_stagei.solve(c['m'], c['prior'], **kw, **sh), len(c['frames']), dist, on_device=on_device)
+    out = stagei_solve_sharded(lambda **sh: emu_stagei.solve(c['m'], c['prior'], **kw, **sh), len(c['frames']), dist, on_device=on_device, device_memory_is_host=True)
     np.savez(os.path.join(outdir, f'rank{rank}.npz'), **{k: np.asarray(v) for k, v in out.items()})
     dist.barrier()
     dist.destroy_process_group()
