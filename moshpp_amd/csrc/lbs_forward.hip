@@ -212,39 +212,72 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
 __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
-                                                   float* __restrict__ Atr, _Float16* __restrict__ featF) {
+                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, long long* __restrict__ stamps) {
+#define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
     // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own
     __shared__ float s_fullpose[4][3 * MOSHII_MAXK];
     __shared__ float s_Rl[4][MOSHII_MAXK * 9], s_Rw[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];
+    __shared__ float s_comps[90 * 90], s_pose[4][3 * MOSHII_MAXK], s_hm[4][128], s_J[4][3 * MOSHII_MAXK];
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
     const int K = md.K, P = md.P, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
     const int fw = blockIdx.x * 4 + wv;          // this wave's frame; the last workgroup's spare waves redo frame F - 1 and write nothing
     const int f = min(fw, F - 1);
+    PREP_STAMP(0)
     for (int q = tid; q < 16 * 32; q += 64) s_feat[wv][q] = (_Float16)0.0f;
     float* fullpose = s_fullpose[wv]; float* Rl = s_Rl[wv]; float* Rw = s_Rw[wv]; float* tw = s_tw[wv];
     const float* ps = pose + (size_t)f * md.NP;
     const int bd = md.body_dof, nhf = md.nhand_full;
+    // Everything the frame needs from memory is fetched in ONE round of independent loads at the top (with 4 000 waves starting at
+    // once a dependent round trip costs 1-2 000 cycles, and the first version made some thirty of them in a row: per-column loop
+    // bounds, then components one at a time, then tree depth / parents, then the parents' joints): the hand-component matrix
+    // (hand_dof x nhand_full <= 90 x 90, f64 -> f32, shared by the workgroup's four frames), the pose row, the hands' mean, the
+    // tree and the rest joints -- staged in LDS, from where the rest of the kernel reads.
+    const int hd = md.hand_dof, ncomp = hd * nhf;
+    {
+        double cst[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int i = threadIdx.x + 256 * u; cst[u] = (i < ncomp) ? md.comps[i] : 0.0; }
+        float pv[3], hmv[2], jv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = tid + 64 * u; pv[u] = (i < md.NP) ? ps[i] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = tid + 64 * u; hmv[u] = (i < nhf) ? (float)md.hands_mean[i] : 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) jv[i] = (tid < K) ? Jf[tid * 3 + i] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int i = threadIdx.x + 256 * u; if (i < ncomp) s_comps[i] = (float)cst[u]; }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = tid + 64 * u; if (i < md.NP) s_pose[wv][i] = pv[u]; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = tid + 64 * u; if (i < nhf) s_hm[wv][i] = hmv[u]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (tid < K) s_J[wv][tid * 3 + i] = jv[i];
+    }
+    const int lvl_of = (tid < K) ? md.depth[tid] : -1;
+    const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
+    __syncthreads();
+    // fullpose = [pose[:body_dof], hands_mean + pose_hand . components]  (block diagonal: the other hand's entries are exact zeros)
     for (int d = tid; d < P; d += 64) {
         float v;
-        if (d < bd) v = ps[d];
+        if (d < bd) v = s_pose[wv][d];
         else {
             const int h = d - bd;
-            const int lo = md.col_lo[h], hi = md.col_hi[h];
-            float a0 = md.hands_mean[h], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // four independent chains: the loads overlap
-            int i = lo;
-            for (; i + 4 <= hi; i += 4) {
-                a0 += ps[bd + i] * (float)md.comps[i * nhf + h];
-                a1 += ps[bd + i + 1] * (float)md.comps[(i + 1) * nhf + h];
-                a2 += ps[bd + i + 2] * (float)md.comps[(i + 2) * nhf + h];
-                a3 += ps[bd + i + 3] * (float)md.comps[(i + 3) * nhf + h];
+            float a0 = s_hm[wv][h], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            int i = 0;
+            for (; i + 4 <= hd; i += 4) {
+                a0 += s_pose[wv][bd + i] * s_comps[i * nhf + h];
+                a1 += s_pose[wv][bd + i + 1] * s_comps[(i + 1) * nhf + h];
+                a2 += s_pose[wv][bd + i + 2] * s_comps[(i + 2) * nhf + h];
+                a3 += s_pose[wv][bd + i + 3] * s_comps[(i + 3) * nhf + h];
             }
-            for (; i < hi; ++i) a0 += ps[bd + i] * (float)md.comps[i * nhf + h];
+            for (; i < hd; ++i) a0 += s_pose[wv][bd + i] * s_comps[i * nhf + h];
             v = (a0 + a1) + (a2 + a3);
         }
         fullpose[d] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    PREP_STAMP(1)
     if (tid < K) {
         const float x = fullpose[3 * tid], y = fullpose[3 * tid + 1], z = fullpose[3 * tid + 2];
         const float t2 = x * x + y * y + z * z;
@@ -261,15 +294,14 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
             if (tid >= 1) s_feat[wv][(tid - 1) * 9 + e] = (_Float16)(a * Km[e] + b * K2[e]);   // R - I without the cancellation
         }
     }
+    PREP_STAMP(2)
     // kinematic chain inside the wavefront (in-order LDS), one tree level per step
     if (tid == 0) {
         for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];
-        for (int i = 0; i < 3; ++i) tw[i] = Jf[i];
+        for (int i = 0; i < 3; ++i) tw[i] = s_J[wv][i];
     }
-    const int lvl_of = (tid < K) ? md.depth[tid] : -1;
-    const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
     float Jd[3] = {0.0f, 0.0f, 0.0f}, Jme[3] = {0.0f, 0.0f, 0.0f};
-    if (tid < K) for (int i = 0; i < 3; ++i) { Jme[i] = Jf[tid * 3 + i]; Jd[i] = Jme[i] - Jf[p * 3 + i]; }
+    if (tid < K) for (int i = 0; i < 3; ++i) { Jme[i] = s_J[wv][tid * 3 + i]; Jd[i] = Jme[i] - s_J[wv][p * 3 + i]; }
     for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -285,6 +317,7 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    PREP_STAMP(3)
     if (tid < K && fw < F) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint)
         f32x4* o = reinterpret_cast<f32x4*>(Atr + (((size_t)(f >> 4) * KJ + tid) * 16 + (f & 15)) * 12);
         const float* tr = trans + (size_t)f * 3;
@@ -296,6 +329,7 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
             o[i] = row;
         }
     }
+    PREP_STAMP(4)
     // B fragments of v_mfma_f32_16x16x32_f16: features 8 g .. 8 g + 7 of frame f are the 16 bytes of record (f / 128, g / 4,
     // (f / 16) % 8), lane (f % 16) + 16 (g % 4).  The workgroup's four frames are four consecutive lanes: thread (g, frame) writes
     // one 16-byte piece, four threads a 64-byte run (the first version wrote every feature as a 2-byte store of its own: 2.4 M write
@@ -309,6 +343,8 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
             *reinterpret_cast<f32x4*>(dst) = piece;
         }
     }
+    PREP_STAMP(5)
+#undef PREP_STAMP
 }
 
 // ---- the export kernel ------------------------------------------------------------------------------------
@@ -698,7 +734,10 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
         lmp->Fcap = Fpad;
     }
     const Lbs32Model lm = *lmp;
-    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF);
+    int dbg = 0;
+    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 31;   // (development: phase timing by truncation / clock stamps; incomplete output)
+    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
+                       (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 32 : (long long*)nullptr);
     const int NVT = lm.Vp128 / LBS_TV, NFT = Fpad / LBS_TF;
     int ncu = 0, devid = 0;
     hipGetDevice(&devid);
@@ -712,8 +751,6 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     auto kern = (lm.NW == 4) ? (nwave == 8 ? k_lbs_tile<4, 1> : k_lbs_tile<4, 2>) : k_lbs_tile<8, 2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    int dbg = 0;
-    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 31;   // (development: phase timing by truncation; incomplete output)
     hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(nwave * 64), LBS_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, dbg);
     return hipGetLastError();
 }

@@ -34,7 +34,10 @@ print(f'{mt} F={F}: {t*1e6:.1f} us per call, output {out_bytes/1e6:.1f} MB -> {o
 import os
 if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
     torch.cuda.synchronize()
-    st = verts.view(-1)[:2 * 32 * 8].cpu().numpy().view(np.int64).reshape(8, 32)
+    raw = verts.view(-1)[:2 * 32 * 9].cpu().numpy().view(np.int64)
+    st = raw[:256].reshape(8, 32)
+    ps = raw[256:262]
+    print('prep (workgroup 0, wave 0): ' + ' | '.join(f'{n} +{int(ps[k + 1] - ps[k])}' for k, n in enumerate(['hand PCA -> fullpose', 'Rodrigues + features', 'chain', 'transform rows out', 'feature pieces out'])))
     names = ['start', 'prologue done', 'k-loop done'] + [f'h{h} {w}' for h in range(8) for w in ('transforms in', 'blend done', 'exchange ready')] + ['rows out']
     for ti in range(7):
         row = st[ti]
