@@ -372,8 +372,11 @@ template <int NWT, int NVG>
 __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, int dbg) {
     constexpr int TPB = 512 / NVG, NWAVE = TPB / 64, WV = 16 * NVG;   // threads, waves, vertices per wave
     constexpr int RPW = 16 / NWAVE;                                  // exchange rows a wave stores per half tile
-    constexpr int NB = NVG;                                          // B-fragment sets: two (the fragments of step t + 1 are read while step t multiplies) where
-                                                                     // the registers allow it; with eight waves the partner wave of the SIMD covers the read
+    // B-fragment sets: two (the fragments of step t + 1 are read while step t multiplies) for the four-wave form; ONE for the
+    // eight-wave form -- its 256 registers per wave do not hold a second set: tried with two A sets instead of three, the loop was
+    // free of scratch but the tile's vertex records were parked there, 266 us against 240
+    constexpr int NB = NVG;
+    constexpr int NA = 3;                                            // A-fragment sets = k-steps of lead of the posedirs loads + 1
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, KJ = lm.KJ;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
     // Step t: barrier (chunk t + 1 is visible, every wave has left chunk t - 1), drop chunk t + 2 (fetched two steps ago) into
     // the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs fragments of step t + 2, read the B fragments of step
     // t + 1 from LDS, issue the 24 NVG MFMAs of step t.
-    half8 aS[3][NVG][3], bS[NB][8];
+    half8 aS[NA][NVG][3], bS[NB][8];
     f32x4 gS[2][NVG];
 #define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
         aS[SET][vg][c] = (ap + ((size_t)(vg * 3 + c) * KS + kk_) * 64)[lane]; }
@@ -413,19 +416,21 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
         if (ring_) LBS_LDS_BARRIER(); \
         if constexpr (NB == 1) { LBS_LD_B(0, (S) % 3) } \
         __builtin_amdgcn_sched_barrier(0); \
-        LBS_MMA_T((S) % 3, (S) % NB, 0) \
+        LBS_MMA_T((S) % NA, (S) % NB, 0) \
         if (ring_) { LBS_ST_G((S) % 2, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
-        LBS_MMA_T((S) % 3, (S) % NB, 1) \
-        if (ring_ && (KSTEP) + 4 < KS) { LBS_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0);   /* (nothing is fetched past the last k-step: the first half tile would wait for it) */ \
-        LBS_MMA_T((S) % 3, (S) % NB, 2) \
-        if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, 0) \
-        LBS_MMA_T((S) % 3, (S) % NB, 3) \
-        if constexpr (NVG == 2) { if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, NVG - 1) } \
-        LBS_MMA_T((S) % 3, (S) % NB, 4) \
-        LBS_MMA_T((S) % 3, (S) % NB, 5) \
+        LBS_MMA_T((S) % NA, (S) % NB, 1) \
+        if (ring_ && (KSTEP) + 4 < KS) { LBS_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0);   /* (nothing is fetched past the last k-step) */ \
+        LBS_MMA_T((S) % NA, (S) % NB, 2) \
+        if constexpr (NA == 3) { if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, 0) } \
+        LBS_MMA_T((S) % NA, (S) % NB, 3) \
+        if constexpr (NA == 3 && NVG == 2) { if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, NVG - 1) } \
+        LBS_MMA_T((S) % NA, (S) % NB, 4) \
+        LBS_MMA_T((S) % NA, (S) % NB, 5) \
         if constexpr (NB == 2) { LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) } __builtin_amdgcn_sched_barrier(0); \
-        LBS_MMA_T((S) % 3, (S) % NB, 6) \
-        LBS_MMA_T((S) % 3, (S) % NB, 7) }
+        LBS_MMA_T((S) % NA, (S) % NB, 6) \
+        LBS_MMA_T((S) % NA, (S) % NB, 7) \
+        /* two A sets: the set this step multiplied with is free now -- the fragments of step t + 1 go into it behind the last MFMA */ \
+        if constexpr (NA == 2) { if (lda_ && (KSTEP) + 2 < KS) { LBS_LD_A1((S) % 2, (KSTEP) + 2, 0) } } }
     // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in the output buffer instead of vertices -- tools/lbs_bench.py prints them)
 #define LBS_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 32 + (K)] = clock64(); }
     const int npieces = tlb >> 10;
@@ -488,6 +493,7 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
         constexpr int RECW = 4 + 2 * NWT;   // dwords per vertex record in LDS: x y z - | weights | joint addresses
         {
             LBS_LDS_BARRIER();   // every wave has read its last B fragments: the ring is free
+            LBS_STAMP(28)
             if (tid < LBS_TV) {
                 float* rec = reinterpret_cast<float*>(ring) + tid * RECW;
                 rec[0] = vrec[0]; rec[1] = vrec[1]; rec[2] = vrec[2];
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, 
                 for (int i = 0; i < NWT; ++i) { rec[4 + i] = __int_as_float(jrec[i].y); reinterpret_cast<int*>(rec)[4 + NWT + i] = jrec[i].x; }
             }
             LBS_LDS_BARRIER();
+            LBS_STAMP(29)
         }
         // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + WV wv + 16 vg + 4 (lane / 16) + r
         float vs[NVG][4][3], ww[NVG][4][NWT];

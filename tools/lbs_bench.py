@@ -41,4 +41,4 @@ if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
     names = ['start', 'prologue done', 'k-loop done'] + [f'h{h} {w}' for h in range(8) for w in ('transforms in', 'blend done', 'exchange ready')] + ['rows out']
     for ti in range(7):
         row = st[ti]
-        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(28)) + f' | total {int(row[27] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[27])}' if ti < 6 else ''))
+        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(28)) + f' | [after k-loop: ring free +{int(row[28] - row[2])}, records in +{int(row[29] - row[28])}, transforms in +{int(row[3] - row[29])}] | total {int(row[27] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[27])}' if ti < 6 else ''))
