@@ -2384,18 +2384,23 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
             case 13: kern = k_chain_solve<13, 1, true>; break;
             default: return hipErrorInvalidValue;
         }
-    } else {
-        // (a 256-register variant for two workgroups per CU existed through round 2: 1.9x slower per chain for +6 % aggregate
-        //  throughput -- the register cap alone cost 36 % -- and was never the default; removed)
-        if (two_per_cu) return hipErrorInvalidValue;
-        switch (nblk) {
-            case 2: kern = k_chain_solve<2, 1, false>; break;
-            case 4: kern = k_chain_solve<4, 1, false>; break;
-            case 5: kern = k_chain_solve<5, 1, false>; break;
-            case 7: kern = k_chain_solve<7, 1, false>; break;
-            case 8: kern = k_chain_solve<8, 1, false>; break;
-            default: return hipErrorInvalidValue;
-        }
+    } else switch (nblk * 2 + (two_per_cu ? 1 : 0)) {
+        // (the 256-register instantiations <N, 2> -- two workgroups per CU, 1.9x slower per chain for +6 % aggregate throughput -- are
+        //  not selectable any more (moshii_api.hip passes two_per_cu = 0), but they STAY instantiated: the solver's phases are
+        //  __noinline__ functions shared by both instantiations of a block count, and compiled for the 512-register caller alone
+        //  they come out 14 % slower (measured round 3: 308 against 265 us per frame) than compiled under the tighter budget of
+        //  the 256-register caller)
+        case 4: kern = k_chain_solve<2, 1, false>; break;
+        case 5: kern = k_chain_solve<2, 2, false>; break;
+        case 8: kern = k_chain_solve<4, 1, false>; break;
+        case 9: kern = k_chain_solve<4, 2, false>; break;
+        case 10: kern = k_chain_solve<5, 1, false>; break;
+        case 11: kern = k_chain_solve<5, 2, false>; break;
+        case 14: kern = k_chain_solve<7, 1, false>; break;
+        case 15: kern = k_chain_solve<7, 2, false>; break;
+        case 16: kern = k_chain_solve<8, 1, false>; break;
+        case 17: kern = k_chain_solve<8, 2, false>; break;
+        default: return hipErrorInvalidValue;
     }
 #endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
