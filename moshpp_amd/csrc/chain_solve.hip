@@ -2389,7 +2389,7 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
         //  not selectable any more (moshii_api.hip passes two_per_cu = 0), but they STAY instantiated: the solver's phases are
         //  __noinline__ functions shared by both instantiations of a block count, and compiled for the 512-register caller alone
         //  they come out 14 % slower (measured round 3: 308 against 265 us per frame) than compiled under the tighter budget of
-        //  the 256-register caller)
+        //  the 256-register caller; instantiations with 3, 4 or 5 waves per SIMD beside them change nothing: 265-267 us)
         case 4: kern = k_chain_solve<2, 1, false>; break;
         case 5: kern = k_chain_solve<2, 2, false>; break;
         case 8: kern = k_chain_solve<4, 1, false>; break;
