@@ -1933,7 +1933,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 
 // MINW = 1: one workgroup per CU, the compiler may use the whole 512-entry register file (lowest latency per chain);
 // MINW = 2: registers capped at 256 so that two workgroups share a CU and cover each other's dependency stalls
-//           (highest throughput when there are more chains than CUs).
+//           (+6 % aggregate when there are more chains than CUs, 1.9x slower per chain: not instantiated since round 3).
 // XT = true: the extended variant with the Step-2 extras of chmosh.py:685-699 (jaw term, free shape block); kept out of
 //           the plain instantiations so that their register allocation and timings are untouched.
 template <int NBLK, int MINW, bool XT>
@@ -2317,8 +2317,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
 template __global__ void k_chain_solve<4, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
 #else
 #define MOSHII_INSTANTIATE(N) \
-    template __global__ void k_chain_solve<N, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout); \
-    template __global__ void k_chain_solve<N, 2, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+    template __global__ void k_chain_solve<N, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
 MOSHII_INSTANTIATE(2)
 MOSHII_INSTANTIATE(4)
 MOSHII_INSTANTIATE(5)
@@ -2385,21 +2384,14 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
             default: return hipErrorInvalidValue;
         }
     } else switch (nblk * 2 + (two_per_cu ? 1 : 0)) {
-        // (the 256-register instantiations <N, 2> -- two workgroups per CU, 1.9x slower per chain for +6 % aggregate throughput -- are
-        //  not selectable any more (moshii_api.hip passes two_per_cu = 0), but they STAY instantiated: the solver's phases are
-        //  __noinline__ functions shared by both instantiations of a block count, and compiled for the 512-register caller alone
-        //  they come out 14 % slower (measured round 3: 308 against 265 us per frame) than compiled under the tighter budget of
-        //  the 256-register caller; instantiations with 3, 4 or 5 waves per SIMD beside them change nothing: 265-267 us)
+        // (the 256-register instantiations <N, 2> -- two workgroups per CU, 1.9x slower per chain for +6 % aggregate throughput -- were
+        //  removed in round 3; a build without them times 262-264 us per frame against 266-267 with them on the same box.  The "14 %
+        //  slower without them" of an earlier commit was a slow box: profiles/r03_bench_line_slow_box.json)
         case 4: kern = k_chain_solve<2, 1, false>; break;
-        case 5: kern = k_chain_solve<2, 2, false>; break;
         case 8: kern = k_chain_solve<4, 1, false>; break;
-        case 9: kern = k_chain_solve<4, 2, false>; break;
         case 10: kern = k_chain_solve<5, 1, false>; break;
-        case 11: kern = k_chain_solve<5, 2, false>; break;
         case 14: kern = k_chain_solve<7, 1, false>; break;
-        case 15: kern = k_chain_solve<7, 2, false>; break;
         case 16: kern = k_chain_solve<8, 1, false>; break;
-        case 17: kern = k_chain_solve<8, 2, false>; break;
         default: return hipErrorInvalidValue;
     }
 #endif

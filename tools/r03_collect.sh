@@ -3,6 +3,9 @@
 # memory-side PMC passes over a bench step, in-kernel phase breakdown.  Output under gpurun_out/r03f/; summaries are copied to profiles/.
 cd /root/repo; export TMPDIR=/tmp PYTHONPATH=/root/repo
 O=gpurun_out/r03f; mkdir -p $O
+# box probe: the pool's boxes are not all alike (two collections of this round ran ~15 % slower on every kernel than the runs around
+# them with the same binary) -- record a 400-frame chain (266 us/frame on the usual box) before and after the collection
+( hostname; date +%T; python tools/chain_time.py 400 | tail -1 ) > $O/box_probe.txt 2>&1
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $O/smoke.txt
 timeout 1200 python bench.py > $O/bench_line.json 2> $O/bench_err.txt
 python -m moshpp_amd.build --profile > /dev/null 2>&1
@@ -28,4 +31,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python tools/pmc_summary.py $O/pmc_$c k_chain_solve > $O/pmc_$c.txt 2>&1
   rm -rf $O/pmc_$c
 done
+( date +%T; python tools/chain_time.py 400 | tail -1 ) >> $O/box_probe.txt 2>&1
 ls $O
