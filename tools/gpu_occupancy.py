@@ -5,17 +5,16 @@ import numpy as np
 sys.path.insert(0, '.')
 import torch
 from moshpp_amd import capi, workload
-L = int(os.environ.get('OCC_L', 60))
+L = int(os.environ.get('OCC_L', 120))
 dev = torch.device('cuda', 0)
 stream = torch.cuda.current_stream().cuda_stream
 base = workload.make_job('smplh', n_frames=1024, n_markers=53, seed=1000)
 solver = workload.make_solver(base)
-for C, two in ((1, 0), (64, 0), (256, 0), (256, 1), (512, 1), (512, 0), (1024, 1)):
+for C in (1, 8, 32, 64, 128, 256, 512):
     F = C * L
     reps = (F + 1023) // 1024
     job = dict(base, obs=np.tile(base['obs'], (reps, 1, 1))[:F], vis=np.tile(base['vis'], (reps, 1))[:F])
     ds = workload.DeviceSequence(job, solver, dev)
-    os.environ['MOSHII_TWO_PER_CU'] = str(two)
     ds.solve_chunked(stream, num_chunks=C, warmup=0, verify_tol=1e300)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -23,5 +22,5 @@ for C, two in ((1, 0), (64, 0), (256, 0), (256, 1), (512, 1), (512, 0), (1024, 1
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     it = ds.iters.cpu().numpy()
-    print(dict(C=C, two_per_cu=two, kernel=capi.last_launch_info(), frames=F, ms=round(t * 1e3, 2), us_per_frame_per_chain=round(t * 1e6 / L, 1),
+    print(dict(C=C, kernel=capi.last_launch_info(), frames=F, ms=round(t * 1e3, 2), us_per_frame_per_chain=round(t * 1e6 / L, 1),
                fps=round(F / t), iters_per_frame=round(float(it[:, 0].mean()), 2), repaired=rep['n_repaired']), flush=True)
