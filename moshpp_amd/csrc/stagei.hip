@@ -5,12 +5,11 @@
 // shape Jacobians, the residual rows and the dense Jacobian, the normal equations (tiled SYRK), the Cholesky solve.  The host
 // drives Powell's dogleg (the trust-region bookkeeping on n-vectors) and the four annealing rounds.
 //
-// Kernels are written with block-strided loops over TID/NT so that tests/emu can compile this very file with g++ (-DS1_EMU,
-// one "thread" per block) and debug the arithmetic on a CPU-only container.  The emulation is test infrastructure: the product
-// library is built from this file by hipcc only.
-#ifndef S1_EMU
+// Kernels are written with block-strided loops over TID/NT.  tests/emu compiles this very file with g++ against a stand-in
+// <hip/hip_runtime.h> that runs every workgroup as fibers on the CPU (test infrastructure: the product library is built from this
+// file by hipcc only); the workgroup size S1_TPB and the lanes per vertex S1_VL can be set from the command line for that build
+// (fewer fibers per workgroup: the kernels are correct for any power of two >= 64 / >= 1, the summation order follows them).
 #include <hip/hip_runtime.h>
-#endif
 #include "stagei_views.h"
 #include "../../include/moshii.h"
 #include <math.h>
@@ -20,25 +19,6 @@
 #include <vector>
 #include <algorithm>
 
-#ifdef S1_EMU
-#define KERNEL static void
-#define KERNEL_LB(n) static void
-#define DEVFN static inline
-static int s1_bx, s1_by;
-#define TID 0
-#define NT 1
-#define BX s1_bx
-#define BY s1_by
-#define SYNC()
-#define SHARED static
-#define S1_TPB 1
-#define S1_CHOL_TPB 1
-#define DYN_LDS(name) static double name[S1_FSMAX * (S1_FSMAX + 1) + S1_FSMAX]
-#define LAUNCH_LDS(k, gx, gy, nt, bytes, stream, ...) LAUNCH(k, gx, gy, nt, stream, __VA_ARGS__)
-#define S1_VL 1
-#define S1_TRSM_TPB 1
-#define LAUNCH(k, gx, gy, nt, stream, ...) do { for (int _y = 0; _y < (int)(gy); ++_y) for (int _x = 0; _x < (int)(gx); ++_x) { s1_bx = _x; s1_by = _y; k(__VA_ARGS__); } } while (0)
-#else
 #define KERNEL __global__ void
 #define KERNEL_LB(n) __global__ void __launch_bounds__(n)
 #define DEVFN __device__ static inline
@@ -48,14 +28,17 @@ static int s1_bx, s1_by;
 #define BY ((int)blockIdx.y)
 #define SYNC() __syncthreads()
 #define SHARED __shared__
+#ifndef S1_TPB
 #define S1_TPB 256
+#endif
 #define S1_CHOL_TPB 1024
 #define DYN_LDS(name) extern __shared__ double name[]
 #define LAUNCH_LDS(k, gx, gy, nt, bytes, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), bytes, stream, __VA_ARGS__)
 #define S1_TRSM_TPB 64
+#ifndef S1_VL
 #define S1_VL 64          // lanes that share one vertex's pose-corrective dot products
-#define LAUNCH(k, gx, gy, nt, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), 0, stream, __VA_ARGS__)
 #endif
+#define LAUNCH(k, gx, gy, nt, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), 0, stream, __VA_ARGS__)
 
 #define S1_NMAX 4096     // unknowns (one column of the factor is staged in LDS)
 #define S1_FSMAX 120     // per-frame unknowns the elimination kernel keeps in LDS (120 x 121 doubles = 116 KB)
@@ -939,9 +922,6 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
 // ---------------------------------------------------------------------------------------------------------------------------
 #define S1_T 32
 #define S1_PB 32     // panel width of the blocked Cholesky further down
-#ifdef S1_EMU
-#include "stagei_emu_twins.h"   // tests/emu (test infrastructure): sequential restatements of k_s1_syrk / k_s1_chol_diag / k_s1_chol_update tiles
-#endif
 // flags[row chunk][column block] = 1 iff that 32 x 32 block of J holds a non-zero (most do not: a frame's pose columns appear only
 // in that frame's rows)                                                    grid (ceil(R / 32), ceil(n / 32))
 KERNEL k_s1_nzflags(const double* Jm, int R, int n, int ldn, int* flags) {
@@ -960,9 +940,6 @@ KERNEL k_s1_nzflags(const double* Jm, int R, int n, int ldn, int* flags) {
 KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A, const int* flags) {
     int ti = BX, tj = BY;
     if (tj > ti) return;
-#ifdef S1_EMU
-    s1_emu_syrk_tile(Jm, R, n, ldn, A, ti, tj);   // (tests/emu/stagei_emu_twins.h)
-#else
     __shared__ double Si[S1_T][S1_T + 1], Sj[S1_T][S1_T + 1];
     int tx = TID % 16, ty = TID / 16;
     double acc[2][2] = {{0, 0}, {0, 0}};
@@ -988,7 +965,6 @@ KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A, const int* 
         int i = ti * S1_T + ty + 16 * u, j = tj * S1_T + tx + 16 * w;
         if (i < n && j < n) { A[(size_t)i * n + j] = acc[u][w]; A[(size_t)j * n + i] = acc[u][w]; }
     }
-#endif
 }
 
 // partial[BY][n] = J[rows of chunk BY]^T r ; then y = sign * sum over chunks        grid (ceil(n / S1_TPB), S1_GT_CHUNKS)
@@ -1023,7 +999,6 @@ KERNEL k_s1_gemv(const double* Mx, const double* x, int n, int ld, double* y) {
 // Blocked right-looking Cholesky of A[n][n] (lower), panel width S1_PB.  Per panel: k_s1_chol_diag (one workgroup: the diagonal
 // block is factored and inverted in LDS), k_s1_chol_trsm (every row below: its 32 entries times the inverse) and k_s1_chol_update (one 32 x 32 tile of the
 // trailing matrix per workgroup: A_ik -= L_i L_k^T).  status[1] = 1 if a pivot is not positive.
-#ifndef S1_EMU
 // GPU version: one wavefront, lane r keeps row r of the block in registers; pivots and columns travel by lane shuffles.
 // Then lane c solves L x = e_c for column c of the inverse with the factor's entries broadcast the same way.
 __global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, double* dinv, int* status) {
@@ -1058,7 +1033,8 @@ __global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, d
         double sacc = (rr == r) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < S1_PB; ++k) if (k < rr) sacc -= __shfl(a[k], rr) * x[k];
-        x[rr] = (rr < r) ? 0.0 : sacc / __shfl(a[rr], rr);
+        const double lrr = __shfl(a[rr], rr);   // (taken by every lane: the lanes left of the diagonal do not need it, but a shuffle inside
+        x[rr] = (rr < r) ? 0.0 : sacc / lrr;    //  the conditional is a divergent collective to the CPU emulation of this file)
     }
     double* Di = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
     if (threadIdx.x < 32) {
@@ -1066,7 +1042,6 @@ __global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, d
         for (int rr = 0; rr < S1_PB; ++rr) Di[rr * S1_PB + r] = x[rr];
     }
 }
-#endif
 
 // rows below the diagonal block: x = a . L_D^{-T}, i.e. x_c = sum_{k <= c} a_k Dinv[c][k]        grid ceil(rows / 64), 64 threads
 KERNEL_LB(64) k_s1_chol_trsm(double* A, int n, int j0, const double* dinv) {
@@ -1094,9 +1069,6 @@ KERNEL k_s1_chol_update(double* A, int n, int j0, int jb) {
     int ti = BX, tj = BY;
     if (tj > ti) return;
     const int s0 = j0 + jb;
-#ifdef S1_EMU
-    s1_emu_chol_update_tile(A, n, j0, jb, ti, tj);   // (tests/emu/stagei_emu_twins.h)
-#else
     __shared__ double Li[S1_PB][S1_PB + 1], Lk[S1_PB][S1_PB + 1];
     for (int e = TID; e < S1_PB * S1_PB; e += NT) {
         int r = e / S1_PB, c = e % S1_PB;
@@ -1116,7 +1088,6 @@ KERNEL k_s1_chol_update(double* A, int n, int j0, int jb) {
         int i = s0 + ti * S1_PB + ty + 16 * u, k = s0 + tj * S1_PB + tx + 16 * w;
         if (i < n && k <= i) A[(size_t)i * n + k] -= acc[u][w];
     }
-#endif
 }
 
 // L y = g, L^T x = y with the factor of the kernels above, one workgroup, panel by panel: the 32 x 32 diagonal block goes through
@@ -1256,20 +1227,6 @@ KERNEL k_s1_back(const int* fcols, int fs, const int* scols, int ns, int nsp, co
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
-#ifdef S1_EMU
-typedef void* hipStream_t;
-static int emuMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 1; }
-#define hipMalloc(p, n) emuMalloc((void**)(p), n)
-#define hipFree(p) free(p)
-#define hipMemcpyAsync(d, s, n, kind, st) (memcpy(d, s, n), 0)
-#define hipMemsetAsync(d, v, n, st) (memset(d, v, n), 0)
-#define hipStreamSynchronize(st) 0
-#define hipSuccess 0
-#define hipGetLastError() 0
-#define hipMemcpyHostToDevice 1
-#define hipMemcpyDeviceToHost 2
-#define hipMemcpyDeviceToDevice 3
-#endif
 
 struct DevPool {        // every device allocation of one solve; freed together
     std::vector<void*> ptrs;
@@ -1683,9 +1640,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                         const size_t lds_bytes = ((size_t)fs * (fs + 1) + fs) * sizeof(double);
                         hipMemsetAsync(d_Y, 0, (size_t)F * fs * nsp * 8, st);
                         hipMemsetAsync(d_z, 0, (size_t)F * fs * 8, st);
-#ifndef S1_EMU
                         hipFuncSetAttribute(reinterpret_cast<const void*>(k_s1_elim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-#endif
                         // (sharded: every rank eliminates its own frames -- their rows live only here, so A_ff, A_fs and g_f are complete --
                         //  and contributes A_ss,r - Y_r^T Y_r and g_s,r - Y_r^T z_r; the sum over ranks is the Schur system: ns^2 + ns doubles)
                         if (nown > 0) LAUNCH_LDS(k_s1_elim, nown, 1, S1_TPB, lds_bytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, p.status, f_lo);

@@ -1,10 +1,13 @@
-"""TEST INFRASTRUCTURE: drive the g++ emulation build of the Stage-I solver (tests/emu/build_emu.py) from NumPy arrays."""
+"""TEST INFRASTRUCTURE: drive the Stage-I solver of the CPU emulation build (tests/emu/build_chain_emu.py: stagei.hip compiled unchanged
+against the stand-in HIP runtime, kernels on fibers) from NumPy arrays."""
 import ctypes as C
 
 import numpy as np
 
 from moshpp_amd import capi
 from . import build_emu
+
+CORE_SYMBOL = '_Z18moshii_stagei_corePK11S1ModelViewPK11S1PriorViewPK18moshii_stagei_descPvPci'
 
 
 class ModelView(C.Structure):
@@ -42,8 +45,10 @@ def solve(m, prior, **kw):
                        ptr(-np.log(prior['weights']), np.float64))
     desc, out, keep2 = capi.stagei_desc(NP=m['NP'], **kw)
     err = C.create_string_buffer(256)
-    lib.stagei_emu_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
-    rc = lib.stagei_emu_solve(C.byref(mv), C.byref(pv) if pv is not None else None, C.byref(desc), err, 256)
+    core = getattr(lib, CORE_SYMBOL)     # moshii_stagei_core(mv, pv, desc, stream, err, errlen): C++ linkage in stagei_views.h
+    core.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    core.restype = C.c_int
+    rc = core(C.byref(mv), C.byref(pv) if pv is not None else None, C.byref(desc), None, err, 256)
     if rc != 0:
         raise RuntimeError(f'stagei emu failed ({rc}): {err.value.decode()}')
     return out

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE.  A stand-in for <hip/hip_runtime.h> that lets g++ compile moshpp_amd/csrc/{moshii_api,chain_solve,lbs_forward}.hip UNCHANGED
+// TEST INFRASTRUCTURE.  A stand-in for <hip/hip_runtime.h> that lets g++ compile moshpp_amd/csrc/{moshii_api,chain_solve,lbs_forward,stagei}.hip UNCHANGED
 // and run their kernels on the CPU: every workgroup is executed as one fiber per thread (ucontext), with real barrier semantics for
 // __syncthreads / s_barrier and wave-level rendezvous for the cross-lane operations the kernels use (__shfl_down, readlane,
 // wave_barrier).  "Device" memory is host memory.  Used only by tests/emu (build_chain_emu.py); the product is built by hipcc.
@@ -21,12 +21,14 @@ struct alignas(16) double4 { double x, y, z, w; };
 
 namespace hipemu {
 struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
-ThreadCtx& cur();                                   // the running fiber's indices
+extern ThreadCtx* cur_ptr;                          // the running fiber's indices (set by the scheduler at every switch)
+inline ThreadCtx& cur() { return *cur_ptr; }
 void barrier();                                     // workgroup barrier
 void wave_sync();                                   // all lanes of the caller's wavefront rendezvous
 double wave_exchange(double v, int src_lane);       // value of `v` in lane `src_lane` of the caller's wavefront (all lanes call)
 void wave_gather2(double a, double b, const double** all);   // every lane's (a, b) of the caller's wavefront: all[0][2*lane], all[0][2*lane+1]
 const char* wave_allgather(const void* mine, int nbytes);    // every lane's `nbytes` (<= 64) of the caller's wavefront, lane-major, 64 bytes apart
+extern const char* launch_name;                     // (HIPEMU_PROF=1: per-kernel wall time at exit)
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
 void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `extern __shared__`: guarded beyond the launch's lds_bytes
 }
@@ -74,7 +76,7 @@ inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 8; return hipSuccess; }     // 8 "CUs": small chunk counts in the emulated runs
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
-    hipemu::launch(grid, block, lds, [&]() { kern(__VA_ARGS__); })
+    (hipemu::launch_name = #kern, hipemu::launch(grid, block, lds, [&]() { kern(__VA_ARGS__); }))
 
 inline void __syncthreads() { hipemu::barrier(); }
 template <class T> inline T __shfl_down(T v, int delta, int width = 64) {
@@ -82,6 +84,10 @@ template <class T> inline T __shfl_down(T v, int delta, int width = 64) {
     int src = lane + delta;
     double got = hipemu::wave_exchange((double)v, (src < width && src < 64) ? src : lane);
     return (T)got;
+}
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+    const int lane = (int)(hipemu::cur().tid.x % 64);
+    return (T)hipemu::wave_exchange((double)v, (lane & ~(width - 1)) | (src & (width - 1)));
 }
 inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }   // (blocks and fibers run one at a time)
 inline int __double2loint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b & 0xffffffff); }
@@ -179,6 +185,13 @@ inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
 // namespace, moshii_api.hip); with __shared__ = thread_local these block-scope externs need a definition in their namespace
 namespace moshii { alignas(16) inline thread_local double lds[160 * 1024 / 8]; }
 namespace { alignas(16) thread_local double sm[160 * 1024 / 8]; }
+#ifdef HIPEMU_UNNAMED_LDS   // stagei.hip: `extern __shared__ double lds[]` inside its unnamed namespace (k_s1_elim)
+namespace { alignas(16) thread_local double lds[160 * 1024 / 8]; }
+// (g++ routes the kernel's block-scope `extern thread_local` through the unit's TLS init function and only emits that function when
+//  some thread_local of the unit has a dynamic initialiser: give it one)
+namespace { inline int hipemu_tls_anchor_value() { return 1; } thread_local int hipemu_tls_anchor = hipemu_tls_anchor_value(); }
+namespace { struct HipEmuLdsRegistration2 { HipEmuLdsRegistration2() { hipemu::register_dynamic_lds(lds, sizeof(lds)); } } hipemu_lds_registration2; }
+#endif
 #ifdef HIPEMU_NATIVE_F16   // lbs_forward.hip: `extern __shared__ char lds_raw[]` (export kernel), `... float smf[]` (plain kernel)
 namespace { alignas(16) thread_local char lds_raw[160 * 1024]; alignas(16) thread_local float smf[160 * 1024 / 4]; }
 namespace { struct HipEmuLdsRegistration { HipEmuLdsRegistration() { hipemu::register_dynamic_lds((double*)lds_raw, sizeof(lds_raw)); hipemu::register_dynamic_lds((double*)smf, sizeof(smf)); } } hipemu_lds_registration; }

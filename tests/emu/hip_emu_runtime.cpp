@@ -1,15 +1,52 @@
-// TEST INFRASTRUCTURE.  Fiber scheduler behind tests/emu/fakehip/hip/hip_runtime.h: one ucontext per GPU thread of the running
+// TEST INFRASTRUCTURE.  Fiber scheduler behind tests/emu/fakehip/hip/hip_runtime.h: one fiber (its own stack, a hand-written x86-64
+// register switch: glibc's swapcontext makes a signal-mask system call per switch, which was most of the emulated run time) per GPU thread of the running
 // workgroup; a fiber blocks at a workgroup barrier or at a wavefront rendezvous and the scheduler releases a group when all of its
 // live members have arrived (convergent use of the collectives is assumed; anything else is reported as a deadlock).
-#include <ucontext.h>
+#if !defined(__x86_64__)
+#error "the fiber switch below is x86-64 System V only"
+#endif
+// void hipemu_switch(void** save_sp, void* load_sp): push the callee-saved registers, park the stack pointer, adopt the other one
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <map>
+#include <string>
+#include <chrono>
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 namespace hipemu {
@@ -17,25 +54,26 @@ struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
 
 namespace {
 enum State { RUN, AT_BARRIER, AT_WAVE, DONE };
-struct Fiber { ucontext_t ctx; char* stack; State st; ThreadCtx tc; double xval; int xsrc; double xgot; double xval2; const void* xptr; int xbytes; };
+struct Fiber { void* sp; char* stack; State st; ThreadCtx tc; double xval; int xsrc; double xgot; double xval2; const void* xptr; int xbytes; };
 std::vector<char> gatherb_buf;   // [wave][64][64 bytes]: the operands of the wave's last byte gather
 std::vector<double> gather_buf;   // [wave][64][2]: the operands of the wave's last gather, filled when the wave is released
 const size_t STACK = 1 << 20;
 std::vector<Fiber> fibers;
 std::vector<char*> stacks;
-ucontext_t sched_ctx;
+void* sched_sp = nullptr;
 int cur_fiber = -1;
 const std::function<void()>* cur_body = nullptr;
 
 void trampoline() {
     (*cur_body)();
     fibers[cur_fiber].st = DONE;
-    swapcontext(&fibers[cur_fiber].ctx, &sched_ctx);
+    hipemu_switch(&fibers[cur_fiber].sp, sched_sp);
+    __builtin_trap();   // (a finished fiber is never resumed)
 }
 void yield_as(State s) {
     Fiber& f = fibers[cur_fiber];
     f.st = s;
-    swapcontext(&f.ctx, &sched_ctx);
+    hipemu_switch(&f.sp, sched_sp);
 }
 }  // namespace
 
@@ -47,7 +85,8 @@ void register_dynamic_lds(double* base, size_t bytes) {
 }
 static const double CANARY = -7.25e77;
 
-ThreadCtx& cur() { return fibers[cur_fiber].tc; }
+ThreadCtx* cur_ptr = nullptr;
+static inline ThreadCtx& cur() { return *cur_ptr; }
 void barrier() { yield_as(AT_BARRIER); }
 void wave_sync() { fibers[cur_fiber].xsrc = -1; yield_as(AT_WAVE); }
 double wave_exchange(double v, int src_lane) {
@@ -80,7 +119,18 @@ static void segv_backtrace(int) {   // a kernel bug on the CPU: say where (symbo
     _exit(139);
 }
 
+const char* launch_name = "?";
+namespace {
+struct ProfRow { double s; long n; long fibers; };
+std::map<std::string, ProfRow>& prof() { static std::map<std::string, ProfRow> m; return m; }
+void prof_dump() { for (auto& kv : prof()) fprintf(stderr, "hipemu prof: %-40s %9.3f s  %8ld launches %12ld fibers\n", kv.first.c_str(), kv.second.s, kv.second.n, kv.second.fibers); }
+}
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+    static const bool profiling = getenv("HIPEMU_PROF") != nullptr;
+    static bool registered = false;
+    if (profiling && !registered) { atexit(prof_dump); registered = true; }
+    const auto t_launch0 = std::chrono::steady_clock::now();
+    const std::string name_now = launch_name;
     const int nt = (int)(block.x * block.y * block.z);
     static bool handler_installed = false;
     if (!handler_installed) {
@@ -105,15 +155,22 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
             f.stack = stacks[t]; f.st = RUN;
             f.tc.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             f.tc.bid = dim3(bx, by, bz); f.tc.bdim = block; f.tc.gdim = grid;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &sched_ctx;
-            makecontext(&f.ctx, trampoline, 0);
+            // a fresh stack as hipemu_switch expects to find it: [mxcsr / x87 control word][r15 r14 r13 r12 rbx rbp][return address =
+            // trampoline][a null return address for trampoline itself: it never returns], entered with rsp = 8 mod 16 like any call
+            uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+            void** sp = (void**)(top - 8);
+            *sp = nullptr;
+            *--sp = (void*)&trampoline;
+            for (int k = 0; k < 6; ++k) *--sp = nullptr;
+            --sp;
+            { unsigned int mx; unsigned short cw; asm volatile("stmxcsr %0" : "=m"(mx)); asm volatile("fnstcw %0" : "=m"(cw)); ((unsigned int*)sp)[0] = mx; ((unsigned short*)sp)[2] = cw; }
+            f.sp = (void*)sp;
         }
         while (true) {
             bool progressed = false;
             for (int t = 0; t < nt; ++t) if (fibers[t].st == RUN) {
-                cur_fiber = t;
-                swapcontext(&sched_ctx, &fibers[t].ctx);
+                cur_fiber = t; cur_ptr = &fibers[t].tc;
+                hipemu_switch(&sched_sp, fibers[t].sp);
                 progressed = true;
             }
             // release wavefronts whose live lanes have all arrived
@@ -144,5 +201,6 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
         }
     }
     cur_fiber = -1;
+    if (profiling) { ProfRow& r = prof()[name_now]; r.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch0).count(); r.n += 1; r.fibers += (long)grid.x * grid.y * grid.z * nt; }
 }
 }  // namespace hipemu
