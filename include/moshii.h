@@ -326,6 +326,9 @@ typedef struct moshii_stagei_desc {
                                                 * staged through a device scratch).  The stream has been synchronised when the callback
                                                 * runs and the callback returns after its collective has completed -- e.g. RCCL
                                                 * (torch.distributed backend "nccl") on a tensor wrapped around the pointer.            */
+    double*  init_sq;                          /* [M] or NULL (output): every latent marker's share of errs[2], the squared weighted
+                                                * distance to its initial placement at the solution -- the reference keeps one `init_<type>`
+                                                * entry per marker type in stagei_errs (chmosh.py:362-371); the caller sums by type       */
 } moshii_stagei_desc;
 
 int moshii_stagei_solve(moshii_model_t m, moshii_prior_t prior /* may be NULL */, const moshii_stagei_desc* desc, void* stream);

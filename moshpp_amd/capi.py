@@ -428,7 +428,7 @@ class StageIDesc(C.Structure):
                 ('betas', C.c_void_p), ('markers_latent', C.c_void_p), ('markers_latent_vids', C.c_void_p),
                 ('pose', C.c_void_p), ('trans', C.c_void_p), ('markers_sim', C.c_void_p), ('expression', C.c_void_p),
                 ('errs', C.c_void_p), ('iters', C.c_void_p), ('extra_initial_rigid_adjustment', C.c_int32),
-                ('allreduce_on_device', C.c_int32)]
+                ('allreduce_on_device', C.c_int32), ('init_sq', C.c_void_p)]
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
@@ -498,7 +498,7 @@ def stagei_desc(NP, faces, marker_vids, m2b, wt_init, frames, nb, weights, pose_
         d.allreduce_sum = C.cast(cb, C.c_void_p)
     out = dict(betas=np.zeros(max(nb, 1)), markers_latent=np.zeros((M, 3)), markers_latent_vids=np.zeros(M, np.int32),
                pose=np.zeros((F, NP)), trans=np.zeros((F, 3)), markers_sim=np.zeros((F, M, 3)), expression=np.zeros((F, max(int(n_expr), 1))), errs=np.zeros(8),
-               iters=np.zeros(1, np.int32))
+               iters=np.zeros(1, np.int32), init_sq=np.zeros(M))
     for k, v in out.items():
         setattr(d, k, v.ctypes.data)
     out['betas'] = out['betas'][:nb]
@@ -512,7 +512,7 @@ EXPORTS['moshii_stagei_solve'] = (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(St
 
 def stagei_solve_host(model: Model, prior, **kw):
     """moshii_stagei_solve on host buffers; kw as stagei_desc().  Returns dict(betas, markers_latent, markers_latent_vids, pose,
-    trans, errs{term: SSE}, iters)."""
+    trans, errs{term: SSE}, iters, init_sq[M]: every marker's share of errs['init'])."""
     require_device()
     desc, out, _keep = stagei_desc(NP=model.NP, **kw)
     check(load().moshii_stagei_solve(model.handle, prior.handle if prior is not None else None, C.byref(desc), None))

@@ -465,12 +465,28 @@ def mosh_stagei(stagei_frames, cfg, betas_fname=None, v_template_fname=None) -> 
                                  wt_init_head=wt_init_head, extra_initial_rigid_adjustment=extra_rigid, **face_kw)
     if nb:
         all_betas[:nb] = out['betas']
-    errs = {k: v for k, v in out['errs'].items() if not (k == 'poseH' and not finger_ids) and not (k == 'beta' and not nb)
-            and not (k == 'poseB' and prior is None) and not (k == 'init_head_corr' and head_corr is None)}
+    # stagei_errs: the SSE of every entry of the last round's opt_objs, under its keys and in its insertion order (:350-398, 415):
+    # data, poseB, init_<type> per marker type of the layout (without 'head' when the head correlation term is on), init_head_corr,
+    # beta, surf, then poseH / poseF / expr of the detailed rounds
+    oe = out['errs']
+    errs = {'data': oe['data']}
+    if len(body_ids) and prior is not None:
+        errs['poseB'] = oe['poseB']
+    init_sq = np.asarray(out.get('init_sq', np.zeros(len(latent_labels))), dtype=np.float64)
+    for k, mask in marker_meta['marker_type_mask'].items():
+        if head_corr is not None and k == 'head':
+            continue
+        errs[f'init_{k}'] = float(init_sq[np.asarray(mask, dtype=bool)].sum())
+    if head_corr is not None:
+        errs['init_head_corr'] = oe['init_head_corr']
+    if nb and not face_kw:
+        errs['beta'] = oe['beta']
+    errs['surf'] = oe['surf']
+    if finger_ids:
+        errs['poseH'] = oe['poseH']
     if face_kw:
-        errs['expr'] = out['errs']['beta']          # the shape block held the expressions
-    else:
-        errs.pop('poseF', None)
+        errs['poseF'] = oe['poseF']
+        errs['expr'] = oe['beta']          # the shape block held the expressions
     # markers_latent_all_vids (:424-430): nearest vertex of the LAST frame's posed body for every valid marker of that frame
     b_last = (all_betas if optimize_betas else np.zeros_like(all_betas)).copy()
     if face_kw:     # opt_models[-1].r carries the last frame's expression coefficients (:300-305)

@@ -1739,6 +1739,10 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                 ds->errs[3] = sse_rows(d.r_beta, d.r_surf); ds->errs[4] = sse_rows(d.r_surf, d.r_poseH); ds->errs[5] = sse_rows(d.r_poseH, d.r_head); ds->errs[6] = sse_rows(d.r_head, d.r_poseF); ds->errs[7] = sse_rows(d.r_poseF, d.R);
                 reduce(ds->errs, 8);
             }
+            if (ds->init_sq) {   // (rows r_init + 3 m .. + 3: marker m's weighted offset from its initial placement; summed over ranks like errs[2])
+                for (int mk = 0; mk < M; ++mk) ds->init_sq[mk] = sse_rows(d.r_init + 3 * mk, d.r_init + 3 * mk + 3);
+                reduce(ds->init_sq, M);
+            }
         }
         int hstat[4];
         hipMemcpyAsync(hstat, p.status, sizeof(hstat), hipMemcpyDeviceToHost, st);

@@ -491,10 +491,32 @@ class _RigidAdjustment:
         return jac['data'][:, self.cols]
 
 
+class _CentralDifferences:
+    """The same residual with its Jacobian taken by central differences (h = 1e-6), as the executed-reference fixture's stand-in
+    for ch.minimize does (tests/golden/make_ref_stageii_golden.py: minimize): for comparing trajectories like with like -- the
+    objective is only piecewise smooth (re-evaluated attachment / nearest triangle), so a differenced Jacobian and the analytic one
+    can part ways at a stopping decision."""
+
+    def __init__(self, obj, h=1e-6):
+        self.obj, self.h = obj, h
+
+    def r(self, x):
+        return self.obj.r(x)
+
+    def J(self, x):
+        cols = []
+        for i in range(len(x)):
+            xp = x.copy(); xp[i] += self.h
+            xm = x.copy(); xm[i] -= self.h
+            cols.append((self.obj.r(xp) - self.obj.r(xm)) / (2 * self.h))
+        self.obj.r(x)
+        return np.array(cols).T
+
+
 def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_mask, m2b_distance, nb, weights=None,
                  optimize_fingers=False, optimize_toes=False, betas_init=None, maxiter=100, stagei_lr=1e-3, exclude_vids=None,
                  head_corr=None, stats=None, optimize_face=False, expr_start=None, n_expr=0,
-                 extra_initial_rigid_adjustment=False):
+                 extra_initial_rigid_adjustment=False, difference_jacobian=False):
     """mosh_stagei's numeric core (chmosh.py:177-447).  `frames`: list of (latent marker ids, obs[n,3]) -- the `common_labels`
     selection of :199-206 already applied; `marker_vids`[M]; `marker_type_mask`: {type: bool[M]}; `m2b_distance`: {type: metres}.
     Returns betas, markers_latent, markers_latent_vids, per-frame pose / trans, per-term SSE of the last round."""
@@ -529,7 +551,7 @@ def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_m
         obj.trans[f] = np.asarray(T).ravel()
     if extra_initial_rigid_adjustment:   # chmosh.py:230-232
         adj = _RigidAdjustment(obj)
-        xa = o2.minimize_dogleg(adj, adj.x(), e_3=.001, delta_0=0.5, maxiter=maxiter, stats=stats)
+        xa = o2.minimize_dogleg(_CentralDifferences(adj) if difference_jacobian else adj, adj.x(), e_3=.001, delta_0=0.5, maxiter=maxiter, stats=stats)
         obj.set_x(adj._full(xa))
     anneal = list(W['stagei_wt_annealing'])
     res = None
@@ -545,7 +567,7 @@ def stagei_solve(m, faces, prior, model_type, frames, marker_vids, marker_type_m
         fc = list(face) if detailed else []
         pose_ids = sorted(set(pose_ids + fing + fc))
         obj.set_round(pose_ids, fing, w, face_ids=fc, expr_on=detailed and optimize_face)
-        x = o2.minimize_dogleg(obj, obj.x(), e_3=stagei_lr, delta_0=0.5, maxiter=maxiter, stats=stats)
+        x = o2.minimize_dogleg(_CentralDifferences(obj) if difference_jacobian else obj, obj.x(), e_3=stagei_lr, delta_0=0.5, maxiter=maxiter, stats=stats)
         obj.set_x(x)
         res = obj.evaluate(x)
     can = obj.can_verts(obj.betas)

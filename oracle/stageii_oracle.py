@@ -524,6 +524,7 @@ def minimize_dogleg(obj, x0, e_3=0.0, delta_0=None, maxiter=200, e_1=1e-15, e_2=
             done = True
     if stats is not None:
         stats['iterations'] = stats.get('iterations', 0) + iteration
+        stats.setdefault('per_call', []).append(iteration)
         stats['fevals'] = stats.get('fevals', 0) + n_fev
         stats['jevals'] = stats.get('jevals', 0) + n_jev
     return p

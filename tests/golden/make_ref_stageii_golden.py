@@ -74,7 +74,22 @@ class Ch(object):
         obj = object.__new__(cls)
         d = obj.__dict__
         d['_dirty'] = set(); d['_seen'] = {}; d['_cache'] = None; d['_cache_ver'] = -1; d['_own_ver'] = _tick()
-        d['_ver_memo'] = (-1, 0); d['_extra'] = []
+        d['_ver_memo'] = (-1, 0); d['_extra'] = []; d['_fn'] = None
+        if cls is Ch and len(args) == 1 and callable(args[0]) and not _is_ch(args[0]):
+            # chumpy: Ch(lambda a, b: expression) -- a node whose inputs are the lambda's arguments, assigned as attributes afterwards
+            import inspect
+            d['_fn'] = args[0]
+            d['_extra'] = list(inspect.signature(args[0]).parameters)
+            return obj
+        if args and cls.__init__ is Ch.__init__:
+            # positional construction of a declared node (TriEdges(f, 1, 0, v), CrossProduct(a, b)): term_order, else terms + dterms
+            order = getattr(cls, 'term_order', None)
+            if order is None:
+                order = []
+                for t in (cls.terms, cls.dterms):
+                    order += [t] if isinstance(t, str) else list(t)
+            for k, v in zip(order, args):
+                setattr(obj, k, v)
         for k, v in kwargs.items():
             if k in obj._input_names():
                 setattr(obj, k, v)
@@ -124,7 +139,10 @@ class Ch(object):
         pass
 
     def compute_r(self):
-        raise NotImplementedError
+        fn = self.__dict__.get('_fn')
+        if fn is None:
+            raise NotImplementedError
+        return _val(fn(**{n: getattr(self, n) for n in self.__dict__['_extra']}))
 
     @property
     def r(self):
@@ -327,11 +345,25 @@ ch.cross = lambda a, b: Op(np.cross, a, b)
 ch.sqrt = lambda a: Op(np.sqrt, a)
 ch.sum = lambda a, axis=None: Op(lambda v: np.atleast_1d(v.sum(axis=axis)), a)
 ch.minimize = minimize
+def depends_on(*_names):
+    """chumpy.depends_on: a cached property invalidated when the named inputs change; here simply re-evaluated at every access."""
+    return lambda fn: property(fn)
+
+
+ch.depends_on = depends_on
+ch.abs = lambda a: Op(np.abs, a)
 ch_ch = types.ModuleType('chumpy.ch')
 ch_ch.MatVecMult = MatVecMult
+ch_ch.Ch = Ch
+ch_ch.depends_on = depends_on
 ch.ch = ch_ch
+ch_utils = types.ModuleType('chumpy.utils')
+ch_utils.row = lambda a: np.asarray(a).reshape((1, -1))
+ch_utils.col = lambda a: np.asarray(a).reshape((-1, 1))
+ch.utils = ch_utils
 sys.modules['chumpy'] = ch
 sys.modules['chumpy.ch'] = ch_ch
+sys.modules['chumpy.utils'] = ch_utils
 
 
 # ---------------------------------------------------------------------------------------------------

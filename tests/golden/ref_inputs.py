@@ -289,3 +289,52 @@ def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_f
                 mocap_fname=mocap_fname, markers_latent=s['markers_latent'], latent_labels=s['latent_labels'], betas=s['betas'],
                 marker_meta=s['marker_meta'], dof_per_hand=dof_per_hand, use_hands_mean=use_hands_mean, model_type=model_type,
                 dmpl_fname=dmpl_fname, free_dirs=free_dirs, n_free_shape=int(n_free_shape), shape_kind=shape_kind)
+
+
+def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_per_hand=12, finger_markers=False, head_markers=0):
+    """One seeded Stage-I call as the reference reads it: model pickle (with faces), body-prior pickle, hand-prior npz and the marker
+    layout json written to `outdir`, plus the list of frame dicts {label: xyz} `mosh_stagei` takes (one label the layout does not
+    know, one NaN observation).  The problem is synth.make_stagei_problem's (triangulated capsule body, ground-truth subject a few
+    millimetres off the layout).  Returns the file names, the frames and the arrays the oracle's stagei_solve takes."""
+    import json
+    import pickle
+    import scipy.sparse as sp
+    from moshpp_amd import synth
+    pb = synth.make_stagei_problem(model_type, n_verts=n_verts, nb=nb, M=n_markers, F=n_frames, seed=seed, dof_per_hand=dof_per_hand,
+                                   finger_markers=finger_markers)
+    dd = pb['dd']
+    pk = {k: v for k, v in dd.items() if not k.startswith('_') and k != 'model_type'}
+    pk['J_regressor'] = sp.csc_matrix(dd['J_regressor'])
+    model_fname = os.path.join(outdir, 'model.pkl')
+    with open(model_fname, 'wb') as fh:
+        pickle.dump(pk, fh, protocol=2)
+    body_prior_fname = None
+    if model_type != 'mano':
+        body_prior_fname = os.path.join(outdir, 'body_prior.pkl')
+        with open(body_prior_fname, 'wb') as fh:
+            pickle.dump(pb['gmm'], fh, protocol=2)
+    hand_prior_fname = None
+    if model_type in ('smplh', 'smplx'):
+        hand_prior_fname = os.path.join(outdir, 'hand_prior.npz')
+        np.savez(hand_prior_fname, **synth.synth_hand_prior(seed))
+    labels = [f'MK{i:02d}' for i in range(n_markers)]
+    K = dd['weights'].shape[1]
+    dom = np.argmax(dd['weights'][pb['vids']], axis=1)
+    types_ = ['body'] * n_markers
+    if finger_markers:
+        hand0 = (3 * K - 90) // 3
+        types_ = ['finger' if d >= hand0 else 'body' for d in dom]
+    sets = []
+    for t in sorted(set(types_)):
+        sets.append({'type': t, 'distance_from_skin': float(pb['skin']),
+                     'indices': {l: int(v) for l, v, tt in zip(labels, pb['vids'], types_) if tt == t}})
+    layout_fname = os.path.join(outdir, 'layout.json')
+    with open(layout_fname, 'w') as fh:
+        json.dump({'surface_model_type': model_type, 'markersets': sets}, fh)
+    frames = [{labels[i]: np.asarray(xyz, dtype=np.float64) for i, xyz in zip(ids, obs)} for ids, obs in pb['frames']]
+    frames[0]['UNKNOWN'] = np.zeros(3)                               # a label the layout does not know: ignored (chmosh.py:199-206)
+    drop = sorted(frames[1])[0]
+    frames[1][drop] = np.full(3, np.nan)                             # a NaN observation: dropped from that frame (:201)
+    return dict(problem=pb, model_fname=model_fname, body_prior_fname=body_prior_fname, hand_prior_fname=hand_prior_fname,
+                layout_fname=layout_fname, frames=frames, labels=labels, types=types_, dof_per_hand=dof_per_hand, model_type=model_type,
+                nb=nb)

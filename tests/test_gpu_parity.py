@@ -296,6 +296,29 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
 
 
+def test_lbs_f32_soak_random_frame_counts(gpu_lib):
+    """Soak of the export kernel: 24 seeded frame counts between 1 and 1500 (partial frame tiles of every size, one to twelve frame tiles,
+    workgroups with and without a second tile), fresh random poses each, against the float64 kernel; every call repeated once and
+    compared bit for bit (a wrong DMA wait or a stale LDS buffer shows up as a difference between two runs before it shows up as
+    an error above the tolerance)."""
+    case = oracle_case('smplh', F=4, M=53, seed=77)
+    dev = device_case(case)
+    m = case['m']
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for F in [1, 15, 16, 17, 127, 128, 129] + [int(f) for f in rng.integers(2, 1500, 17)]:
+        pose = rng.normal(0, 0.4, (F, m['NP']))
+        trans = rng.normal(0, 1.5, (F, 3))
+        ref = dev['model'].lbs_forward(pose, trans)
+        got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+        again = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+        np.testing.assert_array_equal(got, again, err_msg=f'F={F}: two runs differ')
+        e = float(np.abs(got - ref).max())
+        assert e < 2e-5, (F, e)
+        worst = max(worst, e)
+    print(f'soak: worst |f32 export - f64| {worst:.2e} m')
+
+
 @pytest.mark.parametrize('strategy', ['carry_on', 'rounds', 'one_chunk_per_chain'])
 def test_sequence_solve_cascading_repairs_stay_consistent(gpu_lib, strategy):
     """Short warm-up + tight tolerance makes most hand-offs fail, in runs.  Every repair strategy must end on the sequential

@@ -179,7 +179,7 @@ def test_mosh_stagei_then_stageii_end_to_end(tmp_path):
     assert set(stagei) >= {'betas', 'markers_latent', 'latent_labels', 'marker_meta', 'markers_latent_vids', 'stagei_debug_details'}
     assert stagei['latent_labels'] == labels and stagei['betas'].shape == (10,) and stagei['markers_latent'].shape == (M, 3)
     dbg = stagei['stagei_debug_details']
-    assert set(dbg['stagei_errs']) == {'data', 'poseB', 'init', 'beta', 'surf'} and len(dbg['stagei_fnames']) == 5
+    assert list(dbg['stagei_errs']) == ['data', 'poseB', 'init_body', 'init_head', 'beta', 'surf'] and len(dbg['stagei_fnames']) == 5
     assert os.path.exists(tmp_path / 'out' / 'stagei.pkl')
     assert len(dbg['stagei_markers_sim_all']) == 5 and dbg['stagei_markers_sim_all'][0].shape == (M, 3)
     assert all(a.shape == b.shape for a, b in zip(dbg['stagei_markers_sim'], dbg['stagei_markers_obs']))
@@ -256,3 +256,32 @@ def test_stagei_allreduce_on_device_through_rccl(tmp_path):
     assert int(o['iters'][0]) == int(o['iters'][1])
     assert np.abs(o['betas'] - o['betas1']).max() < 1e-9 and np.abs(o['ml'] - o['ml1']).max() < 1e-10
     assert np.abs(o['pose'] - o['pose1']).max() < 1e-9
+
+
+@pytest.mark.parametrize('name', ['smplh_body', 'smplh_extra_rigid', 'smplh_fingers'])
+def test_mosh_stagei_matches_executed_reference(name, tmp_path):
+    """The drop-in `mosh_stagei` (files in, dict out; kernels on the GPU) against the reference's own `mosh_stagei` EXECUTED on the
+    same files and frame dicts (tests/golden/make_ref_stagei_golden.py -> ref_stagei.npz): result keys, the per-frame label matching,
+    betas / latent markers / poses / translations, nearest vertex ids, and stagei_errs under the reference's keys in its order."""
+    from moshpp_amd import chmosh
+    from moshpp_amd.cfg import make_cfg
+    from tests.test_ref_golden import stagei_ref_case, check_stagei_against_reference_run
+    sc = stagei_ref_case(name, tmp_path)
+    c, ref = sc['case'], sc['ref']
+    cfg = make_cfg(**{'surface_model.type': sc['model_type'], 'surface_model.fname': c['model_fname'], 'surface_model.num_betas': sc['nb'],
+                      'surface_model.dof_per_hand': c['dof_per_hand'], 'surface_model.use_hands_mean': False,
+                      'moshpp.pose_body_prior_fname': c['body_prior_fname'], 'moshpp.pose_hand_prior_fname': c['hand_prior_fname'],
+                      'moshpp.optimize_fingers': sc['fingers'], 'opt_settings.extra_initial_rigid_adjustment': sc['extra'],
+                      'dirs.marker_layout.fname': c['layout_fname']})
+    res = chmosh.mosh_stagei(c['frames'], cfg)
+    assert sorted(res) == list(ref[f'{name}_keys'])
+    assert bool(cfg.moshpp.optimize_fingers) == bool(ref[f'{name}_optimize_fingers_after'])
+    assert res['latent_labels'] == list(ref[f'{name}_latent_labels'])
+    dbg = res['stagei_debug_details']
+    assert set(ref[f'{name}_debug_keys']) <= set(dbg)
+    assert ['|'.join(sorted(l)) for l in dbg['stagei_labels_obs']] == list(ref[f'{name}_labels_obs'])
+    got = dict(betas=res['betas'][:sc['nb']], markers_latent=res['markers_latent'],
+               markers_latent_vids=[res['markers_latent_vids'][l] for l in res['latent_labels']],
+               pose=np.array(dbg['opt_models_pose']), trans=np.array(dbg['opt_models_trans']), errs=dbg['stagei_errs'])
+    assert np.all(res['betas'][sc['nb']:] == 0)
+    check_stagei_against_reference_run(name, ref, got)

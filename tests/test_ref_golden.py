@@ -373,3 +373,93 @@ def test_host_mosh_stageii_keys_match_reference_function(name, tmp_path):
     src = inspect.getsource(chmosh.mosh_stageii)
     for k in list(ref[f'{name}_keys']) + list(ref[f'{name}_debug_keys']):
         assert f"'{k}'" in src, k
+
+
+# ---- Stage-I: the reference's own mosh_stagei + prepare_mosh_markers_latent + PtsToMesh / MeshDistanceSquared executed
+#      (tests/golden/make_ref_stagei_golden.py -> ref_stagei.npz)
+STAGEI_REF_CASES = ('smplh_body', 'smplh_extra_rigid', 'smplh_fingers')
+
+
+def stagei_ref_case(name, tmp_path):
+    """The seeded inputs of one Stage-I fixture case, rebuilt (no reference needed): the files `mosh_stagei` reads, the frame dicts,
+    and the same problem prepared for the oracle's stagei_solve; + the fixture arrays."""
+    from tests.golden.ref_inputs import stagei_case
+    ref = np.load(os.path.join(GOLD, 'ref_stagei.npz'))
+    V, nb, M, F, seed, fingers, extra = [int(v) for v in ref[f'{name}_args']]
+    mt = str(ref[f'{name}_model_type'])
+    c = stagei_case(mt, V, nb, M, F, seed, str(tmp_path), finger_markers=bool(fingers))
+    pb = c['problem']
+    labels, types_ = c['labels'], c['types']
+    # the layout's order: marker sets by type, labels sorted inside (marker_layout_load, edit_tools.py:83-183; pinned above)
+    order = [i for t in sorted(set(types_)) for i in sorted(range(M), key=lambda i: labels[i]) if types_[i] == t]
+    lab = [labels[i] for i in order]
+    assert lab == list(ref[f'{name}_latent_labels'])
+    typ = [types_[i] for i in order]
+    mask = {t: np.array([tt == t for tt in typ]) for t in sorted(set(typ))}
+    frames = []
+    for fr in c['frames']:       # chmosh.py:199-206: labels the layout knows, without NaN observations
+        ids = [k for k, l in enumerate(lab) if l in fr and not np.any(np.isnan(fr[l]))]
+        frames.append((np.array(ids), np.array([fr[lab[k]] for k in ids])))
+    return dict(ref=ref, case=c, pb=pb, model_type=mt, nb=nb, M=M, F=F, fingers=bool(fingers), extra=bool(extra), labels=lab,
+                vids=np.asarray(pb['vids'])[order], mask=mask, m2b={t: pb['skin'] for t in mask}, frames=frames)
+
+
+def check_stagei_against_reference_run(name, ref, got, iters_per_call=None):
+    """`got`: betas, markers_latent, markers_latent_vids, pose, trans, errs {reference key: SSE}.  The fixture's solves used a
+    central-difference Jacobian of the reference's residuals, ours the analytic one; on this piecewise-smooth objective (attachment and
+    nearest triangle re-evaluated at every point) the two part ways at a stopping decision in two of the three cases (last round:
+    3 vs 4 iterations; 11 + 17 vs 7 + 10 with the weakly determined finger block), so those are held to 2e-3, the third -- where the
+    iteration counts of all five solves agree -- to 1e-6.  With a differenced Jacobian on the oracle's side all three agree to 1e-7
+    with equal iteration counts in every solve (tests/golden/check_ref_stagei.py, output in tests/golden/ref_stagei_check.txt)."""
+    nb = len(got['betas'])
+    tight = name == 'smplh_extra_rigid'
+    tol = dict(betas=1e-6, ml=1e-7, pose=1e-6, trans=1e-7, errs=1e-5) if tight else dict(betas=2e-3, ml=1e-3, pose=5e-3, trans=2e-4, errs=0.5)
+    assert np.abs(got['betas'] - ref[f'{name}_betas'][:nb]).max() < tol['betas']
+    assert np.all(ref[f'{name}_betas'][nb:] == 0)
+    assert np.abs(got['markers_latent'] - ref[f'{name}_markers_latent']).max() < tol['ml']
+    assert np.abs(got['pose'] - ref[f'{name}_pose']).max() < tol['pose']
+    assert np.abs(got['trans'] - ref[f'{name}_trans']).max() < tol['trans']
+    np.testing.assert_array_equal(np.asarray(got['markers_latent_vids']), ref[f'{name}_markers_latent_vids'])
+    assert list(got['errs']) == list(ref[f'{name}_err_keys']), (list(got['errs']), list(ref[f'{name}_err_keys']))   # names AND order (:350-398)
+    np.testing.assert_allclose([got['errs'][k] for k in got['errs']], ref[f'{name}_errs'], rtol=tol['errs'])
+    if iters_per_call is not None:
+        want = ref[f'{name}_minimize_calls'][:, 2].tolist()
+        assert len(iters_per_call) == len(want)                      # [extra rigid adjustment +] one solve per annealing factor
+        if tight:
+            assert list(iters_per_call) == want
+        else:
+            assert list(iters_per_call)[:2] == want[:2]
+
+
+def oracle_errs_under_reference_keys(errs, mask):
+    """The oracle numbers its init terms (init_0, ...) in the order of the type masks; the reference names them init_<type>."""
+    out = {}
+    for k, v in errs.items():
+        if k.startswith('init_') and k[5:].isdigit():
+            out['init_' + list(mask)[int(k[5:])]] = v
+        else:
+            out[k] = v
+    order = ['data', 'poseB'] + [f'init_{t}' for t in mask] + ['init_head_corr', 'beta', 'surf', 'poseH', 'poseF', 'expr']
+    return {k: out[k] for k in order if k in out}
+
+
+@pytest.mark.parametrize('name', STAGEI_REF_CASES)
+def test_stagei_schedule_matches_reference_function(name, tmp_path):
+    """The oracle's stagei_solve against the EXECUTED reference mosh_stagei (ref_stagei.npz): annealing rounds, weights, free sets
+    (toes out, fingers only in the last two rounds), label matching, rigid start [+ the extra rigid adjustment], surface term."""
+    from oracle import stagei_oracle as s1
+    sc = stagei_ref_case(name, tmp_path)
+    ref = sc['ref']
+    assert bool(ref[f'{name}_optimize_fingers_after']) == sc['fingers']
+    assert list(ref[f'{name}_keys']) == sorted(['betas', 'markers_latent', 'latent_labels', 'marker_meta', 'markers_latent_vids',
+                                                'stagei_debug_details'])
+    n_obs = [len(l.split('|')) for l in ref[f'{name}_labels_obs']]
+    assert n_obs == [len(ids) for ids, _ in sc['frames']]
+    assert list(ref[f'{name}_labels_obs']) == ['|'.join(sorted(sc['labels'][k] for k in ids)) for ids, _ in sc['frames']]
+    m = so.prepare_model(sc['pb']['model'])
+    prior = so.prepare_gmm_prior(sc['pb']['gmm'], 63)
+    st = {}
+    got = s1.stagei_solve(m, sc['pb']['faces'], prior, sc['model_type'], sc['frames'], sc['vids'], sc['mask'], sc['m2b'], sc['nb'],
+                          optimize_fingers=sc['fingers'], extra_initial_rigid_adjustment=sc['extra'], stats=st)
+    got = dict(got, errs=oracle_errs_under_reference_keys(got['errs'], sc['mask']))
+    check_stagei_against_reference_run(name, ref, got, iters_per_call=st['per_call'])

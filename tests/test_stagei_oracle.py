@@ -181,7 +181,7 @@ def test_mosh_stagei_host_path_on_cpu(tmp_path, monkeypatch):
     assert set(res) == {'betas', 'markers_latent', 'latent_labels', 'marker_meta', 'markers_latent_vids', 'stagei_debug_details'}
     assert res['latent_labels'] == labels and res['betas'].shape == (10,) and np.all(res['betas'][4:] == 0)
     dbg = res['stagei_debug_details']
-    assert set(dbg['stagei_errs']) == {'data', 'poseB', 'init', 'beta', 'surf'}
+    assert set(dbg['stagei_errs']) == {'data', 'poseB', 'init_body', 'beta', 'surf'}
     assert [len(l) for l in dbg['stagei_labels_obs']] == [len(pb['frames'][0][0]), len(pb['frames'][1][0]) - (0 in pb['frames'][1][0]),
                                                           len(pb['frames'][2][0])]
     assert labels[0] not in dbg['stagei_labels_obs'][1]
