@@ -18,15 +18,16 @@ for name in (sys.argv[1:] or STAGEI_REF_CASES):
         sc = stagei_ref_case(name, tempfile.mkdtemp())
         z = sc['ref']
         m = so.prepare_model(sc['pb']['model'])
-        prior = so.prepare_gmm_prior(sc['pb']['gmm'], 63)
+        prior = so.prepare_gmm_prior(sc['pb']['gmm'], sc['npose']) if sc['npose'] else None
         st = {}
         got = s1.stagei_solve(m, sc['pb']['faces'], prior, sc['model_type'], sc['frames'], sc['vids'], sc['mask'], sc['m2b'], sc['nb'],
-                              optimize_fingers=sc['fingers'], extra_initial_rigid_adjustment=sc['extra'], stats=st, difference_jacobian=diff)
-        errs = oracle_errs_under_reference_keys(got['errs'], sc['mask'])
+                              optimize_fingers=sc['fingers'], extra_initial_rigid_adjustment=sc['extra'], stats=st, difference_jacobian=diff,
+                              head_corr=sc['head_corr'], betas_init=sc['betas_init'])
+        errs = oracle_errs_under_reference_keys(got['errs'], sc['mask'], drop_head=sc['head_corr'] is not None)
         nb = sc['nb']
         print(f"{name} [oracle Jacobian: {'central differences (as the fixture)' if diff else 'analytic'}]")
         print('  dogleg iterations per solve: oracle', st['per_call'], '| executed reference', z[f'{name}_minimize_calls'][:, 2].tolist())
-        print(f"  max |difference|: betas {np.abs(got['betas'] - z[f'{name}_betas'][:nb]).max():.2e}  markers_latent "
+        print(f"  max |difference|: betas {np.abs(got['betas'] - z[f'{name}_betas'][:nb]).max() if nb else 0.0:.2e}  markers_latent "
               f"{np.abs(got['markers_latent'] - z[f'{name}_markers_latent']).max():.2e} m  pose {np.abs(got['pose'] - z[f'{name}_pose']).max():.2e} rad  "
               f"trans {np.abs(got['trans'] - z[f'{name}_trans']).max():.2e} m  vids equal {np.array_equal(got['markers_latent_vids'], z[f'{name}_markers_latent_vids'])}")
         print('  SSE oracle   ', {k: float(f'{v:.6g}') for k, v in errs.items()})

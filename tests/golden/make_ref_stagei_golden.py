@@ -112,14 +112,16 @@ def _marker_layout_load(mods):
     return ns['marker_layout_load']
 
 
-def run_reference_stagei(model_type, n_verts, nb, n_markers, n_frames, seed, optimize_fingers=False, extra_rigid=False):
+def run_reference_stagei(model_type, n_verts, nb, n_markers, n_frames, seed, optimize_fingers=False, extra_rigid=False, head=0,
+                         optimize_betas=True, betas_init=False):
     from pathlib import Path
     from typing import Dict, List, Union
     from sklearn.neighbors import NearestNeighbors
     from tests.golden.ref_inputs import stagei_case
     mods = _install()
     tmp = tempfile.mkdtemp(prefix='ref_stagei_')
-    case = stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, tmp, finger_markers=optimize_fingers)
+    case = stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, tmp, finger_markers=optimize_fingers, head_markers=head,
+                       betas_init=betas_init)
     src = open(os.path.join(REF, 'chmosh.py')).read()
     fns = {n.name: n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef)}
     ns = {'np': np, 'ch': H.ch, 'logger': H._quiet, 'Path': Path, 'Union': Union, 'List': List, 'Dict': Dict, 'DictConfig': dict,
@@ -133,16 +135,16 @@ def run_reference_stagei(model_type, n_verts, nb, n_markers, n_frames, seed, opt
     cfg = H.Cfg.of(dict(
         mocap=dict(exclude_markers=None, exclude_marker_types=None, only_markers=None),
         dirs=dict(marker_layout=dict(fname=case['layout_fname'])),
-        moshpp=dict(optimize_betas=True, optimize_fingers=optimize_fingers, optimize_face=False, optimize_toes=False, optimize_dynamics=False,
+        moshpp=dict(optimize_betas=optimize_betas, optimize_fingers=optimize_fingers, optimize_face=False, optimize_toes=False, optimize_dynamics=False,
                     pose_hand_prior_fname=case['hand_prior_fname'], pose_body_prior_fname=case['body_prior_fname'], verbosity=0,
-                    head_marker_corr_fname=None, stagei_frame_picker=dict(num_frames=n_frames),
+                    head_marker_corr_fname=case['head_corr_fname'], stagei_frame_picker=dict(num_frames=n_frames),
                     visualization=dict(marker_radius=dict(body=0.009))),
         surface_model=dict(fname=case['model_fname'], type=model_type, use_hands_mean=False, dof_per_hand=case['dof_per_hand'],
                            num_betas=nb, num_expressions=0, betas_expr_start_id=300),
         opt_settings=dict(maxiter=100, stagei_lr=1e-3, weights_type=model_type, extra_initial_rigid_adjustment=extra_rigid,
                           weights=dict(W))))
     del H.N_MINIMIZE[:]
-    out = ns['mosh_stagei'](case['frames'], cfg)
+    out = ns['mosh_stagei'](case['frames'], cfg, betas_fname=case['betas_fname'])
     return out, case, cfg
 
 
@@ -150,6 +152,11 @@ CASES = {   # name: (model type, vertices, free betas, markers, frames, seed, sw
     'smplh_body': dict(mt='smplh', V=700, nb=4, M=16, F=3, seed=21),                       # BASELINE config 4's calibration part, small
     'smplh_extra_rigid': dict(mt='smplh', V=700, nb=3, M=14, F=2, seed=22, extra_rigid=True),   # opt_settings.extra_initial_rigid_adjustment (:230-232)
     'smplh_fingers': dict(mt='smplh', V=900, nb=3, M=22, F=2, seed=23, fingers=True),      # finger markers: poseH + finger ids in the last two rounds (:389-393)
+    'smplh_head_corr': dict(mt='smplh', V=700, nb=3, M=16, F=2, seed=24, head=4),          # head_marker_corr_fname: init_<type> without 'head', init_head_corr (:252-266, 362-369)
+    'smplh_fixed_betas': dict(mt='smplh', V=700, nb=3, M=14, F=2, seed=25, optimize_betas=False),   # optimize_betas off: no beta term, betas not free (:155, 374, 402)
+    'smplh_betas_init': dict(mt='smplh', V=700, nb=3, M=14, F=2, seed=26, betas_init=True),         # betas_fname given, optimize_betas on: the solve starts from them (:93-98, 164-170)
+    'smpl_body': dict(mt='smpl', V=700, nb=3, M=14, F=2, seed=27),                         # SMPL: pose_body_ids = all_pose_ids[3:], 69-d prior (:284-285)
+    'mano_fingers': dict(mt='mano', V=500, nb=3, M=12, F=2, seed=28, fingers=True),        # MANO: no body ids / prior, pose_finger_ids = all_pose_ids[3:] (:306-307)
 }
 
 
@@ -161,10 +168,13 @@ def main():
         if only and name not in only:
             continue
         res, case, cfg = run_reference_stagei(cs['mt'], cs['V'], cs['nb'], cs['M'], cs['F'], cs['seed'],
-                                              optimize_fingers=cs.get('fingers', False), extra_rigid=cs.get('extra_rigid', False))
+                                              optimize_fingers=cs.get('fingers', False), extra_rigid=cs.get('extra_rigid', False),
+                                              head=cs.get('head', 0), optimize_betas=cs.get('optimize_betas', True),
+                                              betas_init=cs.get('betas_init', False))
         dbg = res['stagei_debug_details']
         out[f'{name}_args'] = np.array([cs['V'], cs['nb'], cs['M'], cs['F'], cs['seed'], int(cs.get('fingers', False)),
-                                        int(cs.get('extra_rigid', False))], dtype=np.int64)
+                                        int(cs.get('extra_rigid', False)), int(cs.get('head', 0)), int(cs.get('optimize_betas', True)),
+                                        int(cs.get('betas_init', False))], dtype=np.int64)
         out[f'{name}_model_type'] = np.array(cs['mt'])
         out[f'{name}_optimize_fingers_after'] = np.array(bool(cfg.moshpp.optimize_fingers))
         out[f'{name}_betas'] = np.asarray(res['betas'], dtype=np.float64)

@@ -291,7 +291,8 @@ def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_f
                 dmpl_fname=dmpl_fname, free_dirs=free_dirs, n_free_shape=int(n_free_shape), shape_kind=shape_kind)
 
 
-def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_per_hand=12, finger_markers=False, head_markers=0):
+def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_per_hand=12, finger_markers=False, head_markers=0,
+                betas_init=False):
     """One seeded Stage-I call as the reference reads it: model pickle (with faces), body-prior pickle, hand-prior npz and the marker
     layout json written to `outdir`, plus the list of frame dicts {label: xyz} `mosh_stagei` takes (one label the layout does not
     know, one NaN observation).  The problem is synth.make_stagei_problem's (triangulated capsule body, ground-truth subject a few
@@ -324,6 +325,19 @@ def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_
     if finger_markers:
         hand0 = (3 * K - 90) // 3
         types_ = ['finger' if d >= hand0 else 'body' for d in dom]
+    head_corr_fname = None
+    if head_markers:       # the last `head_markers` labels form a 'head' set with a correlation file (chmosh.py:252-266, 362-369)
+        for i in range(n_markers - head_markers, n_markers):
+            types_[i] = 'head'
+        head_corr_fname = os.path.join(outdir, 'head_corr.npz')
+        np.savez(head_corr_fname, mrk_labels=np.array(labels[n_markers - head_markers:]),
+                 corr=np.random.default_rng(seed + 1000).normal(0, 1, (3, head_markers)))
+    betas_fname = None
+    if betas_init:         # betas_fname: a previous shape estimate the solve starts from (chmosh.py:93-98, 164-170)
+        betas_fname = os.path.join(outdir, 'betas.npz')
+        b0 = np.zeros(dd['shapedirs'].shape[2])
+        b0[:nb] = np.random.default_rng(seed + 2000).normal(0, 0.3, nb)
+        np.savez(betas_fname, betas=b0)
     sets = []
     for t in sorted(set(types_)):
         sets.append({'type': t, 'distance_from_skin': float(pb['skin']),
@@ -337,4 +351,4 @@ def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_
     frames[1][drop] = np.full(3, np.nan)                             # a NaN observation: dropped from that frame (:201)
     return dict(problem=pb, model_fname=model_fname, body_prior_fname=body_prior_fname, hand_prior_fname=hand_prior_fname,
                 layout_fname=layout_fname, frames=frames, labels=labels, types=types_, dof_per_hand=dof_per_hand, model_type=model_type,
-                nb=nb)
+                nb=nb, head_corr_fname=head_corr_fname, betas_fname=betas_fname)

@@ -258,7 +258,8 @@ def test_stagei_allreduce_on_device_through_rccl(tmp_path):
     assert np.abs(o['pose'] - o['pose1']).max() < 1e-9
 
 
-@pytest.mark.parametrize('name', ['smplh_body', 'smplh_extra_rigid', 'smplh_fingers'])
+@pytest.mark.parametrize('name', ['smplh_body', 'smplh_extra_rigid', 'smplh_fingers', 'smplh_head_corr', 'smplh_fixed_betas',
+                                  'smplh_betas_init', 'smpl_body', 'mano_fingers'])
 def test_mosh_stagei_matches_executed_reference(name, tmp_path):
     """The drop-in `mosh_stagei` (files in, dict out; kernels on the GPU) against the reference's own `mosh_stagei` EXECUTED on the
     same files and frame dicts (tests/golden/make_ref_stagei_golden.py -> ref_stagei.npz): result keys, the per-frame label matching,
@@ -268,12 +269,14 @@ def test_mosh_stagei_matches_executed_reference(name, tmp_path):
     from tests.test_ref_golden import stagei_ref_case, check_stagei_against_reference_run
     sc = stagei_ref_case(name, tmp_path)
     c, ref = sc['case'], sc['ref']
-    cfg = make_cfg(**{'surface_model.type': sc['model_type'], 'surface_model.fname': c['model_fname'], 'surface_model.num_betas': sc['nb'],
+    cfg = make_cfg(**{'surface_model.type': sc['model_type'], 'surface_model.fname': c['model_fname'], 'surface_model.num_betas': sc['nb_cfg'],
                       'surface_model.dof_per_hand': c['dof_per_hand'], 'surface_model.use_hands_mean': False,
                       'moshpp.pose_body_prior_fname': c['body_prior_fname'], 'moshpp.pose_hand_prior_fname': c['hand_prior_fname'],
-                      'moshpp.optimize_fingers': sc['fingers'], 'opt_settings.extra_initial_rigid_adjustment': sc['extra'],
-                      'dirs.marker_layout.fname': c['layout_fname']})
-    res = chmosh.mosh_stagei(c['frames'], cfg)
+                      'moshpp.optimize_fingers': sc['fingers'], 'moshpp.optimize_betas': sc['optimize_betas'],
+                      'moshpp.head_marker_corr_fname': c['head_corr_fname'],
+                      'opt_settings.extra_initial_rigid_adjustment': sc['extra'], 'dirs.marker_layout.fname': c['layout_fname'],
+                      'opt_settings.weights_type': 'smplh'})   # (the yaml has no smpl / mano tables: the fixture used the smplh weights)
+    res = chmosh.mosh_stagei(c['frames'], cfg, betas_fname=c['betas_fname'])
     assert sorted(res) == list(ref[f'{name}_keys'])
     assert bool(cfg.moshpp.optimize_fingers) == bool(ref[f'{name}_optimize_fingers_after'])
     assert res['latent_labels'] == list(ref[f'{name}_latent_labels'])
