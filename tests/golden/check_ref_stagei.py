@@ -22,7 +22,8 @@ for name in (sys.argv[1:] or STAGEI_REF_CASES):
         st = {}
         got = s1.stagei_solve(m, sc['pb']['faces'], prior, sc['model_type'], sc['frames'], sc['vids'], sc['mask'], sc['m2b'], sc['nb'],
                               optimize_fingers=sc['fingers'], extra_initial_rigid_adjustment=sc['extra'], stats=st, difference_jacobian=diff,
-                              head_corr=sc['head_corr'], betas_init=sc['betas_init'])
+                              head_corr=sc['head_corr'], betas_init=sc['betas_init'], optimize_face=sc['face'],
+                              expr_start=sc['expr_start'] if sc['face'] else None, n_expr=sc['n_expr'])
         errs = oracle_errs_under_reference_keys(got['errs'], sc['mask'], drop_head=sc['head_corr'] is not None)
         nb = sc['nb']
         print(f"{name} [oracle Jacobian: {'central differences (as the fixture)' if diff else 'analytic'}]")

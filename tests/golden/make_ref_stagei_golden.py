@@ -113,7 +113,7 @@ def _marker_layout_load(mods):
 
 
 def run_reference_stagei(model_type, n_verts, nb, n_markers, n_frames, seed, optimize_fingers=False, extra_rigid=False, head=0,
-                         optimize_betas=True, betas_init=False):
+                         optimize_betas=True, betas_init=False, face=False, n_expr=0, expr_start=300):
     from pathlib import Path
     from typing import Dict, List, Union
     from sklearn.neighbors import NearestNeighbors
@@ -121,7 +121,7 @@ def run_reference_stagei(model_type, n_verts, nb, n_markers, n_frames, seed, opt
     mods = _install()
     tmp = tempfile.mkdtemp(prefix='ref_stagei_')
     case = stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, tmp, finger_markers=optimize_fingers, head_markers=head,
-                       betas_init=betas_init)
+                       betas_init=betas_init, face_markers=face)
     src = open(os.path.join(REF, 'chmosh.py')).read()
     fns = {n.name: n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef)}
     ns = {'np': np, 'ch': H.ch, 'logger': H._quiet, 'Path': Path, 'Union': Union, 'List': List, 'Dict': Dict, 'DictConfig': dict,
@@ -135,12 +135,12 @@ def run_reference_stagei(model_type, n_verts, nb, n_markers, n_frames, seed, opt
     cfg = H.Cfg.of(dict(
         mocap=dict(exclude_markers=None, exclude_marker_types=None, only_markers=None),
         dirs=dict(marker_layout=dict(fname=case['layout_fname'])),
-        moshpp=dict(optimize_betas=optimize_betas, optimize_fingers=optimize_fingers, optimize_face=False, optimize_toes=False, optimize_dynamics=False,
+        moshpp=dict(optimize_betas=optimize_betas, optimize_fingers=optimize_fingers, optimize_face=face, optimize_toes=False, optimize_dynamics=False,
                     pose_hand_prior_fname=case['hand_prior_fname'], pose_body_prior_fname=case['body_prior_fname'], verbosity=0,
                     head_marker_corr_fname=case['head_corr_fname'], stagei_frame_picker=dict(num_frames=n_frames),
                     visualization=dict(marker_radius=dict(body=0.009))),
         surface_model=dict(fname=case['model_fname'], type=model_type, use_hands_mean=False, dof_per_hand=case['dof_per_hand'],
-                           num_betas=nb, num_expressions=0, betas_expr_start_id=300),
+                           num_betas=nb, num_expressions=n_expr, betas_expr_start_id=expr_start),
         opt_settings=dict(maxiter=100, stagei_lr=1e-3, weights_type=model_type, extra_initial_rigid_adjustment=extra_rigid,
                           weights=dict(W))))
     del H.N_MINIMIZE[:]
@@ -157,6 +157,9 @@ CASES = {   # name: (model type, vertices, free betas, markers, frames, seed, sw
     'smplh_betas_init': dict(mt='smplh', V=700, nb=3, M=14, F=2, seed=26, betas_init=True),         # betas_fname given, optimize_betas on: the solve starts from them (:93-98, 164-170)
     'smpl_body': dict(mt='smpl', V=700, nb=3, M=14, F=2, seed=27),                         # SMPL: pose_body_ids = all_pose_ids[3:], 69-d prior (:284-285)
     'mano_fingers': dict(mt='mano', V=500, nb=3, M=12, F=2, seed=28, fingers=True),        # MANO: no body ids / prior, pose_finger_ids = all_pose_ids[3:] (:306-307)
+    # SMPL-X optimize_face: betas fixed (the reference refuses shared betas + per-frame expressions, :295-299), every frame's model with
+    # its own betas vector, jaw ids 66:69 + the expression block free in the last two rounds, poseF / expr terms (:300-305, 394-398)
+    'smplx_face': dict(mt='smplx', V=800, nb=4, M=18, F=2, seed=29, face=True, optimize_betas=False, E=5, expr_start=4),
 }
 
 
@@ -170,11 +173,13 @@ def main():
         res, case, cfg = run_reference_stagei(cs['mt'], cs['V'], cs['nb'], cs['M'], cs['F'], cs['seed'],
                                               optimize_fingers=cs.get('fingers', False), extra_rigid=cs.get('extra_rigid', False),
                                               head=cs.get('head', 0), optimize_betas=cs.get('optimize_betas', True),
-                                              betas_init=cs.get('betas_init', False))
+                                              betas_init=cs.get('betas_init', False), face=cs.get('face', False), n_expr=cs.get('E', 0),
+                                              expr_start=cs.get('expr_start', 300))
         dbg = res['stagei_debug_details']
         out[f'{name}_args'] = np.array([cs['V'], cs['nb'], cs['M'], cs['F'], cs['seed'], int(cs.get('fingers', False)),
                                         int(cs.get('extra_rigid', False)), int(cs.get('head', 0)), int(cs.get('optimize_betas', True)),
-                                        int(cs.get('betas_init', False))], dtype=np.int64)
+                                        int(cs.get('betas_init', False)), int(cs.get('face', False)), int(cs.get('E', 0)),
+                                        int(cs.get('expr_start', 300))], dtype=np.int64)
         out[f'{name}_model_type'] = np.array(cs['mt'])
         out[f'{name}_optimize_fingers_after'] = np.array(bool(cfg.moshpp.optimize_fingers))
         out[f'{name}_betas'] = np.asarray(res['betas'], dtype=np.float64)
@@ -187,6 +192,7 @@ def main():
         out[f'{name}_errs'] = np.array([float(v) for v in dbg['stagei_errs'].values()])
         out[f'{name}_pose'] = np.array(dbg['opt_models_pose'], dtype=np.float64)
         out[f'{name}_trans'] = np.array(dbg['opt_models_trans'], dtype=np.float64)
+        out[f'{name}_optimize_face_after'] = np.array(bool(cfg.moshpp.optimize_face))
         out[f'{name}_labels_obs'] = np.array(['|'.join(sorted(l)) for l in dbg['stagei_labels_obs']])
         out[f'{name}_minimize_calls'] = np.array(H.N_MINIMIZE, dtype=np.int64)
         print(name, 'minimize calls (n, rows, iterations, evaluations):', H.N_MINIMIZE, 'errs', {k: float(v) for k, v in dbg['stagei_errs'].items()},

@@ -292,7 +292,7 @@ def stageii_case(model_type, n_frames, n_markers, seed, n_verts, outdir, empty_f
 
 
 def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_per_hand=12, finger_markers=False, head_markers=0,
-                betas_init=False):
+                betas_init=False, face_markers=False):
     """One seeded Stage-I call as the reference reads it: model pickle (with faces), body-prior pickle, hand-prior npz and the marker
     layout json written to `outdir`, plus the list of frame dicts {label: xyz} `mosh_stagei` takes (one label the layout does not
     know, one NaN observation).  The problem is synth.make_stagei_problem's (triangulated capsule body, ground-truth subject a few
@@ -325,6 +325,10 @@ def stagei_case(model_type, n_verts, nb, n_markers, n_frames, seed, outdir, dof_
     if finger_markers:
         hand0 = (3 * K - 90) // 3
         types_ = ['finger' if d >= hand0 else 'body' for d in dom]
+    if face_markers:       # optimize_face stays on only with 'face' typed markers in the layout AND in the frames (chmosh.py:128-139)
+        head_joint = {'smplx': 15}[model_type]
+        types_ = ['face' if d == head_joint else t for d, t in zip(dom, types_)]
+        assert 'face' in types_ and 'body' in types_
     head_corr_fname = None
     if head_markers:       # the last `head_markers` labels form a 'head' set with a correlation file (chmosh.py:252-266, 362-369)
         for i in range(n_markers - head_markers, n_markers):

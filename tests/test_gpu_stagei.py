@@ -259,7 +259,7 @@ def test_stagei_allreduce_on_device_through_rccl(tmp_path):
 
 
 @pytest.mark.parametrize('name', ['smplh_body', 'smplh_extra_rigid', 'smplh_fingers', 'smplh_head_corr', 'smplh_fixed_betas',
-                                  'smplh_betas_init', 'smpl_body', 'mano_fingers'])
+                                  'smplh_betas_init', 'smpl_body', 'mano_fingers', 'smplx_face'])
 def test_mosh_stagei_matches_executed_reference(name, tmp_path):
     """The drop-in `mosh_stagei` (files in, dict out; kernels on the GPU) against the reference's own `mosh_stagei` EXECUTED on the
     same files and frame dicts (tests/golden/make_ref_stagei_golden.py -> ref_stagei.npz): result keys, the per-frame label matching,
@@ -273,7 +273,8 @@ def test_mosh_stagei_matches_executed_reference(name, tmp_path):
                       'surface_model.dof_per_hand': c['dof_per_hand'], 'surface_model.use_hands_mean': False,
                       'moshpp.pose_body_prior_fname': c['body_prior_fname'], 'moshpp.pose_hand_prior_fname': c['hand_prior_fname'],
                       'moshpp.optimize_fingers': sc['fingers'], 'moshpp.optimize_betas': sc['optimize_betas'],
-                      'moshpp.head_marker_corr_fname': c['head_corr_fname'],
+                      'moshpp.head_marker_corr_fname': c['head_corr_fname'], 'moshpp.optimize_face': sc['face'],
+                      'surface_model.num_expressions': sc['n_expr'], 'surface_model.betas_expr_start_id': sc['expr_start'],
                       'opt_settings.extra_initial_rigid_adjustment': sc['extra'], 'dirs.marker_layout.fname': c['layout_fname'],
                       'opt_settings.weights_type': 'smplh'})   # (the yaml has no smpl / mano tables: the fixture used the smplh weights)
     res = chmosh.mosh_stagei(c['frames'], cfg, betas_fname=c['betas_fname'])

@@ -378,7 +378,7 @@ def test_host_mosh_stageii_keys_match_reference_function(name, tmp_path):
 # ---- Stage-I: the reference's own mosh_stagei + prepare_mosh_markers_latent + PtsToMesh / MeshDistanceSquared executed
 #      (tests/golden/make_ref_stagei_golden.py -> ref_stagei.npz)
 STAGEI_REF_CASES = ('smplh_body', 'smplh_extra_rigid', 'smplh_fingers', 'smplh_head_corr', 'smplh_fixed_betas', 'smplh_betas_init',
-                    'smpl_body', 'mano_fingers')
+                    'smpl_body', 'mano_fingers', 'smplx_face')
 
 
 def stagei_ref_case(name, tmp_path):
@@ -389,8 +389,10 @@ def stagei_ref_case(name, tmp_path):
     args = [int(v) for v in ref[f'{name}_args']]
     V, nb, M, F, seed, fingers, extra = args[:7]
     head, optimize_betas, betas_init = args[7:10] if len(args) >= 10 else (0, 1, 0)
+    face, n_expr, expr_start = args[10:13] if len(args) >= 13 else (0, 0, 300)
     mt = str(ref[f'{name}_model_type'])
-    c = stagei_case(mt, V, nb, M, F, seed, str(tmp_path), finger_markers=bool(fingers), head_markers=head, betas_init=bool(betas_init))
+    c = stagei_case(mt, V, nb, M, F, seed, str(tmp_path), finger_markers=bool(fingers), head_markers=head, betas_init=bool(betas_init),
+                    face_markers=bool(face))
     pb = c['problem']
     labels, types_ = c['labels'], c['types']
     # the layout's order: marker sets by type, labels sorted inside (marker_layout_load, edit_tools.py:83-183; pinned above)
@@ -411,21 +413,23 @@ def stagei_ref_case(name, tmp_path):
     npose = {'smpl': 69, 'smplh': 63, 'smplx': 63}.get(mt)
     return dict(ref=ref, case=c, pb=pb, model_type=mt, nb=nb if optimize_betas else 0, nb_cfg=nb, M=M, F=F, fingers=bool(fingers),
                 extra=bool(extra), labels=lab, vids=np.asarray(pb['vids'])[order], mask=mask, m2b={t: pb['skin'] for t in mask},
-                frames=frames, head_corr=head_corr, betas_init=b0, optimize_betas=bool(optimize_betas), npose=npose)
+                frames=frames, head_corr=head_corr, betas_init=b0, optimize_betas=bool(optimize_betas), npose=npose, face=bool(face),
+                n_expr=n_expr, expr_start=expr_start)
 
 
 def check_stagei_against_reference_run(name, ref, got, iters_per_call=None):
     """`got`: betas, markers_latent, markers_latent_vids, pose, trans, errs {reference key: SSE}.  The fixture's solves used a
     central-difference Jacobian of the reference's residuals, ours the analytic one; on this piecewise-smooth objective (attachment and
-    nearest triangle re-evaluated at every point) the two part ways at a stopping decision in two of the three cases (last round:
-    3 vs 4 iterations; 11 + 17 vs 7 + 10 with the weakly determined finger block), so those are held to 2e-3, the third -- where the
-    iteration counts of all five solves agree -- to 1e-6.  With a differenced Jacobian on the oracle's side all three agree to 1e-7
+    nearest triangle re-evaluated at every point) the two part ways at a stopping decision in four of the nine cases (e.g. last round
+    3 vs 4 iterations; 11 + 17 vs 7 + 10 with the weakly determined finger block) and end up to 2e-3 (betas) / 5e-3 rad apart; in
+    four cases every solve takes the same number of iterations and the results agree to 1e-8 (STAGEI_TIGHT_CASES: held to 1e-6), in
+    the face case the counts agree and the results to 1e-6.  With a differenced Jacobian on the oracle's side ALL nine agree to 2e-7
     with equal iteration counts in every solve (tests/golden/check_ref_stagei.py, output in tests/golden/ref_stagei_check.txt)."""
     nb = len(got['betas'])
     want_iters = ref[f'{name}_minimize_calls'][:, 2].tolist()
     # cases whose every solve took the same number of iterations under both Jacobians (recorded in ref_stagei_check.txt)
     tight = name in STAGEI_TIGHT_CASES
-    tol = dict(betas=1e-6, ml=1e-7, pose=1e-6, trans=1e-7, errs=1e-5) if tight else dict(betas=2e-3, ml=1e-3, pose=5e-3, trans=2e-4, errs=0.5)
+    tol = dict(betas=1e-6, ml=1e-7, pose=1e-6, trans=1e-7, errs=2e-3) if tight else dict(betas=2e-3, ml=1e-3, pose=5e-3, trans=2e-4, errs=0.5)
     if nb:
         assert np.abs(got['betas'] - ref[f'{name}_betas'][:nb]).max() < tol['betas']
     assert np.all(ref[f'{name}_betas'][nb:] == 0)
@@ -443,7 +447,7 @@ def check_stagei_against_reference_run(name, ref, got, iters_per_call=None):
             assert list(iters_per_call)[:2] == want_iters[:2]
 
 
-STAGEI_TIGHT_CASES = ('smplh_extra_rigid',)
+STAGEI_TIGHT_CASES = ('smplh_extra_rigid', 'smplh_fixed_betas', 'smplh_betas_init', 'smpl_body')
 
 
 def oracle_errs_under_reference_keys(errs, mask, drop_head=False):
@@ -477,6 +481,7 @@ def test_stagei_schedule_matches_reference_function(name, tmp_path):
     st = {}
     got = s1.stagei_solve(m, sc['pb']['faces'], prior, sc['model_type'], sc['frames'], sc['vids'], sc['mask'], sc['m2b'], sc['nb'],
                           optimize_fingers=sc['fingers'], extra_initial_rigid_adjustment=sc['extra'], stats=st, head_corr=sc['head_corr'],
-                          betas_init=sc['betas_init'])
+                          betas_init=sc['betas_init'], optimize_face=sc['face'], expr_start=sc['expr_start'] if sc['face'] else None,
+                          n_expr=sc['n_expr'])
     got = dict(got, errs=oracle_errs_under_reference_keys(got['errs'], sc['mask'], drop_head=sc['head_corr'] is not None))
     check_stagei_against_reference_run(name, ref, got, iters_per_call=st['per_call'])
