@@ -848,12 +848,17 @@ __device__ __forceinline__ bool ldl_panel_eliminate(const LdlCtx<NBLK>& c) {
             pin = fma(fma(-pj, pin, 1.0), pin, pin);
             *((c.lane == 0) ? c.pinv + c0 + j : c.Lp + c.trash) = pin;
             const double lj = a[0][j] * pin;   // lane k: c_kj pin_j of row c0 + k
+            // (all the later columns' multipliers first, then the updates: taken one at a time the compiler funnels every pair of
+            //  v_readlane through the same scalar pair with a wait state before each fma -- 1.7 % of a frame; the same entries through
+            //  LDS broadcasts instead of v_readlane time the same)
+            double lkv[16];
 #pragma unroll
-            for (int k = j + 1; k < 16; ++k) {
-                const double lk = readlane_f64(lj, k);
+            for (int k = j + 1; k < 16; ++k) lkv[k] = readlane_f64(lj, k);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s_ = 0; s_ < NS; ++s_) a[s_][k] = fma(-a[s_][j], lk, a[s_][k]);
-            }
+            for (int k = j + 1; k < 16; ++k)
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) a[s_][k] = fma(-a[s_][j], lkv[k], a[s_][k]);
         }
     }
 #pragma unroll
