@@ -210,21 +210,27 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 }
 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
-__global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KS, int KJ,
+__global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
                                                    float* __restrict__ Atr, _Float16* __restrict__ featF, long long* __restrict__ stamps) {
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
-    // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own
+    // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own.  27 KB of static LDS + the
+    // hand-component matrix (dynamic: hand_dof x nhand_full floats, 8.6 KB for SMPL-H / SMPL-X) and 81 registers: four workgroups
+    // share a CU, so the 1000 workgroups of a 4000-frame export are resident at once.  (Its first form -- 69 KB, 169 registers, two
+    // workgroups per CU -- timed the same 29 us under the profiler: the kernel is one latency chain per wave, cold loads and ~10
+    // dependent tree levels, and residency was not what bounded it.)
     __shared__ float s_fullpose[4][3 * MOSHII_MAXK];
-    __shared__ float s_Rl[4][MOSHII_MAXK * 9], s_Rw[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];
-    __shared__ float s_comps[90 * 90], s_pose[4][3 * MOSHII_MAXK], s_hm[4][128], s_J[4][3 * MOSHII_MAXK];
+    __shared__ float s_R[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];      // local rotations, turned into world rotations in place
+    __shared__ float s_pose[4][3 * MOSHII_MAXK], s_hm[4][128], s_J[4][3 * MOSHII_MAXK];
+    extern __shared__ float smf[];
+    float* const s_comps = smf;
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
     const int K = md.K, P = md.P, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
     const int fw = blockIdx.x * 4 + wv;          // this wave's frame; the last workgroup's spare waves redo frame F - 1 and write nothing
     const int f = min(fw, F - 1);
     PREP_STAMP(0)
     for (int q = tid; q < 16 * 32; q += 64) s_feat[wv][q] = (_Float16)0.0f;
-    float* fullpose = s_fullpose[wv]; float* Rl = s_Rl[wv]; float* Rw = s_Rw[wv]; float* tw = s_tw[wv];
+    float* fullpose = s_fullpose[wv]; float* Rw = s_R[wv]; float* tw = s_tw[wv];
     const float* ps = pose + (size_t)f * md.NP;
     const int bd = md.body_dof, nhf = md.nhand_full;
     // Everything the frame needs from memory is fetched in ONE round of independent loads at the top (with 4 000 waves starting at
@@ -234,9 +240,9 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
     // tree and the rest joints -- staged in LDS, from where the rest of the kernel reads.
     const int hd = md.hand_dof, ncomp = hd * nhf;
     {
-        double cst[32];
+        double cst[16];    // (16 x 256 entries per pass: one pass for the 24 x 90 of the default hand spaces)
 #pragma unroll
-        for (int u = 0; u < 32; ++u) { const int i = threadIdx.x + 256 * u; cst[u] = (i < ncomp) ? md.comps[i] : 0.0; }
+        for (int u = 0; u < 16; ++u) { const int i = threadIdx.x + 256 * u; cst[u] = (i < ncomp) ? md.comps[i] : 0.0; }
         float pv[3], hmv[2], jv[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) { const int i = tid + 64 * u; pv[u] = (i < md.NP) ? ps[i] : 0.0f; }
@@ -245,7 +251,8 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
 #pragma unroll
         for (int i = 0; i < 3; ++i) jv[i] = (tid < K) ? Jf[tid * 3 + i] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 32; ++u) { const int i = threadIdx.x + 256 * u; if (i < ncomp) s_comps[i] = (float)cst[u]; }
+        for (int u = 0; u < 16; ++u) { const int i = threadIdx.x + 256 * u; if (i < ncomp) s_comps[i] = (float)cst[u]; }
+        for (int i = threadIdx.x + 4096; i < ncomp; i += 256) s_comps[i] = (float)md.comps[i];   // (larger hand spaces: the rest, plainly)
 #pragma unroll
         for (int u = 0; u < 3; ++u) { const int i = tid + 64 * u; if (i < md.NP) s_pose[wv][i] = pv[u]; }
 #pragma unroll
@@ -290,27 +297,27 @@ __global__ __launch_bounds__(256) void k_lbs_prep(ModelDev md, const float* __re
         for (int e = 0; e < 9; ++e) {
             const float id = (e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f;
             const float r = id + a * Km[e] + b * K2[e];
-            Rl[tid * 9 + e] = r;
+            Rw[tid * 9 + e] = r;
             if (tid >= 1) s_feat[wv][(tid - 1) * 9 + e] = (_Float16)(a * Km[e] + b * K2[e]);   // R - I without the cancellation
         }
     }
     PREP_STAMP(2)
     // kinematic chain inside the wavefront (in-order LDS), one tree level per step
-    if (tid == 0) {
-        for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];
-        for (int i = 0; i < 3; ++i) tw[i] = s_J[wv][i];
-    }
+    if (tid == 0) for (int i = 0; i < 3; ++i) tw[i] = s_J[wv][i];      // (the root's local rotation is its world rotation)
     float Jd[3] = {0.0f, 0.0f, 0.0f}, Jme[3] = {0.0f, 0.0f, 0.0f};
     if (tid < K) for (int i = 0; i < 3; ++i) { Jme[i] = s_J[wv][tid * 3 + i]; Jd[i] = Jme[i] - s_J[wv][p * 3 + i]; }
     for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lvl_of == lvl) {
+            float rl[9];       // this joint's local rotation, read before its slot takes the world rotation
+#pragma unroll
+            for (int e = 0; e < 9; ++e) rl[e] = Rw[tid * 9 + e];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float p0 = Rw[p * 9 + i * 3 + 0], p1 = Rw[p * 9 + i * 3 + 1], p2 = Rw[p * 9 + i * 3 + 2];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) Rw[tid * 9 + i * 3 + j] = p0 * Rl[tid * 9 + j] + p1 * Rl[tid * 9 + 3 + j] + p2 * Rl[tid * 9 + 6 + j];
+                for (int j = 0; j < 3; ++j) Rw[tid * 9 + i * 3 + j] = p0 * rl[j] + p1 * rl[3 + j] + p2 * rl[6 + j];
                 tw[tid * 3 + i] = p0 * Jd[0] + p1 * Jd[1] + p2 * Jd[2] + tw[p * 3 + i];
             }
         }
@@ -743,7 +750,7 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     const Lbs32Model lm = *lmp;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 31;   // (development: phase timing by truncation / clock stamps; incomplete output)
-    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
+    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), (size_t)md->hand_dof * md->nhand_full * sizeof(float), stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
                        (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 32 : (long long*)nullptr);
     const int NVT = lm.Vp128 / LBS_TV, NFT = Fpad / LBS_TF;
     int ncu = 0, devid = 0;
