@@ -178,9 +178,12 @@ def _skin_and_blend(model_type, v_template, J0, seg_a, seg_b, rad, rng, num_beta
     return weights, outward, J_regressor, shapedirs, posedirs
 
 
-def synth_model(model_type, seed=0, num_betas=16, chunk=2048):
+def synth_model(model_type, seed=0, num_betas=16, chunk=2048, vertex_order='shuffled'):
     """A synthetic body model with the exact topology sizes of `model_type`, in the layout of the
-    reference's model pickles (keys as read by smpl_fast_derivatives.py:52-166)."""
+    reference's model pickles (keys as read by smpl_fast_derivatives.py:52-166).
+    vertex_order: 'shuffled' (default; every fixture and bench number is on it) gives the vertices random ids -- the worst case for
+    anything that hopes consecutive vertices share joints; 'mesh' keeps them bone by bone, along each bone, the way a registered
+    artist mesh numbers them (tools/joint_census.py compares the two)."""
     V, K = MODEL_DIMS[model_type]
     rng = np.random.default_rng(seed + 7919 * (list(MODEL_DIMS).index(model_type) + 1))
     parents = kintree_parents(model_type)
@@ -213,9 +216,12 @@ def synth_model(model_type, seed=0, num_betas=16, chunk=2048):
         p = seg_a[j][None] + t[:, None] * axis[None] + rr[:, None] * (np.cos(ang)[:, None] * u[None]
                                                                          + np.sin(ang)[:, None] * w[None])
         verts.append(p)
+    if vertex_order == 'mesh':
+        verts = [p[np.argsort((p - seg_a[j]).dot((seg_b[j] - seg_a[j]) / np.linalg.norm(seg_b[j] - seg_a[j])))] for j, p in enumerate(verts)]
     v_template = np.vstack(verts)
-    perm = rng.permutation(V)
-    v_template = v_template[perm]
+    perm = rng.permutation(V)          # (drawn in both cases: the random stream behind it stays what it was)
+    if vertex_order != 'mesh':
+        v_template = v_template[perm]
 
     weights, outward, J_regressor, shapedirs, posedirs = _skin_and_blend(model_type, v_template, J0, seg_a, seg_b, rad, rng,
                                                                          num_betas, chunk)

@@ -8,7 +8,11 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 mt = sys.argv[3] if len(sys.argv) > 3 else 'smplh'
 M = {'smplh': 53, 'smpl': 41, 'smplx': 89, 'mano': 33}[mt]
-job = workload.make_job(mt, 8, M, seed=1000, optimize_fingers=(mt == 'mano'))
+# LBS_BODY=mesh: the synthetic body with the vertex order of a registered mesh (bone by bone, along each bone) instead of shuffled ids
+import os
+from moshpp_amd import synth
+order = os.environ.get('LBS_BODY', 'shuffled')
+job = workload.make_job(mt, 8, M, seed=1000, optimize_fingers=(mt == 'mano'), dd=synth.synth_model(mt, seed=1000, vertex_order=order))
 solver = workload.make_solver(job)
 sm = job['sm']
 dev = torch.device('cuda', 0)
@@ -29,9 +33,12 @@ e1.record()
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) * 1e-3 / reps
 out_bytes = F * sm.V * 12
-print(f'{mt} F={F}: {t*1e6:.1f} us per call, output {out_bytes/1e6:.1f} MB -> {out_bytes/t/1e9:.0f} GB/s ({out_bytes/t/8e12*100:.1f}% of 8 TB/s), {F/t:.0f} frames/s')
+print(f'{mt} [{order} vertex order] F={F}: {t*1e6:.1f} us per call, output {out_bytes/1e6:.1f} MB -> {out_bytes/t/1e9:.0f} GB/s ({out_bytes/t/8e12*100:.1f}% of 8 TB/s), {F/t:.0f} frames/s')
 
-import os
+if os.environ.get('LBS_CHECK'):
+    ref = solver.dev.lbs_forward(pose[:40].cpu().numpy().astype(np.float64), trans[:40].cpu().numpy().astype(np.float64))
+    got = verts[:40].cpu().numpy()
+    print(f'  check vs the f64 kernel on 40 frames: max |diff| {np.abs(got - ref).max():.2e} m')
 if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
     torch.cuda.synchronize()
     raw = verts.view(-1)[:2 * 32 * 9].cpu().numpy().view(np.int64)
