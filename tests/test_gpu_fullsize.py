@@ -414,3 +414,43 @@ def test_chunked_solve_is_exact_under_gpu_contention(gpu_lib):
     finally:
         proc.kill()
         proc.wait()
+
+
+@pytest.mark.gpu
+def test_config3_oracle_window_on_four_captures(gpu_lib):
+    """BASELINE configs[2]'s subject as bench.py's `config3` leg builds it (workload.make_face_job: SMPL-X, 89 markers incl. face / hand
+    vertices, fingers + jaw + 80 expression coefficients free: 194 unknowns), four captures with different motion seeds (none of them
+    picked for being tame): the first frames of every chain against the oracle's, with equal dogleg iteration counts."""
+    from moshpp_amd import workload
+    job = workload.make_face_job()
+    solver = workload.make_solver(job)
+    m, pr, closest, coef = _face_job_oracle(job)
+    assert np.array_equal(closest, solver.tc.closest) and np.abs(coef - solver.tc.coef).max() < 1e-12    # the same attachment on both sides
+    H = 40
+    for ms in (6001, 6002, 6003, 6004):
+        cap = workload.make_face_capture(job, solver, ms, n_frames=40)
+        out = solver.solve(cap['obs'], cap['vis'])
+        assert np.all(out['status'] == 0)
+        ref = so.stageii_chain(m, pr, closest, coef, np.nan_to_num(cap['obs'][:H]), cap['vis'][:H], 'smplx', optimize_fingers=True,
+                               optimize_face=True, free_shape='expr')
+        dp = np.abs(out['fullpose'][:H] - ref['fullpose']).max()
+        ds = np.abs(out['shape'][:H] - ref['shape']).max()
+        d = (out['markers_sim'] - cap['obs'])[cap['vis']]
+        print(f'config 3 capture {ms}: first {H} frames vs oracle {dp:.2e} rad / {ds:.2e} (expression); marker rmse over 40 frames '
+              f'{np.sqrt((d ** 2).sum(1).mean()):.2e} m')
+        assert dp < 1e-6 and ds < 1e-6
+        np.testing.assert_array_equal(out['iters'][:H, 0], ref['iters'])
+
+
+def _face_job_oracle(job):
+    """The oracle's model / prior / attachment of a workload.make_face_job subject."""
+    sm = job['sm']
+    E = job['num_expressions']
+    m = so.prepare_model(dict(v_template=sm.v_template, shapedirs=sm.shapedirs, posedirs=sm.posedirs, weights=sm.weights,
+                              J_regressor=sm.J_regressor, parents=sm.parents, body_dof=sm.body_dof, hand_dof=sm.hand_dof,
+                              hands_mean=sm.hands_mean, selected_components=sm.selected_components), job['betas'])
+    so.set_free_shape(m, job['betas_expr_start_id'], E)
+    pr = so.prepare_gmm_prior(job['seq']['gmm'], 63)
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
+    closest, coef = so.transformed_coeffs(can, job['markers_latent'], exclude_vids=np.arange(9383, 10475))
+    return m, pr, closest, coef
