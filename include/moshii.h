@@ -49,6 +49,9 @@ typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact 
 #define MOSHII_BUFFERS_DEVICE  1u   /* obs/vis/outputs are device pointers; launch is async on `stream` */
 
 const char* moshii_last_error(void);
+/* 100: round 1-2 ABI.  101: moshii_stagei_desc grew by the trailing output pointer `init_sq` -- the struct carries no size field, so a
+ * caller built against the 100 header must not call a 101 library's moshii_stagei_solve (it would read past the caller's struct);
+ * check moshii_version() >= 101 before filling a moshii_stagei_desc declared from this header, and zero the struct first. */
 int  moshii_version(void);
 /* first 16 hex digits of the SHA-256 over the sources this binary was compiled from (python -m moshpp_amd.build computes the same
  * over the tree: a stale binary is detectable); "unknown" for a build outside build.py */
@@ -313,7 +316,9 @@ typedef struct moshii_stagei_desc {
     int32_t* markers_latent_vids;           /* [M] nearest canonical vertex of each latent marker (:420-422)     */
     double*  pose;                          /* [n_frames][NP]                                                    */
     double*  trans;                         /* [n_frames][3]                                                     */
-    double*  markers_sim;                   /* [n_frames][M][3] or NULL: every latent marker simulated on every frame's body */
+    double*  markers_sim;                   /* [n_frames][M][3] or NULL: every latent marker simulated on every frame's body
+                                             * (sharded: the frames are gathered with an all-reduce -- set it on EVERY rank or on none;
+                                             * errs / init_sq may differ between ranks, their reductions are always issued)            */
     double*  expression;                    /* [n_frames][n_expr] or NULL                                        */
     double*  errs;                          /* [8] SSE of data, poseB, init, beta (expr when n_expr > 0), surf, poseH, init_head_corr, poseF */
     int32_t* iters;                         /* [1] dogleg outer iterations over all rounds                       */

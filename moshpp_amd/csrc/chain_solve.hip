@@ -2014,9 +2014,16 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
                 __syncthreads();
                 if (tid == 0) { __threadfence(); __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
             }
-            if (chp->fuse_F == 0 && t == F) {                  // (a chain without a right neighbour: its rows are complete)
+            if (chp->fuse_F == 0 && t == F) {                  // (a chain without a right neighbour: its rows are complete ...
                 __syncthreads();
-                if (tid == 0) { __threadfence(); __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+                if (tid == 0) {
+                    __threadfence();
+                    __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    // ... and it never carries on: its verdict is final too.  The chain of the chunk before it waits for BOTH flags
+                    // before it takes this chunk over; without this store it waited out its whole patience and left the
+                    // last chunk of every sequence to a host round.)
+                    __hip_atomic_store(&chp->fuse_flags[3 * chp->fuse_c + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if (chp->fuse_F > 0 && t == chp->fuse_F) {
                 // The end of this chain's own chunk (ChainDev::fuse_F): its end state ...

@@ -331,7 +331,7 @@ struct LaunchInfo { std::string name; int lds = 0; int threads = 0; } g_last;
 extern "C" {
 
 const char* moshii_last_error(void) { return g_err.c_str(); }
-int moshii_version(void) { return 100; }
+int moshii_version(void) { return 101; }   // 101: moshii_stagei_desc grew by init_sq (include/moshii.h)
 #ifndef MOSHII_SRC_HASH
 #define MOSHII_SRC_HASH "unknown"
 #endif

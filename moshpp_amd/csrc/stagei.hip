@@ -1318,20 +1318,20 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         hipStreamSynchronize(st);
     };
     if (shard) {
-        // The device path stages host vectors through d_red: that buffer is sized HERE for the largest vector the solve will ever
-        // stage (the n unknowns; 3 F M marker coordinates) and its allocation status rides in the verdict, so that no rank can drop out of a later all-reduce
-        // because of it.  (A rank that cannot even get these few KB still enters the verdict sum: with the callback's host fallback
-        // if there is one, else it fails alone -- there is nothing to sum on.)
-        double verdict[3] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0, 0.0};
+        // The device path stages host vectors through d_red: that buffer is sized HERE, before the first collective, for the largest
+        // vector the solve will ever stage (the n unknowns; 3 F M marker coordinates), so that no rank can drop out of a LATER all-reduce
+        // because of it.  A rank that cannot even get these few KB has no buffer to join the verdict sum with (the callback takes device
+        // pointers only): it fails alone, before any collective, and says so -- the other ranks then wait in their first all-reduce
+        // until the process group's own timeout, which is the launcher's business.
+        double verdict[2] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0};
         if (red_dev) {
             const long long cap0 = 3LL * M + (long long)F * (3 + NP) + (long long)nb * (d.per_frame ? F : 1) + 3LL * F * M + 6LL * F + 64;   // >= n, 3 F M, 6 F
             d_red = pool.get<double>((size_t)cap0);
             d_red_cap = pool.ok ? cap0 : 0;
             if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed before the first all-reduce (the other ranks were not joined)");
         }
-        reduce(verdict, 3);
+        reduce(verdict, 2);
         if (reduce_rc) return fail(MOSHII_ERR_ARG, "stagei: the all-reduce callback failed");
-        if (verdict[2] > 0) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed on a rank");
         if (verdict[0] > 0) return fail(MOSHII_ERR_ARG, "stagei: frame range of a rank out of bounds");
         if (verdict[1] > 0) return fail(MOSHII_ERR_ARG, "stagei: the rank that owns the shared rows must own at least one frame");
     }
@@ -1734,14 +1734,17 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                 memcpy(ds->markers_sim, sa.data(), sa.size() * 8);
             }
             auto sse_rows = [&](int lo, int hi) { double s = 0; for (int i = lo; i < hi; ++i) s += r[i] * r[i]; return s; };
-            if (ds->errs) {
-                ds->errs[0] = sse_rows(d.r_data, d.r_prior); ds->errs[1] = sse_rows(d.r_prior, d.r_init); ds->errs[2] = sse_rows(d.r_init, d.r_beta);
-                ds->errs[3] = sse_rows(d.r_beta, d.r_surf); ds->errs[4] = sse_rows(d.r_surf, d.r_poseH); ds->errs[5] = sse_rows(d.r_poseH, d.r_head); ds->errs[6] = sse_rows(d.r_head, d.r_poseF); ds->errs[7] = sse_rows(d.r_poseF, d.R);
-                reduce(ds->errs, 8);
-            }
-            if (ds->init_sq) {   // (rows r_init + 3 m .. + 3: marker m's weighted offset from its initial placement; summed over ranks like errs[2])
-                for (int mk = 0; mk < M; ++mk) ds->init_sq[mk] = sse_rows(d.r_init + 3 * mk, d.r_init + 3 * mk + 3);
-                reduce(ds->init_sq, M);
+            {   // (the collectives below are issued whether or not THIS rank asked for the output: ranks whose callers differ in which
+                //  optional pointers they set must still issue the same sequence of all-reduces)
+                std::vector<double> ev(8 + (size_t)M);
+                ev[0] = sse_rows(d.r_data, d.r_prior); ev[1] = sse_rows(d.r_prior, d.r_init); ev[2] = sse_rows(d.r_init, d.r_beta);
+                ev[3] = sse_rows(d.r_beta, d.r_surf); ev[4] = sse_rows(d.r_surf, d.r_poseH); ev[5] = sse_rows(d.r_poseH, d.r_head); ev[6] = sse_rows(d.r_head, d.r_poseF); ev[7] = sse_rows(d.r_poseF, d.R);
+                // rows r_init + 3 m .. + 3: marker m's weighted offset from its initial placement; summed over ranks like errs[2]
+                for (int mk = 0; mk < M; ++mk) ev[8 + mk] = sse_rows(d.r_init + 3 * mk, d.r_init + 3 * mk + 3);
+                reduce(ev.data(), 8);
+                reduce(ev.data() + 8, M);
+                if (ds->errs) memcpy(ds->errs, ev.data(), 8 * sizeof(double));
+                if (ds->init_sq) memcpy(ds->init_sq, ev.data() + 8, (size_t)M * sizeof(double));
             }
         }
         int hstat[4];

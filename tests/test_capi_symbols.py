@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(capi.EXPORTS), declared.symmetric_difference(set(capi.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.moshii_version() >= 100
+    assert lib.moshii_version() >= 101   # 101: moshii_stagei_desc.init_sq
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     structs = {'moshii_model_desc': capi.ModelDesc, 'moshii_solve_opts': capi.SolveOpts, 'moshii_chain_desc': capi.ChainDesc,
                'moshii_sequence_desc': capi.SequenceDesc, 'moshii_chunk_opts': capi.ChunkOpts,
-               'moshii_chunk_report': capi.ChunkReport}
+               'moshii_chunk_report': capi.ChunkReport, 'moshii_stagei_desc': capi.StageIDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "moshii.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

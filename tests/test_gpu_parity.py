@@ -241,6 +241,24 @@ def test_sequence_solve_repair_reproduces_chain_bitwise(gpu_lib):
     np.testing.assert_array_equal(outs[0]['iters'], seq['iters'])
 
 
+def test_fused_repair_takes_the_last_chunk_without_a_host_round(gpu_lib):
+    """Two chunks, no warm-up: the hand-off into the LAST chunk of the sequence misses, so chunk 0's chain must carry on as its
+    repair chain inside the first launch.  It waits for the last chunk's `rows complete` AND `verdict` flags; a chain without a
+    right neighbour never set the second one (round 3), the wait ran out its patience and a host round did the repair."""
+    from moshpp_amd import capi
+    case = oracle_case('smplh', F=24, M=53, seed=52)
+    dev = device_case(case)
+    seq = _sequential(dev, case)
+    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                         [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                         num_chunks=2, warmup=0, verify_tol=1e-12)
+    print('chunk report', rep)
+    assert rep['n_chunks'] == 2 and rep['n_repaired'] == 1
+    assert rep['repair_rounds'] == 0, 'the carried-on chain of chunk 0 must repair the last chunk inside the first launch'
+    for k in ('fullpose', 'trans', 'markers_sim', 'status', 'pose', 'iters'):
+        np.testing.assert_array_equal(outs[0][k], seq[k])
+
+
 def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
     """Several sequences, automatic chunk count: every sequence matches its own sequential chain."""
     from moshpp_amd import capi
