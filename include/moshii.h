@@ -48,6 +48,14 @@ typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact 
 #define MOSHII_BUFFERS_HOST    0u   /* obs/vis/outputs are host pointers (library stages them)     */
 #define MOSHII_BUFFERS_DEVICE  1u   /* obs/vis/outputs are device pointers; launch is async on `stream` */
 
+/* moshii_chain_solve only: COOPERATIVE chains -- every chain is solved by g workgroups (g CUs; 2 <= g <= 8) instead of one.  The ranks
+ * split the work that scales with the markers (pose correctives, skinning, marker frames, Jacobian rows, J^T J) and one of them
+ * evaluates the prior; they meet twice per dogleg iteration through device memory (csrc/moshii_dev.h: CoopDev).  Same algorithm, same
+ * decisions; sums over markers are taken rank by rank, so results agree with a plain chain's to round-off, not bit for bit.  Needs
+ * g x n_chains <= CUs (all workgroups resident: otherwise plain chains are used) and a plain body / finger solve (no face / free shape
+ * block); the call synchronises the stream.  0 = plain chains unless the environment says MOSHII_COOP=g. */
+#define MOSHII_COOP_GROUP(g)   (((uint32_t)(g) & 0xffu) << 8)
+
 const char* moshii_last_error(void);
 /* 100: round 1-2 ABI.  101: moshii_stagei_desc grew by the trailing output pointer `init_sq` -- the struct carries no size field, so a
  * caller built against the 100 header must not call a 101 library's moshii_stagei_solve (it would read past the caller's struct);

@@ -314,10 +314,16 @@ def make_opts(weights, step1_ids, step2_ids, body_ids, finger_ids, maxiter=100, 
     return o, arrs
 
 
-def chain_solve_host(model: Model, prior, opts_tuple, chains):
+def coop_group(g):
+    """MOSHII_COOP_GROUP(g) of include/moshii.h: the cooperative-chain request in the `flags` of moshii_chain_solve."""
+    return (int(g) & 0xff) << 8
+
+
+def chain_solve_host(model: Model, prior, opts_tuple, chains, coop=0):
     """Run moshii_chain_solve on host buffers.
     chains: list of dict(attach, obs[F,M,3], vis[F,M], first=True, init_pose=None, init_trans=None, init_pose_prev=None,
-    init_shape=None).  Returns list of dict(pose, fullpose, trans, markers_sim, errs[F,NERR], iters, status, shape[F,n_shape])."""
+    init_shape=None).  Returns list of dict(pose, fullpose, trans, markers_sim, errs[F,NERR], iters, status, shape[F,n_shape]).
+    coop = g > 0: cooperative chains, g workgroups (CUs) per chain (MOSHII_COOP_GROUP(g) in the flags of the C ABI)."""
     lib = load()
     opts, _keep = opts_tuple
     n = len(chains)
@@ -349,7 +355,7 @@ def chain_solve_host(model: Model, prior, opts_tuple, chains):
             d.shape = o['shape'].ctypes.data
         outs.append(o)
     check(lib.moshii_chain_solve(model.handle, prior.handle if prior is not None else None, C.byref(opts), n, descs,
-                                 BUFFERS_HOST, None))
+                                 BUFFERS_HOST | coop_group(coop), None))
     del keep
     return outs
 

@@ -23,13 +23,14 @@ typedef double v2d __attribute__((vector_size(16)));   // one 16-byte load
 #ifdef MOSHII_PROFILE
 __device__ long long g_prof[64];
 #define PROF_BEGIN() long long _pt = clock64()
-#define PROF_LAP(slot) do { __syncthreads(); if (threadIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - _pt; _pt = _n; } else { _pt = 0; } } while (0)
-#define PROF_COUNT(slot) do { if (threadIdx.x == 0) g_prof[slot] += 1; } while (0)
+// (block 0 only: the one chain of a profiled run -- rank 0 of a cooperative chain)
+#define PROF_LAP(slot) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - _pt; _pt = _n; } else { _pt = 0; } } while (0)
+#define PROF_COUNT(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += 1; } while (0)
 // (laps inside helper functions: the running time stamp lives in g_prof[63]; PROF_MARK starts it -- one workgroup only)
-#define PROF_MARK() do { if (threadIdx.x == 0) g_prof[63] = clock64(); } while (0)
-#define PROF_LAP_EXT(slot) do { __syncthreads(); if (threadIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - g_prof[63]; g_prof[63] = _n; } } while (0)
+#define PROF_MARK() do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[63] = clock64(); } while (0)
+#define PROF_LAP_EXT(slot) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - g_prof[63]; g_prof[63] = _n; } } while (0)
 #define PROF_T(var) const long long var = clock64()
-#define PROF_ACC(slot, var) do { if (threadIdx.x == 0) g_prof[slot] += clock64() - var; } while (0)   // thread 0's time since PROF_T
+#define PROF_ACC(slot, var) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += clock64() - var; } while (0)   // thread 0's time since PROF_T
 #else
 #define PROF_BEGIN() do {} while (0)
 #define PROF_LAP(slot) do {} while (0)
@@ -40,7 +41,10 @@ __device__ long long g_prof[64];
 #define PROF_ACC(slot, var) do {} while (0)
 #endif
 
-enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6, S_PRIOR_REF = 7, S_PRIOR_KB0 = 8, S_BATON = 9, S_ABORT = 10 };
+enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6, S_PRIOR_REF = 7, S_PRIOR_KB0 = 8, S_BATON = 9, S_ABORT = 10,
+       S_V0 = 11, S_V1 = 12,              // cooperative variant: this rank's share [v0, v1) of the frame's visible-marker list
+       S_COOP_SEQ = 13, S_COOP_FAIL = 14  // ... number of exchanges completed; the group is broken (a rank did not show up)
+     };
 
 struct Ctx {
     double *pose, *trans, *pose_t, *trans_t, *pose_prev, *vtarget, *fullpose;
@@ -62,6 +66,7 @@ struct FrameParams {
     // extended variant (XT): jaw term, free shape block and its "stay" term are live in this phase
     double wt_poseF;
     int use_face, use_shape, has_stay;
+    int v0, v1;             // the entries [v0, v1) of the visible-marker list whose Jacobian rows are built here (plain chain: all of them)
 };
 
 struct Sse { double data, prior, velo, hand, total, face, shape, stay; };
@@ -129,6 +134,62 @@ __device__ __forceinline__ double block_max(double a, double* red) {
     if ((tid & 63) == 0) red[tid >> 6] = a;
     __syncthreads();
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cooperative chains: the exchange step between the G workgroups of one chain (moshii_dev.h: CoopDev).
+// Protocol (cdna_hip_programming.md, Guideline 16, form R1): payload words are 8-byte agent-scope stores (write-through: no release
+// fence), every storing wave drains its stores, ONE lane then stores the rank's flag = the exchange's sequence number; a reader polls
+// the G flags (one lane each, relaxed), and reads the other ranks' payload with agent-scope loads (they bypass this CU's L1, which is
+// never refreshed by another CU's stores).  Two slots per rank (parity of the sequence number): a rank can only be one exchange ahead
+// of the slowest one -- it posts exchange s + 1 after it has read everybody's s, and needs everybody's s + 1 before it posts s + 2 --
+// so slot s & 1 is never rewritten while somebody still reads it.  Every wait is bounded; a rank that gives up raises the group's
+// abort word, everybody unwinds and the host reports the launch as failed (co-residency of the G workgroups is the caller's job).
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOSHII_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define MOSHII_DRAIN_VMEM() do {} while (0)
+#endif
+__device__ __forceinline__ unsigned long long f64_bits(double v) { unsigned long long b; __builtin_memcpy(&b, &v, 8); return b; }
+__device__ __forceinline__ double bits_f64(unsigned long long b) { double v; __builtin_memcpy(&v, &b, 8); return v; }
+__device__ __forceinline__ void coop_st(MOSHII_GP(unsigned long long) p, double v) {
+    __hip_atomic_store(p, f64_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coop_ld(MOSHII_GP(unsigned long long) p) {
+    return bits_f64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned coop_begin(const Ctx& cx) { return (unsigned)cx.scal[S_COOP_SEQ] + 1u; }   // (uniform)
+__device__ __forceinline__ MOSHII_GP(unsigned long long) coop_slot(const CoopCtx& co, unsigned seq, int r) {
+    return co.slots + ((size_t)(seq & 1u) * co.G + r) * co.slot_doubles;
+}
+// All threads call, after their payload stores: publish this rank's slot, wait for every rank's.  false: the group is broken.
+__device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& cx, unsigned seq) {
+    const int tid = threadIdx.x;
+    MOSHII_DRAIN_VMEM();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(co.flags + co.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < co.G && cx.scal[S_COOP_FAIL] == 0.0) {
+        bool ok = true;
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(co.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u)   // now and then: has somebody given up?  have we waited for about a second?
+                if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+        }
+        if (!ok) {
+            __hip_atomic_store(co.flags + co.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cx.scal[S_COOP_FAIL] = 1.0;
+        }
+    }
+    __syncthreads();
+    return cx.scal[S_COOP_FAIL] == 0.0;
+}
+// All threads call once they have read what they need of the other ranks' slots.
+__device__ __forceinline__ void coop_end(const Ctx& cx, unsigned seq) {
+    __syncthreads();
+    if (threadIdx.x == 0) cx.scal[S_COOP_SEQ] = (double)seq;
+    __syncthreads();
 }
 
 // Rodrigues + SO(3) left Jacobian; same formulas and small-angle switch as oracle/stageii_oracle.py:rodrigues.
@@ -305,6 +366,61 @@ __device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev&
     }
 }
 
+// The same for the vertices [a_lo, a_hi) only (cooperative chains: a rank's share of the attached vertices).  A share is a few dozen
+// vertices, i.e. far fewer (coordinate, vertex pair) items than threads: the joint list of an item is then dealt to JG = 2 or 4
+// ADJACENT lanes (bursts of PB joints, round-robin), whose partial sums meet through DPP quad moves -- the pass is a latency chain per
+// lane (one L2 round trip per burst), so this divides its length, not just its width.
+__device__ __forceinline__ void posedirs_partial_range(const Ctx& cx, const AttachDev& at, const int* klist, int nk,
+                                                       const double* base, double* dst, int a_lo, int a_hi) {
+    const int tid = threadIdx.x;
+    const int Nvp = at.Nvp, Nvh = Nvp >> 1;
+    const int p_lo = a_lo >> 1, np = ((a_hi + 1) >> 1) - p_lo;   // the vertex pairs that cover the range
+    const int items = 3 * np;
+    if (items <= 0) return;
+    const int jsh = (items * 4 <= MOSHII_TPB) ? 2 : ((items * 2 <= MOSHII_TPB) ? 1 : 0);   // log2 of the lanes per item
+    const int JG = 1 << jsh;
+    constexpr int PB = 3;
+    for (int l0 = 0; l0 < items * JG; l0 += MOSHII_TPB) {   // (uniform trip count: the DPP moves below need whole wavefronts)
+        const int lin = l0 + tid;
+        const bool live = lin < items * JG;
+        const int it = min(lin, items * JG - 1) >> jsh, jg = lin & (JG - 1);
+        const int i = it / np, a2 = p_lo + (it - i * np);
+        double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0, s2x = 0.0, s2y = 0.0;
+        const auto* pp = gptr(reinterpret_cast<const v2d*>(at.Pt)) + (size_t)(i * 9) * Nvh + a2;
+        for (int idx0 = jg * PB; idx0 < nk; idx0 += JG * PB) {
+            v2d q[PB][9];
+            int kk[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                kk[u] = klist[min(idx0 + u, nk - 1)];
+                const auto* pk = pp + (size_t)((kk[u] - 1) * 27) * Nvh;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) q[u][e] = pk[(size_t)e * Nvh];
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (idx0 + u < nk) {
+                    const double* f = &cx.feat[kk[u] * 9];
+#pragma unroll
+                    for (int e = 0; e < 9; e += 3) {
+                        s0x += q[u][e][0] * f[e]; s0y += q[u][e][1] * f[e];
+                        s1x += q[u][e + 1][0] * f[e + 1]; s1y += q[u][e + 1][1] * f[e + 1];
+                        s2x += q[u][e + 2][0] * f[e + 2]; s2y += q[u][e + 2][1] * f[e + 2];
+                    }
+                }
+            }
+        }
+        double sx = (s0x + s1x) + s2x, sy = (s0y + s1y) + s2y;
+        if (jsh >= 1) { sx += dpp_f64<DPP_QUAD_1032>(sx); sy += dpp_f64<DPP_QUAD_1032>(sy); }   // (uniform branches)
+        if (jsh >= 2) { sx += dpp_f64<DPP_QUAD_2301>(sx); sy += dpp_f64<DPP_QUAD_2301>(sy); }
+        const int a = 2 * a2;
+        if (live && jg == 0) {
+            if (a >= a_lo && a < a_hi) dst[a * 3 + i] = base[a * 3 + i] + sx;
+            if (a + 1 >= a_lo && a + 1 < a_hi) dst[(a + 1) * 3 + i] = base[(a + 1) * 3 + i] + sy;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward evaluation of every residual block at (pose, trans): leaves joint transforms, posed
 // attached vertices, simulated markers, weighted data residuals and the prior's l-vectors in LDS.
@@ -313,11 +429,16 @@ __device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev&
 // every other joint (cx.vconst, see posedirs_partial) -- or klist = all joints and vbase = v_shaped.
 // XT (extended variant): the free shape coefficients s ride behind the pose variables (pose[NP .. NP + nshape)); the rest
 // vertices and the regressed joints are re-shaped with them at every evaluation (smpl_fast_derivatives.py:186-191).
-template <bool XT>
+// COOP (cooperative chains): this workgroup is rank co.rank of co.G; it evaluates the markers [co.mlo, co.mhi) and their vertices, the
+// rank co.prior_rank the prior; the partial sums of squares meet in an exchange, after which every rank holds the same totals.
+template <bool XT, bool COOP = false>
 __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                             const OptsDev& op, const double* pose, const double* trans, const FrameParams& fp,
-                            const uint8_t* visrow, const int* klist, int nk, const double* vbase, const bool light) {
+                            const uint8_t* visrow, const int* klist, int nk, const double* vbase, const bool light,
+                            const CoopCtx& co = CoopCtx()) {
     const int tid = threadIdx.x;
+    const int m_lo = COOP ? co.mlo : 0, m_hi = COOP ? co.mhi : at.M;   // this workgroup's markers ...
+    const int a_lo = 3 * m_lo, a_hi = COOP ? 3 * co.mhi : at.Nv;        // ... and attached vertices (a = 3 m + s)
     const int K = md.K, P = md.P, bd = md.body_dof, hd = md.hand_dof, nhf = md.nhand_full;
     PROF_BEGIN(); PROF_COUNT(20);
     // `light` (wave-uniform): the forward state in LDS -- rotations, chain, vertices, simulated markers, the prior's argmin and
@@ -398,12 +519,13 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         }
     }
     // F4: v_posed = vbase + sum_{k in klist} posedirs_k . vec(R_k - I) for the attached vertices.
-    posedirs_partial(cx, at, klist, nk, vbase, cx.vposed);
+    if constexpr (COOP) posedirs_partial_range(cx, at, klist, nk, vbase, cx.vposed, a_lo, a_hi);
+    else posedirs_partial(cx, at, klist, nk, vbase, cx.vposed);
     __syncthreads();
     PROF_LAP(1);
     // F5: skinning  v = sum_j w_j (Rw_j (v_posed - J_j) + tw_j) + trans
-    const int NW = at.NW, Nv = at.Nv;
-    for (int a = tid; a < Nv; a += MOSHII_TPB) {
+    const int NW = at.NW;
+    for (int a = a_lo + tid; a < a_hi; a += MOSHII_TPB) {
         const double px = cx.vposed[a * 3 + 0], py = cx.vposed[a * 3 + 1], pz = cx.vposed[a * 3 + 2];
         double ax = 0.0, ay = 0.0, az = 0.0;
         for (int s = 0; s < NW; ++s) {
@@ -423,8 +545,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     }   // (!light)
     // F6: simulated markers + weighted data residual
     double sd = 0.0;
-    const int M = at.M;
-    for (int m = tid; m < M; m += MOSHII_TPB) {
+    for (int m = m_lo + tid; m < m_hi; m += MOSHII_TPB) {
         double mk[3];
         if (!light) {
             const double c[3] = {gptr(at.coef)[m * 3 + 0], gptr(at.coef)[m * 3 + 1], gptr(at.coef)[m * 3 + 2]};
@@ -465,7 +586,7 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     const int np_ = op.nbody;
     double prior_ss = 0.0;
     if (np_ > 0 && light) prior_ss = cx.scal[S_PRIOR_SS];   // (stored by the evaluation that left this state; S_KBEST stands too)
-    if (np_ > 0 && !light) {
+    if (np_ > 0 && !light && (!COOP || co.rank == co.prior_rank)) {
         for (int b = tid; b < np_; b += MOSHII_TPB) cx.xb[b] = pose[op.body[b]];
         __syncthreads();
         const int G = pr.G;
@@ -578,7 +699,27 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     }
     block_sum3(sd, sv, sh, cx.red);
     if constexpr (XT) block_sum3(sf, ss, sy, cx.red);
-    PROF_LAP(3);
+    if constexpr (COOP) {
+        PROF_LAP(3);
+        // the ranks' data sums of squares, added in rank order by every rank; the prior's value (and argmin) from the rank that has it
+        const unsigned seq = coop_begin(cx);
+        auto* mine = coop_slot(co, seq, co.rank);
+        if (tid == 0) { coop_st(mine, sd); coop_st(mine + 1, prior_ss); coop_st(mine + 2, (np_ > 0) ? cx.scal[S_KBEST] : 0.0); }
+        sd = 0.0;
+        if (coop_publish_wait(co, cx, seq)) {
+            for (int r = 0; r < co.G; ++r) sd += coop_ld(coop_slot(co, seq, r));
+            if (np_ > 0) {
+                auto* ps = coop_slot(co, seq, co.prior_rank);
+                prior_ss = coop_ld(ps + 1);
+                const double kbv = coop_ld(ps + 2);
+                if (tid == 0 && co.rank != co.prior_rank) { cx.scal[S_PRIOR_SS] = prior_ss; cx.scal[S_KBEST] = kbv; }   // (what a light evaluation picks up)
+            }
+        }
+        coop_end(cx, seq);
+        PROF_LAP(31);
+    } else {
+        PROF_LAP(3);
+    }
     Sse out;
     out.data = sd; out.velo = sv; out.hand = sh;
     out.face = sf; out.shape = ss; out.stay = sy;
@@ -1177,10 +1318,12 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
 // Normal equations at the point whose forward state is in LDS:  A = J^T J (registers), g = -J^T r (LDS).
 // ------------------------------------------------------------------------------------------------
 // Columns: [trans 3][free pose variables][free shape coefficients]; ncp = 3 + #pose columns, n - ncp = #shape columns (XT only).
-template <int NBLK, bool XT>
+// COOP: the rows of this rank's visible markers only (entries [fp.v0, fp.v1) of the list); the ranks' partial products -- and the prior
+// rank's structured terms -- meet in an exchange before the tiles are re-dealt, after which every rank holds the same A and g.
+template <int NBLK, bool XT, bool COOP = false>
 __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at,
                          const PriorDev& pr, const OptsDev& op, const double* pose, const FrameParams& fp,
-                         int n, int ncp, int nkf, int nfree_hand, double* qs, AReg<NBLK>& A) {
+                         int n, int ncp, int nkf, int nfree_hand, double* qs, AReg<NBLK>& A, const CoopCtx& co = CoopCtx()) {
     const int tid = threadIdx.x;
     const int LDJ = ly.LDJ, Tm = ly.Tm, NW = at.NW, Nvp = at.Nvp, bd = md.body_dof, nhf = md.nhand_full;
     const int nshp = XT ? n - ncp : 0;
@@ -1255,8 +1398,9 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
     }
-    for (int tile0 = 0; tile0 < fp.nobs; tile0 += Tm) {
-        const int cnt = min(Tm, fp.nobs - tile0);
+    const int v_lo = COOP ? fp.v0 : 0, v_hi = COOP ? fp.v1 : fp.nobs;
+    for (int tile0 = v_lo; tile0 < v_hi; tile0 += Tm) {
+        const int cnt = min(Tm, v_hi - tile0);
         const int ntv = 3 * cnt;
         // T0: per tile vertex blended rotation + rigidly-attached positions; per tile marker local Jacobian
         if (tid < ntv) {
@@ -1467,6 +1611,72 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         __syncthreads();
         PROF_LAP(7);
     }
+    const int np_ = op.nbody;
+    double pblk[COOP ? AReg<NBLK>::NE : 1];   // cooperative variant: the prior's block of A in the owners' layout, as received from the prior rank
+    if constexpr (COOP) {
+        constexpr int NT = JtJAcc<NBLK>::NT, NE = AReg<NBLK>::NE;
+        const unsigned seq = coop_begin(cx);
+        auto* mine = coop_slot(co, seq, co.rank);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) coop_st(mine + (size_t)(4 * t + i) * MOSHII_TPB + tid, acc.c[t][i]);
+        if (np_ > 0 && co.rank == co.prior_rank) {
+            // the prior's share of the normal equations at this point (its argmin component kb was found by this rank's evaluation):
+            // block w^2 (1/2 L L^T)[colprior, colprior] in the owners' layout, gradient -w^2 (1/2 L L^T)(x - mu) per column
+            const int kb = (int)cx.scal[S_KBEST];
+            const double w2 = fp.wt_pose * fp.wt_pose;
+            AReg<NBLK> P;
+            P.zero();
+            P.add_prior(w2, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) coop_st(mine + (size_t)(4 * NT + e) * MOSHII_TPB + tid, P.a[e]);
+            double gq = 0.0;
+            if (tid < n) {
+                const int pb = cx.colprior[tid];
+                if (pb >= 0) {
+                    const auto* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
+                    const auto* mu = pr.means + (size_t)kb * np_;
+                    double s0 = 0.0, s1 = 0.0;
+                    for (int b0 = 0; b0 < np_; b0 += 32) {
+                        double h[32];
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) h[k] = Hk[(size_t)min(b0 + k, np_ - 1) * np_];
+#pragma unroll
+                        for (int k = 0; k < 32; k += 2) {
+                            const int b = b0 + k;
+                            s0 = fma(h[k] * ((b < np_) ? 1.0 : 0.0), cx.xb[min(b, np_ - 1)] - mu[min(b, np_ - 1)], s0);
+                            s1 = fma(h[k + 1] * ((b + 1 < np_) ? 1.0 : 0.0), cx.xb[min(b + 1, np_ - 1)] - mu[min(b + 1, np_ - 1)], s1);
+                        }
+                    }
+                    gq = -(w2 * (s0 + s1));
+                }
+            }
+            coop_st(mine + (size_t)(4 * NT + NE) * MOSHII_TPB + tid, gq);
+        }
+        acc.zero();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) pblk[e] = 0.0;
+        double gqp = 0.0;
+        if (coop_publish_wait(co, cx, seq)) {
+            for (int r = 0; r < co.G; ++r) {   // (rank order: the same sums, bit for bit, on every rank)
+                auto* sr = coop_slot(co, seq, r);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc.c[t][i] += coop_ld(sr + (size_t)(4 * t + i) * MOSHII_TPB + tid);
+            }
+            if (np_ > 0) {
+                auto* sp = coop_slot(co, seq, co.prior_rank);
+#pragma unroll
+                for (int e = 0; e < NE; ++e) pblk[e] = coop_ld(sp + (size_t)(4 * NT + e) * MOSHII_TPB + tid);
+                gqp = coop_ld(sp + (size_t)(4 * NT + NE) * MOSHII_TPB + tid);
+            }
+        }
+        if (tid < n) cx.dgn[tid] = gqp;   // (free here: the Gauss-Newton step of the last iteration has been used up)
+        coop_end(cx, seq);
+        PROF_LAP(32);
+    }
     A.take(acc, cx.big);   // (the tile loop ended with a barrier: the Jacobian tile region is free)
     {   // data-term gradient g = -J^T r: row n of the product (its owners: ty == n % 16 in block row n / 16)
         const int ty = tid >> 4, tx = tid & 15, bn = n >> 4;
@@ -1480,7 +1690,6 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         __syncthreads();
     }
     // structured terms: prior (dense, precomputed 0.5 L L^T per component), velocity and finger terms (diagonal)
-    const int np_ = op.nbody;
     double* dvec = cx.y;   // diagonal additions
     const int kb = (np_ > 0) ? (int)cx.scal[S_KBEST] : 0;
     for (int q = tid; q < n; q += MOSHII_TPB) {
@@ -1495,7 +1704,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             const int pid = cx.colpid[q];
             if (fp.has_velo) { const double w2 = fp.wt_velo * fp.wt_velo; dg += w2; gq -= w2 * (pose[pid] - cx.vtarget[pid]); }
             const int pb = cx.colprior[q];
-            if (pb >= 0) {   // prior gradient w^2 (1/2 L L^T)(x - mu): column pb of the symmetric half-precision, b uniform
+            if (COOP) { gq += cx.dgn[q]; }   // (the prior rank's column sums, received above)
+            else if (pb >= 0) {   // prior gradient w^2 (1/2 L L^T)(x - mu): column pb of the symmetric half-precision, b uniform
                 const auto* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
                 const auto* mu = pr.means + (size_t)kb * np_;
                 double s0 = 0.0, s1 = 0.0;
@@ -1529,7 +1739,12 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     }
     __syncthreads();
     A.add_diag(dvec, n);
-    if (np_ > 0) A.add_prior(fp.wt_pose * fp.wt_pose, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
+    if constexpr (COOP) {
+#pragma unroll
+        for (int e = 0; e < AReg<NBLK>::NE; ++e) A.a[e] += pblk[e];
+    } else {
+        if (np_ > 0) A.add_prior(fp.wt_pose * fp.wt_pose, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
+    }
     __syncthreads();
     PROF_LAP(8);
 }
@@ -1575,7 +1790,7 @@ __device__ __forceinline__ T uniform_load(const T* p) {
     return out;
 }
 
-template <bool XT>
+template <bool XT, bool COOP>
 __device__ __noinline__ Sse eval_forward_fn(const uint8_t* visrow, int o_pose, int o_trans, int i_klist, int nk,
                                             int o_vbase, int light) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1588,9 +1803,11 @@ __device__ __noinline__ Sse eval_forward_fn(const uint8_t* visrow, int o_pose, i
     const FrameParams fp = uniform_load(reinterpret_cast<const FrameParams*>(kc->fp_raw));
     const Ctx cx = make_ctx(lds, ly);
     const int* ints = reinterpret_cast<const int*>(lds + ly.o_ints);
-    return eval_forward<XT>(cx, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), lds + __builtin_amdgcn_readfirstlane(o_trans),
-                            fp, visrow, ints + __builtin_amdgcn_readfirstlane(i_klist), __builtin_amdgcn_readfirstlane(nk),
-                            lds + __builtin_amdgcn_readfirstlane(o_vbase), __builtin_amdgcn_readfirstlane(light) != 0);
+    CoopCtx co = CoopCtx();
+    if constexpr (COOP) co = uniform_load(&kc->co);
+    return eval_forward<XT, COOP>(cx, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), lds + __builtin_amdgcn_readfirstlane(o_trans),
+                                  fp, visrow, ints + __builtin_amdgcn_readfirstlane(i_klist), __builtin_amdgcn_readfirstlane(nk),
+                                  lds + __builtin_amdgcn_readfirstlane(o_vbase), __builtin_amdgcn_readfirstlane(light) != 0, co);
 }
 
 #ifdef MOSHII_ASM_INLINE
@@ -1598,7 +1815,7 @@ __device__ __noinline__ Sse eval_forward_fn(const uint8_t* visrow, int o_pose, i
 #else
 #define MOSHII_ASM_LINKAGE __noinline__
 #endif
-template <int NBLK, bool XT>
+template <int NBLK, bool XT, bool COOP>
 __device__ MOSHII_ASM_LINKAGE typename APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::type assemble_fn(int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
@@ -1610,8 +1827,10 @@ __device__ MOSHII_ASM_LINKAGE typename APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::ty
     const FrameParams fp = uniform_load(reinterpret_cast<const FrameParams*>(kc->fp_raw));
     const Ctx cx = make_ctx(lds, ly);
     AReg<NBLK> A;
-    assemble<NBLK, XT>(cx, ly, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), fp, __builtin_amdgcn_readfirstlane(n),
-                       __builtin_amdgcn_readfirstlane(ncp), __builtin_amdgcn_readfirstlane(nkf), __builtin_amdgcn_readfirstlane(nfree_hand), qs, A);
+    CoopCtx co = CoopCtx();
+    if constexpr (COOP) co = uniform_load(&kc->co);
+    assemble<NBLK, XT, COOP>(cx, ly, md, at, pr, op, lds + __builtin_amdgcn_readfirstlane(o_pose), fp, __builtin_amdgcn_readfirstlane(n),
+                             __builtin_amdgcn_readfirstlane(ncp), __builtin_amdgcn_readfirstlane(nkf), __builtin_amdgcn_readfirstlane(nfree_hand), qs, A, co);
     return APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::pack(A);
 }
 
@@ -1704,12 +1923,12 @@ __device__ __noinline__ void rigid_init_serial(const Ctx& cx, const FrameParams&
 // ------------------------------------------------------------------------------------------------
 // XT: the unknowns are x = [trans, pose[ids], shape coefficients (nshp of them, Step 2 only)]; the shape block is stored
 // behind the pose variables (cx.pose[NP ..]), so a shape column q has colpid[q] = NP + e and moves with the same code.
-template <int NBLK, bool XT>
+template <int NBLK, bool XT, bool COOP>
 __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& md, const AttachDev& at, const PriorDev& pr,
                          const OptsDev& op, const FrameParams& fp, const uint8_t* visrow, MOSHII_GP(const int) ids, int nids, int nshp,
                          double* qs, double e3,
                          bool rigid, bool eval_only, bool reuse, Sse& carried, bool& at_pose, int& fwd_set, int set_id, int& vc_key,
-                         int& tab_key, int& n_iter, int& n_fev, int& fail) {
+                         int& tab_key, int& n_iter, int& n_fev, int& fail, const CoopCtx& co) {
     const int tid = threadIdx.x;
     const int ncp = 3 + nids;
     const int n = ncp + (XT ? nshp : 0);
@@ -1762,7 +1981,8 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             for (int e = 0; e < 9; ++e) cx.feat[tid * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
         }
         __syncthreads();
-        posedirs_partial(cx, at, cx.kconst, nkc, at.vsh, cx.vconst);
+        if constexpr (COOP) posedirs_partial_range(cx, at, cx.kconst, nkc, at.vsh, cx.vconst, 3 * co.mlo, 3 * co.mhi);
+        else posedirs_partial(cx, at, cx.kconst, nkc, at.vsh, cx.vconst);
         __syncthreads();
         vc_key = set_id;
     }
@@ -1791,11 +2011,28 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     int light = (!rigid && at_pose && fwd_set == set_id) ? 1 : 0;
     while (true) {
         if (skip_eval) { last = carried; skip_eval = false; }
-        else { PROF_T(_te); last = eval_forward_fn<XT>(visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst, light); PROF_ACC(15, _te); }
+        else { PROF_T(_te); last = eval_forward_fn<XT, COOP>(visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst, light); PROF_ACC(15, _te); }
+        if constexpr (COOP) { if (cx.scal[S_COOP_FAIL] != 0.0) break; }   // the group is broken: unwind (the host reports the launch as failed)
         light = 0;
         at_pose = true;   // cleared below when a trial point is rejected
         fwd_set = set_id;
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
+            if constexpr (COOP) {   // every rank needs all the simulated markers: gather the ranks' rows (its own stay as they are)
+                const unsigned seq = coop_begin(cx);
+                auto* mine = coop_slot(co, seq, co.rank);
+                for (int i = 3 * co.mlo + tid; i < 3 * co.mhi; i += MOSHII_TPB) coop_st(mine + i, cx.msim[i]);
+                if (tid == 0) coop_st(mine + 3 * at.M, (double)co.mlo);   // (where this rank's range starts)
+                if (coop_publish_wait(co, cx, seq)) {
+                    const int M3 = 3 * at.M;
+                    for (int i = tid; i < M3; i += MOSHII_TPB) {
+                        // owner of marker i / 3: the rank whose range holds it (ranges are contiguous and ascending: count the boundaries passed)
+                        int r = 0;
+                        for (int q = 1; q < co.G; ++q) r += (i >= 3 * (int)coop_ld(coop_slot(co, seq, q) + 3 * at.M)) ? 1 : 0;
+                        if (r != co.rank) cx.msim[i] = coop_ld(coop_slot(co, seq, r) + i);
+                    }
+                }
+                coop_end(cx, seq);
+            }
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
             __syncthreads();
             for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
@@ -1830,7 +2067,8 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         }
         PROF_ACC(23, _t1);
         if (do_assemble) {
-            { PROF_T(_ta); A = APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::unpack(assemble_fn<NBLK, XT>(ly.o_pose, n, ncp, nkf, nfree_hand, qs)); PROF_ACC(16, _ta); }
+            { PROF_T(_ta); A = APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::unpack(assemble_fn<NBLK, XT, COOP>(ly.o_pose, n, ncp, nkf, nfree_hand, qs)); PROF_ACC(16, _ta); }
+            if constexpr (COOP) { if (cx.scal[S_COOP_FAIL] != 0.0) break; }
             PROF_T(_t2);
             double gm = 0.0;
             for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
@@ -1941,17 +2179,35 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 //           (+6 % aggregate when there are more chains than CUs, 1.9x slower per chain: not instantiated since round 3).
 // XT = true: the extended variant with the Step-2 extras of chmosh.py:685-699 (jaw term, free shape block); kept out of
 //           the plain instantiations so that their register allocation and timings are untouched.
-template <int NBLK, int MINW, bool XT>
+// COOP = true: cooperative chains -- G workgroups per chain (ChainDev::coop; see moshii_dev.h).  Block b is rank (b / 8) % G of chain
+//           8 ((b / 8) / G) + b % 8: the ranks of a chain sit on blocks that are congruent modulo 8, i.e. (as blocks are observed to be dealt
+//           to the XCDs round-robin) on CUs that share an L2 -- a matter of speed only.  Plain chains only: the hand-off / baton / re-join
+//           fields of a chunked solve are ignored.  Rank 0 writes the per-frame rows, every rank its own simulated markers.
+template <int NBLK, int MINW, bool XT, bool COOP = false>
 __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev* __restrict__ chains, ModelDev md, PriorDev pr,
-                                                             OptsDev op, ChainLayout ly) {
+                                                             OptsDev op, ChainLayout ly, int n_chains) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
-    const ChainDev* chp = chains + blockIdx.x;   // fields are (re)loaded where used: keeps SGPR pressure down
+    int chain_id = blockIdx.x;
+    CoopCtx co = CoopCtx();
+    if constexpr (COOP) {
+        const int G = chains[0].coop.G;   // (the same for every chain of a launch)
+        const int q = blockIdx.x >> 3;
+        chain_id = 8 * (q / G) + (blockIdx.x & 7);
+        if (chain_id >= n_chains) return;
+        const ChainDev* c0 = chains + chain_id;
+        co.G = G; co.rank = q % G; co.prior_rank = c0->coop.prior_rank;
+        co.mlo = c0->coop.mlo[co.rank]; co.mhi = c0->coop.mlo[co.rank + 1];
+        co.slot_doubles = c0->coop.slot_doubles; co.slots = c0->coop.slots; co.flags = c0->coop.flags;
+    }
+    const bool lead = !COOP || co.rank == 0;   // writes the rows every rank holds alike
+    const ChainDev* chp = chains + chain_id;   // fields are (re)loaded where used: keeps SGPR pressure down
     const AttachDev at = *chp->att;
     const Ctx cx = make_ctx(lds, ly);
     if (tid == 0) {   // the descriptors for the separately compiled phases (eval_forward_fn / assemble_fn)
         KernelCtx* kc = reinterpret_cast<KernelCtx*>(lds);
         kc->ly = ly; kc->md = md; kc->pr = pr; kc->op = op; kc->at = at;
+        if constexpr (COOP) { kc->co = co; cx.scal[S_COOP_SEQ] = 0.0; cx.scal[S_COOP_FAIL] = 0.0; }
     }
 
     const int NP = md.NP, M = at.M, F = chp->F, skip = chp->skip;
@@ -2001,14 +2257,14 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         // chunk hand-off states: moshii_sequence_solve checks a chunk's entry state against its predecessor's final one
         for (int which = 0; which < 2; ++which) {
             double* so = (which == 0) ? ((t == skip) ? chp->entry_state : nullptr) : ((t == F) ? chp->final_state : nullptr);
-            if (so == nullptr) continue;
+            if (so == nullptr || !lead) continue;
             for (int i = tid; i < NP; i += MOSHII_TPB) { so[i] = cx.pose[i]; so[NP + i] = cx.pose_prev[i]; }
             if (tid < 3) so[2 * NP + tid] = cx.trans[tid];
             if (tid == 3) so[2 * NP + 3] = has_prev ? 1.0 : 0.0;
             if (tid == 4) so[2 * NP + 4] = first ? 1.0 : 0.0;
             if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) so[2 * NP + 5 + e] = cx.pose[NP + e];
         }
-        if (chp->fuse_flags != nullptr) {
+        if (!COOP && chp->fuse_flags != nullptr) {
             const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
             if (t == skip && chp->entry_state != nullptr) {   // the entry state is out: the left neighbour may compare with it
                 __syncthreads();
@@ -2117,7 +2373,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
         }
         const bool sweeping = chp->fuse_F == 0 || fuse_on;   // (a pass-1 chain inside its own chunk is not a repair chain yet)
-        if (bi_next < chp->nb && t == chp->bnd[bi_next] - chp->bnd_off) {   // a chunk boundary inside a run-through repair chain
+        if (!COOP && bi_next < chp->nb && t == chp->bnd[bi_next] - chp->bnd_off) {   // a chunk boundary inside a run-through repair chain
             const int S = 2 * NP + 5 + (XT ? op.nshape : 0);
             double* s1 = chp->run_final + (size_t)bi_next * S;          // end state of the chunk just left ...
             for (int i = tid; i < NP; i += MOSHII_TPB) { s1[i] = cx.pose[i]; s1[NP + i] = cx.pose_prev[i]; }
@@ -2171,7 +2427,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             if constexpr (XT) for (int e = tid; e < op.nshape; e += MOSHII_TPB) s2[2 * NP + 5 + e] = cx.pose[NP + e];
             ++bi_next;
         }
-        if (chp->baton != nullptr && sweeping && t < F) {
+        if (!COOP && chp->baton != nullptr && sweeping && t < F) {
             // Has an upstream chain of this round asked for this chain's territory (ChainDev::baton)?  Then stop here.  The rows
             // of the chunk this chain is in now switch from its own to older ones at frame t -- in the middle of a chunk, where
             // no hand-off check looks -- so the chunk's entry state is spoiled (an impossible flag value): unless the upstream
@@ -2198,27 +2454,33 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         const uint8_t* visrow = chp->vis + (size_t)t * M;
         // visible-marker list (chmosh.py:591-594), kept in label order
         if (tid < 64) {   // wave 0: one ballot per 64 markers, list position = number of visible markers before this one
-            int c = 0;
+            int c = 0, c0 = 0, c1 = 0;
             for (int m0 = 0; m0 < M; m0 += 64) {
                 const int m = m0 + tid;
                 const bool v = m < M && gptr(visrow)[min(m, M - 1)] != 0;
                 const unsigned long long mask = __ballot(v);
                 if (v) cx.visidx[c + __popcll(mask & ((1ull << tid) - 1ull))] = m;
                 c += __popcll(mask);
+                if constexpr (COOP) {   // this rank's share of the list: the visible markers of [mlo, mhi) (the list is in label order)
+                    c0 += __popcll(__ballot(v && m < co.mlo));
+                    c1 += __popcll(__ballot(v && m < co.mhi));
+                }
             }
-            if (tid == 0) cx.scal[S_TMP1] = (double)c;
+            if (tid == 0) { cx.scal[S_TMP1] = (double)c; cx.scal[S_V0] = (double)c0; cx.scal[S_V1] = (double)c1; }
         }
         __syncthreads();
         const int nobs = (int)cx.scal[S_TMP1];
         if (nobs == 0) {   // chmosh.py:586-588
             int* st = chp->status;
-            if (tid == 0 && st && record) st[t] = 1;
+            if (tid == 0 && st && record && lead) st[t] = 1;
             __syncthreads();
             continue;
         }
         FrameParams fp;
         fp.obs = chp->obs + (size_t)t * M * 3;
         fp.nobs = nobs;
+        fp.v0 = COOP ? (int)cx.scal[S_V0] : 0;
+        fp.v1 = COOP ? (int)cx.scal[S_V1] : nobs;
         const double n_miss = (double)(M - nobs);
         double anneal = 1.0;
         if (n_miss > 0.0) anneal = anneal + (n_miss / (double)M) * op.wt_annealing;   // :596-601
@@ -2263,15 +2525,19 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
             const int terms = fp.use_fingers | (fp.use_face << 1) | (fp.use_shape << 2);   // the Step-2-only residual blocks
             const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_terms == terms;
-            fin = run_phase<NBLK, XT>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
+            fin = run_phase<NBLK, XT, COOP>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
                                   (XT && step2) ? op.nshape : 0, XT ? chp->qscratch : nullptr,
                                   round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose, fwd_set,
-                                  /*set_id=*/(kind >= 4 && !same_sets) ? 2 : 1, vc_key, tab_key, n_iter, n_fev, fail);
+                                  /*set_id=*/(kind >= 4 && !same_sets) ? 2 : 1, vc_key, tab_key, n_iter, n_fev, fail, co);
             prev_wt_pose = fp.wt_pose; prev_terms = terms;
+            if constexpr (COOP) { if (cx.scal[S_COOP_FAIL] != 0.0) break; }
+        }
+        if constexpr (COOP) {   // a rank did not show up: nothing of this frame is recorded; the host sees the group's abort word
+            if (cx.scal[S_COOP_FAIL] != 0.0) break;
         }
         first = false;
         PROF_T(_tr);
-        if (record && sweeping && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
+        if (!COOP && record && sweeping && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
             // repair chains: has this chain re-joined the trajectory already stored for this chunk?
             double dv = 0.0;
             const double* po = chp->pose + (size_t)t * NP;
@@ -2285,12 +2551,15 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         }
         if (record) {   // record
             double* o;
-            if ((o = chp->pose) != nullptr) for (int i = tid; i < NP; i += MOSHII_TPB) o[(size_t)t * NP + i] = cx.pose[i];
-            if ((o = chp->fullpose) != nullptr) for (int i = tid; i < md.P; i += MOSHII_TPB) o[(size_t)t * md.P + i] = cx.fullpose[i];
-            if ((o = chp->msim) != nullptr) for (int i = tid; i < 3 * M; i += MOSHII_TPB) o[(size_t)t * 3 * M + i] = cx.msim[i];
+            if (lead && (o = chp->pose) != nullptr) for (int i = tid; i < NP; i += MOSHII_TPB) o[(size_t)t * NP + i] = cx.pose[i];
+            if (lead && (o = chp->fullpose) != nullptr) for (int i = tid; i < md.P; i += MOSHII_TPB) o[(size_t)t * md.P + i] = cx.fullpose[i];
+            if ((o = chp->msim) != nullptr) {   // (cooperative chains: every rank the rows of its own markers)
+                const int i_lo = COOP ? 3 * co.mlo : 0, i_hi = COOP ? 3 * co.mhi : 3 * M;
+                for (int i = i_lo + tid; i < i_hi; i += MOSHII_TPB) o[(size_t)t * 3 * M + i] = cx.msim[i];
+            }
             if constexpr (XT)
-                if ((o = chp->shape) != nullptr) for (int e = tid; e < op.nshape; e += MOSHII_TPB) o[(size_t)t * op.nshape + e] = cx.pose[NP + e];
-            if (tid == 0) {
+                if (lead && (o = chp->shape) != nullptr) for (int e = tid; e < op.nshape; e += MOSHII_TPB) o[(size_t)t * op.nshape + e] = cx.pose[NP + e];
+            if (tid == 0 && lead) {
                 if ((o = chp->trans) != nullptr) { o[t * 3 + 0] = cx.trans[0]; o[t * 3 + 1] = cx.trans[1]; o[t * 3 + 2] = cx.trans[2]; }
                 if ((o = chp->errs) != nullptr) {
                     o[t * 8 + 0] = fin.data; o[t * 8 + 1] = fin.prior; o[t * 8 + 2] = fin.velo; o[t * 8 + 3] = fin.hand;
@@ -2302,17 +2571,17 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
         }
         __syncthreads();
-        if (rejoin_run > 0 && chp->abort_at != nullptr) {
+        if (!COOP && rejoin_run > 0 && chp->abort_at != nullptr) {
             // rows a stopped chain left in this chunk (ChainDev::abort_at) do not count: matching THEM says nothing about the
             // older rows behind them -- only frames at or past the mark do
             const int mark = __hip_atomic_load(chp->abort_at + chp->chunk0 + bi_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (chp->bnd_off + t < mark) rejoin_run = 0;
         }
         if (rejoin_run >= 2 && t + 1 < F) { if (tid == 0 && chp->frames_done) *chp->frames_done = t + 1; break; }   // pose and pose_prev both match: the stored rows (and final state) stand
-        if (t + 1 == F && tid == 0 && chp->frames_done) *chp->frames_done = F;
+        if (t + 1 == F && tid == 0 && lead && chp->frames_done) *chp->frames_done = F;
         PROF_ACC(19, _tr);
     }
-    if (chp->baton != nullptr) {   // this chain is out of the way: everything it stored is visible before the flag is
+    if (!COOP && chp->baton != nullptr) {   // this chain is out of the way: everything it stored is visible before the flag is
         __syncthreads();
         if (tid == 0) {
             __threadfence();
@@ -2325,27 +2594,26 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
 #endif
 }
 
-#ifdef MOSHII_DEV_ONLY_NBLK4   // development builds: one instantiation (the 63-unknown body solve) compiles in seconds
-template __global__ void k_chain_solve<4, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
+#ifdef MOSHII_DEV_ONLY_NBLK4   // development builds: one size class (the 63-unknown body solve) compiles in seconds
+template __global__ void k_chain_solve<4, 1, false, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout, int);
+template __global__ void k_chain_solve<4, 1, false, true>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout, int);
 #else
-#define MOSHII_INSTANTIATE(N) \
-    template __global__ void k_chain_solve<N, 1, false>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
-MOSHII_INSTANTIATE(2)
-MOSHII_INSTANTIATE(4)
-MOSHII_INSTANTIATE(5)
-MOSHII_INSTANTIATE(7)
-MOSHII_INSTANTIATE(8)
-#undef MOSHII_INSTANTIATE
+#define MOSHII_INSTANTIATE(N, XT_, COOP_) \
+    template __global__ void k_chain_solve<N, 1, XT_, COOP_>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout, int);
+MOSHII_INSTANTIATE(2, false, false)
+MOSHII_INSTANTIATE(4, false, false)
+MOSHII_INSTANTIATE(5, false, false)
+MOSHII_INSTANTIATE(7, false, false)
+MOSHII_INSTANTIATE(8, false, false)
 // extended variant: up to 3 + 111 pose + 80 expression unknowns (SMPL-X with fingers and face: NBLK = 13)
-#define MOSHII_INSTANTIATE_XT(N) \
-    template __global__ void k_chain_solve<N, 1, true>(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout);
-MOSHII_INSTANTIATE_XT(5)
-MOSHII_INSTANTIATE_XT(8)
-MOSHII_INSTANTIATE_XT(10)
-MOSHII_INSTANTIATE_XT(13)
-#undef MOSHII_INSTANTIATE_XT
-
-
+MOSHII_INSTANTIATE(5, true, false)
+MOSHII_INSTANTIATE(8, true, false)
+MOSHII_INSTANTIATE(10, true, false)
+MOSHII_INSTANTIATE(13, true, false)
+// cooperative chains (G workgroups per chain): the body solve and the solve with fingers
+MOSHII_INSTANTIATE(4, false, true)
+MOSHII_INSTANTIATE(8, false, true)
+#undef MOSHII_INSTANTIATE
 #endif
 
 // Simulated markers for explicit pose variables (TransformedLms.r), one frame per workgroup.
@@ -2372,22 +2640,32 @@ __global__ __launch_bounds__(MOSHII_TPB) void k_markers(const AttachDev* __restr
     for (int k = 1 + tid; k < md.K; k += MOSHII_TPB) cx.ksum[k - 1] = k;   // every joint's correctives, on top of v_shaped
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];
     __syncthreads();
+    fp.v0 = 0; fp.v1 = 0;
     eval_forward<false>(cx, md, at, pr, op, cx.pose, cx.trans, fp, nullptr, cx.ksum, md.K - 1, at.vsh, false);
     for (int i = tid; i < 3 * at.M; i += MOSHII_TPB) out[(size_t)f * 3 * at.M + i] = cx.msim[i];
 }
 
 }  // namespace moshii
 
+// coop_g >= 1: cooperative chains, coop_g workgroups per chain (every ChainDev::coop of the launch is filled in for that group size);
+// the grid is 8 coop_g ceil(n_chains / 8) blocks, of which those beyond the last chain return at once (block -> (chain, rank): k_chain_solve).
 extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt, int n_chains, size_t lds_bytes, hipStream_t stream,
                                                 const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
-                                                const OptsDev* op, const ChainLayout* ly) {
+                                                const OptsDev* op, const ChainLayout* ly, int coop_g) {
     using namespace moshii;
-    void (*kern)(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout) = nullptr;
+    void (*kern)(const ChainDev*, ModelDev, PriorDev, OptsDev, ChainLayout, int) = nullptr;
 #ifdef MOSHII_DEV_ONLY_NBLK4
     if (xt || nblk != 4 || two_per_cu) return hipErrorInvalidValue;
-    kern = k_chain_solve<4, 1, false>;
+    if (coop_g >= 1) kern = k_chain_solve<4, 1, false, true>; else kern = k_chain_solve<4, 1, false, false>;
 #else
-    if (xt) {
+    if (coop_g >= 1) {
+        if (xt) return hipErrorInvalidValue;
+        switch (nblk) {
+            case 4: kern = k_chain_solve<4, 1, false, true>; break;
+            case 8: kern = k_chain_solve<8, 1, false, true>; break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (xt) {
         switch (nblk) {
             case 5: kern = k_chain_solve<5, 1, true>; break;
             case 8: kern = k_chain_solve<8, 1, true>; break;
@@ -2409,7 +2687,8 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
 #endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(MOSHII_TPB), lds_bytes, stream, chains, *md, *pr, *op, *ly);
+    const int grid = (coop_g >= 1) ? 8 * coop_g * ((n_chains + 7) / 8) : n_chains;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MOSHII_TPB), lds_bytes, stream, chains, *md, *pr, *op, *ly, n_chains);
     return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@
 
 extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt, int n_chains, size_t lds_bytes, hipStream_t stream,
                                                 const ChainDev* chains, const ModelDev* md, const PriorDev* pr,
-                                                const OptsDev* op, const ChainLayout* ly);
+                                                const OptsDev* op, const ChainLayout* ly, int coop_g);
 extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t stream, const AttachDev* att,
                                             const ModelDev* md, const ChainLayout* ly, const double* pose,
                                             const double* trans, double* out);
@@ -70,6 +70,7 @@ struct moshii_model_s {
     double* d_JS = nullptr;             // [K][nshape][3] (moshii_model_set_free_shape)
     int shape_start = 0, nshape = 0;
     Scratch qscratch;                   // per-chain shape-derivative scratch of the extended chain kernel
+    Scratch coopbuf;                    // exchange slots + flags of cooperative chains (moshii_dev.h: CoopDev)
     int *d_parents = nullptr, *d_depth = nullptr, *d_comp_lo = nullptr, *d_comp_hi = nullptr, *d_col_lo = nullptr, *d_col_hi = nullptr;
     unsigned long long* d_anc = nullptr;
     bool betas_set = false;
@@ -676,6 +677,10 @@ struct LaunchCfg {
     int nblk = 0;
     int two_per_cu = 0;
     int xt = 0;                 // extended kernel variant (jaw term / free shape block)
+    int coop_g = 0;             // > 0: cooperative chains, this many workgroups per chain
+    int coop_prior_rank = 0;
+    int coop_slot_doubles = 0;
+    double coop_prior_frac = 0.4;
     ChainLayout ly;
     size_t lds_bytes = 0;
     OptsDev od;
@@ -686,8 +691,22 @@ struct LaunchCfg {
 // Validates the options, picks the J^T J register tiling and the LDS layout (marker-tile size Tm as large as the
 // per-workgroup LDS budget allows) and uploads the id lists.  `extra_bytes` of the model's control scratch are
 // reserved after the id lists; their device/host offsets come back through ctl_off.
+// Cooperative chains: the markers [mlo[r], mlo[r + 1]) of rank r.  The ranks 0 .. G-2 get equal shares, the last rank -- which also
+// evaluates the prior for the group -- `prior_frac` of one (MOSHII_COOP_PRIOR_FRAC; 1 without a prior).
+void coop_split(int M, int G, double prior_frac, int* mlo) {
+    const double w_last = (G > 1) ? prior_frac : 1.0;
+    const double total = (G - 1) + w_last;
+    double acc = 0.0;
+    mlo[0] = 0;
+    for (int r = 0; r < G; ++r) {
+        acc += (r == G - 1) ? w_last : 1.0;
+        mlo[r + 1] = (r == G - 1) ? M : std::min(M, (int)std::lround(M * acc / total));
+        if (mlo[r + 1] < mlo[r]) mlo[r + 1] = mlo[r];
+    }
+}
+
 int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_opts* o, int Mmax, int Nvmax, int NWmax,
-                   int n_workgroups, hipStream_t stream, size_t extra_bytes, LaunchCfg* cfg, size_t* ctl_off) {
+                   int n_workgroups, hipStream_t stream, size_t extra_bytes, LaunchCfg* cfg, size_t* ctl_off, int coop_g = 0) {
     if (!m->betas_set) return fail(MOSHII_ERR_ARG, "moshii_model_set_betas has not been called");
     if (o->n_body > 0 && (!prior || prior->npose != o->n_body)) return fail(MOSHII_ERR_ARG, "prior npose must equal n_body");
     if (o->n_step1 < 0 || o->n_step2 < 0 || o->n_step1 > m->NP || o->n_step2 > m->NP) return fail(MOSHII_ERR_ARG, "bad free-variable lists");
@@ -740,6 +759,27 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     // tiles of 27 / 26 cost 3 + 3), weighted by what a round and a tile's fixed work cost (about 3 : 4).
     int Tm = std::min(40, std::max(2, Mmax));
     ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
+    if (coop_g > 0) {   // cooperative chains: a rank builds the rows of its own markers only -- one tile of its largest possible share
+        if (xt) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: the extended variant is not built");
+        if (nblk != 4 && nblk != 8) { nblk = (nblk < 4) ? 4 : 8; }
+        if (nmax + 1 > nblk * 16) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: too many unknowns");
+        if (coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: at most 8 workgroups per chain");
+        cfg->coop_prior_frac = (npose > 0) ? 0.4 : 1.0;
+        if (const char* e = getenv("MOSHII_COOP_PRIOR_FRAC")) cfg->coop_prior_frac = std::min(1.0, std::max(0.0, atof(e)));
+        int mlo[MOSHII_COOP_MAXG + 1];
+        coop_split(Mmax, coop_g, cfg->coop_prior_frac, mlo);
+        int share = 2;
+        for (int r = 0; r < coop_g; ++r) share = std::max(share, mlo[r + 1] - mlo[r]);
+        Tm = std::min(40, share + 1);   // (+1: a chain with fewer markers than Mmax rounds its shares on its own)
+        ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
+        while (Tm > 2 && (size_t)ly.total_doubles * 8 > (size_t)budget) {   // (a share larger than the LDS leaves room for: several tiles per rank)
+            --Tm;
+            ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
+        }
+        const int NE = nblk * (nblk + 1) / 2, NT = (NE + 3) / 4;
+        cfg->coop_slot_doubles = std::max((4 * NT + NE + 1) * MOSHII_TPB, 3 * Mmax + 2);
+        cfg->coop_prior_rank = coop_g - 1;
+    } else
     if (const char* e = getenv("MOSHII_TM")) {
         Tm = std::max(1, std::min(40, atoi(e)));
         ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
@@ -795,12 +835,14 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     if (prior) cfg->pd = prior->dev();
     cfg->md = m->dev();
     cfg->nblk = nblk; cfg->two_per_cu = xt ? 0 : two_per_cu; cfg->xt = xt; cfg->ly = ly; cfg->lds_bytes = lds_bytes;
+    cfg->coop_g = coop_g;
     return MOSHII_OK;
 }
 
 int launch_chains(const LaunchCfg& cfg, int n, const ChainDev* d_chains, hipStream_t stream) {
-    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, cfg.two_per_cu, cfg.xt, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly));
-    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + "," + std::to_string(cfg.two_per_cu ? 2 : 1) + (cfg.xt ? ",xt>" : ">");
+    HIP_TRY(moshii_launch_chain_solve(cfg.nblk, cfg.two_per_cu, cfg.xt, n, cfg.lds_bytes, stream, d_chains, &cfg.md, &cfg.pd, &cfg.od, &cfg.ly, cfg.coop_g));
+    g_last.name = "k_chain_solve<" + std::to_string(cfg.nblk) + "," + std::to_string(cfg.two_per_cu ? 2 : 1) + (cfg.xt ? ",xt" : "") +
+                  (cfg.coop_g > 0 ? ",coop" + std::to_string(cfg.coop_g) : "") + ">";
     g_last.lds = (int)cfg.lds_bytes; g_last.threads = MOSHII_TPB;
     return MOSHII_OK;
 }
@@ -915,10 +957,27 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     // control block after the id lists: [ChainDev x n][init vectors]
     const int E = o->n_shape > 0 ? o->n_shape : 0;
     const size_t extra = sizeof(ChainDev) * n_chains + sizeof(double) * (size_t)n_chains * (2 * NP + 4 + E + 2) + 256;
+    // cooperative chains (MOSHII_COOP_GROUP(g) in `flags`, or MOSHII_COOP=g): g workgroups per chain, all of them resident at once
+    int coop_g = (int)((flags >> 8) & 0xffu);
+    if (coop_g == 0) if (const char* e = getenv("MOSHII_COOP")) coop_g = atoi(e);
+    if (coop_g < 0 || coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: group size out of range");
+    if (coop_g > 0) {
+        int n_cu = 256;
+        { int d = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d); if (n_cu < 1) n_cu = 256; }
+        const bool fits = (long long)coop_g * n_chains <= n_cu;   // (the blocks beyond the last chain return at once)
+        if (!fits || o->n_shape > 0 || o->n_face > 0) coop_g = 0;   // (more workgroups than CUs would not all be resident: plain chains)
+    }
     LaunchCfg cfg;
     size_t ctl = 0;
-    int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, n_chains, stream, extra, &cfg, &ctl);
+    int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, n_chains, stream, extra, &cfg, &ctl, coop_g);
     if (rc) return rc;
+    size_t coop_bytes_per_chain = 0;
+    if (coop_g > 0) {
+        coop_bytes_per_chain = ((size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(coop_g + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+        if ((rc = m->coopbuf.reserve(coop_bytes_per_chain * n_chains))) return rc;
+        m->coopbuf.used = true; m->coopbuf.last_stream = stream;
+        HIP_TRY(hipMemsetAsync(m->coopbuf.ptr, 0, coop_bytes_per_chain * n_chains, stream));   // flags and abort words start at zero on EVERY call
+    }
     char* dbase = m->scratch.ptr + ctl;
     // extended variant: per-chain scratch for the shape derivatives of the joint transforms ([2][K][E][3] doubles)
     const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;   // global packed factor + trash / zero words (ldl_big)
@@ -938,6 +997,13 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         ChainDev& cd = cds[c];
         memset(&cd, 0, sizeof(cd));
         cd.att = ch.attach->d_self; cd.F = ch.F; cd.first = ch.first_frame_schedule;
+        if (coop_g > 0) {
+            cd.coop.G = coop_g; cd.coop.prior_rank = cfg.coop_prior_rank; cd.coop.slot_doubles = cfg.coop_slot_doubles;
+            coop_split(ch.attach->M, coop_g, cfg.coop_prior_frac, cd.coop.mlo);
+            char* cb = m->coopbuf.ptr + coop_bytes_per_chain * c;
+            cd.coop.slots = as_gp_rw((unsigned long long*)cb);
+            cd.coop.flags = as_gp_rw((unsigned*)(cb + (size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long)));
+        }
         if (ch.init_pose) cd.init_pose = (const double*)(dbase + put(ch.init_pose, sizeof(double) * NP));
         if (ch.init_trans) cd.init_trans = (const double*)(dbase + put(ch.init_trans, sizeof(double) * 3));
         if (ch.init_pose_prev) cd.init_prev = (const double*)(dbase + put(ch.init_pose_prev, sizeof(double) * NP));
@@ -967,6 +1033,15 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     HIP_TRY(hipMemcpyAsync(dbase, hostbuf.data(), off, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // hostbuf is pageable and goes out of scope
     if ((rc = launch_chains(cfg, n_chains, (const ChainDev*)dbase, stream))) return rc;
+    if (coop_g > 0) {   // did every group stay whole?  (the call synchronises: a broken group has to be reported, not left in the rows)
+        std::vector<unsigned> ab(n_chains, 0u);
+        for (int c = 0; c < n_chains; ++c)
+            HIP_TRY(hipMemcpyAsync(&ab[c], m->coopbuf.ptr + coop_bytes_per_chain * c + (size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + coop_g * sizeof(unsigned),
+                                   sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < n_chains; ++c)
+            if (ab[c] != 0u) return fail(MOSHII_ERR_HIP, "cooperative chain: a workgroup of the group did not show up within the wait limit (not all resident?); rerun without MOSHII_COOP");
+    }
     if (!dev) {
         HIP_TRY(hipStreamSynchronize(stream));
         for (int c = 0; c < n_chains; ++c) {

@@ -26,6 +26,7 @@ template <class T> __device__ __forceinline__ const T MOSHII_AS_GLOBAL* gptr(con
 #define MOSHII_GP(T) T*
 #endif
 template <class T> __host__ __device__ inline MOSHII_GP(const T) as_gp(const T* p) { return (MOSHII_GP(const T))p; }   // (filling a descriptor)
+template <class T> __host__ __device__ inline MOSHII_GP(T) as_gp_rw(T* p) { return (MOSHII_GP(T))p; }
 #define MOSHII_TPB 256      // threads per chain workgroup: 4 waves, one per SIMD
 
 struct ModelDev {
@@ -81,6 +82,28 @@ struct OptsDev {
     double wt_poseF, wt_shape, wt_shape_stay;
     int nface, nshape;
     MOSHII_GP(const int) face;
+};
+
+// Cooperative chains (chain_solve.hip, COOP variant): ONE chain solved by G workgroups = G CUs.  Every rank holds the whole solver state
+// in its own LDS and runs the whole dogleg control flow (same inputs, same code: same bits); what is SPLIT is the work that scales with
+// the markers -- rank r owns the markers [mlo[r], mlo[r + 1]) and their attached vertices: pose correctives, skinning, marker frames,
+// residuals, Jacobian rows, its share of J^T J -- and the max-mixture prior, which one rank (prior_rank, given fewer markers) evaluates
+// for all.  The ranks meet twice per dogleg iteration: partial sums of squares after a residual evaluation, partial normal equations
+// after an assembly (summed in rank order by every rank: identical results everywhere, no broadcast of a step).
+#define MOSHII_COOP_MAXG 8
+struct CoopDev {
+    int G;                                   // ranks of the group (0 or 1: a plain chain)
+    int prior_rank;
+    int mlo[MOSHII_COOP_MAXG + 1];
+    int slot_doubles;                        // doubles per (parity, rank) slot
+    MOSHII_GP(unsigned long long) slots;     // [2][G][slot_doubles] payload words (doubles as bit patterns: 8-byte agent-scope accesses)
+    MOSHII_GP(unsigned int) flags;           // [G] sequence number of the last exchange each rank has posted, [G] = the group's abort word
+};
+// the rank's view, in KernelCtx
+struct CoopCtx {
+    int G, rank, prior_rank, mlo, mhi, slot_doubles;
+    MOSHII_GP(unsigned long long) slots;
+    MOSHII_GP(unsigned int) flags;
 };
 
 struct ChainDev {
@@ -142,6 +165,7 @@ struct ChainDev {
     int* fuse_flags;            // device [3 x chunks of the launch]
     int* fuse_count;            // device: number of chains that carried on
     double fuse_tol;
+    CoopDev coop;               // cooperative chains only (G >= 2 ... or 1 for tests); zero otherwise
 };
 
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).
@@ -177,6 +201,7 @@ struct KernelCtx {
     OptsDev op;
     AttachDev at;
     double fp_raw[12];   // the running phase's per-frame parameters (chain_solve.hip: FrameParams), rewritten at every phase start
+    CoopCtx co;          // cooperative variant only
 };
 #define MOSHII_KC_DOUBLES ((int)((sizeof(KernelCtx) + 15) / 16 * 2))
 

@@ -21,7 +21,7 @@ struct alignas(16) double4 { double x, y, z, w; };
 
 namespace hipemu {
 struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
-extern ThreadCtx* cur_ptr;                          // the running fiber's indices (set by the scheduler at every switch)
+extern thread_local ThreadCtx* cur_ptr;             // the running fiber's indices (set by the scheduler at every switch)
 inline ThreadCtx& cur() { return *cur_ptr; }
 void barrier();                                     // workgroup barrier
 void wave_sync();                                   // all lanes of the caller's wavefront rendezvous
@@ -36,7 +36,7 @@ void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `exter
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ thread_local                     // one OS thread runs one workgroup at a time: thread_local == per-workgroup
+#define __shared__ thread_local                     // one OS thread runs one workgroup at a time (HIPEMU_CONCURRENT=1: one OS thread PER workgroup of a launch): thread_local == per-workgroup
 #define __constant__ static
 #define __forceinline__ inline
 #define __noinline__ __attribute__((noinline))
@@ -89,7 +89,7 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
     const int lane = (int)(hipemu::cur().tid.x % 64);
     return (T)hipemu::wave_exchange((double)v, (lane & ~(width - 1)) | (src & (width - 1)));
 }
-inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }   // (blocks and fibers run one at a time)
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }   // (HIPEMU_CONCURRENT=1: workgroups of a launch run side by side)
 inline int __double2loint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b & 0xffffffff); }
 inline int __double2hiint(double v) { int64_t b; memcpy(&b, &v, 8); return (int)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) { int64_t b = ((int64_t)hi << 32) | (uint32_t)lo; double v; memcpy(&v, &b, 8); return v; }
@@ -165,12 +165,14 @@ inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
 inline void __builtin_amdgcn_fence(int, const char*) {}
-inline void __builtin_amdgcn_s_sleep(int) {}
-// device-scope atomics / fences of the inter-workgroup baton: workgroups run one after another here, plain accesses do
+void hipemu_yield();                                  // (a spinning workgroup lets the other workgroups' OS threads run)
+inline void __builtin_amdgcn_s_sleep(int) { hipemu_yield(); }
+// device-scope atomics / fences of the inter-workgroup protocols: real (sequentially consistent) atomics, so that workgroups running
+// side by side (HIPEMU_CONCURRENT=1: the cooperative chains) see each other's flags; plain semantics otherwise
 #define __HIP_MEMORY_SCOPE_AGENT 0
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
-inline void __threadfence() {}
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline long long clock64() { return 0; }
 inline long long wall_clock64() { return 0; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }

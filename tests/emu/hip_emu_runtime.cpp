@@ -47,6 +47,8 @@ hipemu_switch:
 #include <map>
 #include <string>
 #include <chrono>
+#include <thread>
+#include <sched.h>
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 namespace hipemu {
@@ -55,14 +57,15 @@ struct ThreadCtx { dim3 tid, bid, bdim, gdim; };
 namespace {
 enum State { RUN, AT_BARRIER, AT_WAVE, DONE };
 struct Fiber { void* sp; char* stack; State st; ThreadCtx tc; double xval; int xsrc; double xgot; double xval2; const void* xptr; int xbytes; };
-std::vector<char> gatherb_buf;   // [wave][64][64 bytes]: the operands of the wave's last byte gather
-std::vector<double> gather_buf;   // [wave][64][2]: the operands of the wave's last gather, filled when the wave is released
+// (all scheduler state is per OS thread: with HIPEMU_CONCURRENT=1 every workgroup of a launch runs on a thread of its own)
+thread_local std::vector<char> gatherb_buf;   // [wave][64][64 bytes]: the operands of the wave's last byte gather
+thread_local std::vector<double> gather_buf;   // [wave][64][2]: the operands of the wave's last gather, filled when the wave is released
 const size_t STACK = 1 << 20;
-std::vector<Fiber> fibers;
-std::vector<char*> stacks;
-void* sched_sp = nullptr;
-int cur_fiber = -1;
-const std::function<void()>* cur_body = nullptr;
+thread_local std::vector<Fiber> fibers;
+thread_local std::vector<char*> stacks;
+thread_local void* sched_sp = nullptr;
+thread_local int cur_fiber = -1;
+thread_local const std::function<void()>* cur_body = nullptr;
 
 void trampoline() {
     (*cur_body)();
@@ -85,7 +88,7 @@ void register_dynamic_lds(double* base, size_t bytes) {
 }
 static const double CANARY = -7.25e77;
 
-ThreadCtx* cur_ptr = nullptr;
+thread_local ThreadCtx* cur_ptr = nullptr;
 static inline ThreadCtx& cur() { return *cur_ptr; }
 void barrier() { yield_as(AT_BARRIER); }
 void wave_sync() { fibers[cur_fiber].xsrc = -1; yield_as(AT_WAVE); }
@@ -141,13 +144,16 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
         sigaction(SIGSEGV, &sa, nullptr);
         handler_installed = true;
     }
-    gather_buf.assign((size_t)((nt + 63) / 64) * 128, 0.0);
-    gatherb_buf.assign((size_t)((nt + 63) / 64) * 4096, 0);
     if (const char* e = getenv("HIPEMU_LDS_SHRINK")) { size_t cut = (size_t)atol(e); lds_bytes = lds_bytes > cut ? lds_bytes - cut : 0; }   // (self-test of the guard)
     // everything beyond the dynamic LDS this launch asked for is a canary: a kernel writing past its allocation is caught below
     for (auto& a : lds_arrays()) for (size_t i = (lds_bytes + 7) / 8; i < a.bytes / 8; ++i) a.base[i] = CANARY;
-    while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
-    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // HIPEMU_CONCURRENT=1: the workgroups of a launch run side by side, one OS thread each (their LDS is thread_local) -- what kernels
+    // whose workgroups wait for each other need (the cooperative chains); the default runs them one after another on this thread
+    const bool concurrent = getenv("HIPEMU_CONCURRENT") != nullptr && atoi(getenv("HIPEMU_CONCURRENT")) != 0 && grid.x * grid.y * grid.z > 1;
+    auto run_block = [&](unsigned bx, unsigned by, unsigned bz, bool check_lds) {
+        gather_buf.assign((size_t)((nt + 63) / 64) * 128, 0.0);
+        gatherb_buf.assign((size_t)((nt + 63) / 64) * 4096, 0);
+        while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
         fibers.assign(nt, Fiber());
         cur_body = &body;
         for (int t = 0; t < nt; ++t) {
@@ -192,15 +198,30 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
             int live = 0, atb = 0;
             for (int t = 0; t < nt; ++t) { if (fibers[t].st != DONE) ++live; if (fibers[t].st == AT_BARRIER) ++atb; }
             if (live == 0) {
-                for (auto& a : lds_arrays()) for (size_t i = (lds_bytes + 7) / 8; i < a.bytes / 8; ++i)
-                    if (a.base[i] != CANARY) { fprintf(stderr, "hipemu: write past the %zu bytes of dynamic LDS (double index %zu) in block %u\n", lds_bytes, i, bx); abort(); }
+                if (check_lds)   // (the registry holds the launching thread's LDS arrays)
+                    for (auto& a : lds_arrays()) for (size_t i = (lds_bytes + 7) / 8; i < a.bytes / 8; ++i)
+                        if (a.base[i] != CANARY) { fprintf(stderr, "hipemu: write past the %zu bytes of dynamic LDS (double index %zu) in block %u\n", lds_bytes, i, bx); abort(); }
                 break;
             }
             if (atb == live) { for (int t = 0; t < nt; ++t) if (fibers[t].st == AT_BARRIER) fibers[t].st = RUN; progressed = true; }
             if (!progressed) { fprintf(stderr, "hipemu: deadlock (divergent barrier / collective) in block %u\n", bx); abort(); }
         }
+        cur_fiber = -1;
+    };
+    if (concurrent) {
+        std::vector<std::thread> ths;
+        for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx)
+            ths.emplace_back([&run_block, bx, by, bz]() {
+                run_block(bx, by, bz, false);
+                for (char* st : stacks) free(st);
+                stacks.clear();
+            });
+        for (auto& t : ths) t.join();
+    } else {
+        for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) run_block(bx, by, bz, true);
     }
     cur_fiber = -1;
     if (profiling) { ProfRow& r = prof()[name_now]; r.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch0).count(); r.n += 1; r.fibers += (long)grid.x * grid.y * grid.z * nt; }
 }
 }  // namespace hipemu
+void hipemu_yield() { sched_yield(); }

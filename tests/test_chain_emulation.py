@@ -177,3 +177,50 @@ def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F):
             del os.environ['MOSHII_LBS_WAVES']
     assert np.abs(got - ref).max() < 2e-5
     np.testing.assert_array_equal(got, got2)
+
+
+@pytest.mark.parametrize('model_type,fingers,G,F', [('smplh', False, 5, 5), ('smplh', True, 4, 3), ('mano', True, 3, 4), ('smpl', False, 2, 3)])
+def test_cooperative_chain_matches_oracle_in_emulation(monkeypatch, model_type, fingers, G, F):
+    """One chain solved by G workgroups (MOSHII_COOP_GROUP; chain_solve.hip, COOP variant): the ranks split markers / vertices / Jacobian
+    rows and the prior, meet in two exchanges per dogleg iteration, and every rank takes the same decisions.  The emulation runs the G
+    workgroups on G OS threads (HIPEMU_CONCURRENT=1) with real atomics.  Held to the oracle like the plain chain (identical iteration
+    counts), with an empty frame and occluded markers in the sequence."""
+    monkeypatch.setenv('HIPEMU_CONCURRENT', '1')
+    M = {'smpl': 41, 'smplh': 53, 'smplx': 89, 'mano': 33}[model_type]
+    case = oracle_case(model_type, F=F, M=M, seed=4, body_only_markers=not fingers, empty_frames=(2,))
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_fingers=fingers)
+        ch = [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)]
+        plain = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch)[0]
+        out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch, coop=G)[0]
+        kernel = capi.last_launch_info()[0]
+    assert kernel.endswith(f',coop{G}>'), kernel
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], model_type,
+                           optimize_fingers=fingers)
+    solved = np.flatnonzero(out['status'] == 0)
+    assert list(solved) == list(ref['frame_ids']) and out['status'][2] == 1
+    assert np.abs(out['fullpose'][solved] - ref['fullpose']).max() < 1e-9 and np.abs(out['trans'][solved] - ref['trans']).max() < 1e-10
+    np.testing.assert_array_equal(out['iters'][solved, 0], ref['iters'])
+    # against the plain chain: every output row (the ranks write their own simulated markers; rank 0 the rest)
+    np.testing.assert_array_equal(out['iters'], plain['iters'])
+    for k in ('pose', 'fullpose', 'trans', 'markers_sim'):
+        assert np.abs(out[k] - plain[k]).max() < 1e-9, k
+    assert np.abs(out['errs'] - plain['errs']).max() < 1e-7 * max(1.0, np.abs(plain['errs']).max())
+
+
+def test_cooperative_chains_several_groups_in_one_launch_in_emulation(monkeypatch):
+    """Two chains x 3 workgroups in one launch (block -> (chain, rank) mapping, separate exchange buffers), one of them continuing a chain."""
+    monkeypatch.setenv('HIPEMU_CONCURRENT', '1')
+    case = oracle_case('smplh', F=6, M=53, seed=6)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case)
+        first = dict(attach=dev['attach'], obs=case['obs'][:3], vis=case['vis'][:3], first=True)
+        a = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], [first])[0]
+        cont = dict(attach=dev['attach'], obs=case['obs'][3:], vis=case['vis'][3:], first=False, init_pose=a['pose'][2], init_trans=a['trans'][2],
+                    init_pose_prev=a['pose'][1])
+        plain = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], [first, cont])
+        outs = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], [first, cont], coop=3)
+        assert capi.last_launch_info()[0].endswith(',coop3>')
+    for o, p_ in zip(outs, plain):
+        np.testing.assert_array_equal(o['iters'], p_['iters'])
+        assert np.abs(o['fullpose'] - p_['fullpose']).max() < 1e-9 and np.abs(o['markers_sim'] - p_['markers_sim']).max() < 1e-9

@@ -21,7 +21,8 @@ names = {0: 'eval: fullpose/rodrigues/chain', 1: 'eval: posedirs', 2: 'eval: ski
          4: 'asm: T0', 5: 'asm: T1 vertex jac', 6: 'asm: T2 marker rows', 7: 'asm: T3 JtJ', 8: 'asm: structured',
          9: 'chol: set-up + verdicts', 10: 'back-subst', 12: 'kernel total',
          46: 'chol: publish', 44: 'chol: panel (wave 0)', 45: 'chol: trailing update',
-         40: 'eval: velocity / finger sums', 41: 'eval: prior setup (xb)', 42: 'eval: prior shortcut', 43: 'eval: prior full + argmin'}
+         40: 'eval: velocity / finger sums', 41: 'eval: prior setup (xb)', 42: 'eval: prior shortcut', 43: 'eval: prior full + argmin',
+         31: 'coop: exchange after an evaluation (incl. waiting)', 32: 'coop: exchange of the normal equations (incl. waiting)'}
 p[9] -= p[44] + p[45] + p[46]   # (slot 9 laps the whole factorisation; 44-46 are laps inside it)
 tot = p[12]
 print(f'{mt} F={F} fingers={fingers} wall {dt*1e3:.1f} ms  ({dt/F*1e6:.1f} us/frame)  launch {capi.last_launch_info()}')
