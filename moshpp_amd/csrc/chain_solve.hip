@@ -22,6 +22,11 @@ typedef double v2d __attribute__((vector_size(16)));   // one 16-byte load
 
 #ifdef MOSHII_PROFILE
 __device__ long long g_prof[64];
+// cooperative chains: wall-clock stamps (100 MHz, one clock for the whole device) of every exchange, per rank of chain 0:
+// [rank][exchange][0 arrive, 1 posted, 2 everybody seen, 3 payload read]
+#define MOSHII_TRACE_N 8192
+__device__ long long g_trace[8][MOSHII_TRACE_N][4];
+#define TRACE_STAMP(co, seq, ev) do { if (threadIdx.x == 0 && blockIdx.x < 8u * (co).G && (blockIdx.x & 7u) == 0u && (seq) < MOSHII_TRACE_N) g_trace[(co).rank][(seq)][(ev)] = wall_clock64(); } while (0)
 #define PROF_BEGIN() long long _pt = clock64()
 // (block 0 only: the one chain of a profiled run -- rank 0 of a cooperative chain)
 #define PROF_LAP(slot) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { long long _n = clock64(); g_prof[slot] += _n - _pt; _pt = _n; } else { _pt = 0; } } while (0)
@@ -39,6 +44,7 @@ __device__ long long g_prof[64];
 #define PROF_LAP_EXT(slot) do {} while (0)
 #define PROF_T(var) do {} while (0)
 #define PROF_ACC(slot, var) do {} while (0)
+#define TRACE_STAMP(co, seq, ev) do {} while (0)
 #endif
 
 enum { S_KBEST = 0, S_PRIOR_SS = 1, S_FAIL = 2, S_TMP0 = 3, S_TMP1 = 4, S_TMP2 = 5, S_TMP3 = 6, S_PRIOR_REF = 7, S_PRIOR_KB0 = 8, S_BATON = 9, S_ABORT = 10,
@@ -159,16 +165,46 @@ __device__ __forceinline__ void coop_st(MOSHII_GP(unsigned long long) p, double 
 __device__ __forceinline__ double coop_ld(MOSHII_GP(unsigned long long) p) {
     return bits_f64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ unsigned coop_begin(const Ctx& cx) { return (unsigned)cx.scal[S_COOP_SEQ] + 1u; }   // (uniform)
+__device__ __forceinline__ unsigned coop_begin(const Ctx& cx) { return (unsigned)__builtin_amdgcn_readfirstlane((int)cx.scal[S_COOP_SEQ]) + 1u; }   // (a scalar)
 __device__ __forceinline__ MOSHII_GP(unsigned long long) coop_slot(const CoopCtx& co, unsigned seq, int r) {
     return co.slots + ((size_t)(seq & 1u) * co.G + r) * co.slot_doubles;
 }
+// 16-byte write-through stores / L1-bypassing loads of a slot (buffer instructions with the sc1 bit: 8-byte agent-scope accesses run at
+// 0.54-0.70x the rate of 16-byte ones -- MI355X_MICROARCH.md); off16 = index of the 16-byte unit inside the slot
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned coop_u4 __attribute__((ext_vector_type(4)));
+struct CoopSlot { __amdgpu_buffer_rsrc_t rs; };
+__device__ __forceinline__ CoopSlot coop_slot16(const CoopCtx& co, unsigned seq, int r) {   // (seq, r: scalars)
+    CoopSlot cs;
+    cs.rs = __builtin_amdgcn_make_buffer_rsrc((void*)coop_slot(co, seq, r), 0, co.slot_doubles * 8, 0x00020000);
+    return cs;
+}
+__device__ __forceinline__ void coop_st16(const CoopSlot& cs, int off16, double a, double b) {
+    const unsigned long long ba = f64_bits(a), bb = f64_bits(b);
+    const coop_u4 v = {(unsigned)ba, (unsigned)(ba >> 32), (unsigned)bb, (unsigned)(bb >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, cs.rs, off16 * 16, 0, 16);   // (aux 16: sc1)
+}
+__device__ __forceinline__ void coop_ld16(const CoopSlot& cs, int off16, double& a, double& b) {
+    const coop_u4 v = __builtin_amdgcn_raw_buffer_load_b128(cs.rs, off16 * 16, 0, 16);
+    a = bits_f64(((unsigned long long)v[1] << 32) | v[0]);
+    b = bits_f64(((unsigned long long)v[3] << 32) | v[2]);
+}
+#else
+struct CoopSlot { MOSHII_GP(unsigned long long) p; };
+__device__ __forceinline__ CoopSlot coop_slot16(const CoopCtx& co, unsigned seq, int r) { CoopSlot cs; cs.p = coop_slot(co, seq, r); return cs; }
+__device__ __forceinline__ void coop_st16(const CoopSlot& cs, int off16, double a, double b) { coop_st(cs.p + 2 * (size_t)off16, a); coop_st(cs.p + 2 * (size_t)off16 + 1, b); }
+__device__ __forceinline__ void coop_ld16(const CoopSlot& cs, int off16, double& a, double& b) { a = coop_ld(cs.p + 2 * (size_t)off16); b = coop_ld(cs.p + 2 * (size_t)off16 + 1); }
+#endif
 // All threads call, after their payload stores: publish this rank's slot, wait for every rank's.  false: the group is broken.
 __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& cx, unsigned seq) {
     const int tid = threadIdx.x;
+    PROF_T(_tp0);
     MOSHII_DRAIN_VMEM();
     __syncthreads();
+    PROF_ACC(33, _tp0);
+    PROF_T(_tp1);
     if (tid == 0) __hip_atomic_store(co.flags + co.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TRACE_STAMP(co, seq, 1);
     if (tid < co.G && cx.scal[S_COOP_FAIL] == 0.0) {
         bool ok = true;
         unsigned spins = 0;
@@ -183,6 +219,8 @@ __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& 
         }
     }
     __syncthreads();
+    PROF_ACC(34, _tp1);
+    TRACE_STAMP(co, seq, 2);
     return cx.scal[S_COOP_FAIL] == 0.0;
 }
 // All threads call once they have read what they need of the other ranks' slots.
@@ -190,6 +228,43 @@ __device__ __forceinline__ void coop_end(const Ctx& cx, unsigned seq) {
     __syncthreads();
     if (threadIdx.x == 0) cx.scal[S_COOP_SEQ] = (double)seq;
     __syncthreads();
+}
+// A few numbers per rank (NS <= 4 doubles): 8-byte {tag = sequence number, half a double} granules in the last 32 words of the slot --
+// the data is its own flag (Guideline 16, form R2): no drain, no flag hop; a reader polls the granule until its tag is this exchange's.
+// All threads call; on return land[r * NS + k] (LDS) holds value k of rank r.  Follow with coop_end().
+template <int NS>
+__device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx& cx, unsigned seq, const double (&mine)[NS], double* land) {
+    const int tid = threadIdx.x;
+    const int goff = co.slot_doubles - 32;
+    if (tid < 2 * NS) {
+        double v = mine[0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) if ((tid >> 1) == k) v = mine[k];
+        const unsigned long long b = f64_bits(v);
+        const unsigned half = (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b;
+        __hip_atomic_store(coop_slot(co, seq, co.rank) + goff + tid, ((unsigned long long)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    TRACE_STAMP(co, seq, 1);
+    if (tid < co.G * 2 * NS && cx.scal[S_COOP_FAIL] == 0.0) {
+        const int r = tid / (2 * NS), k = tid - r * 2 * NS;
+        auto* g = coop_slot(co, seq, r) + goff + k;
+        unsigned long long x;
+        unsigned spins = 0;
+        bool ok = true;
+        while (((x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u)
+                if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+        }
+        if (!ok) {
+            __hip_atomic_store(co.flags + co.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cx.scal[S_COOP_FAIL] = 1.0;
+        }
+        reinterpret_cast<unsigned*>(land)[tid] = (unsigned)x;   // (little-endian halves: word 2 (r NS + j) + h of land)
+    }
+    __syncthreads();
+    TRACE_STAMP(co, seq, 2);
+    return cx.scal[S_COOP_FAIL] == 0.0;
 }
 
 // Rodrigues + SO(3) left Jacobian; same formulas and small-angle switch as oracle/stageii_oracle.py:rodrigues.
@@ -372,15 +447,18 @@ __device__ __forceinline__ void posedirs_partial(const Ctx& cx, const AttachDev&
 // lane (one L2 round trip per burst), so this divides its length, not just its width.
 __device__ __forceinline__ void posedirs_partial_range(const Ctx& cx, const AttachDev& at, const int* klist, int nk,
                                                        const double* base, double* dst, int a_lo, int a_hi) {
-    const int tid = threadIdx.x;
+    // wavefronts 1 .. 3 only: wavefront 0 walks the kinematic chain meanwhile (eval_forward, F3), and a share is small enough for 192 lanes
+    constexpr int LANES = MOSHII_TPB - 64;
+    if (threadIdx.x < 64) return;
+    const int tid = threadIdx.x - 64;
     const int Nvp = at.Nvp, Nvh = Nvp >> 1;
     const int p_lo = a_lo >> 1, np = ((a_hi + 1) >> 1) - p_lo;   // the vertex pairs that cover the range
     const int items = 3 * np;
     if (items <= 0) return;
-    const int jsh = (items * 4 <= MOSHII_TPB) ? 2 : ((items * 2 <= MOSHII_TPB) ? 1 : 0);   // log2 of the lanes per item
+    const int jsh = (items * 4 <= LANES) ? 2 : ((items * 2 <= LANES) ? 1 : 0);   // log2 of the lanes per item
     const int JG = 1 << jsh;
     constexpr int PB = 3;
-    for (int l0 = 0; l0 < items * JG; l0 += MOSHII_TPB) {   // (uniform trip count: the DPP moves below need whole wavefronts)
+    for (int l0 = 0; l0 < items * JG; l0 += LANES) {   // (uniform trip count: the DPP moves below need whole wavefronts)
         const int lin = l0 + tid;
         const bool live = lin < items * JG;
         const int it = min(lin, items * JG - 1) >> jsh, jg = lin & (JG - 1);
@@ -445,7 +523,9 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     // value -- is that of THIS point already (the evaluation that ended the previous frame was at it, with the same joint
     // lists); only what depends on the frame's data is redone: data residuals, velocity / finger / shape sums, the weights.
     // Same arithmetic on the same stored values: the result has the bits of a full evaluation.
-    if (!light) {
+    // (cooperative chains: a rank without markers -- the prior's -- needs none of the body's forward state)
+    const bool body = !COOP || m_hi > m_lo;
+    if (!light && body) {
     // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
     for (int d = tid; d < P; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, pose, d);
     if constexpr (XT) {
@@ -528,6 +608,24 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     for (int a = a_lo + tid; a < a_hi; a += MOSHII_TPB) {
         const double px = cx.vposed[a * 3 + 0], py = cx.vposed[a * 3 + 1], pz = cx.vposed[a * 3 + 2];
         double ax = 0.0, ay = 0.0, az = 0.0;
+        if (NW <= 4) {   // (uniform) the influences of the vertex in one round of loads (a rolled loop pays a memory round trip per influence)
+            int jj[4];
+            double wv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { jj[s] = gptr(at.wj)[a * NW + min(s, NW - 1)]; wv[s] = gptr(at.ww)[a * NW + min(s, NW - 1)]; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < NW) {   // (uniform)
+                    const int j = jj[s];
+                    const double w = wv[s];
+                    double ox, oy, oz;
+                    mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
+                    ax += w * (ox + cx.tw[j * 3 + 0]);
+                    ay += w * (oy + cx.tw[j * 3 + 1]);
+                    az += w * (oz + cx.tw[j * 3 + 2]);
+                }
+            }
+        } else
         for (int s = 0; s < NW; ++s) {
             const int j = gptr(at.wj)[a * NW + s];
             const double w = gptr(at.ww)[a * NW + s];
@@ -703,18 +801,19 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         PROF_LAP(3);
         // the ranks' data sums of squares, added in rank order by every rank; the prior's value (and argmin) from the rank that has it
         const unsigned seq = coop_begin(cx);
-        auto* mine = coop_slot(co, seq, co.rank);
-        if (tid == 0) { coop_st(mine, sd); coop_st(mine + 1, prior_ss); coop_st(mine + 2, (np_ > 0) ? cx.scal[S_KBEST] : 0.0); }
+        TRACE_STAMP(co, seq, 0);
+        const double mine[3] = {sd, prior_ss, (np_ > 0) ? cx.scal[S_KBEST] : 0.0};
+        double* land = cx.y;   // (free during an evaluation: the solve's reciprocal pivots / the assembly's diagonal terms are used up)
         sd = 0.0;
-        if (coop_publish_wait(co, cx, seq)) {
-            for (int r = 0; r < co.G; ++r) sd += coop_ld(coop_slot(co, seq, r));
+        if (coop_exchange_small<3>(co, cx, seq, mine, land)) {
+            for (int r = 0; r < co.G; ++r) sd += land[3 * r];
             if (np_ > 0) {
-                auto* ps = coop_slot(co, seq, co.prior_rank);
-                prior_ss = coop_ld(ps + 1);
-                const double kbv = coop_ld(ps + 2);
+                prior_ss = land[3 * co.prior_rank + 1];
+                const double kbv = land[3 * co.prior_rank + 2];
                 if (tid == 0 && co.rank != co.prior_rank) { cx.scal[S_PRIOR_SS] = prior_ss; cx.scal[S_KBEST] = kbv; }   // (what a light evaluation picks up)
             }
         }
+        TRACE_STAMP(co, seq, 3);
         coop_end(cx, seq);
         PROF_LAP(31);
     } else {
@@ -1334,6 +1433,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     PROF_BEGIN(); PROF_COUNT(21);
     JtJAcc<NBLK> acc;
     acc.zero();
+    const bool rows_here = !COOP || co.mhi > co.mlo;   // (a cooperative rank without markers builds no Jacobian rows)
+    if (rows_here) {
     for (int e = tid; e < 3 * Tm * LDJ; e += MOSHII_TPB) cx.Jrow[e] = 0.0;
     // Jacobian-only joint quantities at the current point (the forward state of the last evaluation is in LDS):
     // left-Jacobian columns a_c of each joint rotation and dR/dtheta_c = [a_c]x R
@@ -1364,6 +1465,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         if (k > 0) mat3_vec(&cx.Rw[md.parents[k] * 9], ax, ay, az, ox, oy, oz);
         cx.omega[k * 10 + c * 3 + 0] = ox; cx.omega[k * 10 + c * 3 + 1] = oy; cx.omega[k * 10 + c * 3 + 2] = oz;
     }
+    }   // (rows_here)
     if constexpr (XT) {
         if (nshp > 0) {
             // shape derivative of the joint transforms at the current point (the restated lbs_derivatives_wrt_shape):
@@ -1410,9 +1512,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             double Tr[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) Tr[e] = 0.0;
-            for (int s = 0; s < NW; ++s) {
-                const int j = gptr(at.wj)[av * NW + s];
-                const double w = gptr(at.ww)[av * NW + s];
+            auto influence = [&](int s, int j, double w) {
                 double ox, oy, oz;
                 mat3_vec(&cx.Rw[j * 9], px - cx.Jl[j * 3 + 0], py - cx.Jl[j * 3 + 1], pz - cx.Jl[j * 3 + 2], ox, oy, oz);
                 cx.xjs[tid * XS + s * 4 + 0] = ox + cx.tw[j * 3 + 0];
@@ -1422,6 +1522,16 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 cx.tjs[tid * TS + s] = j;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) Tr[e] += w * cx.Rw[j * 9 + e];
+            };
+            if (NW <= 4) {   // (uniform; see eval_forward F5: the influences in one round of loads)
+                int jj[4];
+                double wv[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { jj[s] = gptr(at.wj)[av * NW + min(s, NW - 1)]; wv[s] = gptr(at.ww)[av * NW + min(s, NW - 1)]; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (s < NW) influence(s, jj[s], wv[s]);
+            } else {
+                for (int s = 0; s < NW; ++s) influence(s, gptr(at.wj)[av * NW + s], gptr(at.ww)[av * NW + s]);
             }
 #pragma unroll
             for (int e = 0; e < 9; ++e) cx.Trot[tid * 10 + e] = Tr[e];
@@ -1614,13 +1724,19 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     const int np_ = op.nbody;
     double pblk[COOP ? AReg<NBLK>::NE : 1];   // cooperative variant: the prior's block of A in the owners' layout, as received from the prior rank
     if constexpr (COOP) {
-        constexpr int NT = JtJAcc<NBLK>::NT, NE = AReg<NBLK>::NE;
+        // Slot layout in 16-byte units, thread index fastest (coalesced 1 KiB rows): units [0, 2 NT) x 256 = this thread's accumulator
+        // registers (t, 2 h), (t, 2 h + 1); then (prior rank only) NUP units = its NE prior-block entries and its gradient entry.
+        constexpr int NT = JtJAcc<NBLK>::NT, NE = AReg<NBLK>::NE, NUA = 2 * NT, NUP = (NE + 2) / 2;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const unsigned seq = coop_begin(cx);
-        auto* mine = coop_slot(co, seq, co.rank);
+        TRACE_STAMP(co, seq, 0);
+        const CoopSlot mine = coop_slot16(co, seq, co.rank);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) coop_st(mine + (size_t)(4 * t + i) * MOSHII_TPB + tid, acc.c[t][i]);
+            if (4 * t + wv < NE) {   // (uniform: the tile slots beyond the last tile hold zeros nobody reads)
+                coop_st16(mine, (2 * t) * MOSHII_TPB + tid, acc.c[t][0], acc.c[t][1]);
+                coop_st16(mine, (2 * t + 1) * MOSHII_TPB + tid, acc.c[t][2], acc.c[t][3]);
+            }
         if (np_ > 0 && co.rank == co.prior_rank) {
             // the prior's share of the normal equations at this point (its argmin component kb was found by this rank's evaluation):
             // block w^2 (1/2 L L^T)[colprior, colprior] in the owners' layout, gradient -w^2 (1/2 L L^T)(x - mu) per column
@@ -1629,8 +1745,6 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             AReg<NBLK> P;
             P.zero();
             P.add_prior(w2, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
-#pragma unroll
-            for (int e = 0; e < NE; ++e) coop_st(mine + (size_t)(4 * NT + e) * MOSHII_TPB + tid, P.a[e]);
             double gq = 0.0;
             if (tid < n) {
                 const int pb = cx.colprior[tid];
@@ -1652,28 +1766,66 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                     gq = -(w2 * (s0 + s1));
                 }
             }
-            coop_st(mine + (size_t)(4 * NT + NE) * MOSHII_TPB + tid, gq);
+            double pe[2 * NUP];
+#pragma unroll
+            for (int e = 0; e < 2 * NUP; ++e) pe[e] = (e < NE) ? P.a[e] : ((e == NE) ? gq : 0.0);
+#pragma unroll
+            for (int u = 0; u < NUP; ++u) coop_st16(mine, (NUA + u) * MOSHII_TPB + tid, pe[2 * u], pe[2 * u + 1]);
         }
+        double own[4 * NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) own[4 * t + i] = acc.c[t][i];
         acc.zero();
 #pragma unroll
         for (int e = 0; e < NE; ++e) pblk[e] = 0.0;
         double gqp = 0.0;
         if (coop_publish_wait(co, cx, seq)) {
-            for (int r = 0; r < co.G; ++r) {   // (rank order: the same sums, bit for bit, on every rank)
-                auto* sr = coop_slot(co, seq, r);
+            // Ranks in batches of RB: every load of a batch is in flight before the first is added (a rank-by-rank loop pays the
+            // round trip to the memory side -- write-through lines are not kept in the L2 -- once per rank).  Rank order in the sums:
+            // the same bits on every rank; the own share comes from the registers (what the slot holds).
+            constexpr int RB = (NBLK <= 4) ? 6 : 4;
+            const bool has_prior = np_ > 0;
+            const CoopSlot sp = coop_slot16(co, seq, co.prior_rank);
+            double pv[2 * NUP];
+            if (has_prior) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc.c[t][i] += coop_ld(sr + (size_t)(4 * t + i) * MOSHII_TPB + tid);
+                for (int u = 0; u < NUP; ++u) coop_ld16(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
             }
-            if (np_ > 0) {
-                auto* sp = coop_slot(co, seq, co.prior_rank);
+            for (int r0 = 0; r0 < co.G; r0 += RB) {
+                double v[RB][4 * NT];
 #pragma unroll
-                for (int e = 0; e < NE; ++e) pblk[e] = coop_ld(sp + (size_t)(4 * NT + e) * MOSHII_TPB + tid);
-                gqp = coop_ld(sp + (size_t)(4 * NT + NE) * MOSHII_TPB + tid);
+                for (int u = 0; u < RB; ++u) {
+                    const CoopSlot sr = coop_slot16(co, seq, min(r0 + u, co.G - 1));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (4 * t + wv < NE) {
+                            coop_ld16(sr, (2 * t) * MOSHII_TPB + tid, v[u][4 * t], v[u][4 * t + 1]);
+                            coop_ld16(sr, (2 * t + 1) * MOSHII_TPB + tid, v[u][4 * t + 2], v[u][4 * t + 3]);
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (r0 + u < co.G) {   // (uniform)
+                        const bool mine_ = (r0 + u) == co.rank;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (4 * t + wv < NE) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc.c[t][i] += mine_ ? own[4 * t + i] : v[u][4 * t + i];
+                            }
+                    }
+                }
+            }
+            if (has_prior) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) pblk[e] = pv[e];
+                gqp = pv[NE];
             }
         }
         if (tid < n) cx.dgn[tid] = gqp;   // (free here: the Gauss-Newton step of the last iteration has been used up)
+        TRACE_STAMP(co, seq, 3);
         coop_end(cx, seq);
         PROF_LAP(32);
     }
@@ -2703,6 +2855,9 @@ extern "C" hipError_t moshii_launch_markers(int F, size_t lds_bytes, hipStream_t
 }
 
 #ifdef MOSHII_PROFILE
+extern "C" int moshii_prof_trace_read(long long* out /* [8][MOSHII_TRACE_N][4] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(moshii::g_trace), sizeof(long long) * 8 * MOSHII_TRACE_N * 4) == hipSuccess ? MOSHII_TRACE_N : -1;
+}
 extern "C" int moshii_prof_read(long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(moshii::g_prof), sizeof(long long) * 64) != hipSuccess) return -1;
     if (reset) { long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(moshii::g_prof), z, sizeof(z)) != hipSuccess) return -1; }

@@ -764,7 +764,8 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
         if (nblk != 4 && nblk != 8) { nblk = (nblk < 4) ? 4 : 8; }
         if (nmax + 1 > nblk * 16) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: too many unknowns");
         if (coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: at most 8 workgroups per chain");
-        cfg->coop_prior_frac = (npose > 0) ? 0.4 : 1.0;
+        // with a prior: from three ranks on the last one does nothing but the prior (measured: its evaluation is as long as the others' forward pass)
+        cfg->coop_prior_frac = (npose > 0) ? ((coop_g >= 3) ? 0.0 : 0.4) : 1.0;
         if (const char* e = getenv("MOSHII_COOP_PRIOR_FRAC")) cfg->coop_prior_frac = std::min(1.0, std::max(0.0, atof(e)));
         int mlo[MOSHII_COOP_MAXG + 1];
         coop_split(Mmax, coop_g, cfg->coop_prior_frac, mlo);
@@ -777,7 +778,8 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
             ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
         }
         const int NE = nblk * (nblk + 1) / 2, NT = (NE + 3) / 4;
-        cfg->coop_slot_doubles = std::max((4 * NT + NE + 1) * MOSHII_TPB, 3 * Mmax + 2);
+        // slot: accumulators (2 NT 16-byte units per thread), prior block + gradient ((NE + 2) / 2 units), or 3 M marker coordinates; + 32 granule words
+        cfg->coop_slot_doubles = std::max((4 * NT + 2 * ((NE + 2) / 2)) * MOSHII_TPB, 3 * Mmax + 2) + 32;
         cfg->coop_prior_rank = coop_g - 1;
     } else
     if (const char* e = getenv("MOSHII_TM")) {
