@@ -124,8 +124,9 @@ def main():
     ap.add_argument('--frames', type=int, default=4000)
     ap.add_argument('--markers', type=int, default=53)
     ap.add_argument('--mode', choices=('chunked', 'sequential'), default='chunked')
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
-                    help='weak: every rank its own copies of the workload (replicas); strong: the fixed 32-sequence job is the headline')
+    ap.add_argument('--scaling', choices=('auto', 'weak', 'strong'), default='auto',
+                    help='strong: the fixed many-sequence job (sequences dealt to the ranks) is the headline; weak: every rank its own copies of '
+                         'the config[1] sequence (replicas); auto = config[1] on one GPU, strong on several')
     ap.add_argument('--seeds', default='1000,123,71,5,2024,7', help='the timed steps cycle through sequences generated from these seeds')
     ap.add_argument('--chunks', type=int, default=0, help='chunks per sequence (0 = one per CU)')
     ap.add_argument('--chunk-warmup', type=int, default=32)
@@ -138,7 +139,7 @@ def main():
     ap.add_argument('--no-stagei', action='store_true', help='skip the Stage-I leg')
     ap.add_argument('--no-sequential', action='store_true', help='skip the one-workgroup sequential reference run')
     ap.add_argument('--no-strong', action='store_true', help='skip the fixed-job (strong scaling) legs')
-    ap.add_argument('--strong-sequences', type=int, default=32)
+    ap.add_argument('--strong-sequences', type=int, default=256, help='distinct captures in the fixed many-sequence job (256 x 4000 frames: ~2 s on one GPU)')
     ap.add_argument('--long-frames', type=int, default=50000)
     ap.add_argument('--no-config3', action='store_true', help='skip the BASELINE config 3 leg (32 x 4000 SMPL-X frames, 194 unknowns: ~30 s)')
     ap.add_argument('--config3-sequences', type=int, default=32)
@@ -223,27 +224,39 @@ def main():
 
     # ---- the fixed many-sequence job (strong scaling; also the headline with --scaling strong)
     def strong_many():
-        """32 sequences dealt to the ranks; a rank solves its share in ONE moshii_sequence_solve call.  The sequences are 32
-        DISTINCT captures of the seed-1000 subject (sequences of one subject share the model / prior handles of a call):
-        capture i is motion seed 5000 + i through workload.make_capture -- the job waits for its hardest sequence, as a real
-        batch does.  Returns (frames solved here, seconds here, sequences here)."""
-        share = strong_job_shares(args.strong_sequences, F, world)[rank]
-        copies = [workload.DeviceSequence(workload.make_capture(job, solver, 5000 + i), solver, dev) for i in share]
+        """The fixed many-sequence job: --strong-sequences DISTINCT captures of the seed-1000 subject (sequences of one subject share the
+        model / prior handles of a call; capture i is motion seed 5000 + i through workload.make_capture -- the job waits for its hardest
+        sequence, as a real batch does), dealt to the ranks by longest-processing-time; a rank solves its share in ONE
+        moshii_sequence_solve call.  On several GPUs rank 0 first solves the WHOLE job alone (the other ranks wait), so that the line
+        carries the one-GPU time of the same job on the same box.  Returns (frames solved here, seconds here, sequences here,
+        one-GPU seconds or None, one-GPU frames)."""
+        shares = strong_job_shares(args.strong_sequences, F, world)
+        share = shares[rank]
         stream = torch.cuda.current_stream().cuda_stream
-        n_local = len(copies)
-        per_seq_chunks = max(8, 256 // max(n_local, 1))      # keep every CU carrying a chain when a rank has few sequences
-        t_here, n_here = 0.0, 0
-        if n_local:
+
+        def solve(idx):
+            copies = [workload.DeviceSequence(workload.make_capture(job, solver, 5000 + i), solver, dev) for i in idx]
+            per_seq_chunks = max(8, 256 // max(len(copies), 1))      # keep every CU carrying a chain when a rank has few sequences
             workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)   # untimed first pass (allocations inside the library)
-        barrier()
-        if n_local:
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)
             torch.cuda.synchronize()
-            t_here = time.perf_counter() - t0
-            n_here = sum(int((c.results()['status'] != 1).sum()) for c in copies)
+            dt = time.perf_counter() - t0
+            return dt, sum(int((c.results()['status'] != 1).sum()) for c in copies)
+
+        t_one, n_one = None, 0
+        if world > 1:
+            if rank == 0:
+                t_one, n_one = solve(list(range(args.strong_sequences)))
+            barrier()
+        n_local = len(share)
+        t_here, n_here = 0.0, 0
         barrier()
-        return n_here, t_here, n_local
+        if n_local:
+            t_here, n_here = solve(share)
+        barrier()
+        return n_here, t_here, n_local, t_one, n_one
 
     def strong_long():
         """One long sequence over the ranks by frame ranges (host buffers: the boundary rows travel through the process group)."""
@@ -351,14 +364,24 @@ def main():
     if not args.no_strong and args.mode == 'chunked':
         strong = {}
         try:
-            n_here, t_here, n_local = strong_many()
+            n_here, t_here, n_local, t_one, n_one = strong_many()
             t_job = allmax(t_here)
             n_job = allsum(n_here)
+            if dist is not None:    # every rank's own seconds: who waited for whom
+                tl = [None] * world
+                dist.all_gather_object(tl, float(t_here))
+            else:
+                tl = [float(t_here)]
             strong['many_sequences'] = {
                 'workload': f'{args.strong_sequences} DISTINCT {F}-frame SMPL-H captures of the seed-{seeds[0]} subject (BASELINE config 3 shape with body markers; motion seeds 5000..), dealt to the ranks by '
                             'longest-processing-time (parallel.partition_units); no collective on the data path',
                 'frames': int(n_job), 'frames_per_s': round(n_job / t_job, 1), 'ms': round(t_job * 1e3, 2),
-                'sequences_on_rank0': n_local, 'rank0_idle_ms': round((t_job - t_here) * 1e3, 2)}
+                'sequences_on_rank0': n_local, 'rank0_idle_ms': round((t_job - t_here) * 1e3, 2),
+                'rank_ms': [round(x * 1e3, 2) for x in tl], 'rank_idle_ms': [round((t_job - x) * 1e3, 2) for x in tl]}
+            if t_one:
+                strong['many_sequences']['one_gpu_same_job'] = {'frames_per_s': round(n_one / t_one, 1), 'ms': round(t_one * 1e3, 2),
+                                                                'speedup': round((n_job / t_job) / (n_one / t_one), 3),
+                                                                'note': 'rank 0 alone on the whole job, same box, before the sharded run'}
         except Exception as e:
             strong['many_sequences'] = {'error': repr(e)}
         try:
@@ -376,11 +399,12 @@ def main():
         except Exception as e:
             strong['long_sequence'] = {'error': repr(e)}
         result['strong'] = strong
-        if args.scaling == 'strong' and 'frames_per_s' in strong.get('many_sequences', {}):
+        if (args.scaling == 'strong' or (args.scaling == 'auto' and world > 1)) and 'frames_per_s' in strong.get('many_sequences', {}):
             sj = strong['many_sequences']
             result.update(value=sj['frames_per_s'], scaling='strong', ms_per_step=sj['ms'], steps=1, warmup=1,
                           value_is='job frames / max-over-ranks seconds of the fixed many-sequence job')
-            result['config'] = {'workload': sj['workload'], 'mode': args.mode, 'markers': M, 'parallelism': f'{world} rank(s), sequences sharded'}
+            result['config'] = {'workload': sj['workload'], 'mode': args.mode, 'markers': M,
+                                'parallelism': f'{world} rank(s) = {world} GPU(s), one process each; sequences sharded by longest-processing-time, no data-path collective'}
             result['replicas'] = {'value': round(value, 2), 'scaling': 'weak', 'seeds': per_seed}
 
     if rank == 0:

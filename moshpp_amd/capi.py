@@ -370,7 +370,7 @@ def plan_chunks(F, num_chunks, warmup, cap=1 << 20):
     return starts[:c].copy(), launch[:c].copy()
 
 
-def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, warmup=32, verify_tol=1e-11):
+def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, warmup=32, verify_tol=1e-11, coop=0):
     """moshii_sequence_solve on host buffers.  seqs: list of dict(attach, obs[F,M,3], vis[F,M], init_pose=None,
     init_trans=None, init_pose_prev=None) -- with init_* the sequence continues a chain from that state instead of running
     the first-frame schedule.  Returns (list of per-sequence output dicts as chain_solve_host, report dict)."""
@@ -402,7 +402,7 @@ def sequence_solve_host(model: Model, prior, opts_tuple, seqs, num_chunks=0, war
     co = ChunkOpts(int(num_chunks), int(warmup), float(verify_tol))
     rep = ChunkReport()
     check(lib.moshii_sequence_solve(model.handle, prior.handle if prior is not None else None, C.byref(opts), n, descs,
-                                    C.byref(co), BUFFERS_HOST, None, C.byref(rep)))
+                                    C.byref(co), BUFFERS_HOST | coop_group(coop), None, C.byref(rep)))
     del keep
     report = {k: getattr(rep, k) for k, _ in ChunkReport._fields_}
     return outs, report

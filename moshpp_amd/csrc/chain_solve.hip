@@ -171,7 +171,7 @@ __device__ __forceinline__ MOSHII_GP(unsigned long long) coop_slot(const CoopCtx
 }
 // 16-byte write-through stores / L1-bypassing loads of a slot (buffer instructions with the sc1 bit: 8-byte agent-scope accesses run at
 // 0.54-0.70x the rate of 16-byte ones -- MI355X_MICROARCH.md); off16 = index of the 16-byte unit inside the slot
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOSHII_COOP_NO_BUF)
 typedef unsigned coop_u4 __attribute__((ext_vector_type(4)));
 struct CoopSlot { __amdgpu_buffer_rsrc_t rs; };
 __device__ __forceinline__ CoopSlot coop_slot16(const CoopCtx& co, unsigned seq, int r) {   // (seq, r: scalars)
@@ -457,7 +457,10 @@ __device__ __forceinline__ void posedirs_partial_range(const Ctx& cx, const Atta
     if (items <= 0) return;
     const int jsh = (items * 4 <= LANES) ? 2 : ((items * 2 <= LANES) ? 1 : 0);   // log2 of the lanes per item
     const int JG = 1 << jsh;
-    constexpr int PB = 3;
+#ifndef MOSHII_COOP_PB
+#define MOSHII_COOP_PB 3
+#endif
+    constexpr int PB = MOSHII_COOP_PB;   // joints per burst: 9 PB 16-byte loads in flight per lane (5 measured slower than 3: 181 vs 177.5 us per frame)
     for (int l0 = 0; l0 < items * JG; l0 += LANES) {   // (uniform trip count: the DPP moves below need whole wavefronts)
         const int lin = l0 + tid;
         const bool live = lin < items * JG;
@@ -527,7 +530,10 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     const bool body = !COOP || m_hi > m_lo;
     if (!light && body) {
     // F1: fullpose = [pose[:bd], hands_mean + pose_hand . comps]
-    for (int d = tid; d < P; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, pose, d);
+    // (cooperative chains: while no hand coefficient is free in the running solve -- S_TMP2, set with the column tables -- the hand part
+    //  stands as run_phase computed it with the fixed joints' correctives: its PCA sums are a latency chain of their own)
+    const int d_hi = (COOP && hd > 0 && cx.scal[S_TMP2] == 0.0) ? min(P, bd) : P;
+    for (int d = tid; d < d_hi; d += MOSHII_TPB) cx.fullpose[d] = fullpose_entry(md, pose, d);
     if constexpr (XT) {
         if (op.nshape > 0) {
             const int E = op.nshape, Nvp = at.Nvp;
@@ -574,7 +580,61 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
     // F3 (wave 0 only): kinematic chain G_j = G_par(j) . [R_j | J_j - J_par(j)], one tree level per step.  All K <= 64
     // joints live in one wavefront, whose LDS operations complete in order, so levels need no workgroup barrier;
     // waves 1..3 are already streaming posedirs (which needs only the local rotations) meanwhile.
-    if (tid < 64) {
+#ifdef MOSHII_COOP_LEVEL_CHAIN
+    constexpr bool JUMP = false;
+#else
+    constexpr bool JUMP = COOP;
+#endif
+    if (JUMP && tid < 64) {
+        // Cooperative chains: the same products by pointer jumping -- every joint holds the composition of the local transforms from
+        // itself up to (not including) its pointer `anc`, and in every step composes with what `anc` holds and takes over anc's pointer:
+        // ceil(log2(depth + 1)) steps of one LDS round trip instead of one per tree level (the chain is what the other three wavefronts'
+        // share of the pose correctives waits for here; the products are associated differently from the level-order walk: round-off).
+        const bool act = tid < K;
+        double R[9], t[3] = {0.0, 0.0, 0.0};
+        int anc = -1;
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) R[e] = cx.Rloc[tid * 9 + e];
+            if (tid > 0) anc = md.parents[tid];
+            const int pj = max(anc, 0);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) t[e] = (tid > 0) ? cx.Jl[tid * 3 + e] - cx.Jl[pj * 3 + e] : cx.Jl[e];
+        }
+        for (int span = 1; span <= md.maxdepth; span *= 2) {   // (uniform)
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) cx.Rw[tid * 9 + e] = R[e];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) cx.tw[tid * 3 + e] = t[e];
+                cx.jointslot[tid] = anc;   // (the table builder's scratch: free between table builds)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (act && anc >= 0) {
+                double Ra[9], Ro[9], ox, oy, oz;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) Ra[e] = cx.Rw[anc * 9 + e];
+                const double tax = cx.tw[anc * 3 + 0], tay = cx.tw[anc * 3 + 1], taz = cx.tw[anc * 3 + 2];
+                const int aa = cx.jointslot[anc];
+                mat3_mul(Ra, R, Ro);
+                mat3_vec(Ra, t[0], t[1], t[2], ox, oy, oz);
+#pragma unroll
+                for (int e = 0; e < 9; ++e) R[e] = Ro[e];
+                t[0] = ox + tax; t[1] = oy + tay; t[2] = oz + taz;
+                anc = aa;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) cx.Rw[tid * 9 + e] = R[e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) cx.tw[tid * 3 + e] = t[e];
+        }
+    }
+    if (!JUMP && tid < 64) {
         const int lvl_of = (tid < K) ? md.depth[tid] : -1;
         const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
         for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
@@ -1785,11 +1845,13 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             // Ranks in batches of RB: every load of a batch is in flight before the first is added (a rank-by-rank loop pays the
             // round trip to the memory side -- write-through lines are not kept in the L2 -- once per rank).  Rank order in the sums:
             // the same bits on every rank; the own share comes from the registers (what the slot holds).
-            constexpr int RB = (NBLK <= 4) ? 6 : 4;
+            // (at most ~48 loads in flight per thread: with more than the 63 the vector-memory counter can tell apart -- 8 blocks, four ranks per
+            //  batch: 72 + 19 -- the device build returned wrong sums, in the emulation as on paper nothing is wrong with it)
+            constexpr int RB = (48 / (2 * NT) < 1) ? 1 : ((48 / (2 * NT) > 6) ? 6 : 48 / (2 * NT));
             const bool has_prior = np_ > 0;
             const CoopSlot sp = coop_slot16(co, seq, co.prior_rank);
             double pv[2 * NUP];
-            if (has_prior) {
+            if (has_prior && NUP + RB * NUA <= 48) {   // (the prior rank's units ride with the first batch where the counter allows)
 #pragma unroll
                 for (int u = 0; u < NUP; ++u) coop_ld16(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
             }
@@ -1819,6 +1881,10 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 }
             }
             if (has_prior) {
+                if (NUP + RB * NUA > 48) {
+#pragma unroll
+                    for (int u = 0; u < NUP; ++u) coop_ld16(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
+                }
 #pragma unroll
                 for (int e = 0; e < NE; ++e) pblk[e] = pv[e];
                 gqp = pv[NE];
@@ -2165,6 +2231,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         if (skip_eval) { last = carried; skip_eval = false; }
         else { PROF_T(_te); last = eval_forward_fn<XT, COOP>(visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst, light); PROF_ACC(15, _te); }
         if constexpr (COOP) { if (cx.scal[S_COOP_FAIL] != 0.0) break; }   // the group is broken: unwind (the host reports the launch as failed)
+        if (!(last.total == last.total)) { fail = 1; break; }   // a NaN objective: no comparison below would ever end the loop
         light = 0;
         at_pose = true;   // cleared below when a trial point is rejected
         fwd_set = set_id;
@@ -2406,6 +2473,76 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
 
     for (int t = 0; t <= F; ++t) {
         PROF_T(_tf);
+        if constexpr (COOP) {
+            // A cooperative REPAIR chain of a chunked solve (moshii_sequence_solve's host rounds).  Everything that depends on memory other
+            // chains write -- the stop request of an upstream sweep, the negotiation at a chunk boundary, whether the last two frames
+            // reproduced the stored rows -- is looked at by rank 0 alone, with the plain chain's code, and its verdict for this frame goes
+            // to the other ranks in one small exchange: ranks that read such words for themselves could part ways.
+            if (chp->baton != nullptr || chp->nb > 0 || chp->rejoin_tol > 0.0) {   // (descriptor constants: the same on every rank)
+                bool halt = false;
+                if (lead) {
+                    const int S = 2 * NP + 5;
+                    if (rejoin_run >= 2 && t < F) {   // the previous frame's verdict: pose and pose_prev both match, the stored rows (and final state) stand
+                        if (tid == 0 && chp->frames_done) *chp->frames_done = t;
+                        halt = true;
+                    }
+                    if (!halt && bi_next < chp->nb && t == chp->bnd[bi_next] - chp->bnd_off) {   // a chunk boundary (see the plain chain below)
+                        double* s1 = chp->run_final + (size_t)bi_next * S;
+                        for (int i = tid; i < NP; i += MOSHII_TPB) { s1[i] = cx.pose[i]; s1[NP + i] = cx.pose_prev[i]; }
+                        if (tid < 3) s1[2 * NP + tid] = cx.trans[tid];
+                        if (tid == 3) s1[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+                        if (tid == 4) s1[2 * NP + 4] = first ? 1.0 : 0.0;
+                        if (chp->baton != nullptr) {
+                            if (tid == 0) {
+                                int* st = chp->baton + 2 * (chp->chunk0 + 1 + bi_next);
+                                double go = 1.0;
+                                if (__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+                                    __hip_atomic_store(st + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                    int spins = 0;
+                                    while (__hip_atomic_load(st, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 2) {
+                                        __builtin_amdgcn_s_sleep(64);
+                                        if (++spins > 20000) { go = 0.0; break; }
+                                    }
+                                }
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                cx.scal[S_BATON] = go;
+                            }
+                            __syncthreads();
+                            if (cx.scal[S_BATON] == 0.0) { if (tid == 0 && chp->frames_done) *chp->frames_done = t; halt = true; }
+                            __syncthreads();
+                        }
+                        if (!halt) {
+                            double* s2 = chp->run_entry + (size_t)(bi_next + 1) * S;
+                            for (int i = tid; i < NP; i += MOSHII_TPB) { s2[i] = cx.pose[i]; s2[NP + i] = cx.pose_prev[i]; }
+                            if (tid < 3) s2[2 * NP + tid] = cx.trans[tid];
+                            if (tid == 3) s2[2 * NP + 3] = has_prev ? 1.0 : 0.0;
+                            if (tid == 4) s2[2 * NP + 4] = first ? 1.0 : 0.0;
+                            ++bi_next;
+                        }
+                    }
+                    if (!halt && chp->baton != nullptr && t < F) {   // has an upstream chain of this round asked for this chain's territory?
+                        if (tid == 0) cx.scal[S_ABORT] = (double)__hip_atomic_load(&chp->baton[2 * chp->chunk0 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __syncthreads();
+                        if (cx.scal[S_ABORT] != 0.0) {
+                            if (tid == 0) {
+                                chp->run_entry[(size_t)bi_next * S + 2 * NP + 3] = -1.0;
+                                int* mark = chp->abort_at + chp->chunk0 + bi_next;
+                                if (*mark < chp->bnd_off + t) *mark = chp->bnd_off + t;
+                                if (chp->frames_done) *chp->frames_done = -t - 1;
+                            }
+                            halt = true;
+                        }
+                        __syncthreads();
+                    }
+                }
+                const unsigned seq = coop_begin(cx);
+                const double mine[1] = {halt ? 1.0 : 0.0};
+                const bool okx = coop_exchange_small<1>(co, cx, seq, mine, cx.y);
+                const double verdict = okx ? cx.y[0] : 1.0;   // (rank 0's word)
+                coop_end(cx, seq);
+                if (verdict != 0.0) break;
+            }
+        }
         // chunk hand-off states: moshii_sequence_solve checks a chunk's entry state against its predecessor's final one
         for (int which = 0; which < 2; ++which) {
             double* so = (which == 0) ? ((t == skip) ? chp->entry_state : nullptr) : ((t == F) ? chp->final_state : nullptr);
@@ -2689,7 +2826,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         }
         first = false;
         PROF_T(_tr);
-        if (!COOP && record && sweeping && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
+        if (lead && record && sweeping && chp->rejoin_tol > 0.0 && chp->pose != nullptr && chp->trans != nullptr) {
             // repair chains: has this chain re-joined the trajectory already stored for this chunk?
             double dv = 0.0;
             const double* po = chp->pose + (size_t)t * NP;
@@ -2723,17 +2860,36 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             }
         }
         __syncthreads();
-        if (!COOP && rejoin_run > 0 && chp->abort_at != nullptr) {
+        if (lead && rejoin_run > 0 && chp->abort_at != nullptr) {
             // rows a stopped chain left in this chunk (ChainDev::abort_at) do not count: matching THEM says nothing about the
             // older rows behind them -- only frames at or past the mark do
             const int mark = __hip_atomic_load(chp->abort_at + chp->chunk0 + bi_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (chp->bnd_off + t < mark) rejoin_run = 0;
         }
-        if (rejoin_run >= 2 && t + 1 < F) { if (tid == 0 && chp->frames_done) *chp->frames_done = t + 1; break; }   // pose and pose_prev both match: the stored rows (and final state) stand
+        // (cooperative chains: rank 0's verdict reaches the others at the top of the next frame)
+        if (!COOP && rejoin_run >= 2 && t + 1 < F) { if (tid == 0 && chp->frames_done) *chp->frames_done = t + 1; break; }   // pose and pose_prev both match: the stored rows (and final state) stand
         if (t + 1 == F && tid == 0 && lead && chp->frames_done) *chp->frames_done = F;
         PROF_ACC(19, _tr);
     }
-    if (!COOP && chp->baton != nullptr) {   // this chain is out of the way: everything it stored is visible before the flag is
+    if constexpr (COOP) {
+        // a group that broke up inside a chunked solve: the rows of the chunk it stopped in change hands in mid-chunk, where no hand-off
+        // check looks -- spoil that chunk's entry state so that the next verification re-solves it (as a stopped plain chain does)
+        if (cx.scal[S_COOP_FAIL] != 0.0 && lead && tid == 0 && chp->run_entry != nullptr) {
+            const int S = 2 * NP + 5;
+            chp->run_entry[(size_t)bi_next * S + 2 * NP + 3] = -1.0;
+            if (chp->abort_at != nullptr) chp->abort_at[chp->chunk0 + bi_next] = 0x7fffffff;   // (nothing behind the break counts as re-joined)
+        }
+        // (a cooperative repair chain: EVERY rank's rows -- the simulated markers are written rank by rank -- are out before rank 0 says so)
+        if (chp->baton != nullptr && cx.scal[S_COOP_FAIL] == 0.0) {
+            __syncthreads();
+            if (tid == 0) __threadfence();
+            const unsigned seq = coop_begin(cx);
+            const double mine[1] = {0.0};
+            coop_exchange_small<1>(co, cx, seq, mine, cx.y);
+            coop_end(cx, seq);
+        }
+    }
+    if (lead && chp->baton != nullptr) {   // this chain is out of the way: everything it stored is visible before the flag is
         __syncthreads();
         if (tid == 0) {
             __threadfence();
@@ -2764,6 +2920,8 @@ MOSHII_INSTANTIATE(10, true, false)
 MOSHII_INSTANTIATE(13, true, false)
 // cooperative chains (G workgroups per chain): the body solve and the solve with fingers
 MOSHII_INSTANTIATE(4, false, true)
+MOSHII_INSTANTIATE(5, false, true)
+MOSHII_INSTANTIATE(7, false, true)
 MOSHII_INSTANTIATE(8, false, true)
 #undef MOSHII_INSTANTIATE
 #endif
@@ -2814,6 +2972,8 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
         if (xt) return hipErrorInvalidValue;
         switch (nblk) {
             case 4: kern = k_chain_solve<4, 1, false, true>; break;
+            case 5: kern = k_chain_solve<5, 1, false, true>; break;
+            case 7: kern = k_chain_solve<7, 1, false, true>; break;
             case 8: kern = k_chain_solve<8, 1, false, true>; break;
             default: return hipErrorInvalidValue;
         }

@@ -691,6 +691,27 @@ struct LaunchCfg {
 // Validates the options, picks the J^T J register tiling and the LDS layout (marker-tile size Tm as large as the
 // per-workgroup LDS budget allows) and uploads the id lists.  `extra_bytes` of the model's control scratch are
 // reserved after the id lists; their device/host offsets come back through ctl_off.
+// The cooperative-chain request of a call: MOSHII_COOP_GROUP(g) in `flags` (0 = no word: the environment variable `env`, else the library's
+// choice; 1 = plain chains; 2 .. 8 = that many workgroups per chain).  Returns -1 (library's choice), 0 (plain), g, or -2 (out of range).
+int coop_request(uint32_t flags, const char* env) {
+    int g = (int)((flags >> 8) & 0xffu);
+    if (g == 0) {
+        const char* e = getenv(env);
+        if (!e) {
+#ifdef MOSHII_EMULATION   // (the CPU emulation runs workgroups one after another unless told otherwise: a group would wait for itself)
+            return 0;
+#else
+            return -1;
+#endif
+        }
+        g = atoi(e);
+        if (g == 0) return 0;
+    }
+    if (g == 1) return 0;
+    if (g < 0 || g > MOSHII_COOP_MAXG) return -2;
+    return g;
+}
+
 // Cooperative chains: the markers [mlo[r], mlo[r + 1]) of rank r.  The ranks 0 .. G-2 get equal shares, the last rank -- which also
 // evaluates the prior for the group -- `prior_frac` of one (MOSHII_COOP_PRIOR_FRAC; 1 without a prior).
 void coop_split(int M, int G, double prior_frac, int* mlo) {
@@ -759,9 +780,18 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     // tiles of 27 / 26 cost 3 + 3), weighted by what a round and a tile's fixed work cost (about 3 : 4).
     int Tm = std::min(40, std::max(2, Mmax));
     ChainLayout ly = make_layout(m, Mmax, Nvmax, NWmax, npose, G, nmax, nkfmax, Tm, nblk, nhj, nshape);
+    // coop_g: -1 = the library's choice, 0 = plain chains, 2 .. 8 = that many workgroups per chain.  The choice: one rank per round of
+    // (marker, joint) Jacobian items (256 threads build 256 of them at a time) plus one for the prior, when every workgroup of the
+    // launch can be resident at once (n_workgroups chains x g <= CUs) and the solve is a plain body / finger solve.
+    if (coop_g == -1) {
+        const int item_ranks = (Mmax * nkfmax + MOSHII_TPB - 1) / MOSHII_TPB;
+        coop_g = std::min(MOSHII_COOP_MAXG, item_ranks + (npose > 0 ? 1 : 0));
+        if (coop_g < 3 || nblk < 4) coop_g = 0;   // (few items, or a solve so small -- MANO -- that the exchanges cost what the split saves: measured)
+    }
+    if (coop_g > 0 && (xt || nmax + 1 > 8 * 16 || (long long)coop_g * std::max(n_workgroups, 1) > n_cu)) coop_g = 0;   // (not built / not all resident: plain chains)
     if (coop_g > 0) {   // cooperative chains: a rank builds the rows of its own markers only -- one tile of its largest possible share
         if (xt) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: the extended variant is not built");
-        if (nblk != 4 && nblk != 8) { nblk = (nblk < 4) ? 4 : 8; }
+        if (nblk < 4) nblk = 4;   // (cooperative instantiations: 4, 5, 7, 8 register blocks)
         if (nmax + 1 > nblk * 16) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: too many unknowns");
         if (coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: at most 8 workgroups per chain");
         // with a prior: from three ranks on the last one does nothing but the prior (measured: its evaluation is as long as the others' forward pass)
@@ -960,19 +990,13 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     const int E = o->n_shape > 0 ? o->n_shape : 0;
     const size_t extra = sizeof(ChainDev) * n_chains + sizeof(double) * (size_t)n_chains * (2 * NP + 4 + E + 2) + 256;
     // cooperative chains (MOSHII_COOP_GROUP(g) in `flags`, or MOSHII_COOP=g): g workgroups per chain, all of them resident at once
-    int coop_g = (int)((flags >> 8) & 0xffu);
-    if (coop_g == 0) if (const char* e = getenv("MOSHII_COOP")) coop_g = atoi(e);
-    if (coop_g < 0 || coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: group size out of range");
-    if (coop_g > 0) {
-        int n_cu = 256;
-        { int d = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d); if (n_cu < 1) n_cu = 256; }
-        const bool fits = (long long)coop_g * n_chains <= n_cu;   // (the blocks beyond the last chain return at once)
-        if (!fits || o->n_shape > 0 || o->n_face > 0) coop_g = 0;   // (more workgroups than CUs would not all be resident: plain chains)
-    }
+    int coop_req = coop_request(flags, "MOSHII_COOP");
+    if (coop_req < -1) return fail(MOSHII_ERR_ARG, "cooperative chains: group size out of range");
     LaunchCfg cfg;
     size_t ctl = 0;
-    int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, n_chains, stream, extra, &cfg, &ctl, coop_g);
+    int rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, n_chains, stream, extra, &cfg, &ctl, coop_req);
     if (rc) return rc;
+    const int coop_g = cfg.coop_g;   // (0: plain chains -- asked for, or the group does not fit the chip / the solve is an extended one)
     size_t coop_bytes_per_chain = 0;
     if (coop_g > 0) {
         coop_bytes_per_chain = ((size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(coop_g + 1) * sizeof(unsigned) + 255) & ~size_t(255);
@@ -1041,8 +1065,15 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
             HIP_TRY(hipMemcpyAsync(&ab[c], m->coopbuf.ptr + coop_bytes_per_chain * c + (size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + coop_g * sizeof(unsigned),
                                    sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int c = 0; c < n_chains; ++c)
-            if (ab[c] != 0u) return fail(MOSHII_ERR_HIP, "cooperative chain: a workgroup of the group did not show up within the wait limit (not all resident?); rerun without MOSHII_COOP");
+        bool broken = false;
+        for (int c = 0; c < n_chains; ++c) broken |= ab[c] != 0u;
+        if (broken) {
+            // a workgroup of a group did not show up within the wait limit (the chip is shared with another process?): the same solve as
+            // plain chains, over whatever the broken groups left in the rows
+            if (getenv("MOSHII_TRACE_REPAIR")) fprintf(stderr, "[moshii] a cooperative group broke up: re-running the call with plain chains\n");
+            if (!dev) for (int c = 0; c < n_chains; ++c) { st[c].release(); if (d_shape[c]) hipFree(d_shape[c]); }
+            return moshii_chain_solve(m, prior, o, n_chains, chains, (flags & ~0xff00u) | (1u << 8), stream_);
+        }
     }
     if (!dev) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1135,8 +1166,21 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     int* d_fuse_count = d_fuse + 3 * NC;
     // Pass-1 chains check their own right-hand hand-off and carry on as the repair chain of the next chunk when it misses
     // (ChainDev::fuse_F): possible when every chunk has a CU of its own for the whole launch, so that the flags they wait on are set.
-    const bool fuse = rejoin && NC <= n_cu && getenv("MOSHII_NO_FUSE") == nullptr;
+    // Cooperative repair chains (MOSHII_COOP_GROUP(g) in `flags`, or MOSHII_COOP_REPAIR=g): the sweeps that bound a chunked solve run with g
+    // workgroups each (csrc/moshii_dev.h: CoopDev), launched by the host's rounds -- a pass-1 chain cannot recruit CUs, so with them the
+    // chains do not carry on inside the first launch.
+    int coop_rep = coop_request(flags, "MOSHII_COOP_REPAIR");
+    if (coop_rep < -1) return fail(MOSHII_ERR_ARG, "cooperative chains: group size out of range");
+    if (coop_rep == -1) {   // the library's choice: as moshii_chain_solve picks it for one chain (prepare_launch)
+        const int item_ranks = (Mmax * cfg.ly.nkfmax + MOSHII_TPB - 1) / MOSHII_TPB;
+        coop_rep = std::min(MOSHII_COOP_MAXG, item_ranks + ((prior && o->n_body > 0) ? 1 : 0));
+        if (coop_rep < 3 || cfg.ly.nmax + 1 > 8 * 16 || cfg.nblk < 4) coop_rep = 0;
+    }
+    if (coop_rep < 2 || E > 0 || o->n_face > 0 || !rejoin) coop_rep = 0;
+    const bool fuse = rejoin && NC <= n_cu && getenv("MOSHII_NO_FUSE") == nullptr && coop_rep == 0;
     const bool trace = getenv("MOSHII_TRACE_REPAIR") != nullptr;
+    std::vector<LaunchCfg> coop_cfgs(MOSHII_COOP_MAXG + 1);   // per group size, prepared when first used
+    std::vector<char> coop_cfg_ready(MOSHII_COOP_MAXG + 1, 0);
     // device buffers of this call: released on EVERY way out of the function (error returns included)
     struct Owned { std::vector<void*> p; ~Owned() { for (void* q : p) if (q) hipFree(q); } } owned;
     double *d_entry = nullptr, *d_final = nullptr, *d_dev = nullptr;
@@ -1356,10 +1400,53 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             cd.frames_done = trace ? d_done + i : nullptr;
             rep[i] = cd;
         }
+        // cooperative sweeps: as many workgroups per chain as the request and the chip allow (every workgroup of the launch resident)
+        int g_round = 0;
+        if (coop_rep >= 2) g_round = std::min(coop_rep, n_cu / (int)rep.size());
+        const LaunchCfg* use = &cfg;
+        if (g_round >= 2) {
+            LaunchCfg& cc = coop_cfgs[g_round];
+            if (!coop_cfg_ready[g_round]) {
+                size_t ctl2 = 0;
+                // (n_workgroups = 1: the residency of this round's chains has been settled just above)
+                if ((rc = prepare_launch(m, prior, o, Mmax, Nvmax, NWmax, 1, stream, extra, &cc, &ctl2, g_round))) { cleanup(); return rc; }
+                if (cc.coop_g != g_round) { cleanup(); return fail(MOSHII_ERR_ARG, "internal: cooperative repair launch not prepared"); }
+                if (ctl2 != ctl) { cleanup(); return fail(MOSHII_ERR_ARG, "internal: control block moved"); }
+                coop_cfg_ready[g_round] = 1;
+            }
+            const size_t per = ((size_t)2 * g_round * cc.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(g_round + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+            if ((rc = m->coopbuf.reserve(per * rep.size()))) { cleanup(); return rc; }
+            m->coopbuf.used = true; m->coopbuf.last_stream = stream;
+            HIP_TRY(hipMemsetAsync(m->coopbuf.ptr, 0, per * rep.size(), stream));
+            for (size_t i = 0; i < rep.size(); ++i) {
+                ChainDev& cd = rep[i];
+                cd.coop.G = g_round; cd.coop.prior_rank = cc.coop_prior_rank; cd.coop.slot_doubles = cc.coop_slot_doubles;
+                coop_split(seqs[chunks[todo[i]].seq].attach->M, g_round, cc.coop_prior_frac, cd.coop.mlo);
+                char* cb = m->coopbuf.ptr + per * i;
+                cd.coop.slots = as_gp_rw((unsigned long long*)cb);
+                cd.coop.flags = as_gp_rw((unsigned*)(cb + (size_t)2 * g_round * cc.coop_slot_doubles * sizeof(unsigned long long)));
+            }
+            use = &cc;
+        }
         HIP_TRY(hipMemcpyAsync(d_baton, hbaton.data(), sizeof(int) * hbaton.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_repair, rep.data(), sizeof(ChainDev) * rep.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if ((rc = launch_chains(cfg, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }
+        if ((rc = launch_chains(*use, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }
+        if (g_round >= 2) {   // did every group stay whole?
+            const size_t per = ((size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + (size_t)(g_round + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+            std::vector<unsigned> ab(rep.size(), 0u);
+            for (size_t i = 0; i < rep.size(); ++i)
+                HIP_TRY(hipMemcpyAsync(&ab[i], m->coopbuf.ptr + per * i + (size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + g_round * sizeof(unsigned),
+                                       sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            bool broken = false;
+            for (size_t i = 0; i < rep.size(); ++i) broken |= ab[i] != 0u;
+            if (broken) {   // (the chip is shared?)  Whatever the broken groups left is caught by the next verification -- they spoil the entry state of
+                            // the chunk they stopped in -- and re-solved by plain chains from here on
+                if (trace) fprintf(stderr, "[moshii] a cooperative repair group broke up: plain repair chains from here on\n");
+                coop_rep = 0;
+            }
+        }
         n_repaired += (int)rep.size();
         ++rounds;
         if (trace) {

@@ -148,19 +148,21 @@ class DeviceSequence:
         s = self.solver
         return s.dev.handle, (s.prior.handle if s.prior is not None else None), s.opts[0]
 
-    def solve_sequential(self, stream):
+    def solve_sequential(self, stream, coop=0):
+        """coop = g > 0: the chain as a cooperative chain of g workgroups (capi.coop_group)."""
         import ctypes as C
         from . import capi
         mh, ph, opts = self._handles()
-        capi.check(capi.load().moshii_chain_solve(mh, ph, C.byref(opts), 1, self.cdesc, capi.BUFFERS_DEVICE, C.c_void_p(stream)))
+        capi.check(capi.load().moshii_chain_solve(mh, ph, C.byref(opts), 1, self.cdesc, capi.BUFFERS_DEVICE | capi.coop_group(coop), C.c_void_p(stream)))
 
-    def solve_chunked(self, stream, num_chunks=0, warmup=32, verify_tol=1e-11):
+    def solve_chunked(self, stream, num_chunks=0, warmup=32, verify_tol=1e-11, coop=0):
+        """coop = g > 0: the repair sweeps as cooperative chains of g workgroups, launched by the host's rounds."""
         import ctypes as C
         from . import capi
         mh, ph, opts = self._handles()
         co = capi.ChunkOpts(int(num_chunks), int(warmup), float(verify_tol))
         rep = capi.ChunkReport()
-        capi.check(capi.load().moshii_sequence_solve(mh, ph, C.byref(opts), 1, self.sdesc, C.byref(co), capi.BUFFERS_DEVICE,
+        capi.check(capi.load().moshii_sequence_solve(mh, ph, C.byref(opts), 1, self.sdesc, C.byref(co), capi.BUFFERS_DEVICE | capi.coop_group(coop),
                                                      C.c_void_p(stream), C.byref(rep)))
         self.report = {k: getattr(rep, k) for k, _ in capi.ChunkReport._fields_}
         return self.report

@@ -33,6 +33,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 void register_dynamic_lds(double* base, size_t bytes);   // arrays behind `extern __shared__`: guarded beyond the launch's lds_bytes
 }
 
+#define MOSHII_EMULATION 1                           // (moshii_api.hip: cooperative chains only on request -- see HIPEMU_CONCURRENT)
 #define __global__
 #define __device__
 #define __host__

@@ -224,3 +224,26 @@ def test_cooperative_chains_several_groups_in_one_launch_in_emulation(monkeypatc
     for o, p_ in zip(outs, plain):
         np.testing.assert_array_equal(o['iters'], p_['iters'])
         assert np.abs(o['fullpose'] - p_['fullpose']).max() < 1e-9 and np.abs(o['markers_sim'] - p_['markers_sim']).max() < 1e-9
+
+
+def test_chunked_solve_with_cooperative_repair_chains_in_emulation(monkeypatch):
+    """moshii_sequence_solve with MOSHII_COOP_GROUP(g): no carry-on inside the first launch; the host's repair rounds launch every
+    repair chain as g workgroups -- rank 0 takes the decisions that depend on other chains' memory (boundary negotiation, stop
+    requests, re-joining the stored rows) and the other ranks follow its word.  Short warm-up + tight tolerance: most hand-offs miss,
+    sweeps run through several chunks, meet other chains' territories and re-join.  Result: the sequential chain's."""
+    monkeypatch.setenv('HIPEMU_CONCURRENT', '1')
+    case = oracle_case('smplh', F=40, M=53, seed=52, empty_frames=(9, 10, 20))
+    with emulated_libmoshii() as capi:
+        dev = device_case(case)
+        seq = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                    [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+        outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                             [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                             num_chunks=5, warmup=2, verify_tol=1e-12, coop=3)
+        kernel = capi.last_launch_info()[0]
+    print(rep, kernel)
+    assert rep['n_chunks'] == 5 and rep['n_repaired'] >= 1 and rep['repair_rounds'] >= 1
+    assert ',coop' in kernel
+    np.testing.assert_array_equal(outs[0]['status'], seq['status'])
+    assert np.abs(outs[0]['fullpose'] - seq['fullpose']).max() < 1e-9 and np.abs(outs[0]['markers_sim'] - seq['markers_sim']).max() < 1e-9
+    np.testing.assert_array_equal(outs[0]['iters'], seq['iters'])

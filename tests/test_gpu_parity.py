@@ -188,10 +188,12 @@ def test_mosh_stageii_end_to_end(gpu_lib, tmp_path):
 # ---------------------------------------------------------------------------------------------------
 # chunked sequence solve (moshii_sequence_solve): concurrent chunks, verified + repaired hand-offs
 # ---------------------------------------------------------------------------------------------------
-def _sequential(dev, case):
+def _sequential(dev, case, coop=1):
+    """The sequential chain; coop=1: as ONE workgroup (the plain chain the chunk chains of moshii_sequence_solve are: bitwise comparisons
+    below), coop=0: as the library picks it (a cooperative chain of several workgroups where it can)."""
     from moshpp_amd import capi
     return capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
-                                 [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
+                                 [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)], coop=coop)[0]
 
 
 def test_sequence_solve_matches_sequential_chain(gpu_lib):
@@ -233,7 +235,7 @@ def test_sequence_solve_repair_reproduces_chain_bitwise(gpu_lib):
     seq = _sequential(dev, case)
     outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
                                          [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
-                                         num_chunks=4, warmup=0, verify_tol=1e-12)
+                                         num_chunks=4, warmup=0, verify_tol=1e-12, coop=1)   # (plain repair chains: bit for bit)
     print('chunk report', rep)
     assert rep['n_chunks'] == 4 and 1 <= rep['n_repaired'] <= 3   # one run-through chain (or one per chunk) re-solves chunks 1..3
     for k in ('fullpose', 'trans', 'markers_sim', 'status', 'errs', 'pose'):
@@ -251,12 +253,58 @@ def test_fused_repair_takes_the_last_chunk_without_a_host_round(gpu_lib):
     seq = _sequential(dev, case)
     outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
                                          [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
-                                         num_chunks=2, warmup=0, verify_tol=1e-12)
+                                         num_chunks=2, warmup=0, verify_tol=1e-12, coop=1)   # (plain chains: the carry-on protocol)
     print('chunk report', rep)
     assert rep['n_chunks'] == 2 and rep['n_repaired'] == 1
     assert rep['repair_rounds'] == 0, 'the carried-on chain of chunk 0 must repair the last chunk inside the first launch'
     for k in ('fullpose', 'trans', 'markers_sim', 'status', 'pose', 'iters'):
         np.testing.assert_array_equal(outs[0][k], seq[k])
+
+
+@pytest.mark.parametrize('g', [0, 3, 6])
+def test_cooperative_chain_on_the_device(gpu_lib, g):
+    """One chain solved by several workgroups (MOSHII_COOP_GROUP; g = 0: the library's own choice) against the plain chain and the
+    oracle: same iteration counts, results to round-off (sums over markers are taken rank by rank), every rank's simulated markers
+    in place; an empty frame and occluded markers in the sequence."""
+    from moshpp_amd import capi
+    case = oracle_case('smplh', F=40, M=53, seed=58, empty_frames=(7, 8, 21))
+    dev = device_case(case)
+    plain = _sequential(dev, case, coop=1)
+    assert capi.last_launch_info()[0] == 'k_chain_solve<4,1>'
+    out = _sequential(dev, case, coop=g)
+    kernel = capi.last_launch_info()[0]
+    print(kernel)
+    assert ',coop' in kernel and (g == 0 or kernel.endswith(f',coop{g}>'))
+    np.testing.assert_array_equal(out['status'], plain['status'])
+    np.testing.assert_array_equal(out['iters'], plain['iters'])
+    for k in ('pose', 'fullpose', 'trans', 'markers_sim'):
+        assert np.abs(out[k] - plain[k]).max() < 1e-9, k
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplh')
+    solved = np.flatnonzero(out['status'] == 0)
+    assert list(solved) == list(ref['frame_ids'])
+    assert np.abs(out['fullpose'][solved] - ref['fullpose']).max() < TIGHT
+    np.testing.assert_array_equal(out['iters'][solved, 0], ref['iters'])
+
+
+def test_chunked_solve_with_cooperative_sweeps_on_the_device(gpu_lib):
+    """moshii_sequence_solve as the library runs it by default for a body solve: pass-1 chunk chains that do not carry on, then the
+    host's repair rounds with every repair chain a cooperative chain (rank 0 takes the decisions that depend on other chains' memory).
+    Short warm-up + tight tolerance: runs of missed hand-offs, sweeps through several chunks, re-joins.  Against the plain sequential chain."""
+    from moshpp_amd import capi
+    case = oracle_case('smplh', F=480, M=53, seed=71)
+    dev = device_case(case)
+    seq = _sequential(dev, case)
+    outs, rep = capi.sequence_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                         [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'])],
+                                         num_chunks=40, warmup=6, verify_tol=1e-12)
+    kernel = capi.last_launch_info()[0]
+    print('chunk report', rep, kernel)
+    assert rep['n_repaired'] >= 1 and rep['repair_rounds'] >= 1 and ',coop' in kernel
+    solved = seq['status'] == 0
+    dp = np.abs(outs[0]['fullpose'] - seq['fullpose'])[solved].max(1)
+    print(f'max dev {dp.max():.2e}, frames > 1e-9: {(dp > 1e-9).sum()}')
+    assert dp.max() < 1e-7
+    np.testing.assert_array_equal(outs[0]['status'], seq['status'])
 
 
 def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):

@@ -26,7 +26,7 @@ def run(reps=3):
     return best, out
 
 
-os.environ.pop('MOSHII_COOP', None)
+os.environ['MOSHII_COOP'] = '1'   # plain chains (unset = the library's own choice)
 t0, ref = run()
 print(f'{mt} F={F} fingers={fingers} plain: {t0 / F * 1e6:7.1f} us/frame  {capi.last_launch_info()}  iters/frame {ref["iters"][:, 0].mean():.2f}', flush=True)
 for g in groups:
