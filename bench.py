@@ -340,7 +340,7 @@ def main():
     name, lds, thr = capi.last_launch_info()
     rep = reports[seeds[0]][-1] if reports[seeds[0]] else None
     how = (f'chunked: {rep["n_chunks"]} concurrent chunks (1 workgroup each), {rep["warmup"]}-frame warm-up overlap, hand-offs '
-           f'verified to {rep["verify_tol"]:g} and repaired exactly' if rep else 'exact sequential chain (1 chain = 1 workgroup)')
+           f'verified to {rep["verify_tol"]:g} and repaired exactly by cooperative sweeps ({name})' if rep else f'exact sequential chain ({name})')
     result = {
         'metric': 'solved mocap frames/sec (Stage-II)', 'value': round(value, 2), 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -358,6 +358,21 @@ def main():
     }
     if rep:
         result['chunking'] = dict(rep, repaired_per_step=float(np.mean([r['n_repaired'] for sd in used for r in reports[sd]])))
+    if args.mode == 'chunked' and world == 1:
+        # the same steps with PLAIN repair chains carried on inside the first launch (rounds 2-3's scheme; MOSHII_COOP_GROUP(1)), once per
+        # seed, beside the timed default (cooperative sweeps from the host's rounds where the solve allows)
+        tps = {}
+        stream_ = torch.cuda.current_stream().cuda_stream
+        for sd in used:
+            torch.cuda.synchronize()
+            tq0 = time.perf_counter()
+            seqs[sd].solve_chunked(stream_, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol, coop=1)
+            torch.cuda.synchronize()
+            tps[str(sd)] = round((time.perf_counter() - tq0) * 1e3, 3)
+            seqs[sd].solve_chunked(stream_, num_chunks=args.chunks, warmup=args.chunk_warmup, verify_tol=args.verify_tol)   # leave the default's rows
+        torch.cuda.synchronize()
+        result['plain_sweeps'] = {'ms_per_step_by_seed': tps, 'aggregate_frames_per_s': round(sum(solved_of[sd] for sd in used) / (sum(tps.values()) * 1e-3), 1),
+                                  'note': 'one untimed-warm step per seed with one-workgroup repair chains carried on inside the first launch'}
 
     # ---- fixed jobs at this N (all ranks take part)
     strong = None
@@ -445,6 +460,17 @@ def main():
         if extras and args.mode == 'chunked' and not args.no_sequential:
             dsq = workload.DeviceSequence(job, solver, dev)
             stream = torch.cuda.current_stream().cuda_stream
+            # the ONE-workgroup chain first (rounds 1-3's `sequential_chain`), then the chain as the library runs it when asked for the
+            # sequential order: a cooperative chain of several workgroups where the solve allows
+            dsq.solve_sequential(stream, coop=1)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            dsq.solve_sequential(stream, coop=1)
+            torch.cuda.synchronize()
+            tplain = time.perf_counter() - tp0
+            kplain = capi.last_launch_info()[0]
+            splain = dsq.results()
+            dsq.solve_sequential(stream)
             torch.cuda.synchronize()
             ts0 = time.perf_counter()
             dsq.solve_sequential(stream)
@@ -456,6 +482,9 @@ def main():
             result['sequential_chain'] = {
                 'frames_per_s': round(solved / tsq, 1), 'ms': round(tsq * 1e3, 1), 'us_per_frame': round(tsq * 1e6 / max(solved, 1), 1),
                 'kernel': capi.last_launch_info()[0], 'seed': seeds[0],
+                'one_workgroup': {'frames_per_s': round(solved / tplain, 1), 'us_per_frame': round(tplain * 1e6 / max(solved, 1), 1), 'kernel': kplain,
+                                  'max_abs_pose_diff_vs_default_rad': float(np.abs(splain['fullpose'] - sq['fullpose'])[solved_mask].max()),
+                                  'iteration_counts_identical': bool((splain['iters'] == sq['iters']).all())},
                 'timed_mode_vs_sequential': {'max_abs_pose_diff_rad': float(dp.max()), 'frames_over_1e-4_rad': int((dp > 1e-4).sum()),
                                              'frames_over_1e-6_rad': int((dp > 1e-6).sum()),
                                              'marker_rmse_m': float(np.sqrt((dm ** 2).sum(-1).mean())),

@@ -546,8 +546,9 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
                 if (e < E) s0 += js[e * 3] * shp[e];
                 cx.Jl[i] = s0 + s1;
             }
-            for (int it = tid; it < 3 * Nvp; it += MOSHII_TPB) {   // rest vertices: vbase + S . s (vertex fastest: coalesced rows)
-                const int i = it / Nvp, a = it - i * Nvp;
+            const int na = COOP ? (a_hi - a_lo) : Nvp;   // (cooperative chains: this rank's vertices only)
+            for (int it = tid; it < 3 * na; it += MOSHII_TPB) {   // rest vertices: vbase + S . s (vertex fastest: coalesced rows)
+                const int i = it / na, a = (COOP ? a_lo : 0) + (it - i * na);
                 const auto* sp = gptr(at.Ssh) + (size_t)i * Nvp + a;
                 const size_t st = (size_t)3 * Nvp;
                 double s0 = 0.0, s1 = 0.0;
@@ -1389,7 +1390,7 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
                 const double v = W[bi];
                 double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl + (tid & 63);
                 *dst = v;
-                Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;
+                Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;   // (as a predicated store instead: hipcc 7.2 segfaults on this function)
             }
             // LDS-only barrier: the step exchanges data through Cv / pinv (LDS); a __syncthreads() would also wait for the
             // acknowledgement of the factor's global stores, ~2 us per step.  They are fenced once per block column.
@@ -1527,7 +1528,7 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     }
     }   // (rows_here)
     if constexpr (XT) {
-        if (nshp > 0) {
+        if (nshp > 0 && rows_here) {
             // shape derivative of the joint transforms at the current point (the restated lbs_derivatives_wrt_shape):
             //   dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par)   (joint world positions, one tree level per step)
             //   q_j  = dt_j - Rw_j JS_j                               (so that dv/ds = Trot . S(v) + sum_j w_j q_j)
@@ -2815,7 +2816,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
             const int terms = fp.use_fingers | (fp.use_face << 1) | (fp.use_shape << 2);   // the Step-2-only residual blocks
             const bool reuse = at_pose && prev_wt_pose == fp.wt_pose && prev_terms == terms;
             fin = run_phase<NBLK, XT, COOP>(cx, ly, md, at, pr, op, fp, visrow, step2 ? op.step2 : op.step1, step2 ? op.n2 : op.n1,
-                                  (XT && step2) ? op.nshape : 0, XT ? chp->qscratch : nullptr,
+                                  (XT && step2) ? op.nshape : 0, XT ? chp->qscratch + (COOP ? (size_t)co.rank * chp->coop.qstride : 0) : nullptr,
                                   round ? op.e3_first : op.e3, /*rigid=*/kind == 0, /*eval_only=*/kind == 5, reuse, carried, at_pose, fwd_set,
                                   /*set_id=*/(kind >= 4 && !same_sets) ? 2 : 1, vc_key, tab_key, n_iter, n_fev, fail, co);
             prev_wt_pose = fp.wt_pose; prev_terms = terms;
@@ -2923,6 +2924,11 @@ MOSHII_INSTANTIATE(4, false, true)
 MOSHII_INSTANTIATE(5, false, true)
 MOSHII_INSTANTIATE(7, false, true)
 MOSHII_INSTANTIATE(8, false, true)
+// ... and the extended variant (BASELINE config 3: 32 sequences x 8 workgroups = the chip)
+MOSHII_INSTANTIATE(5, true, true)
+MOSHII_INSTANTIATE(8, true, true)
+MOSHII_INSTANTIATE(10, true, true)
+MOSHII_INSTANTIATE(13, true, true)
 #undef MOSHII_INSTANTIATE
 #endif
 
@@ -2968,8 +2974,15 @@ extern "C" hipError_t moshii_launch_chain_solve(int nblk, int two_per_cu, int xt
     if (xt || nblk != 4 || two_per_cu) return hipErrorInvalidValue;
     if (coop_g >= 1) kern = k_chain_solve<4, 1, false, true>; else kern = k_chain_solve<4, 1, false, false>;
 #else
-    if (coop_g >= 1) {
-        if (xt) return hipErrorInvalidValue;
+    if (coop_g >= 1 && xt) {
+        switch (nblk) {
+            case 5: kern = k_chain_solve<5, 1, true, true>; break;
+            case 8: kern = k_chain_solve<8, 1, true, true>; break;
+            case 10: kern = k_chain_solve<10, 1, true, true>; break;
+            case 13: kern = k_chain_solve<13, 1, true, true>; break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (coop_g >= 1) {
         switch (nblk) {
             case 4: kern = k_chain_solve<4, 1, false, true>; break;
             case 5: kern = k_chain_solve<5, 1, false, true>; break;

@@ -786,12 +786,11 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
     if (coop_g == -1) {
         const int item_ranks = (Mmax * nkfmax + MOSHII_TPB - 1) / MOSHII_TPB;
         coop_g = std::min(MOSHII_COOP_MAXG, item_ranks + (npose > 0 ? 1 : 0));
-        if (coop_g < 3 || nblk < 4) coop_g = 0;   // (few items, or a solve so small -- MANO -- that the exchanges cost what the split saves: measured)
+        if (coop_g < 3 || (!xt && nblk < 4)) coop_g = 0;   // (few items, or a solve so small -- MANO -- that the exchanges cost what the split saves: measured)
     }
-    if (coop_g > 0 && (xt || nmax + 1 > 8 * 16 || (long long)coop_g * std::max(n_workgroups, 1) > n_cu)) coop_g = 0;   // (not built / not all resident: plain chains)
+    if (coop_g > 0 && ((!xt && nmax + 1 > 8 * 16) || (long long)coop_g * std::max(n_workgroups, 1) > n_cu)) coop_g = 0;   // (not built / not all resident: plain chains)
     if (coop_g > 0) {   // cooperative chains: a rank builds the rows of its own markers only -- one tile of its largest possible share
-        if (xt) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: the extended variant is not built");
-        if (nblk < 4) nblk = 4;   // (cooperative instantiations: 4, 5, 7, 8 register blocks)
+        if (!xt && nblk < 4) nblk = 4;   // (cooperative instantiations: 4, 5, 7, 8 register blocks; extended variant: 5, 8, 10, 13 as the plain one)
         if (nmax + 1 > nblk * 16) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: too many unknowns");
         if (coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: at most 8 workgroups per chain");
         // with a prior: from three ranks on the last one does nothing but the prior (measured: its evaluation is as long as the others' forward pass)
@@ -1008,8 +1007,9 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     // extended variant: per-chain scratch for the shape derivatives of the joint transforms ([2][K][E][3] doubles)
     const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;   // global packed factor + trash / zero words (ldl_big)
     const size_t qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
+    const int qranks = (coop_g > 0) ? coop_g : 1;   // (cooperative chains: a slice per rank -- every rank keeps its own derivative arrays / factor)
     if (E > 0) {
-        if ((rc = m->qscratch.reserve(qbytes * n_chains))) return rc;
+        if ((rc = m->qscratch.reserve(qbytes * n_chains * qranks))) return rc;
         m->qscratch.used = true; m->qscratch.last_stream = stream;
     }
     std::vector<double*> d_shape(n_chains, nullptr);
@@ -1035,7 +1035,8 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         if (ch.init_pose_prev) cd.init_prev = (const double*)(dbase + put(ch.init_pose_prev, sizeof(double) * NP));
         if (E > 0) {
             if (ch.init_shape) cd.init_shape = (const double*)(dbase + put(ch.init_shape, sizeof(double) * E));
-            cd.qscratch = (double*)(m->qscratch.ptr + qbytes * c);
+            cd.qscratch = (double*)(m->qscratch.ptr + qbytes * (size_t)c * qranks);
+            cd.coop.qstride = (int)(qbytes / sizeof(double));
         }
         if (dev) {
             cd.obs = ch.obs; cd.vis = ch.vis; cd.pose = ch.pose; cd.fullpose = ch.fullpose; cd.trans = ch.trans;
@@ -1181,6 +1182,14 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     const bool trace = getenv("MOSHII_TRACE_REPAIR") != nullptr;
     std::vector<LaunchCfg> coop_cfgs(MOSHII_COOP_MAXG + 1);   // per group size, prepared when first used
     std::vector<char> coop_cfg_ready(MOSHII_COOP_MAXG + 1, 0);
+    if (coop_rep >= 2) {
+        // the exchange buffers of the repair rounds, once and for the largest round this call can launch (a buffer that grows from
+        // round to round is a hipFree + hipMalloc in the middle of the solve)
+        const int nb = std::max(4, cfg.nblk), NEc = nb * (nb + 1) / 2, NTc = (NEc + 3) / 4;
+        const size_t slot = (size_t)std::max((4 * NTc + 2 * ((NEc + 2) / 2)) * MOSHII_TPB, 3 * Mmax + 2) + 32;
+        const size_t per = ((size_t)2 * coop_rep * slot * sizeof(unsigned long long) + (size_t)(coop_rep + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+        if ((rc = m->coopbuf.reserve(per * (size_t)std::min(NC, std::max(1, n_cu / 2))))) return rc;
+    }
     // device buffers of this call: released on EVERY way out of the function (error returns included)
     struct Owned { std::vector<void*> p; ~Owned() { for (void* q : p) if (q) hipFree(q); } } owned;
     double *d_entry = nullptr, *d_final = nullptr, *d_dev = nullptr;

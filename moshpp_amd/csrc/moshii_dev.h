@@ -96,6 +96,7 @@ struct CoopDev {
     int prior_rank;
     int mlo[MOSHII_COOP_MAXG + 1];
     int slot_doubles;                        // doubles per (parity, rank) slot
+    int qstride;                             // extended variant: doubles between the ranks' slices of ChainDev::qscratch
     MOSHII_GP(unsigned long long) slots;     // [2][G][slot_doubles] payload words (doubles as bit patterns: 8-byte agent-scope accesses)
     MOSHII_GP(unsigned int) flags;           // [G] sequence number of the last exchange each rank has posted, [G] = the group's abort word
 };

@@ -247,3 +247,24 @@ def test_chunked_solve_with_cooperative_repair_chains_in_emulation(monkeypatch):
     np.testing.assert_array_equal(outs[0]['status'], seq['status'])
     assert np.abs(outs[0]['fullpose'] - seq['fullpose']).max() < 1e-9 and np.abs(outs[0]['markers_sim'] - seq['markers_sim']).max() < 1e-9
     np.testing.assert_array_equal(outs[0]['iters'], seq['iters'])
+
+
+@pytest.mark.parametrize('G', [3, 5])
+def test_cooperative_extended_kernel_matches_oracle_in_emulation(monkeypatch, G):
+    """The xt variant (jaw + expression coefficients free) as a cooperative chain: every rank re-shapes its own rest vertices, keeps its
+    own shape-derivative arrays, builds the shape columns of its own markers' rows; the regulariser columns are every rank's alike."""
+    from tests.helpers import shape_case
+    monkeypatch.setenv('HIPEMU_CONCURRENT', '1')
+    case = shape_case('smplx', F=3, M=40, E=6, seed=3, kind='expr')
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_face=True, shape_kind='expr')
+        ch = [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)]
+        plain = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch)[0]
+        out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch, coop=G)[0]
+        assert capi.last_launch_info()[0].endswith(f',xt,coop{G}>'), capi.last_launch_info()
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplx',
+                           optimize_face=True, free_shape='expr')
+    assert np.abs(out['fullpose'] - ref['fullpose']).max() < 1e-8 and np.abs(out['shape'] - ref['shape']).max() < 1e-8
+    np.testing.assert_array_equal(out['iters'][:, 0], ref['iters'])
+    np.testing.assert_array_equal(out['iters'], plain['iters'])
+    assert np.abs(out['shape'] - plain['shape']).max() < 1e-9 and np.abs(out['markers_sim'] - plain['markers_sim']).max() < 1e-9
