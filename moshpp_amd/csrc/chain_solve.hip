@@ -128,6 +128,32 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
     b = (red[1] + red[4]) + (red[7] + red[10]);
     c = (red[2] + red[5]) + (red[8] + red[11]);
 }
+// four sums at once / a maximum and three sums at once: each quantity's reduction tree is that of block_sum3 (same bits), one pair of
+// barriers for all of them (the dogleg's bookkeeping was seven reductions per iteration: now three)
+__device__ __forceinline__ void block_sum4(double& a, double& b, double& c, double& d, double* red) {
+    wave_sum3(a, b, c);
+    d = wave_sum(d);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = a; red[(tid >> 6) * 4 + 1] = b; red[(tid >> 6) * 4 + 2] = c; red[(tid >> 6) * 4 + 3] = d; }
+    __syncthreads();
+    a = (red[0] + red[4]) + (red[8] + red[12]);
+    b = (red[1] + red[5]) + (red[9] + red[13]);
+    c = (red[2] + red[6]) + (red[10] + red[14]);
+    d = (red[3] + red[7]) + (red[11] + red[15]);
+}
+__device__ __forceinline__ void block_max_sum3(double& mx, double& a, double& b, double& c, double* red) {
+    wave_sum3(a, b, c);
+    mx = wave_max(mx);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = a; red[(tid >> 6) * 4 + 1] = b; red[(tid >> 6) * 4 + 2] = c; red[(tid >> 6) * 4 + 3] = mx; }
+    __syncthreads();
+    a = (red[0] + red[4]) + (red[8] + red[12]);
+    b = (red[1] + red[5]) + (red[9] + red[13]);
+    c = (red[2] + red[6]) + (red[10] + red[14]);
+    mx = fmax(fmax(red[3], red[7]), fmax(red[11], red[15]));
+}
 __device__ __forceinline__ double block_sum(double a, double* red) {
     double b = 0.0, c = 0.0;
     block_sum3(a, b, c, red);
@@ -2219,6 +2245,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     __syncthreads();
     Sse last;
     double sse = 0.0, delta = op.delta0, norm_sd = 0.0, norm_gn = 0.0, step = 0.0, p2 = 0.0, gd = 0.0;
+    double dAd = 0.0, dl_dd = 0.0, dl_gs = 0.0, dl_ds = 0.0;   // d^T A d of the current step; the dogleg leg's sums of the current solve
     bool init = true, done = false, have_gn = false;
     int iteration = 0;
     // `reuse`: the previous phase of this frame ended with the forward state of the CURRENT point in LDS and the same
@@ -2271,10 +2298,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             do_assemble = true;
         } else {
             rho = sse - last.total;
-            if (rho > 0.0) {
-                const double dAd = block_sum(A.quad_partial(cx.ddl, n), cx.red);
-                rho = rho / (2.0 * gd - dAd);
-            }
+            if (rho > 0.0) rho = rho / (2.0 * gd - dAd);   // (d^T A d: reduced with the step's norms when the trial point was formed)
             improved = rho > 0.0;
             at_pose = improved;
             if (improved) {
@@ -2286,23 +2310,26 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
         PROF_ACC(23, _t1);
+        double pp = 0.0, gg = 0.0, gAg = 0.0;
         if (do_assemble) {
             { PROF_T(_ta); A = APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::unpack(assemble_fn<NBLK, XT, COOP>(ly.o_pose, n, ncp, nkf, nfree_hand, qs)); PROF_ACC(16, _ta); }
             if constexpr (COOP) { if (cx.scal[S_COOP_FAIL] != 0.0) break; }
             PROF_T(_t2);
+            // the gradient's maximum, |p|^2 at the accepted point, |g|^2 and g^T A g in ONE block reduction
             double gm = 0.0;
-            for (int q = tid; q < n; q += MOSHII_TPB) gm = fmax(gm, fabs(cx.g[q]));
-            if (block_max(gm, cx.red) < 1e-15) done = true;
+            for (int q = tid; q < n; q += MOSHII_TPB) {
+                const double gq = cx.g[q];
+                const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
+                gm = fmax(gm, fabs(gq)); pp += pq * pq; gg += gq * gq;
+            }
+            gAg = A.quad_partial(cx.g, n);
+            block_max_sum3(gm, pp, gg, gAg, cx.red);
+            if (gm < 1e-15) done = true;
             PROF_ACC(24, _t2);
         }
         PROF_T(_t3);
         if (!init) {   // updateRadius + trust-region floor
-            double pnorm2 = p2;
-            if (improved) {
-                double pp = 0.0;
-                for (int q = tid; q < n; q += MOSHII_TPB) { const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]]; pp += pq * pq; }
-                pnorm2 = block_sum(pp, cx.red);
-            }
+            const double pnorm2 = (improved && do_assemble) ? pp : p2;   // (improved without an assembly: the e_3 stop -- done already)
             if (rho > 0.9) delta = fmax(delta, 2.5 * step);
             else if (rho < 0.05) delta *= 0.25;
             if (delta <= 1e-15 * sqrt(pnorm2)) done = true;
@@ -2312,11 +2339,6 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             if (done) break;
             // start_iteration: d_sd = |g|^2 / |J g|^2 g, with |J g|^2 = g^T A g
             ++iteration;
-            double gg = 0.0;
-            for (int q = tid; q < n; q += MOSHII_TPB) gg += cx.g[q] * cx.g[q];
-            double gAg = A.quad_partial(cx.g, n);
-            double dummy = 0.0;
-            block_sum3(gg, gAg, dummy, cx.red);
             const double csd = gg / gAg;
             norm_sd = fabs(csd) * sqrt(gg);
             for (int q = tid; q < n; q += MOSHII_TPB) cx.dsd[q] = csd * cx.g[q];
@@ -2347,30 +2369,30 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                     for (int q = tid; q < n; q += MOSHII_TPB) cx.dgn[q] = cx.dsd[q];
                     __syncthreads();
                 }
-                double s = 0.0;
-                for (int q = tid; q < n; q += MOSHII_TPB) s += cx.dgn[q] * cx.dgn[q];
-                norm_gn = sqrt(block_sum(s, cx.red));
+                // |d_gn|^2 and the three sums of the dogleg leg, once per solve (a rejected step re-uses them with a smaller radius)
+                double sg = 0.0;
+                dl_dd = 0.0; dl_gs = 0.0; dl_ds = 0.0;
+                for (int q = tid; q < n; q += MOSHII_TPB) {
+                    const double dg_ = cx.dgn[q], dsq = cx.dsd[q], df = dg_ - dsq;
+                    sg += dg_ * dg_; dl_dd += df * df; dl_gs += dg_ * dsq; dl_ds += df * dsq;
+                }
+                block_sum4(sg, dl_dd, dl_gs, dl_ds, cx.red);
+                norm_gn = sqrt(sg);
                 have_gn = true;
             }
             if (norm_gn <= delta) {
                 for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dgn[q];
             } else {
-                double dd = 0.0, gs = 0.0, ds = 0.0;
-                for (int q = tid; q < n; q += MOSHII_TPB) {
-                    const double df = cx.dgn[q] - cx.dsd[q];
-                    dd += df * df; gs += cx.dgn[q] * cx.dsd[q]; ds += df * cx.dsd[q];
-                }
-                block_sum3(dd, gs, ds, cx.red);
                 const double delta_sq = delta * delta;
                 const double sqnorm_sd = norm_sd * norm_sd;
-                const double pnow = dd * delta_sq + gs * gs - (norm_gn * norm_gn) * sqnorm_sd;
-                const double beta = (delta_sq - sqnorm_sd) / (ds + sqrt(pnow));
+                const double pnow = dl_dd * delta_sq + dl_gs * dl_gs - (norm_gn * norm_gn) * sqnorm_sd;
+                const double beta = (delta_sq - sqnorm_sd) / (dl_ds + sqrt(pnow));
                 for (int q = tid; q < n; q += MOSHII_TPB) cx.ddl[q] = cx.dsd[q] + beta * (cx.dgn[q] - cx.dsd[q]);
             }
         }
         __syncthreads();
         PROF_T(_t5);
-        // ---- trial point and norms
+        // ---- trial point and norms (+ d^T A d for the gain ratio of this step)
         double s2 = 0.0;
         p2 = 0.0; gd = 0.0;
         for (int q = tid; q < n; q += MOSHII_TPB) {
@@ -2378,7 +2400,8 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
             s2 += dq * dq; p2 += pq * pq; gd += cx.g[q] * dq;
         }
-        block_sum3(s2, p2, gd, cx.red);
+        dAd = A.quad_partial(cx.ddl, n);
+        block_sum4(s2, p2, gd, dAd, cx.red);
         step = sqrt(s2);
         if (step <= 1e-15 * sqrt(p2)) break;   // "small step size" stop
         for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];

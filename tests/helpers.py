@@ -148,3 +148,43 @@ def stagei_kwargs(case, optimize_fingers=False, exclude_vids=None, head_corr=Non
                 frames=case['frames'], nb=case['nb'], weights=W, pose_ids=step1, body_ids=body if case['prior'] is not None else [],
                 finger_ids=finger, exclude_vids=exclude_vids, head_corr=head_corr, betas_init=betas_init, n_expr=n_expr,
                 expr_start=expr_start, face_ids=face_ids, extra_initial_rigid_adjustment=extra_initial_rigid_adjustment)
+
+
+# ---- BASELINE config 3 (SMPL-X, face + fingers free) ---------------------------------------------------------------------------------
+def face_job_oracle(job):
+    """The oracle's model / prior / attachment of a workload.make_face_job subject."""
+    sm = job['sm']
+    E = job['num_expressions']
+    m = so.prepare_model(dict(v_template=sm.v_template, shapedirs=sm.shapedirs, posedirs=sm.posedirs, weights=sm.weights,
+                              J_regressor=sm.J_regressor, parents=sm.parents, body_dof=sm.body_dof, hand_dof=sm.hand_dof,
+                              hands_mean=sm.hands_mean, selected_components=sm.selected_components), job['betas'])
+    so.set_free_shape(m, job['betas_expr_start_id'], E)
+    pr = so.prepare_gmm_prior(job['seq']['gmm'], 63)
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
+    closest, coef = so.transformed_coeffs(can, job['markers_latent'], exclude_vids=np.arange(9383, 10475))
+    return m, pr, closest, coef
+
+
+def face_capture_host(job, m, closest, coef, motion_seed, n_frames, expr_amp=0.3, noise=0.0005, dropout=0.02):
+    """A capture of the config-3 subject generated on the HOST (oracle forward; the same recipe as workload.make_face_capture, which
+    goes through the device): seeded body + finger motion, a jaw motion, a per-capture expression offset, noise and dropout.  The same
+    numbers wherever it runs -- the fixture generator (tests/golden/make_config3_golden.py) and the GPU tests feed on it."""
+    sm = job['sm']
+    E = job['num_expressions']
+    rng = np.random.default_rng(motion_seed + 5)
+    pose_gt, trans_gt = synth.synth_motion(sm.NP, sm.body_dof, n_frames, seed=motion_seed)
+    t = np.arange(n_frames)[:, None] / 30.0
+    pose_gt[:, 66:69] = 0.15 * np.sin(2 * np.pi * 1.1 * t + np.array([0.0, 1.0, 2.0]))   # jaw
+    pose_gt[:, 69:75] = 0.0
+    shp = expr_amp * rng.standard_normal(E)
+    M = closest.shape[0]
+    flat = closest.reshape(-1)
+    markers = np.zeros((n_frames, M, 3))
+    for f in range(n_frames):
+        v = so.verts_forward(m, so.fullpose_from_pose(m, pose_gt[f]), trans_gt[f], flat, shp=shp).reshape(M, 3, 3)
+        markers[f] = so.markers_from_verts(coef, v[:, 0], v[:, 1], v[:, 2])
+    markers += rng.normal(0, noise, markers.shape)
+    drop = rng.random(markers.shape[:2]) < dropout
+    drop[0, :] = False
+    markers[drop] = 0.0
+    return dict(obs=markers, vis=~drop, pose_gt=pose_gt, trans_gt=trans_gt, expr_gt=shp)

@@ -195,41 +195,62 @@ def test_config5_50000_frames_one_sequence(gpu_lib):
     assert dw < 1e-7
 
 
+def _config3_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden', 'config3_oracle.npz'))
+
+
+def _hold_to_config3_golden(g, ms, out, n_frames):
+    """A chain's first `n_frames` frames of capture `ms` against the committed oracle trajectory (tests/golden/make_config3_golden.py):
+    every frame's dogleg iteration count, every 10th frame's fullpose / expression / translation."""
+    st = int(g['stride'])
+    sel = np.arange(0, n_frames, st)
+    k = len(sel)
+    dp = np.abs(out['fullpose'][sel] - g[f'fullpose_{ms}'][:k]).max()
+    ds = np.abs(out['shape'][sel] - g[f'shape_{ms}'][:k]).max()
+    dt = np.abs(out['trans'][sel] - g[f'trans_{ms}'][:k]).max()
+    same = out['iters'][:n_frames, 0] == g[f'iters_{ms}'][:n_frames]
+    return dp, ds, dt, same
+
+
 def test_config3_smplx_32_sequences_of_4000_frames(gpu_lib):
     """BASELINE configs[2] at its stated size: 32 SMPL-X sequences x 4000 frames, 89 markers incl. face / hand vertices, fingers +
-    jaw + the yaml-default 80 expression coefficients free (194 unknowns per Step-2 solve), one launch of 32 chains in the
-    reference's frame order (with a free expression block a chunk start never reproduces the chain's coefficients, DESIGN.md
-    section 4a, so this size class runs sequentially per sequence).  Copies agree bit for bit; the oracle holds the first 50
-    frames; every frame reproduces its markers."""
+    jaw + the yaml-default 80 expression coefficients free (194 unknowns per Step-2 solve), one launch in the reference's frame order --
+    each chain a cooperative chain of 8 workgroups where the chip has 256 CUs (with a free expression block a chunk start never reproduces
+    the chain's coefficients, DESIGN.md section 4a, so this size class runs sequentially per sequence).  The subject and capture are the
+    bench's config-3 leg's (workload.make_face_job; capture 7000, generated on the host so that the committed oracle trajectory applies):
+    copies agree bit for bit; the oracle holds the first 400 frames (every iteration count, every 10th frame's state); every frame
+    reproduces its markers."""
     import time
-    from moshpp_amd import capi
-    from tests.helpers import shape_case, device_case
-    F, E, NSEQ = 4000, 80, 32
-    # (seed: the boosted synthetic expression motion makes most seeds lose track for a stretch within the first 60 frames -- data
-    #  SSE in the thousands, in the oracle and on the GPU alike -- after which two float64 runs no longer agree; 26 keeps both on
-    #  the same trajectory over the oracle window, tools/config3_diag.py)
-    case = shape_case('smplx', F=F, M=89, E=E, seed=26, kind='expr')
-    dev = device_case(case, optimize_fingers=True, optimize_face=True, shape_kind='expr')
+    from moshpp_amd import capi, workload
+    from tests.helpers import face_capture_host, face_job_oracle
+    F, NSEQ, H = 4000, 32, 400
+    job = workload.make_face_job()
+    solver = workload.make_solver(job)
+    m, pr, closest, coef = face_job_oracle(job)
+    assert np.array_equal(closest, solver.tc.closest) and np.abs(coef - solver.tc.coef).max() < 1e-12    # the same attachment on both sides
+    cap = face_capture_host(job, m, closest, coef, 7000, F)
     t0 = time.perf_counter()
-    outs = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
-                                 [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True) for _ in range(NSEQ)])
+    outs = capi.chain_solve_host(solver.dev, solver.prior, solver.opts,
+                                 [dict(attach=solver.attach, obs=cap['obs'], vis=cap['vis'], first=True) for _ in range(NSEQ)])
     dt = time.perf_counter() - t0
+    kernel = capi.last_launch_info()[0]
     for o in outs[1:]:
         assert np.array_equal(o['fullpose'], outs[0]['fullpose']) and np.array_equal(o['shape'], outs[0]['shape'])
     o = outs[0]
-    assert np.all(o['status'] == 0)
-    d = (o['markers_sim'] - case['obs'])[case['vis']]
+    # (every frame is solved; over 4000 frames the chain still meets a handful of ~10-frame stretches where the fingers + face block
+    #  loses track -- data SSE in the hundreds, in the oracle as on the GPU, profiles/r04_config3_full_parity.txt -- and a frame of one
+    #  of them can meet a non-positive pivot: flagged -1, solved by the Cauchy step)
+    assert np.all(o['status'] <= 0) and (o['status'] != 0).mean() < 2e-3
+    d = (o['markers_sim'] - cap['obs'])[cap['vis']]
     rmse = float(np.sqrt((d ** 2).sum(1).mean()))
-    assert rmse < 2e-2          # (the expression regulariser biases the boosted synthetic expression block towards 0: ~1 cm)
-    H = 50
-    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'][:H], case['vis'][:H], 'smplx',
-                           optimize_fingers=True, optimize_face=True, free_shape='expr')
-    dp = np.abs(o['fullpose'][:H] - ref['fullpose']).max()
-    ds = np.abs(o['shape'][:H] - ref['shape']).max()
-    print(f'config 3: {NSEQ} x {F} frames in {dt:.1f} s = {NSEQ * F / dt:.0f} frames/s; marker rmse {rmse:.2e} m; first {H} frames vs oracle '
-          f'{dp:.2e} rad / {ds:.2e} (expression)')
-    assert dp < 1e-6 and ds < 1e-6
-    np.testing.assert_array_equal(o['iters'][:H, 0], ref['iters'])
+    assert rmse < 5e-3          # (noise 0.5 mm; the expression regulariser holds the block towards 0)
+    g = _config3_golden()
+    dp, ds, dtr, same = _hold_to_config3_golden(g, 7000, o, H)
+    print(f'config 3: {NSEQ} x {F} frames in {dt:.1f} s = {NSEQ * F / dt:.0f} frames/s ({kernel}); marker rmse {rmse:.2e} m; data SSE max {o["errs"][:, 0].max():.1f}; '
+          f'first {H} frames vs oracle {dp:.2e} rad / {ds:.2e} (expression) / {dtr:.2e} m, iteration counts equal on {same.mean() * 100:.1f} % of frames')
+    assert dp < 1e-6 and ds < 1e-6 and dtr < 1e-6
+    assert same.all()
 
 
 @pytest.mark.gpu
@@ -417,40 +438,28 @@ def test_chunked_solve_is_exact_under_gpu_contention(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_config3_oracle_window_on_four_captures(gpu_lib):
+def test_config3_oracle_window_on_three_captures(gpu_lib):
     """BASELINE configs[2]'s subject as bench.py's `config3` leg builds it (workload.make_face_job: SMPL-X, 89 markers incl. face / hand
-    vertices, fingers + jaw + 80 expression coefficients free: 194 unknowns), four captures with different motion seeds (none of them
-    picked for being tame): the first frames of every chain against the oracle's, with equal dogleg iteration counts."""
-    from moshpp_amd import workload
+    vertices, fingers + jaw + 80 expression coefficients free: 194 unknowns), the captures 7000, 7001, 7002 (the first three motion
+    seeds of the bench leg: nobody picked them), 400 frames each, against the committed oracle trajectories
+    (tests/golden/make_config3_golden.py): equal dogleg iteration counts on every frame, states to 1e-6 on every 10th.  Both as the
+    library runs the chain by default (cooperative) and as one workgroup."""
+    from moshpp_amd import capi, workload
+    from tests.helpers import face_capture_host, face_job_oracle
     job = workload.make_face_job()
     solver = workload.make_solver(job)
-    m, pr, closest, coef = _face_job_oracle(job)
-    assert np.array_equal(closest, solver.tc.closest) and np.abs(coef - solver.tc.coef).max() < 1e-12    # the same attachment on both sides
-    H = 40
-    for ms in (6001, 6002, 6003, 6004):
-        cap = workload.make_face_capture(job, solver, ms, n_frames=40)
-        out = solver.solve(cap['obs'], cap['vis'])
-        assert np.all(out['status'] == 0)
-        ref = so.stageii_chain(m, pr, closest, coef, np.nan_to_num(cap['obs'][:H]), cap['vis'][:H], 'smplx', optimize_fingers=True,
-                               optimize_face=True, free_shape='expr')
-        dp = np.abs(out['fullpose'][:H] - ref['fullpose']).max()
-        ds = np.abs(out['shape'][:H] - ref['shape']).max()
-        d = (out['markers_sim'] - cap['obs'])[cap['vis']]
-        print(f'config 3 capture {ms}: first {H} frames vs oracle {dp:.2e} rad / {ds:.2e} (expression); marker rmse over 40 frames '
-              f'{np.sqrt((d ** 2).sum(1).mean()):.2e} m')
-        assert dp < 1e-6 and ds < 1e-6
-        np.testing.assert_array_equal(out['iters'][:H, 0], ref['iters'])
-
-
-def _face_job_oracle(job):
-    """The oracle's model / prior / attachment of a workload.make_face_job subject."""
-    sm = job['sm']
-    E = job['num_expressions']
-    m = so.prepare_model(dict(v_template=sm.v_template, shapedirs=sm.shapedirs, posedirs=sm.posedirs, weights=sm.weights,
-                              J_regressor=sm.J_regressor, parents=sm.parents, body_dof=sm.body_dof, hand_dof=sm.hand_dof,
-                              hands_mean=sm.hands_mean, selected_components=sm.selected_components), job['betas'])
-    so.set_free_shape(m, job['betas_expr_start_id'], E)
-    pr = so.prepare_gmm_prior(job['seq']['gmm'], 63)
-    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
-    closest, coef = so.transformed_coeffs(can, job['markers_latent'], exclude_vids=np.arange(9383, 10475))
-    return m, pr, closest, coef
+    m, pr, closest, coef = face_job_oracle(job)
+    assert np.array_equal(closest, solver.tc.closest) and np.abs(coef - solver.tc.coef).max() < 1e-12
+    g = _config3_golden()
+    H = int(g['frames'])
+    for ms in (7000, 7001, 7002):
+        cap = face_capture_host(job, m, closest, coef, ms, H)
+        ch = [dict(attach=solver.attach, obs=cap['obs'], vis=cap['vis'], first=True)]
+        for coop in (0, 1):
+            out = capi.chain_solve_host(solver.dev, solver.prior, solver.opts, ch, coop=coop)[0]
+            assert np.all(out['status'] == 0)
+            dp, ds, dtr, same = _hold_to_config3_golden(g, ms, out, H)
+            d = (out['markers_sim'] - cap['obs'])[cap['vis']]
+            print(f'config 3 capture {ms} ({capi.last_launch_info()[0]}): {H} frames vs oracle {dp:.2e} rad / {ds:.2e} (expression); iteration counts equal on '
+                  f'{same.mean() * 100:.1f} % of frames; marker rmse {np.sqrt((d ** 2).sum(1).mean()):.2e} m; data SSE max {out["errs"][:, 0].max():.1f}')
+            assert dp < 1e-6 and ds < 1e-6 and same.all()
