@@ -1416,7 +1416,6 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
                 const double v = W[bi];
                 double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl + (tid & 63);
                 *dst = v;
-                Lp[(ownA && q1 > j && rS[bi] >= 0) ? rS[bi] + j : trash] = v;   // (as a predicated store instead: hipcc 7.2 segfaults on this function)
             }
             // LDS-only barrier: the step exchanges data through Cv / pinv (LDS); a __syncthreads() would also wait for the
             // acknowledgement of the factor's global stores, ~2 us per step.  They are fenced once per block column.
@@ -1445,13 +1444,20 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
             pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
             if (!pair) pin1 = 0.0;
             if (tid == 0) { pinv[j] = pin0; if (pair) pinv[j + 1] = pin1; }
+            {   // the two columns go to the packed factor from the broadcast buffer, ONE row per thread (the owners' own stores were 2 NBLK
+                // store instructions per step with most lanes parked on a spare word: 3 300 lane-stores for the ~400 entries of the pair);
+                // lanes without a row park on a spare word of their own
+                const bool r0_ = tid > j && tid <= n, r1_ = pair && tid > j + 1 && tid <= n;
+                const int rowo = tid * (tid + 1) / 2;
+                const double c0v = cv[min(tid, CVR - 1)], c1v = cv[CVR + min(tid, CVR - 1)];
+                Lp[r0_ ? rowo + j : trash + 10 + tid] = c0v;
+                Lp[r1_ ? rowo + j + 1 : trash + 10 + tid] = fma(-c0v, l10, c1v);   // (the value the owners hold as ci1)
+            }
             ck1 = fma(-ck0, l10, ck1);
             ck0 *= pin0; ck1 *= pin1;
 #pragma unroll
             for (int b = bj0; b < NBLK; ++b) {
                 ci1[b] = fma(-ci0[b], l10, ci1[b]);
-                const int q1 = b * 16 + ty;
-                Lp[(ownB && pair && q1 > j + 1 && rS[b] >= 0) ? rS[b] + j + 1 : trash] = ci1[b];
                 W[b] = fma(-ci1[b], ck1, fma(-ci0[b], ck0, W[b]));
             }
         }

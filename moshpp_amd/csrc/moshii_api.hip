@@ -1005,7 +1005,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     }
     char* dbase = m->scratch.ptr + ctl;
     // extended variant: per-chain scratch for the shape derivatives of the joint transforms ([2][K][E][3] doubles)
-    const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;   // global packed factor + trash / zero words (ldl_big)
+    const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 + 256 : 0;   // global packed factor + trash / zero words + a spare word per thread (ldl_big)
     const size_t qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
     const int qranks = (coop_g > 0) ? coop_g : 1;   // (cooperative chains: a slice per rank -- every rank keeps its own derivative arrays / factor)
     if (E > 0) {
@@ -1239,7 +1239,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     size_t qbytes = 0;
     auto cleanup_shape = [&]() {};   // (released by `owned`)
     if (E > 0) {
-        const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 : 0;
+        const size_t nfac = (cfg.nblk > 8) ? (size_t)(cfg.ly.nmax + 1) * (cfg.ly.nmax + 2) / 2 + 12 + 256 : 0;
         qbytes = ((size_t)2 * m->K * E * 3 + nfac) * sizeof(double);
         if ((rc = m->qscratch.reserve(qbytes * NC))) { cleanup(); return rc; }
         m->qscratch.used = true; m->qscratch.last_stream = stream;
