@@ -1303,18 +1303,25 @@ __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n
     // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
     // Rows of the factor and 1/d_j are fetched a whole group of U steps ahead (an LDS round trip is several times the
     // readlane -> multiply -> fma chain of a step); rows are read branch-free (lanes beyond the row read the zero word).
+    // A step is readlane, multiply, fma and nothing else: no lane is ever overwritten with "its" solution inside the loop (the entries
+    // of row j on and beyond the diagonal are zeros, so y_j stays what it was when step j broadcast it) -- every lane multiplies its
+    // y by its own 1/d once, after the loop: the same product the step formed.  (Round 3's form selected lane j per step through the
+    // exec mask and branched on j >= 0: 178 cycles a step.)  Steps below row 0 of the last group run with 1/d = 0: no effect.
+    PROF_T(_tb0);
     if (tid < 64) {
-        constexpr int U = 8;
+        constexpr int U = 8;   // (2 / 4 / 8 rows ahead time the same: 5.2 us per solve, of which the 63 readlane -> multiply -> fma steps are the smaller part)
         constexpr bool HI = NBLK > 4;   // unknowns 64.. exist
         const int base = n * (n + 1) / 2;
         double y0 = Lp[(tid < n) ? base + tid : zero];
         double y1 = HI ? Lp[(tid + 64 < n) ? base + tid + 64 : zero] : 0.0;
+        const double pl0 = pinv[min(tid, max(n - 1, 0))];
+        const double pl1 = HI ? pinv[min(tid + 64, max(n - 1, 0))] : 0.0;
         double L0[U], L1[U], PV[U];
-        auto fetch = [&](int jr, double& a0, double& a1, double& pv) {   // row jr (rows below 0: row 0 again, harmlessly)
+        auto fetch = [&](int jr, double& a0, double& a1, double& pv) {   // row jr (rows below 0: nothing)
             const int jn = max(jr, 0), off = jn * (jn + 1) / 2;
             a0 = Lp[(tid < jn) ? off + tid : zero];
             a1 = HI ? Lp[(tid + 64 < jn) ? off + tid + 64 : zero] : 0.0;
-            pv = pinv[jn];
+            pv = (jr >= 0) ? pinv[jn] : 0.0;
         };
 #pragma unroll
         for (int u = 0; u < U; ++u) fetch(n - 1 - u, L0[u], L1[u], PV[u]);
@@ -1324,20 +1331,20 @@ __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n
             for (int u = 0; u < U; ++u) fetch(jb - U - u, N0[u], N1[u], NPV[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = __builtin_amdgcn_readfirstlane(jb - u);
-                if (j >= 0) {
-                    const double yj = (!HI || j < 64) ? readlane_f64(y0, j) : readlane_f64(y1, j - 64);
-                    const double dj = yj * PV[u];
-                    y0 = (tid == j) ? dj : fma(-L0[u], dj, y0);        // L0 / L1 are zero on and beyond the diagonal
-                    if (HI) y1 = (tid + 64 == j) ? dj : fma(-L1[u], dj, y1);
-                }
+                const int j = max(__builtin_amdgcn_readfirstlane(jb - u), 0);
+                double yj = readlane_f64(y0, j & 63);
+                if constexpr (HI) { const double yh = readlane_f64(y1, j & 63); yj = (j >= 64) ? yh : yj; }   // (a scalar select)
+                const double dj = yj * PV[u];
+                y0 = fma(-L0[u], dj, y0);        // L0 / L1 are zero on and beyond the diagonal
+                if (HI) y1 = fma(-L1[u], dj, y1);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) { L0[u] = N0[u]; L1[u] = N1[u]; PV[u] = NPV[u]; }
         }
-        if (tid < n) d[tid] = y0;
-        if (HI && tid + 64 < n) d[tid + 64] = y1;
+        if (tid < n) d[tid] = y0 * pl0;
+        if (HI && tid + 64 < n) d[tid + 64] = y1 * pl1;
     }
+    PROF_ACC(35, _tb0);
     __syncthreads();
     PROF_LAP(10);
 }

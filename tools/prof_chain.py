@@ -39,6 +39,7 @@ print(f'  calls (thread 0, wall): eval_forward_fn {p[15]*us_per_tick/F:.1f} (pha
       f' | ldl_solve {p[17]*us_per_tick/F:.1f} (inside {ph([9,10]):.1f}) | frame setup {p[18]*us_per_tick/F:.1f} | frame end {p[19]*us_per_tick/F:.1f} us/frame')
 print(f'  control (thread 0, wall): post-eval {p[23]*us_per_tick/F:.1f} | gradient max {p[24]*us_per_tick/F:.1f} | radius + start_iteration {p[25]*us_per_tick/F:.1f}'
       f' | trial point {p[27]*us_per_tick/F:.1f} us/frame')
+print(f'  back-substitution, thread 0 from entry to its last store: {p[35]*us_per_tick/F:.1f} us/frame')
 if p[33] or p[34]:
     print(f'  coop (thread 0, wall): drain + barrier before the flag {p[33]*us_per_tick/F:.1f} | flag store .. every rank seen {p[34]*us_per_tick/F:.1f} us/frame')
 print(f'  prior: shortcut taken {p[28]:.0f} times, full evaluation {p[29]:.0f} times')
