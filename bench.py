@@ -436,14 +436,18 @@ def main():
         ach = fl_timed / kt / 1e12
         result['roofline'] = {
             'kernel': name, 'bound': 'valu_f64',
-            'bound_note': 'neither hbm nor mfma: float64 vector pipe, instruction-count / latency-bound small dense solves with one wave per SIMD; memory side 44 KB/frame for a chain alone, ~410 KB/frame (mostly scratch write-back) with a chain on every CU (PMC)',
+            'bound_note': 'neither hbm nor mfma: float64 vector pipe, instruction-count / latency-bound small dense solves with one wave per SIMD; memory side 45 KB/frame for a one-workgroup chain alone, ~476 KB/frame (mostly scratch write-back) with a chain on every CU, 1.6 MB/frame for a cooperative chain (write-through exchanges) (PMC)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
             # PMC (separate FETCH_SIZE / WRITE_SIZE passes over a seed-1000 bench step, profiles/r02_chain_pmc.txt): the pass-1 launch
             # moves 2 x 1.27 GB fetched (wide-load correction of the guide) + 2.89 GB written for its 13 250 solved frames = 410 KB per
             # solved frame (a chain alone on the GPU: 44 KB, profiles/r01_chain_pmc.txt), the repair launches < 0.1 GB; scaled to
             # the frames pass 1 of the timed mode solves
-            'traffic': int(410e3 * (F + (rep['n_chunks'] * (rep['warmup'] + 5) if rep else 0))),
-            'traffic_source': 'rocprofv3 PMC per solved frame of the pass-1 launch (profiles/r02_chain_pmc.txt) x frames solved in pass 1 of one step; not collected live',
+            # PMC (separate FETCH_SIZE / WRITE_SIZE passes over a seed-1000 step, profiles/r04_chain_pmc.txt, tools/r04_collect.sh): the
+            # pass-1 launch (250 one-workgroup chains x 48 frames) 2 x 1.25 GB fetched (wide-load correction of the guide) + 3.22 GB
+            # written = 476 KB per solved frame (scratch write-back: 250 x 256 lanes x 1552 B do not fit the L2s); the cooperative repair
+            # rounds of that step 2 x 0.18 + 0.78 GB (their exchanges are write-through by design).  Scaled to the frames pass 1 solves.
+            'traffic': int(476e3 * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0)) + (1.14e9 if rep else 0)),
+            'traffic_source': 'rocprofv3 PMC of one seed-1000 step (profiles/r04_chain_pmc.txt): pass-1 launch per solved frame x frames solved in pass 1, + the cooperative repair rounds of that step; not collected live',
             # the same fraction seed by seed (round 1 quoted seed 1000 alone: 0.0058; `frac` above is over all timed steps)
             'frac_by_seed': {str(sd): round(sum(fl_seed[sd] for k in range(args.steps) if seeds[k % len(seeds)] == sd)
                                             / max(sum(float(step_ms[k]) for k in range(args.steps) if seeds[k % len(seeds)] == sd) * 1e-3, 1e-12)
@@ -530,7 +534,7 @@ def main():
             fl_many = fl * args.strong_sequences
             mach = fl_many / (sj['ms'] * 1e-3) / 1e12
             result['many_sequences'] = {'sequences': args.strong_sequences, 'frames': sj['frames'], 'frames_per_s': sj['frames_per_s'], 'ms': sj['ms'],
-                                        'roofline': {'kernel': name, 'bound': 'valu_f64', 'achieved': round(mach, 4), 'peak': F64_VALU_PEAK_TFLOPS,
+                                        'roofline': {'kernel': 'k_chain_solve<4,1> chunk chains + cooperative repair chains', 'bound': 'valu_f64', 'achieved': round(mach, 4), 'peak': F64_VALU_PEAK_TFLOPS,
                                                      'unit': 'TFLOP/s', 'frac': round(mach / F64_VALU_PEAK_TFLOPS, 5)}}
         # ---- BASELINE config 3 as stated: 32 x 4000-frame SMPL-X captures, 89 markers incl. face / hands, fingers + jaw + 80 expression
         # coefficients free (194 unknowns per Step-2 solve; chmosh.py:560-567, 681-689).  With a free expression block a chunk start

@@ -153,22 +153,24 @@ class StageIISolver:
         self.optimize_face = bool(optimize_face)
         self.optimize_dynamics = bool(optimize_dynamics)
 
-    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, init=None):
+    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, init=None, coop_group=0):
         """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
         chain_mode 'sequential': one chain, the reference's exact frame order (chmosh.py:584).
         chain_mode 'chunked': moshii_sequence_solve -- concurrent chunks with warm-up overlap, verified and
         repaired against the sequential chain to `verify_tol` (out['chunk_report']); free expression / DMPL coefficients travel in
-        the hand-off states.  chain_mode 'chunked_host': the same scheme driven from the host (parallel.solve_sequence_chunked_host)."""
+        the hand-off states.  chain_mode 'chunked_host': the same scheme driven from the host (parallel.solve_sequence_chunked_host).
+        coop_group: 0 = the library's choice (a lone chain / the repair sweeps of a chunked solve run as COOPERATIVE chains of several
+        workgroups where that pays: body and finger solves), 1 = one workgroup per chain always, 2..8 = that many (capi.coop_group)."""
         F = obs.shape[0]
         # init = dict(pose, trans, pose_prev | None): continue a chain from that state (no first-frame schedule)
         ikw = {} if init is None else dict(init_pose=init['pose'], init_trans=init['trans'], init_pose_prev=init.get('pose_prev'))
         if chain_mode == 'sequential' or F == 0:
             out = capi.chain_solve_host(self.dev, self.prior, self.opts,
-                                        [dict(attach=self.attach, obs=obs, vis=vis, first=init is None, **ikw)])[0]
+                                        [dict(attach=self.attach, obs=obs, vis=vis, first=init is None, **ikw)], coop=coop_group)[0]
             return out
         if chain_mode == 'chunked':
             outs, report = capi.sequence_solve_host(self.dev, self.prior, self.opts, [dict(attach=self.attach, obs=obs, vis=vis, **ikw)],
-                                                    num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol)
+                                                    num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol, coop=coop_group)
             outs[0]['chunk_report'] = report
             return outs[0]
         if chain_mode == 'chunked_host':
@@ -269,7 +271,7 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     default_mode = 'sequential'
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
-                       verify_tol=float(_get(ext, 'verify_tol', 1e-11)))
+                       verify_tol=float(_get(ext, 'verify_tol', 1e-11)), coop_group=int(_get(ext, 'coop_group', 0)))
     for fi in np.flatnonzero(out['status'] == 1):
         logger.error(f'no available observed markers for frame {selected_frames[fi]}. skipping the frame.')
     if np.any(out['status'] < 0):
