@@ -1309,37 +1309,42 @@ __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n
     // exec mask and branched on j >= 0: 178 cycles a step.)  Steps below row 0 of the last group run with 1/d = 0: no effect.
     PROF_T(_tb0);
     if (tid < 64) {
-        constexpr int U = 8;   // (2 / 4 / 8 rows ahead time the same: 5.2 us per solve, of which the 63 readlane -> multiply -> fma steps are the smaller part)
+        constexpr int U = 8;
         constexpr bool HI = NBLK > 4;   // unknowns 64.. exist
         const int base = n * (n + 1) / 2;
         double y0 = Lp[(tid < n) ? base + tid : zero];
         double y1 = HI ? Lp[(tid + 64 < n) ? base + tid + 64 : zero] : 0.0;
         const double pl0 = pinv[min(tid, max(n - 1, 0))];
         const double pl1 = HI ? pinv[min(tid + 64, max(n - 1, 0))] : 0.0;
-        double L0[U], L1[U], PV[U];
-        auto fetch = [&](int jr, double& a0, double& a1, double& pv) {   // row jr (rows below 0: nothing)
-            const int jn = max(jr, 0), off = jn * (jn + 1) / 2;
-            a0 = Lp[(tid < jn) ? off + tid : zero];
-            a1 = HI ? Lp[(tid + 64 < jn) ? off + tid + 64 : zero] : 0.0;
-            pv = (jr >= 0) ? pinv[jn] : 0.0;
+        // The wavefront issues one instruction at a time, so a step costs its instruction count: the row fetch is kept to a scalar
+        // subtract (the row offset j (j + 1) / 2 steps down by j), the address, the select of the zero word and the read -- round 3's
+        // form recomputed the offset with a multiply and branched around a per-row read of 1 / d_j: 24 instructions a step, of which
+        // the readlane -> multiply -> fma chain was six.  1 / d_j now comes from the lane that owns unknown j (every lane forms
+        // y pinv, lane j's product is the one broadcast: the same product as before).
+        double L0[U], L1[U];
+        int jr = n - 1, offr = base - n;   // the next row to fetch and its offset jr (jr + 1) / 2   (scalars)
+        auto fetch = [&](double& a0, double& a1) {   // (rows <= 0 have no entries: zeros)
+            a0 = Lp[(tid < jr) ? offr + tid : zero];
+            a1 = HI ? Lp[(tid + 64 < jr) ? offr + tid + 64 : zero] : 0.0;
+            offr -= jr; --jr;
         };
 #pragma unroll
-        for (int u = 0; u < U; ++u) fetch(n - 1 - u, L0[u], L1[u], PV[u]);
-        for (int jb = n - 1; jb >= 0; jb -= U) {
-            double N0[U], N1[U], NPV[U];
+        for (int u = 0; u < U; ++u) fetch(L0[u], L1[u]);
+        for (int jb = n - 1; jb >= 1; jb -= U) {
+            double N0[U], N1[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) fetch(jb - U - u, N0[u], N1[u], NPV[u]);
+            for (int u = 0; u < U; ++u) fetch(N0[u], N1[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = max(__builtin_amdgcn_readfirstlane(jb - u), 0);
-                double yj = readlane_f64(y0, j & 63);
-                if constexpr (HI) { const double yh = readlane_f64(y1, j & 63); yj = (j >= 64) ? yh : yj; }   // (a scalar select)
-                const double dj = yj * PV[u];
+                const int j = max(jb - u, 0);
+                const double v0 = y0 * pl0;
+                double dj = readlane_f64(v0, j & 63);
+                if constexpr (HI) { const double v1 = y1 * pl1; const double dh = readlane_f64(v1, j & 63); dj = (j >= 64) ? dh : dj; }   // (a scalar select)
                 y0 = fma(-L0[u], dj, y0);        // L0 / L1 are zero on and beyond the diagonal
                 if (HI) y1 = fma(-L1[u], dj, y1);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) { L0[u] = N0[u]; L1[u] = N1[u]; PV[u] = NPV[u]; }
+            for (int u = 0; u < U; ++u) { L0[u] = N0[u]; L1[u] = N1[u]; }
         }
         if (tid < n) d[tid] = y0 * pl0;
         if (HI && tid + 64 < n) d[tid + 64] = y1 * pl1;
