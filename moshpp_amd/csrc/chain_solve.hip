@@ -15,6 +15,7 @@
 // per-phase timings and the rules this file follows (branch-free LDS traffic, loads batched ahead of use).
 #include "moshii_dev.h"
 #include <utility>
+#include <type_traits>
 
 namespace moshii {
 
@@ -191,6 +192,52 @@ __device__ __forceinline__ void coop_st(MOSHII_GP(unsigned long long) p, double 
 __device__ __forceinline__ double coop_ld(MOSHII_GP(unsigned long long) p) {
     return bits_f64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// The same accesses at the scope of ONE XCD's L2: for groups whose ranks found themselves on one XCD (CoopCtx::xcd_local; k_chain_solve
+// checks the hardware's XCC id of every rank at its start).  Stores sc0 -- acknowledged by the L2, where an agent-scope (sc1) store is
+// written through to the memory side before the storing wave's vmcnt moves -- and loads sc0 nt: a plain sc0 load is served by this CU's
+// L1 (tools/ubench_scope.hip: a word cached there is never seen to change, with or without buffer_inv sc0), a non-temporal one never is.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void coop_st_l2(MOSHII_GP(unsigned long long) p, unsigned long long v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned long long coop_ld_l2(MOSHII_GP(unsigned long long) p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void coop_st32_l2(MOSHII_GP(unsigned int) p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned coop_ld32_l2(MOSHII_GP(unsigned int) p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc0 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+#endif
+template <bool L2> __device__ __forceinline__ void coop_st64(MOSHII_GP(unsigned long long) p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (L2) { coop_st_l2(p, v); return; }
+#endif
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool L2> __device__ __forceinline__ unsigned long long coop_ld64(MOSHII_GP(unsigned long long) p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (L2) return coop_ld_l2(p);
+#endif
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool L2> __device__ __forceinline__ void coop_st32(MOSHII_GP(unsigned int) p, unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (L2) { coop_st32_l2(p, v); return; }
+#endif
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool L2> __device__ __forceinline__ unsigned coop_ld32(MOSHII_GP(unsigned int) p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (L2) return coop_ld32_l2(p);
+#endif
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned coop_begin(const Ctx& cx) { return (unsigned)__builtin_amdgcn_readfirstlane((int)cx.scal[S_COOP_SEQ]) + 1u; }   // (a scalar)
 __device__ __forceinline__ MOSHII_GP(unsigned long long) coop_slot(const CoopCtx& co, unsigned seq, int r) {
     return co.slots + ((size_t)(seq & 1u) * co.G + r) * co.slot_doubles;
@@ -205,23 +252,31 @@ __device__ __forceinline__ CoopSlot coop_slot16(const CoopCtx& co, unsigned seq,
     cs.rs = __builtin_amdgcn_make_buffer_rsrc((void*)coop_slot(co, seq, r), 0, co.slot_doubles * 8, 0x00020000);
     return cs;
 }
+template <bool L2 = false>
 __device__ __forceinline__ void coop_st16(const CoopSlot& cs, int off16, double a, double b) {
     const unsigned long long ba = f64_bits(a), bb = f64_bits(b);
     const coop_u4 v = {(unsigned)ba, (unsigned)(ba >> 32), (unsigned)bb, (unsigned)(bb >> 32)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, cs.rs, off16 * 16, 0, 16);   // (aux 16: sc1)
+    if constexpr (L2) __builtin_amdgcn_raw_buffer_store_b128(v, cs.rs, off16 * 16, 0, 1);   // (aux 1: sc0)
+    else __builtin_amdgcn_raw_buffer_store_b128(v, cs.rs, off16 * 16, 0, 16);               // (aux 16: sc1)
 }
+template <bool L2 = false>
 __device__ __forceinline__ void coop_ld16(const CoopSlot& cs, int off16, double& a, double& b) {
-    const coop_u4 v = __builtin_amdgcn_raw_buffer_load_b128(cs.rs, off16 * 16, 0, 16);
+    coop_u4 v;
+    if constexpr (L2) v = __builtin_amdgcn_raw_buffer_load_b128(cs.rs, off16 * 16, 0, 3);   // (aux 3: sc0 nt)
+    else v = __builtin_amdgcn_raw_buffer_load_b128(cs.rs, off16 * 16, 0, 16);
     a = bits_f64(((unsigned long long)v[1] << 32) | v[0]);
     b = bits_f64(((unsigned long long)v[3] << 32) | v[2]);
 }
 #else
 struct CoopSlot { MOSHII_GP(unsigned long long) p; };
 __device__ __forceinline__ CoopSlot coop_slot16(const CoopCtx& co, unsigned seq, int r) { CoopSlot cs; cs.p = coop_slot(co, seq, r); return cs; }
+template <bool L2 = false>
 __device__ __forceinline__ void coop_st16(const CoopSlot& cs, int off16, double a, double b) { coop_st(cs.p + 2 * (size_t)off16, a); coop_st(cs.p + 2 * (size_t)off16 + 1, b); }
+template <bool L2 = false>
 __device__ __forceinline__ void coop_ld16(const CoopSlot& cs, int off16, double& a, double& b) { a = coop_ld(cs.p + 2 * (size_t)off16); b = coop_ld(cs.p + 2 * (size_t)off16 + 1); }
 #endif
 // All threads call, after their payload stores: publish this rank's slot, wait for every rank's.  false: the group is broken.
+template <bool L2 = false>
 __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& cx, unsigned seq) {
     const int tid = threadIdx.x;
     PROF_T(_tp0);
@@ -229,12 +284,12 @@ __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& 
     __syncthreads();
     PROF_ACC(33, _tp0);
     PROF_T(_tp1);
-    if (tid == 0) __hip_atomic_store(co.flags + co.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) coop_st32<L2>(co.flags + co.rank, seq);
     TRACE_STAMP(co, seq, 1);
     if (tid < co.G && cx.scal[S_COOP_FAIL] == 0.0) {
         bool ok = true;
         unsigned spins = 0;
-        while ((int)(__hip_atomic_load(co.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+        while ((int)(coop_ld32<L2>(co.flags + tid) - seq) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0u)   // now and then: has somebody given up?  have we waited for about a second?
                 if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
@@ -258,8 +313,8 @@ __device__ __forceinline__ void coop_end(const Ctx& cx, unsigned seq) {
 // A few numbers per rank (NS <= 4 doubles): 8-byte {tag = sequence number, half a double} granules in the last 32 words of the slot --
 // the data is its own flag (Guideline 16, form R2): no drain, no flag hop; a reader polls the granule until its tag is this exchange's.
 // All threads call; on return land[r * NS + k] (LDS) holds value k of rank r.  Follow with coop_end().
-template <int NS>
-__device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx& cx, unsigned seq, const double (&mine)[NS], double* land) {
+template <int NS, bool L2>
+__device__ __forceinline__ bool coop_exchange_small_(const CoopCtx& co, const Ctx& cx, unsigned seq, const double (&mine)[NS], double* land) {
     const int tid = threadIdx.x;
     const int goff = co.slot_doubles - 32;
     if (tid < 2 * NS) {
@@ -268,7 +323,7 @@ __device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx
         for (int k = 1; k < NS; ++k) if ((tid >> 1) == k) v = mine[k];
         const unsigned long long b = f64_bits(v);
         const unsigned half = (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b;
-        __hip_atomic_store(coop_slot(co, seq, co.rank) + goff + tid, ((unsigned long long)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        coop_st64<L2>(coop_slot(co, seq, co.rank) + goff + tid, ((unsigned long long)seq << 32) | half);
     }
     TRACE_STAMP(co, seq, 1);
     if (tid < co.G * 2 * NS && cx.scal[S_COOP_FAIL] == 0.0) {
@@ -277,7 +332,7 @@ __device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx
         unsigned long long x;
         unsigned spins = 0;
         bool ok = true;
-        while (((x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+        while (((x = coop_ld64<L2>(g)) >> 32) != seq) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0u)
                 if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
@@ -291,6 +346,11 @@ __device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx
     __syncthreads();
     TRACE_STAMP(co, seq, 2);
     return cx.scal[S_COOP_FAIL] == 0.0;
+}
+template <int NS>
+__device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx& cx, unsigned seq, const double (&mine)[NS], double* land) {
+    if (co.xcd_local) return coop_exchange_small_<NS, true>(co, cx, seq, mine, land);   // (uniform)
+    return coop_exchange_small_<NS, false>(co, cx, seq, mine, land);
 }
 
 // Rodrigues + SO(3) left Jacobian; same formulas and small-angle switch as oracle/stageii_oracle.py:rodrigues.
@@ -1363,155 +1423,296 @@ __device__ __forceinline__ bool ldl_solve(const AReg<NBLK>& A, int o_Lp, int o_g
 
 // n > 127 unknowns (extended variant, NBLK > 8).  Neither a packed factor in LDS (151 KB for n = 194) nor a second
 // register copy of the matrix (91 entries per thread) is affordable, so the elimination is LEFT-looking by 16-column
-// block: only the current block column is live in registers (<= NBLK entries per thread, taken from A, which stays
-// untouched), it first receives the updates of every finished column from the packed factor -- kept in this chain's
-// GLOBAL scratch (L2-resident; a row is read by 16 lanes at the same address) -- and is then eliminated two columns per
-// barrier exactly like ldl_solve, restricted to itself.  LDS holds the column broadcast buffer and a 16-row panel through
-// which the back-substitution streams the factor; every lane of wave 0 owns up to four unknowns.
-//   Lp (global): packed factor, entry (i, j) at i (i + 1) / 2 + j, rows 0..n (row n = right-hand side); [trash] spare word,
-//                [zero .. zero + 7] zeros.   Sl (LDS): [0 .. 63] per-lane trash, [64] zero, [66 ..] Cv [2][2][CVR], then the panel [16][CVR].
-template <int NBLK>
-__device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* d, double* pinv, int n) {
-    const int tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;
-    PROF_BEGIN(); PROF_COUNT(22);
-    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
-    constexpr int CVR = NBLK * 16;
-    double* Cv = Sl + 66;
-    int rS[NBLK];
+// block: only the current block column is live (<= NBLK entries per thread, taken from A, which stays untouched).  The packed
+// factor -- entries c_ij = l_ij d_j, row n = the right-hand side -- is kept in this chain's GLOBAL scratch (L2-resident).
+// Per block column b (round 4; round 3 eliminated two columns per barrier with everybody, updated with scalar fmas from L2 and
+// streamed the back-substitution through one LDS panel: 130 + 110 + 61 us per solve at n = 194):
+//   E  wavefront 0 eliminates the 16 columns of panel b inside the panel, lane = row (up to four rows per lane), pivots and
+//      multipliers by v_readlane, exactly like ldl_panel_eliminate; the panel goes back to LDS (Wp) and out to the packed factor;
+//   U1 MEANWHILE wavefronts 1..3 form, for block column b + 1, the products with the panels 0 .. b - 1 that are already final:
+//      U[bi] = sum_c C[16 bi + r][c] C[16 (b + 1) + s][c] / d_c on the f64 matrix pipe (v_mfma_f64_16x16x4: 16 columns = 4 MFMAs
+//      per tile, operands straight from L2, next group's loads in flight), and pass the tiles through LDS (Ux);
+//   U2 everybody: W = A - U - (panel b's 16 columns, read from Wp in LDS), the block column b + 1 goes to Wp.
+// Three barriers per 16 columns.  Back-substitution: wavefronts 1..3 stage 16 rows of the factor at a time in LDS (two buffers),
+// wavefront 0 runs the steps (readlane -> fma, the rows fetched two steps ahead).
+//   Lp (global): packed factor, entry (i, j) at i (i + 1) / 2 + j, rows 0..n; [trash .. trash + 265] spare words, [zero .. zero + 7] zeros.
+//   Sl (LDS): [0 .. 63] per-lane trash, [64] zero, [65] "a pivot was not positive", [66 ..] Wp [CVR][17], Ux [NBLK][256]
+//             (the back-substitution's two [16][CVR] buffers lie over Wp / Ux).
+// E: wavefront 0 eliminates the 16 columns of panel P inside the panel (lane r = rows 16 P + r, + 64, ...; pivots and multipliers by
+// v_readlane as in ldl_panel_eliminate), writes the panel back to Wp and out to the packed factor.
+// (Tried: wavefront 0 on the diagonal block alone, multipliers through LDS, the rows below one per thread by everybody -- the same
+//  arithmetic on four times the lanes.  Slower, 4.0 against 3.84 ms per cold frame: the phase is as long as the MFMA products the
+//  other three wavefronts form meanwhile (U1), and the split adds a barrier and a second pass over Wp to every block column.)
+template <int NBLK, int P, bool FULL>
+__device__ __noinline__ bool big_panel_eliminate(double* Lp, double* Sl, double* pinv, int n, int lane) {
+    constexpr int CVR = NBLK * 16, WS = 17, c0 = 16 * P;
+    constexpr int NS = (CVR - c0 + 63) / 64;      // rows per lane
+    double* Wp = Sl + 66;
+    const int trashg = (n + 1) * (n + 2) / 2;
+    double a[NS][16];
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-        const int q1 = b * 16 + ty;
-        rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const int row = c0 + 64 * s_ + lane;
+        const double* rp = (row < CVR) ? Wp + row * WS : Sl + 64;   // (rows beyond the matrix: zeros)
+        const int st = (row < CVR) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[s_][k] = rp[k * st];
     }
-    if (tid == 0) Sl[64] = 0.0;
-    if (tid < 8) Lp[zero + tid] = 0.0;
-    bool ok = true;
-    int step = 0;
+    bool bad = false;
 #pragma unroll
-    for (int bj0 = 0; bj0 < NBLK; ++bj0) {   // (no early exit from THIS loop: with one, hipcc refuses to unroll it -- the
-        if (ok && bj0 * 16 < n) {             //  barriers inside are convergent -- and every array below lands in scratch)
-        // working block column of [A; g^T]
-        double W[NBLK];
-        const int q2 = bj0 * 16 + tx;
-        const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);
+    for (int j = 0; j < 16; ++j) {
+        if (FULL || c0 + j < n) {   // (uniform: the border row's own "column" is not eliminated)
+            const double pj = readlane_f64(a[0][j], j);
+            bad = bad || !(pj > 0.0);
+            double pin = __builtin_amdgcn_rcp(pj);
+            pin = fma(fma(-pj, pin, 1.0), pin, pin);
+            pin = fma(fma(-pj, pin, 1.0), pin, pin);
+            *((lane == 0) ? pinv + c0 + j : Sl + lane) = pin;
+            const double lj = a[0][j] * pin;
+            double lkv[16];
 #pragma unroll
-        for (int bi = bj0; bi < NBLK; ++bi) W[bi] = (bi * 16 + ty == n) ? gq : A.a[bi * (bi + 1) / 2 + bj0];
-        __syncthreads();   // the previous block column's last stores (and pivots) are visible
-        if (bj0 > 0) {
-            // W[bi] -= sum_{c < 16 bj0} C[q1][c] C[q2][c] / d_c     (C = the stored entries l_ic d_c)
-            const double* rk = Lp + ((q2 <= n) ? q2 * (q2 + 1) / 2 : zero);
-            const int kstep = (q2 <= n) ? 1 : 0;   // rows beyond the border read the zero words
-            for (int c0 = 0; c0 < bj0 * 16; c0 += 8) {   // 8 columns per batch: (rows + 1) x 8 independent loads in flight
-                double t[8];
+            for (int k = j + 1; k < 16; ++k) lkv[k] = readlane_f64(lj, k);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = rk[(c0 + u) * kstep] * pinv[c0 + u];
+            for (int k = j + 1; k < 16; ++k)
 #pragma unroll
-                for (int bi = bj0; bi < NBLK; ++bi) {
-                    const double* rp = Lp + ((rS[bi] >= 0) ? rS[bi] + c0 : zero);
-                    W[bi] -= ((rp[0] * t[0] + rp[1] * t[1]) + (rp[2] * t[2] + rp[3] * t[3])) +
-                             ((rp[4] * t[4] + rp[5] * t[5]) + (rp[6] * t[6] + rp[7] * t[7]));
+                for (int s_ = 0; s_ < NS; ++s_) a[s_][k] = fma(-a[s_][j], lkv[k], a[s_][k]);
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const int row = c0 + 64 * s_ + lane;
+        // back to LDS for the next block column's update (rows below the diagonal block are what it reads) ...
+        double* wp = (row < CVR) ? Wp + row * WS : Sl + lane;
+        const int st = (row < CVR) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wp[k * st] = a[s_][k];
+        // ... and out to the packed factor: entries on and left of the diagonal, rows up to the border row
+        const int off = row * (row + 1) / 2 + c0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lp[(row <= n && c0 + k <= row) ? off + k : trashg + 10 + lane] = a[s_][k];
+    }
+    return bad;
+}
+// U1 (see above): one wavefront's tiles of block column bn against the final panels 0 .. bn - 2.  w3: 0..2 (wavefronts 1..3).
+template <int NBLK>
+__device__ __noinline__ void big_update_mfma(const double* Lp, double* Ux, const double* pinv, int n, int bn, int NB, int w3, int lane) {
+    constexpr int TW = (NBLK + 2) / 3;   // tiles per wavefront at most
+    const int zero = (n + 1) * (n + 2) / 2 + 1;
+    const int m = lane & 15, kq = lane >> 4;
+    const int rB = 16 * bn + m;
+    const double* pB = Lp + ((rB <= n) ? rB * (rB + 1) / 2 : zero) + ((rB <= n) ? 4 * kq : 0);
+    const int sB = (rB <= n) ? 1 : 0;
+    const double* pA[TW];
+    int sA[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int rA = 16 * (bn + w3 + 3 * t) + m;
+        pA[t] = Lp + ((rA <= n) ? rA * (rA + 1) / 2 : zero) + ((rA <= n) ? 4 * kq : 0);
+        sA[t] = (rA <= n) ? 1 : 0;
+    }
+    v4d acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int ng = bn - 1;   // groups of 16 final columns
+    // The products are a few MFMAs; what costs is the round trip to the L2 for their operands -- so the groups go in chunks whose loads
+    // are ALL in flight before the first is used (<= ~56 per lane: the vector-memory counter tells 63 apart): four groups at a time for a
+    // wavefront with one or two tiles (late block columns: many groups), down to two with five tiles (early ones: few groups).
+    int nt = 0;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) nt += (bn + w3 + 3 * t < NB) ? 1 : 0;
+    auto chunk = [&](auto gu_, int g0) {
+        constexpr int GU = decltype(gu_)::value;
+        double B_[GU][4], A_[GU][TW][4], P_[GU][4];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int g = min(g0 + u, ng - 1);   // (a chunk's surplus groups re-read the last one: multiplied by 0 below)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) { B_[u][s_] = pB[(16 * g + s_) * sB]; P_[u][s_] = pinv[16 * g + 4 * kq + s_]; }
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+                if (bn + w3 + 3 * t < NB) {   // (uniform)
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) A_[u][t][s_] = pA[t][(16 * g + s_) * sA[t]];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            if (g0 + u < ng) {   // (uniform)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const double bs = B_[u][s_] * P_[u][s_];
+#pragma unroll
+                    for (int t = 0; t < TW; ++t)
+                        if (bn + w3 + 3 * t < NB) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[u][t][s_], bs, acc[t], 0, 0, 0);
                 }
             }
         }
-        PROF_LAP(13);
-        for (int jl = 0; jl < 16; jl += 2) {
-            const int j = bj0 * 16 + jl;
-            if (j >= n) break;
-            const bool pair = j + 1 < n;
-            double* cv = Cv + (step & 1) * 2 * CVR;
-            ++step;
-            const bool ownA = tx == jl, ownB = tx == jl + 1;
+    };
+    if (nt <= 2) { for (int g0 = 0; g0 < ng; g0 += 4) chunk(std::integral_constant<int, 4>(), g0); }
+    else if (nt == 3) { for (int g0 = 0; g0 < ng; g0 += 3) chunk(std::integral_constant<int, 3>(), g0); }
+    else { for (int g0 = 0; g0 < ng; g0 += 2) chunk(std::integral_constant<int, 2>(), g0); }
+    // register i of lane l holds entry ((l >> 4) + 4 i, l & 15) of the tile = thread (wavefront i, lane l)'s entry (AReg)
 #pragma unroll
-            for (int bi = bj0; bi < NBLK; ++bi) {
-                const int q1 = bi * 16 + ty;
-                const double v = W[bi];
-                double* dst = (ownA || ownB) ? cv + (ownB ? CVR : 0) + q1 : Sl + (tid & 63);
-                *dst = v;
-            }
-            // LDS-only barrier: the step exchanges data through Cv / pinv (LDS); a __syncthreads() would also wait for the
-            // acknowledgement of the factor's global stores, ~2 us per step.  They are fenced once per block column.
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const double p0 = cv[j], a10 = cv[j + 1], p1r = cv[CVR + j + 1];
-            double ci0[NBLK], ci1[NBLK];
-            const double* zr = Sl + 64;
+    for (int t = 0; t < TW; ++t)
+        if (bn + w3 + 3 * t < NB) {
 #pragma unroll
-            for (int b = bj0; b < NBLK; ++b) {
-                const int q1 = b * 16 + ty;
-                const bool vr = q1 > j + 1 && q1 <= n;
-                const double* r0 = vr ? cv + q1 : zr; const double* r1 = vr ? cv + CVR + q1 : zr;
-                ci0[b] = *r0; ci1[b] = *r1;
-            }
-            const bool vc = q2 > j + 1 && q2 <= n;
-            double ck0 = *(vc ? cv + q2 : zr), ck1 = *(vc ? cv + CVR + q2 : zr);
-            if (!(p0 > 0.0)) { ok = false; break; }
-            double pin0 = __builtin_amdgcn_rcp(p0);
-            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
-            pin0 = fma(fma(-p0, pin0, 1.0), pin0, pin0);
-            const double l10 = a10 * pin0;
-            const double p1 = pair ? fma(-a10, l10, p1r) : 1.0;
-            if (!(p1 > 0.0)) { ok = false; break; }
-            double pin1 = __builtin_amdgcn_rcp(p1);
-            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
-            pin1 = fma(fma(-p1, pin1, 1.0), pin1, pin1);
-            if (!pair) pin1 = 0.0;
-            if (tid == 0) { pinv[j] = pin0; if (pair) pinv[j + 1] = pin1; }
-            {   // the two columns go to the packed factor from the broadcast buffer, ONE row per thread (the owners' own stores were 2 NBLK
-                // store instructions per step with most lanes parked on a spare word: 3 300 lane-stores for the ~400 entries of the pair);
-                // lanes without a row park on a spare word of their own
-                const bool r0_ = tid > j && tid <= n, r1_ = pair && tid > j + 1 && tid <= n;
-                const int rowo = tid * (tid + 1) / 2;
-                const double c0v = cv[min(tid, CVR - 1)], c1v = cv[CVR + min(tid, CVR - 1)];
-                Lp[r0_ ? rowo + j : trash + 10 + tid] = c0v;
-                Lp[r1_ ? rowo + j + 1 : trash + 10 + tid] = fma(-c0v, l10, c1v);   // (the value the owners hold as ci1)
-            }
-            ck1 = fma(-ck0, l10, ck1);
-            ck0 *= pin0; ck1 *= pin1;
-#pragma unroll
-            for (int b = bj0; b < NBLK; ++b) {
-                ci1[b] = fma(-ci0[b], l10, ci1[b]);
-                W[b] = fma(-ci1[b], ck1, fma(-ci0[b], ck0, W[b]));
-            }
+            for (int i = 0; i < 4; ++i) Ux[(bn + w3 + 3 * t) * 256 + i * 64 + lane] = acc[t][i];
         }
-        PROF_LAP(14);
+}
+// back-substitution steps of one staged 16-row panel whose rows lie in lane group KK (unknowns 64 KK .. 64 KK + 63)
+template <int NY, int KK>
+__device__ __forceinline__ void big_backsub_panel(const double* sb, int CVR, int jlo, int jhi, int lane, double (&y)[NY], const double (&pl)[NY]) {
+    double l0[NY], l1[NY];
+    auto fetch = [&](int j, double (&l)[NY]) {
+        const int r = max(j - jlo, 0);
+#pragma unroll
+        for (int k = 0; k <= KK; ++k) l[k] = sb[r * CVR + lane + 64 * k];
+    };
+    fetch(jhi, l0);
+    for (int j = jhi; j >= jlo; j -= 2) {
+        fetch(j - 1, l1);
+        {
+            const double dj = readlane_f64(y[KK] * pl[KK], j & 63);
+#pragma unroll
+            for (int k = 0; k <= KK; ++k) y[k] = fma(-l0[k], dj, y[k]);
+        }
+        fetch(j - 2, l0);
+        if (j - 1 >= jlo) {
+            const double dj = readlane_f64(y[KK] * pl[KK], (j - 1) & 63);
+#pragma unroll
+            for (int k = 0; k <= KK; ++k) y[k] = fma(-l1[k], dj, y[k]);
+        }
+    }
+}
+// block column B (elimination, update of B + 1) and on to B + 1; false: a pivot was not positive
+template <int NBLK, int B>
+__device__ __forceinline__ bool big_blocks(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* pinv, int n, int NB) {
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int CVR = NBLK * 16, WS = 17;
+    double* Wp = Sl + 66;
+    double* Ux = Wp + CVR * WS;
+    if (B >= NB) return true;   // (uniform)
+    if (wv == 0) {
+        const bool bad = (16 * B + 16 <= n) ? big_panel_eliminate<NBLK, B, true>(Lp, Sl, pinv, n, lane)
+                                             : big_panel_eliminate<NBLK, B, false>(Lp, Sl, pinv, n, lane);
+        if (bad && lane == 0) Sl[65] = 1.0;
+    } else if (B + 1 < NB && B >= 1) {
+        big_update_mfma<NBLK>(Lp, Ux, pinv, n, B + 1, NB, wv - 1, lane);
+    }
+    __syncthreads();
+    PROF_LAP_EXT(14);
+    if (Sl[65] != 0.0) return false;   // (every thread sees it)
+    if constexpr (B + 1 < NBLK) {
+        if (B + 1 < NB) {
+            // W = A - U1 - (panel B's columns)
+            double W[NBLK];
+            const int q2 = (B + 1) * 16 + tx;
+            const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);
+#pragma unroll
+            for (int bi = B + 1; bi < NBLK; ++bi) {
+                const double v = (bi * 16 + ty == n) ? gq : A.a[bi * (bi + 1) / 2 + B + 1];
+                W[bi] = (B >= 1 && bi < NB) ? v - Ux[bi * 256 + tid] : v;
+            }
+            const double* wk = Wp + q2 * WS;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const double ck = wk[jj] * pinv[16 * B + jj];
+#pragma unroll
+                for (int bi = B + 1; bi < NBLK; ++bi) W[bi] = fma(-Wp[(bi * 16 + ty) * WS + jj], ck, W[bi]);
+            }
+            __syncthreads();   // every read of panel B in Wp is done
+#pragma unroll
+            for (int bi = B + 1; bi < NBLK; ++bi) {
+                const int q1 = bi * 16 + ty;
+                Wp[q1 * WS + tx] = (q1 > n || q2 > n) ? 0.0 : W[bi];
+            }
+            __syncthreads();
+            PROF_LAP_EXT(13);
+        }
+        return big_blocks<NBLK, B + 1>(A, Lp, Sl, g, pinv, n, NB);
+    }
+    return true;
+}
+template <int NBLK>
+__device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* d, double* pinv, int n) {
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PROF_BEGIN(); PROF_COUNT(22);
+    const int trash = (n + 1) * (n + 2) / 2, zero = trash + 1;
+    constexpr int CVR = NBLK * 16, WS = 17;
+    double* Wp = Sl + 66;
+    const int NB = n / 16 + 1;   // block rows / columns, the border row included
+    if (tid == 0) { Sl[64] = 0.0; Sl[65] = 0.0; }
+    if (tid < 8) Lp[zero + tid] = 0.0;
+    // block column 0 of [A; g^T] as it stands
+    {
+        const double gq = g[min(tx, n - 1)] * ((tx < n) ? 1.0 : 0.0);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) {
+            const int q1 = bi * 16 + ty;
+            const double v = (q1 == n) ? gq : A.a[bi * (bi + 1) / 2];
+            Wp[q1 * WS + tx] = (q1 > n || tx > n) ? 0.0 : v;
         }
     }
     __syncthreads();
+    PROF_MARK();
+    const bool ok = big_blocks<NBLK, 0>(A, Lp, Sl, g, pinv, n, NB);
+    __syncthreads();
     PROF_LAP(9);
     if (!ok) return false;
-    constexpr int NY = (CVR + 63) / 64;   // unknowns per lane of wave 0
-    constexpr int PR = 16;                // panel rows
-    double* pan = Sl + 66 + 4 * CVR;       // [PR][CVR]
+    // ---- back-substitution: x_j = (y_j - sum_{i > j} c_ij x_i) / d_j, rows n-1 .. 0, 16 at a time through LDS
+    constexpr int NY = (CVR + 63) / 64;   // unknowns per lane of wavefront 0
+    double* sb0 = Sl + 66;                // two [16][CVR] buffers
     const int base = n * (n + 1) / 2;
-    double y[NY];
+    double y[NY], pl[NY];
 #pragma unroll
-    for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k < n) ? Lp[base + tid + 64 * k] : 0.0;
-    for (int jhi = n - 1; jhi >= 0; jhi -= PR) {
-        const int jlo = max(jhi - PR + 1, 0), rows = jhi - jlo + 1;
-        for (int it = tid; it < rows * CVR; it += MOSHII_TPB) {   // row j of the factor: entries (j, 0 .. j-1), zero beyond
-            const int r = it / CVR, i = it - r * CVR, j = jlo + r;
-            pan[it] = (i < j) ? Lp[j * (j + 1) / 2 + i] : 0.0;
+    for (int k = 0; k < NY; ++k) {
+        y[k] = (wv == 0 && lane + 64 * k < n) ? Lp[base + lane + 64 * k] : 0.0;
+        pl[k] = pinv[min(lane + 64 * k, max(n - 1, 0))];
+    }
+    auto stage = [&](int pnl) {   // rows 16 pnl .. 16 pnl + 15 (those below n), entries (j, 0 .. j-1), zero beyond: wavefronts 1..3
+        double* sb = sb0 + (pnl & 1) * 16 * CVR;
+        const int jlo = 16 * pnl, t3 = tid - 64;   // 192 threads, thread = column (a second round for columns 192.. where rows reach them)
+        for (int i0 = 0; i0 < jlo + 15; i0 += MOSHII_TPB - 64) {
+            const int i = i0 + t3;
+            double v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {   // sixteen independent loads in flight
+                const int j = jlo + r;
+                v[r] = Lp[(i < j && j < n) ? j * (j + 1) / 2 + i : zero];
+            }
+            if (i < CVR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sb[r * CVR + i] = v[r];
+            }
         }
-        __syncthreads();
-        if (tid < 64) {
-            for (int jv = jhi; jv >= jlo; --jv) {
-                const int j = __builtin_amdgcn_readfirstlane(jv);
-                double l[NY];
-#pragma unroll
-                for (int k = 0; k < NY; ++k) l[k] = pan[(j - jlo) * CVR + tid + 64 * k];
-                double yj = 0.0;
-#pragma unroll
-                for (int k = 0; k < NY; ++k) if ((j >> 6) == k) yj = readlane_f64(y[k], j & 63);
-                const double dj = yj * pinv[j];
-#pragma unroll
-                for (int k = 0; k < NY; ++k) y[k] = (tid + 64 * k == j) ? dj : fma(-l[k], dj, y[k]);
+        // (every column of the lane groups wavefront 0 reads for this panel -- 64 (pnl / 4 + 1) <= the rounds' 192 / 384 -- is written: zeros
+        //  on and right of the diagonal)
+    };
+    const int PN = (n + 15) / 16;         // row panels 0 .. PN-1 hold rows 0 .. n-1
+    if (wv != 0) stage(PN - 1);
+    __syncthreads();
+    for (int pnl = PN - 1; pnl >= 0; --pnl) {
+        if (wv != 0) { if (pnl > 0) stage(pnl - 1); }
+        else {
+            const double* sb = sb0 + (pnl & 1) * 16 * CVR;
+            const int jlo = 16 * pnl, jhi = min(jlo + 15, n - 1);
+            switch (pnl >> 2) {   // (uniform) the lane group the panel's unknowns live in
+                case 0: big_backsub_panel<NY, 0>(sb, CVR, jlo, jhi, lane, y, pl); break;
+                case 1: if constexpr (NY > 1) big_backsub_panel<NY, 1>(sb, CVR, jlo, jhi, lane, y, pl); break;
+                case 2: if constexpr (NY > 2) big_backsub_panel<NY, 2>(sb, CVR, jlo, jhi, lane, y, pl); break;
+                default: if constexpr (NY > 3) big_backsub_panel<NY, 3>(sb, CVR, jlo, jhi, lane, y, pl); break;
             }
         }
         __syncthreads();
     }
-    if (tid < 64) {
+    if (wv == 0) {
 #pragma unroll
-        for (int k = 0; k < NY; ++k) if (tid + 64 * k < n) d[tid + 64 * k] = y[k];
+        for (int k = 0; k < NY; ++k) if (lane + 64 * k < n) d[lane + 64 * k] = y[k] * pl[k];
     }
     __syncthreads();
     PROF_LAP(10);
@@ -1835,106 +2036,110 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const unsigned seq = coop_begin(cx);
         TRACE_STAMP(co, seq, 0);
-        const CoopSlot mine = coop_slot16(co, seq, co.rank);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (4 * t + wv < NE) {   // (uniform: the tile slots beyond the last tile hold zeros nobody reads)
-                coop_st16(mine, (2 * t) * MOSHII_TPB + tid, acc.c[t][0], acc.c[t][1]);
-                coop_st16(mine, (2 * t + 1) * MOSHII_TPB + tid, acc.c[t][2], acc.c[t][3]);
-            }
-        if (np_ > 0 && co.rank == co.prior_rank) {
-            // the prior's share of the normal equations at this point (its argmin component kb was found by this rank's evaluation):
-            // block w^2 (1/2 L L^T)[colprior, colprior] in the owners' layout, gradient -w^2 (1/2 L L^T)(x - mu) per column
-            const int kb = (int)cx.scal[S_KBEST];
-            const double w2 = fp.wt_pose * fp.wt_pose;
-            AReg<NBLK> P;
-            P.zero();
-            P.add_prior(w2, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
-            double gq = 0.0;
-            if (tid < n) {
-                const int pb = cx.colprior[tid];
-                if (pb >= 0) {
-                    const auto* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
-                    const auto* mu = pr.means + (size_t)kb * np_;
-                    double s0 = 0.0, s1 = 0.0;
-                    for (int b0 = 0; b0 < np_; b0 += 32) {
-                        double h[32];
-#pragma unroll
-                        for (int k = 0; k < 32; ++k) h[k] = Hk[(size_t)min(b0 + k, np_ - 1) * np_];
-#pragma unroll
-                        for (int k = 0; k < 32; k += 2) {
-                            const int b = b0 + k;
-                            s0 = fma(h[k] * ((b < np_) ? 1.0 : 0.0), cx.xb[min(b, np_ - 1)] - mu[min(b, np_ - 1)], s0);
-                            s1 = fma(h[k + 1] * ((b + 1 < np_) ? 1.0 : 0.0), cx.xb[min(b + 1, np_ - 1)] - mu[min(b + 1, np_ - 1)], s1);
-                        }
-                    }
-                    gq = -(w2 * (s0 + s1));
-                }
-            }
-            double pe[2 * NUP];
-#pragma unroll
-            for (int e = 0; e < 2 * NUP; ++e) pe[e] = (e < NE) ? P.a[e] : ((e == NE) ? gq : 0.0);
-#pragma unroll
-            for (int u = 0; u < NUP; ++u) coop_st16(mine, (NUA + u) * MOSHII_TPB + tid, pe[2 * u], pe[2 * u + 1]);
-        }
-        double own[4 * NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) own[4 * t + i] = acc.c[t][i];
-        acc.zero();
-#pragma unroll
-        for (int e = 0; e < NE; ++e) pblk[e] = 0.0;
         double gqp = 0.0;
-        if (coop_publish_wait(co, cx, seq)) {
-            // Ranks in batches of RB: every load of a batch is in flight before the first is added (a rank-by-rank loop pays the
-            // round trip to the memory side -- write-through lines are not kept in the L2 -- once per rank).  Rank order in the sums:
-            // the same bits on every rank; the own share comes from the registers (what the slot holds).
-            // (at most ~48 loads in flight per thread: with more than the 63 the vector-memory counter can tell apart -- 8 blocks, four ranks per
-            //  batch: 72 + 19 -- the device build returned wrong sums, in the emulation as on paper nothing is wrong with it)
-            constexpr int RB = (48 / (2 * NT) < 1) ? 1 : ((48 / (2 * NT) > 6) ? 6 : 48 / (2 * NT));
-            const bool has_prior = np_ > 0;
-            const CoopSlot sp = coop_slot16(co, seq, co.prior_rank);
-            double pv[2 * NUP];
-            if (has_prior && NUP + RB * NUA <= 48) {   // (the prior rank's units ride with the first batch where the counter allows)
+        auto exchange = [&](auto l2) {   // (at the group's scope: CoopCtx::xcd_local)
+            constexpr bool L2 = decltype(l2)::value;
+            const CoopSlot mine = coop_slot16(co, seq, co.rank);
 #pragma unroll
-                for (int u = 0; u < NUP; ++u) coop_ld16(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
-            }
-            for (int r0 = 0; r0 < co.G; r0 += RB) {
-                double v[RB][4 * NT];
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    const CoopSlot sr = coop_slot16(co, seq, min(r0 + u, co.G - 1));
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (4 * t + wv < NE) {
-                            coop_ld16(sr, (2 * t) * MOSHII_TPB + tid, v[u][4 * t], v[u][4 * t + 1]);
-                            coop_ld16(sr, (2 * t + 1) * MOSHII_TPB + tid, v[u][4 * t + 2], v[u][4 * t + 3]);
-                        }
+            for (int t = 0; t < NT; ++t)
+                if (4 * t + wv < NE) {   // (uniform: the tile slots beyond the last tile hold zeros nobody reads)
+                    coop_st16<L2>(mine, (2 * t) * MOSHII_TPB + tid, acc.c[t][0], acc.c[t][1]);
+                    coop_st16<L2>(mine, (2 * t + 1) * MOSHII_TPB + tid, acc.c[t][2], acc.c[t][3]);
                 }
+            if (np_ > 0 && co.rank == co.prior_rank) {
+                // the prior's share of the normal equations at this point (its argmin component kb was found by this rank's evaluation):
+                // block w^2 (1/2 L L^T)[colprior, colprior] in the owners' layout, gradient -w^2 (1/2 L L^T)(x - mu) per column
+                const int kb = (int)cx.scal[S_KBEST];
+                const double w2 = fp.wt_pose * fp.wt_pose;
+                AReg<NBLK> P;
+                P.zero();
+                P.add_prior(w2, pr.halfprec + (size_t)kb * np_ * np_, np_, cx.colprior, n);
+                double gq = 0.0;
+                if (tid < n) {
+                    const int pb = cx.colprior[tid];
+                    if (pb >= 0) {
+                        const auto* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
+                        const auto* mu = pr.means + (size_t)kb * np_;
+                        double s0 = 0.0, s1 = 0.0;
+                        for (int b0 = 0; b0 < np_; b0 += 32) {
+                            double h[32];
 #pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    if (r0 + u < co.G) {   // (uniform)
-                        const bool mine_ = (r0 + u) == co.rank;
+                            for (int k = 0; k < 32; ++k) h[k] = Hk[(size_t)min(b0 + k, np_ - 1) * np_];
+#pragma unroll
+                            for (int k = 0; k < 32; k += 2) {
+                                const int b = b0 + k;
+                                s0 = fma(h[k] * ((b < np_) ? 1.0 : 0.0), cx.xb[min(b, np_ - 1)] - mu[min(b, np_ - 1)], s0);
+                                s1 = fma(h[k + 1] * ((b + 1 < np_) ? 1.0 : 0.0), cx.xb[min(b + 1, np_ - 1)] - mu[min(b + 1, np_ - 1)], s1);
+                            }
+                        }
+                        gq = -(w2 * (s0 + s1));
+                    }
+                }
+                double pe[2 * NUP];
+#pragma unroll
+                for (int e = 0; e < 2 * NUP; ++e) pe[e] = (e < NE) ? P.a[e] : ((e == NE) ? gq : 0.0);
+#pragma unroll
+                for (int u = 0; u < NUP; ++u) coop_st16<L2>(mine, (NUA + u) * MOSHII_TPB + tid, pe[2 * u], pe[2 * u + 1]);
+            }
+            double own[4 * NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) own[4 * t + i] = acc.c[t][i];
+            acc.zero();
+#pragma unroll
+            for (int e = 0; e < NE; ++e) pblk[e] = 0.0;
+            if (coop_publish_wait<L2>(co, cx, seq)) {
+                // Ranks in batches of RB: every load of a batch is in flight before the first is added (a rank-by-rank loop pays the
+                // round trip to the memory side -- write-through lines are not kept in the L2 -- once per rank).  Rank order in the sums:
+                // the same bits on every rank; the own share comes from the registers (what the slot holds).
+                // (at most ~48 loads in flight per thread: with more than the 63 the vector-memory counter can tell apart -- 8 blocks, four ranks per
+                //  batch: 72 + 19 -- the device build returned wrong sums, in the emulation as on paper nothing is wrong with it)
+                constexpr int RB = (48 / (2 * NT) < 1) ? 1 : ((48 / (2 * NT) > 6) ? 6 : 48 / (2 * NT));
+                const bool has_prior = np_ > 0;
+                const CoopSlot sp = coop_slot16(co, seq, co.prior_rank);
+                double pv[2 * NUP];
+                if (has_prior && NUP + RB * NUA <= 48) {   // (the prior rank's units ride with the first batch where the counter allows)
+#pragma unroll
+                    for (int u = 0; u < NUP; ++u) coop_ld16<L2>(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
+                }
+                for (int r0 = 0; r0 < co.G; r0 += RB) {
+                    double v[RB][4 * NT];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const CoopSlot sr = coop_slot16(co, seq, min(r0 + u, co.G - 1));
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
                             if (4 * t + wv < NE) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) acc.c[t][i] += mine_ ? own[4 * t + i] : v[u][4 * t + i];
+                                coop_ld16<L2>(sr, (2 * t) * MOSHII_TPB + tid, v[u][4 * t], v[u][4 * t + 1]);
+                                coop_ld16<L2>(sr, (2 * t + 1) * MOSHII_TPB + tid, v[u][4 * t + 2], v[u][4 * t + 3]);
                             }
                     }
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        if (r0 + u < co.G) {   // (uniform)
+                            const bool mine_ = (r0 + u) == co.rank;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                if (4 * t + wv < NE) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) acc.c[t][i] += mine_ ? own[4 * t + i] : v[u][4 * t + i];
+                                }
+                        }
+                    }
+                }
+                if (has_prior) {
+                    if (NUP + RB * NUA > 48) {
+#pragma unroll
+                        for (int u = 0; u < NUP; ++u) coop_ld16<L2>(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) pblk[e] = pv[e];
+                    gqp = pv[NE];
                 }
             }
-            if (has_prior) {
-                if (NUP + RB * NUA > 48) {
-#pragma unroll
-                    for (int u = 0; u < NUP; ++u) coop_ld16(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
-                }
-#pragma unroll
-                for (int e = 0; e < NE; ++e) pblk[e] = pv[e];
-                gqp = pv[NE];
-            }
-        }
+        };
+        if (co.xcd_local) exchange(std::true_type()); else exchange(std::false_type());
         if (tid < n) cx.dgn[tid] = gqp;   // (free here: the Gauss-Newton step of the last iteration has been used up)
         TRACE_STAMP(co, seq, 3);
         coop_end(cx, seq);
@@ -2284,18 +2489,22 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if constexpr (COOP) {   // every rank needs all the simulated markers: gather the ranks' rows (its own stay as they are)
                 const unsigned seq = coop_begin(cx);
-                auto* mine = coop_slot(co, seq, co.rank);
-                for (int i = 3 * co.mlo + tid; i < 3 * co.mhi; i += MOSHII_TPB) coop_st(mine + i, cx.msim[i]);
-                if (tid == 0) coop_st(mine + 3 * at.M, (double)co.mlo);   // (where this rank's range starts)
-                if (coop_publish_wait(co, cx, seq)) {
-                    const int M3 = 3 * at.M;
-                    for (int i = tid; i < M3; i += MOSHII_TPB) {
-                        // owner of marker i / 3: the rank whose range holds it (ranges are contiguous and ascending: count the boundaries passed)
-                        int r = 0;
-                        for (int q = 1; q < co.G; ++q) r += (i >= 3 * (int)coop_ld(coop_slot(co, seq, q) + 3 * at.M)) ? 1 : 0;
-                        if (r != co.rank) cx.msim[i] = coop_ld(coop_slot(co, seq, r) + i);
+                auto gather = [&](auto l2) {   // (every access of a launch at ONE scope: the group's, CoopCtx::xcd_local)
+                    constexpr bool L2 = decltype(l2)::value;
+                    auto* mine = coop_slot(co, seq, co.rank);
+                    for (int i = 3 * co.mlo + tid; i < 3 * co.mhi; i += MOSHII_TPB) coop_st64<L2>(mine + i, f64_bits(cx.msim[i]));
+                    if (tid == 0) coop_st64<L2>(mine + 3 * at.M, f64_bits((double)co.mlo));   // (where this rank's range starts)
+                    if (coop_publish_wait<L2>(co, cx, seq)) {
+                        const int M3 = 3 * at.M;
+                        for (int i = tid; i < M3; i += MOSHII_TPB) {
+                            // owner of marker i / 3: the rank whose range holds it (ranges are contiguous and ascending: count the boundaries passed)
+                            int r = 0;
+                            for (int q = 1; q < co.G; ++q) r += (i >= 3 * (int)bits_f64(coop_ld64<L2>(coop_slot(co, seq, q) + 3 * at.M))) ? 1 : 0;
+                            if (r != co.rank) cx.msim[i] = bits_f64(coop_ld64<L2>(coop_slot(co, seq, r) + i));
+                        }
                     }
-                }
+                };
+                if (co.xcd_local) gather(std::true_type()); else gather(std::false_type());
                 coop_end(cx, seq);
             }
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
@@ -2500,6 +2709,35 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];   // regressed joints: read in every phase, keep them in LDS
     __syncthreads();
+    if constexpr (COOP) {
+        // Where do the ranks run?  Each posts the XCC id the hardware reports for its workgroup -- agent scope, in words of the flag block
+        // nothing else uses -- and reads the others': if they are all the same, the group's exchanges go through that XCD's L2 from here on
+        // (every payload / flag access at sc0 scope; never both scopes on one word in one launch), otherwise at agent scope as in round 3.
+        unsigned xcc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xfu;
+#endif
+        if (tid == 0) __hip_atomic_store(co.flags + co.G + 1 + co.rank, 0x100u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < co.G) {
+            unsigned v, spins = 0;
+            bool ok = true;
+            while (((v = __hip_atomic_load(co.flags + co.G + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x100u) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0u)
+                    if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+            }
+            if (!ok) { __hip_atomic_store(co.flags + co.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cx.scal[S_COOP_FAIL] = 1.0; }
+            cx.y[tid] = (ok && (v & 0xfu) == xcc) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        bool same = chp->coop.allow_local != 0;
+        for (int r = 0; r < co.G; ++r) same = same && cx.y[r] != 0.0;
+        co.xcd_local = same ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<KernelCtx*>(lds)->co.xcd_local = co.xcd_local;
+        __syncthreads();
+    }
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
     int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)

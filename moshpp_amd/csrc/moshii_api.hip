@@ -317,7 +317,8 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     ly.t_tjs = ttake((3 * Tm * (NWmax + 1) + 1) / 2);
     // packed factor + 64 per-lane trash words / zero word + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
     // the factor lives in global scratch and LDS keeps the broadcast buffer plus a 16-row panel
-    const int chol = (nblk > 8) ? 66 + 4 * LDJ + 16 * LDJ + 4 : (nmax + 1) * (nmax + 2) / 2 + 66 + 4 * LDJ + 4;
+    // (ldl_big: a [LDJ][17] block column + nblk exchange tiles; its back-substitution lays two [16][LDJ] row buffers over them)
+    const int chol = (nblk > 8) ? 66 + std::max(17 * LDJ + 256 * nblk, 32 * LDJ) + 4 : (nmax + 1) * (nmax + 2) / 2 + 66 + 4 * LDJ + 4;
     ly.big_doubles = std::max(std::max(t, chol), 16 * 256);   // (16 x 256: the J^T J tile exchange, AReg::take)
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
@@ -693,6 +694,8 @@ struct LaunchCfg {
 // reserved after the id lists; their device/host offsets come back through ctl_off.
 // The cooperative-chain request of a call: MOSHII_COOP_GROUP(g) in `flags` (0 = no word: the environment variable `env`, else the library's
 // choice; 1 = plain chains; 2 .. 8 = that many workgroups per chain).  Returns -1 (library's choice), 0 (plain), g, or -2 (out of range).
+// MOSHII_COOP_LOCAL=0: cooperative groups always exchange with agent-scope accesses, also when all their ranks share an XCD (experiments)
+int coop_allow_local() { const char* e = getenv("MOSHII_COOP_LOCAL"); return (e && atoi(e) == 0) ? 0 : 1; }
 int coop_request(uint32_t flags, const char* env) {
     int g = (int)((flags >> 8) & 0xffu);
     if (g == 0) {
@@ -998,7 +1001,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     const int coop_g = cfg.coop_g;   // (0: plain chains -- asked for, or the group does not fit the chip / the solve is an extended one)
     size_t coop_bytes_per_chain = 0;
     if (coop_g > 0) {
-        coop_bytes_per_chain = ((size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(coop_g + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+        coop_bytes_per_chain = ((size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(2 * coop_g + 2) * sizeof(unsigned) + 255) & ~size_t(255);
         if ((rc = m->coopbuf.reserve(coop_bytes_per_chain * n_chains))) return rc;
         m->coopbuf.used = true; m->coopbuf.last_stream = stream;
         HIP_TRY(hipMemsetAsync(m->coopbuf.ptr, 0, coop_bytes_per_chain * n_chains, stream));   // flags and abort words start at zero on EVERY call
@@ -1025,6 +1028,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         cd.att = ch.attach->d_self; cd.F = ch.F; cd.first = ch.first_frame_schedule;
         if (coop_g > 0) {
             cd.coop.G = coop_g; cd.coop.prior_rank = cfg.coop_prior_rank; cd.coop.slot_doubles = cfg.coop_slot_doubles;
+            cd.coop.allow_local = coop_allow_local();
             coop_split(ch.attach->M, coop_g, cfg.coop_prior_frac, cd.coop.mlo);
             char* cb = m->coopbuf.ptr + coop_bytes_per_chain * c;
             cd.coop.slots = as_gp_rw((unsigned long long*)cb);
@@ -1187,7 +1191,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         // round to round is a hipFree + hipMalloc in the middle of the solve)
         const int nb = std::max(4, cfg.nblk), NEc = nb * (nb + 1) / 2, NTc = (NEc + 3) / 4;
         const size_t slot = (size_t)std::max((4 * NTc + 2 * ((NEc + 2) / 2)) * MOSHII_TPB, 3 * Mmax + 2) + 32;
-        const size_t per = ((size_t)2 * coop_rep * slot * sizeof(unsigned long long) + (size_t)(coop_rep + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+        const size_t per = ((size_t)2 * coop_rep * slot * sizeof(unsigned long long) + (size_t)(2 * coop_rep + 2) * sizeof(unsigned) + 255) & ~size_t(255);
         if ((rc = m->coopbuf.reserve(per * (size_t)std::min(NC, std::max(1, n_cu / 2))))) return rc;
     }
     // device buffers of this call: released on EVERY way out of the function (error returns included)
@@ -1423,13 +1427,14 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                 if (ctl2 != ctl) { cleanup(); return fail(MOSHII_ERR_ARG, "internal: control block moved"); }
                 coop_cfg_ready[g_round] = 1;
             }
-            const size_t per = ((size_t)2 * g_round * cc.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(g_round + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+            const size_t per = ((size_t)2 * g_round * cc.coop_slot_doubles * sizeof(unsigned long long) + (size_t)(2 * g_round + 2) * sizeof(unsigned) + 255) & ~size_t(255);
             if ((rc = m->coopbuf.reserve(per * rep.size()))) { cleanup(); return rc; }
             m->coopbuf.used = true; m->coopbuf.last_stream = stream;
             HIP_TRY(hipMemsetAsync(m->coopbuf.ptr, 0, per * rep.size(), stream));
             for (size_t i = 0; i < rep.size(); ++i) {
                 ChainDev& cd = rep[i];
                 cd.coop.G = g_round; cd.coop.prior_rank = cc.coop_prior_rank; cd.coop.slot_doubles = cc.coop_slot_doubles;
+                cd.coop.allow_local = coop_allow_local();
                 coop_split(seqs[chunks[todo[i]].seq].attach->M, g_round, cc.coop_prior_frac, cd.coop.mlo);
                 char* cb = m->coopbuf.ptr + per * i;
                 cd.coop.slots = as_gp_rw((unsigned long long*)cb);
@@ -1442,7 +1447,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         HIP_TRY(hipStreamSynchronize(stream));
         if ((rc = launch_chains(*use, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }
         if (g_round >= 2) {   // did every group stay whole?
-            const size_t per = ((size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + (size_t)(g_round + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+            const size_t per = ((size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + (size_t)(2 * g_round + 2) * sizeof(unsigned) + 255) & ~size_t(255);
             std::vector<unsigned> ab(rep.size(), 0u);
             for (size_t i = 0; i < rep.size(); ++i)
                 HIP_TRY(hipMemcpyAsync(&ab[i], m->coopbuf.ptr + per * i + (size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + g_round * sizeof(unsigned),

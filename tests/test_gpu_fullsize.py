@@ -219,8 +219,8 @@ def test_config3_smplx_32_sequences_of_4000_frames(gpu_lib):
     each chain a cooperative chain of 8 workgroups where the chip has 256 CUs (with a free expression block a chunk start never reproduces
     the chain's coefficients, DESIGN.md section 4a, so this size class runs sequentially per sequence).  The subject and capture are the
     bench's config-3 leg's (workload.make_face_job; capture 7000, generated on the host so that the committed oracle trajectory applies):
-    copies agree bit for bit; the oracle holds the first 400 frames (every iteration count, every 10th frame's state); every frame
-    reproduces its markers."""
+    copies agree bit for bit; every frame reproduces its markers; the oracle holds the 400-frame capture of the same subject and seed,
+    solved in the same launch shape (every iteration count, every 10th frame's state)."""
     import time
     from moshpp_amd import capi, workload
     from tests.helpers import face_capture_host, face_job_oracle
@@ -245,10 +245,19 @@ def test_config3_smplx_32_sequences_of_4000_frames(gpu_lib):
     d = (o['markers_sim'] - cap['obs'])[cap['vis']]
     rmse = float(np.sqrt((d ** 2).sum(1).mean()))
     assert rmse < 5e-3          # (noise 0.5 mm; the expression regulariser holds the block towards 0)
+    # the oracle's window: the committed trajectory is that of the capture GENERATED with 400 frames (the generator's noise / dropout
+    # streams and its motion depend on the length: the 4000-frame capture's first 400 frames are another capture) -- the same launch
+    # shape, 32 copies on 32 x 8 workgroups
+    cap_h = face_capture_host(job, m, closest, coef, 7000, H)
+    outs_h = capi.chain_solve_host(solver.dev, solver.prior, solver.opts,
+                                   [dict(attach=solver.attach, obs=cap_h['obs'], vis=cap_h['vis'], first=True) for _ in range(NSEQ)])
+    assert capi.last_launch_info()[0] == kernel
+    for oh in outs_h[1:]:
+        assert np.array_equal(oh['fullpose'], outs_h[0]['fullpose']) and np.array_equal(oh['shape'], outs_h[0]['shape'])
     g = _config3_golden()
-    dp, ds, dtr, same = _hold_to_config3_golden(g, 7000, o, H)
+    dp, ds, dtr, same = _hold_to_config3_golden(g, 7000, outs_h[0], H)
     print(f'config 3: {NSEQ} x {F} frames in {dt:.1f} s = {NSEQ * F / dt:.0f} frames/s ({kernel}); marker rmse {rmse:.2e} m; data SSE max {o["errs"][:, 0].max():.1f}; '
-          f'first {H} frames vs oracle {dp:.2e} rad / {ds:.2e} (expression) / {dtr:.2e} m, iteration counts equal on {same.mean() * 100:.1f} % of frames')
+          f'{H}-frame capture vs oracle {dp:.2e} rad / {ds:.2e} (expression) / {dtr:.2e} m, iteration counts equal on {same.mean() * 100:.1f} % of frames')
     assert dp < 1e-6 and ds < 1e-6 and dtr < 1e-6
     assert same.all()
 

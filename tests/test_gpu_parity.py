@@ -438,7 +438,7 @@ def test_free_shape_block_matches_oracle(gpu_lib, model_type, kind, E, fingers, 
                            model_type, optimize_fingers=fingers, optimize_face=face, free_shape=kind)
     out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
                                 [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])[0]
-    assert capi.last_launch_info()[0].endswith(',xt>')
+    assert ',xt' in capi.last_launch_info()[0]   # (the library may run the chain on several workgroups: k_chain_solve<N,1,xt,coopG>)
     assert np.all(out['status'] == 0)
     dp = np.abs(out['fullpose'] - ref['fullpose']).max()
     dt = np.abs(out['trans'] - ref['trans']).max()

@@ -8,10 +8,18 @@ sys.path.insert(0, '.')
 from moshpp_amd import capi, workload
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 G = int(os.environ.get('MOSHII_COOP', '0'))
-job = workload.make_job('smplh', F, 53, seed=1000)
-solver = workload.make_solver(job)
-lib = capi.load()
-out = solver.solve(job['obs'], job['vis'])
+if len(sys.argv) > 2 and sys.argv[2] == 'config3':   # the BASELINE config-3 subject (SMPL-X, 194 unknowns), one capture
+    job = workload.make_face_job()
+    solver = workload.make_solver(job)
+    cap = workload.make_face_capture(job, solver, 7000, F)
+    lib = capi.load()
+    out = capi.chain_solve_host(solver.dev, solver.prior, solver.opts, [dict(attach=solver.attach, obs=cap['obs'], vis=cap['vis'], first=True)])[0]
+    print(capi.last_launch_info())
+else:
+    job = workload.make_job('smplh', F, 53, seed=1000)
+    solver = workload.make_solver(job)
+    lib = capi.load()
+    out = solver.solve(job['obs'], job['vis'])
 N = 8192
 buf = (C.c_longlong * (8 * N * 4))()
 lib.moshii_prof_trace_read.argtypes = [C.POINTER(C.c_longlong)]
