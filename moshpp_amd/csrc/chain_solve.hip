@@ -192,10 +192,13 @@ __device__ __forceinline__ void coop_st(MOSHII_GP(unsigned long long) p, double 
 __device__ __forceinline__ double coop_ld(MOSHII_GP(unsigned long long) p) {
     return bits_f64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-// The same accesses at the scope of ONE XCD's L2: for groups whose ranks found themselves on one XCD (CoopCtx::xcd_local; k_chain_solve
-// checks the hardware's XCC id of every rank at its start).  Stores sc0 -- acknowledged by the L2, where an agent-scope (sc1) store is
-// written through to the memory side before the storing wave's vmcnt moves -- and loads sc0 nt: a plain sc0 load is served by this CU's
-// L1 (tools/ubench_scope.hip: a word cached there is never seen to change, with or without buffer_inv sc0), a non-temporal one never is.
+// The same accesses at the scope of ONE XCD's L2 (the L2 = true forms below), for groups whose ranks share an XCD: stores sc0 --
+// acknowledged by the L2, where an agent-scope (sc1) store is written through to the memory side before the storing wave's vmcnt moves --
+// and loads sc0 nt: a plain sc0 load is served by this CU's L1 (tools/ubench_scope.hip: a word cached there is never seen to change, with
+// or without buffer_inv sc0), a non-temporal one never is.  Round 4 ran every exchange this way when the ranks' XCC ids (s_getreg
+// HW_REG_XCC_ID, compared in a first agent-scope exchange) agreed: correct, and NO faster -- 171.5 against 174.9 us per frame on the body
+// solve, 652 against 649 us per cold frame in config 3's large exchange: the exchange is bound by the readers' round trips, which an
+// sc1 load and an nt load pay alike (0.18 us a settled poll, either way), not by the write-through.  Not instantiated any more.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void coop_st_l2(MOSHII_GP(unsigned long long) p, unsigned long long v) {
     asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
@@ -349,7 +352,6 @@ __device__ __forceinline__ bool coop_exchange_small_(const CoopCtx& co, const Ct
 }
 template <int NS>
 __device__ __forceinline__ bool coop_exchange_small(const CoopCtx& co, const Ctx& cx, unsigned seq, const double (&mine)[NS], double* land) {
-    if (co.xcd_local) return coop_exchange_small_<NS, true>(co, cx, seq, mine, land);   // (uniform)
     return coop_exchange_small_<NS, false>(co, cx, seq, mine, land);
 }
 
@@ -1719,6 +1721,8 @@ __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const doubl
     return true;
 }
 
+template <int NBLK> __device__ __noinline__ bool coop_rs_reduce(unsigned seq_);   // (defined behind the context helpers below)
+
 // ------------------------------------------------------------------------------------------------
 // Normal equations at the point whose forward state is in LDS:  A = J^T J (registers), g = -J^T r (LDS).
 // ------------------------------------------------------------------------------------------------
@@ -2034,10 +2038,10 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         // registers (t, 2 h), (t, 2 h + 1); then (prior rank only) NUP units = its NE prior-block entries and its gradient entry.
         constexpr int NT = JtJAcc<NBLK>::NT, NE = AReg<NBLK>::NE, NUA = 2 * NT, NUP = (NE + 2) / 2;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const unsigned seq = coop_begin(cx);
+        unsigned seq = coop_begin(cx);   // (the reduce-scatter form below moves on to a second exchange)
         TRACE_STAMP(co, seq, 0);
         double gqp = 0.0;
-        auto exchange = [&](auto l2) {   // (at the group's scope: CoopCtx::xcd_local)
+        auto exchange = [&](auto l2) {   // (l2: the access scope, see coop_st_l2)
             constexpr bool L2 = decltype(l2)::value;
             const CoopSlot mine = coop_slot16(co, seq, co.rank);
 #pragma unroll
@@ -2081,12 +2085,15 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 #pragma unroll
                 for (int u = 0; u < NUP; ++u) coop_st16<L2>(mine, (NUA + u) * MOSHII_TPB + tid, pe[2 * u], pe[2 * u + 1]);
             }
-            double own[4 * NT];
+            constexpr bool RS = NT >= 9;   // reduce-scatter + all-gather instead of the all-gather of every rank's whole slot (below)
+            double own[RS ? 1 : 4 * NT];
+            if constexpr (!RS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) own[4 * t + i] = acc.c[t][i];
-            acc.zero();
+                    for (int i = 0; i < 4; ++i) own[4 * t + i] = acc.c[t][i];
+                acc.zero();
+            }
 #pragma unroll
             for (int e = 0; e < NE; ++e) pblk[e] = 0.0;
             if (coop_publish_wait<L2>(co, cx, seq)) {
@@ -2098,6 +2105,38 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 constexpr int RB = (48 / (2 * NT) < 1) ? 1 : ((48 / (2 * NT) > 6) ? 6 : 48 / (2 * NT));
                 const bool has_prior = np_ > 0;
                 const CoopSlot sp = coop_slot16(co, seq, co.prior_rank);
+                if constexpr (RS) {
+                    // Large matrices (8 register blocks and up: 72 KB .. 184 KB per rank) as a REDUCE-SCATTER + ALL-GATHER: rank k sums tiles
+                    // [k TPR, (k + 1) TPR) of every rank -- in rank order, the own share from registers: the bits of the all-gather form --,
+                    // posts the sums in a second exchange and collects the other ranks'.  A rank reads 2 (G - 1) / G of a slot instead
+                    // of G - 1 slots (config 3, eight ranks: 0.33 MB instead of 1.3 MB, which took 62 us of an assembly's ~170), and the
+                    // ranks no longer stream the same slot at the same moment.
+                    if (has_prior) {
+                        double pv[2 * NUP];
+#pragma unroll
+                        for (int u = 0; u < NUP; ++u) coop_ld16<L2>(sp, (NUA + u) * MOSHII_TPB + tid, pv[2 * u], pv[2 * u + 1]);
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) pblk[e] = pv[e];
+                        gqp = pv[NE];
+                    }
+                    // (the reduction in a function of its own that works slot to slot -- this rank's own share is read back from its
+                    //  slot like everybody else's: inside assemble_fn hipcc 7.2's register allocator crashes on it, and handing it the
+                    //  accumulators by value faulted on the device)
+                    const bool ok2 = coop_rs_reduce<NBLK>(seq);
+                    seq += 1;
+                    if (ok2) {
+                        const int TPR = (NT + co.G - 1) / co.G;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (4 * t + wv < NE) {   // (every load in flight: 2 NT <= 46)
+                                const CoopSlot sr = coop_slot16(co, seq, t / TPR);
+                                double w0, w1, w2, w3;
+                                coop_ld16<L2>(sr, (2 * t) * MOSHII_TPB + tid, w0, w1);
+                                coop_ld16<L2>(sr, (2 * t + 1) * MOSHII_TPB + tid, w2, w3);
+                                acc.c[t] = v4d{w0, w1, w2, w3};
+                            }
+                    }
+                } else {
                 double pv[2 * NUP];
                 if (has_prior && NUP + RB * NUA <= 48) {   // (the prior rank's units ride with the first batch where the counter allows)
 #pragma unroll
@@ -2137,9 +2176,10 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                     for (int e = 0; e < NE; ++e) pblk[e] = pv[e];
                     gqp = pv[NE];
                 }
+                }   // (all-gather form)
             }
         };
-        if (co.xcd_local) exchange(std::true_type()); else exchange(std::false_type());
+        exchange(std::false_type());   // (the L2-scope form -- MOSHII_COOP_L2SCOPE builds -- bought nothing: see coop_st_l2)
         if (tid < n) cx.dgn[tid] = gqp;   // (free here: the Gauss-Newton step of the last iteration has been used up)
         TRACE_STAMP(co, seq, 3);
         coop_end(cx, seq);
@@ -2256,6 +2296,55 @@ __device__ __forceinline__ T uniform_load(const T* p) {
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(T) / 4); ++i) o[i] = __builtin_amdgcn_readfirstlane(q[i]);
     return out;
+}
+
+// Cooperative assembly, large matrices (assemble(): the reduce-scatter + all-gather form), after the wait of exchange `seq` in which
+// every rank posted its partial products: this rank sums its tiles [rank TPR, (rank + 1) TPR) over the ranks -- in rank order, from zero:
+// the bits of the all-gather form --, posts the sums at the same offsets in exchange seq + 1 and waits for everybody's.  Slot to slot
+// (no large arguments); leaves exchange seq + 1 open (the caller reads the sums and ends it).  false: the group is broken.
+template <int NBLK>
+__device__ __noinline__ bool coop_rs_reduce(unsigned seq_) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
+    const ChainLayout ly = uniform_load(&kc->ly);
+    const Ctx cx = make_ctx(lds, ly);
+    const CoopCtx co = uniform_load(&kc->co);
+    constexpr int NT = JtJAcc<NBLK>::NT, NE = AReg<NBLK>::NE;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq_);
+    const int TPR = (NT + co.G - 1) / co.G, tlo = co.rank * TPR, thi = min(NT, tlo + TPR);
+    v4d sums[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t >= tlo && t < thi && 4 * t + wv < NE) {   // (uniform)
+            double v[MOSHII_COOP_MAXG][4];
+#pragma unroll
+            for (int r = 0; r < MOSHII_COOP_MAXG; ++r)
+                if (r < co.G) {
+                    const CoopSlot sr = coop_slot16(co, seq, r);
+                    coop_ld16(sr, (2 * t) * MOSHII_TPB + tid, v[r][0], v[r][1]);
+                    coop_ld16(sr, (2 * t + 1) * MOSHII_TPB + tid, v[r][2], v[r][3]);
+                }
+            v4d sum = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < MOSHII_COOP_MAXG; ++r)
+                if (r < co.G) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum[i] += v[r][i];
+                }
+            sums[t] = sum;
+        }
+    coop_end(cx, seq);
+    seq = coop_begin(cx);
+    const CoopSlot mine2 = coop_slot16(co, seq, co.rank);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t >= tlo && t < thi && 4 * t + wv < NE) {
+            coop_st16(mine2, (2 * t) * MOSHII_TPB + tid, sums[t][0], sums[t][1]);
+            coop_st16(mine2, (2 * t + 1) * MOSHII_TPB + tid, sums[t][2], sums[t][3]);
+        }
+    return coop_publish_wait(co, cx, seq);
 }
 
 template <bool XT, bool COOP>
@@ -2489,7 +2578,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         if (rigid) {   // rigid_transformations.py:72-83 on the markers just simulated
             if constexpr (COOP) {   // every rank needs all the simulated markers: gather the ranks' rows (its own stay as they are)
                 const unsigned seq = coop_begin(cx);
-                auto gather = [&](auto l2) {   // (every access of a launch at ONE scope: the group's, CoopCtx::xcd_local)
+                auto gather = [&](auto l2) {   // (l2: the access scope, see coop_st_l2)
                     constexpr bool L2 = decltype(l2)::value;
                     auto* mine = coop_slot(co, seq, co.rank);
                     for (int i = 3 * co.mlo + tid; i < 3 * co.mhi; i += MOSHII_TPB) coop_st64<L2>(mine + i, f64_bits(cx.msim[i]));
@@ -2504,7 +2593,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                         }
                     }
                 };
-                if (co.xcd_local) gather(std::true_type()); else gather(std::false_type());
+                gather(std::false_type());
                 coop_end(cx, seq);
             }
             if (tid == 0) rigid_init_serial(cx, fp, visrow, at.M);
@@ -2709,35 +2798,6 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     if (tid < md.K) cx.anc[tid] = md.anc[tid];
     for (int i = tid; i < 3 * md.K; i += MOSHII_TPB) cx.Jl[i] = md.J[i];   // regressed joints: read in every phase, keep them in LDS
     __syncthreads();
-    if constexpr (COOP) {
-        // Where do the ranks run?  Each posts the XCC id the hardware reports for its workgroup -- agent scope, in words of the flag block
-        // nothing else uses -- and reads the others': if they are all the same, the group's exchanges go through that XCD's L2 from here on
-        // (every payload / flag access at sc0 scope; never both scopes on one word in one launch), otherwise at agent scope as in round 3.
-        unsigned xcc = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc &= 0xfu;
-#endif
-        if (tid == 0) __hip_atomic_store(co.flags + co.G + 1 + co.rank, 0x100u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < co.G) {
-            unsigned v, spins = 0;
-            bool ok = true;
-            while (((v = __hip_atomic_load(co.flags + co.G + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x100u) == 0u) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 255u) == 0u)
-                    if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
-            }
-            if (!ok) { __hip_atomic_store(co.flags + co.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cx.scal[S_COOP_FAIL] = 1.0; }
-            cx.y[tid] = (ok && (v & 0xfu) == xcc) ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        bool same = chp->coop.allow_local != 0;
-        for (int r = 0; r < co.G; ++r) same = same && cx.y[r] != 0.0;
-        co.xcd_local = same ? 1 : 0;
-        __syncthreads();
-        if (tid == 0) reinterpret_cast<KernelCtx*>(lds)->co.xcd_local = co.xcd_local;
-        __syncthreads();
-    }
     for (int b = tid; b < op.nbody; b += MOSHII_TPB) cx.pid2prior[op.body[b]] = b;
     __syncthreads();
     int vc_key = 0, tab_key = 0;   // which free set cx.vconst / the column tables were built for (0: none yet)

@@ -694,8 +694,6 @@ struct LaunchCfg {
 // reserved after the id lists; their device/host offsets come back through ctl_off.
 // The cooperative-chain request of a call: MOSHII_COOP_GROUP(g) in `flags` (0 = no word: the environment variable `env`, else the library's
 // choice; 1 = plain chains; 2 .. 8 = that many workgroups per chain).  Returns -1 (library's choice), 0 (plain), g, or -2 (out of range).
-// MOSHII_COOP_LOCAL=0: cooperative groups always exchange with agent-scope accesses, also when all their ranks share an XCD (experiments)
-int coop_allow_local() { const char* e = getenv("MOSHII_COOP_LOCAL"); return (e && atoi(e) == 0) ? 0 : 1; }
 int coop_request(uint32_t flags, const char* env) {
     int g = (int)((flags >> 8) & 0xffu);
     if (g == 0) {
@@ -1028,7 +1026,6 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         cd.att = ch.attach->d_self; cd.F = ch.F; cd.first = ch.first_frame_schedule;
         if (coop_g > 0) {
             cd.coop.G = coop_g; cd.coop.prior_rank = cfg.coop_prior_rank; cd.coop.slot_doubles = cfg.coop_slot_doubles;
-            cd.coop.allow_local = coop_allow_local();
             coop_split(ch.attach->M, coop_g, cfg.coop_prior_frac, cd.coop.mlo);
             char* cb = m->coopbuf.ptr + coop_bytes_per_chain * c;
             cd.coop.slots = as_gp_rw((unsigned long long*)cb);
@@ -1434,8 +1431,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             for (size_t i = 0; i < rep.size(); ++i) {
                 ChainDev& cd = rep[i];
                 cd.coop.G = g_round; cd.coop.prior_rank = cc.coop_prior_rank; cd.coop.slot_doubles = cc.coop_slot_doubles;
-                cd.coop.allow_local = coop_allow_local();
-                coop_split(seqs[chunks[todo[i]].seq].attach->M, g_round, cc.coop_prior_frac, cd.coop.mlo);
+                    coop_split(seqs[chunks[todo[i]].seq].attach->M, g_round, cc.coop_prior_frac, cd.coop.mlo);
                 char* cb = m->coopbuf.ptr + per * i;
                 cd.coop.slots = as_gp_rw((unsigned long long*)cb);
                 cd.coop.flags = as_gp_rw((unsigned*)(cb + (size_t)2 * g_round * cc.coop_slot_doubles * sizeof(unsigned long long)));

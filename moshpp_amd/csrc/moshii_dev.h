@@ -97,14 +97,12 @@ struct CoopDev {
     int mlo[MOSHII_COOP_MAXG + 1];
     int slot_doubles;                        // doubles per (parity, rank) slot
     int qstride;                             // extended variant: doubles between the ranks' slices of ChainDev::qscratch
-    int allow_local;                         // the ranks may use L2-scope accesses when they find themselves on one XCD (0: always agent scope)
     MOSHII_GP(unsigned long long) slots;     // [2][G][slot_doubles] payload words (doubles as bit patterns: 8-byte agent-scope accesses)
     MOSHII_GP(unsigned int) flags;           // [G] sequence number of the last exchange each rank has posted, [G] = the group's abort word
 };
 // the rank's view, in KernelCtx
 struct CoopCtx {
     int G, rank, prior_rank, mlo, mhi, slot_doubles;
-    int xcd_local;                           // every rank of the group runs on the same XCD: exchanges through that XCD's L2 (chain_solve.hip)
     MOSHII_GP(unsigned long long) slots;
     MOSHII_GP(unsigned int) flags;
 };
