@@ -1203,8 +1203,14 @@ struct APass<NBLK, true> {
 //   C  everyone applies the panel to the tiles to its right: 16 rank-1 updates per tile from LDS reads that are broadcasts
 //      (row entries) or spread over the banks (column entries), the next panel's entries included.
 // Two barriers per 16 columns instead of eight.
+// Up to four register blocks (the body solve) the factor is stored SQUARE -- row i at i (16 NBLK + 1), zeros right of the diagonal --
+// instead of packed: twice the LDS (33 KB of a region that holds the Jacobian tiles otherwise), and every address in the elimination and
+// the back-substitution is a row base plus a compile-time offset: no per-entry select of a spare word, no offset arithmetic per row.
+template <int NBLK> constexpr bool ldl_square() { return NBLK <= 4; }
 template <int NBLK>
 struct LdlCtx {
+    static constexpr bool SQ = ldl_square<NBLK>();
+    static constexpr int LS = NBLK * 16 + 1;   // row stride of the square form (odd: a lane-per-row access spreads over the banks)
     double* Lp; double* pinv; double* Zr;
     int n, trash, zero, ty, tx, lane;
     int rS[NBLK], cS[NBLK];   // packed offsets of this thread's rows b 16 + ty / b 16 + tx (-1: beyond the border row)
@@ -1221,9 +1227,17 @@ __device__ __forceinline__ bool ldl_panel_eliminate(const LdlCtx<NBLK>& c) {
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
         const int row = c0 + 64 * s_ + c.lane;
-        off[s_] = (row <= c.n) ? row * (row + 1) / 2 + c0 : -1;
+        if constexpr (LdlCtx<NBLK>::SQ) {
+            off[s_] = (row <= c.n) ? row * LdlCtx<NBLK>::LS + c0 : -1;
+            const double* rp = c.Lp + ((row < NBLK * 16) ? row * LdlCtx<NBLK>::LS + c0 : c.zero);   // (zeros right of the diagonal: stored)
+            const int st = (row < NBLK * 16) ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[s_][k] = c.Lp[(off[s_] >= 0 && c0 + k <= row) ? off[s_] + k : c.zero];
+            for (int k = 0; k < 16; ++k) a[s_][k] = rp[k * st];
+        } else {
+            off[s_] = (row <= c.n) ? row * (row + 1) / 2 + c0 : -1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[s_][k] = c.Lp[(off[s_] >= 0 && c0 + k <= row) ? off[s_] + k : c.zero];
+        }
     }
     bool bad = false;
 #pragma unroll
@@ -1269,8 +1283,13 @@ __device__ __forceinline__ void ldl_panel_apply(const LdlCtx<NBLK>& c, double (&
             double ci[NBLK], ck[NBLK];
 #pragma unroll
             for (int b = P + 1; b < NBLK; ++b) {
-                ci[b] = c.Lp[(c.rS[b] >= 0) ? c.rS[b] + c0 + j : c.zero];
-                ck[b] = c.Lp[(c.cS[b] >= 0) ? c.cS[b] + c0 + j : c.zero] * pin;
+                if constexpr (LdlCtx<NBLK>::SQ) {   // (every row of the square exists: rows beyond the border row hold zeros)
+                    ci[b] = c.Lp[c.rS[b] + c0 + j];
+                    ck[b] = c.Lp[c.cS[b] + c0 + j] * pin;
+                } else {
+                    ci[b] = c.Lp[(c.rS[b] >= 0) ? c.rS[b] + c0 + j : c.zero];
+                    ck[b] = c.Lp[(c.cS[b] >= 0) ? c.cS[b] + c0 + j : c.zero] * pin;
+                }
             }
 #pragma unroll
             for (int bi = P + 1; bi < NBLK; ++bi)
@@ -1287,7 +1306,8 @@ __device__ __forceinline__ bool ldl_panels(const LdlCtx<NBLK>& c, double (&w)[NB
 #pragma unroll
     for (int bi = P; bi < NBLK; ++bi) {
         const int q1 = bi * 16 + c.ty, q2 = c0 + c.tx;
-        c.Lp[(c.rS[bi] >= 0 && q2 <= q1) ? c.rS[bi] + q2 : c.trash] = w[bi * (bi + 1) / 2 + P];
+        if constexpr (LdlCtx<NBLK>::SQ) c.Lp[c.rS[bi] + q2] = (q2 <= q1 && q1 <= c.n) ? w[bi * (bi + 1) / 2 + P] : 0.0;   // (zeros above the diagonal and below the border row)
+        else c.Lp[(c.rS[bi] >= 0 && q2 <= q1) ? c.rS[bi] + q2 : c.trash] = w[bi * (bi + 1) / 2 + P];
     }
     __syncthreads();
     PROF_LAP_EXT(46);
@@ -1334,13 +1354,22 @@ __device__ __noinline__ bool ldl_factor(const typename APass<NBLK>::type Av, int
     }
     // Lp: the packed factor, entry (i, j), j <= i, at i (i + 1) / 2 + j; row n is the right-hand side.  Behind it: 64 per-lane
     // trash words (stores that do not apply), a zero word (loads that do not apply), the panels' verdict.
-    c.trash = (n + 1) * (n + 2) / 2 + c.lane; c.zero = (n + 1) * (n + 2) / 2 + 64;
+    constexpr bool SQ = LdlCtx<NBLK>::SQ;
+    constexpr int LS = LdlCtx<NBLK>::LS;
+    const int fend = SQ ? NBLK * 16 * LS : (n + 1) * (n + 2) / 2;   // the factor's words
+    c.trash = fend + c.lane; c.zero = fend + 64;
     c.Zr = c.Lp + c.zero;
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int q1 = b * 16 + c.ty, q2 = b * 16 + c.tx;
-        c.rS[b] = (q1 <= n) ? q1 * (q1 + 1) / 2 : -1;
-        c.cS[b] = (q2 <= n) ? q2 * (q2 + 1) / 2 : -1;
+        c.rS[b] = SQ ? q1 * LS : ((q1 <= n) ? q1 * (q1 + 1) / 2 : -1);
+        c.cS[b] = SQ ? q2 * LS : ((q2 <= n) ? q2 * (q2 + 1) / 2 : -1);
+    }
+    if constexpr (SQ) {   // the tiles right of the diagonal tiles: zeros (the back-substitution reads whole rows)
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+            for (int bj = bi + 1; bj < NBLK; ++bj) c.Lp[c.rS[bi] + bj * 16 + c.tx] = 0.0;
     }
     if (tid == 0) { c.Zr[0] = 0.0; c.Zr[1] = 0.0; }
     PROF_MARK();
@@ -1360,7 +1389,9 @@ __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n
     double* const d = lds + o_d;
     const double* const pinv = lds + o_pinv;
     const int tid = threadIdx.x;
-    const int zero = (n + 1) * (n + 2) / 2 + 64;
+    constexpr bool SQ = ldl_square<NBLK>();
+    constexpr int LS = LdlCtx<NBLK>::LS;
+    const int zero = (SQ ? NBLK * 16 * LS : (n + 1) * (n + 2) / 2) + 64;
     PROF_BEGIN();
     // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
     // Rows of the factor and 1/d_j are fetched a whole group of U steps ahead (an LDS round trip is several times the
@@ -1370,6 +1401,30 @@ __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n
     // y by its own 1/d once, after the loop: the same product the step formed.  (Round 3's form selected lane j per step through the
     // exec mask and branched on j >= 0: 178 cycles a step.)  Steps below row 0 of the last group run with 1/d = 0: no effect.
     PROF_T(_tb0);
+    if constexpr (SQ) {
+        // Square factor: row j at a compile-time offset from the lane's base address, zeros on and right of the diagonal stored --
+        // a step is multiply, readlane, read, fma with nothing to compute about addresses.  Every row 16 NBLK - 2 .. 1 is stepped
+        // through: rows at and beyond the border row meet y = 0 in their lane (their products are zero: the border row's entries
+        // and the zero rows behind it are finite), so n needs no test.
+        if (tid < 64) {
+            const double* row0 = Lp + tid;
+            if (NBLK * 16 >= 64 || tid < NBLK * 16) lds[o_Lp + tid * LS + tid] = 0.0;   // (the diagonal holds the pivots: lane j's own entry of row j must not touch y_j; same wavefront: ordered)
+            double y0 = Lp[(tid < n) ? n * LS + tid : zero];
+            const double pl0 = pinv[min(tid, max(n - 1, 0))];
+            // (all rows first: 16 NBLK - 2 reads whose only cost is their issue slots -- left to the scheduler they sit two steps ahead of
+            //  their use and every other step waits out an LDS round trip)
+            double L[NBLK * 16 - 1];
+#pragma unroll
+            for (int j = NBLK * 16 - 2; j >= 1; --j) L[j] = row0[j * LS];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = NBLK * 16 - 2; j >= 1; --j) {
+                const double dj = readlane_f64(y0 * pl0, j);
+                y0 = fma(-L[j], dj, y0);
+            }
+            if (tid < n) d[tid] = y0 * pl0;
+        }
+    } else
     if (tid < 64) {
         constexpr int U = 8;
         constexpr bool HI = NBLK > 4;   // unknowns 64.. exist

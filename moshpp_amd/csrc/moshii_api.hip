@@ -318,7 +318,7 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     // packed factor + 64 per-lane trash words / zero word + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
     // the factor lives in global scratch and LDS keeps the broadcast buffer plus a 16-row panel
     // (ldl_big: a [LDJ][17] block column + nblk exchange tiles; its back-substitution lays two [16][LDJ] row buffers over them)
-    const int chol = (nblk > 8) ? 66 + std::max(17 * LDJ + 256 * nblk, 32 * LDJ) + 4 : (nmax + 1) * (nmax + 2) / 2 + 66 + 4 * LDJ + 4;
+    const int chol = (nblk > 8) ? 66 + std::max(17 * LDJ + 256 * nblk, 32 * LDJ) + 4 : ((nblk <= 4) ? LDJ * (LDJ + 1) : (nmax + 1) * (nmax + 2) / 2) + 66 + 4 * LDJ + 4;   // (<= 4 blocks: the factor square, chain_solve.hip: ldl_square)
     ly.big_doubles = std::max(std::max(t, chol), 16 * 256);   // (16 x 256: the J^T J tile exchange, AReg::take)
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
@@ -795,7 +795,9 @@ int prepare_launch(moshii_model_t m, moshii_prior_t prior, const moshii_solve_op
         if (nmax + 1 > nblk * 16) return fail(MOSHII_ERR_UNSUPPORTED, "cooperative chains: too many unknowns");
         if (coop_g > MOSHII_COOP_MAXG) return fail(MOSHII_ERR_ARG, "cooperative chains: at most 8 workgroups per chain");
         // with a prior: from three ranks on the last one does nothing but the prior (measured: its evaluation is as long as the others' forward pass)
-        cfg->coop_prior_frac = (npose > 0) ? ((coop_g >= 3) ? 0.0 : 0.4) : 1.0;
+        // (the extended variant's per-marker work -- shape columns, 13-block tiles -- outweighs the prior: its rank takes half a share of markers too;
+        //  measured on config 3, eight ranks: 3.53 / 3.30 / 3.65 / 3.60 ms per cold frame at 0 / 0.5 / 0.8 / 1)
+        cfg->coop_prior_frac = (npose > 0) ? ((coop_g >= 3) ? (xt ? 0.5 : 0.0) : 0.4) : 1.0;
         if (const char* e = getenv("MOSHII_COOP_PRIOR_FRAC")) cfg->coop_prior_frac = std::min(1.0, std::max(0.0, atof(e)));
         int mlo[MOSHII_COOP_MAXG + 1];
         coop_split(Mmax, coop_g, cfg->coop_prior_frac, mlo);
