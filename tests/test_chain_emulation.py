@@ -268,3 +268,27 @@ def test_cooperative_extended_kernel_matches_oracle_in_emulation(monkeypatch, G)
     np.testing.assert_array_equal(out['iters'][:, 0], ref['iters'])
     np.testing.assert_array_equal(out['iters'], plain['iters'])
     assert np.abs(out['shape'] - plain['shape']).max() < 1e-9 and np.abs(out['markers_sim'] - plain['markers_sim']).max() < 1e-9
+
+
+@pytest.mark.parametrize('E,G', [(20, 0), (20, 3)])
+def test_extended_kernel_with_more_than_127_unknowns_in_emulation(monkeypatch, E, G):
+    """3 + 111 + E unknowns (fingers, jaw and E expression coefficients free): beyond eight register blocks the factor lives in global
+    memory and the solve is ldl_big -- 16-column panels on wavefront 0, the left-looking products on the matrix pipe (v_mfma_f64_16x16x4)
+    by the other wavefronts, a staged back-substitution; as a cooperative chain the assembly's exchange is the reduce-scatter +
+    all-gather form (14 tiles per wavefront at ten blocks).  Same iteration counts as the oracle, the first frame from a cold start."""
+    from tests.helpers import shape_case
+    if G:
+        monkeypatch.setenv('HIPEMU_CONCURRENT', '1')
+    case = shape_case('smplx', F=2, M=60, E=E, seed=5, kind='expr')
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_fingers=True, optimize_face=True, shape_kind='expr')
+        out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'],
+                                    [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)], coop=G or 1)[0]
+        name = capi.last_launch_info()[0]
+        assert name == ('k_chain_solve<10,1,xt,coop3>' if G else 'k_chain_solve<10,1,xt>'), name
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplx',
+                           optimize_fingers=True, optimize_face=True, free_shape='expr')
+    assert np.abs(out['fullpose'] - ref['fullpose']).max() < 2e-8 and np.abs(out['shape'] - ref['shape']).max() < 2e-8
+    np.testing.assert_array_equal(out['iters'][:, 0], ref['iters'])
+    assert np.all(out['status'] == 0)
+

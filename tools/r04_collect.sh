@@ -11,6 +11,10 @@ MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=1 timeout 200 python tools/p
 MOSHII_LIB=moshpp_amd/libmoshii_prof.so timeout 200 python tools/prof_chain.py 400 smplh > $O/phase_breakdown_cooperative.txt 2>&1
 MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=6 timeout 200 python tools/coop_trace.py 200 > $O/coop_exchange_trace.txt 2>&1
 timeout 300 python tools/coop_time.py 400 --groups=2,3,4,5,6,7,8 --fracs=0 > $O/coop_groups.txt 2>&1
+( echo "# MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=1 python tools/prof_config3.py 40 80"; MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=1 timeout 200 python tools/prof_config3.py 40 80;
+  echo; echo "# MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=8 python tools/prof_config3.py 40 80  (rank 0 of the group)"; MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=8 timeout 200 python tools/prof_config3.py 40 80;
+  echo; echo "# MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=8 python tools/coop_trace.py 60 config3"; MOSHII_LIB=moshpp_amd/libmoshii_prof.so MOSHII_COOP=8 timeout 200 python tools/coop_trace.py 60 config3 ) > $O/config3_phases.txt 2>&1
+timeout 120 tools/bin/ubench_scope > $O/scope_ubench.txt 2>&1
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/stats -o bench -- python /root/repo/bench.py --no-cpu --no-stagei --no-config3 > /root/repo/$O/bench_line_under_rocprof.json 2> /root/repo/$O/rocprof_err.txt)
 cp $O/stats/bench_kernel_stats.csv $O/ 2>/dev/null
 python - <<'PY' > $O/bench_launches.txt 2>&1
