@@ -25,7 +25,11 @@ buf = (C.c_longlong * (8 * N * 4))()
 lib.moshii_prof_trace_read.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.moshii_prof_trace_read(buf) == N
 t = np.array(buf, dtype=np.int64).reshape(8, N, 4)[:G]
-used = (t[0, :, 0] > 0)
+# (an assembly's exchange in the reduce-scatter form spans two sequence numbers: its read-done stamp is the next one's)
+for i in range(N - 1):
+    if t[0, i, 0] > 0 and t[0, i, 3] == 0 and t[0, i + 1, 3] > 0:
+        t[:, i, 3] = t[:, i + 1, 3]
+used = (t[0, :, 0] > 0) & (t[0, :, 3] > 0)
 idx = np.flatnonzero(used)[5:-5]
 tt = t[:, idx, :].astype(np.float64) * 0.01     # us
 arrive, posted, seen, done = tt[..., 0], tt[..., 1], tt[..., 2], tt[..., 3]
