@@ -91,6 +91,26 @@ __device__ __forceinline__ double readlane_f64(double v, int lane /* wave-unifor
     return __hiloint2double(hi, lo);
 }
 enum { DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140 };
+// 64-bit DPP with row_newbcast:K (gfx90a on: the only lane control the double-precision ALU takes): every lane reads lane K of its own row
+// of 16.  rowbcast_f64<K>(v) = that value; fmac_rowbcast<K>(acc, m, a): acc = fma(-m[lane K of the row], a, acc) in ONE instruction --
+// what two v_readlane + an fma do when the broadcast value sits in every row (ldl_panel_eliminate_rows).  The source of a DPP read must
+// not have been written by the two instructions before it (hazard the compiler handles for its own DPP, not inside asm): dpp_settle()
+// ties a two-wait-state s_nop to the value.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void dpp_settle(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
+template <int K> __device__ __forceinline__ double rowbcast_f64(double v) {
+    double r;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+template <int K> __device__ __forceinline__ void fmac_rowbcast(double& acc, double m, double a) {
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(a), "n"(K));
+}
+#else
+__device__ __forceinline__ void dpp_settle(double&) {}
+template <int K> __device__ __forceinline__ double rowbcast_f64(double v) { return __shfl(v, K, 16); }
+template <int K> __device__ __forceinline__ void fmac_rowbcast(double& acc, double m, double a) { acc = fma(-__shfl(m, K, 16), a, acc); }
+#endif
 
 // Sum over the wavefront, the bitwise-identical total in every lane: an exchange butterfly inside each row of 16 lanes
 // (pairs, quads, halves, row -- both partners add the same two numbers, so all 16 lanes agree), then the four row sums.
@@ -626,24 +646,33 @@ __device__ Sse eval_forward(const Ctx& cx, const ModelDev& md, const AttachDev& 
         if (op.nshape > 0) {
             const int E = op.nshape, Nvp = at.Nvp;
             const double* shp = pose + md.NP;
+            // (both sums: sixteen coefficients' loads in flight at a time -- one item per thread and 40 dependent round trips to the L2 made
+            //  these two loops 17 us of a config-3 evaluation; the same two accumulators in the same order: the same bits)
+            auto dot_s = [&](auto ld, double s0) {   // s0 + sum_e ld(e) shp[e], even e into s0, odd into s1 (a trailing odd one into s0)
+                double s1 = 0.0;
+                int e = 0;
+                for (; e + 16 <= E; e += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = ld(e + u);
+#pragma unroll
+                    for (int u = 0; u < 16; u += 2) { s0 += v[u] * shp[e + u]; s1 += v[u + 1] * shp[e + u + 1]; }
+                }
+                for (; e + 2 <= E; e += 2) { s0 += ld(e) * shp[e]; s1 += ld(e + 1) * shp[e + 1]; }
+                if (e < E) s0 += ld(e) * shp[e];
+                return s0 + s1;
+            };
             for (int i = tid; i < 3 * K; i += MOSHII_TPB) {   // J = J0 + JS . s
                 const auto* js = md.JS + (size_t)(i / 3) * E * 3 + (i % 3);
-                double s0 = md.J[i], s1 = 0.0;
-                int e = 0;
-                for (; e + 2 <= E; e += 2) { s0 += js[e * 3] * shp[e]; s1 += js[(e + 1) * 3] * shp[e + 1]; }
-                if (e < E) s0 += js[e * 3] * shp[e];
-                cx.Jl[i] = s0 + s1;
+                cx.Jl[i] = dot_s([&](int e) { return js[e * 3]; }, md.J[i]);
             }
             const int na = COOP ? (a_hi - a_lo) : Nvp;   // (cooperative chains: this rank's vertices only)
             for (int it = tid; it < 3 * na; it += MOSHII_TPB) {   // rest vertices: vbase + S . s (vertex fastest: coalesced rows)
                 const int i = it / na, a = (COOP ? a_lo : 0) + (it - i * na);
                 const auto* sp = gptr(at.Ssh) + (size_t)i * Nvp + a;
                 const size_t st = (size_t)3 * Nvp;
-                double s0 = 0.0, s1 = 0.0;
-                int e = 0;
-                for (; e + 2 <= E; e += 2) { s0 += sp[e * st] * shp[e]; s1 += sp[(e + 1) * st] * shp[e + 1]; }
-                if (e < E) s0 += sp[e * st] * shp[e];
-                if (a < at.Nv) cx.vshp[a * 3 + i] = vbase[a * 3 + i] + (s0 + s1);
+                const double sv = dot_s([&](int e) { return sp[e * st]; }, 0.0);
+                if (a < at.Nv) cx.vshp[a * 3 + i] = vbase[a * 3 + i] + sv;
             }
             vbase = cx.vshp;
         }
@@ -1272,6 +1301,65 @@ __device__ __forceinline__ bool ldl_panel_eliminate(const LdlCtx<NBLK>& c) {
     }
     return bad;
 }
+// B for the square form (<= 4 register blocks): the diagonal block's 16 rows sit in ALL FOUR rows of 16 lanes of wavefront 0 (lane l: row
+// c0 + l % 16) beside the up to 48 rows below it (lane l: row c0 + 16 + l), so a pivot-column multiplier reaches every lane through a
+// row broadcast inside the fma -- v_fmac_f64_dpp ... row_newbcast:k -- instead of two v_readlane and an fma per (column, later column)
+// pair: ~500 instructions a panel instead of ~710 (~340 on the last, which has no rows below).  The same products and sums in the same
+// order: the same bits.
+template <int J, int K>
+__device__ __forceinline__ void ldl_rows_update(double (&a)[16], double lj) {   // a_k -= a_J l_kJ for k = K .. 15
+    if constexpr (K < 16) {
+        fmac_rowbcast<K>(a[K], lj, a[J]);
+        ldl_rows_update<J, K + 1>(a, lj);
+    }
+}
+template <int NBLK, int P, bool FULL, int J>
+__device__ __forceinline__ void ldl_rows_column(const LdlCtx<NBLK>& c, double* pinp, double (&ad)[16], double (&ab)[16], bool& bad) {
+    constexpr int c0 = 16 * P;
+    constexpr bool BELOW = c0 + 16 < NBLK * 16;
+    if (FULL || c0 + J < c.n) {   // (uniform: the border row's own "column" is not eliminated)
+        dpp_settle(ad[J]);
+        const double pj = rowbcast_f64<J>(ad[J]);
+        bad = bad || !(pj > 0.0);
+        double pin = __builtin_amdgcn_rcp(pj);
+        pin = fma(fma(-pj, pin, 1.0), pin, pin);
+        pin = fma(fma(-pj, pin, 1.0), pin, pin);
+        pinp[J] = pin;   // (lane 0: pinv[c0 + J]; the others: their parking words)
+        double lj = ad[J] * pin;   // lane l: c_kj pin_j of diagonal row k = l % 16
+        dpp_settle(lj);
+        ldl_rows_update<J, J + 1>(ad, lj);
+        if constexpr (BELOW) ldl_rows_update<J, J + 1>(ab, lj);
+    }
+    if constexpr (J + 1 < 16) ldl_rows_column<NBLK, P, FULL, J + 1>(c, pinp, ad, ab, bad);
+}
+template <int NBLK, int P, bool FULL>
+__device__ __forceinline__ bool ldl_panel_eliminate_rows(const LdlCtx<NBLK>& c) {
+    constexpr int c0 = 16 * P, LS = LdlCtx<NBLK>::LS, LD = NBLK * 16;
+    constexpr bool BELOW = c0 + 16 < LD;
+    const int rd = c0 + (c.lane & 15), rb = c0 + 16 + c.lane;
+    double ad[16], ab[16];
+    {
+        const double* pd = c.Lp + rd * LS + c0;
+        const double* pb = c.Lp + ((BELOW && rb < LD) ? rb * LS + c0 : c.zero);
+        const int sb = (BELOW && rb < LD) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ad[k] = pd[k]; ab[k] = BELOW ? pb[k * sb] : 0.0; }
+    }
+    bool bad = false;
+    double* const pinp = (c.lane == 0) ? c.pinv + c0 : c.Lp + c.trash;
+    ldl_rows_column<NBLK, P, FULL, 0>(c, pinp, ad, ab, bad);
+    {   // the factor's entries: the diagonal block's rows from the first row of lanes (on and left of the diagonal, rows up to the border row) ...
+        const int offd = rd * LS + c0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c.Lp[(c.lane < 16 && rd <= c.n && k <= (c.lane & 15)) ? offd + k : c.trash] = ad[k];
+        if constexpr (BELOW) {   // ... and the rows below whole
+            double* const pb = c.Lp + ((rb <= c.n) ? rb * LS + c0 : c.trash);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pb[k] = ab[k];
+        }
+    }
+    return bad;
+}
 // C: panel P applied to every tile to its right
 template <int NBLK, int P, bool FULL>
 __device__ __forceinline__ void ldl_panel_apply(const LdlCtx<NBLK>& c, double (&w)[NBLK * (NBLK + 1) / 2]) {
@@ -1312,7 +1400,9 @@ __device__ __forceinline__ bool ldl_panels(const LdlCtx<NBLK>& c, double (&w)[NB
     __syncthreads();
     PROF_LAP_EXT(46);
     if (threadIdx.x < 64) {
-        const bool bad = (c0 + 16 <= c.n) ? ldl_panel_eliminate<NBLK, P, true>(c) : ldl_panel_eliminate<NBLK, P, false>(c);
+        bool bad;
+        if constexpr (LdlCtx<NBLK>::SQ && NBLK == 4) bad = (c0 + 16 <= c.n) ? ldl_panel_eliminate_rows<NBLK, P, true>(c) : ldl_panel_eliminate_rows<NBLK, P, false>(c);
+        else bad = (c0 + 16 <= c.n) ? ldl_panel_eliminate<NBLK, P, true>(c) : ldl_panel_eliminate<NBLK, P, false>(c);
         if (c.lane == 0 && bad) c.Zr[1] = 1.0;
     }
     __syncthreads();
@@ -1357,7 +1447,7 @@ __device__ __noinline__ bool ldl_factor(const typename APass<NBLK>::type Av, int
     constexpr bool SQ = LdlCtx<NBLK>::SQ;
     constexpr int LS = LdlCtx<NBLK>::LS;
     const int fend = SQ ? NBLK * 16 * LS : (n + 1) * (n + 2) / 2;   // the factor's words
-    c.trash = fend + c.lane; c.zero = fend + 64;
+    c.trash = fend + c.lane; c.zero = fend + (SQ ? 80 : 64);   // (square form: 16 words more, a parked lane's 16-entry row store lands at trash .. trash + 15)
     c.Zr = c.Lp + c.zero;
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
@@ -1391,7 +1481,7 @@ __device__ __noinline__ void ldl_backsub(int o_Lp_, int o_d_, int o_pinv_, int n
     const int tid = threadIdx.x;
     constexpr bool SQ = ldl_square<NBLK>();
     constexpr int LS = LdlCtx<NBLK>::LS;
-    const int zero = (SQ ? NBLK * 16 * LS : (n + 1) * (n + 2) / 2) + 64;
+    const int zero = SQ ? NBLK * 16 * LS + 80 : (n + 1) * (n + 2) / 2 + 64;
     PROF_BEGIN();
     // back substitution by wave 0: lane l owns unknowns l and l+64; the solved x_j is broadcast with v_readlane.
     // Rows of the factor and 1/d_j are fetched a whole group of U steps ahead (an LDS round trip is several times the
@@ -1842,9 +1932,13 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             double* dtv = qs;
             double* qv = qs + (size_t)KE * 3;
             for (int lvl = 0; lvl <= md.maxdepth; ++lvl) {
-                for (int it = tid; it < KE; it += MOSHII_TPB) {
-                    const int j = it / E, e = it - j * E;
-                    if (md.depth[j] != lvl) continue;
+                // (the level's joints from a list built once per chain: scanning all K E items for those of this depth was 17 rounds of a
+                //  division, a depth load and a branch per thread and level -- a third of this phase's 45 us at 55 joints x 80 coefficients)
+                const auto* const bl = gptr(md.depth) + md.K;   // (ModelDev::depth: the sorted list and the level starts ride behind the depths)
+                const int l0 = bl[md.K + lvl], nl = bl[md.K + lvl + 1] - l0;
+                for (int ix = tid; ix < nl * E; ix += MOSHII_TPB) {
+                    const int jl = ix / E, e = ix - jl * E;
+                    const int j = bl[l0 + jl], it = j * E + e;
                     const auto* js = md.JS + (size_t)it * 3;
                     const double jx = js[0], jy = js[1], jz = js[2];
                     double dx = jx, dy = jy, dz = jz;
@@ -2067,11 +2161,18 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const int ml = it / nfree_hand, q = ncp - nfree_hand + (it - ml * nfree_hand);   // hand columns are the tail of the pose columns
                 const int i = cx.colpid[q] - bd;
                 double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-                for (int h = md.comp_lo[i]; h < md.comp_hi[i]; ++h) {
-                    const int hj = h / 3, c = h - 3 * hj;
-                    const double cc = md.comps[i * nhf + h];
-                    const double* jh = &cx.Jh[((size_t)ml * ly.nhj + hj) * 9];
-                    r0 += cc * jh[0 * 3 + c]; r1 += cc * jh[1 * 3 + c]; r2 += cc * jh[2 * 3 + c];
+                const int hlo = md.comp_lo[i], hhi = md.comp_hi[i];
+                for (int h0 = hlo; h0 < hhi; h0 += 15) {   // fifteen components' loads in flight at a time (one by one: 45 round trips to the L2 per item)
+                    double ccv[15];
+#pragma unroll
+                    for (int u = 0; u < 15; ++u) ccv[u] = md.comps[i * nhf + min(h0 + u, hhi - 1)] * ((h0 + u < hhi) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int u = 0; u < 15; ++u) {
+                        const int h = min(h0 + u, hhi - 1), hj = h / 3, c = h - 3 * hj;
+                        const double cc = ccv[u];
+                        const double* jh = &cx.Jh[((size_t)ml * ly.nhj + hj) * 9];
+                        r0 += cc * jh[0 * 3 + c]; r1 += cc * jh[1 * 3 + c]; r2 += cc * jh[2 * 3 + c];
+                    }
                 }
                 cx.Jrow[(3 * ml + 0) * LDJ + q] = fp.wt_data * r0;
                 cx.Jrow[(3 * ml + 1) * LDJ + q] = fp.wt_data * r1;

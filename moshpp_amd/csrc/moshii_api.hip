@@ -318,7 +318,7 @@ ChainLayout make_layout(const moshii_model_s* m, int Mmax, int Nvmax, int NWmax,
     // packed factor + 64 per-lane trash words / zero word + the column broadcast buffer of ldl_solve; beyond 8 register blocks (extended variant)
     // the factor lives in global scratch and LDS keeps the broadcast buffer plus a 16-row panel
     // (ldl_big: a [LDJ][17] block column + nblk exchange tiles; its back-substitution lays two [16][LDJ] row buffers over them)
-    const int chol = (nblk > 8) ? 66 + std::max(17 * LDJ + 256 * nblk, 32 * LDJ) + 4 : ((nblk <= 4) ? LDJ * (LDJ + 1) : (nmax + 1) * (nmax + 2) / 2) + 66 + 4 * LDJ + 4;   // (<= 4 blocks: the factor square, chain_solve.hip: ldl_square)
+    const int chol = (nblk > 8) ? 66 + std::max(17 * LDJ + 256 * nblk, 32 * LDJ) + 4 : ((nblk <= 4) ? LDJ * (LDJ + 1) + 16 : (nmax + 1) * (nmax + 2) / 2) + 66 + 4 * LDJ + 4;   // (<= 4 blocks: the factor square, chain_solve.hip: ldl_square)
     ly.big_doubles = std::max(std::max(t, chol), 16 * 256);   // (16 x 256: the J^T J tile exchange, AReg::take)
     ly.o_big = take(ly.big_doubles);
     ly.total_doubles = off;
@@ -388,7 +388,13 @@ int moshii_model_create(const moshii_model_desc* d, moshii_model_t* out) {
     if ((rc = dev_upload(d->weights, V * K, &m->d_weights))) return rc;
     if ((rc = dev_upload(d->J_regressor, K * V, &m->d_Jreg))) return rc;
     if ((rc = dev_upload(m->parents.data(), K, &m->d_parents))) return rc;
-    if ((rc = dev_upload(m->depth.data(), K, &m->d_depth))) return rc;
+    {   // behind the depths: the joints sorted by depth ([K]) and where each depth starts ([maxdepth + 2]) -- the level-by-level walks of the kernels
+        std::vector<int> dl(m->depth);
+        for (int l = 0; l <= m->maxdepth; ++l) for (size_t j = 0; j < K; ++j) if (m->depth[j] == l) dl.push_back((int)j);
+        int c = 0;
+        for (int l = 0; l <= m->maxdepth + 1; ++l) { dl.push_back(c); for (size_t j = 0; j < K; ++j) c += (m->depth[j] == l) ? 1 : 0; }
+        if ((rc = dev_upload(dl.data(), dl.size(), &m->d_depth))) return rc;
+    }
     if ((rc = dev_upload(anc.data(), K, &m->d_anc))) return rc;
     if (d->hand_dof > 0) {
         std::vector<int> lo(d->hand_dof), hi(d->hand_dof);

@@ -40,7 +40,7 @@ struct ModelDev {
     MOSHII_GP(const int) col_lo;               // [nhand_full] first component with a non-zero entry in this column
     MOSHII_GP(const int) col_hi;               // [nhand_full] one past the last such component
     MOSHII_GP(const unsigned long long) anc;   // [K] bit j set iff k is j or an ancestor of j
-    MOSHII_GP(const int) depth;                // [K]
+    MOSHII_GP(const int) depth;                // [K] depths, [K] the joints sorted by depth, [maxdepth + 2] where each depth starts in that list
     // free shape block (moshii_model_set_free_shape): dJ/ds, joint-major so that (joint, coefficient) items are contiguous
     int nshape;
     MOSHII_GP(const double) JS;                // [K][nshape][3]
