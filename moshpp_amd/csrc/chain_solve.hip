@@ -1755,6 +1755,8 @@ __device__ __forceinline__ bool big_blocks(const AReg<NBLK>& A, double* Lp, doub
     if constexpr (B + 1 < NBLK) {
         if (B + 1 < NB) {
             // W = A - U1 - (panel B's columns)
+            // (tried: panel B's columns on the matrix pipe too, operands from Wp, added into the exchange tiles by their owners -- the same
+            //  33 us per solve: this phase is its three barriers and the two passes over Ux / Wp, not the 16 x NBLK fmas)
             double W[NBLK];
             const int q2 = (B + 1) * 16 + tx;
             const double gq = g[min(q2, n - 1)] * ((q2 < n) ? 1.0 : 0.0);
@@ -2114,6 +2116,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             }
         }
         if constexpr (XT) {
+            // (tried: an item's 9 + 36 loads all in flight before the first use instead of influence by influence -- T1 + T1s 160 -> 284 us per cold
+            //  config-3 frame: assemble_fn<13> has no registers left for 45 more doubles per lane and spills them)
             // T1s: shape columns.  item = (tile marker, coefficient): dv/ds_e = Trot . S_e(v) + sum_s w_s q_{j_s, e} for the
             // marker's three vertices, contracted with the marker's local 3x9 Jacobian.
             if (nshp > 0) {
