@@ -456,27 +456,40 @@ KERNEL k_s1_vjac(S1Dims d, S1Ptr p, int zbase) {
 
 #define S1_NNK 8          // neighbours kept per marker (transformed_lm.py:73: the kd-tree query asks for 8)
 KERNEL k_s1_knn(S1Dims d, S1Ptr p, int* cl8_out) {
+    // ONE pass over the vertices: every thread keeps the 8 nearest of its own stride in registers, ordered by (distance, vertex id) -- a fixed
+    // insertion network, no indexing by a run-time value -- then eight rounds of "the nearest head wins and its owner moves on".  (Round 3
+    // made eight passes over V, one per neighbour: 2.7 x the work of the three-neighbour search it replaced, in every residual and Jacobian
+    // evaluation of the dogleg.)
     SHARED double bd[256]; SHARED int bi[256];
     int m = BX;
     const double* x = p.ml + 3 * m;
-    int found[S1_NNK];
-    for (int s = 0; s < S1_NNK; ++s) found[s] = -1;
-    for (int pass = 0; pass < S1_NNK; ++pass) {
-        double best = 1e300; int besti = 0x7fffffff;
-        for (int v = TID; v < d.V; v += NT) {
-            if (p.excl[v]) continue;
-            bool taken = false;
-            for (int s = 0; s < pass; ++s) taken = taken || v == found[s];
-            if (taken) continue;
-            double dx = x[0] - p.can[3 * v], dy = x[1] - p.can[3 * v + 1], dz = x[2] - p.can[3 * v + 2];
-            double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < best || (d2 == best && v < besti)) { best = d2; besti = v; }
+    double kd[S1_NNK]; int ki[S1_NNK];
+    for (int s = 0; s < S1_NNK; ++s) { kd[s] = 1e300; ki[s] = 0x7fffffff; }
+    for (int v = TID; v < d.V; v += NT) {
+        if (p.excl[v]) continue;
+        double dx = x[0] - p.can[3 * v], dy = x[1] - p.can[3 * v + 1], dz = x[2] - p.can[3 * v + 2];
+        double cd = dx * dx + dy * dy + dz * dz; int ci = v;
+        if (cd < kd[S1_NNK - 1] || (cd == kd[S1_NNK - 1] && ci < ki[S1_NNK - 1])) {
+            for (int s = 0; s < S1_NNK; ++s) {   // (cd, ci) sinks to its place, what it displaces moves on down
+                const bool lt = cd < kd[s] || (cd == kd[s] && ci < ki[s]);
+                const double td = lt ? kd[s] : cd; const int ti = lt ? ki[s] : ci;
+                kd[s] = lt ? cd : kd[s]; ki[s] = lt ? ci : ki[s];
+                cd = td; ci = ti;
+            }
         }
-        bd[TID] = best; bi[TID] = besti;
+    }
+    int found[S1_NNK];
+    for (int pass = 0; pass < S1_NNK; ++pass) {
+        bd[TID] = kd[0]; bi[TID] = ki[0];
         SYNC();
         S1_BLOCK_ARGMIN(bd, bi)
-        found[pass] = bi[0];
+        const int win = bi[0];
+        found[pass] = win;
         SYNC();
+        if (ki[0] == win) {   // this thread's head was taken: its list moves up
+            for (int s = 0; s + 1 < S1_NNK; ++s) { kd[s] = kd[s + 1]; ki[s] = ki[s + 1]; }
+            kd[S1_NNK - 1] = 1e300; ki[S1_NNK - 1] = 0x7fffffff;
+        }
     }
     if (TID == 0) for (int s = 0; s < S1_NNK; ++s) cl8_out[S1_NNK * m + s] = found[s];
 }
