@@ -234,15 +234,21 @@ def main():
         share = shares[rank]
         stream = torch.cuda.current_stream().cuda_stream
 
-        def solve(idx):
+        def solve(idx, reps=1, warm=1, sync=None):
+            """`warm` untimed passes over the share (>= 1: allocations inside the library), then `reps` timed ones (a pass = one step of the
+            N > 1 headline); sync(): the ranks' barrier in front of the timed passes.  Returns seconds PER PASS and frames per pass."""
             copies = [workload.DeviceSequence(workload.make_capture(job, solver, 5000 + i), solver, dev) for i in idx]
             per_seq_chunks = max(8, 256 // max(len(copies), 1))      # keep every CU carrying a chain when a rank has few sequences
-            workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)   # untimed first pass (allocations inside the library)
+            for _ in range(max(1, warm)):
+                workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)
             torch.cuda.synchronize()
+            if sync is not None:
+                sync()
             t0 = time.perf_counter()
-            workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)
+            for _ in range(max(1, reps)):
+                workload.solve_many_chunked(copies, stream, num_chunks=per_seq_chunks)
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = (time.perf_counter() - t0) / max(1, reps)
             return dt, sum(int((c.results()['status'] != 1).sum()) for c in copies)
 
         t_one, n_one = None, 0
@@ -252,11 +258,15 @@ def main():
             barrier()
         n_local = len(share)
         t_here, n_here = 0.0, 0
-        barrier()
+        # the N > 1 headline: --warmup untimed and --steps timed passes over the job, a barrier on both sides of the timed ones (a rank
+        # without a share still meets the barriers); on one GPU the leg is an extra of the default line: one warm-up, one pass
+        reps, warm = (args.steps, args.warmup) if headline_is_strong else (1, 1)
         if n_local:
-            t_here, n_here = solve(share)
+            t_here, n_here = solve(share, reps=reps, warm=warm, sync=barrier)
+        else:
+            barrier()
         barrier()
-        return n_here, t_here, n_local, t_one, n_one
+        return n_here, t_here, n_local, t_one, n_one, reps, max(1, warm)
 
     def strong_long():
         """One long sequence over the ranks by frame ranges (host buffers: the boundary rows travel through the process group)."""
@@ -376,10 +386,11 @@ def main():
 
     # ---- fixed jobs at this N (all ranks take part)
     strong = None
+    headline_is_strong = (args.scaling == 'strong' or (args.scaling == 'auto' and world > 1)) and args.mode == 'chunked' and not args.no_strong
     if not args.no_strong and args.mode == 'chunked':
         strong = {}
         try:
-            n_here, t_here, n_local, t_one, n_one = strong_many()
+            n_here, t_here, n_local, t_one, n_one, s_reps, s_warm = strong_many()
             t_job = allmax(t_here)
             n_job = allsum(n_here)
             if dist is not None:    # every rank's own seconds: who waited for whom
@@ -390,7 +401,7 @@ def main():
             strong['many_sequences'] = {
                 'workload': f'{args.strong_sequences} DISTINCT {F}-frame SMPL-H captures of the seed-{seeds[0]} subject (BASELINE config 3 shape with body markers; motion seeds 5000..), dealt to the ranks by '
                             'longest-processing-time (parallel.partition_units); no collective on the data path',
-                'frames': int(n_job), 'frames_per_s': round(n_job / t_job, 1), 'ms': round(t_job * 1e3, 2),
+                'frames': int(n_job), 'frames_per_s': round(n_job / t_job, 1), 'ms': round(t_job * 1e3, 2), 'timed_passes': s_reps, 'warmup_passes': s_warm,
                 'sequences_on_rank0': n_local, 'rank0_idle_ms': round((t_job - t_here) * 1e3, 2),
                 'rank_ms': [round(x * 1e3, 2) for x in tl], 'rank_idle_ms': [round((t_job - x) * 1e3, 2) for x in tl]}
             if t_one:
@@ -416,8 +427,8 @@ def main():
         result['strong'] = strong
         if (args.scaling == 'strong' or (args.scaling == 'auto' and world > 1)) and 'frames_per_s' in strong.get('many_sequences', {}):
             sj = strong['many_sequences']
-            result.update(value=sj['frames_per_s'], scaling='strong', ms_per_step=sj['ms'], steps=1, warmup=1,
-                          value_is='job frames / max-over-ranks seconds of the fixed many-sequence job')
+            result.update(value=sj['frames_per_s'], scaling='strong', ms_per_step=sj['ms'], steps=sj['timed_passes'], warmup=sj['warmup_passes'],
+                          value_is='job frames / max-over-ranks seconds per pass of the fixed many-sequence job (a step = one pass over the job)')
             result['config'] = {'workload': sj['workload'], 'mode': args.mode, 'markers': M,
                                 'parallelism': f'{world} rank(s) = {world} GPU(s), one process each; sequences sharded by longest-processing-time, no data-path collective'}
             result['replicas'] = {'value': round(value, 2), 'scaling': 'weak', 'seeds': per_seed}
