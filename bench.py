@@ -432,6 +432,9 @@ def main():
             result['config'] = {'workload': sj['workload'], 'mode': args.mode, 'markers': M,
                                 'parallelism': f'{world} rank(s) = {world} GPU(s), one process each; sequences sharded by longest-processing-time, no data-path collective'}
             result['replicas'] = {'value': round(value, 2), 'scaling': 'weak', 'seeds': per_seed}
+            if 'one_gpu_same_job' in sj:   # the same job on ONE GPU of this box (rank 0 alone, before the sharded run): what `value` is to be divided by
+                result['one_gpu_same_job'] = sj['one_gpu_same_job']
+                result['speedup_vs_one_gpu_same_job'] = sj['one_gpu_same_job']['speedup']
 
     if rank == 0:
         nobs_mean = float(job['vis'].sum(1).mean())
