@@ -2373,6 +2373,8 @@ __device__ void assemble(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             if (fp.has_velo) { const double w2 = fp.wt_velo * fp.wt_velo; dg += w2; gq -= w2 * (pose[pid] - cx.vtarget[pid]); }
             const int pb = cx.colprior[q];
             if (COOP) { gq += cx.dgn[q]; }   // (the prior rank's column sums, received above)
+            // (tried: these column sums formed at the top of the assembly by wavefronts 1..3 while wavefront 0 does the joints' Rodrigues
+            //  derivatives, parked in cx.dgn: `structured` 16 -> 6 us per frame and T0 19 -> 30 -- the two round trips are longer than what they hid behind)
             else if (pb >= 0) {   // prior gradient w^2 (1/2 L L^T)(x - mu): column pb of the symmetric half-precision, b uniform
                 const auto* Hk = pr.halfprec + (size_t)kb * np_ * np_ + pb;
                 const auto* mu = pr.means + (size_t)kb * np_;
