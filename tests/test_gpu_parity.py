@@ -286,6 +286,32 @@ def test_cooperative_chain_on_the_device(gpu_lib, g):
     np.testing.assert_array_equal(out['iters'][solved, 0], ref['iters'])
 
 
+@pytest.mark.parametrize('g', [3, 8])
+def test_cooperative_chain_with_fingers_on_the_device(gpu_lib, monkeypatch, g):
+    """SMPL-X with the finger coefficients free, run with eight register blocks (MOSHII_FORCE_NBLK: the solve itself fits seven; eight is
+    what the extended variant's mid-size solves use): from this size on a cooperative
+    assembly exchanges its normal equations as a reduce-scatter + all-gather pair (every rank sums a slice of the tiles over the ranks,
+    in rank order, and collects the others' sums), and the packed -- not square -- factor is what the solve keeps.  Against the plain
+    chain (round-off) and the oracle (iteration counts)."""
+    from moshpp_amd import capi
+    monkeypatch.setenv('MOSHII_FORCE_NBLK', '8')
+    case = oracle_case('smplx', F=24, M=89, seed=9, body_only_markers=False)
+    dev = device_case(case, optimize_fingers=True)
+    plain = _sequential(dev, case, coop=1)
+    assert capi.last_launch_info()[0] == 'k_chain_solve<8,1>', capi.last_launch_info()
+    out = _sequential(dev, case, coop=g)
+    assert capi.last_launch_info()[0] == f'k_chain_solve<8,1,coop{g}>', capi.last_launch_info()
+    np.testing.assert_array_equal(out['status'], plain['status'])
+    np.testing.assert_array_equal(out['iters'], plain['iters'])
+    for k in ('pose', 'fullpose', 'trans', 'markers_sim'):
+        assert np.abs(out[k] - plain[k]).max() < 1e-9, k
+    ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], 'smplx', optimize_fingers=True)
+    solved = np.flatnonzero(out['status'] == 0)
+    assert list(solved) == list(ref['frame_ids'])
+    assert np.abs(out['fullpose'][solved] - ref['fullpose']).max() < TIGHT
+    np.testing.assert_array_equal(out['iters'][solved, 0], ref['iters'])
+
+
 def test_chunked_solve_with_cooperative_sweeps_on_the_device(gpu_lib):
     """moshii_sequence_solve as the library runs it by default for a body solve: pass-1 chunk chains that do not carry on, then the
     host's repair rounds with every repair chain a cooperative chain (rank 0 takes the decisions that depend on other chains' memory).
