@@ -1069,6 +1069,10 @@ struct JtJAcc {
 
 // ------------------------------------------------------------------------------------------------
 // J^T J in registers: thread (ty, tx) of a 16x16 grid owns A[bi*16+ty][bj*16+tx] for bj <= bi.
+// (Tried for the 13-block solve, whose 91 entries per thread are 182 registers held across the whole dogleg loop of a kernel that spills
+//  690 vector and 1067 scalar registers: the matrix parked in the chain's global scratch between its uses -- stored by the assembly, read
+//  back by the two quadratic forms of an iteration and by the factorisation's block columns.  Spills 690 -> 566 only, the iteration 394 ->
+//  431 us: the block columns' reads from the L2 sit on the factorisation's critical path.  The registers stay.)
 // ------------------------------------------------------------------------------------------------
 template <int NBLK>
 struct AReg {
