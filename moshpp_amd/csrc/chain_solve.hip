@@ -94,22 +94,22 @@ enum { DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, 
 // 64-bit DPP with row_newbcast:K (gfx90a on: the only lane control the double-precision ALU takes): every lane reads lane K of its own row
 // of 16.  rowbcast_f64<K>(v) = that value; fmac_rowbcast<K>(acc, m, a): acc = fma(-m[lane K of the row], a, acc) in ONE instruction --
 // what two v_readlane + an fma do when the broadcast value sits in every row (ldl_panel_eliminate_rows).  The source of a DPP read must
-// not have been written by the two instructions before it (hazard the compiler handles for its own DPP, not inside asm): dpp_settle()
-// ties a two-wait-state s_nop to the value.
+// not have been written by the two instructions before it (hazard the compiler handles for its own DPP, not inside asm).
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void dpp_settle(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
+// (the wait states ride INSIDE the statement that reads through DPP where the value was just produced -- rowbcast_f64, the first fma of a
+//  column -- so that nothing the register allocator might place between the two, a copy of the value included, can undo them)
 template <int K> __device__ __forceinline__ double rowbcast_f64(double v) {
     double r;
-    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
     return r;
 }
-template <int K> __device__ __forceinline__ void fmac_rowbcast(double& acc, double m, double a) {
-    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(a), "n"(K));
+template <int K, bool SETTLE = false> __device__ __forceinline__ void fmac_rowbcast(double& acc, double m, double a) {
+    if constexpr (SETTLE) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(a), "n"(K));
+    else asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(a), "n"(K));
 }
 #else
-__device__ __forceinline__ void dpp_settle(double&) {}
 template <int K> __device__ __forceinline__ double rowbcast_f64(double v) { return __shfl(v, K, 16); }
-template <int K> __device__ __forceinline__ void fmac_rowbcast(double& acc, double m, double a) { acc = fma(-__shfl(m, K, 16), a, acc); }
+template <int K, bool SETTLE = false> __device__ __forceinline__ void fmac_rowbcast(double& acc, double m, double a) { acc = fma(-__shfl(m, K, 16), a, acc); }
 #endif
 
 // Sum over the wavefront, the bitwise-identical total in every lane: an exchange butterfly inside each row of 16 lanes
@@ -1310,11 +1310,11 @@ __device__ __forceinline__ bool ldl_panel_eliminate(const LdlCtx<NBLK>& c) {
 // row broadcast inside the fma -- v_fmac_f64_dpp ... row_newbcast:k -- instead of two v_readlane and an fma per (column, later column)
 // pair: ~500 instructions a panel instead of ~710 (~340 on the last, which has no rows below).  The same products and sums in the same
 // order: the same bits.
-template <int J, int K>
+template <int J, int K, bool FIRST = true>
 __device__ __forceinline__ void ldl_rows_update(double (&a)[16], double lj) {   // a_k -= a_J l_kJ for k = K .. 15
     if constexpr (K < 16) {
-        fmac_rowbcast<K>(a[K], lj, a[J]);
-        ldl_rows_update<J, K + 1>(a, lj);
+        fmac_rowbcast<K, FIRST>(a[K], lj, a[J]);
+        ldl_rows_update<J, K + 1, false>(a, lj);
     }
 }
 template <int NBLK, int P, bool FULL, int J>
@@ -1322,15 +1322,13 @@ __device__ __forceinline__ void ldl_rows_column(const LdlCtx<NBLK>& c, double* p
     constexpr int c0 = 16 * P;
     constexpr bool BELOW = c0 + 16 < NBLK * 16;
     if (FULL || c0 + J < c.n) {   // (uniform: the border row's own "column" is not eliminated)
-        dpp_settle(ad[J]);
         const double pj = rowbcast_f64<J>(ad[J]);
         bad = bad || !(pj > 0.0);
         double pin = __builtin_amdgcn_rcp(pj);
         pin = fma(fma(-pj, pin, 1.0), pin, pin);
         pin = fma(fma(-pj, pin, 1.0), pin, pin);
         pinp[J] = pin;   // (lane 0: pinv[c0 + J]; the others: their parking words)
-        double lj = ad[J] * pin;   // lane l: c_kj pin_j of diagonal row k = l % 16
-        dpp_settle(lj);
+        const double lj = ad[J] * pin;   // lane l: c_kj pin_j of diagonal row k = l % 16
         ldl_rows_update<J, J + 1>(ad, lj);
         if constexpr (BELOW) ldl_rows_update<J, J + 1>(ab, lj);
     }
