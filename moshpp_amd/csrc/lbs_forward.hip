@@ -10,30 +10,13 @@
 //
 //   k_lbs_prep   one wavefront per frame: hand-PCA -> fullpose, Rodrigues, kinematic chain; writes the skinning transforms
 //                Atr[16-frame block][joint][frame][12] (f32, translation folded with trans[f]) -- one contiguous K x 768 B
-//                block per 16 frames, the LDS image the export kernel copies -- and the pose features as MFMA B fragments
+//                block per 16 frames, from which the export kernel's waves gather their joints -- and the pose features as MFMA B fragments
 //                featF[128-frame tile][k-step][16-frame block][lane][8] (f16).
-//   k_lbs_tile   ONE persistent workgroup per CU (4 waves, one per SIMD, the whole register file), a tile = 128 vertices x
-//                128 frames, a wave = 32 vertices x 128 frames = 2 x 8 MFMA tiles of 16 x 16 per coordinate (192 accumulator
-//                registers).  Round 3 rewrite; what the round-2 kernel (128 x 64 tiles, two workgroups per CU, 32x32x16
-//                MFMAs with lane = vertex) lost its time on, and what replaces it:
-//                  * its k-loop ran at 44 % of the MFMA rate behind an up-front copy of the whole feature panel (59 KB per
-//                    tile at the ~11 B/clk a CU gets when every CU fetches at once).  Now the features stream through a
-//                    three-slot LDS ring, one 8 KB k-step chunk at a time, loaded two steps ahead -- nothing is staged
-//                    before the first MFMA -- and a tile covers 128 frames, so the posedirs fragments (the big operand, 19 MB)
-//                    are streamed F / 128 times instead of F / 64;
-//                  * its epilogue gathered each (vertex, frame)'s four joint transforms from LDS with lane = vertex: the 16
-//                    lanes of a ds_read_b128 group hit 16 random joints, 2-3 of them on the same banks (66 B/clk/CU measured
-//                    against 256).  The accumulators are now the other way round -- lane = frame, register = vertex -- so the
-//                    16 lanes of a group read 16 consecutive frames of ONE joint (48 B apart, joint blocks 768 B = 3 x 256
-//                    apart: conflict-free by construction), the lane's joint addresses and weights are per-(register, influence)
-//                    constants kept in registers for the whole tile, and no address arithmetic is left in the loop;
-//                  * the joint transforms of a 16-frame half tile are ONE contiguous block in memory and reach LDS by LDS-DMA
-//                    (global_load_lds_dwordx4, double buffered, issued a half tile ahead): no staging registers, no ds_write
-//                    pass, and the wait is a counted vmcnt that leaves the row stores in flight;
-//                  * results leave through an LDS exchange as whole 1536-byte tile rows (16-byte streaming stores) as before;
-//                    the exchange rows are 386 dwords apart, which keeps the lane = frame writes at two lanes per bank.
-//                workgroup -> tile order is XCD-aware: XCD x owns the vertex tiles x, x + 8, ... (2.5 MB of fragments, L2
-//                resident) and its 32 workgroups walk (frame tile, vertex tile) together.
+//   k_lbs_export two persistent workgroups per CU (4 waves each), a tile = 64 vertices x 128 frames, a wave = 16 vertices x 128
+//                frames = 8 MFMA tiles of 16 x 16 per coordinate (96 accumulator registers); k-loop with the features through a
+//                three-slot LDS ring, blend over per-group joint lists with packed FMAs, rows out through an LDS exchange --
+//                described at the kernel.  (Rounds 3/4: k_lbs_tile, one workgroup of eight waves per CU, 128 x 128 tiles, a
+//                per-vertex four-influence gather from LDS: 216 us per 4000-frame SMPL-H export, 0.18 of the HBM peak.)
 //
 // Accuracy: f16 operands give |err| ~ 2^-11 |posedirs| |R - I| sqrt(9(K-1)) ~ 5e-6 m for millimetre-scale correctives
 // (tests bound it at 2e-5 m); moshii_lbs_forward_f64 is the reference-precision path.
@@ -44,23 +27,14 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte, dword-aligned store unit
-
-#define LBS_NWMAX 8          // skinning influences per vertex (else the launch falls back to the plain kernel)
-#define LBS_TV 128           // vertices per tile (32 per wave)
-#define LBS_TF 128           // frames per tile (8 MFMA column tiles of 16)
-#define LBS_SXP 386          // dwords per row of the result exchange: 128 vertices x 3 + 2.  A ds_write_b32 of the exchange has its 32
-                             // lanes on 16 frames (rows) x 2 vertices 12 dwords apart: with rows 2 banks apart that is 16 distinct even
-                             // banks, each hit twice (free on ds_write_b32); a 16-byte-aligned pitch would make it 4-way.  Rows are
-                             // therefore 8-byte aligned only and are read back as pairs of ds_read_b64.
-#define LBS_RING 3           // slots of the feature ring
-#define LBS_CHUNK 8192       // bytes of one k-step's feature fragments: 8 frame blocks x 64 lanes x 16 B
-#define LBS_JBYTES 768       // one joint's transforms for the 16 frames of a half tile (16 x 12 floats = 3 x 256 B)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 extern "C" {
 int moshii_internal_model_dims(moshii_model_t m, int* V, int* K);
@@ -111,23 +85,32 @@ __global__ void k_absmax(size_t n, const double* __restrict__ src, double* __res
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
-// fragment-major f16 posedirs (MFMA A operand of v_mfma_f32_16x16x32_f16): record (vg, i, ks) holds, for lane l, the 8 values
-// posedirs[v = 16 vg + (l & 15)][i][32 ks + 8 (l >> 4) + e]
-__global__ void k_pack_pfrag(int V, int nfeat, int KS, int nvg, double pscale, const double* __restrict__ src, _Float16* __restrict__ dst) {
-    const size_t total = (size_t)nvg * 3 * KS * 64 * 8;
+// fragment-major f16 posedirs (MFMA A operand of v_mfma_f32_16x16x32_f16): record (group, i, ks) holds, for lane l, the 8 values
+// posedirs[v = perm[16 group + (l & 15)]][i][32 ks + 8 (l >> 4) + e]  (perm: the export kernel's vertex groups, -1 = padding)
+__global__ void k_pack_pfrag(int nfeat, int KS, int ng, double pscale, const int* __restrict__ perm, const double* __restrict__ src, _Float16* __restrict__ dst) {
+    const size_t total = (size_t)ng * 3 * KS * 64 * 8;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7);
         const int l = (int)((idx >> 3) & 63);
         size_t r = idx >> 9;
         const int ks = (int)(r % KS); r /= KS;
         const int i = (int)(r % 3);
-        const int vg = (int)(r / 3);
-        const int v = vg * 16 + (l & 15);
+        const int g = (int)(r / 3);
+        const int v = perm[g * 16 + (l & 15)];
         const int q = ks * 32 + (l >> 4) * 8 + e;
         double val = 0.0;
-        if (v < V && q < nfeat) val = src[((size_t)v * 3 + i) * nfeat + q] * pscale;
+        if (v >= 0 && q < nfeat) val = src[((size_t)v * 3 + i) * nfeat + q] * pscale;
         dst[idx] = (_Float16)val;
     }
+}
+
+// rest positions in group order, x pscale: vshs[slot] = {x, y, z, 0} of vertex perm[slot]
+__global__ void k_pack_vsh(int n, float pscale, const int* __restrict__ perm, const double* __restrict__ vsh, float* __restrict__ dst) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int v = perm[s];
+    for (int c = 0; c < 3; ++c) dst[s * 4 + c] = v >= 0 ? (float)(vsh[(size_t)v * 3 + c] * (double)pscale) : 0.0f;
+    dst[s * 4 + 3] = 0.0f;
 }
 
 // ---- fallback kernel: one workgroup = 256 vertices of one frame (plain f32, dense weights) ----------------
@@ -212,7 +195,9 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
 __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
-                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, long long* __restrict__ stamps) {
+                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, int* __restrict__ cu_seen, long long* __restrict__ stamps) {
+    // (the export kernel's per-CU arrival counters: zero for the launch that follows in this stream)
+    if (cu_seen != nullptr && blockIdx.x == 0) for (int i = threadIdx.x; i < 4096; i += 256) cu_seen[i] = 0;
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
     // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own.  27 KB of static LDS + the
     // hand-component matrix (dynamic: hand_dof x nhand_full floats, 8.6 KB for SMPL-H / SMPL-X) and 81 registers: four workgroups
@@ -325,16 +310,19 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     PREP_STAMP(3)
-    if (tid < K && fw < F) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint)
+    if (tid < K && fw < F) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint), stored as the
+                               // pairs the export kernel's packed FMAs take: (R00,R10) (R01,R11) (R02,R12) (t0,t1) (R20,R21) (R22,t2)
         f32x4* o = reinterpret_cast<f32x4*>(Atr + (((size_t)(f >> 4) * KJ + tid) * 16 + (f & 15)) * 12);
         const float* tr = trans + (size_t)f * 3;
+        float R[3][3], t3[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float r0 = Rw[tid * 9 + i * 3 + 0], r1 = Rw[tid * 9 + i * 3 + 1], r2 = Rw[tid * 9 + i * 3 + 2];
-            const float t3 = tw[tid * 3 + i] - (r0 * Jme[0] + r1 * Jme[1] + r2 * Jme[2]) + tr[i];
-            const f32x4 row = {r0, r1, r2, t3};
-            o[i] = row;
+            R[i][0] = Rw[tid * 9 + i * 3 + 0]; R[i][1] = Rw[tid * 9 + i * 3 + 1]; R[i][2] = Rw[tid * 9 + i * 3 + 2];
+            t3[i] = tw[tid * 3 + i] - (R[i][0] * Jme[0] + R[i][1] * Jme[1] + R[i][2] * Jme[2]) + tr[i];
         }
+        o[0] = f32x4{R[0][0], R[1][0], R[0][1], R[1][1]};
+        o[1] = f32x4{R[0][2], R[1][2], t3[0], t3[1]};
+        o[2] = f32x4{R[2][0], R[2][1], R[2][2], t3[2]};
     }
     PREP_STAMP(4)
     // B fragments of v_mfma_f32_16x16x32_f16: features 8 g .. 8 g + 7 of frame f are the 16 bytes of record (f / 128, g / 4,
@@ -355,278 +343,380 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 }
 
 // ---- the export kernel ------------------------------------------------------------------------------------
-// LDS map (bytes; every offset is a compile-time constant so that the epilogue's reads carry their buffer base as an immediate):
-//   [0, 43008)        transforms of the half tile in work, buffer 0   (KJ <= 56 joints x 768 B)
-//   [43008, 86016)    buffer 1
-//   [86016, 110592)   feature ring, 3 slots of 8 KiB
-//   [110592, 160000)  result exchange, two buffers of 16 rows of LBS_SXP dwords
-#define LBS_TLMAX 43008
-#define LBS_KJMAX 56
-#define LBS_OFF_RING (2 * LBS_TLMAX)
-#define LBS_OFF_SX (LBS_OFF_RING + LBS_RING * LBS_CHUNK)
-#define LBS_SXBYTES (16 * LBS_SXP * 4)
-#define LBS_LDS_BYTES (LBS_OFF_SX + 2 * LBS_SXBYTES)
+// k_lbs_export: a workgroup = 4 waves (one per SIMD, <= 256 registers, 80 KB of LDS) so that TWO workgroups share a CU, each with
+// its own tile of 64 vertices x 128 frames, and run in antiphase: while one is in its k-loop (matrix pipe: 360 MFMAs per wave) the
+// other is in its blend epilogue (vector pipe + LDS).  The two pipes issue side by side from different waves of a SIMD, so a CU's
+// tile pair costs max(matrix, vector) instead of their sum -- the round-3/4 kernel (ONE workgroup per CU, all eight waves in the
+// same phase) paid the sum: 18 k cycles of k-loop with the vector pipe idle, then 26 k of epilogue with the matrix pipe idle.
+//
+// Wave w of a tile owns the vertex GROUP w: 16 of the tile's 64 vertices, chosen at model-prepare time (group_tiles below) so that
+// a group depends on as few joints as possible -- its JOINT LIST, padded to rounds of LX_JR = 4 joints.  The MFMA accumulators are
+// lane = frame, register = vertex (as before), and the blend runs over the group's joint list instead of over each vertex's own
+// influences: per 16-frame block and round the wave copies the four joints' transforms (4 x 768 B, gathered by LDS-DMA with
+// per-lane source addresses) into a wave-private LDS buffer, every lane reads its frame's 4 x 48 B ONCE for all four of its
+// vertices (the round-3 form read 4 vertices x 4 influences x 48 B: the LDS pipe and ~450 instructions per block) and accumulates
+// T_v += w_vj A_j as packed FMAs (v_pk_fma_f32: the transforms are stored as the pairs (R00,R10) (R01,R11) (R02,R12) (t0,t1)
+// (R20,R21) (R22,t2), the weight is broadcast by op_sel) -- 96 packed FMAs per round, 24 instructions to apply T to the four
+// corrected rest positions.  Vertices whose joints are not in a round have weight 0 there.  Nothing in the epilogue is shared
+// between waves except the result exchange (un-permutes the group order, whole 768-byte tile rows leave as 16-byte streaming
+// stores): ONE workgroup barrier per 16-frame block; the transforms need none (a wave waits for its own DMA with a counted vmcnt).
+#define LX_TV 64             // vertices per tile (16 per wave)
+#define LX_TF 128            // frames per tile (8 MFMA column tiles of 16)
+#ifndef LX_XP
+#define LX_XP 194            // dwords per row of the result exchange: 64 vertices x 3 + 2: the 16 frame rows of a two-dword write start
+                             // on 16 distinct even banks
+#endif
+#define LX_JR 4              // joints per blend round
+#ifndef LX_NRMAX
+#define LX_NRMAX 6           // rounds per group the kernel's LDS tables hold (24 joints per 16 vertices; else the plain kernel runs)
+#endif
+#define LX_RING 3            // slots of the feature ring
+#define LX_CHUNK 8192        // bytes of one k-step's feature fragments: 8 frame blocks x 64 lanes x 16 B
+#define LX_JBYTES 768        // one joint's transforms for 16 frames (16 x 12 floats)
+#define LX_TSLOT (LX_JR * LX_JBYTES)                           // one round's transforms: 3 KiB = three DMA pieces
+#define LX_OFF_TR (LX_RING * LX_CHUNK)                         // [wave][LX_TSLOT]: the transforms of the round a wave is working on
+#define LX_OFF_SX (LX_OFF_TR + 4 * LX_TSLOT)                   // result exchange, two buffers of 16 rows
+#define LX_SXBYTES (16 * LX_XP * 4)
+#define LX_OFF_W (LX_OFF_SX + 2 * LX_SXBYTES)                  // weights [group][round][slot 16][joint 4] f32
+#define LX_OFF_J (LX_OFF_W + 4 * LX_NRMAX * 256)               // joint lists [group][round][4] (byte offsets j x 768)
+#define LX_LDS_BYTES (LX_OFF_J + 4 * LX_NRMAX * LX_JR * 4)     // 68 224 B: two workgroups per CU
 
 #define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their "no wait" values): the LDS-DMA pieces are older than the N memory
-// instructions issued behind them, which stay in flight
-#define LBS_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
+// (wave_barrier: no instruction on the device, where a wave's lanes move together; the CPU emulation runs lanes one after another and
+//  meets there -- a lane reads LDS bytes that the other lanes of its wave wrote)
+#define LBS_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-// NWT: skinning influences per vertex (padded).  NVG: 16-vertex groups per wave -- 2: four waves per workgroup, one per SIMD, the
-// whole register file each; 1: eight waves, two per SIMD with 256 registers each, so that one wave's LDS / memory latency is
-// covered by the other's arithmetic (the workgroup tile is 128 vertices x 128 frames either way).
-template <int NWT, int NVG>
-__global__ __launch_bounds__(512 / NVG, 2 / NVG) void k_lbs_tile(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, int dbg) {
-    constexpr int TPB = 512 / NVG, NWAVE = TPB / 64, WV = 16 * NVG;   // threads, waves, vertices per wave
-    constexpr int RPW = 16 / NWAVE;                                  // exchange rows a wave stores per half tile
-    // B-fragment sets: two (the fragments of step t + 1 are read while step t multiplies) for the four-wave form; ONE for the
-    // eight-wave form -- its 256 registers per wave do not hold a second set: tried with two A sets instead of three, the loop was
-    // free of scratch but the tile's vertex records were parked there, 266 us against 240
-    constexpr int NB = NVG;
-    constexpr int NA = 3;                                            // A-fragment sets = k-steps of lead of the posedirs loads + 1
+// LX_OPAQUE(x): the compiler may not treat x as loop-invariant behind this point (it would hoist every lane-only address computation
+// of the epilogue out of the tile loop and park the results in registers the loops need -- measured: 35 spills ahead of the tile
+// loop, reloaded inside the block loop); on the host / in the emulation nothing
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LX_OPAQUE(x) __asm__ __volatile__("" : "+v"(x))
+#else
+#define LX_OPAQUE(x)
+#endif
+
+__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out,
+                                                        int* __restrict__ cu_seen, int stagger, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int KS = lm.KS, KJ = lm.KJ;
-    const int tlb = KJ * LBS_JBYTES;                       // bytes of one half tile's transforms (a multiple of 1024)
-    char* ring = lds_raw + LBS_OFF_RING;                   // [LBS_RING][8 frame blocks][64 lanes][16 B]
-    char* Sx = lds_raw + LBS_OFF_SX;                       // [2][16 frames][LBS_SXP] f32
-    // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...}, whose posedirs
-    // fragments (356 KB each) stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side, so the
-    // transforms and features of a few frame tiles are what else the L2 has to hold.
+    const int KS = lm.KS, NRM = lm.NRM;
+    const unsigned tlb = (unsigned)lm.KJ * LX_JBYTES;      // bytes of one 16-frame block's transforms
+    char* ring = lds_raw;                                  // [LX_RING][8 frame blocks][64 lanes][16 B]
+    char* Sx = lds_raw + LX_OFF_SX;                        // [2][16 frames][LX_XP] f32
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...}, whose posedirs fragments
+    // stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int NVX = (NVT - xcd + 7) >> 3;
     const int ntiles = NVX * NFT;
     const float isc = lm.inv_pscale;
     const int q4 = lane >> 4, fl = lane & 15;
-    const int sxw = fl * (LBS_SXP * 4) + (wv * WV + 4 * q4) * 12;   // this lane's row / first vertex in the exchange (bytes)
-    // Three rotating A-fragment sets (k-steps t .. t+2), two B-fragment sets (t, t+1), two feature-chunk register sets and the
-    // three ring slots are addressed by NAME (the loop is unrolled six-fold) so that no register copy ever waits on a load.
-    // Step t: barrier (chunk t + 1 is visible, every wave has left chunk t - 1), drop chunk t + 2 (fetched two steps ago) into
-    // the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs fragments of step t + 2, read the B fragments of step
-    // t + 1 from LDS, issue the 24 NVG MFMAs of step t.
-    half8 aS[NA][NVG][3], bS[NB][8];
-    f32x4 gS[2][NVG];
-#define LBS_LD_A(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        aS[SET][vg][c] = (ap + ((size_t)(vg * 3 + c) * KS + kk_) * 64)[lane]; }
-#define LBS_LD_G(SET, KSTEP) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int u = 0; u < NVG; ++u) gS[SET][u] = (fp + (size_t)kk_ * 512 + u * TPB)[tid]; }
-#define LBS_ST_G(SET, SLOT) { _Pragma("unroll") for (int u = 0; u < NVG; ++u) *reinterpret_cast<f32x4*>(ring + (SLOT) * LBS_CHUNK + (tid + u * TPB) * 16) = gS[SET][u]; }
-#define LBS_LD_B(SET, SLOT) { _Pragma("unroll") for (int t = 0; t < 8; ++t) bS[SET][t] = *reinterpret_cast<const half8*>(ring + (SLOT) * LBS_CHUNK + t * 1024 + lane * 16); }
-    // The memory instructions of a step are spread BETWEEN its MFMAs (sched_barrier pins the order): a wave issues in order, and
-    // a global load does not leave the issue stage while the CU's address unit is busy with the other waves' loads -- with all
-    // loads of a step ahead of its MFMAs (the first version), every wave sat ~500 cycles behind the other seven's 1 KB loads
-    // before its first MFMA (measured: 1 420 cycles per step against 768 of MFMA; 800 with the loads ablated).
-#define LBS_MMA_T(ASET, BSET, T) { _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        acc[vg][T][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][vg][c], bS[BSET][T], acc[vg][T][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
-#define LBS_LD_A1(SET, KSTEP, VG) { const int kk_ = min((KSTEP), KS - 1); _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        aS[SET][VG][c] = (ap + ((size_t)((VG) * 3 + c) * KS + kk_) * 64)[lane]; __builtin_amdgcn_sched_barrier(0); }
-#define LBS_STEP(S, KSTEP) { const bool ring_ = !(dbg & 8), lda_ = !(dbg & 4); \
-        if (ring_) LBS_LDS_BARRIER(); \
-        if constexpr (NB == 1) { LBS_LD_B(0, (S) % 3) } \
-        __builtin_amdgcn_sched_barrier(0); \
-        LBS_MMA_T((S) % NA, (S) % NB, 0) \
-        if (ring_) { LBS_ST_G((S) % 2, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
-        LBS_MMA_T((S) % NA, (S) % NB, 1) \
-        if (ring_ && (KSTEP) + 4 < KS) { LBS_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0);   /* (nothing is fetched past the last k-step) */ \
-        LBS_MMA_T((S) % NA, (S) % NB, 2) \
-        if constexpr (NA == 3) { if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, 0) } \
-        LBS_MMA_T((S) % NA, (S) % NB, 3) \
-        if constexpr (NA == 3 && NVG == 2) { if (lda_ && (KSTEP) + 2 < KS) LBS_LD_A1(((S) + 2) % 3, (KSTEP) + 2, NVG - 1) } \
-        LBS_MMA_T((S) % NA, (S) % NB, 4) \
-        LBS_MMA_T((S) % NA, (S) % NB, 5) \
-        if constexpr (NB == 2) { LBS_LD_B(((S) + 1) % 2, ((S) + 1) % 3) } __builtin_amdgcn_sched_barrier(0); \
-        LBS_MMA_T((S) % NA, (S) % NB, 6) \
-        LBS_MMA_T((S) % NA, (S) % NB, 7) \
-        /* two A sets: the set this step multiplied with is free now -- the fragments of step t + 1 go into it behind the last MFMA */ \
-        if constexpr (NA == 2) { if (lda_ && (KSTEP) + 2 < KS) { LBS_LD_A1((S) % 2, (KSTEP) + 2, 0) } } }
     // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in the output buffer instead of vertices -- tools/lbs_bench.py prints them)
-#define LBS_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 32 + (K)] = clock64(); }
-    const int npieces = tlb >> 10;
-    auto dma_piece = [&](const char* src, int buf, int p) {   // 1 KiB piece p of a half tile's transforms -> LDS buffer buf, by LDS-DMA
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(lds_raw + buf * LBS_TLMAX + p * 1024), 16, 0, 0);
+#define LX_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + (K)] = clock64(); }
+    const long long wg_t0 = (dbg & 32) ? wall_clock64() : 0;   // (MOSHII_LBS_STOP=32: every workgroup leaves its start / end time in cu_seen[2048 ..])
+    // ---- antiphase: the second workgroup to arrive on a CU starts one k-loop late (the two then alternate matrix and vector phases;
+    // a phase offset neither grows nor shrinks by itself -- both slow down alike while they overlap in the same phase)
+    if (stagger > 0 && cu_seen != nullptr) {
+        int* flag = reinterpret_cast<int*>(lds_raw + LX_OFF_J);
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));     // HW_ID[15:8]: CU, shader array, shader engine
+            const unsigned xc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));    // XCC_ID[3:0]
+            *flag = atomicAdd(&cu_seen[((xc & 15) << 8) | (hw & 255)], 1) & 1;
+        }
+        __syncthreads();
+        const int late = *flag;
+        __syncthreads();
+        if (late) for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);      // (2 048 cycles each)
+    }
+    // No LDS-DMA anywhere in this kernel (rounds 3/4 fetched the transforms with global_load_lds; the first form of this kernel the
+    // features as well).  Measured this round: (1) the compiler books a FLAT-encoded LDS load as an access to both memories and turns
+    // every wait it inserts while one is in flight into a full drain of both counters -- no read-ahead survives; (2) as BUFFER loads
+    // (buffer_load_dwordx4 ... lds) its waits stay counted, but counted waits of my own across LDS loads + register loads + stores
+    // returned stale LDS on the device (vmcnt(2) wrong, vmcnt(0) right: the three kinds do not retire in issue order relative to each
+    // other); (3) MI355X_MICROARCH.md puts the landing rate of LDS-DMA at ~12 B/clk per CU, a fifth of what plain loads deliver --
+    // this kernel wants 20-25.  So everything comes through registers: plain loads whose waits the compiler counts, then ds_write.
+    // All hot loads and stores are BUFFER instructions: wave-uniform resource (4 SGPRs) + scalar offset + ONE 32-bit lane offset.  As
+    // global_load / global_store the compiler kept a 64-bit address per lane and per stream in registers across the loops (hoisted out
+    // of the tile loop as loop invariants: ~30 registers, spilled and reloaded inside the k-steps).
+    // Resource words: base, no stride, 2^31 - 1 bytes, raw 32-bit data format.
+    const __amdgpu_buffer_rsrc_t rs_atr = __builtin_amdgcn_make_buffer_rsrc((void*)lm.Atr, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_feat = __builtin_amdgcn_make_buffer_rsrc((void*)lm.featF, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pf = __builtin_amdgcn_make_buffer_rsrc((void*)lm.Pfrag, 0, 0x7fffffff, 0x00020000);
+    // (the small per-tile tables as well: ONE kind of vector load in the kernel, so that the compiler's counted waits never span loads of
+    //  different kinds -- see the note on stores at the block body)
+    const __amdgpu_buffer_rsrc_t rs_gw = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gw, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gj = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gjid, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gn = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gnr, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gx, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc((void*)lm.vshs, 0, 0x7fffffff, 0x00020000);
+    const unsigned trb = LX_OFF_TR + wv * LX_TSLOT;        // this wave's transform buffer
+    // one round's transforms, 4 joints x 768 B: lane l holds bytes [1024 p + 16 l, + 16) for p = 0 .. 2, i.e. a piece of joint slot
+    // (64 p + l) / 48; off[p] = that joint's offset in the 16-frame block + the lane's offset in the joint
+    f32x4 sg[3];   // the NEXT item's transforms, loaded one item ahead
+    auto load_item = [&](unsigned block, const unsigned* off) {   // block: byte offset of the 16-frame block in Atr (wave-uniform)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) sg[p] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_atr, off[p], block, 0);
     };
-    auto stage_dma = [&](const char* asrc, int h, int buf) { for (int p = wv; p < npieces; p += NWAVE) dma_piece(asrc + (size_t)h * tlb, buf, p); };
-    if (slot < ntiles) stage_dma(reinterpret_cast<const char*>(lm.Atr) + (size_t)(slot / NVX) * 8 * tlb, 0, 0);
+    auto store_item = [&]() {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(lds_raw + trb + p * 1024 + lane * 16) = sg[p];
+    };
+    auto item_offsets = [&](auto jlist, unsigned* off) {   // jlist(js): byte offset of the round's joint slot js in a 16-frame block
+        unsigned lane_o = lane;
+        LX_OPAQUE(lane_o);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { const unsigned c = 64u * p + lane_o, js = c / 48u; off[p] = (unsigned)jlist(js) + (c - js * 48u) * 16u; }
+    };
+    const int* ljt = reinterpret_cast<const int*>(lds_raw + LX_OFF_J) + wv * NRM * LX_JR;   // this group's joint list in LDS
+    half8 aS[3][3], bS[8];
+    f32x4 gS[2][2];
+#define LX_LD_A(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), KS - 1); _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+        aS[SET][c] = (half8)__builtin_amdgcn_raw_buffer_load_b128(rs_pf, lane * 16u, ap + (c * (unsigned)KS + kk_) * 1024u, 0); __builtin_amdgcn_sched_barrier(0); }
+#define LX_LD_G(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), KS - 1); gS[SET][0] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_feat, tid * 16u, fp + kk_ * LX_CHUNK, 0); \
+        gS[SET][1] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_feat, tid * 16u, fp + kk_ * LX_CHUNK + 4096u, 0); }
+#define LX_ST_G(SET, SLOT) { *reinterpret_cast<f32x4*>(ring + (SLOT) * LX_CHUNK + tid * 16) = gS[SET][0]; *reinterpret_cast<f32x4*>(ring + (SLOT) * LX_CHUNK + (tid + 256) * 16) = gS[SET][1]; }
+    // (four B-fragment registers: the fragments of frame blocks 0 .. 3 are read behind the barrier, block T + 4 goes into block T's
+    //  register as soon as its three MFMAs are issued -- 144 cycles of MFMAs ahead of its own)
+#ifdef LX_DBG_B8
+#define LX_BI(T) (T)
+#else
+#define LX_BI(T) ((T) & 3)
+#endif
+#define LX_LD_B1(SLOT, T) { bS[LX_BI(T)] = *reinterpret_cast<const half8*>(ring + (SLOT) * LX_CHUNK + (T) * 1024 + lane * 16); }
+#define LX_LD_B(SLOT) { LX_LD_B1(SLOT, 0) LX_LD_B1(SLOT, 1) LX_LD_B1(SLOT, 2) LX_LD_B1(SLOT, 3) }
+#define LX_MMA_T(ASET, T) { _Pragma("unroll") for (int c = 0; c < 3; ++c) acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[ASET][c], bS[LX_BI(T)], acc[T][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+    // Step t.  Chunk c lives in ring slot c % 3.  Barrier: chunk t (and t + 1) are visible, every wave has left chunk t - 1; read the eight
+    // B fragments of chunk t, drop chunk t + 2 (fetched two steps ago) into the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs
+    // fragments of step t + 2; the memory instructions sit BETWEEN the step's 24 MFMAs (a load does not leave the issue stage while the
+    // address unit is busy with other waves' loads).
+#define LX_STEP(S, KSTEP) { \
+        LBS_LDS_BARRIER(); \
+        LX_LD_B((S) % 3) __builtin_amdgcn_sched_barrier(0); \
+        LX_MMA_T((S) % 3, 0) LX_LD_B1((S) % 3, 4) \
+        if ((KSTEP) + 2 < KS) { LX_ST_G((S) % 2, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
+        LX_MMA_T((S) % 3, 1) LX_LD_B1((S) % 3, 5) \
+        if ((KSTEP) + 4 < KS) { LX_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0); \
+        LX_MMA_T((S) % 3, 2) LX_LD_B1((S) % 3, 6) \
+        if ((KSTEP) + 2 < KS) LX_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
+        LX_MMA_T((S) % 3, 3) LX_LD_B1((S) % 3, 7) __builtin_amdgcn_sched_barrier(0); \
+        LX_MMA_T((S) % 3, 4) LX_MMA_T((S) % 3, 5) LX_MMA_T((S) % 3, 6) LX_MMA_T((S) % 3, 7) }
+    unsigned off0[3] = {0, 0, 0};   // lane offsets of the tile's round 0 in a 16-frame block of transforms
     for (int idx = slot; idx < ntiles; idx += nslots) {
         const int ft = idx / NVX, vt = xcd + 8 * (idx - ft * NVX);
-        const int f0 = ft * LBS_TF, v0 = vt * LBS_TV;
-        // ---- main loop: acc[vg][t][c] (16 vertices x 16 frames) += Pfrag(vg, c, ks) x featF(t, ks)
-        f32x4 acc[NVG][8][3];
+        const int f0 = ft * LX_TF, v0 = vt * LX_TV, gi = vt * 4 + wv;
+        LX_STAMP(0)
+        if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + 12] = wall_clock64();   // (100 MHz: the shader clock the stamps ran at)
+        const int nr = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(rs_gn, 0u, (unsigned)gi * 4u, 0));
+        // ---- the tile's tables: the four groups' weights and joint lists into LDS (every wave is past the previous tile's last block)
+        for (int i = tid; i < 64 * NRM; i += 256) {   // (4 groups x NRM rounds x 16 slots, 16 bytes each)
+            const f32x4 wrow = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_gw, (unsigned)i * 16u, (unsigned)(vt * 64 * NRM) * 16u, 0);
+            *reinterpret_cast<f32x4*>(lds_raw + LX_OFF_W + i * 16) = wrow;
+        }
+        if (tid < 4 * NRM * LX_JR) reinterpret_cast<int*>(lds_raw + LX_OFF_J)[tid] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_gj, tid * 4u, (unsigned)(vt * 4 * NRM * LX_JR) * 4u, 0);
+        // this lane's four vertices (slots 4 q4 .. 4 q4 + 3 of the group): exchange columns and scaled rest positions -- the accumulators
+        // start AT the rest position (x pscale), so the k-loop delivers rest + corrective in one piece
+        f32x4 acc[8][3];
+        {
+            f32x4 vs[4];
 #pragma unroll
-        for (int vg = 0; vg < NVG; ++vg)
+            for (int r = 0; r < 4; ++r) vs[r] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_vs, (unsigned)(4 * q4 + r) * 16u, (unsigned)gi * 256u, 0);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[vg][t][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // (wave-uniform bases: the loads take them as scalar pairs plus ONE lane-offset register instead of a 64-bit address each)
-        const half8* ap = reinterpret_cast<const half8*>(lm.Pfrag) + ((size_t)(vt * 8 + wv * NVG) * 3 * KS) * 64;
-        const f32x4* fp = reinterpret_cast<const f32x4*>(lm.featF) + (size_t)ft * KS * 512;
-        LBS_STAMP(0)
-        // the tile's 128 vertex records {rest position, NWT x (joint address, weight)}: threads 0 .. 127 fetch one each now and hold it
-        // across the k-loop (3 + 2 NWT registers in two waves); behind the loop the records go through the (then idle) feature ring,
-        // from where every lane picks up the 4 NVG vertices of its accumulator registers.  (Every lane fetching its own vertices
-        // here kept 44 registers live across the loop -- spilled; fetching them behind the loop left the first half tile waiting
-        // 4 000 cycles for memory.)
-        float vrec[3]; int2 jrec[NWT];
-        if (tid < LBS_TV) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vrec[c] = lm.vsh_pad[(size_t)(v0 + tid) * 3 + c];
-#pragma unroll
-            for (int i = 0; i < NWT; ++i) jrec[i] = lm.sjw[(size_t)(v0 + tid) * NWT + i];
+                for (int c = 0; c < 3; ++c) acc[t][c] = f32x4{vs[0][c], vs[1][c], vs[2][c], vs[3][c]};
         }
-        LBS_LD_G(0, 0) LBS_LD_G(1, 1) LBS_LD_A(0, 0) LBS_LD_A(1, 1)
-        LBS_ST_G(0, 0) LBS_ST_G(1, 1)
-        LBS_LD_G(0, 2) LBS_LD_G(1, 3)
-        LBS_LDS_BARRIER();
-        if constexpr (NB == 2) LBS_LD_B(0, 0)
-        LBS_STAMP(1)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- main loop: acc[t][c] (16 vertices x 16 frames) += Pfrag(group, c, ks) x featF(t, ks)
+        const unsigned ap = (unsigned)(gi * 3 * KS) * 1024u;      // byte offset of the group's fragments in Pfrag
+        const unsigned fp = (unsigned)(ft * KS) * LX_CHUNK;      // byte offset of the frame tile's chunks in featF
+        LX_LD_G(0, 0) LX_LD_G(1, 1) LX_LD_A(0, 0) LX_LD_A(1, 1)
+        LX_ST_G(0, 0) LX_ST_G(1, 1)
+        LX_LD_G(0, 2) LX_LD_G(1, 3)
+        LX_STAMP(1)
         int ks = 0;
         for (; ks + 6 <= KS; ks += 6) {
-            LBS_STEP(0, ks) LBS_STEP(1, ks + 1) LBS_STEP(2, ks + 2) LBS_STEP(3, ks + 3) LBS_STEP(4, ks + 4) LBS_STEP(5, ks + 5)
+            LX_STEP(0, ks) LX_STEP(1, ks + 1) LX_STEP(2, ks + 2) LX_STEP(3, ks + 3) LX_STEP(4, ks + 4) LX_STEP(5, ks + 5)
         }
-        if (ks < KS) { LBS_STEP(0, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(1, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(2, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(3, ks) ++ks; }
-        if (ks < KS) { LBS_STEP(4, ks) ++ks; }
-        // ---- epilogue: eight half tiles of 16 frames.  Per half tile: transforms in LDS (barrier), every lane blends and
-        // applies its 4 NVG (vertex, frame) pairs and drops the results into the exchange (barrier), the workgroup writes 16 whole
-        // tile rows.  The transforms of half tile h + 1 are on their way (LDS-DMA) while h is worked on.
-        LBS_STAMP(2)
-        // transforms of this tile / of this workgroup's next tile (whose first half tile is fetched during the last one of this tile:
-        // issued behind the k-loop it kept the first half tile waiting 3 000 cycles)
-        const char* asrc = reinterpret_cast<const char*>(lm.Atr) + (size_t)ft * 8 * tlb;
-        const char* asrc_next = reinterpret_cast<const char*>(lm.Atr) + (size_t)((idx + nslots) / NVX) * 8 * tlb;
-        constexpr int RECW = 4 + 2 * NWT;   // dwords per vertex record in LDS: x y z - | weights | joint addresses
-        {
-            LBS_LDS_BARRIER();   // every wave has read its last B fragments: the ring is free
-            LBS_STAMP(28)
-            if (tid < LBS_TV) {
-                float* rec = reinterpret_cast<float*>(ring) + tid * RECW;
-                rec[0] = vrec[0]; rec[1] = vrec[1]; rec[2] = vrec[2];
-#pragma unroll
-                for (int i = 0; i < NWT; ++i) { rec[4 + i] = __int_as_float(jrec[i].y); reinterpret_cast<int*>(rec)[4 + NWT + i] = jrec[i].x; }
-            }
-            LBS_LDS_BARRIER();
-            LBS_STAMP(29)
-        }
-        // ---- this lane's vertices: register r of accumulator tile (vg, .) belongs to vertex v0 + WV wv + 16 vg + 4 (lane / 16) + r
-        float vs[NVG][4][3], ww[NVG][4][NWT];
-        int ja[NVG][4][NWT];
-#pragma unroll
-        for (int vg = 0; vg < NVG; ++vg)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* rec = reinterpret_cast<const float*>(ring) + (wv * WV + vg * 16 + 4 * q4 + r) * RECW;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vs[vg][r][c] = rec[c];
-#pragma unroll
-                for (int i = 0; i < NWT; ++i) {
-                    ww[vg][r][i] = rec[4 + i];
-                    ja[vg][r][i] = reinterpret_cast<const int*>(rec)[4 + NWT + i] + fl * 48;   // byte offset inside a half tile's transform block
-                }
-            }
-        // (MOSHII_LBS_STOP: phase timing by truncation / ablation -- 1: stop after the k-loop, 2: everything but the global stores,
-        //  +4: the k-loop re-uses its first posedirs fragments, +8: ... and its first feature chunks, without the ring and its barriers)
-        if (dbg & 1) {
+        if (ks < KS) { LX_STEP(0, ks) ++ks; }
+        if (ks < KS) { LX_STEP(1, ks) ++ks; }
+        if (ks < KS) { LX_STEP(2, ks) ++ks; }
+        if (ks < KS) { LX_STEP(3, ks) ++ks; }
+        if (ks < KS) { LX_STEP(4, ks) ++ks; }
+        LX_STAMP(2)
+        // what only the epilogue needs is fetched behind the k-loop (held across it these 19 registers were spilled; the first item of a
+        // tile waits for them -- the CU's other workgroup runs meanwhile): the lane's exchange columns, its offsets in a round-0 block
+        // of transforms, the transforms of the first item
+        const u32x4 xo = __builtin_amdgcn_raw_buffer_load_b128(rs_gx, q4 * 16u, (unsigned)gi * 64u, 0);
+        item_offsets([&](unsigned js) { return __builtin_amdgcn_raw_buffer_load_b32(rs_gj, js * 4u, (unsigned)(gi * NRM * LX_JR) * 4u, 0); }, off0);
+        load_item((unsigned)ft * 8u * tlb, off0);
+        if (dbg & 1) {   // (MOSHII_LBS_STOP=1: stop behind the k-loop)
             float sacc = 0.0f;
 #pragma unroll
-            for (int vg = 0; vg < NVG; ++vg)
+            for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) sacc += acc[vg][t][c][0] + acc[vg][t][c][1] + acc[vg][t][c][2] + acc[vg][t][c][3];
-            if (sacc == 123.456f) out[0] = vs[0][0][0] + ww[NVG - 1][3][0] + (float)ja[0][2][1];
-            LBS_WAIT_VM(0);
+                for (int c = 0; c < 3; ++c) sacc += acc[t][c][0] + acc[t][c][1] + acc[t][c][2] + acc[t][c][3];
+            if (sacc == 123.456f) out[0] = sacc + (float)xo[0] + sg[0].x + sg[1].y + sg[2].z;
             LBS_LDS_BARRIER();
             continue;
         }
-        const int nfl = min(LBS_TV, V - v0) * 3;   // valid floats of a tile row
-        // interior tile: every wave issues exactly 2 RPW store instructions per half tile, which is what the counted wait below relies on
-        const bool full = (f0 + LBS_TF <= F) && (nfl == LBS_TV * 3);
-        // The half tiles run as a LOOP (two per trip: the transform and exchange buffers alternate, and their bases are immediates
-        // of the reads): unrolled eight-fold, the epilogue alone was 48 KB of straight-line code executed once per tile.  The
-        // accumulators are registers and cannot be indexed by the trip count: a wave-uniform switch moves the half tile's 12 NVG
-        // values out first (as rest position + corrective).  ONE barrier per half tile: with two exchange buffers, "transforms of
-        // h visible" and "exchange of h - 1 complete" are the same barrier, and the rows of h - 1 are stored while the first
-        // transform reads of h are in flight.
-        constexpr int NPAIR = NWT / 2, NST = 4 * NVG * NPAIR;   // a stage = two influences of one (vertex, frame) item
-        f32x4 A0[2][2], A1[2][2], A2[2][2];
-        float pp[NVG][4][3];
-#define LBS_GATHER(SET, ST, TOFF) { const int k_ = (ST) / NPAIR, p_ = (ST) % NPAIR; _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
-        const char* tp = lds_raw + (TOFF) + ja[k_ >> 2][k_ & 3][2 * p_ + i]; \
-        A0[SET][i] = *reinterpret_cast<const f32x4*>(tp); A1[SET][i] = *reinterpret_cast<const f32x4*>(tp + 16); A2[SET][i] = *reinterpret_cast<const f32x4*>(tp + 32); } }
-#define LBS_TAKE(H) { _Pragma("unroll") for (int vg = 0; vg < NVG; ++vg) _Pragma("unroll") for (int r = 0; r < 4; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c) \
-        pp[vg][r][c] = fmaf(isc, acc[vg][H][c][r], vs[vg][r][c]); }
-        // wave w writes rows w, w + NWAVE, ... of a half tile: 96 16-byte chunks per row = one full wave store + one half-wave store.
-        // The stores of half tile h - 1 are issued one at a time between the stages of h: back to back, a wave's second store
-        // waits at the issue stage while the address unit works through the other waves' (24 KB per half tile at 64 B/clk).
-        auto row_store_part = [&](int h, int soff, int idx) {   // store instruction idx (0 .. 2 RPW - 1) of half tile h's rows
-            const int i = idx >> 1, part = idx & 1;
-            if (part == 1 && lane >= 32) return;
-            const int row = wv + NWAVE * i, f = f0 + 16 * h + row;
-            const f32x2* sp = reinterpret_cast<const f32x2*>(Sx + soff + row * (LBS_SXP * 4) + lane * 16 + part * 1024);
-            const f32x2 lo = sp[0], hi = sp[1];
-            const f32x4u val = {lo.x, lo.y, hi.x, hi.y};
-            float* o = out + ((size_t)f * V + v0) * 3 + lane * 4 + part * 256;
-            const int c = (lane + 64 * part) * 4;
-            if (dbg & 18) return;
-            // (streaming stores: the output must not evict the posedirs fragments the k-loop re-reads from L2)
-            if (full) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
-            else if (f < F) {
-                if (c + 4 <= nfl) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(o));
-                else for (int e = 0; e < 4; ++e) if (c + e < nfl) o[e] = val[e];
+        // ---- epilogue: eight blocks of 16 frames x (this group's rounds).  The block body is expanded eight times (the accumulators are
+        // registers: a rolled loop had to copy a block's 12 out through a branch tree -- ~60 moves per block).
+        const unsigned abase = (unsigned)ft * 8u * tlb;   // byte offset of the tile's first 16-frame block in Atr
+        const int nfl = min(LX_TV, V - v0) * 3;   // valid floats of a tile row
+        const bool full = (f0 + LX_TF <= F) && (nfl == LX_TV * 3) && (dbg & 18) == 0;   // interior tile
+        // row stores: a block's 16 rows x 768 B are 768 16-byte pieces, three per thread: piece k = 256 s + tid lies in row k / 48
+        // (resource = the tile's first row: lane offsets stay below 2^31 whatever the size of the whole output)
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + ((size_t)f0 * V + v0) * 3), 0, 0x7fffffff, 0x00020000);
+        const unsigned rowb = (unsigned)V * 12u;   // bytes of an output row
+        unsigned rp0, rr0;                         // piece 0 of this thread: row tid / 48, column piece tid % 48
+        { unsigned tid_o = tid; LX_OPAQUE(tid_o); rr0 = tid_o / 48u; rp0 = tid_o - rr0 * 48u; }
+        f32x4 rv[3];
+        auto row_read = [&](int t) {   // the thread's three pieces of block t's rows, out of the exchange
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const unsigned pc = rp0 + 16u * s, w = pc >= 48u ? 1u : 0u, piece = pc - 48u * w, row = rr0 + 5u * s + w;
+#if LX_XP % 4 == 0
+                rv[s] = *reinterpret_cast<const f32x4*>(Sx + (t & 1) * LX_SXBYTES + row * (LX_XP * 4) + piece * 16);
+#else
+                const f32x2* sp = reinterpret_cast<const f32x2*>(Sx + (t & 1) * LX_SXBYTES + row * (LX_XP * 4) + piece * 16);
+                const f32x2 lo = sp[0], hi = sp[1];
+                rv[s] = f32x4{lo.x, lo.y, hi.x, hi.y};
+#endif
             }
         };
-#define LBS_HALF(H, TOFF, SOFF) { \
-        /* the transforms of this half tile: its DMA pieces are older than the row stores of half tile H - 2, which stay in flight */ \
-        if ((H) >= 2 && full && (dbg & ~16) == 0) LBS_WAIT_VM(2 * RPW); else LBS_WAIT_VM(0); \
-        LBS_LDS_BARRIER(); \
-        LBS_STAMP(3 + 3 * ((H) & 7)) \
-        const char* dsrc_ = ((H) + 1 < 8) ? asrc + (size_t)((H) + 1) * tlb : asrc_next;   /* next half tile's transforms (the next tile's first) */ \
-        const bool dgo_ = ((H) + 1 < 8) || (idx + nslots < ntiles); \
-        for (int q = NST / 2; dgo_ && q * NWAVE + wv < npieces; ++q) dma_piece(dsrc_, ((H) + 1) & 1, q * NWAVE + wv); \
-        switch (H) { case 0: LBS_TAKE(0) break; case 1: LBS_TAKE(1) break; case 2: LBS_TAKE(2) break; case 3: LBS_TAKE(3) break; \
-                     case 4: LBS_TAKE(4) break; case 5: LBS_TAKE(5) break; case 6: LBS_TAKE(6) break; default: LBS_TAKE(7) break; } \
-        LBS_GATHER(0, 0, TOFF) \
-        LBS_STAMP(4 + 3 * ((H) & 7)) \
-        float ox = 0.0f, oy = 0.0f, oz = 0.0f; \
-        _Pragma("unroll") for (int st = 0; st < NST; ++st) { \
-            if (st + 1 < NST) { if (st & 1) LBS_GATHER(0, st + 1, TOFF) else LBS_GATHER(1, st + 1, TOFF) } \
-            /* memory instructions one at a time between the stages (the address unit serialises them): first the DMA pieces of the next \
-               half tile, then the row stores of the previous one -- all stores younger than all pieces, which the counted wait relies on */ \
-            if (st < NST / 2) { if (dgo_ && st * NWAVE + wv < npieces) dma_piece(dsrc_, ((H) + 1) & 1, st * NWAVE + wv); } \
-            else if ((H) >= 1 && st - NST / 2 < 2 * RPW) row_store_part((H) - 1, LBS_SXBYTES - (SOFF), st - NST / 2); \
-            const int k_ = st / NPAIR, p_ = st % NPAIR, set_ = st & 1; \
-            const float px = pp[k_ >> 2][k_ & 3][0], py = pp[k_ >> 2][k_ & 3][1], pz = pp[k_ >> 2][k_ & 3][2]; \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) { const float w = ww[k_ >> 2][k_ & 3][2 * p_ + i]; \
-                ox = fmaf(w, fmaf(A0[set_][i].x, px, fmaf(A0[set_][i].y, py, fmaf(A0[set_][i].z, pz, A0[set_][i].w))), ox); \
-                oy = fmaf(w, fmaf(A1[set_][i].x, px, fmaf(A1[set_][i].y, py, fmaf(A1[set_][i].z, pz, A1[set_][i].w))), oy); \
-                oz = fmaf(w, fmaf(A2[set_][i].x, px, fmaf(A2[set_][i].y, py, fmaf(A2[set_][i].z, pz, A2[set_][i].w))), oz); } \
-            if (p_ == NPAIR - 1) { float* so = reinterpret_cast<float*>(Sx + (SOFF) + sxw + ((k_ >> 2) * 16 + (k_ & 3)) * 12); so[0] = ox; so[1] = oy; so[2] = oz; ox = 0.0f; oy = 0.0f; oz = 0.0f; } \
-        } \
-        LBS_STAMP(5 + 3 * ((H) & 7)) }
-#pragma unroll 1
-        for (int h2 = 0; h2 < 8; h2 += 2) {
-            LBS_HALF(h2, 0, 0)
-            LBS_HALF(h2 + 1, LBS_TLMAX, LBS_SXBYTES)
-        }
-        LBS_LDS_BARRIER();   // the last exchange is complete
+        // The three stores go out back to back (addresses first), and the wave then WAITS for them (vmcnt(0): nothing else is in flight at
+        // that point).  Measured on the device: with ordinary code behind a buffer_store_dwordx4 -- the compiler re-uses its data registers
+        // two wait states later, which is what the ISA asks for -- single floats of the middle store's pieces arrived wrong in memory
+        // (lanes 12 .. 15 of every 16, only in the workgroup that shares its CU's address unit with an older one, a few thousand floats
+        // per export): the store's data is read out of the registers later than that when the unit is backed up.  Waiting costs 4 %.
+        auto row_write = [&](int t) {
+            if (dbg & 18) return;
+            unsigned voff[3];
+            bool ok[3];
 #pragma unroll
-        for (int q = 0; q < 2 * RPW; ++q) row_store_part(7, LBS_SXBYTES, q);
-        LBS_STAMP(27)
+            for (int s = 0; s < 3; ++s) {
+                const unsigned pc = rp0 + 16u * s, w = pc >= 48u ? 1u : 0u, piece = pc - 48u * w, row = rr0 + 5u * s + w;
+                voff[s] = row * rowb + piece * 16u;
+                ok[s] = full || ((f0 + 16 * t + (int)row < F) && ((int)piece * 4 + 4 <= nfl));
+            }
+            const unsigned soff = (unsigned)(16 * t) * rowb;
+            __builtin_amdgcn_sched_barrier(0);
+            // (streaming stores -- nt: the output must not evict the posedirs fragments the k-loop re-reads from L2)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) if (ok[s]) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 2);
+            if (!full) {   // pieces that straddle the end of a partial vertex tile's rows: float by float
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const unsigned pc = rp0 + 16u * s, w = pc >= 48u ? 1u : 0u, piece = pc - 48u * w, row = rr0 + 5u * s + w;
+                    if (!ok[s] && f0 + 16 * t + (int)row < F) {
+                        float* o = out + ((size_t)(f0 + 16 * t + (int)row) * V + v0) * 3 + piece * 4;
+                        for (int e = 0; e < 4; ++e) if ((int)piece * 4 + e < nfl) o[e] = rv[s][e];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        f32x2 T[4][6];
+        f32x4 W[4], a[2][3];
+        const char* const tb = lds_raw + trb + fl * 48;
+        auto round_reads = [&](int q) {   // the round's weights and its first joint's transforms
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[r] = *reinterpret_cast<const f32x4*>(lds_raw + LX_OFF_W + ((wv * NRM + q) * 16 + 4 * q4 + r) * 16);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(tb + 16 * i);
+        };
+        auto round = [&](auto first) {   // T_v (+)= sum over the round's four joints of w_vj A_j, for this lane's frame and four vertices
+            // the reads of joint j + 1 are in flight while joint j is accumulated (two sets of 12 registers, no more: sched_barrier keeps the
+            // compiler from hoisting all four joints' reads to the top -- 48 registers the kernel does not have)
+#pragma unroll
+            for (int j = 0; j < LX_JR; ++j) {
+                if (j + 1 < LX_JR) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) a[(j + 1) & 1][i] = *reinterpret_cast<const f32x4*>(tb + (j + 1) * LX_JBYTES + 16 * i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 a0 = a[j & 1][0], a1 = a[j & 1][1], a2 = a[j & 1][2];
+                const f32x2 A[6] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}, {a2.x, a2.y}, {a2.z, a2.w}};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x2 w2 = {W[r][j], W[r][j]};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        if (decltype(first)::value && j == 0) T[r][k] = A[k] * w2;
+                        else T[r][k] = __builtin_elementwise_fma(A[k], w2, T[r][k]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        typedef std::integral_constant<bool, true> yes_t;
+        typedef std::integral_constant<bool, false> no_t;
+        // Block t, round 0: the transforms (loaded during the previous item) go into the wave's buffer -- every lane of the wave has read
+        // the previous item's; the previous block's rows are read back from the exchange together with the round's first LDS reads and
+        // stored; only then are the next item's loads issued, with a whole item to arrive in.  (Stores BEFORE loads: the compiler counts
+        // its wait for a load -- vmcnt(N), N = the vector-memory instructions issued behind it -- as if everything retired in issue order,
+        // and on this device a store issued behind a load can retire ahead of it: with the stores between the loads and their use the
+        // kernel wrote registers to LDS that the loads had not filled yet -- on the device only; the emulation has no such freedom.)
+#define LX_BLOCK(TT) { \
+        constexpr int t = (TT); \
+        LBS_WAVE_SYNC() \
+        store_item(); \
+        LBS_WAVE_SYNC() \
+        if (t >= 1) row_read(t - 1); \
+        round_reads(0); \
+        __builtin_amdgcn_sched_barrier(0); \
+        if (t >= 1) row_write(t - 1); \
+        __builtin_amdgcn_sched_barrier(0); \
+        if (nr > 1) { unsigned offq[3]; item_offsets([&](unsigned js) { return ljt[LX_JR + js]; }, offq); load_item(abase + (unsigned)t * tlb, offq); } \
+        else if (t < 7) load_item(abase + (unsigned)(t + 1) * tlb, off0); \
+        __builtin_amdgcn_sched_barrier(0); \
+        if (t == 3) LX_STAMP(13) \
+        round(yes_t()); \
+        if (t == 3) LX_STAMP(14) \
+        for (int q = 1; q < nr; ++q) { \
+            LBS_WAVE_SYNC() \
+            store_item(); \
+            LBS_WAVE_SYNC() \
+            round_reads(q); \
+            __builtin_amdgcn_sched_barrier(0); \
+            if (q + 1 < nr) { unsigned offq[3]; item_offsets([&](unsigned js) { return ljt[(q + 1) * LX_JR + js]; }, offq); load_item(abase + (unsigned)t * tlb, offq); } \
+            else if (t < 7) load_item(abase + (unsigned)(t + 1) * tlb, off0); \
+            __builtin_amdgcn_sched_barrier(0); \
+            round(no_t()); \
+        } \
+        /* ---- apply: out_v = T_v . (p_v, 1), p_v = rest + corrective out of the accumulators; into the exchange at the vertex's column */ \
+        __builtin_amdgcn_sched_barrier(0); \
+        char* sx = Sx + (t & 1) * LX_SXBYTES + fl * (LX_XP * 4); \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
+            const float px = isc * acc[t][0][r], py = isc * acc[t][1][r], pz = isc * acc[t][2][r]; \
+            f32x2 xy = __builtin_elementwise_fma(T[r][0], f32x2{px, px}, T[r][3]); \
+            xy = __builtin_elementwise_fma(T[r][1], f32x2{py, py}, xy); \
+            xy = __builtin_elementwise_fma(T[r][2], f32x2{pz, pz}, xy); \
+            const float oz = fmaf(T[r][4].x, px, fmaf(T[r][4].y, py, fmaf(T[r][5].x, pz, T[r][5].y))); \
+            float* so = reinterpret_cast<float*>(sx + xo[r]); \
+            so[0] = xy.x; so[1] = xy.y; so[2] = oz; \
+        } \
+        if (t == 3) LX_STAMP(15) \
+        LBS_LDS_BARRIER(); \
+        LX_STAMP(3 + t) }
+        LX_BLOCK(0) LX_BLOCK(1) LX_BLOCK(2) LX_BLOCK(3) LX_BLOCK(4) LX_BLOCK(5) LX_BLOCK(6) LX_BLOCK(7)
+#undef LX_BLOCK
+        row_read(7);
+        row_write(7);
+        LX_STAMP(11)
     }
-#undef LBS_LD_A
-#undef LBS_LD_G
-#undef LBS_ST_G
-#undef LBS_LD_B
-#undef LBS_MMA_T
-#undef LBS_LD_A1
-#undef LBS_STEP
-#undef LBS_GATHER
-#undef LBS_TAKE
-#undef LBS_HALF
-#undef LBS_STAMP
+    if ((dbg & 32) && cu_seen != nullptr && tid == 0 && blockIdx.x < 512) {
+        reinterpret_cast<long long*>(cu_seen + 2048)[blockIdx.x * 2] = wg_t0;
+        reinterpret_cast<long long*>(cu_seen + 2048)[blockIdx.x * 2 + 1] = wall_clock64();
+    }
+#undef LX_LD_G
+#undef LX_ST_G
+#undef LX_LD_A
+#undef LX_LD_B
+#undef LX_LD_B1
+#undef LX_MMA_T
+#undef LX_STEP
+#undef LX_STAMP
 }
 
 }  // namespace
@@ -636,9 +726,71 @@ static void free_ptr(void* p) { if (p) hipFree(p); }
 extern "C" void moshii_lbs32_free(void* l32) {
     Lbs32Model* lm = (Lbs32Model*)l32;
     free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
-    free_ptr(lm->Pfrag); free_ptr(lm->vsh_pad); free_ptr(lm->sjw);
+    free_ptr(lm->Pfrag); free_ptr(lm->vshs); free_ptr(lm->perm); free_ptr(lm->gx); free_ptr(lm->gnr); free_ptr(lm->gjid); free_ptr(lm->gw);
+    free_ptr(lm->cu_seen);
     free_ptr(lm->Atr); free_ptr(lm->featF);
     memset(lm, 0, sizeof(*lm));
+}
+
+// Partition of every 64-vertex tile into four groups of 16 so that a group's vertices depend on few joints (its joint list is what
+// the export kernel's blend walks, four joints per round; the workgroup meets at a barrier per block, so the tile's LARGEST list
+// counts first, then the sum).  Start: the tile's vertices sorted by (strongest, second strongest) joint, cut into 16s; then pair
+// swaps between groups while they lower (max rounds, sum of rounds, sum of joints).  mask[v] = the joints of vertex v (K <= 64).
+// Returns order[tile * 64 + slot] = vertex id (or -1: padding behind V).
+static std::vector<int> group_tiles(int V, int K, const double* wh, int NVT) {
+    std::vector<int> order((size_t)NVT * LX_TV, -1);
+    std::vector<unsigned long long> mask((size_t)NVT * LX_TV, 0ull);
+    std::vector<int> key((size_t)NVT * LX_TV, 0);
+    for (int v = 0; v < V; ++v) {
+        int j1 = 0, j2 = -1;
+        double w1 = -1.0, w2 = -1.0;
+        unsigned long long m = 0;
+        for (int j = 0; j < K; ++j) {
+            const double w = std::fabs(wh[(size_t)v * K + j]);
+            if (wh[(size_t)v * K + j] != 0.0) m |= 1ull << j;
+            if (w > w1) { w2 = w1; j2 = j1; w1 = w; j1 = j; }
+            else if (w > w2) { w2 = w; j2 = j; }
+        }
+        if (j2 < 0 || w2 <= 0.0) j2 = j1;
+        mask[v] = m;
+        key[v] = j1 * 64 + j2;
+    }
+    auto pc = [](unsigned long long m) { return __builtin_popcountll(m); };
+    for (int t = 0; t < NVT; ++t) {
+        int ids[LX_TV];
+        for (int s = 0; s < LX_TV; ++s) ids[s] = t * LX_TV + s;
+        std::stable_sort(ids, ids + LX_TV, [&](int a, int b) {
+            const bool pa = a >= V, pb = b >= V;     // padding last
+            if (pa != pb) return pb;
+            return key[a] < key[b];
+        });
+        unsigned long long gm[4];
+        auto umask = [&](int g) { unsigned long long m = 0; for (int s = 0; s < 16; ++s) m |= mask[ids[g * 16 + s]]; return m; };
+        auto cost = [&](const unsigned long long* ms) {
+            long mx = 0, sr = 0, sj = 0;
+            for (int g = 0; g < 4; ++g) { const long n = pc(ms[g]), r = std::max(1L, (n + LX_JR - 1) / LX_JR); mx = std::max(mx, r); sr += r; sj += n; }
+            return mx * 1000000L + sr * 1000L + sj;
+        };
+        for (int g = 0; g < 4; ++g) gm[g] = umask(g);
+        long cur = cost(gm);
+        for (int sweep = 0; sweep < 4; ++sweep) {
+            bool improved = false;
+            for (int a = 0; a < 4; ++a)
+                for (int b = a + 1; b < 4; ++b)
+                    for (int ia = 0; ia < 16; ++ia)
+                        for (int ib = 0; ib < 16; ++ib) {
+                            std::swap(ids[a * 16 + ia], ids[b * 16 + ib]);
+                            unsigned long long ms[4] = {gm[0], gm[1], gm[2], gm[3]};
+                            ms[a] = umask(a); ms[b] = umask(b);
+                            const long c = cost(ms);
+                            if (c < cur) { cur = c; gm[a] = ms[a]; gm[b] = ms[b]; improved = true; }
+                            else std::swap(ids[a * 16 + ia], ids[b * 16 + ib]);
+                        }
+            if (!improved) break;
+        }
+        for (int s = 0; s < LX_TV; ++s) order[(size_t)t * LX_TV + s] = ids[s] < V ? ids[s] : -1;
+    }
+    return order;
 }
 
 extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
@@ -657,37 +809,53 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
         hipLaunchKernelGGL(k_cvt_weights, dim3(512), dim3(256), 0, 0, V, Vp, K, moshii_internal_weights(m), lm->weights);
         // ---- MFMA-path model copy
         lm->mfma_ok = 0;
-        const int Vp128 = (V + LBS_TV - 1) / LBS_TV * LBS_TV;
+        const int NVT = (V + LX_TV - 1) / LX_TV, NG = NVT * 4;
         const int KS = (nfeat + 31) / 32;
-        const int nvg = Vp128 / 16;
-        lm->Vp128 = Vp128; lm->KS = KS;
-        lm->KJ = (K + 3) & ~3;   // joints padded so that a half tile's transforms are whole 1 KiB DMA pieces
-        // per-vertex influence lists (host; once per model)
+        lm->NVT = NVT; lm->KS = KS; lm->K = K;
+        lm->KJ = (K + 3) & ~3;
         const double* wh = moshii_internal_weights_host(m);
-        int NW = 1;
-        for (int v = 0; v < V; ++v) {
-            int c = 0;
-            for (int j = 0; j < K; ++j) c += (wh[(size_t)v * K + j] != 0.0) ? 1 : 0;
-            NW = std::max(NW, c);
-        }
-        bool ok = nfeat > 0 && NW <= LBS_NWMAX;
-        lm->K = K;
-        const int NWT = (NW <= 4) ? 4 : 8;   // influences padded to the kernel's compile-time width (joint 0, weight 0)
-        lm->NW = NWT;
-        std::vector<int> sjw(ok ? (size_t)Vp128 * NWT * 2 : 0, 0);   // {byte offset of the joint's [16][12] f32 block, weight bits}
-        for (int v = 0; v < V && ok; ++v) {
-            int c = 0;
-            for (int j = 0; j < K; ++j) {
-                const double w = wh[(size_t)v * K + j];
-                if (w != 0.0) {
-                    const float wf = (float)w;
-                    int bits; memcpy(&bits, &wf, 4);
-                    sjw[((size_t)v * NWT + c) * 2 + 0] = j * LBS_JBYTES;
-                    sjw[((size_t)v * NWT + c) * 2 + 1] = bits;
-                    ++c;
+        bool ok = nfeat > 0 && K <= 64;
+        std::vector<int> order, gnr, gjid, gx;
+        std::vector<float> gw;
+        int NRM = 1;
+        if (ok) {
+            order = group_tiles(V, K, wh, NVT);
+            std::vector<std::vector<int>> lists(NG);
+            for (int g = 0; g < NG; ++g) {
+                unsigned long long mk = 0;
+                for (int s = 0; s < 16; ++s) {
+                    const int v = order[(size_t)g * 16 + s];
+                    if (v >= 0) for (int j = 0; j < K; ++j) if (wh[(size_t)v * K + j] != 0.0) mk |= 1ull << j;
+                }
+                for (int j = 0; j < K; ++j) if (mk >> j & 1) lists[g].push_back(j);
+                NRM = std::max(NRM, ((int)lists[g].size() + LX_JR - 1) / LX_JR);
+            }
+            ok = NRM <= LX_NRMAX;
+            if (ok) {
+                gnr.assign(NG, 1); gjid.assign((size_t)NG * NRM * LX_JR, 0); gx.assign((size_t)NG * 16, 0);
+                gw.assign((size_t)NG * NRM * 16 * LX_JR, 0.0f);
+                for (int g = 0; g < NG; ++g) {
+                    const int nj = (int)lists[g].size();
+                    gnr[g] = std::max(1, (nj + LX_JR - 1) / LX_JR);
+                    for (int i = 0; i < nj; ++i) gjid[(size_t)g * NRM * LX_JR + i] = lists[g][i] * LX_JBYTES;
+                    for (int s = 0; s < 16; ++s) {
+                        const int v = order[(size_t)g * 16 + s];
+                        // padding keeps its own column of the tile (beyond the valid floats of a row: written to the exchange, never stored)
+                        int col = v >= 0 ? v % LX_TV : -1;
+                        if (col < 0) {   // the free columns of this tile, in slot order
+                            const int tile = g / 4, nvalid = std::min(LX_TV, V - tile * LX_TV);
+                            int npad_before = 0;
+                            for (int s2 = 0; s2 < (g % 4) * 16 + s; ++s2) if (order[(size_t)tile * LX_TV + s2] < 0) ++npad_before;
+                            col = nvalid + npad_before;
+                        }
+                        gx[(size_t)g * 16 + s] = col * 12;
+                        if (v >= 0) for (int i = 0; i < nj; ++i)
+                            gw[(((size_t)g * NRM + i / LX_JR) * 16 + s) * LX_JR + i % LX_JR] = (float)wh[(size_t)v * K + lists[g][i]];
+                    }
                 }
             }
         }
+        lm->NRM = NRM;
         if (ok) {
             double* d_part = nullptr;
             if (hipMalloc((void**)&d_part, 256 * sizeof(double)) != hipSuccess) return MOSHII_ERR_HIP;
@@ -700,24 +868,40 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
             // power-of-two scale that lifts the largest corrective to ~2^13: small entries stay normal in f16
             double pscale = 1.0;
             if (amax > 0.0) pscale = std::ldexp(1.0, 13 - (int)std::ceil(std::log2(amax)));
+            lm->pscale = (float)pscale;
             lm->inv_pscale = (float)(1.0 / pscale);
-            if (hipMalloc((void**)&lm->Pfrag, (size_t)nvg * 3 * KS * 64 * 8 * sizeof(_Float16)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->vsh_pad, (size_t)Vp128 * 3 * sizeof(float)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->sjw, sjw.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
-            hipMemcpy(lm->sjw, sjw.data(), sjw.size() * sizeof(int), hipMemcpyHostToDevice);
-            hipLaunchKernelGGL(k_pack_pfrag, dim3(4096), dim3(256), 0, 0, V, nfeat, KS, nvg, pscale, moshii_internal_posedirs(m), lm->Pfrag);
-            lm->mfma_ok = lm->KJ <= LBS_KJMAX;
+            if (hipMalloc((void**)&lm->Pfrag, (size_t)NG * 3 * KS * 64 * 8 * sizeof(_Float16)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->vshs, (size_t)NG * 16 * 4 * sizeof(float)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->perm, order.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->gx, gx.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->gnr, gnr.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->gjid, gjid.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->gw, gw.size() * sizeof(float)) != hipSuccess) return MOSHII_ERR_HIP;
+            if (hipMalloc((void**)&lm->cu_seen, 8192 * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
+            hipMemset(lm->cu_seen, 0, 8192 * sizeof(int));
+            hipMemcpy(lm->perm, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->gx, gx.data(), gx.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->gnr, gnr.data(), gnr.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->gjid, gjid.data(), gjid.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->gw, gw.data(), gw.size() * sizeof(float), hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_pack_pfrag, dim3(4096), dim3(256), 0, 0, nfeat, KS, NG, pscale, lm->perm, moshii_internal_posedirs(m), lm->Pfrag);
+            lm->mfma_ok = 1;
         }
     }
     hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->v_shaped);
     hipLaunchKernelGGL(k_cvt_vsh, dim3(1), dim3(256), 0, 0, K * 3, moshii_internal_J(m), lm->J);
-    if (lm->mfma_ok) {
-        hipMemset(lm->vsh_pad, 0, (size_t)lm->Vp128 * 3 * sizeof(float));
-        hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->vsh_pad);
-    }
+    if (lm->mfma_ok)   // rest positions in group order, x pscale (the accumulators start there)
+        hipLaunchKernelGGL(k_pack_vsh, dim3((lm->NVT * LX_TV + 255) / 256), dim3(256), 0, 0, lm->NVT * LX_TV, lm->pscale, lm->perm, moshii_internal_vsh(m), lm->vshs);
     if (hipDeviceSynchronize() != hipSuccess) return MOSHII_ERR_HIP;
     moshii_internal_l32_set_valid(m, 1);
     return MOSHII_OK;
+}
+
+extern "C" int moshii_internal_lbs_debug_times(void* lbs32, long long* out512x2) {   // (development: MOSHII_LBS_STOP=32)
+    Lbs32Model* lm = (Lbs32Model*)lbs32;
+    if (!lm->cu_seen) return -1;
+    hipDeviceSynchronize();
+    return hipMemcpy(out512x2, lm->cu_seen + 2048, 512 * 2 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* md, int F, const float* pose,
@@ -730,12 +914,12 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
         hipLaunchKernelGGL(k_lbs_f32_v0, dim3((md->V + 255) / 256, F), dim3(256), lds, stream, *md, lm, pose, trans, verts);
         return hipGetLastError();
     }
-    const int Fpad = (F + LBS_TF - 1) / LBS_TF * LBS_TF;
+    const int Fpad = (F + LX_TF - 1) / LX_TF * LX_TF;
     if (Fpad > lmp->Fcap) {   // per-call scratch grows to the largest F seen (not stream-ordered: sync first)
         hipStreamSynchronize(stream);
         free_ptr(lmp->Atr); free_ptr(lmp->featF);
         lmp->Atr = nullptr; lmp->featF = nullptr; lmp->Fcap = 0;
-        const size_t na = (size_t)(Fpad / 16) * lmp->KJ * LBS_JBYTES, nf = (size_t)(Fpad / LBS_TF) * lmp->KS * LBS_CHUNK;
+        const size_t na = (size_t)(Fpad / 16) * lmp->KJ * LX_JBYTES, nf = (size_t)(Fpad / LX_TF) * lmp->KS * LX_CHUNK;
         hipError_t e = hipMalloc((void**)&lmp->Atr, na);
         if (e != hipSuccess) return e;
         e = hipMalloc((void**)&lmp->featF, nf);
@@ -749,22 +933,21 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     }
     const Lbs32Model lm = *lmp;
     int dbg = 0;
-    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 31;   // (development: phase timing by truncation / clock stamps; incomplete output)
+    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 63;   // (development: phase timing by truncation / clock stamps; incomplete output)
     hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), (size_t)md->hand_dof * md->nhand_full * sizeof(float), stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
-                       (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 32 : (long long*)nullptr);
-    const int NVT = lm.Vp128 / LBS_TV, NFT = Fpad / LBS_TF;
+                       lm.cu_seen, (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 16 : (long long*)nullptr);
+    const int NVT = lm.NVT, NFT = Fpad / LX_TF;
     int ncu = 0, devid = 0;
     hipGetDevice(&devid);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid);
-    // one workgroup per CU (the kernel takes the whole register file and most of the LDS), 8 XCDs
-    const int nslots = std::max(1, std::min((ncu > 0 ? ncu : 256) / 8, ((NVT + 7) / 8) * NFT));
-    // waves per workgroup: 8 (two per SIMD, the default) or 4 (MOSHII_LBS_WAVES=4: one per SIMD with twice the registers)
-    int nwave = 8;
-    if (const char* es = getenv("MOSHII_LBS_WAVES")) nwave = (atoi(es) == 4) ? 4 : 8;
-    if (lm.NW != 4) nwave = 4;   // (eight influences per vertex: the register budget of the one-wave-per-SIMD form)
-    auto kern = (lm.NW == 4) ? (nwave == 8 ? k_lbs_tile<4, 1> : k_lbs_tile<4, 2>) : k_lbs_tile<8, 2>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // two workgroups per CU (a workgroup takes half a CU's registers and LDS), 8 XCDs
+    int nslots = std::max(1, std::min(2 * (ncu > 0 ? ncu : 256) / 8, ((NVT + 7) / 8) * NFT));
+    if (const char* es = getenv("MOSHII_LBS_SLOTS")) nslots = std::max(1, std::min(nslots, atoi(es)));   // (development: fewer workgroups per XCD)
+    // the second workgroup of a CU starts late by about one k-loop (units of 2 048 cycles; MOSHII_LBS_STAGGER=0: all start together)
+    int stagger = (lm.KS * 24 * 17 + 2047) / 2048 + 1;
+    if (const char* es = getenv("MOSHII_LBS_STAGGER")) stagger = atoi(es);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lbs_export), hipFuncAttributeMaxDynamicSharedMemorySize, LX_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(8 * nslots), dim3(nwave * 64), LBS_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, dbg);
+    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, lm.cu_seen, stagger, dbg);
     return hipGetLastError();
 }

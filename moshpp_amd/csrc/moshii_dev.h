@@ -214,17 +214,22 @@ struct Lbs32Model {
     float* weights;        // [K][Vp64]
     float* J;              // [K][3]
     int Vp;                // V padded to 64
-    // MFMA path (lbs_forward.hip: k_lbs_prep + k_lbs_tile)
-    _Float16* Pfrag;       // [Vp128/16][3][KS][64 lanes][8]  posedirs * pscale, A-operand fragments of v_mfma_f32_16x16x32_f16
-    float* vsh_pad;        // [Vp128][3]
-    int2* sjw;             // [Vp128][NW]  skinning influences per vertex: {byte offset of the joint's block in a half tile's transforms, weight bits}
-    int K, NW;
-    float inv_pscale;
-    int Vp128, KS;         // vertices padded to whole tiles; k-steps of 32 pose features
-    int KJ;                // joints padded to a multiple of 4 (a half tile's transforms are whole 1 KiB pieces)
+    // MFMA path (lbs_forward.hip: k_lbs_prep + k_lbs_export).  Tiles of 64 vertices, each cut into four GROUPS of 16 (group_tiles)
+    _Float16* Pfrag;       // [NVT*4 groups][3][KS][64 lanes][8]  posedirs * pscale, A-operand fragments of v_mfma_f32_16x16x32_f16
+    float* vshs;           // [NVT*64][4]  rest positions in group order, x pscale
+    int* perm;             // [NVT*64]     group order -> vertex id (-1: padding)
+    int* gx;               // [NVT*64]     byte offset of the vertex's column in a tile row of the result exchange (12 x local id)
+    int* gnr;              // [NVT*4]      blend rounds of the group (four joints each)
+    int* gjid;             // [NVT*4][NRM][4]      the group's joint list as byte offsets (j x 768) into a 16-frame block of Atr
+    float* gw;             // [NVT*4][NRM][16][4]  weights of the group's 16 vertices on the round's four joints
+    int* cu_seen;          // [4096] per-CU arrival counters of the export kernel (antiphase of a CU's two workgroups)
+    int K, NRM;            // NRM: the largest round count over all groups
+    float pscale, inv_pscale;
+    int NVT, KS;           // vertex tiles; k-steps of 32 pose features
+    int KJ;                // joints padded to a multiple of 4
     int mfma_ok;
     // per-call scratch, grown to the largest frame count seen (padded to whole 128-frame tiles)
-    float* Atr;            // [Fcap/16][KJ][16][12]  joint transforms, one contiguous block per 16 frames
+    float* Atr;            // [Fcap/16][KJ][16][12]  joint transforms (12 floats as the pairs (R00,R10) (R01,R11) (R02,R12) (t0,t1) (R20,R21) (R22,t2))
     _Float16* featF;       // [Fcap/128][KS][8][64 lanes][8]  pose features, B-operand fragments
     int Fcap;
 };

@@ -17,7 +17,7 @@ def gpu_lib():
     from moshpp_amd import capi
     if os.environ.get('MOSHII_EMULATE') == '1':
         # development aid: run the (small) GPU parity tests against the CPU emulation build of the same sources, e.g.
-        #   MOSHII_EMULATE=1 python -m pytest tests/test_gpu_parity.py -m gpu -k 'not lbs'      (the f16/MFMA export path is not emulated)
+        #   MOSHII_EMULATE=1 python -m pytest tests/test_gpu_parity.py -m gpu -k 'not lbs'      (slow there)
         from tests.emu import build_chain_emu
         capi.LIB_PATH, capi._lib = build_chain_emu.build(), None
     lib = capi.load()

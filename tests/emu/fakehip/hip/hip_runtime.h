@@ -15,6 +15,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) double2 { double x, y; };
 inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) double4 { double x, y, z, w; };
@@ -159,7 +160,24 @@ inline void __builtin_amdgcn_global_load_lds(const void* g, void* l, int size, i
     memcpy((char*)l + offset + (size_t)lane * size, (const char*)g + offset, size);
 }
 #endif
+// buffer loads / stores: resource = base pointer; a lane's 16 bytes at base + voffset + soffset
+#ifdef HIPEMU_NATIVE_F16
+struct __amdgpu_buffer_rsrc_t { char* base; };
+typedef unsigned hipemu_u4 __attribute__((ext_vector_type(4)));
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return __amdgpu_buffer_rsrc_t{(char*)p}; }
+inline hipemu_u4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t rs, unsigned voffset, unsigned soffset, int) {
+    hipemu_u4 v; memcpy(&v, rs.base + voffset + soffset, 16); return v;
+}
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t rs, unsigned voffset, unsigned soffset, int) {
+    unsigned v; memcpy(&v, rs.base + voffset + soffset, 4); return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u4 v, __amdgpu_buffer_rsrc_t rs, unsigned voffset, unsigned soffset, int) {
+    memcpy(rs.base + voffset + soffset, &v, 16);
+}
+#endif
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_s_nop(int) {}
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }   // (hardware ids: everything runs on "CU 0")
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }

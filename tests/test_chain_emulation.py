@@ -155,14 +155,16 @@ def test_underdetermined_frames_are_flagged_and_still_fit_their_data_in_emulatio
     assert np.allclose(out['errs'][2:, 0], np.asarray(ref['errs']['data'])[2:], rtol=1e-2)
 
 
-@pytest.mark.parametrize('model_type,F', [('mano', 20), ('smpl', 17)])
-def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F):
-    """The f16-MFMA full-mesh export (lbs_forward.hip: k_lbs_prep + k_lbs_tile, compiled unchanged by the host clang++) against the
-    f64 kernel of the same emulated library: 16x16x32 MFMA fragment layouts, the feature ring, the lane = frame blend, the result
-    exchange and the partial vertex / frame tiles; the eight-wave (two per SIMD) and the four-wave form of the kernel give the same bits."""
-    import os
+@pytest.mark.parametrize('model_type,F,order', [('mano', 20, 'shuffled'), ('smpl', 17, 'shuffled'), ('mano', 140, 'mesh')])
+def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F, order):
+    """The f16-MFMA full-mesh export (lbs_forward.hip: k_lbs_prep + k_lbs_export, compiled unchanged by the host clang++) against the
+    f64 kernel of the same emulated library: 16x16x32 MFMA fragment layouts, the DMA-fed feature ring, the vertex groups and their
+    joint lists (several blend rounds per group on the shuffled bodies, mostly one on the mesh-ordered one), the gathered transform
+    pieces, the result exchange's un-permutation, partial vertex / frame tiles, and a workgroup's second tile (F = 140: two frame
+    tiles, the first round of the next tile fetched behind the last block)."""
+    from moshpp_amd import synth
     M = {'mano': 24, 'smpl': 41}[model_type]
-    case = oracle_case(model_type, F=4, M=M, seed=61)
+    case = oracle_case(model_type, F=4, M=M, seed=61, dd=synth.synth_model(model_type, seed=61, vertex_order=order))
     rng = np.random.default_rng(5)
     pose = rng.normal(0, 0.35, (F, case['m']['NP']))
     trans = rng.normal(0, 1, (F, 3))
@@ -170,11 +172,7 @@ def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F):
         dev = device_case(case)
         ref = dev['model'].lbs_forward(pose, trans)
         got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
-        os.environ['MOSHII_LBS_WAVES'] = '4'
-        try:
-            got2 = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
-        finally:
-            del os.environ['MOSHII_LBS_WAVES']
+        got2 = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
     assert np.abs(got - ref).max() < 2e-5
     np.testing.assert_array_equal(got, got2)
 

@@ -353,13 +353,16 @@ def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
 
 
 @pytest.mark.parametrize('model_type,F', [('smplh', 300), ('smplx', 150), ('mano', 200), ('smpl', 129)])
-def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
-    """The MFMA export kernel (f16-operand correctives, lane = frame blend from LDS-DMA-staged transforms, row stores through
-    LDS) against the reference-precision kernel and against the plain f32 kernel, on frame counts and vertex counts that
-    leave partial frame tiles and partial vertex tiles; the four-wave form of the kernel (one wave per SIMD) must give the same
-    bits as the default eight-wave form (same arithmetic per vertex and frame); repeated calls must too (the DMA waits are counted)."""
+@pytest.mark.parametrize('order', ['shuffled', 'mesh'])
+def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F, order):
+    """The MFMA export kernel (k_lbs_export: f16-operand correctives, per-group joint lists blended with packed FMAs from gathered
+    LDS-DMA transform pieces, row stores through an LDS exchange) against the reference-precision kernel and against the plain f32
+    kernel, on frame counts and vertex counts that leave partial frame tiles and partial vertex tiles, on both vertex orders of the
+    synthetic body (shuffled ids: several blend rounds per group; mesh order: mostly one); repeated calls give the same bits (the DMA
+    waits are counted), with and without the start-up stagger of a CU's second workgroup."""
+    from moshpp_amd import synth
     M = {'smplh': 53, 'smplx': 60, 'mano': 24, 'smpl': 41}[model_type]
-    case = oracle_case(model_type, F=4, M=M, seed=61)
+    case = oracle_case(model_type, F=4, M=M, seed=61, dd=synth.synth_model(model_type, seed=61, vertex_order=order))
     dev = device_case(case)
     m = case['m']
     rng = np.random.default_rng(5)
@@ -368,7 +371,7 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     ref = dev['model'].lbs_forward(pose, trans)                        # f64 kernel
     got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)      # MFMA kernel
     err = np.abs(got - ref)
-    print(f'{model_type} F={F}: mfma vs f64 max {err.max():.2e} m, rms {np.sqrt((err ** 2).mean()):.2e} m')
+    print(f'{model_type} {order} F={F}: mfma vs f64 max {err.max():.2e} m, rms {np.sqrt((err ** 2).mean()):.2e} m')
     assert err.max() < 2e-5
     os.environ['MOSHII_LBS_PLAIN'] = '1'
     try:
@@ -378,14 +381,35 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F):
     assert np.abs(plain - ref).max() < 5e-6
     for _ in range(3):
         np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
-    os.environ['MOSHII_LBS_WAVES'] = '4'
+    os.environ['MOSHII_LBS_STAGGER'] = '0'
     try:
         np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
     finally:
-        del os.environ['MOSHII_LBS_WAVES']
+        del os.environ['MOSHII_LBS_STAGGER']
     # linearity in trans (size-independent property): shifting trans shifts every vertex by the same amount
     got2 = dev['model'].lbs_forward(pose, trans + 0.25, dtype=np.float32)
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
+
+
+@pytest.mark.parametrize('model_type,M', [('smplh', 53), ('smplx', 60), ('mano', 24), ('smpl', 41)])
+def test_lbs_f32_mfma_matches_oracle_directly(gpu_lib, model_type, M):
+    """The export kernel against the ORACLE's LBS forward (oracle/stageii_oracle.py: verts_forward, the restatement of
+    smpl_fast_derivatives.py:206-218,243-244) -- not against the repository's own f64 kernel -- on all four model classes, 130 frames
+    (a full 128-frame tile and a partial one), every vertex of every frame.  Tolerance: 2e-5 m (f16-operand correctives)."""
+    F = 130
+    case = oracle_case(model_type, F=4, M=M, seed=67)
+    dev = device_case(case)
+    m = case['m']
+    rng = np.random.default_rng(11)
+    pose = rng.normal(0, 0.35, (F, m['NP']))
+    trans = rng.normal(0, 1, (F, 3))
+    got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+    worst = 0.0
+    for f in range(F):
+        ref = so.verts_forward(m, so.fullpose_from_pose(m, pose[f]), trans[f])
+        worst = max(worst, float(np.abs(got[f] - ref).max()))
+    print(f'{model_type}: export kernel vs oracle over {F} frames x {m["v_shaped"].shape[0] if "v_shaped" in m else got.shape[1]} vertices: max {worst:.2e} m')
+    assert worst < 2e-5
 
 
 def test_lbs_f32_soak_random_frame_counts(gpu_lib):

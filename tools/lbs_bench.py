@@ -41,11 +41,30 @@ if os.environ.get('LBS_CHECK'):
     print(f'  check vs the f64 kernel on 40 frames: max |diff| {np.abs(got - ref).max():.2e} m')
 if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
     torch.cuda.synchronize()
-    raw = verts.view(-1)[:2 * 32 * 9].cpu().numpy().view(np.int64)
-    st = raw[:256].reshape(8, 32)
-    ps = raw[256:262]
+    raw = verts.view(-1)[:2 * 16 * 9].cpu().numpy().view(np.int64)
+    st = raw[:128].reshape(8, 16)
+    ps = raw[128:134]
     print('prep (workgroup 0, wave 0): ' + ' | '.join(f'{n} +{int(ps[k + 1] - ps[k])}' for k, n in enumerate(['hand PCA -> fullpose', 'Rodrigues + features', 'chain', 'transform rows out', 'feature pieces out'])))
-    names = ['start', 'prologue done', 'k-loop done'] + [f'h{h} {w}' for h in range(8) for w in ('transforms in', 'blend done', 'exchange ready')] + ['rows out']
+    names = ['start', 'tables + first loads issued', 'k-loop done'] + [f'block {h} done' for h in range(8)] + ['rows out']
     for ti in range(7):
         row = st[ti]
-        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(28)) + f' | [after k-loop: ring free +{int(row[28] - row[2])}, records in +{int(row[29] - row[28])}, transforms in +{int(row[3] - row[29])}] | total {int(row[27] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[27])}' if ti < 6 else ''))
+        if ti < 6 and st[ti + 1][11]:
+            print(f'  (shader clock between the starts of tiles {ti} and {ti + 1}: {(st[ti + 1][0] - row[0]) / max(1, st[ti + 1][12] - row[12]) * 0.1:.2f} GHz)')
+        if row[11] == 0:
+            break
+        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(12)) + f' | [block 3: transforms stored, rows out, next loads issued +{int(row[13] - row[5])}, round 0 +{int(row[14] - row[13])}, further rounds + apply + exchange +{int(row[15] - row[14])}, barrier +{int(row[6] - row[15])}]' + f' | total {int(row[11] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[11])}' if ti < 6 and st[ti + 1][11] else ''))
+if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 32:
+    lib = capi.load()
+    lib.moshii_internal_l32.restype = C.c_void_p
+    lib.moshii_internal_l32.argtypes = [C.c_void_p]
+    buf = (C.c_longlong * 1024)()
+    lib.moshii_internal_lbs_debug_times.argtypes = [C.c_void_p, C.c_void_p]
+    rc = lib.moshii_internal_lbs_debug_times(lib.moshii_internal_l32(solver.dev.handle), buf)
+    tt = np.array(buf[:], dtype=np.int64).reshape(512, 2)
+    t0 = tt[:, 0].min()
+    st_, en_ = (tt[:, 0] - t0) * 0.01, (tt[:, 1] - t0) * 0.01    # us
+    print(f'workgroups (last call): start {st_.min():.1f} .. {st_.max():.1f} us, end {en_.min():.1f} .. {en_.max():.1f} us, duration median {np.median(en_ - st_):.1f} us (min {np.min(en_ - st_):.1f}, max {np.max(en_ - st_):.1f})')
+    for x in range(8):
+        sel = np.arange(512) % 8 == x
+        d = (en_ - st_)[sel]
+        print(f'  XCD {x}: duration median {np.median(d):.1f} us, max {d.max():.1f}; first 32 slots {np.median(d[:32]):.1f}, last 32 slots {np.median(d[32:]):.1f}; latest end {en_[sel].max():.1f}')
