@@ -195,9 +195,7 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
 __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
-                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, int* __restrict__ cu_seen, long long* __restrict__ stamps) {
-    // (the export kernel's per-CU arrival counters: zero for the launch that follows in this stream)
-    if (cu_seen != nullptr && blockIdx.x == 0) for (int i = threadIdx.x; i < 4096; i += 256) cu_seen[i] = 0;
+                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, long long* __restrict__ stamps) {
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
     // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own.  27 KB of static LDS + the
     // hand-component matrix (dynamic: hand_dof x nhand_full floats, 8.6 KB for SMPL-H / SMPL-X) and 81 registers: four workgroups
@@ -391,12 +389,13 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 // loop, reloaded inside the block loop); on the host / in the emulation nothing
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LX_OPAQUE(x) __asm__ __volatile__("" : "+v"(x))
+#define LX_KEEP(x) __asm__ __volatile__("" : : "v"(x))   // x stays in its registers, unused by anything else, up to here
 #else
 #define LX_OPAQUE(x)
+#define LX_KEEP(x)
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out,
-                                                        int* __restrict__ cu_seen, int stagger, int dbg) {
+__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, long long* __restrict__ dbgbuf, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, NRM = lm.NRM;
@@ -412,21 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     const int q4 = lane >> 4, fl = lane & 15;
     // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in the output buffer instead of vertices -- tools/lbs_bench.py prints them)
 #define LX_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + (K)] = clock64(); }
-    const long long wg_t0 = (dbg & 32) ? wall_clock64() : 0;   // (MOSHII_LBS_STOP=32: every workgroup leaves its start / end time in cu_seen[2048 ..])
-    // ---- antiphase: the second workgroup to arrive on a CU starts one k-loop late (the two then alternate matrix and vector phases;
-    // a phase offset neither grows nor shrinks by itself -- both slow down alike while they overlap in the same phase)
-    if (stagger > 0 && cu_seen != nullptr) {
-        int* flag = reinterpret_cast<int*>(lds_raw + LX_OFF_J);
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));     // HW_ID[15:8]: CU, shader array, shader engine
-            const unsigned xc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));    // XCC_ID[3:0]
-            *flag = atomicAdd(&cu_seen[((xc & 15) << 8) | (hw & 255)], 1) & 1;
-        }
-        __syncthreads();
-        const int late = *flag;
-        __syncthreads();
-        if (late) for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);      // (2 048 cycles each)
-    }
+    const long long wg_t0 = (dbg & 32) ? wall_clock64() : 0;   // (MOSHII_LBS_STOP=32: every workgroup leaves its start / end time in dbgbuf)
     // No LDS-DMA anywhere in this kernel (rounds 3/4 fetched the transforms with global_load_lds; the first form of this kernel the
     // features as well).  Measured this round: (1) the compiler books a FLAT-encoded LDS load as an access to both memories and turns
     // every wait it inserts while one is in flight into a full drain of both counters -- no read-ahead survives; (2) as BUFFER loads
@@ -441,13 +426,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     const __amdgpu_buffer_rsrc_t rs_atr = __builtin_amdgcn_make_buffer_rsrc((void*)lm.Atr, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_feat = __builtin_amdgcn_make_buffer_rsrc((void*)lm.featF, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_pf = __builtin_amdgcn_make_buffer_rsrc((void*)lm.Pfrag, 0, 0x7fffffff, 0x00020000);
-    // (the small per-tile tables as well: ONE kind of vector load in the kernel, so that the compiler's counted waits never span loads of
-    //  different kinds -- see the note on stores at the block body)
-    const __amdgpu_buffer_rsrc_t rs_gw = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gw, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_gj = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gjid, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_gn = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gnr, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)lm.gx, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc((void*)lm.vshs, 0, 0x7fffffff, 0x00020000);
+    // (the small per-tile tables as well -- ONE kind of vector load in the kernel -- and all of them behind one resource: the model keeps
+    //  them in one allocation, lm.tab_* are the tables' byte offsets in it; a resource is four scalar registers)
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)lm.tables, 0, 0x7fffffff, 0x00020000);
     const unsigned trb = LX_OFF_TR + wv * LX_TSLOT;        // this wave's transform buffer
     // one round's transforms, 4 joints x 768 B: lane l holds bytes [1024 p + 16 l, + 16) for p = 0 .. 2, i.e. a piece of joint slot
     // (64 p + l) / 48; off[p] = that joint's offset in the 16-frame block + the lane's offset in the joint
@@ -505,20 +486,20 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         const int f0 = ft * LX_TF, v0 = vt * LX_TV, gi = vt * 4 + wv;
         LX_STAMP(0)
         if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + 12] = wall_clock64();   // (100 MHz: the shader clock the stamps ran at)
-        const int nr = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(rs_gn, 0u, (unsigned)gi * 4u, 0));
+        const int nr = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(rs_tab, 0u, lm.tab_gnr + (unsigned)gi * 4u, 0));
         // ---- the tile's tables: the four groups' weights and joint lists into LDS (every wave is past the previous tile's last block)
         for (int i = tid; i < 64 * NRM; i += 256) {   // (4 groups x NRM rounds x 16 slots, 16 bytes each)
-            const f32x4 wrow = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_gw, (unsigned)i * 16u, (unsigned)(vt * 64 * NRM) * 16u, 0);
+            const f32x4 wrow = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)i * 16u, lm.tab_gw + (unsigned)(vt * 64 * NRM) * 16u, 0);
             *reinterpret_cast<f32x4*>(lds_raw + LX_OFF_W + i * 16) = wrow;
         }
-        if (tid < 4 * NRM * LX_JR) reinterpret_cast<int*>(lds_raw + LX_OFF_J)[tid] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_gj, tid * 4u, (unsigned)(vt * 4 * NRM * LX_JR) * 4u, 0);
+        if (tid < 4 * NRM * LX_JR) reinterpret_cast<int*>(lds_raw + LX_OFF_J)[tid] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_tab, tid * 4u, lm.tab_gjid + (unsigned)(vt * 4 * NRM * LX_JR) * 4u, 0);
         // this lane's four vertices (slots 4 q4 .. 4 q4 + 3 of the group): exchange columns and scaled rest positions -- the accumulators
         // start AT the rest position (x pscale), so the k-loop delivers rest + corrective in one piece
         f32x4 acc[8][3];
         {
             f32x4 vs[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vs[r] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_vs, (unsigned)(4 * q4 + r) * 16u, (unsigned)gi * 256u, 0);
+            for (int r = 0; r < 4; ++r) vs[r] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)(4 * q4 + r) * 16u, lm.tab_vshs + (unsigned)gi * 256u, 0);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -545,8 +526,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         // what only the epilogue needs is fetched behind the k-loop (held across it these 19 registers were spilled; the first item of a
         // tile waits for them -- the CU's other workgroup runs meanwhile): the lane's exchange columns, its offsets in a round-0 block
         // of transforms, the transforms of the first item
-        const u32x4 xo = __builtin_amdgcn_raw_buffer_load_b128(rs_gx, q4 * 16u, (unsigned)gi * 64u, 0);
-        item_offsets([&](unsigned js) { return __builtin_amdgcn_raw_buffer_load_b32(rs_gj, js * 4u, (unsigned)(gi * NRM * LX_JR) * 4u, 0); }, off0);
+        const u32x4 xo = __builtin_amdgcn_raw_buffer_load_b128(rs_tab, q4 * 16u, lm.tab_gx + (unsigned)gi * 64u, 0);
+        item_offsets([&](unsigned js) { return __builtin_amdgcn_raw_buffer_load_b32(rs_tab, js * 4u, lm.tab_gjid + (unsigned)(gi * NRM * LX_JR) * 4u, 0); }, off0);
         load_item((unsigned)ft * 8u * tlb, off0);
         if (dbg & 1) {   // (MOSHII_LBS_STOP=1: stop behind the k-loop)
             float sacc = 0.0f;
@@ -583,12 +564,13 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
 #endif
             }
         };
-        // The three stores go out back to back (addresses first), and the wave then WAITS for them (vmcnt(0): nothing else is in flight at
-        // that point).  Measured on the device: with ordinary code behind a buffer_store_dwordx4 -- the compiler re-uses its data registers
-        // two wait states later, which is what the ISA asks for -- single floats of the middle store's pieces arrived wrong in memory
-        // (lanes 12 .. 15 of every 16, only in the workgroup that shares its CU's address unit with an older one, a few thousand floats
-        // per export): the store's data is read out of the registers later than that when the unit is backed up.  Waiting costs 4 %.
-        auto row_write = [&](int t) {
+        // The three stores go out back to back (addresses first); their data registers rv stay untouched until the stores have RETIRED:
+        // s_waitcnt vmcnt(0) + LX_KEEP(rv) -- at once (`wait`: a tile's last block), or at the start of the next block, where the wave
+        // waits for its transforms anyway.  Measured on the device: with ordinary code behind a buffer_store_dwordx4 -- the compiler
+        // re-uses its data registers two wait states later, which is what the ISA asks for -- single floats of the stored pieces
+        // arrived wrong in memory (lanes 12 .. 15 of every 16, only in the workgroup that shares its CU's address unit with an older
+        // one, a few thousand floats per export): the unit reads a store's data out of the registers later than that when it is backed up.
+        auto row_write = [&](int t, bool wait) {
             if (dbg & 18) return;
             unsigned voff[3];
             bool ok[3];
@@ -602,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
             __builtin_amdgcn_sched_barrier(0);
             // (streaming stores -- nt: the output must not evict the posedirs fragments the k-loop re-reads from L2)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) if (ok[s]) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 2);
+            for (int s = 0; s < 3; ++s) if (ok[s]) { if (dbg & 64) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 0); else __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 2); }
             if (!full) {   // pieces that straddle the end of a partial vertex tile's rows: float by float
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
@@ -613,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
                     }
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            if (wait) { __builtin_amdgcn_s_waitcnt(0x0F70); LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]); }   // vmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
         };
         f32x2 T[4][6];
@@ -651,29 +633,32 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         };
         typedef std::integral_constant<bool, true> yes_t;
         typedef std::integral_constant<bool, false> no_t;
-        // Block t, round 0: the transforms (loaded during the previous item) go into the wave's buffer -- every lane of the wave has read
-        // the previous item's; the previous block's rows are read back from the exchange together with the round's first LDS reads and
-        // stored; only then are the next item's loads issued, with a whole item to arrive in.  (Stores BEFORE loads: the compiler counts
-        // its wait for a load -- vmcnt(N), N = the vector-memory instructions issued behind it -- as if everything retired in issue order,
-        // and on this device a store issued behind a load can retire ahead of it: with the stores between the loads and their use the
-        // kernel wrote registers to LDS that the loads had not filled yet -- on the device only; the emulation has no such freedom.)
+        // Block t, round 0: wait for everything in flight (vmcnt(0): explicit, because the compiler would count its own wait for the loads
+        // -- vmcnt(N), N = the vector-memory instructions issued behind them -- as if everything retired in issue order, and on this
+        // device a store issued behind a load can retire ahead of it); the transforms go into the wave's buffer -- every lane of the wave
+        // has read the previous item's; the previous block's rows are read back from the exchange together with the round's first LDS
+        // reads; the next item's loads are issued, with a whole block to arrive in; then the row stores, which have the same block to retire.
 #define LX_BLOCK(TT) { \
         constexpr int t = (TT); \
+        /* everything in flight has retired: this block's transforms are in sg, the previous block's row stores have read rv */ \
+        __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_sched_barrier(0); \
+        if (t >= 2) { LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]); } \
         LBS_WAVE_SYNC() \
         store_item(); \
         LBS_WAVE_SYNC() \
         if (t >= 1) row_read(t - 1); \
         round_reads(0); \
         __builtin_amdgcn_sched_barrier(0); \
-        if (t >= 1) row_write(t - 1); \
-        __builtin_amdgcn_sched_barrier(0); \
         if (nr > 1) { unsigned offq[3]; item_offsets([&](unsigned js) { return ljt[LX_JR + js]; }, offq); load_item(abase + (unsigned)t * tlb, offq); } \
         else if (t < 7) load_item(abase + (unsigned)(t + 1) * tlb, off0); \
+        __builtin_amdgcn_sched_barrier(0); \
+        if (t >= 1) row_write(t - 1, nr > 1); \
         __builtin_amdgcn_sched_barrier(0); \
         if (t == 3) LX_STAMP(13) \
         round(yes_t()); \
         if (t == 3) LX_STAMP(14) \
         for (int q = 1; q < nr; ++q) { \
+            __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_sched_barrier(0); \
             LBS_WAVE_SYNC() \
             store_item(); \
             LBS_WAVE_SYNC() \
@@ -701,13 +686,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         LX_STAMP(3 + t) }
         LX_BLOCK(0) LX_BLOCK(1) LX_BLOCK(2) LX_BLOCK(3) LX_BLOCK(4) LX_BLOCK(5) LX_BLOCK(6) LX_BLOCK(7)
 #undef LX_BLOCK
+        __builtin_amdgcn_s_waitcnt(0x0F70); LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]);
         row_read(7);
-        row_write(7);
+        row_write(7, true);
         LX_STAMP(11)
     }
-    if ((dbg & 32) && cu_seen != nullptr && tid == 0 && blockIdx.x < 512) {
-        reinterpret_cast<long long*>(cu_seen + 2048)[blockIdx.x * 2] = wg_t0;
-        reinterpret_cast<long long*>(cu_seen + 2048)[blockIdx.x * 2 + 1] = wall_clock64();
+    if ((dbg & 32) && dbgbuf != nullptr && tid == 0 && blockIdx.x < 512) {
+        dbgbuf[blockIdx.x * 2] = wg_t0;
+        dbgbuf[blockIdx.x * 2 + 1] = wall_clock64();
     }
 #undef LX_LD_G
 #undef LX_ST_G
@@ -726,8 +712,7 @@ static void free_ptr(void* p) { if (p) hipFree(p); }
 extern "C" void moshii_lbs32_free(void* l32) {
     Lbs32Model* lm = (Lbs32Model*)l32;
     free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
-    free_ptr(lm->Pfrag); free_ptr(lm->vshs); free_ptr(lm->perm); free_ptr(lm->gx); free_ptr(lm->gnr); free_ptr(lm->gjid); free_ptr(lm->gw);
-    free_ptr(lm->cu_seen);
+    free_ptr(lm->Pfrag); free_ptr(lm->perm); free_ptr(lm->tables); free_ptr(lm->dbgbuf);
     free_ptr(lm->Atr); free_ptr(lm->featF);
     memset(lm, 0, sizeof(*lm));
 }
@@ -871,19 +856,24 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
             lm->pscale = (float)pscale;
             lm->inv_pscale = (float)(1.0 / pscale);
             if (hipMalloc((void**)&lm->Pfrag, (size_t)NG * 3 * KS * 64 * 8 * sizeof(_Float16)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->vshs, (size_t)NG * 16 * 4 * sizeof(float)) != hipSuccess) return MOSHII_ERR_HIP;
             if (hipMalloc((void**)&lm->perm, order.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->gx, gx.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->gnr, gnr.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->gjid, gjid.size() * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->gw, gw.size() * sizeof(float)) != hipSuccess) return MOSHII_ERR_HIP;
-            if (hipMalloc((void**)&lm->cu_seen, 8192 * sizeof(int)) != hipSuccess) return MOSHII_ERR_HIP;
-            hipMemset(lm->cu_seen, 0, 8192 * sizeof(int));
+            // one allocation for the per-group tables (16-byte aligned parts): rounds | joint lists | exchange columns | rest positions | weights
+            auto al16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+            lm->tab_gnr = 0;
+            lm->tab_gjid = (unsigned)al16(gnr.size() * sizeof(int));
+            lm->tab_gx = lm->tab_gjid + (unsigned)al16(gjid.size() * sizeof(int));
+            lm->tab_vshs = lm->tab_gx + (unsigned)al16(gx.size() * sizeof(int));
+            lm->tab_gw = lm->tab_vshs + (unsigned)((size_t)NG * 16 * 4 * sizeof(float));
+            const size_t tab_bytes = lm->tab_gw + al16(gw.size() * sizeof(float));
+            if (hipMalloc((void**)&lm->tables, tab_bytes) != hipSuccess) return MOSHII_ERR_HIP;
+            hipMemset(lm->tables, 0, tab_bytes);
+            if (hipMalloc((void**)&lm->dbgbuf, 1024 * sizeof(long long)) != hipSuccess) return MOSHII_ERR_HIP;
+            hipMemset(lm->dbgbuf, 0, 1024 * sizeof(long long));
             hipMemcpy(lm->perm, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
-            hipMemcpy(lm->gx, gx.data(), gx.size() * sizeof(int), hipMemcpyHostToDevice);
-            hipMemcpy(lm->gnr, gnr.data(), gnr.size() * sizeof(int), hipMemcpyHostToDevice);
-            hipMemcpy(lm->gjid, gjid.data(), gjid.size() * sizeof(int), hipMemcpyHostToDevice);
-            hipMemcpy(lm->gw, gw.data(), gw.size() * sizeof(float), hipMemcpyHostToDevice);
+            hipMemcpy(lm->tables + lm->tab_gx, gx.data(), gx.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->tables + lm->tab_gnr, gnr.data(), gnr.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->tables + lm->tab_gjid, gjid.data(), gjid.size() * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(lm->tables + lm->tab_gw, gw.data(), gw.size() * sizeof(float), hipMemcpyHostToDevice);
             hipLaunchKernelGGL(k_pack_pfrag, dim3(4096), dim3(256), 0, 0, nfeat, KS, NG, pscale, lm->perm, moshii_internal_posedirs(m), lm->Pfrag);
             lm->mfma_ok = 1;
         }
@@ -891,7 +881,7 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
     hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->v_shaped);
     hipLaunchKernelGGL(k_cvt_vsh, dim3(1), dim3(256), 0, 0, K * 3, moshii_internal_J(m), lm->J);
     if (lm->mfma_ok)   // rest positions in group order, x pscale (the accumulators start there)
-        hipLaunchKernelGGL(k_pack_vsh, dim3((lm->NVT * LX_TV + 255) / 256), dim3(256), 0, 0, lm->NVT * LX_TV, lm->pscale, lm->perm, moshii_internal_vsh(m), lm->vshs);
+        hipLaunchKernelGGL(k_pack_vsh, dim3((lm->NVT * LX_TV + 255) / 256), dim3(256), 0, 0, lm->NVT * LX_TV, lm->pscale, lm->perm, moshii_internal_vsh(m), reinterpret_cast<float*>(lm->tables + lm->tab_vshs));
     if (hipDeviceSynchronize() != hipSuccess) return MOSHII_ERR_HIP;
     moshii_internal_l32_set_valid(m, 1);
     return MOSHII_OK;
@@ -899,9 +889,9 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
 
 extern "C" int moshii_internal_lbs_debug_times(void* lbs32, long long* out512x2) {   // (development: MOSHII_LBS_STOP=32)
     Lbs32Model* lm = (Lbs32Model*)lbs32;
-    if (!lm->cu_seen) return -1;
+    if (!lm->dbgbuf) return -1;
     hipDeviceSynchronize();
-    return hipMemcpy(out512x2, lm->cu_seen + 2048, 512 * 2 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return hipMemcpy(out512x2, lm->dbgbuf, 512 * 2 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* md, int F, const float* pose,
@@ -933,9 +923,9 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     }
     const Lbs32Model lm = *lmp;
     int dbg = 0;
-    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 63;   // (development: phase timing by truncation / clock stamps; incomplete output)
+    if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 127;   // (development: phase timing by truncation / clock stamps; incomplete output)
     hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), (size_t)md->hand_dof * md->nhand_full * sizeof(float), stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
-                       lm.cu_seen, (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 16 : (long long*)nullptr);
+                       (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 16 : (long long*)nullptr);
     const int NVT = lm.NVT, NFT = Fpad / LX_TF;
     int ncu = 0, devid = 0;
     hipGetDevice(&devid);
@@ -943,11 +933,8 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     // two workgroups per CU (a workgroup takes half a CU's registers and LDS), 8 XCDs
     int nslots = std::max(1, std::min(2 * (ncu > 0 ? ncu : 256) / 8, ((NVT + 7) / 8) * NFT));
     if (const char* es = getenv("MOSHII_LBS_SLOTS")) nslots = std::max(1, std::min(nslots, atoi(es)));   // (development: fewer workgroups per XCD)
-    // the second workgroup of a CU starts late by about one k-loop (units of 2 048 cycles; MOSHII_LBS_STAGGER=0: all start together)
-    int stagger = (lm.KS * 24 * 17 + 2047) / 2048 + 1;
-    if (const char* es = getenv("MOSHII_LBS_STAGGER")) stagger = atoi(es);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lbs_export), hipFuncAttributeMaxDynamicSharedMemorySize, LX_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, lm.cu_seen, stagger, dbg);
+    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, lm.dbgbuf, dbg);
     return hipGetLastError();
 }

@@ -216,13 +216,14 @@ struct Lbs32Model {
     int Vp;                // V padded to 64
     // MFMA path (lbs_forward.hip: k_lbs_prep + k_lbs_export).  Tiles of 64 vertices, each cut into four GROUPS of 16 (group_tiles)
     _Float16* Pfrag;       // [NVT*4 groups][3][KS][64 lanes][8]  posedirs * pscale, A-operand fragments of v_mfma_f32_16x16x32_f16
-    float* vshs;           // [NVT*64][4]  rest positions in group order, x pscale
     int* perm;             // [NVT*64]     group order -> vertex id (-1: padding)
-    int* gx;               // [NVT*64]     byte offset of the vertex's column in a tile row of the result exchange (12 x local id)
-    int* gnr;              // [NVT*4]      blend rounds of the group (four joints each)
-    int* gjid;             // [NVT*4][NRM][4]      the group's joint list as byte offsets (j x 768) into a 16-frame block of Atr
-    float* gw;             // [NVT*4][NRM][16][4]  weights of the group's 16 vertices on the round's four joints
-    int* cu_seen;          // [4096] per-CU arrival counters of the export kernel (antiphase of a CU's two workgroups)
+    char* tables;          // the per-group tables, one allocation; byte offsets of its parts:
+    unsigned tab_gnr;      //   int   [NVT*4]              blend rounds of the group (four joints each)
+    unsigned tab_gjid;     //   int   [NVT*4][NRM][4]      the group's joint list as byte offsets (j x 768) into a 16-frame block of Atr
+    unsigned tab_gx;       //   int   [NVT*64]             byte offset of the vertex's column in a tile row of the result exchange (12 x local id)
+    unsigned tab_vshs;     //   float [NVT*64][4]          rest positions in group order, x pscale
+    unsigned tab_gw;       //   float [NVT*4][NRM][16][4]  weights of the group's 16 vertices on the round's four joints
+    long long* dbgbuf;     // [512][2] development: start / end time of every workgroup of the last export (MOSHII_LBS_STOP=32)
     int K, NRM;            // NRM: the largest round count over all groups
     float pscale, inv_pscale;
     int NVT, KS;           // vertex tiles; k-steps of 32 pose features
