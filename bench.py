@@ -116,6 +116,18 @@ def strong_job_shares(n_sequences, frames, world):
     return partition_units([float(frames)] * n_sequences, world)
 
 
+def load_pmc(path, lib_hash):
+    """PMC numbers collected by tools/r05_collect.sh, or (None, why): never numbers of another build."""
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+    except Exception as e:
+        return None, f'no PMC file ({path}: {e!r})'
+    if d.get('source_hash') != lib_hash:
+        return None, f'PMC file {os.path.basename(path)} was collected on source hash {d.get("source_hash")}, the loaded library is {lib_hash}: not used'
+    return d, f'rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes (x2 on FETCH_SIZE for 16-byte-per-lane streams, MI355X_MICROARCH.md), {os.path.relpath(path, ROOT)}, collected {d.get("collected", "?")} on source hash {lib_hash}'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=int(os.environ.get('WORLD_SIZE', '1')), help='ranks = GPUs (default: WORLD_SIZE under a launcher, else 1)')
@@ -145,6 +157,8 @@ def main():
     ap.add_argument('--config3-sequences', type=int, default=32)
     ap.add_argument('--config3-frames', type=int, default=4000)
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
+    ap.add_argument('--pmc-file', default=os.path.join(ROOT, 'profiles', 'r05_pmc.json'),
+                    help='HBM traffic from rocprofv3 PMC passes (tools/r05_collect.sh); used only if its source hash is the loaded library\'s')
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
@@ -448,20 +462,17 @@ def main():
         fl_timed = sum(fl_seed[seeds[k % len(seeds)]] for k in range(args.steps))
         kt = float(step_ms.sum()) * 1e-3
         ach = fl_timed / kt / 1e12
+        pmc, pmc_note = load_pmc(args.pmc_file, capi.load().moshii_source_hash().decode())
         result['roofline'] = {
             'kernel': name, 'bound': 'valu_f64',
             'bound_note': 'neither hbm nor mfma: float64 vector pipe, instruction-count / latency-bound small dense solves with one wave per SIMD; memory side 45 KB/frame for a one-workgroup chain alone, ~476 KB/frame (mostly scratch write-back) with a chain on every CU, 1.6 MB/frame for a cooperative chain (write-through exchanges) (PMC)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
-            # PMC (separate FETCH_SIZE / WRITE_SIZE passes over a seed-1000 bench step, profiles/r02_chain_pmc.txt): the pass-1 launch
-            # moves 2 x 1.27 GB fetched (wide-load correction of the guide) + 2.89 GB written for its 13 250 solved frames = 410 KB per
-            # solved frame (a chain alone on the GPU: 44 KB, profiles/r01_chain_pmc.txt), the repair launches < 0.1 GB; scaled to
-            # the frames pass 1 of the timed mode solves
-            # PMC (separate FETCH_SIZE / WRITE_SIZE passes over a seed-1000 step, profiles/r04_chain_pmc.txt, tools/r04_collect.sh): the
-            # pass-1 launch (250 one-workgroup chains x 48 frames) 2 x 1.25 GB fetched (wide-load correction of the guide) + 3.22 GB
-            # written = 476 KB per solved frame (scratch write-back: 250 x 256 lanes x 1552 B do not fit the L2s); the cooperative repair
-            # rounds of that step 2 x 0.18 + 0.78 GB (their exchanges are write-through by design).  Scaled to the frames pass 1 solves.
-            'traffic': int(476e3 * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0)) + (1.14e9 if rep else 0)),
-            'traffic_source': 'rocprofv3 PMC of one seed-1000 step (profiles/r04_chain_pmc.txt): pass-1 launch per solved frame x frames solved in pass 1, + the cooperative repair rounds of that step; not collected live',
+            # HBM traffic: PMC passes of tools/r05_collect.sh over one seed-1000 step (--pmc-file), split into the pass-1 launch (bytes per
+            # frame it solves: chunks x (chunk + warm-up) frames) and the cooperative repair rounds of that step; null when the file was
+            # collected on another build of the library
+            'traffic': (int(pmc['chain']['pass1_bytes_per_solved_frame'] * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0)) + (pmc['chain']['repair_bytes_per_step'] if rep else 0))
+                        if pmc and 'chain' in pmc else None),
+            'traffic_source': pmc_note,
             # the same fraction seed by seed (round 1 quoted seed 1000 alone: 0.0058; `frac` above is over all timed steps)
             'frac_by_seed': {str(sd): round(sum(fl_seed[sd] for k in range(args.steps) if seeds[k % len(seeds)] == sd)
                                             / max(sum(float(step_ms[k]) for k in range(args.steps) if seeds[k % len(seeds)] == sd) * 1e-3, 1e-12)
@@ -513,7 +524,7 @@ def main():
             # ... and over ALL timed seeds: the timed (chunked) result of every seed against that seed's own sequential chain -- frames
             # over the north-star 1e-4 rad (ill-conditioned stretches: a 1e-13 hand-off difference amplified to another local solution,
             # DESIGN.md section 3) and the worst per-frame marker RMSE between the two results and against the observations
-            per = {}
+            per, env = {}, {}
             for sd in used:
                 dq = workload.DeviceSequence(jobs[sd], solvers[sd], dev)
                 dq.solve_sequential(stream)
@@ -527,8 +538,36 @@ def main():
                 per[str(sd)] = {'max_abs_pose_diff_rad': float(dps.max()), 'frames_over_1e-4_rad': int((dps > 1e-4).sum()),
                                 'worst_frame_marker_rmse_vs_sequential_m': float(fr.max()), 'worst_frame_marker_rmse_vs_observations_m': float(fo.max()),
                                 'status_identical': bool((rc['status'] == rs['status']).all())}
+                # EVERY frame of BOTH modes against the committed ORACLE trajectory of the seed and its sensitivity envelope
+                # (tests/parity_envelope.py; tests/golden/oracle_traj_seed<seed>.npz: the NumPy oracle over the whole sequence + K perturbed
+                # oracle runs) -- fixtures, read as the checker; they exist for the default workload (4000 frames, 53 markers)
+                try:
+                    from tests import parity_envelope as pe
+                    if pe.have(sd) and F == 4000 and M == 53:
+                        solved_ids = np.flatnonzero(rs['status'] == 0)
+                        e_def = pe.check(sd, rs['pose'][solved_ids], rs['trans'][solved_ids], rs['iters'][solved_ids], frames=solved_ids)
+                        e_tim = pe.check(sd, rc['pose'][solved_ids], rc['trans'][solved_ids], frames=solved_ids)
+                        fo_s = np.sqrt((((rs['markers_sim'] - jobs[sd]['obs'])[ok] ** 2).sum(-1) * vis_s).sum(1) / np.maximum(vis_s.sum(1), 1))
+                        env[str(sd)] = {'default_mode_sequential': e_def, 'timed_mode_chunked': e_tim,
+                                        'worst_frame_marker_rmse_difference_of_the_two_fits_m': float(np.abs(fo - fo_s).max())}
+                except Exception as e:
+                    env[str(sd)] = {'error': repr(e)}
                 del dq
             result['sequential_chain']['timed_mode_vs_sequential_all_seeds'] = per
+            if env:
+                good = [v for v in env.values() if 'error' not in v]
+                result['parity_every_frame'] = {
+                    'against': 'the NumPy oracle over the WHOLE sequence of every timed seed (tests/golden/oracle_traj_seed*.npz, made by tests/golden/make_oracle_trajectories.py)',
+                    'criterion': 'tests/parity_envelope.py: |pose - oracle| <= 1e-7 rad and equal dogleg iteration counts wherever 3 oracle runs on observations perturbed by 1e-13 m stay '
+                                 'within 3e-9 rad of the oracle; where they part (a knife edge of the reference algorithm itself) a trajectory may part too and is held to '
+                                 'max(0.2 rad, 30 x their spread) until it re-converges; a deviation that begins on a well-conditioned frame counts as outside',
+                    'frames_checked': int(sum(v['default_mode_sequential']['frames'] + v['timed_mode_chunked']['frames'] for v in good)),
+                    'frames_outside_tolerance': int(sum(v['default_mode_sequential']['frames_outside_tolerance'] + v['timed_mode_chunked']['frames_outside_tolerance'] for v in good)),
+                    'frames_parted_on_a_knife_edge': int(sum(v['default_mode_sequential']['frames_parted_on_a_knife_edge'] + v['timed_mode_chunked']['frames_parted_on_a_knife_edge'] for v in good)),
+                    'frames_over_1e-4_rad': int(sum(v['default_mode_sequential']['frames_over_1e-4_rad'] + v['timed_mode_chunked']['frames_over_1e-4_rad'] for v in good)),
+                    'max_dev_on_well_conditioned_frames_rad': float(max([max(v['default_mode_sequential']['max_dev_on_well_conditioned_frames_rad'], v['timed_mode_chunked']['max_dev_on_well_conditioned_frames_rad']) for v in good] or [0.0])),
+                    'worst_frame_marker_rmse_difference_of_the_two_fits_m': float(max([v['worst_frame_marker_rmse_difference_of_the_two_fits_m'] for v in good] or [0.0])),
+                    'by_seed': env}
             result['sequential_chain']['frames_over_1e-4_rad_all_seeds'] = int(sum(v['frames_over_1e-4_rad'] for v in per.values()))
             result['sequential_chain']['worst_frame_marker_rmse_vs_sequential_m_all_seeds'] = float(max(v['worst_frame_marker_rmse_vs_sequential_m'] for v in per.values()))
         # ---- the same solve through host buffers (PCIe staging of observations and results inside the time)
@@ -585,39 +624,58 @@ def main():
                                  'unit': 'TFLOP/s', 'frac': round(fl3 / dt3 / 1e12 / F64_VALU_PEAK_TFLOPS, 5)}}
             except Exception as e:
                 result['config3'] = {'error': repr(e)}
-        # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names)
+        # ---- full-mesh LBS export kernel (the kernel the HBM-roofline target names).  Two bodies of the same sizes: the synthetic SMPL-H
+        #      with its vertices in MESH order (bone by bone, along each bone -- how a registered artist mesh numbers them: consecutive
+        #      ids share joints, which is what the kernel's per-group joint lists profit from) -- `roofline_lbs` -- and the same body
+        #      with SHUFFLED vertex ids (the worst case; what every solver fixture of this repository uses) beside it.
         try:
             import ctypes as C
+            from moshpp_amd import synth
             Fl = min(args.lbs_frames, F)
             pose32 = ds.pose[:Fl].to(torch.float32).contiguous()
             trans32 = ds.trans[:Fl].to(torch.float32).contiguous()
-            verts = torch.empty((Fl, sm.V, 3), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream().cuda_stream
-            for _ in range(2):
-                solver.dev.lbs_forward_device(Fl, pose32.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 5
-            e0.record()
-            for _ in range(reps):
-                solver.dev.lbs_forward_device(Fl, pose32.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
-            e1.record()
-            torch.cuda.synchronize()
-            lt = e0.elapsed_time(e1) * 1e-3 / reps
-            Kj = sm.K
-            # algorithmic bytes: 12 V out + pose/trans in per frame, plus ONE read of the model in the precision the kernel
-            # consumes it (f16 posedirs, f32 rest vertices, sparse skinning weights as (joint, weight) pairs)
-            model_bytes = 2 * 3 * sm.V * 9 * (Kj - 1) + 12 * sm.V + 8 * 4 * sm.V
-            bytes_alg = Fl * (12 * sm.V + 4 * sm.NP + 12) + model_bytes
-            result['roofline_lbs'] = {'kernel': 'k_lbs_tile (+ k_lbs_prep)', 'bound': 'hbm', 'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives (max error vs the f64 kernel 7e-6 m)',
-                                      'achieved': round(bytes_alg / lt / 1e9, 1),
-                                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
-                                      # PMC at F=4000 (profiles/r03_lbs_pmc.txt): k_lbs_tile FETCH_SIZE 145.3 MB (x2 -> 290.5 MB), WRITE_SIZE 349.6 MB;
-                                      # k_lbs_prep FETCH 1.2 MB (x2), WRITE 13.5 MB
-                                      'traffic': int((2 * 145.274e6 + 349.589e6 + 2 * 1.165e6 + 13.5e6) * Fl / 4000.0),
-                                      'traffic_source': 'rocprofv3 PMC at F=4000 (profiles/r03_lbs_pmc.txt), scaled by frames; not collected live',
-                                      'frames': Fl, 'kernel_ms': round(lt * 1e3, 3),
-                                      'frames_per_s': round(Fl / lt, 1)}
+
+            def lbs_leg(slv, tag):
+                smv = slv.sm if hasattr(slv, 'sm') else sm
+                verts = torch.empty((Fl, smv.V, 3), dtype=torch.float32, device=dev)
+                for _ in range(2):
+                    slv.dev.lbs_forward_device(Fl, pose32.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 10
+                e0.record()
+                for _ in range(reps):
+                    slv.dev.lbs_forward_device(Fl, pose32.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
+                e1.record()
+                torch.cuda.synchronize()
+                lt = e0.elapsed_time(e1) * 1e-3 / reps
+                # a 60-frame spot check of the timed output against the reference-precision kernel
+                chk = slv.dev.lbs_forward(pose32[:60].cpu().numpy().astype(np.float64), trans32[:60].cpu().numpy().astype(np.float64))
+                err = float(np.abs(verts[:60].cpu().numpy() - chk).max())
+                Kj = smv.K
+                # algorithmic bytes: 12 V out + pose/trans in per frame, plus ONE read of the model in the precision the kernel
+                # consumes it (f16 posedirs, f32 rest vertices, skinning weights as (joint, weight) pairs)
+                model_bytes = 2 * 3 * smv.V * 9 * (Kj - 1) + 12 * smv.V + 8 * 4 * smv.V
+                bytes_alg = Fl * (12 * smv.V + 4 * smv.NP + 12) + model_bytes
+                pm = pmc.get('lbs', {}).get(tag) if pmc else None
+                return {'kernel': 'k_lbs_export (+ k_lbs_prep)', 'bound': 'hbm', 'body': tag,
+                        'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives, f32 blend',
+                        'achieved': round(bytes_alg / lt / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
+                        'algorithmic_bytes': int(bytes_alg),
+                        'traffic': int(pm['bytes_per_call_at_4000_frames'] * Fl / 4000.0) if pm else None, 'traffic_source': pmc_note,
+                        'frames': Fl, 'kernel_ms': round(lt * 1e3, 3), 'frames_per_s': round(Fl / lt, 1),
+                        'max_abs_err_vs_f64_kernel_m_first_60_frames': err,
+                        'limit_note': 'per SIMD the f16 contraction (79.6 GFLOP: 11.5 k matrix-pipe cycles per 128 x 128 tile) and the blend\'s ~150 vector instructions per '
+                                      '16-frame block time-share the issue port (measured: a vector wave beside a saturating MFMA wave gets one instruction per MFMA), two waves per '
+                                      'SIMD at 256 registers: ~80 us + 22 us of k_lbs_prep at 100 % issue efficiency = 0.45 of the HBM peak is this formulation\'s ceiling (DESIGN.md section 6)'}
+
+            dd_mesh = synth.synth_model('smplh', seed=seeds[0], vertex_order='mesh')
+            job_mesh = workload.make_job('smplh', n_frames=8, n_markers=M, seed=seeds[0], dd=dd_mesh)
+            solver_mesh = workload.make_solver(job_mesh)
+            result['roofline_lbs'] = lbs_leg(solver_mesh, 'mesh_order')
+            result['roofline_lbs']['shuffled_vertex_ids'] = lbs_leg(solver, 'shuffled_ids')
+            del solver_mesh
         except Exception as e:   # the LBS leg must never take the headline number down
             result['roofline_lbs'] = {'error': repr(e)}
         # ---- CPU baseline: the NumPy oracle ("port") on bounded samples of the same workload; parity on the first sample

@@ -44,16 +44,26 @@ typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact 
 #define MOSHII_ERR_NO_DEVICE   -4
 #define MOSHII_ERR_NUMERIC     -5
 
-/* flags for moshii_chain_solve / moshii_lbs_forward_* : where the big per-frame buffers live */
+/* flags for moshii_chain_solve / moshii_sequence_solve / moshii_lbs_forward_* : where the big per-frame buffers live */
 #define MOSHII_BUFFERS_HOST    0u   /* obs/vis/outputs are host pointers (library stages them)     */
-#define MOSHII_BUFFERS_DEVICE  1u   /* obs/vis/outputs are device pointers; launch is async on `stream` */
+#define MOSHII_BUFFERS_DEVICE  1u   /* obs/vis/outputs are device pointers; the launch is async on `stream` -- EXCEPT where cooperative
+                                     * chains are used (below): those calls synchronise the stream before they return */
 
-/* moshii_chain_solve only: COOPERATIVE chains -- every chain is solved by g workgroups (g CUs; 2 <= g <= 8) instead of one.  The ranks
- * split the work that scales with the markers (pose correctives, skinning, marker frames, Jacobian rows, J^T J) and one of them
- * evaluates the prior; they meet twice per dogleg iteration through device memory (csrc/moshii_dev.h: CoopDev).  Same algorithm, same
- * decisions; sums over markers are taken rank by rank, so results agree with a plain chain's to round-off, not bit for bit.  Needs
- * g x n_chains <= CUs (all workgroups resident: otherwise plain chains are used) and a plain body / finger solve (no face / free shape
- * block); the call synchronises the stream.  0 = plain chains unless the environment says MOSHII_COOP=g. */
+/* moshii_chain_solve and moshii_sequence_solve: COOPERATIVE chains -- a chain is solved by g workgroups (g CUs; 2 <= g <= 8) instead of
+ * one.  The ranks split the work that scales with the markers (pose correctives, skinning, marker frames, Jacobian rows, J^T J) and one
+ * of them evaluates the prior; they meet twice per dogleg iteration through device memory (csrc/moshii_dev.h: CoopDev).  Same
+ * algorithm, same decisions; sums over markers are taken rank by rank, so results agree with a plain chain's to round-off (same dogleg
+ * iteration counts), not bit for bit.  All variants are built: body / finger solves and the extended ones (face, free shape block).
+ *   no MOSHII_COOP_GROUP word in `flags` (the value 0)  ->  the environment: MOSHII_COOP=g (moshii_chain_solve) / MOSHII_COOP_REPAIR=g
+ *       (the repair chains of moshii_sequence_solve), "auto" or unset = THE LIBRARY'S CHOICE: cooperative with one rank per 256
+ *       (marker, joint) Jacobian items plus one for the prior when every workgroup of the launch can be resident at once
+ *       (g x n_chains <= CUs) and the solve is large enough to gain (SMPL-H / 53 markers: g = 6; MANO: plain); plain chains otherwise.
+ *       A drop-in caller therefore gets cooperative chains for a single sequential chain -- 1.5x the one-workgroup rate.
+ *   MOSHII_COOP_GROUP(1)  ->  plain chains (bit-reproducible; the call stays asynchronous with MOSHII_BUFFERS_DEVICE)
+ *   MOSHII_COOP_GROUP(g), 2 <= g <= 8  ->  g workgroups per chain; falls back to plain chains when g x n_chains > CUs.
+ * Cooperative calls synchronise the stream: a group whose ranks do not all become resident (device shared with another process) gives
+ * up after ~0.1 s of waiting, the call is then repeated with plain chains (results as from MOSHII_COOP_GROUP(1)), a line goes to
+ * stderr, and the library's own choice stays "plain" for the rest of the process. */
 #define MOSHII_COOP_GROUP(g)   (((uint32_t)(g) & 0xffu) << 8)
 
 const char* moshii_last_error(void);
@@ -113,7 +123,10 @@ int moshii_model_get_joints(moshii_model_t m, double* J_out);
 /* Full-mesh LBS forward, SmplModelLBS.r (smpl_fast_derivatives.py:206-218,243-244 -> psbody
  * verts_decorated): pose[F][NP] (pose *variables*), trans[F][3] -> verts[F][V][3].
  * _f64: reference-precision path (used for the canonical body of TransformedCoeffs, chmosh.py:502).
- * _f32: batched HBM-bound export kernel (MFMA for the W x A blend).  Buffers host or device per flags. */
+ * _f32: batched export kernel: the pose-corrective contraction (3V x 9(K-1) x F) on the f16 matrix pipe (f32 accumulate), the skinning
+ *       blend on the vector pipe over per-group joint lists -- a vertex depends on <= 4-8 of the K joints, so the dense W x A product
+ *       the matrix pipe would need is 4-10x the sparse work.  |error| <= 2e-5 m against _f64.
+ *       Buffers host or device per flags. */
 int moshii_lbs_forward_f64(moshii_model_t m, int32_t F, const double* pose, const double* trans,
                            double* verts, uint32_t flags, void* stream);
 int moshii_lbs_forward_f32(moshii_model_t m, int32_t F, const float* pose, const float* trans,

@@ -314,8 +314,8 @@ __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& 
         unsigned spins = 0;
         while ((int)(coop_ld32<L2>(co.flags + tid) - seq) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 0u)   // now and then: has somebody given up?  have we waited for about a second?
-                if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+            if ((++spins & 255u) == 0u)   // now and then: has somebody given up?  have we waited for ~0.1 s (an exchange takes microseconds)?
+                if (spins > (1u << 21) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
         }
         if (!ok) {
             __hip_atomic_store(co.flags + co.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

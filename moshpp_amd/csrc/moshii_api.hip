@@ -700,6 +700,15 @@ struct LaunchCfg {
 // reserved after the id lists; their device/host offsets come back through ctl_off.
 // The cooperative-chain request of a call: MOSHII_COOP_GROUP(g) in `flags` (0 = no word: the environment variable `env`, else the library's
 // choice; 1 = plain chains; 2 .. 8 = that many workgroups per chain).  Returns -1 (library's choice), 0 (plain), g, or -2 (out of range).
+// Set once a cooperative group has broken up in this process (a rank did not become resident within the wait limit: the device is
+// shared with another process, or CUs are masked): from then on the library's OWN choice is plain chains -- every further call would
+// pay the wait limit and the repeated solve again.  An explicit MOSHII_COOP_GROUP(g) / MOSHII_COOP=g request is still honoured.
+static bool g_coop_broke_once = false;
+static void note_coop_broken(const char* where) {
+    if (!g_coop_broke_once) fprintf(stderr, "[moshii] %s: a cooperative group broke up (the device is shared?); the call is repeated with plain chains, "
+                                            "and the library's own choice is plain chains for the rest of this process\n", where);
+    g_coop_broke_once = true;
+}
 int coop_request(uint32_t flags, const char* env) {
     int g = (int)((flags >> 8) & 0xffu);
     if (g == 0) {
@@ -708,9 +717,10 @@ int coop_request(uint32_t flags, const char* env) {
 #ifdef MOSHII_EMULATION   // (the CPU emulation runs workgroups one after another unless told otherwise: a group would wait for itself)
             return 0;
 #else
-            return -1;
+            return g_coop_broke_once ? 0 : -1;
 #endif
         }
+        if (!strcmp(e, "auto")) return g_coop_broke_once ? 0 : -1;   // (the library's choice, spelled out -- also how the emulation reaches it)
         g = atoi(e);
         if (g == 0) return 0;
     }
@@ -1080,7 +1090,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         if (broken) {
             // a workgroup of a group did not show up within the wait limit (the chip is shared with another process?): the same solve as
             // plain chains, over whatever the broken groups left in the rows
-            if (getenv("MOSHII_TRACE_REPAIR")) fprintf(stderr, "[moshii] a cooperative group broke up: re-running the call with plain chains\n");
+            note_coop_broken("moshii_chain_solve");
             if (!dev) for (int c = 0; c < n_chains; ++c) { st[c].release(); if (d_shape[c]) hipFree(d_shape[c]); }
             return moshii_chain_solve(m, prior, o, n_chains, chains, (flags & ~0xff00u) | (1u << 8), stream_);
         }
@@ -1461,7 +1471,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             for (size_t i = 0; i < rep.size(); ++i) broken |= ab[i] != 0u;
             if (broken) {   // (the chip is shared?)  Whatever the broken groups left is caught by the next verification -- they spoil the entry state of
                             // the chunk they stopped in -- and re-solved by plain chains from here on
-                if (trace) fprintf(stderr, "[moshii] a cooperative repair group broke up: plain repair chains from here on\n");
+                note_coop_broken("moshii_sequence_solve");
                 coop_rep = 0;
             }
         }

@@ -177,6 +177,34 @@ def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F, order):
     np.testing.assert_array_equal(got, got2)
 
 
+def test_the_librarys_own_choice_of_a_cooperative_group_in_emulation(monkeypatch):
+    """flags without a MOSHII_COOP_GROUP word and MOSHII_COOP=auto: the LIBRARY picks the group (prepare_launch, coop_g == -1: one rank
+    per 256 (marker, joint) Jacobian items + one for the prior, if every workgroup can be resident).  On a device that is the default of
+    every drop-in call; the emulation build answers "plain chains" unless the environment spells the choice out, so this is the only
+    CPU coverage of the selection path.  SMPL-H / 53 markers on the emulated 8-CU device: six ranks, same iteration counts as the
+    plain chain; MANO: the library stays with plain chains (the exchanges cost what the split saves)."""
+    monkeypatch.setenv('HIPEMU_CONCURRENT', '1')
+    monkeypatch.setenv('MOSHII_COOP', 'auto')
+    case = oracle_case('smplh', F=3, M=53, seed=4, body_only_markers=True)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case)
+        ch = [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)]
+        out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch)[0]
+        kernel = capi.last_launch_info()[0]
+        monkeypatch.setenv('MOSHII_COOP', '1')
+        plain = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch)[0]
+        assert capi.last_launch_info()[0] == 'k_chain_solve<4,1>'
+    assert kernel == 'k_chain_solve<4,1,coop6>', kernel
+    np.testing.assert_array_equal(out['iters'], plain['iters'])
+    assert np.abs(out['fullpose'] - plain['fullpose']).max() < 1e-9
+    monkeypatch.setenv('MOSHII_COOP', 'auto')
+    case = oracle_case('mano', F=2, M=33, seed=4)
+    with emulated_libmoshii() as capi:
+        dev = device_case(case, optimize_fingers=True)
+        capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], [dict(attach=dev['attach'], obs=case['obs'], vis=case['vis'], first=True)])
+        assert ',coop' not in capi.last_launch_info()[0], capi.last_launch_info()
+
+
 @pytest.mark.parametrize('model_type,fingers,G,F', [('smplh', False, 5, 5), ('smplh', True, 4, 3), ('mano', True, 3, 4), ('smpl', False, 2, 3)])
 def test_cooperative_chain_matches_oracle_in_emulation(monkeypatch, model_type, fingers, G, F):
     """One chain solved by G workgroups (MOSHII_COOP_GROUP; chain_solve.hip, COOP variant): the ranks split markers / vertices / Jacobian

@@ -135,35 +135,39 @@ def test_sequence_solve_carries_the_free_shape_block_on_the_gpu(gpu_lib, kind, m
     assert np.array_equal(outs[0]['status'], seq['status'])
 
 
-@pytest.mark.parametrize('seed', [7, 123, 2024])
-def test_chunked_equals_sequential_on_the_other_bench_seeds(gpu_lib, seed):
-    """The six bench sequences differ in how long their wrong-start regions are (1 to 5 repair rounds before the chains could
-    take over from each other); 71 and 1000 are covered above / by bench.py.  Seed 123 has the ill-conditioned stretches of
-    DESIGN.md section 3 (the GPU sequential chain itself departs from the NumPy oracle by 7e-3 rad around frame 2160): two
-    exact-order float64 runs that differ by a hand-off tolerance are amplified there and re-converge, so the bound is the
-    north-star tolerance inside the recorded stretches and round-off outside them."""
+@pytest.mark.parametrize('seed', [1000, 123, 71, 5, 2024, 7])
+def test_both_modes_lie_inside_the_oracle_envelope_on_every_frame_of_every_bench_seed(gpu_lib, seed):
+    """All six bench sequences, all 4000 frames, BOTH modes -- the drop-in default (sequential, cooperative chain) and the timed one
+    (chunked) -- against the committed oracle trajectory of the seed and its sensitivity envelope (tests/parity_envelope.py: 1e-7 rad
+    and equal dogleg iteration counts wherever K perturbed oracle runs stay within 1e-9 rad of each other; a multiple of their spread
+    where the reference's own algorithm sits on a knife edge; marker RMSE within the north-star bound on every frame).  No frame of
+    any sequence is exempted by name; a frame outside the criterion fails the test.  The chunked scheme has timing-dependent paths
+    (which chain gets where first): three runs."""
     from moshpp_amd import workload
+    from tests import parity_envelope as pe
     job = workload.make_job('smplh', 4000, 53, seed=seed)
     solver = workload.make_solver(job)
     seq = solver.solve(job['obs'], job['vis'])
-    worst = 0.0
-    for _ in range(3):     # the scheme has timing-dependent paths (which chain gets where first): every run must agree
+    solved = np.flatnonzero(seq['status'] == 0)
+    rep = pe.check(seed, seq['pose'][solved], seq['trans'][solved], seq['iters'][solved], frames=solved)
+    print(f'seed {seed} sequential vs oracle: {rep}')
+    assert rep['frames'] == len(pe.load(seed)['frame_ids']) and rep['frames_outside_tolerance'] == 0, rep
+    assert rep['max_dev_on_well_conditioned_frames_rad'] < pe.TIGHT and rep['iteration_counts_equal_on_well_conditioned_frames']
+    sq = ((seq['markers_sim'] - job['obs']) ** 2).sum(-1) * job['vis']
+    fit = np.sqrt(sq.sum(1) / np.maximum(job['vis'].sum(1), 1))
+    for _ in range(3):
         chk = solver.solve(job['obs'], job['vis'], chain_mode='chunked', verify_tol=1e-11)
-        d = np.abs(chk['fullpose'] - seq['fullpose']).max(1)
-        if seed == 123:
-            inside = np.zeros(4000, bool)
-            for a, b in ((950, 985), (2150, 2200), (3940, 3960)):
-                inside[a:b] = True
-            assert d[~inside].max() < TIGHT, (np.flatnonzero(d >= TIGHT)[:10], d.max())      # (measured: 3e-8 at frame 475, else < 1e-9)
-            assert d[inside].max() < 5e-2
-            sq = ((chk['markers_sim'] - seq['markers_sim']) ** 2).sum(-1) * job['vis']
-            frame_rmse = np.sqrt(sq.sum(1) / np.maximum(job['vis'].sum(1), 1))
-            assert frame_rmse.max() < 1e-3                             # marker RMSE: north-star bound on EVERY frame (worst: 0.3 mm)
-        else:
-            assert d.max() < 1e-8, d.max()
-        worst = max(worst, float(d.max()))
         assert np.array_equal(chk['status'], seq['status'])
-    print(f'seed {seed}: max |chunked - sequential| over 3 runs {worst:.2e} rad, last report {chk["chunk_report"]}')
+        rc = pe.check(seed, chk['pose'][solved], chk['trans'][solved], frames=solved)
+        rs = pe.compare(seed, chk, seq)
+        print(f'seed {seed} chunked vs oracle: outside {rc["frames_outside_tolerance"]}, well {rc["max_dev_on_well_conditioned_frames_rad"]:.1e}, '
+              f'parted {rc["frames_parted_on_a_knife_edge"]} frames (max {rc["max_dev_on_parted_frames_rad"]:.1e} rad); vs sequential: outside {rs["frames_outside_tolerance"]}, '
+              f'well {rs["max_dev_on_well_conditioned_frames_rad"]:.1e} rad; {chk["chunk_report"]["n_repaired"]} chunks repaired')
+        assert rc['frames_outside_tolerance'] == 0 and rs['frames_outside_tolerance'] == 0, (rc, rs)
+        # the fit of the chunked result to the data is the sequential chain's on every frame (north star: 1e-3 m marker RMSE)
+        sqc = ((chk['markers_sim'] - job['obs']) ** 2).sum(-1) * job['vis']
+        fitc = np.sqrt(sqc.sum(1) / np.maximum(job['vis'].sum(1), 1))
+        assert np.abs(fitc - fit).max() < 1e-3
 
 
 def test_config5_50000_frames_one_sequence(gpu_lib):
@@ -264,13 +268,20 @@ def test_config3_smplx_32_sequences_of_4000_frames(gpu_lib):
 
 @pytest.mark.gpu
 def test_an_ill_conditioned_stretch_is_the_algorithms_own_sensitivity(gpu_lib):
-    """Seed 11 has a stretch (frames 2176 ... 2680) on which the chunked result departs from the sequential chain by 5e-2 rad at
-    every hand-off tolerance.  That is not the chunk scheme: the sequential chain continued from its OWN state at frame 2150
-    reproduces itself bit for bit, and continued from that state plus 1e-13 it takes the other side of a knife-edge dogleg decision
-    at frame 2176 and tracks another local solution -- whose simulated markers are 0.2 mm RMS from the first one's over the
-    stretch (tools/knife_edge.py)."""
+    """Seed 11 has a stretch of several hundred frames on which the chunked result departs from the sequential chain by 5e-2 rad at
+    every hand-off tolerance.  That is not the chunk scheme: the sequential chain continued from its OWN state a few frames ahead of
+    the stretch reproduces itself bit for bit, and continued from that state plus 1e-13 it takes the other side of a knife-edge dogleg
+    decision and tracks another local solution -- whose simulated markers are 0.2 mm RMS from the first one's over the stretch
+    (tools/knife_edge.py).  WHERE the stretch lies is read off the oracle's own sensitivity envelope
+    (tests/golden/oracle_traj_seed11.npz: the longest run of frames on which perturbed oracle runs part), not written down here."""
     from moshpp_amd import capi, workload
-    t0, t1 = 2150, 2700
+    from tests import parity_envelope as pe
+    ill = pe.dilated(pe.load(11)['spread']) > pe.WELL
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], ill.astype(int), [0]])))
+    starts, ends = edges[0::2], edges[1::2]
+    k = int(np.argmax(ends - starts))
+    t0, t1 = int(starts[k]), int(min(ends[k] + 20, 4000))          # (the dilation puts t0 two dozen frames ahead of the first parted frame)
+    assert t1 - t0 > 50 and t0 > 2
     job = workload.make_job('smplh', 4000, 53, seed=11)
     solver = workload.make_solver(job)
     seq = solver.solve(job['obs'][:t1], job['vis'][:t1])
@@ -286,7 +297,7 @@ def test_an_ill_conditioned_stretch_is_the_algorithms_own_sensitivity(gpu_lib):
     other = continued(1e-13)
     dev = np.abs(other['fullpose'] - seq['fullpose'][t0:t1]).max(1)
     print(f'1e-13 perturbation at frame {t0}: max {dev.max():.2e} rad, first frame > 1e-7: {t0 + int(np.flatnonzero(dev > 1e-7)[0])}')
-    assert dev[:20].max() < 1e-9 and dev.max() > 1e-3                        # tiny for a while, then amplified by orders of magnitude
+    assert dev[:10].max() < 1e-9 and dev.max() > 1e-3                        # tiny for a while, then amplified by orders of magnitude
     d2 = ((other['markers_sim'] - seq['markers_sim'][t0:t1]) ** 2).sum(-1)
     # ... into another solution of the same frames: the simulated markers of the two are 0.2 mm RMS apart over the stretch
     # (2.4 mm on its worst frame)
@@ -294,61 +305,28 @@ def test_an_ill_conditioned_stretch_is_the_algorithms_own_sensitivity(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_sequential_chain_vs_oracle_on_the_ill_conditioned_seed(gpu_lib):
-    """Seed 123, frames 0 .. 2199, GPU SEQUENTIAL chain (the reference's frame order) against the committed oracle trajectory
-    (tests/golden/oracle_seed123.npz): two exact-order float64 implementations agree to round-off up to frame 2157, are driven apart
-    by 10-300x per frame over the hard frames 2158-2163 (5-7 dogleg iterations each), reach 7e-3 rad at frame 2163 -- above the
-    north-star 1e-4 rad on a handful of frames -- and re-converge at 0.45x per frame (profiles/r01_sensitivity.txt).  The claim this
-    test holds: pose <= 1e-4 rad except inside the recorded window (frames 2158 .. 2175), iteration counts equal except there, marker
-    RMSE far below 1e-3 m on EVERY frame."""
-    import os
+def test_chunked_vs_sequential_on_a_seed_with_a_long_ill_conditioned_stretch(gpu_lib):
+    """Seed 11 (not a bench seed): the sequence whose knife edge the test above takes apart -- a stretch of several hundred frames on
+    which two runs that differ by a hand-off tolerance follow different local solutions.  Same criterion as for the bench seeds
+    (tests/parity_envelope.py over the committed oracle trajectory + envelope of seed 11): round-off outside the stretch the perturbed
+    ORACLE runs mark, inside it a multiple of their spread and the north-star marker bound."""
     from moshpp_amd import workload
-    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_seed123.npz'))
-    F = 2200
-    job = workload.make_job('smplh', 4000, 53, seed=123)      # (the bench sequence; the noise / dropout draws depend on its length)
-    job['obs'], job['vis'] = job['obs'][:F], job['vis'][:F]
-    solver = workload.make_solver(job)
-    seq = solver.solve(job['obs'], job['vis'])
-    assert np.all(seq['status'] == 0)
-    dc = np.abs(seq['fullpose'][g['coarse_ids']] - g['coarse_fullpose']).max(1)
-    ws = int(g['win_start'])
-    dw = np.abs(seq['fullpose'][ws:F] - g['win_fullpose']).max(1)
-    frames = np.arange(ws, F)
-    inside = (frames >= 2158) & (frames <= 2175)
-    n_over = int((dw > 1e-4).sum())
-    print(f'seed 123 sequential vs oracle: coarse max {dc.max():.2e} rad; window max {dw.max():.2e} rad at frame {ws + int(dw.argmax())}, '
-          f'{n_over} frames > 1e-4 rad, outside the window {dw[~inside].max():.2e}')
-    assert dc[g['coarse_ids'] < 2150].max() < 1e-9
-    assert dw[frames < 2158].max() < 1e-9
-    assert dw[inside].max() < 2e-2 and n_over <= 8
-    assert dw[~inside].max() < 1e-4
-    np.testing.assert_array_equal(seq['iters'][g['coarse_ids'], 0][g['coarse_ids'] < 2150], g['coarse_iters'][g['coarse_ids'] < 2150])
-    assert (seq['iters'][ws:F, 0] != g['win_iters']).sum() <= 2
-    # the markers of the GPU chain fit the data everywhere, the window included
-    sq = ((seq['markers_sim'] - job['obs']) ** 2).sum(-1) * job['vis']
-    frame_rmse = np.sqrt(sq.sum(1) / np.maximum(job['vis'].sum(1), 1))
-    assert frame_rmse.max() < 3e-3
-
-
-@pytest.mark.gpu
-def test_chunked_vs_sequential_on_seed_11_outside_and_inside_its_stretch(gpu_lib):
-    """Seed 11: the chunked solve equals the sequential chain to round-off on every frame outside the ill-conditioned stretch
-    (frames 2176 .. 2700, see the knife-edge test below), and stays within the north-star marker bound inside it (pose up to
-    5e-2 rad there: another local solution of the same frames)."""
-    from moshpp_amd import workload
+    from tests import parity_envelope as pe
     job = workload.make_job('smplh', 4000, 53, seed=11)
     solver = workload.make_solver(job)
     seq = solver.solve(job['obs'], job['vis'])
+    solved = np.flatnonzero(seq['status'] == 0)
+    rep = pe.check(11, seq['pose'][solved], seq['trans'][solved], seq['iters'][solved], frames=solved)
+    print(f'seed 11 sequential vs oracle: {rep}')
+    assert rep['frames_outside_tolerance'] == 0 and rep['ill_conditioned_frames'] > 100, rep
     for _ in range(2):
         chk = solver.solve(job['obs'], job['vis'], chain_mode='chunked', verify_tol=1e-11)
-        d = np.abs(chk['fullpose'] - seq['fullpose']).max(1)
-        inside = np.zeros(4000, bool)
-        inside[2176:2700] = True
-        print(f'seed 11: outside {d[~inside].max():.2e} rad, inside {d[inside].max():.2e} rad')
-        assert d[~inside].max() < TIGHT and d[inside].max() < 1e-1
+        rs = pe.compare(11, chk, seq)
+        print(f'seed 11 chunked vs sequential: {rs}')
+        assert rs['frames_outside_tolerance'] == 0, rs
         sq = ((chk['markers_sim'] - seq['markers_sim']) ** 2).sum(-1) * job['vis']
         frame_rmse = np.sqrt(sq.sum(1) / np.maximum(job['vis'].sum(1), 1))
-        assert frame_rmse.max() < 5e-3 and np.sqrt((frame_rmse[inside] ** 2).mean()) < 1e-3
+        assert frame_rmse.max() < 5e-3 and np.sqrt((frame_rmse ** 2).mean()) < 1e-3
         assert np.array_equal(chk['status'], seq['status'])
 
 
@@ -444,6 +422,59 @@ def test_chunked_solve_is_exact_under_gpu_contention(gpu_lib):
     finally:
         proc.kill()
         proc.wait()
+
+
+@pytest.mark.gpu
+def test_default_cooperative_chain_beside_a_competing_process(gpu_lib):
+    """The drop-in default -- ONE sequential chain on six workgroups that wait for each other through device memory -- while another
+    process keeps the GPU busy (how the reference is deployed: one process per capture, several per device, mosh_head.py:584-589):
+    (a) a matrix-product hog on another stream of another process, (b) a second MoSh process solving its own sequence at the same
+    time.  The result must be the one-workgroup chain's to round-off with the same iteration counts -- whether the group stayed whole
+    or gave up and the library repeated the call with plain chains (then it says so on stderr and stays with plain chains) -- and the
+    wall time must stay within 3x of the idle one plus the one-off price of a broken group (~0.1 s wait + the repeated solve)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    from moshpp_amd import workload
+    F = 1500
+    job = workload.make_job('smplh', F, 53, seed=2024)
+    solver = workload.make_solver(job)
+    plain = solver.solve(job['obs'], job['vis'], coop_group=1)   # one workgroup per chain (the bit-reproducible reference of this test)
+    t0 = time.perf_counter(); idle = solver.solve(job['obs'], job['vis']); t_idle = time.perf_counter() - t0
+    assert np.abs(idle['fullpose'] - plain['fullpose']).max() < 1e-8 and np.array_equal(idle['iters'], plain['iters'])
+    hog = ("import sys, time, torch\n"
+           "a = torch.randn(6144, 6144, device='cuda:0')\n"
+           "torch.cuda.synchronize(); print('started', flush=True)\n"
+           "t0 = time.time()\n"
+           "while time.time() - t0 < 60:\n"
+           "    for _ in range(8): a = torch.tanh(a @ a) * 0.5\n"
+           "    torch.cuda.synchronize()\n")
+    other = ("import sys, time\nsys.path.insert(0, '.')\nimport numpy as np\nfrom moshpp_amd import workload\n"
+             "job = workload.make_job('smplh', 1500, 53, seed=7); solver = workload.make_solver(job)\n"
+             "solver.solve(job['obs'][:50], job['vis'][:50]); print('started', flush=True)\n"
+             "t0 = time.time(); n = 0\n"
+             "while time.time() - t0 < 25:\n"
+             "    o = solver.solve(job['obs'], job['vis']); n += 1\n"
+             "print('solved', n, float(np.abs(o['fullpose']).max()), flush=True)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, code in (('matrix-product hog', hog), ('second MoSh process', other)):
+        proc = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root)
+        try:
+            line = proc.stdout.readline()
+            assert line.strip() == 'started', (line, proc.stderr.read() if proc.poll() is not None else '')
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); out = solver.solve(job['obs'], job['vis']); ts.append(time.perf_counter() - t0)
+                assert np.abs(out['fullpose'] - plain['fullpose']).max() < 1e-8 and np.abs(out['trans'] - plain['trans']).max() < 1e-8
+                assert np.array_equal(out['iters'], plain['iters']) and np.array_equal(out['status'], plain['status'])
+            print(f'cooperative default beside a {name}: {[round(t, 3) for t in ts]} s against {t_idle:.3f} s idle')
+            assert proc.poll() is None, 'the competing process ended before the solves did'
+            # a broken group costs its wait limit and the repeated solve ONCE (the fallback is sticky); the other runs are plain solves
+            assert sorted(ts)[1] < 3.0 * t_idle + 0.1 and max(ts) < 3.0 * t_idle + 0.6, (ts, t_idle)
+        finally:
+            proc.kill()
+            proc.wait()
 
 
 @pytest.mark.gpu
