@@ -193,6 +193,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_probe = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -201,6 +202,16 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            # prove the N ranks on real devices before anything is timed: the backend is RCCL, and a sum over the ranks of (1, own device
+            # index + 1) taken ON the devices gives the rank count and tells distinct GPUs from N processes on one
+            assert dist.get_backend() == 'nccl', dist.get_backend()
+            probe = torch.tensor([1.0, float(local_rank + 1)], device=torch.device('cuda', local_rank))
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            rccl_ranks, dev_sum = int(probe[0].item()), int(probe[1].item())
+            assert rccl_ranks == world, (rccl_ranks, world)
+            rccl_probe = {'backend': 'nccl (RCCL)', 'ranks_seen_by_an_all_reduce': rccl_ranks,
+                          'distinct_devices': bool(dev_sum == world * (world + 1) // 2 and torch.cuda.device_count() >= world)}
 
     from moshpp_amd import capi, workload
     lib = capi.load()
@@ -368,6 +379,7 @@ def main():
     result = {
         'metric': 'solved mocap frames/sec (Stage-II)', 'value': round(value, 2), 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        **({'rccl': rccl_probe} if rccl_probe else {}),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'BASELINE config[1]: {F}-frame SMPL-H sequence, {M} body markers, fixed betas; {how}; the steps cycle '
                                f'through {len(used)} seeded sequences, value = all timed frames / all timed seconds'

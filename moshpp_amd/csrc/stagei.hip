@@ -1333,18 +1333,28 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     if (shard) {
         // The device path stages host vectors through d_red: that buffer is sized HERE, before the first collective, for the largest
         // vector the solve will ever stage (the n unknowns; 3 F M marker coordinates), so that no rank can drop out of a LATER all-reduce
-        // because of it.  A rank that cannot even get these few KB has no buffer to join the verdict sum with (the callback takes device
-        // pointers only): it fails alone, before any collective, and says so -- the other ranks then wait in their first all-reduce
-        // until the process group's own timeout, which is the launcher's business.
-        double verdict[2] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0};
+        // because of it.  A rank that does not get it still joins the verdict sum -- through a 32-byte buffer -- and reports the failure
+        // there, so that ALL ranks fail together instead of the others waiting in their first all-reduce for the process group's
+        // timeout; only a rank that cannot even get those 32 bytes fails alone.
+        double verdict[3] = {bad_range ? 1.0 : 0.0, bad_owner ? 1.0 : 0.0, 0.0};
         if (red_dev) {
             const long long cap0 = 3LL * M + (long long)F * (3 + NP) + (long long)nb * (d.per_frame ? F : 1) + 3LL * F * M + 6LL * F + 64;   // >= n, 3 F M, 6 F
             d_red = pool.get<double>((size_t)cap0);
             d_red_cap = pool.ok ? cap0 : 0;
-            if (!pool.ok) return fail(MOSHII_ERR_HIP, "stagei: device allocation failed before the first all-reduce (the other ranks were not joined)");
+            if (!pool.ok) {
+                verdict[2] = 1.0;
+                double* tiny = nullptr;
+                if (hipMalloc((void**)&tiny, 4 * sizeof(double)) != hipSuccess)
+                    return fail(MOSHII_ERR_HIP, "stagei: device allocation failed before the first all-reduce (the other ranks were not joined)");
+                d_red = tiny; d_red_cap = 4;
+                reduce(verdict, 3);
+                hipFree(tiny);
+                return fail(MOSHII_ERR_HIP, "stagei: device allocation of the all-reduce staging buffer failed on this rank (all ranks were told)");
+            }
         }
-        reduce(verdict, 2);
+        reduce(verdict, 3);
         if (reduce_rc) return fail(MOSHII_ERR_ARG, "stagei: the all-reduce callback failed");
+        if (verdict[2] > 0) return fail(MOSHII_ERR_HIP, "stagei: device allocation of the all-reduce staging buffer failed on another rank");
         if (verdict[0] > 0) return fail(MOSHII_ERR_ARG, "stagei: frame range of a rank out of bounds");
         if (verdict[1] > 0) return fail(MOSHII_ERR_ARG, "stagei: the rank that owns the shared rows must own at least one frame");
     }
