@@ -666,9 +666,9 @@ def main():
                 chk = slv.dev.lbs_forward(pose32[:60].cpu().numpy().astype(np.float64), trans32[:60].cpu().numpy().astype(np.float64))
                 err = float(np.abs(verts[:60].cpu().numpy() - chk).max())
                 Kj = smv.K
-                # algorithmic bytes: 12 V out + pose/trans in per frame, plus ONE read of the model in the precision the kernel
-                # consumes it (f16 posedirs, f32 rest vertices, skinning weights as (joint, weight) pairs)
-                model_bytes = 2 * 3 * smv.V * 9 * (Kj - 1) + 12 * smv.V + 8 * 4 * smv.V
+                # algorithmic bytes as SURVEY.md section 8(d) / BASELINE.md section 4 state them: 12 V out + pose/trans in per frame, plus ONE
+                # read of the f32 model, 12 V (1 + 9 (K - 1)) + 4 V K bytes (SMPL-H: 39.5 MB; the kernel actually reads f16 posedirs -- 19 MB)
+                model_bytes = 12 * smv.V * (1 + 9 * (Kj - 1)) + 4 * smv.V * Kj
                 bytes_alg = Fl * (12 * smv.V + 4 * smv.NP + 12) + model_bytes
                 pm = pmc.get('lbs', {}).get(tag) if pmc else None
                 return {'kernel': 'k_lbs_export (+ k_lbs_prep)', 'bound': 'hbm', 'body': tag,
