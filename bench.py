@@ -389,9 +389,12 @@ def main():
         'value_is': 'all timed frames / all timed seconds, max over ranks (rounds 1-3 printed the median over seeds of frames / mean step time: `median_over_seeds`)',
         'seeds': per_seed, 'seed_min': round(float(rates.min()), 1), 'seed_max': round(float(rates.max()), 1),
         'median_over_seeds': round(median_rate, 1), 'aggregate_frames_per_s': round(aggregate, 1),
-        'timed_mode': f'{args.mode} (opt-in: chain_mode=\'chunked\'; the drop-in default of mosh_stageii is the sequential chain -- `sequential_chain` below)' if args.mode == 'chunked'
-                      else 'sequential (the drop-in default of mosh_stageii)',
+        'timed_mode': f"{args.mode} (mosh_stageii's default chain_mode 'auto' picks '{solver.choose_chain_mode(F)}' for this workload: chmosh.StageIISolver.choose_chain_mode; "
+                      f"chain_mode='sequential' -- the run-to-run bit-reproducible choice, and what 'auto' keeps for finger / face / DMPL solves and short captures -- is `sequential_chain` below)",
+        'default_mode': f"auto -> {solver.choose_chain_mode(F)}",
     }
+    if solver.choose_chain_mode(F) == args.mode:
+        result['default_mode_frames_per_s'] = round(value, 1)
     if rep:
         result['chunking'] = dict(rep, repaired_per_step=float(np.mean([r['n_repaired'] for sd in used for r in reports[sd]])))
     if args.mode == 'chunked' and world == 1:
@@ -531,7 +534,8 @@ def main():
                                              'marker_rmse_m': float(np.sqrt((dm ** 2).sum(-1).mean())),
                                              'status_identical': bool((status == sq['status']).all())}}
             result['speedup_vs_sequential_chain'] = round(value / max(solved / tsq, 1e-9), 2)
-            result['default_mode_frames_per_s'] = round(solved / tsq, 1)   # what mosh_stageii does unless asked for chain_mode='chunked'
+            if solver.choose_chain_mode(F) == 'sequential':
+                result['default_mode_frames_per_s'] = round(solved / tsq, 1)
             del dsq
             # ... and over ALL timed seeds: the timed (chunked) result of every seed against that seed's own sequential chain -- frames
             # over the north-star 1e-4 rad (ill-conditioned stretches: a 1e-13 hand-off difference amplified to another local solution,
@@ -560,7 +564,7 @@ def main():
                         e_def = pe.check(sd, rs['pose'][solved_ids], rs['trans'][solved_ids], rs['iters'][solved_ids], frames=solved_ids)
                         e_tim = pe.check(sd, rc['pose'][solved_ids], rc['trans'][solved_ids], frames=solved_ids)
                         fo_s = np.sqrt((((rs['markers_sim'] - jobs[sd]['obs'])[ok] ** 2).sum(-1) * vis_s).sum(1) / np.maximum(vis_s.sum(1), 1))
-                        env[str(sd)] = {'default_mode_sequential': e_def, 'timed_mode_chunked': e_tim,
+                        env[str(sd)] = {'sequential_chain': e_def, 'timed_mode_chunked': e_tim,
                                         'worst_frame_marker_rmse_difference_of_the_two_fits_m': float(np.abs(fo - fo_s).max())}
                 except Exception as e:
                     env[str(sd)] = {'error': repr(e)}
@@ -573,11 +577,11 @@ def main():
                     'criterion': 'tests/parity_envelope.py: |pose - oracle| <= 1e-7 rad and equal dogleg iteration counts wherever 3 oracle runs on observations perturbed by 1e-13 m stay '
                                  'within 3e-9 rad of the oracle; where they part (a knife edge of the reference algorithm itself) a trajectory may part too and is held to '
                                  'max(0.2 rad, 30 x their spread) until it re-converges; a deviation that begins on a well-conditioned frame counts as outside',
-                    'frames_checked': int(sum(v['default_mode_sequential']['frames'] + v['timed_mode_chunked']['frames'] for v in good)),
-                    'frames_outside_tolerance': int(sum(v['default_mode_sequential']['frames_outside_tolerance'] + v['timed_mode_chunked']['frames_outside_tolerance'] for v in good)),
-                    'frames_parted_on_a_knife_edge': int(sum(v['default_mode_sequential']['frames_parted_on_a_knife_edge'] + v['timed_mode_chunked']['frames_parted_on_a_knife_edge'] for v in good)),
-                    'frames_over_1e-4_rad': int(sum(v['default_mode_sequential']['frames_over_1e-4_rad'] + v['timed_mode_chunked']['frames_over_1e-4_rad'] for v in good)),
-                    'max_dev_on_well_conditioned_frames_rad': float(max([max(v['default_mode_sequential']['max_dev_on_well_conditioned_frames_rad'], v['timed_mode_chunked']['max_dev_on_well_conditioned_frames_rad']) for v in good] or [0.0])),
+                    'frames_checked': int(sum(v['sequential_chain']['frames'] + v['timed_mode_chunked']['frames'] for v in good)),
+                    'frames_outside_tolerance': int(sum(v['sequential_chain']['frames_outside_tolerance'] + v['timed_mode_chunked']['frames_outside_tolerance'] for v in good)),
+                    'frames_parted_on_a_knife_edge': int(sum(v['sequential_chain']['frames_parted_on_a_knife_edge'] + v['timed_mode_chunked']['frames_parted_on_a_knife_edge'] for v in good)),
+                    'frames_over_1e-4_rad': int(sum(v['sequential_chain']['frames_over_1e-4_rad'] + v['timed_mode_chunked']['frames_over_1e-4_rad'] for v in good)),
+                    'max_dev_on_well_conditioned_frames_rad': float(max([max(v['sequential_chain']['max_dev_on_well_conditioned_frames_rad'], v['timed_mode_chunked']['max_dev_on_well_conditioned_frames_rad']) for v in good] or [0.0])),
                     'worst_frame_marker_rmse_difference_of_the_two_fits_m': float(max([v['worst_frame_marker_rmse_difference_of_the_two_fits_m'] for v in good] or [0.0])),
                     'by_seed': env}
             result['sequential_chain']['frames_over_1e-4_rad_all_seeds'] = int(sum(v['frames_over_1e-4_rad'] for v in per.values()))

@@ -88,8 +88,8 @@ def default_cfg():
         'dirs': dict(support_base_dir=None, work_base_dir=None, stagei_fname=None, stageii_fname=None, log_fname=None,
                      marker_layout=dict(fname=None)),
         'opt_settings': dict(weights_type=None, weights=None, maxiter=100, stagei_lr=1e-3, extra_initial_rigid_adjustment=False),
-        # extensions of this implementation (absent in the reference; all default to reference behaviour)
-        'moshpp_amd': dict(chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, device=None),
+        # extensions of this implementation (absent in the reference; chain_mode 'auto': chmosh.StageIISolver.choose_chain_mode)
+        'moshpp_amd': dict(chain_mode='auto', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, device=None),
         'runtime': dict(stagei_only=False),
     })
 

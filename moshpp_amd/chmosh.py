@@ -153,8 +153,20 @@ class StageIISolver:
         self.optimize_face = bool(optimize_face)
         self.optimize_dynamics = bool(optimize_dynamics)
 
+    AUTO_MIN_FRAMES = 512     # shorter sequences: the chunk starts' 32 warm-up frames cost what the chunks save ("which mode `auto` picks")
+
+    def choose_chain_mode(self, n_frames, requested='auto'):
+        """'auto' -> 'chunked' for a body-only solve of >= AUTO_MIN_FRAMES frames, 'sequential' otherwise: with finger / face / DMPL /
+        shape coefficients free the chain's state has long memory, every fresh chunk start misses and the first repair sweep walks the
+        whole sequence -- correct, but no faster than the sequential chain.  Any other request is returned as it is."""
+        if requested != 'auto':
+            return requested
+        long_memory = self.optimize_fingers or self.optimize_face or self.optimize_dynamics or self.n_shape > 0
+        return 'sequential' if (long_memory or n_frames < self.AUTO_MIN_FRAMES) else 'chunked'
+
     def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, init=None, coop_group=0):
         """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
+        chain_mode 'auto': choose_chain_mode(F) -- what mosh_stageii asks for by default; out['chain_mode'] says which one ran.
         chain_mode 'sequential': one chain, the reference's exact frame order (chmosh.py:584).
         chain_mode 'chunked': moshii_sequence_solve -- concurrent chunks with warm-up overlap, verified and
         repaired against the sequential chain to `verify_tol` (out['chunk_report']); free expression / DMPL coefficients travel in
@@ -164,14 +176,17 @@ class StageIISolver:
         F = obs.shape[0]
         # init = dict(pose, trans, pose_prev | None): continue a chain from that state (no first-frame schedule)
         ikw = {} if init is None else dict(init_pose=init['pose'], init_trans=init['trans'], init_pose_prev=init.get('pose_prev'))
+        chain_mode = self.choose_chain_mode(F, chain_mode)
         if chain_mode == 'sequential' or F == 0:
             out = capi.chain_solve_host(self.dev, self.prior, self.opts,
                                         [dict(attach=self.attach, obs=obs, vis=vis, first=init is None, **ikw)], coop=coop_group)[0]
+            out['chain_mode'] = 'sequential'
             return out
         if chain_mode == 'chunked':
             outs, report = capi.sequence_solve_host(self.dev, self.prior, self.opts, [dict(attach=self.attach, obs=obs, vis=vis, **ikw)],
                                                     num_chunks=num_chunks, warmup=chunk_warmup, verify_tol=verify_tol, coop=coop_group)
             outs[0]['chunk_report'] = report
+            outs[0]['chain_mode'] = 'chunked'
             return outs[0]
         if chain_mode == 'chunked_host':
             # the chunk scheme driven from the host over ONE batched moshii_chain_solve per round (parallel.solve_sequence_chunked_host):
@@ -194,6 +209,7 @@ class StageIISolver:
             out, info = solve_sequence_chunked_host(solve_ranges, F, num_chunks or capi.device_cu_count(), warmup=chunk_warmup, verify_tol=verify_tol,
                                                     state_keys=keys)
             out['chunk_report'] = info
+            out['chain_mode'] = 'chunked_host'
             return out
         raise ValueError(f'unknown chain_mode {chain_mode}')
 
@@ -261,14 +277,17 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     obs, vis = mocap.markers_aslabeled_arrays(latent_labels, selected_frames)
 
     # 5. the frame loop (:584-724) on the GPU
-    # chain mode.  DEFAULT: 'sequential' -- the reference's literal frame order on one workgroup, bit-reproducible from run to run.
-    # 'chunked' (cfg.moshpp_amd.chain_mode) is an explicit opt-in: the same chain cut into concurrently solved chunks whose hand-offs
-    # are verified to `verify_tol` and repaired (12x faster on the bench sequence).  It ends on the sequential
-    # chain to `verify_tol` -- except on ill-conditioned stretches, where a 1e-13 difference in a hand-off state is amplified to
-    # another, equally valid local solution (2 of 13 seeded sequences: up to 5e-2 rad over a few hundred frames, markers < 1 mm
-    # apart; tests/test_gpu_fullsize.py) -- and which chunk is repaired by which chain depends on timing, so the last digits of a
-    # result can differ between runs.  A drop-in default must not have either property.
-    default_mode = 'sequential'
+    # chain mode.  DEFAULT: 'auto' (StageIISolver.choose_chain_mode): a body-only solve of >= 512 frames runs 'chunked' -- the same
+    # chain cut into concurrently solved chunks whose hand-offs are verified to `verify_tol` and repaired until the stitched result is
+    # the sequential chain's (10x faster on the bench sequence) --, everything else (fingers / face / dynamics
+    # free, short captures) 'sequential': the reference's literal frame order as one (cooperative) chain.  Why the chunked mode may
+    # be the default since round 5: against the oracle's full-length trajectories and their sensitivity envelope
+    # (tests/parity_envelope.py) the two modes have the SAME standing on every frame of every bench sequence -- both <= 1e-9 rad on the
+    # well-conditioned frames, both part from the oracle on the same knife-edge stretches the oracle's own perturbed runs part on
+    # (test_both_modes_lie_inside_the_oracle_envelope_on_every_frame_of_every_bench_seed; bench.py parity_every_frame).  What remains
+    # particular to it: which chain repairs which chunk depends on timing, so the last digits (<= 1e-9 rad) can differ between runs;
+    # cfg.moshpp_amd.chain_mode = 'sequential' is the run-to-run bit-reproducible choice.
+    default_mode = 'auto'
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
                        verify_tol=float(_get(ext, 'verify_tol', 1e-11)), coop_group=int(_get(ext, 'coop_group', 0)))

@@ -380,3 +380,23 @@ def test_prepare_stagei_frames_dispatch(tmp_path):
     cfg.moshpp.stagei_frame_picker.type = 'nope'
     with pytest.raises(ValueError):
         prepare_stagei_frames(cfg, [fn])
+
+
+def test_the_default_chain_mode_is_chunked_only_for_long_body_only_solves():
+    """mosh_stageii's default ('auto', chmosh.StageIISolver.choose_chain_mode): a body-only solve of a long capture is cut into
+    verified chunks; free finger / face / DMPL / shape coefficients (long memory: every fresh chunk start misses) and short captures
+    stay on the sequential chain; an explicit request is never overridden."""
+    from types import SimpleNamespace
+    from moshpp_amd.chmosh import StageIISolver
+    from moshpp_amd.cfg import default_cfg
+    body = SimpleNamespace(optimize_fingers=False, optimize_face=False, optimize_dynamics=False, n_shape=0, AUTO_MIN_FRAMES=StageIISolver.AUTO_MIN_FRAMES)
+    pick = StageIISolver.choose_chain_mode
+    assert pick(body, 4000) == 'chunked' and pick(body, StageIISolver.AUTO_MIN_FRAMES) == 'chunked'
+    assert pick(body, StageIISolver.AUTO_MIN_FRAMES - 1) == 'sequential' and pick(body, 0) == 'sequential'
+    for k in ('optimize_fingers', 'optimize_face', 'optimize_dynamics'):
+        s = SimpleNamespace(**{**vars(body), k: True})
+        assert pick(s, 4000) == 'sequential'
+    assert pick(SimpleNamespace(**{**vars(body), 'n_shape': 8}), 4000) == 'sequential'
+    for m in ('sequential', 'chunked', 'chunked_host'):
+        assert pick(body, 10, m) == m and pick(body, 4000, m) == m
+    assert default_cfg().moshpp_amd.chain_mode == 'auto'
