@@ -153,7 +153,8 @@ class StageIISolver:
         self.optimize_face = bool(optimize_face)
         self.optimize_dynamics = bool(optimize_dynamics)
 
-    AUTO_MIN_FRAMES = 512     # shorter sequences: the chunk starts' 32 warm-up frames cost what the chunks save ("which mode `auto` picks")
+    AUTO_MIN_FRAMES = 128     # below ~100 frames the chunk starts' 32 warm-up frames cost what the chunks save (profiles/r05_auto_threshold.txt:
+                              # 64 frames 0.88x, 128 frames 1.6-1.7x, 256 frames 2-3x, 4000 frames 5.5-12.6x the sequential cooperative chain)
 
     def choose_chain_mode(self, n_frames, requested='auto'):
         """'auto' -> 'chunked' for a body-only solve of >= AUTO_MIN_FRAMES frames, 'sequential' otherwise: with finger / face / DMPL /
@@ -277,7 +278,7 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     obs, vis = mocap.markers_aslabeled_arrays(latent_labels, selected_frames)
 
     # 5. the frame loop (:584-724) on the GPU
-    # chain mode.  DEFAULT: 'auto' (StageIISolver.choose_chain_mode): a body-only solve of >= 512 frames runs 'chunked' -- the same
+    # chain mode.  DEFAULT: 'auto' (StageIISolver.choose_chain_mode): a body-only solve of >= 128 frames runs 'chunked' -- the same
     # chain cut into concurrently solved chunks whose hand-offs are verified to `verify_tol` and repaired until the stitched result is
     # the sequential chain's (10x faster on the bench sequence) --, everything else (fingers / face / dynamics
     # free, short captures) 'sequential': the reference's literal frame order as one (cooperative) chain.  Why the chunked mode may
@@ -291,6 +292,7 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
                        verify_tol=float(_get(ext, 'verify_tol', 1e-11)), coop_group=int(_get(ext, 'coop_group', 0)))
+    logger.debug(f"stageii chain mode: {out.get('chain_mode')}")
     for fi in np.flatnonzero(out['status'] == 1):
         logger.error(f'no available observed markers for frame {selected_frames[fi]}. skipping the frame.')
     if np.any(out['status'] < 0):

@@ -298,16 +298,36 @@ __device__ __forceinline__ void coop_st16(const CoopSlot& cs, int off16, double 
 template <bool L2 = false>
 __device__ __forceinline__ void coop_ld16(const CoopSlot& cs, int off16, double& a, double& b) { a = coop_ld(cs.p + 2 * (size_t)off16); b = coop_ld(cs.p + 2 * (size_t)off16 + 1); }
 #endif
+// Test aid (MOSHII_COOP_SKEW=seed, tests/test_gpu_fullsize.py: the ranks' arrival order at the exchanges, randomised): the whole workgroup
+// sleeps 0 .. 3 x 127 x 64 clocks (0 .. ~10 us), drawn from (seed, rank, exchange).  Results must not move by a bit.
+__device__ __forceinline__ void coop_skew(const CoopCtx& co, unsigned seq) {
+    if (co.skew != 0) {
+        unsigned h = (seq * 2654435761u) ^ ((unsigned)co.rank * 40503u + (unsigned)co.skew * 977u);
+        h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        for (unsigned i = h & 3u; i > 0u; --i) __builtin_amdgcn_s_sleep(127);
+    }
+}
 // All threads call, after their payload stores: publish this rank's slot, wait for every rank's.  false: the group is broken.
 template <bool L2 = false>
 __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& cx, unsigned seq) {
     const int tid = threadIdx.x;
+    coop_skew(co, seq);
     PROF_T(_tp0);
     MOSHII_DRAIN_VMEM();
     __syncthreads();
     PROF_ACC(33, _tp0);
     PROF_T(_tp1);
+#if defined(MOSHII_COOP_FENCES)
+    // Development variant (python -m moshpp_amd.build --variant=fences -DMOSHII_COOP_FENCES): the flag as a C++ release store / the read side
+    // closed by an acquire fence, at agent scope.  On gfx950 that is a buffer_wbl2 sc1 before the flag and a buffer_inv sc1 behind the
+    // poll -- an L2 write-back the written-through payload does not need, and the loss of this CU's L1 (model tables) at every exchange.
+    // Measured beside the shipped protocol in DESIGN.md section 4b; the shipped one orders the same accesses by construction: payload
+    // stores carry sc1 and are drained (vmcnt(0)) before the barrier that precedes the flag store; payload loads carry sc1 (never
+    // served by an L1) and are issued after the poll has returned the flag.
+    if (tid == 0) __hip_atomic_store(co.flags + co.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
     if (tid == 0) coop_st32<L2>(co.flags + co.rank, seq);
+#endif
     TRACE_STAMP(co, seq, 1);
     if (tid < co.G && cx.scal[S_COOP_FAIL] == 0.0) {
         bool ok = true;
@@ -323,6 +343,9 @@ __device__ __forceinline__ bool coop_publish_wait(const CoopCtx& co, const Ctx& 
         }
     }
     __syncthreads();
+#if defined(MOSHII_COOP_FENCES)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     PROF_ACC(34, _tp1);
     TRACE_STAMP(co, seq, 2);
     return cx.scal[S_COOP_FAIL] == 0.0;
@@ -340,6 +363,7 @@ template <int NS, bool L2>
 __device__ __forceinline__ bool coop_exchange_small_(const CoopCtx& co, const Ctx& cx, unsigned seq, const double (&mine)[NS], double* land) {
     const int tid = threadIdx.x;
     const int goff = co.slot_doubles - 32;
+    coop_skew(co, seq);
     if (tid < 2 * NS) {
         double v = mine[0];
 #pragma unroll
@@ -358,7 +382,7 @@ __device__ __forceinline__ bool coop_exchange_small_(const CoopCtx& co, const Ct
         while (((x = coop_ld64<L2>(g)) >> 32) != seq) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0u)
-                if (spins > (1u << 24) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                if (spins > (1u << 21) || __hip_atomic_load(co.flags + co.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
         }
         if (!ok) {
             __hip_atomic_store(co.flags + co.G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2921,7 +2945,7 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         const ChainDev* c0 = chains + chain_id;
         co.G = G; co.rank = q % G; co.prior_rank = c0->coop.prior_rank;
         co.mlo = c0->coop.mlo[co.rank]; co.mhi = c0->coop.mlo[co.rank + 1];
-        co.slot_doubles = c0->coop.slot_doubles; co.slots = c0->coop.slots; co.flags = c0->coop.flags;
+        co.slot_doubles = c0->coop.slot_doubles; co.slots = c0->coop.slots; co.flags = c0->coop.flags; co.skew = c0->coop.skew;
     }
     const bool lead = !COOP || co.rank == 0;   // writes the rows every rank holds alike
     const ChainDev* chp = chains + chain_id;   // fields are (re)loaded where used: keeps SGPR pressure down

@@ -709,6 +709,11 @@ static void note_coop_broken(const char* where) {
                                             "and the library's own choice is plain chains for the rest of this process\n", where);
     g_coop_broke_once = true;
 }
+// test aid: MOSHII_COOP_SKEW=seed (read at every call) -> CoopDev::skew, the ranks' arrival order at the exchanges randomised
+int coop_skew_env() {
+    const char* e = getenv("MOSHII_COOP_SKEW");
+    return (e && *e) ? atoi(e) : 0;
+}
 int coop_request(uint32_t flags, const char* env) {
     int g = (int)((flags >> 8) & 0xffu);
     if (g == 0) {
@@ -1043,7 +1048,7 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
         memset(&cd, 0, sizeof(cd));
         cd.att = ch.attach->d_self; cd.F = ch.F; cd.first = ch.first_frame_schedule;
         if (coop_g > 0) {
-            cd.coop.G = coop_g; cd.coop.prior_rank = cfg.coop_prior_rank; cd.coop.slot_doubles = cfg.coop_slot_doubles;
+            cd.coop.G = coop_g; cd.coop.prior_rank = cfg.coop_prior_rank; cd.coop.slot_doubles = cfg.coop_slot_doubles; cd.coop.skew = coop_skew_env();
             coop_split(ch.attach->M, coop_g, cfg.coop_prior_frac, cd.coop.mlo);
             char* cb = m->coopbuf.ptr + coop_bytes_per_chain * c;
             cd.coop.slots = as_gp_rw((unsigned long long*)cb);
@@ -1448,7 +1453,7 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             HIP_TRY(hipMemsetAsync(m->coopbuf.ptr, 0, per * rep.size(), stream));
             for (size_t i = 0; i < rep.size(); ++i) {
                 ChainDev& cd = rep[i];
-                cd.coop.G = g_round; cd.coop.prior_rank = cc.coop_prior_rank; cd.coop.slot_doubles = cc.coop_slot_doubles;
+                cd.coop.G = g_round; cd.coop.prior_rank = cc.coop_prior_rank; cd.coop.slot_doubles = cc.coop_slot_doubles; cd.coop.skew = coop_skew_env();
                     coop_split(seqs[chunks[todo[i]].seq].attach->M, g_round, cc.coop_prior_frac, cd.coop.mlo);
                 char* cb = m->coopbuf.ptr + per * i;
                 cd.coop.slots = as_gp_rw((unsigned long long*)cb);

@@ -97,12 +97,13 @@ struct CoopDev {
     int mlo[MOSHII_COOP_MAXG + 1];
     int slot_doubles;                        // doubles per (parity, rank) slot
     int qstride;                             // extended variant: doubles between the ranks' slices of ChainDev::qscratch
+    int skew;                                // test aid (MOSHII_COOP_SKEW=seed): every rank is held back a pseudo-random 0 .. 10 us before each exchange
     MOSHII_GP(unsigned long long) slots;     // [2][G][slot_doubles] payload words (doubles as bit patterns: 8-byte agent-scope accesses)
     MOSHII_GP(unsigned int) flags;           // [G] sequence number of the last exchange each rank has posted, [G] = the group's abort word
 };
 // the rank's view, in KernelCtx
 struct CoopCtx {
-    int G, rank, prior_rank, mlo, mhi, slot_doubles;
+    int G, rank, prior_rank, mlo, mhi, slot_doubles, skew;
     MOSHII_GP(unsigned long long) slots;
     MOSHII_GP(unsigned int) flags;
 };

@@ -220,7 +220,13 @@ def test_cooperative_chain_matches_oracle_in_emulation(monkeypatch, model_type, 
         plain = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch)[0]
         out = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch, coop=G)[0]
         kernel = capi.last_launch_info()[0]
+        # the ranks' arrival order at every exchange randomised (MOSHII_COOP_SKEW, chain_solve.hip: coop_skew): not a bit may move
+        monkeypatch.setenv('MOSHII_COOP_SKEW', '5')
+        skewed = capi.chain_solve_host(dev['model'], dev['prior'], dev['opts'], ch, coop=G)[0]
+        monkeypatch.delenv('MOSHII_COOP_SKEW')
     assert kernel.endswith(f',coop{G}>'), kernel
+    for k in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status'):
+        np.testing.assert_array_equal(skewed[k], out[k], err_msg=k)
     ref = so.stageii_chain(case['m'], case['prior'], case['closest'], case['coef'], case['obs'], case['vis'], model_type,
                            optimize_fingers=fingers)
     solved = np.flatnonzero(out['status'] == 0)

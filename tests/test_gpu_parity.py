@@ -666,4 +666,87 @@ def test_loaded_library_was_built_from_this_tree(gpu_lib):
     """The binary the GPU tests run is the one this tree's sources produce: the source hash compiled into it
     (moshii_source_hash) equals the hash of moshpp_amd/csrc + include/moshii.h as they are on disk."""
     from moshpp_amd import build, capi
-    assert capi.load().moshii_source_hash().decode() == build.source_hash()
+    assert capi.load().moshii_source_hash().decode() == build.source_hash()@pytest.mark.gpu
+@pytest.mark.parametrize('which', ['body_g6', 'fingers_8_blocks_g8', 'expression_194_unknowns_g8'])
+def test_cooperative_exchanges_under_randomised_rank_skew(gpu_lib, monkeypatch, which):
+    """The exchange protocol of the cooperative chains (chain_solve.hip: payload written through, drained, then the rank's flag;
+    readers poll the flags, then read the slots past their L1) with the ranks' ARRIVAL ORDER randomised: MOSHII_COOP_SKEW=seed holds
+    every rank back a pseudo-random 0 .. 10 us before each of its exchanges (drawn from seed, rank and exchange number), so that
+    every rank is at some point the first and the last to post, slots are read while their owner is already two phases on, and the
+    two-slot parity scheme is walked with the largest lead it allows.  A visibility or ordering hole (a reader seeing a flag before
+    the payload behind it, a slot rewritten under a reader) would show as a changed bit: sums are taken in rank order, so the
+    result of a cooperative configuration must be bit-identical whatever the timing.  Three exchange shapes: the body solve (all-to-all
+    of the accumulators), eight register blocks and 194 unknowns (reduce-scatter + all-gather, two flag rounds per assembly)."""
+    from moshpp_amd import capi
+    from tests.helpers import shape_case
+    if which == 'body_g6':
+        case = oracle_case('smplh', F=120, M=53, seed=123)
+        dev = device_case(case)
+        g, want = 6, 'k_chain_solve<4,1,coop6>'
+    elif which == 'fingers_8_blocks_g8':
+        monkeypatch.setenv('MOSHII_FORCE_NBLK', '8')
+        case = oracle_case('smplx', F=16, M=89, seed=9, body_only_markers=False)
+        dev = device_case(case, optimize_fingers=True)
+        g, want = 8, 'k_chain_solve<8,1,coop8>'
+    else:
+        case = shape_case('smplx', F=4, M=40, E=80, seed=3, kind='expr')
+        dev = device_case(case, optimize_fingers=True, optimize_face=True, shape_kind='expr')
+        g, want = 8, 'k_chain_solve<13,1,xt,coop8>'
+    base = _sequential(dev, case, coop=g)
+    assert capi.last_launch_info()[0] == want, capi.last_launch_info()
+    keys = [k for k in ('pose', 'fullpose', 'trans', 'markers_sim', 'errs', 'iters', 'status', 'shape') if k in base]
+    for seed in (1, 2, 3):
+        monkeypatch.setenv('MOSHII_COOP_SKEW', str(seed))
+        out = _sequential(dev, case, coop=g)
+        monkeypatch.delenv('MOSHII_COOP_SKEW')
+        assert capi.last_launch_info()[0] == want
+        for k in keys:
+            np.testing.assert_array_equal(out[k], base[k], err_msg=f'{which}: {k} moved under skew seed {seed}')
+    again = _sequential(dev, case, coop=g)
+    for k in keys:
+        np.testing.assert_array_equal(again[k], base[k], err_msg=k)
+
+
+@pytest.mark.gpu
+def test_mosh_stageii_default_runs_a_long_body_capture_as_verified_chunks(gpu_lib, tmp_path, monkeypatch):
+    """mosh_stageii without a cfg.moshpp_amd node on a 300-frame body capture: chain_mode 'auto' picks the chunked solve (concurrent
+    chunks, hand-offs verified and repaired: moshii_sequence_solve), and the result is the sequential chain's -- same solved frames,
+    same per-frame error terms, poses to 1e-7 rad (both are the same chain; a well-conditioned synthetic capture) -- which
+    cfg.moshpp_amd.chain_mode = 'sequential' still delivers on request."""
+    import pickle
+    from moshpp_amd import chmosh, synth
+    from moshpp_amd.cfg import make_cfg
+    from moshpp_amd.mocap_interface import write_mocap_c3d
+    F = 300
+    s = synth.make_sequence('smplh', F, 53, seed=1000, empty_frames=(150,))
+    with open(tmp_path / 'model.pkl', 'wb') as f:
+        pickle.dump({k: v for k, v in s['model'].items() if not k.startswith('_')}, f)
+    with open(tmp_path / 'pose_body_prior.pkl', 'wb') as f:
+        pickle.dump(s['gmm'], f)
+    np.savez(tmp_path / 'pose_hand_prior.npz', **s['hand_prior'])
+    c3d = str(tmp_path / 'ds' / 'subj' / 'long.c3d')
+    os.makedirs(os.path.dirname(c3d))
+    write_mocap_c3d(s['markers'], list(s['labels']), c3d, frame_rate=120)
+    ran = []
+    real = chmosh.StageIISolver.solve
+
+    def spy(self, *a, **k):
+        out = real(self, *a, **k)
+        ran.append((k.get('chain_mode'), out['chain_mode'], out.get('chunk_report')))
+        return out
+    monkeypatch.setattr(chmosh.StageIISolver, 'solve', spy)
+    kw = {'mocap.fname': c3d, 'surface_model.type': 'smplh', 'surface_model.fname': str(tmp_path / 'model.pkl'),
+          'moshpp.pose_body_prior_fname': str(tmp_path / 'pose_body_prior.pkl'), 'moshpp.pose_hand_prior_fname': str(tmp_path / 'pose_hand_prior.npz')}
+    auto = chmosh.mosh_stageii(c3d, make_cfg(**kw), s['markers_latent'], s['latent_labels'], s['betas'], s['marker_meta'])
+    seq = chmosh.mosh_stageii(c3d, make_cfg(**kw, **{'moshpp_amd.chain_mode': 'sequential'}), s['markers_latent'], s['latent_labels'], s['betas'], s['marker_meta'])
+    assert [r[:2] for r in ran] == [('auto', 'chunked'), ('sequential', 'sequential')], ran
+    assert ran[0][2] is not None and ran[0][2]['n_chunks'] > 1
+    assert auto['fullpose'].shape == seq['fullpose'].shape == (F - 1, 156)
+    assert np.abs(auto['fullpose'] - seq['fullpose']).max() < 1e-7 and np.abs(auto['trans'] - seq['trans']).max() < 1e-7
+    da, ds_ = auto['stageii_debug_details'], seq['stageii_debug_details']
+    for k in ds_['stageii_errs']:
+        np.testing.assert_allclose(da['stageii_errs'][k], ds_['stageii_errs'][k], rtol=1e-5, atol=1e-9)
+    assert all(np.abs(a - b).max() < 1e-7 for a, b in zip(da['markers_sim'], ds_['markers_sim']))
+
+
+
