@@ -16,6 +16,18 @@
 #include "moshii_dev.h"
 #include <utility>
 #include <type_traits>
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOSHII_OPAQUE(x) __asm__ __volatile__("" : "+v"(x))
+#else
+#define MOSHII_OPAQUE(x) do {} while (0)
+#endif
+__device__ __forceinline__ double uni64(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+#else
+    return v;
+#endif
+}
 
 namespace moshii {
 
@@ -1170,8 +1182,8 @@ struct AReg {
     }
     // sum_{q1,q2} A[q1][q2] x[q1] x[q2] over the full symmetric matrix (block partial; reduce outside).  Branch-free: the
     // 2 NBLK vector entries are fetched up front (zero beyond n), off-diagonal blocks count twice, diagonal blocks by ty/tx.
-    __device__ __forceinline__ double quad_partial(const double* x, int n) const {
-        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    __device__ __forceinline__ double quad_partial(const double* x, int n, int tid_) const {
+        const int ty = tid_ >> 4, tx = tid_ & 15;
         double xr[NBLK], xc[NBLK];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
@@ -2756,6 +2768,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
     // evaluation then only redoes what depends on the frame's data and weights (eval_forward's `light`).
     int light = (!rigid && at_pose && fwd_set == set_id) ? 1 : 0;
     while (true) {
+        int tid = threadIdx.x; MOSHII_OPAQUE(tid);
         if (skip_eval) { last = carried; skip_eval = false; }
         else { PROF_T(_te); last = eval_forward_fn<XT, COOP>(visrow, ly.o_pose_t, ly.o_trans_t, ly.i_ksum, nks, ly.o_vconst, light); PROF_ACC(15, _te); }
         if constexpr (COOP) { if (cx.scal[S_COOP_FAIL] != 0.0) break; }   // the group is broken: unwind (the host reports the launch as failed)
@@ -2798,7 +2811,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
         bool improved = false, do_assemble = false;
         double rho = 0.0;
         if (init) {
-            sse = last.total;
+            sse = uni64(last.total);
             do_assemble = true;
         } else {
             rho = sse - last.total;
@@ -2810,7 +2823,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 if (tid < 3) cx.trans[tid] = cx.trans_t[tid];
                 __syncthreads();
                 if (e3 > 0.0 && (sse - last.total) / sse < e3) done = true;
-                else { do_assemble = true; sse = last.total; }
+                else { do_assemble = true; sse = uni64(last.total); }
             }
         }
         PROF_ACC(23, _t1);
@@ -2826,8 +2839,9 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                 const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
                 gm = fmax(gm, fabs(gq)); pp += pq * pq; gg += gq * gq;
             }
-            gAg = A.quad_partial(cx.g, n);
+            gAg = A.quad_partial(cx.g, n, tid);
             block_max_sum3(gm, pp, gg, gAg, cx.red);
+            gm = uni64(gm); pp = uni64(pp); gg = uni64(gg); gAg = uni64(gAg);
             if (gm < 1e-15) done = true;
             PROF_ACC(24, _t2);
         }
@@ -2836,6 +2850,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             const double pnorm2 = (improved && do_assemble) ? pp : p2;   // (improved without an assembly: the e_3 stop -- done already)
             if (rho > 0.9) delta = fmax(delta, 2.5 * step);
             else if (rho < 0.05) delta *= 0.25;
+            delta = uni64(delta);
             if (delta <= 1e-15 * sqrt(pnorm2)) done = true;
         }
         if (init || improved) {
@@ -2844,7 +2859,7 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             // start_iteration: d_sd = |g|^2 / |J g|^2 g, with |J g|^2 = g^T A g
             ++iteration;
             const double csd = gg / gAg;
-            norm_sd = fabs(csd) * sqrt(gg);
+            norm_sd = uni64(fabs(csd) * sqrt(gg));
             for (int q = tid; q < n; q += MOSHII_TPB) cx.dsd[q] = csd * cx.g[q];
             have_gn = false;
             __syncthreads();
@@ -2881,7 +2896,8 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
                     sg += dg_ * dg_; dl_dd += df * df; dl_gs += dg_ * dsq; dl_ds += df * dsq;
                 }
                 block_sum4(sg, dl_dd, dl_gs, dl_ds, cx.red);
-                norm_gn = sqrt(sg);
+                dl_dd = uni64(dl_dd); dl_gs = uni64(dl_gs); dl_ds = uni64(dl_ds);
+                norm_gn = uni64(sqrt(sg));
                 have_gn = true;
             }
             if (norm_gn <= delta) {
@@ -2904,9 +2920,10 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
             const double pq = (q < 3) ? cx.trans[q] : cx.pose[cx.colpid[q]];
             s2 += dq * dq; p2 += pq * pq; gd += cx.g[q] * dq;
         }
-        dAd = A.quad_partial(cx.ddl, n);
+        dAd = A.quad_partial(cx.ddl, n, tid);
         block_sum4(s2, p2, gd, dAd, cx.red);
-        step = sqrt(s2);
+        p2 = uni64(p2); gd = uni64(gd); dAd = uni64(dAd);
+        step = uni64(sqrt(s2));
         if (step <= 1e-15 * sqrt(p2)) break;   // "small step size" stop
         for (int i = tid; i < NPX; i += MOSHII_TPB) cx.pose_t[i] = cx.pose[i];
         if (tid < 3) cx.trans_t[tid] = cx.trans[tid] + cx.ddl[tid];
