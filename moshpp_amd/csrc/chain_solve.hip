@@ -1370,6 +1370,56 @@ __device__ __forceinline__ void ldl_rows_column(const LdlCtx<NBLK>& c, double* p
     }
     if constexpr (J + 1 < 16) ldl_rows_column<NBLK, P, FULL, J + 1>(c, pinp, ad, ab, bad);
 }
+// The same elimination for a panel whose 16 columns all exist, SOFTWARE-PIPELINED by hand.  Column J's work is (S) the pivot chain -- pivot
+// out of row J, reciprocal, two Newton steps, the multipliers l_J: eight instructions, each waiting for the one before -- and (U) up to 29
+// independent row updates that read l_J.  Only the FIRST update (row J + 1 of the diagonal block) feeds column J + 1's pivot; as statements
+// in column order the wave nevertheless issued all of U(J) before S(J + 1) began (the updates are asm statements, which keep their order)
+// and then sat through S(J + 1)'s latencies with nothing else to issue: ~100 + 8 (29 - 2 J) cycles a column.  Here column J + 1's chain
+// starts right behind that first update and its eight instructions are dealt between seven chunks of the remaining updates of column J
+// (sched_barrier pins the order), so a column costs the LONGER of the two instead of their sum.  Every register still receives the same
+// products in the same order: the same bits.
+template <int J, int LO, int HI, bool BELOW>
+__device__ __forceinline__ void ldl_rows_rest(double (&ad)[16], double (&ab)[16], double lj) {   // items LO .. HI - 1 of U(J) without its first
+    if constexpr (LO < HI) {
+        constexpr int NAD = 14 - J;   // rows J + 2 .. 15 of the diagonal block, then rows J + 1 .. 15 of the block below
+        if constexpr (LO < NAD) fmac_rowbcast<J + 2 + LO, false>(ad[J + 2 + LO], lj, ad[J]);
+        else if constexpr (BELOW) fmac_rowbcast<J + 1 + (LO - NAD), false>(ab[J + 1 + (LO - NAD)], lj, ab[J]);
+        ldl_rows_rest<J, LO + 1, HI, BELOW>(ad, ab, lj);
+    }
+}
+template <bool BELOW, int J>
+__device__ __forceinline__ void ldl_rows_pipe(double* pinp, double (&ad)[16], double (&ab)[16], double lj, bool& bad) {
+    if constexpr (J + 1 < 16) {
+        constexpr int NI = (14 - J) + (BELOW ? 15 - J : 0), CH = (NI + 6) / 7;
+        constexpr int c1 = (CH < NI) ? CH : NI, c2 = (2 * CH < NI) ? 2 * CH : NI, c3 = (3 * CH < NI) ? 3 * CH : NI, c4 = (4 * CH < NI) ? 4 * CH : NI,
+                      c5 = (5 * CH < NI) ? 5 * CH : NI, c6 = (6 * CH < NI) ? 6 * CH : NI;
+        fmac_rowbcast<J + 1, true>(ad[J + 1], lj, ad[J]);   // row J + 1 of the diagonal block is final: column J + 1's chain can start
+        const double pj = rowbcast_f64<J + 1>(ad[J + 1]);
+        bad = bad || !(pj > 0.0);
+        ldl_rows_rest<J, 0, c1, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        double pin = __builtin_amdgcn_rcp(pj);
+        ldl_rows_rest<J, c1, c2, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        double er = fma(-pj, pin, 1.0);
+        ldl_rows_rest<J, c2, c3, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        pin = fma(er, pin, pin);
+        ldl_rows_rest<J, c3, c4, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        er = fma(-pj, pin, 1.0);
+        ldl_rows_rest<J, c4, c5, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        pin = fma(er, pin, pin);
+        ldl_rows_rest<J, c5, c6, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        pinp[J + 1] = pin;
+        const double ljn = ad[J + 1] * pin;
+        ldl_rows_rest<J, c6, NI, BELOW>(ad, ab, lj);
+        __builtin_amdgcn_sched_barrier(0);
+        ldl_rows_pipe<BELOW, J + 1>(pinp, ad, ab, ljn, bad);
+    }
+}
 template <int NBLK, int P, bool FULL>
 __device__ __forceinline__ bool ldl_panel_eliminate_rows(const LdlCtx<NBLK>& c) {
     constexpr int c0 = 16 * P, LS = LdlCtx<NBLK>::LS, LD = NBLK * 16;
@@ -1385,6 +1435,17 @@ __device__ __forceinline__ bool ldl_panel_eliminate_rows(const LdlCtx<NBLK>& c) 
     }
     bool bad = false;
     double* const pinp = (c.lane == 0) ? c.pinv + c0 : c.Lp + c.trash;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOSHII_LDL_NO_PIPE)
+    if constexpr (FULL) {
+        const double pj = rowbcast_f64<0>(ad[0]);
+        bad = !(pj > 0.0);
+        double pin = __builtin_amdgcn_rcp(pj);
+        pin = fma(fma(-pj, pin, 1.0), pin, pin);
+        pin = fma(fma(-pj, pin, 1.0), pin, pin);
+        pinp[0] = pin;
+        ldl_rows_pipe<BELOW, 0>(pinp, ad, ab, ad[0] * pin, bad);
+    } else
+#endif
     ldl_rows_column<NBLK, P, FULL, 0>(c, pinp, ad, ab, bad);
     {   // the factor's entries: the diagonal block's rows from the first row of lanes (on and left of the diagonal, rows up to the border row) ...
         const int offd = rd * LS + c0;
