@@ -776,9 +776,8 @@ def main():
                                             'marker_rmse_m': float(np.sqrt(sq_.mean()))}
                 result['parity']['by_seed'] = by_seed
                 result['parity']['frames_outside_tolerance_vs_oracle_all_seeds'] = int(sum(v['frames_outside_tolerance_vs_oracle'] for v in by_seed.values()))
-                result['parity']['note'] = (f'first {S} frames of every timed seed; the full-length comparison of the timed mode is against the GPU sequential chain '
-                                            '(sequential_chain.timed_mode_vs_sequential_all_seeds), whose own full-length agreement with the oracle is '
-                                            'profiles/r02_full_parity.txt (seed 1000) and tests/golden/oracle_seed123.npz (seed 123, the ill-conditioned one)')
+                result['parity']['note'] = (f'the oracle run live on the first {S} frames of every timed seed (the cpu_baseline leg); the FULL-LENGTH check of both '
+                                            'modes against the committed oracle trajectories of all timed seeds is `parity_every_frame`')
             except Exception as e:
                 result['parity']['by_seed'] = {'error': repr(e)}
             result['speedup_vs_cpu_port'] = round(value / max(n_ref / tc, 1e-9), 1)
