@@ -2559,6 +2559,23 @@ __device__ __forceinline__ T uniform_load(const T* p) {
     return out;
 }
 
+// The kernel's own arguments -- layout, model, prior, options: ~1.3 KB of which a phase uses a few hundred bytes -- are read where they
+// already are, the kernel-argument segment, with SCALAR loads (the segment's address travels through the KernelCtx; a function cannot ask
+// for it: __builtin_amdgcn_kernarg_segment_ptr() is null outside the kernel with this toolchain).  From the LDS copy every dword cost a
+// ds_read lane and a v_readfirstlane: ~100 of them at the head of every call, ten calls a frame.  KArgsMirror = k_chain_solve's parameter
+// list as the struct the argument segment is laid out as.
+struct KArgsMirror { const ChainDev* chains; ModelDev md; PriorDev pr; OptsDev op; ChainLayout ly; int n_chains; };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOSHII_NO_KARGS)
+typedef const KArgsMirror __attribute__((address_space(4)))* KArgsPtr;
+__device__ __forceinline__ KArgsPtr kargs_of(const KernelCtx* kc) {
+    const unsigned long long v = kc->kargs;
+    return (KArgsPtr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+#define MOSHII_CTX_FROM_KARGS(kc) const KArgsPtr ka_ = kargs_of(kc); const ChainLayout ly = ka_->ly; const ModelDev md = ka_->md; const PriorDev pr = ka_->pr; const OptsDev op = ka_->op;
+#else
+#define MOSHII_CTX_FROM_KARGS(kc) const ChainLayout ly = uniform_load(&(kc)->ly); const ModelDev md = uniform_load(&(kc)->md); const PriorDev pr = uniform_load(&(kc)->pr); const OptsDev op = uniform_load(&(kc)->op);
+#endif
+
 // Cooperative assembly, large matrices (assemble(): the reduce-scatter + all-gather form), after the wait of exchange `seq` in which
 // every rank posted its partial products: this rank sums its tiles [rank TPR, (rank + 1) TPR) over the ranks -- in rank order, from zero:
 // the bits of the all-gather form --, posts the sums at the same offsets in exchange seq + 1 and waits for everybody's.  Slot to slot
@@ -2613,10 +2630,7 @@ __device__ __noinline__ Sse eval_forward_fn(const uint8_t* visrow, int o_pose, i
                                             int o_vbase, int light) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
-    const ChainLayout ly = uniform_load(&kc->ly);
-    const ModelDev md = uniform_load(&kc->md);
-    const PriorDev pr = uniform_load(&kc->pr);
-    const OptsDev op = uniform_load(&kc->op);
+    MOSHII_CTX_FROM_KARGS(kc)
     const AttachDev at = uniform_load(&kc->at);
     const FrameParams fp = uniform_load(reinterpret_cast<const FrameParams*>(kc->fp_raw));
     const Ctx cx = make_ctx(lds, ly);
@@ -2637,10 +2651,7 @@ template <int NBLK, bool XT, bool COOP>
 __device__ MOSHII_ASM_LINKAGE typename APass<NBLK, MOSHII_ASM_RET_VEC(NBLK)>::type assemble_fn(int o_pose, int n, int ncp, int nkf, int nfree_hand, double* qs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KernelCtx* kc = reinterpret_cast<const KernelCtx*>(lds);
-    const ChainLayout ly = uniform_load(&kc->ly);
-    const ModelDev md = uniform_load(&kc->md);
-    const PriorDev pr = uniform_load(&kc->pr);
-    const OptsDev op = uniform_load(&kc->op);
+    MOSHII_CTX_FROM_KARGS(kc)
     const AttachDev at = uniform_load(&kc->at);
     const FrameParams fp = uniform_load(reinterpret_cast<const FrameParams*>(kc->fp_raw));
     const Ctx cx = make_ctx(lds, ly);
@@ -3032,6 +3043,9 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     if (tid == 0) {   // the descriptors for the separately compiled phases (eval_forward_fn / assemble_fn)
         KernelCtx* kc = reinterpret_cast<KernelCtx*>(lds);
         kc->ly = ly; kc->md = md; kc->pr = pr; kc->op = op; kc->at = at;
+#if defined(__HIP_DEVICE_COMPILE__)
+        kc->kargs = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
         if constexpr (COOP) { kc->co = co; cx.scal[S_COOP_SEQ] = 0.0; cx.scal[S_COOP_FAIL] = 0.0; }
     }
 

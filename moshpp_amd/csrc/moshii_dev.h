@@ -204,6 +204,7 @@ struct KernelCtx {
     AttachDev at;
     double fp_raw[12];   // the running phase's per-frame parameters (chain_solve.hip: FrameParams), rewritten at every phase start
     CoopCtx co;          // cooperative variant only
+    unsigned long long kargs;   // the kernel's argument segment (device builds: the functions read ly / md / pr / op from there with scalar loads)
 };
 #define MOSHII_KC_DOUBLES ((int)((sizeof(KernelCtx) + 15) / 16 * 2))
 

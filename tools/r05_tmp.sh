@@ -1,25 +1,30 @@
 #!/bin/bash
 export PYTHONPATH=. TMPDIR=/tmp
-O=gpurun_out/r05b; mkdir -p $O
-cat > /tmp/clk.py <<'P'
-import ctypes as C, sys, time
+cat > /tmp/seqt.py <<'P'
+import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 from moshpp_amd import capi, workload
-lib = capi.load()
-buf = (C.c_longlong * 64)()
-lib.moshii_prof_read.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+F = 1500
 dev = torch.device('cuda', 0); stream = torch.cuda.current_stream().cuda_stream
-job = workload.make_job('smplh', 4000, 53, seed=1000); solver = workload.make_solver(job)
-ds = workload.DeviceSequence(job, solver, dev)
-for name, fn in (('one sequential cooperative chain (6 CUs busy)', lambda: ds.solve_sequential(stream)),
-                 ('one sequential one-workgroup chain (1 CU busy)', lambda: ds.solve_sequential(stream, coop=1)),
-                 ('chunked solve: pass 1 = 250 chains, one per CU (block 0 = the first chunk chain)', lambda: ds.solve_chunked(stream, verify_tol=1e-9, coop=1))):
-    fn(); torch.cuda.synchronize(); lib.moshii_prof_read(buf, 1)
-    fn(); torch.cuda.synchronize(); lib.moshii_prof_read(buf, 1)
-    p = np.array(list(buf), dtype=np.float64)
-    print(f'{name}: shader clock of block 0 during its kernel(s): {p[12] / (p[30] / 100e6) / 1e6:.0f} MHz', flush=True)
+for sd in (1000,):
+    job = workload.make_job('smplh', n_frames=F, n_markers=53, seed=sd)
+    solver = workload.make_solver(job)
+    ds = workload.DeviceSequence(job, solver, dev)
+    for coop in (0, 1):
+        ds.solve_sequential(stream, coop=coop); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); ds.solve_sequential(stream, coop=coop); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        r = ds.results(); print(f'{capi.last_launch_info()[0]:28s} checksum {float(np.abs(r["fullpose"]).sum()):.12f} {min(ts) / F * 1e6:7.2f} us/frame (median {sorted(ts)[2] / F * 1e6:7.2f})', flush=True)
+    ts = []
+    ds.solve_chunked(stream, verify_tol=1e-9, coop=1); torch.cuda.synchronize()
+    for _ in range(5):
+        t0 = time.perf_counter(); ds.solve_chunked(stream, verify_tol=1e-9, coop=1); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f'chunked, plain sweeps carried on: {min(ts) * 1e3:.2f} ms for {F} frames (median {sorted(ts)[2] * 1e3:.2f})', flush=True)
 P
-MOSHII_LIB=$PWD/moshpp_amd/libmoshii_prof.so python /tmp/clk.py 2>&1 | grep -v amdgpu.ids > $O/chain_clock.txt
-MOSHII_LIB=$PWD/moshpp_amd/libmoshii_prof.so python tools/prof_chain.py 400 smplh 2>&1 | grep -v amdgpu.ids > $O/prof_coop.txt
-cat $O/chain_clock.txt; head -30 $O/prof_coop.txt
+for rep in 1 2; do
+for v in head new; do
+  echo "== $v"; if [ $v = new ]; then python /tmp/seqt.py 2>&1 | grep -v amdgpu.ids; else MOSHII_LIB=$PWD/moshpp_amd/ab/libmoshii_$v.so python /tmp/seqt.py 2>&1 | grep -v amdgpu.ids; fi
+done; done
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "cooperative or free_shape or chain_kernel or sequence_solve_matches" 2>&1 | tail -3
