@@ -103,4 +103,10 @@ json.dump(out, open(f'{O}/r05_pmc.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY
 rm -rf $O/pmc_chain_* $O/pmc_lbs_*
+# ---- where the default chain mode switches; the frame's phases (profile build: python -m moshpp_amd.build --profile); the clock under load
+timeout 900 python tools/auto_threshold.py 2>&1 | grep -v amdgpu.ids > $O/auto_threshold.txt
+if [ -f moshpp_amd/libmoshii_prof.so ]; then
+  MOSHII_LIB=$PWD/moshpp_amd/libmoshii_prof.so timeout 300 python tools/prof_chain.py 400 smplh 2>&1 | grep -v amdgpu.ids > $O/phase_breakdown_cooperative.txt
+  MOSHII_COOP=1 MOSHII_LIB=$PWD/moshpp_amd/libmoshii_prof.so timeout 300 python tools/prof_chain.py 400 smplh 2>&1 | grep -v amdgpu.ids > $O/phase_breakdown_one_workgroup.txt
+fi
 ls $O
