@@ -666,7 +666,10 @@ def test_loaded_library_was_built_from_this_tree(gpu_lib):
     """The binary the GPU tests run is the one this tree's sources produce: the source hash compiled into it
     (moshii_source_hash) equals the hash of moshpp_amd/csrc + include/moshii.h as they are on disk."""
     from moshpp_amd import build, capi
-    assert capi.load().moshii_source_hash().decode() == build.source_hash()@pytest.mark.gpu
+    assert capi.load().moshii_source_hash().decode() == build.source_hash()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('which', ['body_g6', 'fingers_8_blocks_g8', 'expression_194_unknowns_g8'])
 def test_cooperative_exchanges_under_randomised_rank_skew(gpu_lib, monkeypatch, which):
     """The exchange protocol of the cooperative chains (chain_solve.hip: payload written through, drained, then the rank's flag;
