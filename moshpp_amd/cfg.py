@@ -89,7 +89,7 @@ def default_cfg():
                      marker_layout=dict(fname=None)),
         'opt_settings': dict(weights_type=None, weights=None, maxiter=100, stagei_lr=1e-3, extra_initial_rigid_adjustment=False),
         # extensions of this implementation (absent in the reference; chain_mode 'auto': chmosh.StageIISolver.choose_chain_mode)
-        'moshpp_amd': dict(chain_mode='auto', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, device=None),
+        'moshpp_amd': dict(chain_mode='auto', num_chunks=0, chunk_warmup=32, verify_tol=1e-9, device=None),
         'runtime': dict(stagei_only=False),
     })
 

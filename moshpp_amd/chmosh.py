@@ -165,7 +165,7 @@ class StageIISolver:
         long_memory = self.optimize_fingers or self.optimize_face or self.optimize_dynamics or self.n_shape > 0
         return 'sequential' if (long_memory or n_frames < self.AUTO_MIN_FRAMES) else 'chunked'
 
-    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-11, init=None, coop_group=0):
+    def solve(self, obs, vis, chain_mode='sequential', num_chunks=0, chunk_warmup=32, verify_tol=1e-9, init=None, coop_group=0):
         """obs[F,M,3], vis[F,M] -> per-frame arrays (rows of unsolved frames flagged by status != 0).
         chain_mode 'auto': choose_chain_mode(F) -- what mosh_stageii asks for by default; out['chain_mode'] says which one ran.
         chain_mode 'sequential': one chain, the reference's exact frame order (chmosh.py:584).
@@ -291,7 +291,7 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     default_mode = 'auto'
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
                        num_chunks=int(_get(ext, 'num_chunks', 0)), chunk_warmup=int(_get(ext, 'chunk_warmup', 32)),
-                       verify_tol=float(_get(ext, 'verify_tol', 1e-11)), coop_group=int(_get(ext, 'coop_group', 0)))
+                       verify_tol=float(_get(ext, 'verify_tol', 1e-9)), coop_group=int(_get(ext, 'coop_group', 0)))
     logger.debug(f"stageii chain mode: {out.get('chain_mode')}")
     for fi in np.flatnonzero(out['status'] == 1):
         logger.error(f'no available observed markers for frame {selected_frames[fi]}. skipping the frame.')
