@@ -1834,7 +1834,8 @@ __device__ __forceinline__ void big_backsub_panel(const double* sb, int CVR, int
 // block column B (elimination, update of B + 1) and on to B + 1; false: a pivot was not positive
 template <int NBLK, int B>
 __device__ __forceinline__ bool big_blocks(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* pinv, int n, int NB) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    MOSHII_OPAQUE(tid);   // (inlined into the dogleg loop: what follows from the thread index is recomputed here, not hoisted out of the loop and spilled)
     const int ty = tid >> 4, tx = tid & 15, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int CVR = NBLK * 16, WS = 17;
@@ -1886,7 +1887,8 @@ __device__ __forceinline__ bool big_blocks(const AReg<NBLK>& A, double* Lp, doub
 }
 template <int NBLK>
 __device__ bool ldl_big(const AReg<NBLK>& A, double* Lp, double* Sl, const double* g, double* d, double* pinv, int n) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    MOSHII_OPAQUE(tid);
     const int ty = tid >> 4, tx = tid & 15, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     PROF_BEGIN(); PROF_COUNT(22);
