@@ -3019,8 +3019,10 @@ __device__ Sse run_phase(const Ctx& cx, const ChainLayout& ly, const ModelDev& m
 //           the plain instantiations so that their register allocation and timings are untouched.
 // COOP = true: cooperative chains -- G workgroups per chain (ChainDev::coop; see moshii_dev.h).  Block b is rank (b / 8) % G of chain
 //           8 ((b / 8) / G) + b % 8: the ranks of a chain sit on blocks that are congruent modulo 8, i.e. (as blocks are observed to be dealt
-//           to the XCDs round-robin) on CUs that share an L2 -- a matter of speed only.  Plain chains only: the hand-off / baton / re-join
-//           fields of a chunked solve are ignored.  Rank 0 writes the per-frame rows, every rank its own simulated markers.
+//           to the XCDs round-robin) on CUs that share an L2 -- a matter of speed only.  A cooperative chain may be a repair chain of a
+//           chunked solve (moshii_sequence_solve's host rounds): rank 0 alone reads the baton / boundary / re-join words other chains
+//           write and sends its verdict to the other ranks at the top of every frame; the carry-on protocol of pass 1 (fuse_F) is the
+//           plain chains'.  Rank 0 writes the per-frame rows, every rank its own simulated markers.
 template <int NBLK, int MINW, bool XT, bool COOP = false>
 __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev* __restrict__ chains, ModelDev md, PriorDev pr,
                                                              OptsDev op, ChainLayout ly, int n_chains) {
