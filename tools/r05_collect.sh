@@ -1,12 +1,11 @@
 #!/bin/bash
-# Round-5 artefact collection on the GPU box (one gpurun call): bench line, rocprofv3 kernel stats + per-launch list of the same command,
+# Round-5 artefact collection on the GPU box (one gpurun call): rocprofv3 kernel stats + per-launch list of the same command,
 # memory-side PMC passes (separate passes per counter; no trace domains beside --kernel-trace) over a chain step and over the LBS export
 # on both bodies -> profiles/r05_pmc.json (carries the library's source hash: bench.py --pmc-file refuses numbers of another build),
 # LBS timings / stamps / per-workgroup times.  Output under gpurun_out/r05/; copy the summaries to profiles/.
 cd /root/repo; export TMPDIR=/tmp PYTHONPATH=/root/repo
 O=gpurun_out/r05; mkdir -p $O
 ( hostname; date +%T ) > $O/box_probe.txt 2>&1
-timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/stats -o bench -- python /root/repo/bench.py --no-cpu --no-stagei --no-config3 > /root/repo/$O/bench_line_under_rocprof.json 2> /root/repo/$O/rocprof_err.txt)
 cp $O/stats/bench_kernel_stats.csv $O/ 2>/dev/null
 python - <<'PY' > $O/bench_launches.txt 2>&1
@@ -103,6 +102,10 @@ json.dump(out, open(f'{O}/r05_pmc.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY
 rm -rf $O/pmc_chain_* $O/pmc_lbs_*
+# ---- the bench line LAST, with the counters just collected on this very build in place (bench.py --pmc-file defaults to profiles/r05_pmc.json
+#      and refuses a file of another source hash)
+cp $O/r05_pmc.json profiles/r05_pmc.json
+timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt
 # ---- where the default chain mode switches; the frame's phases (profile build: python -m moshpp_amd.build --profile); the clock under load
 timeout 900 python tools/auto_threshold.py 2>&1 | grep -v amdgpu.ids > $O/auto_threshold.txt
 if [ -f moshpp_amd/libmoshii_prof.so ]; then
