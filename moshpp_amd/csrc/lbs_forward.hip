@@ -395,32 +395,22 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 #define LX_KEEP(x)
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, int nelder, float* __restrict__ out, long long* __restrict__ dbgbuf, int dbg) {
+__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, long long* __restrict__ dbgbuf, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, NRM = lm.NRM;
     const unsigned tlb = (unsigned)lm.KJ * LX_JBYTES;      // bytes of one 16-frame block's transforms
     char* ring = lds_raw;                                  // [LX_RING][8 frame blocks][64 lanes][16 B]
     char* Sx = lds_raw + LX_OFF_SX;                        // [2][16 frames][LX_XP] f32
-    // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...} of the NVF = NVT / 8 full rounds,
-    // whose posedirs fragments stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side.  The NVT % 8 vertex
-    // tiles of the last, partial round are dealt tile by tile -- (vertex tile, frame tile) pair e to XCD e % 8 -- so that every XCD has
-    // the same number of tiles (SMPL-H: 108 vertex tiles; with whole vertex tiles XCDs 0-3 had 14 x 32 tiles against 13 x 32 on XCDs 4-7
-    // and finished 15 us later: profiles/r05_lbs_timings.txt).
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...}, whose posedirs fragments
+    // stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int NVF = NVT >> 3, nbase = NVF * NFT, nextra = (NVT & 7) * NFT;
-    const int ntiles = nbase + ((nextra - xcd + 7) >> 3);
-    // Who takes how many.  Every slot takes ntiles / nslots tiles (strided); the remainder goes to the first `nelder` slots only.  With two
-    // workgroups on a CU the one dispatched second (slots >= nslots / 2, as observed) loses the arbitration for the CU's issue ports and
-    // memory pipes and needs ~28 us a tile where its elder needs ~22: dealt alike (48 slots with 7 tiles, 16 with 6) the younger 7-tile
-    // workgroups ended 195-202 us after the start, 30 us behind the median (MOSHII_LBS_STOP=32) -- now the elders take the odd tiles
-    // (SMPL-H, 4000 frames: 8 / 7 tiles for them, 6 for every younger one).
-    const int tfull = ntiles / nslots, trem = ntiles - tfull * nslots;
-    const int nmine = tfull + ((slot < nelder && slot < trem) ? (trem - slot + nelder - 1) / nelder : 0);
+    const int NVX = (NVT - xcd + 7) >> 3;
+    const int ntiles = NVX * NFT;
     const float isc = lm.inv_pscale;
     const int q4 = lane >> 4, fl = lane & 15;
     // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in the output buffer instead of vertices -- tools/lbs_bench.py prints them)
-#define LX_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[it * 16 + (K)] = clock64(); }
+#define LX_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + (K)] = clock64(); }
     const long long wg_t0 = (dbg & 32) ? wall_clock64() : 0;   // (MOSHII_LBS_STOP=32: every workgroup leaves its start / end time in dbgbuf)
     // No LDS-DMA anywhere in this kernel (rounds 3/4 fetched the transforms with global_load_lds; the first form of this kernel the
     // features as well).  Measured this round: (1) the compiler books a FLAT-encoded LDS load as an access to both memories and turns
@@ -491,14 +481,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         LX_MMA_T((S) % 3, 3) LX_LD_B1((S) % 3, 7) __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 4) LX_MMA_T((S) % 3, 5) LX_MMA_T((S) % 3, 6) LX_MMA_T((S) % 3, 7) }
     unsigned off0[3] = {0, 0, 0};   // lane offsets of the tile's round 0 in a 16-frame block of transforms
-    for (int it = 0; it < nmine; ++it) {
-        const int idx = (it < tfull) ? slot + it * nslots : tfull * nslots + slot + (it - tfull) * nelder;
-        int ft, vt;
-        if (idx < nbase) { ft = idx / NVF; vt = xcd + 8 * (idx - ft * NVF); }
-        else { const int e = xcd + 8 * (idx - nbase); vt = 8 * NVF + e / NFT; ft = e - (e / NFT) * NFT; }
+    for (int idx = slot; idx < ntiles; idx += nslots) {
+        const int ft = idx / NVX, vt = xcd + 8 * (idx - ft * NVX);
         const int f0 = ft * LX_TF, v0 = vt * LX_TV, gi = vt * 4 + wv;
         LX_STAMP(0)
-        if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[it * 16 + 12] = wall_clock64();   // (100 MHz: the shader clock the stamps ran at)
+        if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + 12] = wall_clock64();   // (100 MHz: the shader clock the stamps ran at)
         const int nr = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(rs_tab, 0u, lm.tab_gnr + (unsigned)gi * 4u, 0));
         // ---- the tile's tables: the four groups' weights and joint lists into LDS (every wave is past the previous tile's last block)
         for (int i = tid; i < 64 * NRM; i += 256) {   // (4 groups x NRM rounds x 16 slots, 16 bytes each)
@@ -948,10 +935,6 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     if (const char* es = getenv("MOSHII_LBS_SLOTS")) nslots = std::max(1, std::min(nslots, atoi(es)));   // (development: fewer workgroups per XCD)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lbs_export), hipFuncAttributeMaxDynamicSharedMemorySize, LX_LDS_BYTES);
     if (e != hipSuccess) return e;
-    // (slots beyond one workgroup per CU are the CUs' second workgroups: k_lbs_export deals them no odd tiles)
-    const int per_xcd = std::max(1, (ncu > 0 ? ncu : 256) / 8);
-    int nelder = (nslots > per_xcd) ? per_xcd : nslots;
-    if (const char* ee = getenv("MOSHII_LBS_ELDER")) nelder = std::max(1, std::min(nslots, atoi(ee)));   // (development: nslots = the even deal)
-    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, nelder, verts, lm.dbgbuf, dbg);
+    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, lm.dbgbuf, dbg);
     return hipGetLastError();
 }
