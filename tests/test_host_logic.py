@@ -400,3 +400,25 @@ def test_the_default_chain_mode_is_chunked_only_for_long_body_only_solves():
     for m in ('sequential', 'chunked', 'chunked_host'):
         assert pick(body, 10, m) == m and pick(body, 4000, m) == m
     assert default_cfg().moshpp_amd.chain_mode == 'auto'
+
+
+def test_bench_takes_counter_numbers_only_from_the_build_it_runs(tmp_path):
+    """bench.py --pmc-file: the committed PMC summary (profiles/r05_pmc.json, tools/r05_collect.sh) carries the source hash of the
+    library it was collected on; a file of another build -- or none -- gives (None, why), never numbers; and the committed file is the
+    one of THIS tree's native sources (so the driver's bench line at round end prints `traffic`, not null)."""
+    import json
+    import os
+    import bench
+    from moshpp_amd import build
+    good = tmp_path / 'pmc.json'
+    good.write_text(json.dumps({'source_hash': 'abc', 'collected': 'now', 'chain': {}, 'lbs': {}}))
+    d, note = bench.load_pmc(str(good), 'abc')
+    assert d is not None and d['source_hash'] == 'abc' and 'abc' in note
+    d, note = bench.load_pmc(str(good), 'def')
+    assert d is None and 'not used' in note
+    d, note = bench.load_pmc(str(tmp_path / 'missing.json'), 'abc')
+    assert d is None and 'no PMC file' in note
+    committed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r05_pmc.json')
+    d, note = bench.load_pmc(committed, build.source_hash())
+    assert d is not None, note
+    assert d['chain']['pass1_bytes_per_solved_frame'] > 0 and d['lbs']['mesh_order']['bytes_per_call_at_4000_frames'] > 0
