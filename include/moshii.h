@@ -63,7 +63,9 @@ typedef struct moshii_attach_s* moshii_attach_t;  /* marker attachment: compact 
  *   MOSHII_COOP_GROUP(g), 2 <= g <= 8  ->  g workgroups per chain; falls back to plain chains when g x n_chains > CUs.
  * Cooperative calls synchronise the stream: a group whose ranks do not all become resident (device shared with another process) gives
  * up after ~0.1 s of waiting, the call is then repeated with plain chains (results as from MOSHII_COOP_GROUP(1)), a line goes to
- * stderr, and the library's own choice stays "plain" for the rest of the process. */
+ * stderr, and the library's own choice stays "plain" for the rest of the process.
+ * (Test aid: MOSHII_COOP_SKEW=seed in the environment holds every rank back a pseudo-random 0 .. 10 us before each of its exchanges;
+ *  results must not move by a bit -- tests/test_gpu_parity.py::test_cooperative_exchanges_under_randomised_rank_skew.) */
 #define MOSHII_COOP_GROUP(g)   (((uint32_t)(g) & 0xffu) << 8)
 
 const char* moshii_last_error(void);

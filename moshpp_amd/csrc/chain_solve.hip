@@ -3049,6 +3049,15 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         kc->ly = ly; kc->md = md; kc->pr = pr; kc->op = op; kc->at = at;
 #if defined(__HIP_DEVICE_COMPILE__)
         kc->kargs = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#if !defined(MOSHII_NO_KARGS)
+        {   // KArgsMirror must BE this kernel's parameter list: a parameter added here and not there would hand the phase functions garbage.
+            // (The parameter list as that one struct -- the same by construction -- does not compile: "Illegal instruction detected: Operand
+            //  has incorrect register class" in one of the instantiations with hipcc 7.2.)  First, last and two middle fields against the arguments:
+            const KArgsPtr kk = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            if (kk->chains != chains || kk->n_chains != n_chains || kk->ly.total_doubles != ly.total_doubles || kk->md.V != md.V || kk->op.maxiter != op.maxiter)
+                __builtin_trap();   // (the launch fails: moshii_chain_solve reports the HIP error)
+        }
+#endif
 #endif
         if constexpr (COOP) { kc->co = co; cx.scal[S_COOP_SEQ] = 0.0; cx.scal[S_COOP_FAIL] = 0.0; }
     }
