@@ -286,7 +286,8 @@ def mosh_stageii(mocap_fname: str, cfg, markers_latent: np.ndarray, latent_label
     # (tests/parity_envelope.py) the two modes have the SAME standing on every frame of every bench sequence -- both <= 1e-9 rad on the
     # well-conditioned frames, both part from the oracle on the same knife-edge stretches the oracle's own perturbed runs part on
     # (test_both_modes_lie_inside_the_oracle_envelope_on_every_frame_of_every_bench_seed; bench.py parity_every_frame).  What remains
-    # particular to it: which chain repairs which chunk depends on timing, so the last digits (<= 1e-9 rad) can differ between runs;
+    # particular to it: which chain repairs which chunk depends on timing, so the last digits can differ between runs (bounded by verify_tol;
+    # measured: <= 1.1e-13 rad over 12 runs x 6 sequences, half of them bit-identical throughout -- profiles/r05_chunked_run_to_run.txt);
     # cfg.moshpp_amd.chain_mode = 'sequential' is the run-to-run bit-reproducible choice.
     default_mode = 'auto'
     out = solver.solve(obs, vis, chain_mode=_get(ext, 'chain_mode', default_mode),
