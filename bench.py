@@ -52,6 +52,133 @@ F64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (AMD spec sheet; half the 15
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+LINE_LIMIT = 4096   # bytes: the driver keeps the tail of stdout; the round-5 line (20 KB) was cut and could not be parsed
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """The ONE stdout line: the contract's keys + the few numbers each extra leg is quoted by (<= LINE_LIMIT bytes, strict JSON).
+    Everything else -- per-seed tables, notes, workloads spelled out -- goes to bench_detail.json / stderr (`write_detail`)."""
+    out = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                       'vs_baseline', 'dtype', 'data'))
+    cfg = full.get('config', {})
+    out['config'] = dict(_pick(cfg, ('mode', 'frames_per_gpu', 'markers', 'free_vars_step1', 'free_vars_step2', 'sequences_per_gpu', 'parallelism')),
+                         workload=str(cfg.get('workload', ''))[:200])
+    out['config'] = {'workload': out['config'].pop('workload'), **out['config']}
+    if 'rccl' in full:
+        out['rccl'] = full['rccl']
+    rf = full.get('roofline')
+    if isinstance(rf, dict):
+        out['roofline'] = _pick(rf, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_is', 'step_ms_hip_events',
+                                     'algorithmic_gflop_per_step'))
+    cb = full.get('cpu_baseline')
+    if isinstance(cb, dict):
+        out['cpu_baseline'] = dict(_pick(cb, ('value', 'unit', 'cores', 'kind')), sample=str(cb.get('sample', ''))[:120])
+        if isinstance(cb.get('reference_cost'), dict):
+            out['cpu_baseline']['reference_cost'] = cb['reference_cost'].get('value')
+        if isinstance(cb.get('all_cores'), dict) and 'value' in cb['all_cores']:
+            out['cpu_baseline']['all_cores'] = _pick(cb['all_cores'], ('value', 'cores'))
+    rl = full.get('roofline_lbs')
+    if isinstance(rl, dict):
+        out['roofline_lbs'] = _pick(rl, ('kernel', 'bound', 'body', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_is', 'kernel_ms',
+                                         'algorithmic_bytes', 'error'))
+        for leg in ('mesh_order', 'shuffled_vertex_ids'):
+            if isinstance(rl.get(leg), dict):
+                out['roofline_lbs'][leg] = _pick(rl[leg], ('frac', 'kernel_ms', 'traffic'))
+    pe = full.get('parity_every_frame')
+    if isinstance(pe, dict):
+        out['parity'] = _pick(pe, ('frames_checked', 'frames_outside_tolerance', 'frames_parted_on_a_knife_edge', 'frames_over_1e-4_rad',
+                                   'max_dev_on_well_conditioned_frames_rad', 'worst_frame_marker_rmse_vs_oracle_m', 'configs'))
+    pl = full.get('parity')
+    if isinstance(pl, dict):
+        out['parity_live_oracle'] = _pick(pl, ('frames', 'max_abs_pose_diff_rad', 'marker_rmse_m', 'frames_outside_tolerance_vs_oracle_all_seeds'))
+    sq = full.get('sequential_chain')
+    if isinstance(sq, dict):
+        out['sequential_chain'] = _pick(sq, ('frames_per_s', 'us_per_frame', 'kernel'))
+        if isinstance(sq.get('one_workgroup'), dict):
+            out['sequential_chain']['one_workgroup_us_per_frame'] = sq['one_workgroup'].get('us_per_frame')
+    c3 = full.get('config3')
+    if isinstance(c3, dict):
+        out['config3'] = _pick(c3, ('frames_per_s', 'frames', 'kernel', 'marker_rmse_m', 'error'))
+        if isinstance(c3.get('roofline'), dict):
+            out['config3']['frac'] = c3['roofline'].get('frac')
+    ms = full.get('many_sequences')
+    if isinstance(ms, dict):
+        out['many_sequences'] = _pick(ms, ('sequences', 'frames_per_s', 'ms'))
+        if isinstance(ms.get('roofline'), dict):
+            out['many_sequences']['frac'] = ms['roofline'].get('frac')
+    st = full.get('strong')
+    if isinstance(st, dict):
+        out['strong'] = {k: _pick(v, ('frames', 'frames_per_s', 'ms', 'error')) for k, v in st.items() if isinstance(v, dict)}
+    for k in ('one_gpu_same_job', 'speedup_vs_one_gpu_same_job', 'seed_min', 'seed_max', 'median_over_seeds', 'default_mode',
+              'speedup_vs_cpu_port', 'speedup_vs_cpu_reference_cost', 'speedup_vs_sequential_chain'):
+        if k in full:
+            out[k] = _pick(full[k], ('frames_per_s', 'ms', 'speedup')) if isinstance(full[k], dict) else full[k]
+    if isinstance(full.get('incl_host_staging'), dict):
+        out['incl_host_staging_frames_per_s'] = full['incl_host_staging'].get('frames_per_s')
+    s1 = full.get('stagei')
+    if isinstance(s1, dict):
+        out['stagei'] = _pick(s1, ('seconds', 'dogleg_iterations', 'launches', 'max_abs_betas_diff', 'error'))
+    if isinstance(full.get('seeds'), dict):
+        out['seeds_frames_per_s'] = {k: v.get('frames_per_s') for k, v in full['seeds'].items() if isinstance(v, dict)}
+    out['detail'] = full.get('detail_file', 'bench_detail.json (+ stderr)')
+    line = json.dumps(out, allow_nan=False, default=float)
+    # never over the limit: drop the optional blocks, least important first
+    for k in ('seeds_frames_per_s', 'stagei', 'strong', 'parity_live_oracle', 'sequential_chain', 'incl_host_staging_frames_per_s',
+              'many_sequences', 'config3'):
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out, allow_nan=False, default=float)
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def _finite(o):
+    """NaN / inf are not JSON: null them (a leg that produced one says so in the detail file's `non_finite` list)."""
+    bad = []
+
+    def walk(x, path):
+        if isinstance(x, dict):
+            return {k: walk(v, path + '.' + str(k)) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [walk(v, path + '[]') for v in x]
+        if isinstance(x, (float, np.floating)):
+            if not np.isfinite(x):
+                bad.append(path)
+                return None
+            return float(x)
+        if isinstance(x, np.integer):
+            return int(x)
+        if isinstance(x, np.bool_):
+            return bool(x)
+        return x
+    r = walk(o, '')
+    if bad:
+        r['non_finite'] = bad
+    return r
+
+
+def write_detail(full):
+    """The whole result: bench_detail.json beside bench.py (and under gpurun_out/ when that exists: it is what travels back from a
+    GPU box), one line on stderr.  Returns the file name written (or None)."""
+    txt = json.dumps(full)
+    print('bench detail: ' + txt, file=sys.stderr, flush=True)
+    wrote = None
+    for d in (os.path.join(ROOT, 'gpurun_out'), ROOT):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, 'bench_detail.json'), 'w') as fh:
+                    fh.write(txt + '\n')
+                wrote = wrote or os.path.relpath(os.path.join(d, 'bench_detail.json'), ROOT)
+        except OSError:
+            pass
+    return wrote
+
+
 def solver_flops(K, Nv, n1, n2, NP, npose, nobs_mean, iters, fevals):
     """Algorithmic FLOPs of the solve (SURVEY.md 8(d) / DESIGN.md 5): forward 2*3Nv*9(K-1) + 2*Nv*K*12 per residual
     evaluation; per Jacobian 3Nv*n*30 + normal equations 2*m*n^2/2 + factorisation n^3/3, m = 3*nobs + (npose+1) + NP."""
@@ -478,6 +605,8 @@ def main():
         kt = float(step_ms.sum()) * 1e-3
         ach = fl_timed / kt / 1e12
         pmc, pmc_note = load_pmc(args.pmc_file, capi.load().moshii_source_hash().decode())
+        pmc_is = (f'from {os.path.relpath(args.pmc_file, ROOT)} (rocprofv3 PMC passes on this build of the library), NOT collected in this run' if pmc
+                  else 'null: no PMC record of this build of the library')
         result['roofline'] = {
             'kernel': name, 'bound': 'valu_f64',
             'bound_note': 'neither hbm nor mfma: float64 vector pipe, instruction-count / latency-bound small dense solves with one wave per SIMD; memory side 45 KB/frame for a one-workgroup chain alone, ~476 KB/frame (mostly scratch write-back) with a chain on every CU, 1.6 MB/frame for a cooperative chain (write-through exchanges) (PMC)',
@@ -487,7 +616,7 @@ def main():
             # collected on another build of the library
             'traffic': (int(pmc['chain']['pass1_bytes_per_solved_frame'] * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0)) + (pmc['chain']['repair_bytes_per_step'] if rep else 0))
                         if pmc and 'chain' in pmc else None),
-            'traffic_source': pmc_note,
+            'traffic_is': pmc_is, 'traffic_source': pmc_note,
             # the same fraction seed by seed (round 1 quoted seed 1000 alone: 0.0058; `frac` above is over all timed steps)
             'frac_by_seed': {str(sd): round(sum(fl_seed[sd] for k in range(args.steps) if seeds[k % len(seeds)] == sd)
                                             / max(sum(float(step_ms[k]) for k in range(args.steps) if seeds[k % len(seeds)] == sd) * 1e-3, 1e-12)
@@ -679,7 +808,7 @@ def main():
                         'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives, f32 blend',
                         'achieved': round(bytes_alg / lt / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
                         'algorithmic_bytes': int(bytes_alg),
-                        'traffic': int(pm['bytes_per_call_at_4000_frames'] * Fl / 4000.0) if pm else None, 'traffic_source': pmc_note,
+                        'traffic': int(pm['bytes_per_call_at_4000_frames'] * Fl / 4000.0) if pm else None, 'traffic_is': pmc_is, 'traffic_source': pmc_note,
                         'frames': Fl, 'kernel_ms': round(lt * 1e3, 3), 'frames_per_s': round(Fl / lt, 1),
                         'max_abs_err_vs_f64_kernel_m_first_60_frames': err,
                         'limit_note': 'per SIMD the f16 contraction (79.6 GFLOP: 11.5 k matrix-pipe cycles per 128 x 128 tile) and the blend\'s ~150 vector instructions per '
@@ -819,9 +948,12 @@ def main():
                 result['stagei'] = leg
             except Exception as e:
                 result['stagei'] = {'error': repr(e)}
+        result = _finite(result)
+        result['detail_file'] = write_detail(result) or 'stderr only'
+        line = compact_line(result)
         sys.stdout.flush()
-        os.dup2(_real_stdout, 1)           # the ONE line on stdout
-        print(json.dumps(result), flush=True)
+        os.dup2(_real_stdout, 1)           # the ONE line on stdout: <= 4 KB (the whole result: bench_detail.json / stderr)
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
