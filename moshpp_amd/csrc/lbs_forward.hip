@@ -193,83 +193,76 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 }
 
 // ---- per-frame preparation: joint transforms + f16 pose features ---------------------------------------
-__global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, int F, int KS, int KJ,
+// One wavefront per frame, lane = joint, four frames per workgroup.  Round 6 form -- everything of a frame lives in the wave's
+// registers: the lane's rotation vector straight from the pose row (body joints) or as hands_mean + sum_i pose_hand[i] comps[i][.]
+// with the f32 component rows fetched in ONE batch of independent loads (the model keeps an f32 copy: rounds 3-5 converted the
+// 2 160 f64 components in every workgroup and ran the product as a per-lane LDS loop -- 62 % of the kernel's 15 us went by before
+// Rodrigues started); Rodrigues; then the kinematic chain level by level with the parent's world transform fetched ACROSS LANES
+// (ds_bpermute, 12 values a level) instead of through LDS arrays with a wave barrier per level (~770 cycles a level).  LDS holds
+// only the four frames' f16 feature rows, from which 16-byte fragment pieces leave.
+__global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, const float* __restrict__ hcompf,
+                                                   const float* __restrict__ hmeanf, int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
                                                    float* __restrict__ Atr, _Float16* __restrict__ featF, long long* __restrict__ stamps) {
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
-    // one wavefront per frame, four frames per workgroup; everything a wave touches in LDS is its own.  27 KB of static LDS + the
-    // hand-component matrix (dynamic: hand_dof x nhand_full floats, 8.6 KB for SMPL-H / SMPL-X) and 81 registers: four workgroups
-    // share a CU, so the 1000 workgroups of a 4000-frame export are resident at once.  (Its first form -- 69 KB, 169 registers, two
-    // workgroups per CU -- timed the same 29 us under the profiler: the kernel is one latency chain per wave, cold loads and ~10
-    // dependent tree levels, and residency was not what bounded it.)
-    __shared__ float s_fullpose[4][3 * MOSHII_MAXK];
-    __shared__ float s_R[4][MOSHII_MAXK * 9], s_tw[4][MOSHII_MAXK * 3];      // local rotations, turned into world rotations in place
-    __shared__ float s_pose[4][3 * MOSHII_MAXK], s_hm[4][128], s_J[4][3 * MOSHII_MAXK];
-    extern __shared__ float smf[];
-    float* const s_comps = smf;
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
-    const int K = md.K, P = md.P, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const int K = md.K, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
     const int fw = blockIdx.x * 4 + wv;          // this wave's frame; the last workgroup's spare waves redo frame F - 1 and write nothing
-    const int f = min(fw, F - 1);
+    const int f = __builtin_amdgcn_readfirstlane(min(fw, F - 1));
     PREP_STAMP(0)
     for (int q = tid; q < 16 * 32; q += 64) s_feat[wv][q] = (_Float16)0.0f;
-    float* fullpose = s_fullpose[wv]; float* Rw = s_R[wv]; float* tw = s_tw[wv];
-    const float* ps = pose + (size_t)f * md.NP;
-    const int bd = md.body_dof, nhf = md.nhand_full;
-    // Everything the frame needs from memory is fetched in ONE round of independent loads at the top (with 4 000 waves starting at
-    // once a dependent round trip costs 1-2 000 cycles, and the first version made some thirty of them in a row: per-column loop
-    // bounds, then components one at a time, then tree depth / parents, then the parents' joints): the hand-component matrix
-    // (hand_dof x nhand_full <= 90 x 90, f64 -> f32, shared by the workgroup's four frames), the pose row, the hands' mean, the
-    // tree and the rest joints -- staged in LDS, from where the rest of the kernel reads.
-    const int hd = md.hand_dof, ncomp = hd * nhf;
-    {
-        double cst[16];    // (16 x 256 entries per pass: one pass for the 24 x 90 of the default hand spaces)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const int i = threadIdx.x + 256 * u; cst[u] = (i < ncomp) ? md.comps[i] : 0.0; }
-        float pv[3], hmv[2], jv[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { const int i = tid + 64 * u; pv[u] = (i < md.NP) ? ps[i] : 0.0f; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = tid + 64 * u; hmv[u] = (i < nhf) ? (float)md.hands_mean[i] : 0.0f; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) jv[i] = (tid < K) ? Jf[tid * 3 + i] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const int i = threadIdx.x + 256 * u; if (i < ncomp) s_comps[i] = (float)cst[u]; }
-        for (int i = threadIdx.x + 4096; i < ncomp; i += 256) s_comps[i] = (float)md.comps[i];   // (larger hand spaces: the rest, plainly)
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { const int i = tid + 64 * u; if (i < md.NP) s_pose[wv][i] = pv[u]; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = tid + 64 * u; if (i < nhf) s_hm[wv][i] = hmv[u]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) if (tid < K) s_J[wv][tid * 3 + i] = jv[i];
-    }
-    const int lvl_of = (tid < K) ? md.depth[tid] : -1;
-    const int p = (tid < K && tid > 0) ? md.parents[tid] : 0;
-    __syncthreads();
-    // fullpose = [pose[:body_dof], hands_mean + pose_hand . components]  (block diagonal: the other hand's entries are exact zeros)
-    for (int d = tid; d < P; d += 64) {
-        float v;
-        if (d < bd) v = s_pose[wv][d];
-        else {
-            const int h = d - bd;
-            float a0 = s_hm[wv][h], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            int i = 0;
-            for (; i + 4 <= hd; i += 4) {
-                a0 += s_pose[wv][bd + i] * s_comps[i * nhf + h];
-                a1 += s_pose[wv][bd + i + 1] * s_comps[(i + 1) * nhf + h];
-                a2 += s_pose[wv][bd + i + 2] * s_comps[(i + 2) * nhf + h];
-                a3 += s_pose[wv][bd + i + 3] * s_comps[(i + 3) * nhf + h];
-            }
-            for (; i < hd; ++i) a0 += s_pose[wv][bd + i] * s_comps[i * nhf + h];
-            v = (a0 + a1) + (a2 + a3);
-        }
-        fullpose[d] = v;
-    }
+    // (no instruction on the device, where a wave's lanes move together; the CPU emulation runs them one after another and meets here:
+    //  the features written below must not be zeroed by a lane that comes later)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const float* ps = pose + (size_t)f * md.NP;
+    const int bd = md.body_dof, nhf = md.nhand_full, hd = md.hand_dof;
+    const int j = min(tid, K - 1);               // (lanes beyond the joints shadow joint K - 1 and write nothing)
+    const bool act = tid < K;
+    const int lvl_of = act ? md.depth[j] : -1;
+    const int p = (act && j > 0) ? md.parents[j] : 0;
+    float Jme[3], Jd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { Jme[i] = Jf[j * 3 + i]; Jd[i] = Jme[i] - Jf[p * 3 + i]; }
+    // ---- the lane's rotation vector
+    float rv[3];
+    const int c0 = 3 * j;
+    if (c0 < bd) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = ps[c0 + i];
+    } else {
+        // fullpose = hands_mean + pose_hand . components (block diagonal for two hands: this joint's columns are non-zero in rows
+        // [i0, i1) only -- md.col_lo / col_hi); the first 16 rows of the range in one batch of loads, any further ones plainly
+        const int h = c0 - bd;
+        const int i0 = min(min(md.col_lo[h], md.col_lo[h + 1]), md.col_lo[h + 2]);
+        const int i1 = max(max(md.col_hi[h], md.col_hi[h + 1]), md.col_hi[h + 2]);
+        float pv[16], cv[16][3];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = min(i0 + u, hd - 1);
+            pv[u] = ps[bd + i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cv[u][c] = hcompf[(size_t)i * nhf + h + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rv[c] = hmeanf[h + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float pu = (i0 + u < i1) ? pv[u] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rv[c] = fmaf(pu, cv[u][c], rv[c]);
+        }
+        for (int i = i0 + 16; i < i1; ++i) {
+            const float pu = ps[bd + i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rv[c] = fmaf(pu, hcompf[(size_t)i * nhf + h + c], rv[c]);
+        }
+    }
     PREP_STAMP(1)
-    if (tid < K) {
-        const float x = fullpose[3 * tid], y = fullpose[3 * tid + 1], z = fullpose[3 * tid + 2];
+    // ---- Rodrigues: the local rotation Rl, and R - I (without the cancellation) as f16 features
+    float Rl[9];
+    {
+        const float x = rv[0], y = rv[1], z = rv[2];
         const float t2 = x * x + y * y + z * z;
         float a, b;
         if (t2 < 1e-6f) { a = 1.0f - t2 / 6.0f; b = 0.5f - t2 / 24.0f; }
@@ -279,48 +272,43 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
             const float id = (e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f;
-            const float r = id + a * Km[e] + b * K2[e];
-            Rw[tid * 9 + e] = r;
-            if (tid >= 1) s_feat[wv][(tid - 1) * 9 + e] = (_Float16)(a * Km[e] + b * K2[e]);   // R - I without the cancellation
+            const float d = a * Km[e] + b * K2[e];
+            Rl[e] = id + d;
+            if (act && j >= 1) s_feat[wv][(j - 1) * 9 + e] = (_Float16)d;
         }
     }
     PREP_STAMP(2)
-    // kinematic chain inside the wavefront (in-order LDS), one tree level per step
-    if (tid == 0) for (int i = 0; i < 3; ++i) tw[i] = s_J[wv][i];      // (the root's local rotation is its world rotation)
-    float Jd[3] = {0.0f, 0.0f, 0.0f}, Jme[3] = {0.0f, 0.0f, 0.0f};
-    if (tid < K) for (int i = 0; i < 3; ++i) { Jme[i] = s_J[wv][tid * 3 + i]; Jd[i] = Jme[i] - s_J[wv][p * 3 + i]; }
-    for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lvl_of == lvl) {
-            float rl[9];       // this joint's local rotation, read before its slot takes the world rotation
+    // ---- kinematic chain: one tree level per step, the parent's world transform from the parent's lane
+    float Rw[9], tw[3];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) rl[e] = Rw[tid * 9 + e];
+    for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];                          // (the root's local rotation is its world rotation)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tw[i] = Jme[i];                         // (meaningful in the root's lane; every other lane's is set at its level)
+    for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
+        float pr[9], pt[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) pr[e] = __shfl(Rw[e], p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pt[i] = __shfl(tw[i], p);
+        if (lvl_of == lvl) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float p0 = Rw[p * 9 + i * 3 + 0], p1 = Rw[p * 9 + i * 3 + 1], p2 = Rw[p * 9 + i * 3 + 2];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) Rw[tid * 9 + i * 3 + j] = p0 * rl[j] + p1 * rl[3 + j] + p2 * rl[6 + j];
-                tw[tid * 3 + i] = p0 * Jd[0] + p1 * Jd[1] + p2 * Jd[2] + tw[p * 3 + i];
+                for (int c = 0; c < 3; ++c) Rw[i * 3 + c] = pr[i * 3 + 0] * Rl[c] + pr[i * 3 + 1] * Rl[3 + c] + pr[i * 3 + 2] * Rl[6 + c];
+                tw[i] = pr[i * 3 + 0] * Jd[0] + pr[i * 3 + 1] * Jd[1] + pr[i * 3 + 2] * Jd[2] + pt[i];
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     PREP_STAMP(3)
-    if (tid < K && fw < F) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint), stored as the
-                               // pairs the export kernel's packed FMAs take: (R00,R10) (R01,R11) (R02,R12) (t0,t1) (R20,R21) (R22,t2)
-        f32x4* o = reinterpret_cast<f32x4*>(Atr + (((size_t)(f >> 4) * KJ + tid) * 16 + (f & 15)) * 12);
+    if (act && fw < F) {   // A_j = [Rw | tw - Rw J_j + trans]  (sum_j w_j = 1 lets the root translation ride in every joint), row major:
+                           // three 16-byte pieces (R_i0, R_i1, R_i2, t_i) -- each float is one B operand of the export kernel's blend
+        f32x4* o = reinterpret_cast<f32x4*>(Atr + (((size_t)(f >> 4) * KJ + j) * 16 + (f & 15)) * 12);
         const float* tr = trans + (size_t)f * 3;
-        float R[3][3], t3[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            R[i][0] = Rw[tid * 9 + i * 3 + 0]; R[i][1] = Rw[tid * 9 + i * 3 + 1]; R[i][2] = Rw[tid * 9 + i * 3 + 2];
-            t3[i] = tw[tid * 3 + i] - (R[i][0] * Jme[0] + R[i][1] * Jme[1] + R[i][2] * Jme[2]) + tr[i];
+            const float r0 = Rw[i * 3 + 0], r1 = Rw[i * 3 + 1], r2 = Rw[i * 3 + 2];
+            o[i] = f32x4{r0, r1, r2, tw[i] - (r0 * Jme[0] + r1 * Jme[1] + r2 * Jme[2]) + tr[i]};
         }
-        o[0] = f32x4{R[0][0], R[1][0], R[0][1], R[1][1]};
-        o[1] = f32x4{R[0][2], R[1][2], t3[0], t3[1]};
-        o[2] = f32x4{R[2][0], R[2][1], R[2][2], t3[2]};
     }
     PREP_STAMP(4)
     // B fragments of v_mfma_f32_16x16x32_f16: features 8 g .. 8 g + 7 of frame f are the 16 bytes of record (f / 128, g / 4,
@@ -371,13 +359,11 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 #define LX_RING 3            // slots of the feature ring
 #define LX_CHUNK 8192        // bytes of one k-step's feature fragments: 8 frame blocks x 64 lanes x 16 B
 #define LX_JBYTES 768        // one joint's transforms for 16 frames (16 x 12 floats)
-#define LX_TSLOT (LX_JR * LX_JBYTES)                           // one round's transforms: 3 KiB = three DMA pieces
-#define LX_OFF_TR (LX_RING * LX_CHUNK)                         // [wave][LX_TSLOT]: the transforms of the round a wave is working on
-#define LX_OFF_SX (LX_OFF_TR + 4 * LX_TSLOT)                   // result exchange, two buffers of 16 rows
+#define LX_OFF_SX (LX_RING * LX_CHUNK)                         // result exchange, two buffers of 16 rows
 #define LX_SXBYTES (16 * LX_XP * 4)
-#define LX_OFF_W (LX_OFF_SX + 2 * LX_SXBYTES)                  // weights [group][round][slot 16][joint 4] f32
+#define LX_OFF_W (LX_OFF_SX + 2 * LX_SXBYTES)                  // weights [group][round][slot 16][joint 4] f32 (rounds >= 1 read them here)
 #define LX_OFF_J (LX_OFF_W + 4 * LX_NRMAX * 256)               // joint lists [group][round][4] (byte offsets j x 768)
-#define LX_LDS_BYTES (LX_OFF_J + 4 * LX_NRMAX * LX_JR * 4)     // 68 224 B: two workgroups per CU
+#define LX_LDS_BYTES (LX_OFF_J + 4 * LX_NRMAX * LX_JR * 4)     // 55 936 B: two workgroups per CU
 
 #define LBS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // (wave_barrier: no instruction on the device, where a wave's lanes move together; the CPU emulation runs lanes one after another and
@@ -405,12 +391,23 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8; XCD x owns the vertex tiles {x, x + 8, ...}, whose posedirs fragments
     // stay in that XCD's L2, and its workgroups walk (frame tile, vertex tile) side by side.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int NVX = (NVT - xcd + 7) >> 3;
-    const int ntiles = NVX * NFT;
+    // Whole vertex tiles per XCD (SMPL-H: 108 = 13 x 8 + 4, so four XCDs carry 14 x NFT tiles against 13 x NFT and end ~20 us behind).
+    // (dbg & 4: the even deal -- the partial round of vertex tiles dealt out as (vertex tile, frame tile) pairs, an eighth to every XCD
+    //  in one contiguous run.  Measured twice, rounds 5 and 6, with two different kernels: every XCD then ends together -- and LATER
+    //  (199.7 against 190.5 us per call): the XCDs that finish early leave the others a faster memory side for their last tiles.)
+    const int nvb = NVT >> 3, nvr = NVT & 7;
+    const bool olddeal = (dbg & 4) == 0;
+    const int NVX = olddeal ? (NVT - xcd + 7) >> 3 : nvb;
+    const int nreg = NVX * NFT;
+    const int upairs = olddeal ? 0 : nvr * NFT, ulo = xcd * upairs / 8, uhi = (xcd + 1) * upairs / 8;
+    const int ntiles = nreg + (uhi - ulo);
     const float isc = lm.inv_pscale;
     const int q4 = lane >> 4, fl = lane & 15;
-    // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in the output buffer instead of vertices -- tools/lbs_bench.py prints them)
-#define LX_STAMP(K) { if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + (K)] = clock64(); }
+    // (MOSHII_LBS_STOP=16: workgroup 0 leaves clock stamps of its phases in dbgbuf -- tools/lbs_bench.py prints them; the output stays complete)
+#define LX_STAMP(K) { if (stamping && tid == 0) dbgbuf[stamp_tile * 24 + (K)] = clock64(); }
+    const bool stamp_wg = (dbg & 16) && blockIdx.x == 0;
+    bool stamping = false;
+    int stamp_tile = 0;
     const long long wg_t0 = (dbg & 32) ? wall_clock64() : 0;   // (MOSHII_LBS_STOP=32: every workgroup leaves its start / end time in dbgbuf)
     // No LDS-DMA anywhere in this kernel (rounds 3/4 fetched the transforms with global_load_lds; the first form of this kernel the
     // features as well).  Measured this round: (1) the compiler books a FLAT-encoded LDS load as an access to both memories and turns
@@ -429,23 +426,17 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     // (the small per-tile tables as well -- ONE kind of vector load in the kernel -- and all of them behind one resource: the model keeps
     //  them in one allocation, lm.tab_* are the tables' byte offsets in it; a resource is four scalar registers)
     const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)lm.tables, 0, 0x7fffffff, 0x00020000);
-    const unsigned trb = LX_OFF_TR + wv * LX_TSLOT;        // this wave's transform buffer
-    // one round's transforms, 4 joints x 768 B: lane l holds bytes [1024 p + 16 l, + 16) for p = 0 .. 2, i.e. a piece of joint slot
-    // (64 p + l) / 48; off[p] = that joint's offset in the 16-frame block + the lane's offset in the joint
-    f32x4 sg[3];   // the NEXT item's transforms, loaded one item ahead
-    auto load_item = [&](unsigned block, const unsigned* off) {   // block: byte offset of the 16-frame block in Atr (wave-uniform)
+    // The blend T_v = sum_j w_vj A_j runs on v_mfma_f32_16x16x4_f32 (round 6): per 16-frame block and ROUND of four list joints,
+    // D[vertex slot 4 q4 + r][frame fl] += W[slot][joint k] . A_k[frame][entry] for each of the 12 entries of the 3 x 4 transforms --
+    // twelve matrix instructions where rounds 3-5 issued 96 packed (or 192 plain) vector FMAs per lane set.  The B operand of entry e
+    // is ONE float per lane: lane (fl, k = lane >> 4) holds entry e of list joint k for frame fl -- the lane's own 48 bytes of that
+    // joint's 16 x 48-byte run in Atr, three 16-byte loads straight from L2 into operand registers (no LDS staging, no wave sync);
+    // the A operand is the lane's weight W[slot fl][joint k] (x 1 / pscale for the rotation entries: the accumulators carry
+    // pscale x (rest + corrective)).  Accumulator layout = the k-loop's: lane = frame, register r = vertex slot 4 q4 + r.
+    f32x4 sg[3];   // the NEXT item's transforms (this lane's joint, this lane's frame), loaded one item ahead
+    auto load_item = [&](unsigned block, unsigned off) {   // block: byte offset of the 16-frame block in Atr (wave-uniform); off: lane offset
 #pragma unroll
-        for (int p = 0; p < 3; ++p) sg[p] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_atr, off[p], block, 0);
-    };
-    auto store_item = [&]() {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(lds_raw + trb + p * 1024 + lane * 16) = sg[p];
-    };
-    auto item_offsets = [&](auto jlist, unsigned* off) {   // jlist(js): byte offset of the round's joint slot js in a 16-frame block
-        unsigned lane_o = lane;
-        LX_OPAQUE(lane_o);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) { const unsigned c = 64u * p + lane_o, js = c / 48u; off[p] = (unsigned)jlist(js) + (c - js * 48u) * 16u; }
+        for (int p = 0; p < 3; ++p) sg[p] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_atr, off + 16u * p, block, 0);
     };
     const int* ljt = reinterpret_cast<const int*>(lds_raw + LX_OFF_J) + wv * NRM * LX_JR;   // this group's joint list in LDS
     half8 aS[3][3], bS[8];
@@ -480,12 +471,15 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         if ((KSTEP) + 2 < KS) LX_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
         LX_MMA_T((S) % 3, 3) LX_LD_B1((S) % 3, 7) __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 4) LX_MMA_T((S) % 3, 5) LX_MMA_T((S) % 3, 6) LX_MMA_T((S) % 3, 7) }
-    unsigned off0[3] = {0, 0, 0};   // lane offsets of the tile's round 0 in a 16-frame block of transforms
+    unsigned off0 = 0;   // this lane's offset in a 16-frame block of transforms for the tile's round 0: its list joint + its frame
     for (int idx = slot; idx < ntiles; idx += nslots) {
-        const int ft = idx / NVX, vt = xcd + 8 * (idx - ft * NVX);
+        int ft, vt;
+        if (idx < nreg) { ft = idx / NVX; vt = xcd + 8 * (idx - ft * NVX); }
+        else { const int u = ulo + idx - nreg, e = u / NFT; ft = u - e * NFT; vt = 8 * nvb + e; }
         const int f0 = ft * LX_TF, v0 = vt * LX_TV, gi = vt * 4 + wv;
+        if (stamp_wg) { stamp_tile = (idx - slot) / nslots; stamping = stamp_tile < 8; }
         LX_STAMP(0)
-        if ((dbg & 16) && blockIdx.x == 0 && tid == 0) reinterpret_cast<long long*>(out)[((idx - slot) / nslots) * 16 + 12] = wall_clock64();   // (100 MHz: the shader clock the stamps ran at)
+        if (stamping && tid == 0) dbgbuf[stamp_tile * 24 + 12] = wall_clock64();   // (100 MHz: the shader clock the stamps ran at)
         const int nr = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(rs_tab, 0u, lm.tab_gnr + (unsigned)gi * 4u, 0));
         // ---- the tile's tables: the four groups' weights and joint lists into LDS (every wave is past the previous tile's last block)
         for (int i = tid; i < 64 * NRM; i += 256) {   // (4 groups x NRM rounds x 16 slots, 16 bytes each)
@@ -527,7 +521,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         // tile waits for them -- the CU's other workgroup runs meanwhile): the lane's exchange columns, its offsets in a round-0 block
         // of transforms, the transforms of the first item
         const u32x4 xo = __builtin_amdgcn_raw_buffer_load_b128(rs_tab, q4 * 16u, lm.tab_gx + (unsigned)gi * 64u, 0);
-        item_offsets([&](unsigned js) { return __builtin_amdgcn_raw_buffer_load_b32(rs_tab, js * 4u, lm.tab_gjid + (unsigned)(gi * NRM * LX_JR) * 4u, 0); }, off0);
+        {
+            unsigned lane_o = lane;
+            LX_OPAQUE(lane_o);
+            off0 = __builtin_amdgcn_raw_buffer_load_b32(rs_tab, (lane_o >> 4) * 4u, lm.tab_gjid + (unsigned)(gi * NRM * LX_JR) * 4u, 0) + (lane_o & 15u) * 48u;
+        }
+        // round 0's weights as the A operand: W[slot fl][joint q4], and the same x 1 / pscale for the rotation entries
+        const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_tab, (unsigned)(fl * 16 + q4 * 4), lm.tab_gw + (unsigned)(gi * NRM) * 256u, 0));
+        const float w0s = w0 * isc;
         load_item((unsigned)ft * 8u * tlb, off0);
         if (dbg & 1) {   // (MOSHII_LBS_STOP=1: stop behind the k-loop)
             float sacc = 0.0f;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) sacc += acc[t][c][0] + acc[t][c][1] + acc[t][c][2] + acc[t][c][3];
-            if (sacc == 123.456f) out[0] = sacc + (float)xo[0] + sg[0].x + sg[1].y + sg[2].z;
+            if (sacc == 123.456f) out[0] = sacc + (float)xo[0] + sg[0].x + sg[1].y + sg[2].z + w0s;
             LBS_LDS_BARRIER();
             continue;
         }
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         // registers: a rolled loop had to copy a block's 12 out through a branch tree -- ~60 moves per block).
         const unsigned abase = (unsigned)ft * 8u * tlb;   // byte offset of the tile's first 16-frame block in Atr
         const int nfl = min(LX_TV, V - v0) * 3;   // valid floats of a tile row
-        const bool full = (f0 + LX_TF <= F) && (nfl == LX_TV * 3) && (dbg & 18) == 0;   // interior tile
+        const bool full = (f0 + LX_TF <= F) && (nfl == LX_TV * 3) && (dbg & 2) == 0;   // interior tile
         // row stores: a block's 16 rows x 768 B are 768 16-byte pieces, three per thread: piece k = 256 s + tid lies in row k / 48
         // (resource = the tile's first row: lane offsets stay below 2^31 whatever the size of the whole output)
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + ((size_t)f0 * V + v0) * 3), 0, 0x7fffffff, 0x00020000);
@@ -570,121 +571,93 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         // re-uses its data registers two wait states later, which is what the ISA asks for -- single floats of the stored pieces
         // arrived wrong in memory (lanes 12 .. 15 of every 16, only in the workgroup that shares its CU's address unit with an older
         // one, a few thousand floats per export): the unit reads a store's data out of the registers later than that when it is backed up.
-        auto row_write = [&](int t, bool wait) {
-            if (dbg & 18) return;
-            unsigned voff[3];
-            bool ok[3];
+        // lane offsets of the thread's three pieces in the tile's output rows (block-independent: the block is the scalar offset)
+        unsigned voff[3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const unsigned pc = rp0 + 16u * s, w = pc >= 48u ? 1u : 0u, piece = pc - 48u * w, row = rr0 + 5u * s + w;
-                voff[s] = row * rowb + piece * 16u;
-                ok[s] = full || ((f0 + 16 * t + (int)row < F) && ((int)piece * 4 + 4 <= nfl));
-            }
+        for (int s = 0; s < 3; ++s) {
+            const unsigned pc = rp0 + 16u * s, w = pc >= 48u ? 1u : 0u, piece = pc - 48u * w, row = rr0 + 5u * s + w;
+            voff[s] = row * rowb + piece * 16u;
+        }
+        const int wmode = (dbg & 2) ? 0 : full ? 1 : 2;    // (MOSHII_LBS_STOP=2: no row stores) / interior tile / edge tile
+        auto row_write = [&](int t, bool wait) {
             const unsigned soff = (unsigned)(16 * t) * rowb;
             __builtin_amdgcn_sched_barrier(0);
-            // (streaming stores -- nt: the output must not evict the posedirs fragments the k-loop re-reads from L2)
+            if (wmode == 1) {
+                // interior tile: three unconditional streaming stores (nt: the output must not evict the posedirs fragments the k-loop
+                // re-reads from L2).  (Round 5's form decided per store and per debug flag: ~15 scalar branches per block, and a taken
+                // branch costs the wave ~30 cycles: the three stores took 480 cycles to issue.)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) if (ok[s]) { if (dbg & 64) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 0); else __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 2); }
-            if (!full) {   // pieces that straddle the end of a partial vertex tile's rows: float by float
-#pragma unroll
+                for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 2);
+            } else if (wmode == 2) {
+#pragma nounroll
                 for (int s = 0; s < 3; ++s) {
                     const unsigned pc = rp0 + 16u * s, w = pc >= 48u ? 1u : 0u, piece = pc - 48u * w, row = rr0 + 5u * s + w;
-                    if (!ok[s] && f0 + 16 * t + (int)row < F) {
-                        float* o = out + ((size_t)(f0 + 16 * t + (int)row) * V + v0) * 3 + piece * 4;
-                        for (int e = 0; e < 4; ++e) if ((int)piece * 4 + e < nfl) o[e] = rv[s][e];
+                    const f32x4 val = s == 0 ? rv[0] : s == 1 ? rv[1] : rv[2];
+                    if (f0 + 16 * t + (int)row < F) {
+                        if ((int)piece * 4 + 4 <= nfl) __builtin_amdgcn_raw_buffer_store_b128((u32x4)val, rs_out, row * rowb + piece * 16u, soff, 2);
+                        else {   // a piece that straddles the end of a partial vertex tile's rows: float by float
+                            float* o = out + ((size_t)(f0 + 16 * t + (int)row) * V + v0) * 3 + piece * 4;
+                            for (int e = 0; e < 4; ++e) if ((int)piece * 4 + e < nfl) o[e] = val[e];
+                        }
                     }
                 }
             }
             if (wait) { __builtin_amdgcn_s_waitcnt(0x0F70); LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]); }   // vmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
         };
-        f32x2 T[4][6];
-        f32x4 W[4], a[2][3];
-        const char* const tb = lds_raw + trb + fl * 48;
-        auto round_reads = [&](int q) {   // the round's weights and its first joint's transforms
-#pragma unroll
-            for (int r = 0; r < 4; ++r) W[r] = *reinterpret_cast<const f32x4*>(lds_raw + LX_OFF_W + ((wv * NRM + q) * 16 + 4 * q4 + r) * 16);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(tb + 16 * i);
-        };
-        auto round = [&](auto first) {   // T_v (+)= sum over the round's four joints of w_vj A_j, for this lane's frame and four vertices
-            // the reads of joint j + 1 are in flight while joint j is accumulated (two sets of 12 registers, no more: sched_barrier keeps the
-            // compiler from hoisting all four joints' reads to the top -- 48 registers the kernel does not have)
-#pragma unroll
-            for (int j = 0; j < LX_JR; ++j) {
-                if (j + 1 < LX_JR) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) a[(j + 1) & 1][i] = *reinterpret_cast<const f32x4*>(tb + (j + 1) * LX_JBYTES + 16 * i);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 a0 = a[j & 1][0], a1 = a[j & 1][1], a2 = a[j & 1][2];
-                const f32x2 A[6] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}, {a2.x, a2.y}, {a2.z, a2.w}};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f32x2 w2 = {W[r][j], W[r][j]};
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        if (decltype(first)::value && j == 0) T[r][k] = A[k] * w2;
-                        else T[r][k] = __builtin_elementwise_fma(A[k], w2, T[r][k]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        typedef std::integral_constant<bool, true> yes_t;
-        typedef std::integral_constant<bool, false> no_t;
-        // Block t, round 0: wait for everything in flight (vmcnt(0): explicit, because the compiler would count its own wait for the loads
-        // -- vmcnt(N), N = the vector-memory instructions issued behind them -- as if everything retired in issue order, and on this
-        // device a store issued behind a load can retire ahead of it); the transforms go into the wave's buffer -- every lane of the wave
-        // has read the previous item's; the previous block's rows are read back from the exchange together with the round's first LDS
-        // reads; the next item's loads are issued, with a whole block to arrive in; then the row stores, which have the same block to retire.
+        f32x4 T[3][4];     // T[c][e][r]: entry (c, e) of the blended 3 x 4 transform of vertex slot 4 q4 + r for this lane's frame
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        // Block t: wait for everything in flight (vmcnt(0): explicit, because the compiler would count its own wait for the loads --
+        // vmcnt(N), N = the vector-memory instructions issued behind them -- as if everything retired in issue order, and on this
+        // device a store issued behind a load can retire ahead of it): this block's round-0 transforms are in sg, the previous block's
+        // row stores have read rv.  Twelve matrix instructions; the next item's loads (a whole block to arrive in); the previous
+        // block's rows out of the exchange and on their way; further rounds accumulate into T; apply; one workgroup barrier.
+#define LX_BLEND(WS, WP, CIN) { \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) { \
+            T[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32((WS), sg[c].x, (CIN) ? zero4 : T[c][0], 0, 0, 0); \
+            T[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32((WS), sg[c].y, (CIN) ? zero4 : T[c][1], 0, 0, 0); \
+            T[c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32((WS), sg[c].z, (CIN) ? zero4 : T[c][2], 0, 0, 0); \
+            T[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32((WP), sg[c].w, (CIN) ? zero4 : T[c][3], 0, 0, 0); \
+        } }
 #define LX_BLOCK(TT) { \
         constexpr int t = (TT); \
-        /* everything in flight has retired: this block's transforms are in sg, the previous block's row stores have read rv */ \
-        __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_sched_barrier(0); \
-        if (t >= 2) { LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]); } \
-        LBS_WAVE_SYNC() \
-        store_item(); \
-        LBS_WAVE_SYNC() \
-        if (t >= 1) row_read(t - 1); \
-        round_reads(0); \
+        __builtin_amdgcn_s_waitcnt(0x0F70); \
         __builtin_amdgcn_sched_barrier(0); \
-        if (nr > 1) { unsigned offq[3]; item_offsets([&](unsigned js) { return ljt[LX_JR + js]; }, offq); load_item(abase + (unsigned)t * tlb, offq); } \
+        if (t >= 2) { LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]); } \
+        LX_BLEND(w0s, w0, true) \
+        __builtin_amdgcn_sched_barrier(0); \
+        if (nr > 1) load_item(abase + (unsigned)t * tlb, (unsigned)ljt[LX_JR + q4] + (unsigned)fl * 48u); \
         else if (t < 7) load_item(abase + (unsigned)(t + 1) * tlb, off0); \
         __builtin_amdgcn_sched_barrier(0); \
-        if (t >= 1) row_write(t - 1, nr > 1); \
+        if (t == 3) LX_STAMP(16) \
+        if (t >= 1) { row_read(t - 1); if (t == 3) LX_STAMP(17) row_write(t - 1, false); } \
         __builtin_amdgcn_sched_barrier(0); \
         if (t == 3) LX_STAMP(13) \
-        round(yes_t()); \
-        if (t == 3) LX_STAMP(14) \
         for (int q = 1; q < nr; ++q) { \
-            __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_sched_barrier(0); \
-            LBS_WAVE_SYNC() \
-            store_item(); \
-            LBS_WAVE_SYNC() \
-            round_reads(q); \
+            const float wq = *reinterpret_cast<const float*>(lds_raw + LX_OFF_W + ((wv * NRM + q) * 16 + fl) * 16 + q4 * 4); \
+            const float wqs = wq * isc; \
+            __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_sched_barrier(0); \
+            if (t >= 1) { LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]); } \
+            LX_BLEND(wqs, wq, false) \
             __builtin_amdgcn_sched_barrier(0); \
-            if (q + 1 < nr) { unsigned offq[3]; item_offsets([&](unsigned js) { return ljt[(q + 1) * LX_JR + js]; }, offq); load_item(abase + (unsigned)t * tlb, offq); } \
+            if (q + 1 < nr) load_item(abase + (unsigned)t * tlb, (unsigned)ljt[(q + 1) * LX_JR + q4] + (unsigned)fl * 48u); \
             else if (t < 7) load_item(abase + (unsigned)(t + 1) * tlb, off0); \
             __builtin_amdgcn_sched_barrier(0); \
-            round(no_t()); \
         } \
-        /* ---- apply: out_v = T_v . (p_v, 1), p_v = rest + corrective out of the accumulators; into the exchange at the vertex's column */ \
-        __builtin_amdgcn_sched_barrier(0); \
+        if (t == 3) LX_STAMP(14) \
+        /* ---- apply: out_v = T_v . (p_v, 1), p_v = pscale x (rest + corrective) out of the accumulators (1 / pscale rides in the rotation \
+           entries' weights); into the exchange at the vertex's column */ \
         char* sx = Sx + (t & 1) * LX_SXBYTES + fl * (LX_XP * 4); \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
-            const float px = isc * acc[t][0][r], py = isc * acc[t][1][r], pz = isc * acc[t][2][r]; \
-            f32x2 xy = __builtin_elementwise_fma(T[r][0], f32x2{px, px}, T[r][3]); \
-            xy = __builtin_elementwise_fma(T[r][1], f32x2{py, py}, xy); \
-            xy = __builtin_elementwise_fma(T[r][2], f32x2{pz, pz}, xy); \
-            const float oz = fmaf(T[r][4].x, px, fmaf(T[r][4].y, py, fmaf(T[r][5].x, pz, T[r][5].y))); \
+            const float px = acc[t][0][r], py = acc[t][1][r], pz = acc[t][2][r]; \
             float* so = reinterpret_cast<float*>(sx + xo[r]); \
-            so[0] = xy.x; so[1] = xy.y; so[2] = oz; \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) so[c] = fmaf(T[c][0][r], px, fmaf(T[c][1][r], py, fmaf(T[c][2][r], pz, T[c][3][r]))); \
         } \
         if (t == 3) LX_STAMP(15) \
         LBS_LDS_BARRIER(); \
         LX_STAMP(3 + t) }
         LX_BLOCK(0) LX_BLOCK(1) LX_BLOCK(2) LX_BLOCK(3) LX_BLOCK(4) LX_BLOCK(5) LX_BLOCK(6) LX_BLOCK(7)
+#undef LX_BLEND
 #undef LX_BLOCK
         __builtin_amdgcn_s_waitcnt(0x0F70); LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]);
         row_read(7);
@@ -713,7 +686,7 @@ extern "C" void moshii_lbs32_free(void* l32) {
     Lbs32Model* lm = (Lbs32Model*)l32;
     free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
     free_ptr(lm->Pfrag); free_ptr(lm->perm); free_ptr(lm->tables); free_ptr(lm->dbgbuf);
-    free_ptr(lm->Atr); free_ptr(lm->featF);
+    free_ptr(lm->Atr); free_ptr(lm->featF); free_ptr(lm->hcompf); free_ptr(lm->hmeanf);
     memset(lm, 0, sizeof(*lm));
 }
 
@@ -921,11 +894,22 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
         if (e != hipSuccess) return e;
         lmp->Fcap = Fpad;
     }
+    if (!lmp->hmeanf) {   // f32 copies of the hand-pose map (stream-ordered: ahead of the first k_lbs_prep that reads them)
+        const int nh = std::max(md->nhand_full, 1), nc = std::max(md->hand_dof * md->nhand_full, 1);
+        hipError_t e = hipMalloc((void**)&lmp->hmeanf, (size_t)nh * sizeof(float));
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&lmp->hcompf, (size_t)nc * sizeof(float));
+        if (e != hipSuccess) return e;
+        if (md->hand_dof > 0) {
+            hipLaunchKernelGGL(k_cvt_vsh, dim3((nh + 255) / 256), dim3(256), 0, stream, md->nhand_full, (const double*)md->hands_mean, lmp->hmeanf);
+            hipLaunchKernelGGL(k_cvt_vsh, dim3((nc + 255) / 256), dim3(256), 0, stream, md->hand_dof * md->nhand_full, (const double*)md->comps, lmp->hcompf);
+        }
+    }
     const Lbs32Model lm = *lmp;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 127;   // (development: phase timing by truncation / clock stamps; incomplete output)
-    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), (size_t)md->hand_dof * md->nhand_full * sizeof(float), stream, *md, lm.J, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
-                       (dbg & 16) ? reinterpret_cast<long long*>(verts) + 8 * 16 : (long long*)nullptr);
+    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, lm.hcompf, lm.hmeanf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
+                       (dbg & 16) ? lm.dbgbuf + 8 * 24 : (long long*)nullptr);
     const int NVT = lm.NVT, NFT = Fpad / LX_TF;
     int ncu = 0, devid = 0;
     hipGetDevice(&devid);

@@ -215,6 +215,8 @@ struct Lbs32Model {
     float* posedirs_t;     // [9(K-1)][3][Vp64]  vertex fastest
     float* weights;        // [K][Vp64]
     float* J;              // [K][3]
+    float* hcompf;         // [hand_dof][nhand_full] f32 copy of the hand-pose components (k_lbs_prep), made at the first export
+    float* hmeanf;         // [nhand_full]
     int Vp;                // V padded to 64
     // MFMA path (lbs_forward.hip: k_lbs_prep + k_lbs_export).  Tiles of 64 vertices, each cut into four GROUPS of 16 (group_tiles)
     _Float16* Pfrag;       // [NVT*4 groups][3][KS][64 lanes][8]  posedirs * pscale, A-operand fragments of v_mfma_f32_16x16x32_f16
@@ -232,7 +234,7 @@ struct Lbs32Model {
     int KJ;                // joints padded to a multiple of 4
     int mfma_ok;
     // per-call scratch, grown to the largest frame count seen (padded to whole 128-frame tiles)
-    float* Atr;            // [Fcap/16][KJ][16][12]  joint transforms (12 floats as the pairs (R00,R10) (R01,R11) (R02,R12) (t0,t1) (R20,R21) (R22,t2))
+    float* Atr;            // [Fcap/16][KJ][16][12]  joint transforms, row major (R_i0, R_i1, R_i2, t_i), i = 0 .. 2: each float one B operand of the blend
     _Float16* featF;       // [Fcap/128][KS][8][64 lanes][8]  pose features, B-operand fragments
     int Fcap;
 };

@@ -132,6 +132,22 @@ inline hipemu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipem
     return d;
 }
 #ifdef HIPEMU_NATIVE_F16
+// v_mfma_f32_16x16x4_f32: D = A (16x4) . B (4x16) + C; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15], register r of lane l
+// holds C/D[4 (l >> 4) + r][l & 15]; the sum over k as an in-order f32 fma chain
+typedef float hipemu_f4s __attribute__((ext_vector_type(4)));
+inline hipemu_f4s __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f4s c, int, int, int) {
+    const double* all = nullptr;
+    hipemu::wave_gather2((double)a, (double)b, &all);
+    const int lane = (int)(hipemu::cur().tid.x % 64), n = lane & 15;
+    hipemu_f4s d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fma((float)all[2 * (m + 16 * k)], (float)all[2 * (n + 16 * k) + 1], acc);
+        d[r] = acc;
+    }
+    return d;
+}
 // v_mfma_f32_16x16x32_f16: D = A (16x32) . B (32x16) + C; lane l supplies A[l & 15][8 (l >> 4) + e] and B[8 (l >> 4) + e][l & 15],
 // register r of lane l holds C/D[4 (l >> 4) + r][l & 15]; products are exact in f32, the sum is taken in double and rounded once
 typedef _Float16 hipemu_h8 __attribute__((ext_vector_type(8)));

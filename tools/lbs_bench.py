@@ -12,6 +12,8 @@ M = {'smplh': 53, 'smpl': 41, 'smplx': 89, 'mano': 33}[mt]
 import os
 from moshpp_amd import synth
 order = os.environ.get('LBS_BODY', 'shuffled')
+if os.environ.get('LBS_V'):   # (experiment: another vertex count, e.g. 6912 = 108 x 64: 128-byte-aligned output rows)
+    synth.MODEL_DIMS = dict(synth.MODEL_DIMS); synth.MODEL_DIMS[mt] = (int(os.environ['LBS_V']), synth.MODEL_DIMS[mt][1])
 job = workload.make_job(mt, 8, M, seed=1000, optimize_fingers=(mt == 'mano'), dd=synth.synth_model(mt, seed=1000, vertex_order=order))
 solver = workload.make_solver(job)
 sm = job['sm']
@@ -41,9 +43,15 @@ if os.environ.get('LBS_CHECK'):
     print(f'  check vs the f64 kernel on 40 frames: max |diff| {np.abs(got - ref).max():.2e} m')
 if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
     torch.cuda.synchronize()
-    raw = verts.view(-1)[:2 * 16 * 9].cpu().numpy().view(np.int64)
-    st = raw[:128].reshape(8, 16)
-    ps = raw[128:134]
+    lib = capi.load()
+    lib.moshii_internal_l32.restype = C.c_void_p
+    lib.moshii_internal_l32.argtypes = [C.c_void_p]
+    buf_ = (C.c_longlong * 1024)()
+    lib.moshii_internal_lbs_debug_times.argtypes = [C.c_void_p, C.c_void_p]
+    lib.moshii_internal_lbs_debug_times(lib.moshii_internal_l32(solver.dev.handle), buf_)
+    raw = np.array(buf_[:], dtype=np.int64)
+    st = raw[:192].reshape(8, 24)
+    ps = raw[192:198]
     print('prep (workgroup 0, wave 0): ' + ' | '.join(f'{n} +{int(ps[k + 1] - ps[k])}' for k, n in enumerate(['hand PCA -> fullpose', 'Rodrigues + features', 'chain', 'transform rows out', 'feature pieces out'])))
     names = ['start', 'tables + first loads issued', 'k-loop done'] + [f'block {h} done' for h in range(8)] + ['rows out']
     for ti in range(7):
@@ -52,7 +60,7 @@ if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
             print(f'  (shader clock between the starts of tiles {ti} and {ti + 1}: {(st[ti + 1][0] - row[0]) / max(1, st[ti + 1][12] - row[12]) * 0.1:.2f} GHz)')
         if row[11] == 0:
             break
-        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(12)) + f' | [block 3: transforms stored, rows out, next loads issued +{int(row[13] - row[5])}, round 0 +{int(row[14] - row[13])}, further rounds + apply + exchange +{int(row[15] - row[14])}, barrier +{int(row[6] - row[15])}]' + f' | total {int(row[11] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[11])}' if ti < 6 and st[ti + 1][11] else ''))
+        print(f'tile {ti}: ' + ' | '.join(f'{names[k]} +{int(row[k] - row[k - 1]) if k else 0}' for k in range(12)) + f' | [block 3: wait + round-0 matrix instructions + next loads issued +{int(row[16] - row[5])}, previous rows read +{int(row[17] - row[16])}, stored +{int(row[13] - row[17])}, further rounds +{int(row[14] - row[13])}, apply + exchange +{int(row[15] - row[14])}, barrier +{int(row[6] - row[15])}]' + f' | total {int(row[11] - row[0])}' + (f' | gap to next {int(st[ti + 1][0] - row[11])}' if ti < 6 and st[ti + 1][11] else ''))
 if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 32:
     lib = capi.load()
     lib.moshii_internal_l32.restype = C.c_void_p
