@@ -188,3 +188,14 @@ def face_capture_host(job, m, closest, coef, motion_seed, n_frames, expr_amp=0.3
     drop[0, :] = False
     markers[drop] = 0.0
     return dict(obs=markers, vis=~drop, pose_gt=pose_gt, trans_gt=trans_gt, expr_gt=shp)
+
+
+def oracle_of_job(job):
+    """The oracle's model / prior / attachment of a workload.make_job job (bench.py's oracle_setup; the parity criterion's marker check)."""
+    sm = job['sm']
+    m = so.prepare_model(dict(v_template=sm.v_template, shapedirs=sm.shapedirs, posedirs=sm.posedirs, weights=sm.weights,
+                              J_regressor=sm.J_regressor, parents=sm.parents, body_dof=sm.body_dof, hand_dof=sm.hand_dof,
+                              hands_mean=sm.hands_mean, selected_components=sm.selected_components), job['betas'])
+    can = so.verts_forward(m, so.fullpose_from_pose(m, np.zeros(m['NP'])), np.zeros(3))
+    closest, coef = so.transformed_coeffs(can, job['markers_latent'])
+    return m, job['prior'], closest, coef

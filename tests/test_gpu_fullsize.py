@@ -135,39 +135,117 @@ def test_sequence_solve_carries_the_free_shape_block_on_the_gpu(gpu_lib, kind, m
     assert np.array_equal(outs[0]['status'], seq['status'])
 
 
+OVER_TOL_BUDGET = 8      # frames of a 4000-frame sequence and mode that may differ from the oracle by more than the north-star 1e-4 rad
+                         # (all of them parted on a knife edge the oracle's own perturbed runs open; measured: seed 123, 3-4 per mode)
+
+
+def _envelope_report(case, out, vis, oracle_model, with_iters=True, shape=False):
+    """pe.check of a device result dict over the frames it solved, simulated markers included."""
+    from tests import parity_envelope as pe
+    solved = np.flatnonzero(out['status'] <= 0) if out['status'].min() < 0 else np.flatnonzero(out['status'] == 0)
+    fid = pe.load(case)['frame_ids']
+    solved = solved[solved <= fid[-1]]
+    return pe.check(case, out['pose'][solved], out['trans'][solved], out['iters'][solved] if with_iters else None, frames=solved,
+                    shape=out['shape'][solved] if shape else None, markers_sim=out['markers_sim'][solved], vis=vis[solved], oracle_model=oracle_model)
+
+
 @pytest.mark.parametrize('seed', [1000, 123, 71, 5, 2024, 7])
 def test_both_modes_lie_inside_the_oracle_envelope_on_every_frame_of_every_bench_seed(gpu_lib, seed):
-    """All six bench sequences, all 4000 frames, BOTH modes -- the drop-in default (sequential, cooperative chain) and the timed one
-    (chunked) -- against the committed oracle trajectory of the seed and its sensitivity envelope (tests/parity_envelope.py: 1e-7 rad
-    and equal dogleg iteration counts wherever K perturbed oracle runs stay within 1e-9 rad of each other; a multiple of their spread
-    where the reference's own algorithm sits on a knife edge; marker RMSE within the north-star bound on every frame).  No frame of
-    any sequence is exempted by name; a frame outside the criterion fails the test.  The chunked scheme has timing-dependent paths
-    (which chain gets where first): three runs."""
+    """All six bench sequences, all 4000 frames, BOTH modes AS SHIPPED -- `chain_mode='sequential'` (the cooperative chain) and the
+    drop-in default (`chain_mode='auto'` = verified chunks for this workload, at the default hand-off tolerance 1e-9) -- against the
+    committed oracle trajectory of the seed and its sensitivity envelope (tests/parity_envelope.py: 1e-7 rad, equal dogleg iteration
+    counts and 1e-6 m marker RMSE per frame wherever K perturbed oracle runs stay within 3e-9 rad of each other; where the reference's
+    own algorithm sits on a knife edge a trajectory may part by max(1e-3, 30 x the stretch's spread) and has to be back within 64
+    frames; whole-sequence marker RMSE against the ORACLE's simulated markers <= 1e-3 m).  No frame of any sequence is exempted by
+    name; a frame outside the criterion fails the test.  The chunked scheme has timing-dependent paths: three runs."""
     from moshpp_amd import workload
     from tests import parity_envelope as pe
+    from tests.helpers import oracle_of_job
     job = workload.make_job('smplh', 4000, 53, seed=seed)
     solver = workload.make_solver(job)
-    seq = solver.solve(job['obs'], job['vis'])
-    solved = np.flatnonzero(seq['status'] == 0)
-    rep = pe.check(seed, seq['pose'][solved], seq['trans'][solved], seq['iters'][solved], frames=solved)
+    m, _, closest, coef = oracle_of_job(job)
+    om = (m, closest, coef)
+    assert np.array_equal(closest, solver.tc.closest) and np.abs(coef - solver.tc.coef).max() < 1e-12
+    seq = solver.solve(job['obs'], job['vis'], chain_mode='sequential')
+    rep = _envelope_report(seed, seq, job['vis'], om)
     print(f'seed {seed} sequential vs oracle: {rep}')
-    assert rep['frames'] == len(pe.load(seed)['frame_ids']) and rep['frames_outside_tolerance'] == 0, rep
-    assert rep['max_dev_on_well_conditioned_frames_rad'] < pe.TIGHT and rep['iteration_counts_equal_on_well_conditioned_frames']
-    sq = ((seq['markers_sim'] - job['obs']) ** 2).sum(-1) * job['vis']
-    fit = np.sqrt(sq.sum(1) / np.maximum(job['vis'].sum(1), 1))
+    assert rep['frames'] == len(pe.load(seed)['frame_ids']) and pe.ok(rep), rep
+    assert rep['frames_over_1e-4_rad'] <= OVER_TOL_BUDGET, rep
+    assert solver.choose_chain_mode(4000) == 'chunked'
     for _ in range(3):
-        chk = solver.solve(job['obs'], job['vis'], chain_mode='chunked', verify_tol=1e-11)
-        assert np.array_equal(chk['status'], seq['status'])
-        rc = pe.check(seed, chk['pose'][solved], chk['trans'][solved], frames=solved)
+        chk = solver.solve(job['obs'], job['vis'], chain_mode='auto')   # what mosh_stageii ships: auto -> chunked, verify_tol 1e-9
+        assert chk['chunk_report']['verify_tol'] == 1e-9 and np.array_equal(chk['status'], seq['status'])
+        rc = _envelope_report(seed, chk, job['vis'], om, with_iters=False)
         rs = pe.compare(seed, chk, seq)
-        print(f'seed {seed} chunked vs oracle: outside {rc["frames_outside_tolerance"]}, well {rc["max_dev_on_well_conditioned_frames_rad"]:.1e}, '
-              f'parted {rc["frames_parted_on_a_knife_edge"]} frames (max {rc["max_dev_on_parted_frames_rad"]:.1e} rad); vs sequential: outside {rs["frames_outside_tolerance"]}, '
-              f'well {rs["max_dev_on_well_conditioned_frames_rad"]:.1e} rad; {chk["chunk_report"]["n_repaired"]} chunks repaired')
-        assert rc['frames_outside_tolerance'] == 0 and rs['frames_outside_tolerance'] == 0, (rc, rs)
-        # the fit of the chunked result to the data is the sequential chain's on every frame (north star: 1e-3 m marker RMSE)
-        sqc = ((chk['markers_sim'] - job['obs']) ** 2).sum(-1) * job['vis']
-        fitc = np.sqrt(sqc.sum(1) / np.maximum(job['vis'].sum(1), 1))
-        assert np.abs(fitc - fit).max() < 1e-3
+        print(f'seed {seed} default (chunked) vs oracle: outside {rc["frames_outside_tolerance"]}, well {rc["max_dev_on_well_conditioned_frames_rad"]:.1e}, '
+              f'parted {rc["frames_parted_on_a_knife_edge"]} frames (max {rc["max_dev_on_parted_frames_rad"]:.1e} rad), marker rmse vs oracle {rc["marker_rmse_vs_oracle_m"]:.1e} m '
+              f'(worst frame {rc["worst_frame_marker_rmse_vs_oracle_m"]:.1e}); vs sequential: outside {rs["frames_outside_tolerance"]}; {chk["chunk_report"]["n_repaired"]} chunks repaired')
+        assert pe.ok(rc) and rs['frames_outside_tolerance'] == 0, (rc, rs)
+        assert rc['frames_over_1e-4_rad'] <= OVER_TOL_BUDGET, rc
+
+
+@pytest.mark.parametrize('case,hand_markers', [('mano_72', 34), ('mano_73', 33)])
+def test_config4_mano_every_frame_against_the_oracle(gpu_lib, case, hand_markers):
+    """BASELINE configs[3] at its stated length: all 10 000 frames of each MANO hand (hand-PCA coefficients free, no pose prior) against
+    the committed oracle trajectory + envelope (tests/golden/make_oracle_trajectories_configs.py) -- the sequential chain (iteration
+    counts too) and the chunked solve, simulated markers against the oracle's."""
+    from moshpp_amd import workload
+    from tests import parity_envelope as pe
+    from tests.helpers import oracle_of_job
+    seed = int(case.split('_')[1])
+    job = workload.make_job('mano', 10000, hand_markers, seed=seed, optimize_fingers=True)
+    solver = workload.make_solver(job)
+    m, _, closest, coef = oracle_of_job(job)
+    assert np.array_equal(closest, solver.tc.closest) and np.abs(coef - solver.tc.coef).max() < 1e-12
+    for mode in ('sequential', 'chunked'):
+        out = solver.solve(job['obs'], job['vis'], chain_mode=mode)
+        rep = _envelope_report(case, out, job['vis'], (m, closest, coef), with_iters=(mode == 'sequential'))
+        print(f'{case} {mode} vs oracle over {rep["frames"]} frames: {rep}')
+        assert rep['frames'] == 10000 and pe.ok(rep), rep
+        assert rep['frames_over_1e-4_rad'] == 0, rep
+
+
+def test_config5_first_8000_frames_against_the_oracle(gpu_lib):
+    """BASELINE configs[4]'s Stage-II leg: the 50 000-frame SMPL-H capture solved as shipped (auto -> verified chunks); its first 8000
+    frames against the committed oracle trajectory + envelope, simulated markers against the oracle's."""
+    from moshpp_amd import workload
+    from tests import parity_envelope as pe
+    from tests.helpers import oracle_of_job
+    job = workload.make_job('smplh', 50000, 53, seed=1000)
+    solver = workload.make_solver(job)
+    m, _, closest, coef = oracle_of_job(job)
+    out = solver.solve(job['obs'], job['vis'], chain_mode='auto')
+    assert out['chain_mode'] == 'chunked' and out['chunk_report']['n_chunks'] > 100
+    rep = _envelope_report('config5_1000', out, job['vis'], (m, closest, coef), with_iters=False)
+    print(f'config 5, first 8000 of 50000 frames (chunked) vs oracle: {rep}')
+    assert rep['frames'] == 8000 and pe.ok(rep), rep
+    assert rep['frames_over_1e-4_rad'] <= OVER_TOL_BUDGET, rep
+    seq = solver.solve(job['obs'][:8000], job['vis'][:8000], chain_mode='sequential')
+    rs = _envelope_report('config5_1000', seq, job['vis'][:8000], (m, closest, coef))
+    print(f'config 5, first 8000 frames (sequential chain) vs oracle: {rs}')
+    assert pe.ok(rs) and rs['frames_over_1e-4_rad'] <= OVER_TOL_BUDGET, rs
+
+
+def test_config3_capture_7000_every_frame_against_the_oracle(gpu_lib):
+    """BASELINE configs[2]: the 4000-frame capture 7000 of the config-3 subject (SMPL-X, 89 markers, fingers + jaw + 80 expression
+    coefficients free: 194 unknowns) as the library runs it (cooperative chain) and as one workgroup, EVERY frame against the committed
+    oracle trajectory + envelope -- pose variables, translation, expression coefficients, dogleg iteration counts, simulated markers.
+    (Round 4's profiles/r04_config3_full_parity.txt: the device parts from the oracle at frame ~2380 by 0.39 rad.  The oracle's own runs
+    on observations perturbed by 1e-13 m part there too -- by up to 0.68 rad: the fingers + face block loses track for a stretch in every
+    float64 execution -- which is what the envelope records and this test holds the device to.)"""
+    from moshpp_amd import capi, workload
+    from tests import parity_envelope as pe
+    from tests.golden.make_oracle_trajectories_configs import case_inputs
+    c = case_inputs('config3_7000')
+    solver = workload.make_solver(c['job'])
+    assert np.array_equal(c['closest'], solver.tc.closest) and np.abs(c['coef'] - solver.tc.coef).max() < 1e-12
+    ch = [dict(attach=solver.attach, obs=c['obs'], vis=c['vis'], first=True)]
+    for coop in (0, 1):
+        o = capi.chain_solve_host(solver.dev, solver.prior, solver.opts, ch, coop=coop)[0]
+        assert np.all(o['status'] <= 0) and (o['status'] != 0).mean() < 2e-3
+        rep = _envelope_report('config3_7000', o, c['vis'], (c['m'], c['closest'], c['coef']), shape=True)
+        print(f'config 3 capture 7000 ({capi.last_launch_info()[0]}) vs oracle over {rep["frames"]} frames: {rep}')
+        assert rep['frames'] == 4000 and pe.ok(rep), rep
 
 
 def test_config5_50000_frames_one_sequence(gpu_lib):
@@ -318,7 +396,7 @@ def test_chunked_vs_sequential_on_a_seed_with_a_long_ill_conditioned_stretch(gpu
     solved = np.flatnonzero(seq['status'] == 0)
     rep = pe.check(11, seq['pose'][solved], seq['trans'][solved], seq['iters'][solved], frames=solved)
     print(f'seed 11 sequential vs oracle: {rep}')
-    assert rep['frames_outside_tolerance'] == 0 and rep['ill_conditioned_frames'] > 100, rep
+    assert pe.ok(rep) and rep['ill_conditioned_frames'] > 100, rep
     for _ in range(2):
         chk = solver.solve(job['obs'], job['vis'], chain_mode='chunked', verify_tol=1e-11)
         rs = pe.compare(11, chk, seq)
