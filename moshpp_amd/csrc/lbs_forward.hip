@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, const float* __restrict__ hcompf,
                                                    const float* __restrict__ hmeanf, int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
-                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, long long* __restrict__ stamps) {
+                                                   float* __restrict__ Atr, _Float16* __restrict__ featF, int* __restrict__ varflag, int epoch,
+                                                   long long* __restrict__ stamps) {
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
     const int K = md.K, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
@@ -224,13 +225,28 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
     float Jme[3], Jd[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { Jme[i] = Jf[j * 3 + i]; Jd[i] = Jme[i] - Jf[p * 3 + i]; }
+    // ---- which joints MOVE in this call: varflag[j] = epoch as soon as one frame's inputs of joint j differ (bitwise) from frame 0's.
+    // A joint nobody marks has the same rotation -- the same nine pose features -- in every frame; the export kernel evaluates the
+    // k-steps behind the last moving joint for ONE frame block instead of eight (a body-only solve leaves the 30 hand joints of
+    // SMPL-H at the hand prior's mean: chmosh.py:626-647 with optimize_fingers off, the reference's default).  The hand joints share
+    // one answer: their rotation vectors depend on the hand-pose variables only.
+    const unsigned* psb = reinterpret_cast<const unsigned*>(ps);
+    const unsigned* p0b = reinterpret_cast<const unsigned*>(pose);
+    const bool hand_lane_differs = tid < hd && psb[bd + min(tid, max(hd - 1, 0))] != p0b[bd + min(tid, max(hd - 1, 0))];
+    bool hands_differ = __ballot(hand_lane_differs) != 0ull;
+    for (int base = 64; base < hd; base += 64) {   // (hand spaces of more than 64 variables: the same, 64 at a time)
+        const int i = min(base + tid, hd - 1);
+        hands_differ = hands_differ || __ballot(psb[bd + i] != p0b[bd + i]) != 0ull;
+    }
     // ---- the lane's rotation vector
     float rv[3];
     const int c0 = 3 * j;
     if (c0 < bd) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) rv[i] = ps[c0 + i];
+        if (act && (psb[c0] != p0b[c0] || psb[c0 + 1] != p0b[c0 + 1] || psb[c0 + 2] != p0b[c0 + 2])) varflag[j] = epoch;
     } else {
+        if (act && hands_differ) varflag[j] = epoch;
         // fullpose = hands_mean + pose_hand . components (block diagonal for two hands: this joint's columns are non-zero in rows
         // [i0, i1) only -- md.col_lo / col_hi); the first 16 rows of the range in one batch of loads, any further ones plainly
         const int h = c0 - bd;
@@ -381,10 +397,69 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 #define LX_KEEP(x)
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, long long* __restrict__ dbgbuf, int dbg) {
+// ---- per call: the correctives of the joints that do not move ---------------------------------------------------------------------
+// k_lbs_prep has marked the joints whose rotation differs between frames (varflag[j] == epoch).  The pose features of the others are
+// the same in every frame, so their correctives  sum_{k >= 32 kseff} posedirs[v][k] feature[k]  are one constant per vertex for the
+// whole call: one wavefront per vertex group evaluates them once -- the k-steps behind the last moving joint, on the fragments the
+// export kernel would read, against frame 0's features -- and writes  pscale x (rest + still correctives)  in the layout of the rest
+// positions (tab_vsc): the start value of the export kernel's accumulators, whose k-loop then ends at kseff.  A body-only Stage-II
+// result (the reference's default: optimize_fingers off) keeps the 30 hand joints of SMPL-H still: 9 of 15 k-steps.
+__global__ __launch_bounds__(64) void k_lbs_still(Lbs32Model lm, const int* __restrict__ varflag, int epoch, int all_move) {
+    const int lane = threadIdx.x, g = blockIdx.x, KS = lm.KS, q4 = lane >> 4, fl = lane & 15;
+    int kseff = KS;
+    if (!all_move) {
+        const bool moves = lane >= 1 && lane < lm.K && varflag[min(lane, lm.K - 1)] == epoch;
+        const unsigned long long mv = __ballot(moves);
+        const int jl = mv ? 63 - __builtin_clzll(mv) : 0;
+        kseff = min(KS, (9 * jl + 31) / 32);
+    }
+    const __amdgpu_buffer_rsrc_t rs_feat = __builtin_amdgcn_make_buffer_rsrc((void*)lm.featF, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pf = __builtin_amdgcn_make_buffer_rsrc((void*)lm.Pfrag, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)lm.tables, 0, 0x7fffffff, 0x00020000);
+    f32x4 vs[4], acc[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vs[r] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)(4 * q4 + r) * 16u, lm.tab_vshs + (unsigned)g * 256u, 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = f32x4{vs[0][c], vs[1][c], vs[2][c], vs[3][c]};
+    const unsigned ap = (unsigned)(g * 3 * KS) * 1024u;
+    for (int kc = kseff; kc < KS; kc += 4) {     // (straight-line batches of four steps; past the last step the last one again with a zero B operand)
+        half8 ca[4][3], cb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned kk = (unsigned)min(kc + u, KS - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ca[u][c] = (half8)__builtin_amdgcn_raw_buffer_load_b128(rs_pf, lane * 16u, ap + (c * (unsigned)KS + kk) * 1024u, 0);
+            const u32x4 braw = __builtin_amdgcn_raw_buffer_load_b128(rs_feat, lane * 16u, kk * LX_CHUNK, 0);   // frame tile 0, frame block 0
+            const unsigned keep = (kc + u < KS) ? 0xffffffffu : 0u;
+            cb[u] = (half8)(braw & u32x4{keep, keep, keep, keep});
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca[u][c], cb[u], acc[c], 0, 0, 0);
+    }
+    if (fl == 0) {   // column 0 = frame 0; register r = vertex slot 4 q4 + r
+        float* o = reinterpret_cast<float*>(lm.tables + lm.tab_vsc) + ((size_t)g * 16 + 4 * q4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(o + r * 4) = f32x4{acc[0][r], acc[1][r], acc[2][r], 0.0f};
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int F, int NVT, int NFT, float* __restrict__ out, const int* __restrict__ varflag, int epoch,
+                                                     long long* __restrict__ dbgbuf, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KS = lm.KS, NRM = lm.NRM;
+    // k-steps [kseff, KS) hold features of joints that do not move in this call (k_lbs_prep's varflag): the same in every frame -- their
+    // correctives are a per-vertex constant of the call, which k_lbs_still has added to the rest positions the accumulators start at
+    // (tab_vsc); the k-loop runs the first kseff steps.  (dbg & 8: treat every joint as moving.)
+    int kseff = KS;
+    if (!(dbg & 8)) {
+        const bool moves = lane >= 1 && lane < lm.K && varflag[min(lane, lm.K - 1)] == epoch;
+        const unsigned long long mv = __ballot(moves);
+        const int jl = mv ? 63 - __builtin_clzll(mv) : 0;          // the last moving joint: its features end at 9 jl
+        kseff = __builtin_amdgcn_readfirstlane(min(KS, (9 * jl + 31) / 32));
+    }
     const unsigned tlb = (unsigned)lm.KJ * LX_JBYTES;      // bytes of one 16-frame block's transforms
     char* ring = lds_raw;                                  // [LX_RING][8 frame blocks][64 lanes][16 B]
     char* Sx = lds_raw + LX_OFF_SX;                        // [2][16 frames][LX_XP] f32
@@ -440,10 +515,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     };
     const int* ljt = reinterpret_cast<const int*>(lds_raw + LX_OFF_J) + wv * NRM * LX_JR;   // this group's joint list in LDS
     half8 aS[3][3], bS[8];
-    f32x4 gS[2][2];
-#define LX_LD_A(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), KS - 1); _Pragma("unroll") for (int c = 0; c < 3; ++c) \
+    f32x4 gS[3][2];
+#define LX_LD_A(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), kseff - 1); _Pragma("unroll") for (int c = 0; c < 3; ++c) \
         aS[SET][c] = (half8)__builtin_amdgcn_raw_buffer_load_b128(rs_pf, lane * 16u, ap + (c * (unsigned)KS + kk_) * 1024u, 0); __builtin_amdgcn_sched_barrier(0); }
-#define LX_LD_G(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), KS - 1); gS[SET][0] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_feat, tid * 16u, fp + kk_ * LX_CHUNK, 0); \
+#define LX_LD_G(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), kseff - 1); gS[SET][0] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_feat, tid * 16u, fp + kk_ * LX_CHUNK, 0); \
         gS[SET][1] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_feat, tid * 16u, fp + kk_ * LX_CHUNK + 4096u, 0); }
 #define LX_ST_G(SET, SLOT) { *reinterpret_cast<f32x4*>(ring + (SLOT) * LX_CHUNK + tid * 16) = gS[SET][0]; *reinterpret_cast<f32x4*>(ring + (SLOT) * LX_CHUNK + (tid + 256) * 16) = gS[SET][1]; }
     // (four B-fragment registers: the fragments of frame blocks 0 .. 3 are read behind the barrier, block T + 4 goes into block T's
@@ -460,15 +535,18 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     // B fragments of chunk t, drop chunk t + 2 (fetched two steps ago) into the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs
     // fragments of step t + 2; the memory instructions sit BETWEEN the step's 24 MFMAs (a load does not leave the issue stage while the
     // address unit is busy with other waves' loads).
+    // Ring bookkeeping, period 3 in everything (chunk c lives in ring slot c % 3, posedirs fragments of step s in register set s % 3, a
+    // chunk fetched at step s in staging set s % 3): at step s the wave reads chunk s, drops chunk s + 2 (fetched at step s - 2: staging
+    // set (s + 1) % 3) into the slot chunk s - 1 occupied, fetches chunk s + 4 and the posedirs fragments of step s + 2.
 #define LX_STEP(S, KSTEP) { \
         LBS_LDS_BARRIER(); \
         LX_LD_B((S) % 3) __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 0) LX_LD_B1((S) % 3, 4) \
-        if ((KSTEP) + 2 < KS) { LX_ST_G((S) % 2, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
+        if ((KSTEP) + 2 < kseff) { LX_ST_G(((S) + 1) % 3, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 1) LX_LD_B1((S) % 3, 5) \
-        if ((KSTEP) + 4 < KS) { LX_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0); \
+        if ((KSTEP) + 4 < kseff) { LX_LD_G((S) % 3, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 2) LX_LD_B1((S) % 3, 6) \
-        if ((KSTEP) + 2 < KS) LX_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
+        if ((KSTEP) + 2 < kseff) LX_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
         LX_MMA_T((S) % 3, 3) LX_LD_B1((S) % 3, 7) __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 4) LX_MMA_T((S) % 3, 5) LX_MMA_T((S) % 3, 6) LX_MMA_T((S) % 3, 7) }
     unsigned off0 = 0;   // this lane's offset in a 16-frame block of transforms for the tile's round 0: its list joint + its frame
@@ -490,32 +568,29 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         // this lane's four vertices (slots 4 q4 .. 4 q4 + 3 of the group): exchange columns and scaled rest positions -- the accumulators
         // start AT the rest position (x pscale), so the k-loop delivers rest + corrective in one piece
         f32x4 acc[8][3];
+        const unsigned ap = (unsigned)(gi * 3 * KS) * 1024u;      // byte offset of the group's fragments in Pfrag
+        const unsigned fp = (unsigned)(ft * KS) * LX_CHUNK;      // byte offset of the frame tile's chunks in featF
         {
             f32x4 vs[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vs[r] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)(4 * q4 + r) * 16u, lm.tab_vshs + (unsigned)gi * 256u, 0);
+            for (int r = 0; r < 4; ++r) vs[r] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)(4 * q4 + r) * 16u, lm.tab_vsc + (unsigned)gi * 256u, 0);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[t][c] = f32x4{vs[0][c], vs[1][c], vs[2][c], vs[3][c]};
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- main loop: acc[t][c] (16 vertices x 16 frames) += Pfrag(group, c, ks) x featF(t, ks)
-        const unsigned ap = (unsigned)(gi * 3 * KS) * 1024u;      // byte offset of the group's fragments in Pfrag
-        const unsigned fp = (unsigned)(ft * KS) * LX_CHUNK;      // byte offset of the frame tile's chunks in featF
-        LX_LD_G(0, 0) LX_LD_G(1, 1) LX_LD_A(0, 0) LX_LD_A(1, 1)
-        LX_ST_G(0, 0) LX_ST_G(1, 1)
-        LX_LD_G(0, 2) LX_LD_G(1, 3)
+        // ---- main loop over the moving joints' k-steps: acc[t][c] (16 vertices x 16 frames) += Pfrag(group, c, ks) x featF(t, ks)
+        if (kseff > 0) {
+            LX_LD_G(0, 0) LX_LD_G(1, 1) LX_LD_A(0, 0) LX_LD_A(1, 1)
+            LX_ST_G(0, 0) LX_ST_G(1, 1)
+            LX_LD_G(1, 2) LX_LD_G(2, 3)
+        }
         LX_STAMP(1)
         int ks = 0;
-        for (; ks + 6 <= KS; ks += 6) {
-            LX_STEP(0, ks) LX_STEP(1, ks + 1) LX_STEP(2, ks + 2) LX_STEP(3, ks + 3) LX_STEP(4, ks + 4) LX_STEP(5, ks + 5)
-        }
-        if (ks < KS) { LX_STEP(0, ks) ++ks; }
-        if (ks < KS) { LX_STEP(1, ks) ++ks; }
-        if (ks < KS) { LX_STEP(2, ks) ++ks; }
-        if (ks < KS) { LX_STEP(3, ks) ++ks; }
-        if (ks < KS) { LX_STEP(4, ks) ++ks; }
+        for (; ks + 3 <= kseff; ks += 3) { LX_STEP(0, ks) LX_STEP(1, ks + 1) LX_STEP(2, ks + 2) }
+        if (ks < kseff) { LX_STEP(0, ks) ++ks; }
+        if (ks < kseff) { LX_STEP(1, ks) ++ks; }
         LX_STAMP(2)
         // what only the epilogue needs is fetched behind the k-loop (held across it these 19 registers were spilled; the first item of a
         // tile waits for them -- the CU's other workgroup runs meanwhile): the lane's exchange columns, its offsets in a round-0 block
@@ -686,7 +761,7 @@ extern "C" void moshii_lbs32_free(void* l32) {
     Lbs32Model* lm = (Lbs32Model*)l32;
     free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
     free_ptr(lm->Pfrag); free_ptr(lm->perm); free_ptr(lm->tables); free_ptr(lm->dbgbuf);
-    free_ptr(lm->Atr); free_ptr(lm->featF); free_ptr(lm->hcompf); free_ptr(lm->hmeanf);
+    free_ptr(lm->Atr); free_ptr(lm->featF); free_ptr(lm->hcompf); free_ptr(lm->hmeanf); free_ptr(lm->varflag);
     memset(lm, 0, sizeof(*lm));
 }
 
@@ -837,7 +912,8 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
             lm->tab_gx = lm->tab_gjid + (unsigned)al16(gjid.size() * sizeof(int));
             lm->tab_vshs = lm->tab_gx + (unsigned)al16(gx.size() * sizeof(int));
             lm->tab_gw = lm->tab_vshs + (unsigned)((size_t)NG * 16 * 4 * sizeof(float));
-            const size_t tab_bytes = lm->tab_gw + al16(gw.size() * sizeof(float));
+            lm->tab_vsc = lm->tab_gw + (unsigned)al16(gw.size() * sizeof(float));     // per call: rest + still correctives (k_lbs_still)
+            const size_t tab_bytes = lm->tab_vsc + (size_t)NG * 16 * 4 * sizeof(float);
             if (hipMalloc((void**)&lm->tables, tab_bytes) != hipSuccess) return MOSHII_ERR_HIP;
             hipMemset(lm->tables, 0, tab_bytes);
             if (hipMalloc((void**)&lm->dbgbuf, 1024 * sizeof(long long)) != hipSuccess) return MOSHII_ERR_HIP;
@@ -905,11 +981,20 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
             hipLaunchKernelGGL(k_cvt_vsh, dim3((nc + 255) / 256), dim3(256), 0, stream, md->hand_dof * md->nhand_full, (const double*)md->comps, lmp->hcompf);
         }
     }
+    if (!lmp->varflag) {   // k_lbs_prep marks the joints that move in a call with the call's number: never reset, never equal to an older call's
+        hipError_t e = hipMalloc((void**)&lmp->varflag, 64 * sizeof(int));
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(lmp->varflag, 0, 64 * sizeof(int), stream);
+        if (e != hipSuccess) return e;
+        lmp->epoch = 0;
+    }
+    lmp->epoch = lmp->epoch >= 0x7ffffff0 ? 1 : lmp->epoch + 1;
     const Lbs32Model lm = *lmp;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 127;   // (development: phase timing by truncation / clock stamps; incomplete output)
-    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, lm.hcompf, lm.hmeanf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF,
+    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, lm.hcompf, lm.hmeanf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF, lm.varflag, lm.epoch,
                        (dbg & 16) ? lm.dbgbuf + 8 * 24 : (long long*)nullptr);
+    hipLaunchKernelGGL(k_lbs_still, dim3(lm.NVT * 4), dim3(64), 0, stream, lm, lm.varflag, lm.epoch, (dbg & 8) ? 1 : 0);
     const int NVT = lm.NVT, NFT = Fpad / LX_TF;
     int ncu = 0, devid = 0;
     hipGetDevice(&devid);
@@ -919,6 +1004,6 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     if (const char* es = getenv("MOSHII_LBS_SLOTS")) nslots = std::max(1, std::min(nslots, atoi(es)));   // (development: fewer workgroups per XCD)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lbs_export), hipFuncAttributeMaxDynamicSharedMemorySize, LX_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, lm.dbgbuf, dbg);
+    hipLaunchKernelGGL(k_lbs_export, dim3(8 * nslots), dim3(256), LX_LDS_BYTES, stream, lm, md->V, F, NVT, NFT, verts, lm.varflag, lm.epoch, lm.dbgbuf, dbg);
     return hipGetLastError();
 }

@@ -217,6 +217,8 @@ struct Lbs32Model {
     float* J;              // [K][3]
     float* hcompf;         // [hand_dof][nhand_full] f32 copy of the hand-pose components (k_lbs_prep), made at the first export
     float* hmeanf;         // [nhand_full]
+    int* varflag;          // [64] varflag[j] == epoch: joint j moves in the current export call (k_lbs_prep writes, k_lbs_export reads)
+    int epoch;             // the export call's number
     int Vp;                // V padded to 64
     // MFMA path (lbs_forward.hip: k_lbs_prep + k_lbs_export).  Tiles of 64 vertices, each cut into four GROUPS of 16 (group_tiles)
     _Float16* Pfrag;       // [NVT*4 groups][3][KS][64 lanes][8]  posedirs * pscale, A-operand fragments of v_mfma_f32_16x16x32_f16
@@ -226,6 +228,7 @@ struct Lbs32Model {
     unsigned tab_gjid;     //   int   [NVT*4][NRM][4]      the group's joint list as byte offsets (j x 768) into a 16-frame block of Atr
     unsigned tab_gx;       //   int   [NVT*64]             byte offset of the vertex's column in a tile row of the result exchange (12 x local id)
     unsigned tab_vshs;     //   float [NVT*64][4]          rest positions in group order, x pscale
+    unsigned tab_vsc;      //   float [NVT*64][4]          per call: rest positions + the correctives of the joints that do not move, x pscale (k_lbs_still)
     unsigned tab_gw;       //   float [NVT*4][NRM][16][4]  weights of the group's 16 vertices on the round's four joints
     long long* dbgbuf;     // [512][2] development: start / end time of every workgroup of the last export (MOSHII_LBS_STOP=32)
     int K, NRM;            // NRM: the largest round count over all groups

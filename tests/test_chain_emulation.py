@@ -155,24 +155,34 @@ def test_underdetermined_frames_are_flagged_and_still_fit_their_data_in_emulatio
     assert np.allclose(out['errs'][2:, 0], np.asarray(ref['errs']['data'])[2:], rtol=1e-2)
 
 
-@pytest.mark.parametrize('model_type,F,order', [('mano', 20, 'shuffled'), ('smpl', 17, 'shuffled'), ('mano', 140, 'mesh')])
-def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F, order):
+@pytest.mark.parametrize('model_type,F,order,still', [('mano', 20, 'shuffled', None), ('smpl', 17, 'shuffled', None), ('mano', 140, 'mesh', None),
+                                                      ('smpl', 19, 'shuffled', 30), ('mano', 21, 'mesh', 3), ('smpl', 18, 'mesh', 0)])
+def test_lbs_export_kernel_matches_f64_in_emulation(model_type, F, order, still):
     """The f16-MFMA full-mesh export (lbs_forward.hip: k_lbs_prep + k_lbs_export, compiled unchanged by the host clang++) against the
-    f64 kernel of the same emulated library: 16x16x32 MFMA fragment layouts, the DMA-fed feature ring, the vertex groups and their
-    joint lists (several blend rounds per group on the shuffled bodies, mostly one on the mesh-ordered one), the gathered transform
-    pieces, the result exchange's un-permutation, partial vertex / frame tiles, and a workgroup's second tile (F = 140: two frame
-    tiles, the first round of the next tile fetched behind the last block)."""
+    f64 kernel of the same emulated library: 16x16x32 MFMA fragment layouts, the feature ring, the vertex groups and their
+    joint lists (several blend rounds per group on the shuffled bodies, mostly one on the mesh-ordered one), the blend on the f32
+    matrix instruction with its operands straight from the transform array, the result exchange's un-permutation, partial vertex /
+    frame tiles, and a workgroup's second tile (F = 140: two frame tiles).  `still`: the pose variables from that index on are the
+    same in every frame -- the joints behind them do not move, k_lbs_prep leaves them unmarked and the export evaluates their k-steps
+    for one frame block (still = 30 on SMPL: 3 of 7 k-steps stay; 3 on MANO: every finger still, no k-step stays; 0: a still body)."""
     from moshpp_amd import synth
     M = {'mano': 24, 'smpl': 41}[model_type]
     case = oracle_case(model_type, F=4, M=M, seed=61, dd=synth.synth_model(model_type, seed=61, vertex_order=order))
     rng = np.random.default_rng(5)
     pose = rng.normal(0, 0.35, (F, case['m']['NP']))
     trans = rng.normal(0, 1, (F, 3))
+    if still is not None:
+        pose[:, still:] = pose[0, still:]
     with emulated_libmoshii():
         dev = device_case(case)
         ref = dev['model'].lbs_forward(pose, trans)
         got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
         got2 = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+        if still is not None:      # ... and a following call in which everything moves again (the marks carry the call's number)
+            pose2 = rng.normal(0, 0.35, pose.shape)
+            ref3 = dev['model'].lbs_forward(pose2, trans)
+            got3 = dev['model'].lbs_forward(pose2, trans, dtype=np.float32)
+            assert np.abs(got3 - ref3).max() < 2e-5
     assert np.abs(got - ref).max() < 2e-5
     np.testing.assert_array_equal(got, got2)
 

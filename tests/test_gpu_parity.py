@@ -355,11 +355,11 @@ def test_sequence_solve_many_sequences_auto_chunks(gpu_lib):
 @pytest.mark.parametrize('model_type,F', [('smplh', 300), ('smplx', 150), ('mano', 200), ('smpl', 129)])
 @pytest.mark.parametrize('order', ['shuffled', 'mesh'])
 def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F, order):
-    """The MFMA export kernel (k_lbs_export: f16-operand correctives, per-group joint lists blended with packed FMAs from gathered
-    LDS-DMA transform pieces, row stores through an LDS exchange) against the reference-precision kernel and against the plain f32
-    kernel, on frame counts and vertex counts that leave partial frame tiles and partial vertex tiles, on both vertex orders of the
-    synthetic body (shuffled ids: several blend rounds per group; mesh order: mostly one); repeated calls give the same bits (the DMA
-    waits are counted), with and without the start-up stagger of a CU's second workgroup."""
+    """The MFMA export kernel (k_lbs_export: f16-operand correctives, per-group joint lists blended on v_mfma_f32_16x16x4_f32 with the
+    transforms straight from L2 as B operands, row stores through an LDS exchange) against the reference-precision kernel and against
+    the plain f32 kernel, on frame counts and vertex counts that leave partial frame tiles and partial vertex tiles, on both vertex
+    orders of the synthetic body (shuffled ids: several blend rounds per group; mesh order: mostly one); repeated calls give the same
+    bits; with every joint treated as moving (MOSHII_LBS_STOP=8) the same result to the tolerance."""
     from moshpp_amd import synth
     M = {'smplh': 53, 'smplx': 60, 'mano': 24, 'smpl': 41}[model_type]
     case = oracle_case(model_type, F=4, M=M, seed=61, dd=synth.synth_model(model_type, seed=61, vertex_order=order))
@@ -381,11 +381,6 @@ def test_lbs_f32_mfma_matches_f64_and_plain_kernel(gpu_lib, model_type, F, order
     assert np.abs(plain - ref).max() < 5e-6
     for _ in range(3):
         np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
-    os.environ['MOSHII_LBS_STAGGER'] = '0'
-    try:
-        np.testing.assert_array_equal(dev['model'].lbs_forward(pose, trans, dtype=np.float32), got)
-    finally:
-        del os.environ['MOSHII_LBS_STAGGER']
     # linearity in trans (size-independent property): shifting trans shifts every vertex by the same amount
     got2 = dev['model'].lbs_forward(pose, trans + 0.25, dtype=np.float32)
     assert np.abs((got2 - got) - 0.25).max() < 1e-5
@@ -410,6 +405,41 @@ def test_lbs_f32_mfma_matches_oracle_directly(gpu_lib, model_type, M):
         worst = max(worst, float(np.abs(got[f] - ref).max()))
     print(f'{model_type}: export kernel vs oracle over {F} frames x {m["v_shaped"].shape[0] if "v_shaped" in m else got.shape[1]} vertices: max {worst:.2e} m')
     assert worst < 2e-5
+
+
+@pytest.mark.parametrize('model_type,M,still', [('smplh', 53, 'hands'), ('smplx', 60, 'hands'), ('smpl', 41, 30), ('mano', 24, 3), ('smplh', 53, 0)])
+def test_lbs_f32_joints_that_do_not_move(gpu_lib, model_type, M, still):
+    """A Stage-II result with the reference's defaults (optimize_fingers off: chmosh.py:626-647) has the same hand pose in every
+    frame.  k_lbs_prep notices (per call, bitwise, against frame 0) which joints move; k_lbs_export evaluates the k-steps behind the last
+    moving joint for one 16-frame block instead of eight.  Here against the ORACLE's forward on every vertex of 260 frames (two full
+    tiles and a partial one), for: still hands (SMPL-H: k-steps 6..14 of 15), still hands + jaw + eyes (SMPL-X), a still upper body
+    (SMPL, pose variables 30.. fixed), still fingers (MANO: no k-step left), a body that does not move at all; then the SAME handles
+    with every joint moving again (the marks carry the call's number), and MOSHII_LBS_STOP=8 (no shortcut) on the still input."""
+    F = 260
+    case = oracle_case(model_type, F=4, M=M, seed=67)
+    dev = device_case(case)
+    m = case['m']
+    rng = np.random.default_rng(12)
+    pose = rng.normal(0, 0.35, (F, m['NP']))
+    trans = rng.normal(0, 1, (F, 3))
+    first = m['body_dof'] - (9 if model_type == 'smplx' else 0) if still == 'hands' else still
+    pose[:, first:] = pose[0, first:]
+
+    def worst(got, pose):
+        return max(float(np.abs(got[f] - so.verts_forward(m, so.fullpose_from_pose(m, pose[f]), trans[f])).max()) for f in range(F))
+    got = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+    w1 = worst(got, pose)
+    os.environ['MOSHII_LBS_STOP'] = '8'
+    try:
+        full = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+    finally:
+        del os.environ['MOSHII_LBS_STOP']
+    w2 = worst(full, pose)
+    pose2 = rng.normal(0, 0.35, pose.shape)
+    w3 = worst(dev['model'].lbs_forward(pose2, trans, dtype=np.float32), pose2)
+    print(f'{model_type} still from {first}: vs oracle {w1:.2e} m with the shortcut, {w2:.2e} m without, {w3:.2e} m on the next call (everything moves); '
+          f'shortcut vs none {np.abs(got - full).max():.2e} m')
+    assert w1 < 2e-5 and w2 < 2e-5 and w3 < 2e-5
 
 
 def test_lbs_f32_soak_random_frame_counts(gpu_lib):
