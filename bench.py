@@ -85,7 +85,7 @@ def compact_line(full):
     if isinstance(rl, dict):
         out['roofline_lbs'] = _pick(rl, ('kernel', 'bound', 'body', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_is', 'kernel_ms',
                                          'algorithmic_bytes', 'error'))
-        for leg in ('mesh_order', 'shuffled_vertex_ids'):
+        for leg in ('all_joints_moving', 'shuffled_vertex_ids', 'shuffled_vertex_ids_all_joints_moving'):
             if isinstance(rl.get(leg), dict):
                 out['roofline_lbs'][leg] = _pick(rl[leg], ('frac', 'kernel_ms', 'traffic'))
     pe = full.get('parity_every_frame')
@@ -835,45 +835,60 @@ def main():
             trans32 = ds.trans[:Fl].to(torch.float32).contiguous()
             stream = torch.cuda.current_stream().cuda_stream
 
-            def lbs_leg(slv, tag):
+            def lbs_leg(slv, tag, pose_t, what):
                 smv = slv.sm if hasattr(slv, 'sm') else sm
                 verts = torch.empty((Fl, smv.V, 3), dtype=torch.float32, device=dev)
                 for _ in range(2):
-                    slv.dev.lbs_forward_device(Fl, pose32.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
+                    slv.dev.lbs_forward_device(Fl, pose_t.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 reps = 10
                 e0.record()
                 for _ in range(reps):
-                    slv.dev.lbs_forward_device(Fl, pose32.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
+                    slv.dev.lbs_forward_device(Fl, pose_t.data_ptr(), trans32.data_ptr(), verts.data_ptr(), C.c_void_p(stream))
                 e1.record()
                 torch.cuda.synchronize()
                 lt = e0.elapsed_time(e1) * 1e-3 / reps
                 # a 60-frame spot check of the timed output against the reference-precision kernel
-                chk = slv.dev.lbs_forward(pose32[:60].cpu().numpy().astype(np.float64), trans32[:60].cpu().numpy().astype(np.float64))
+                chk = slv.dev.lbs_forward(pose_t[:60].cpu().numpy().astype(np.float64), trans32[:60].cpu().numpy().astype(np.float64))
                 err = float(np.abs(verts[:60].cpu().numpy() - chk).max())
                 Kj = smv.K
                 # algorithmic bytes as SURVEY.md section 8(d) / BASELINE.md section 4 state them: 12 V out + pose/trans in per frame, plus ONE
-                # read of the f32 model, 12 V (1 + 9 (K - 1)) + 4 V K bytes (SMPL-H: 39.5 MB; the kernel actually reads f16 posedirs -- 19 MB)
+                # read of the f32 model, 12 V (1 + 9 (K - 1)) + 4 V K bytes (SMPL-H: 39.5 MB; the kernel actually reads f16 posedirs -- 19 MB:
+                # `frac_with_f16_model_bytes` is the same time under rounds 3-4's accounting)
                 model_bytes = 12 * smv.V * (1 + 9 * (Kj - 1)) + 4 * smv.V * Kj
                 bytes_alg = Fl * (12 * smv.V + 4 * smv.NP + 12) + model_bytes
+                bytes_f16 = Fl * (12 * smv.V + 4 * smv.NP + 12) + 6 * smv.V * 9 * (Kj - 1) + 16 * smv.V
                 pm = pmc.get('lbs', {}).get(tag) if pmc else None
-                return {'kernel': 'k_lbs_export (+ k_lbs_prep)', 'bound': 'hbm', 'body': tag,
-                        'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives, f32 blend',
+                return {'kernel': 'k_lbs_export (+ k_lbs_prep, k_lbs_still)', 'bound': 'hbm', 'body': tag, 'poses': what,
+                        'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives, f32 blend on the f32 matrix instruction',
                         'achieved': round(bytes_alg / lt / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
+                        'frac_with_f16_model_bytes': round(bytes_f16 / lt / 1e9 / HBM_PEAK_GBS, 4),
                         'algorithmic_bytes': int(bytes_alg),
                         'traffic': int(pm['bytes_per_call_at_4000_frames'] * Fl / 4000.0) if pm else None, 'traffic_is': pmc_is, 'traffic_source': pmc_note,
                         'frames': Fl, 'kernel_ms': round(lt * 1e3, 3), 'frames_per_s': round(Fl / lt, 1),
-                        'max_abs_err_vs_f64_kernel_m_first_60_frames': err,
-                        'limit_note': 'per SIMD the f16 contraction (79.6 GFLOP: 11.5 k matrix-pipe cycles per 128 x 128 tile) and the blend\'s ~150 vector instructions per '
-                                      '16-frame block time-share the issue port (measured: a vector wave beside a saturating MFMA wave gets one instruction per MFMA), two waves per '
-                                      'SIMD at 256 registers: ~80 us + 22 us of k_lbs_prep at 100 % issue efficiency = 0.45 of the HBM peak is this formulation\'s ceiling (DESIGN.md section 6)'}
+                        'max_abs_err_vs_f64_kernel_m_first_60_frames': err}
 
+            # the poses: (a) the SOLVED sequence as it is -- a body-only solve (the reference's default, optimize_fingers off) leaves the hand
+            # pose at the prior's mean in every frame, which the export notices per call (k_lbs_prep's marks) and folds into the rest
+            # positions (k_lbs_still): 6 of SMPL-H's 15 k-steps remain; (b) the same sequence with every hand-pose variable moving
+            what_a = 'the solved config[1] sequence (body-only Stage-II: the hand pose is the same in every frame)'
+            what_b = 'the solved sequence with seeded N(0, 0.3) hand-pose variables in every frame (every joint moves)'
+            pose_mv = pose32.clone()
+            gen = torch.Generator(device='cpu'); gen.manual_seed(1234)
+            pose_mv[:, sm.body_dof:] = (0.3 * torch.randn((Fl, sm.NP - sm.body_dof), generator=gen)).to(dev)
             dd_mesh = synth.synth_model('smplh', seed=seeds[0], vertex_order='mesh')
             job_mesh = workload.make_job('smplh', n_frames=8, n_markers=M, seed=seeds[0], dd=dd_mesh)
             solver_mesh = workload.make_solver(job_mesh)
-            result['roofline_lbs'] = lbs_leg(solver_mesh, 'mesh_order')
-            result['roofline_lbs']['shuffled_vertex_ids'] = lbs_leg(solver, 'shuffled_ids')
+            result['roofline_lbs'] = lbs_leg(solver_mesh, 'mesh_order', pose32, what_a)
+            result['roofline_lbs']['all_joints_moving'] = lbs_leg(solver_mesh, 'mesh_order', pose_mv, what_b)
+            result['roofline_lbs']['shuffled_vertex_ids'] = lbs_leg(solver, 'shuffled_ids', pose32, what_a)
+            result['roofline_lbs']['shuffled_vertex_ids_all_joints_moving'] = lbs_leg(solver, 'shuffled_ids', pose_mv, what_b)
+            result['roofline_lbs']['limit_note'] = (
+                'round 6: the blend runs on v_mfma_f32_16x16x4_f32 (12 matrix instructions a 16-frame block and round of four joints; the packed FMAs of round 5 '
+                'could not overlap the matrix pipe at all: profiles/r06_ubench_valu.txt), still joints leave the k-loop; what remains per 64 x 128 tile and wave is '
+                '~6 k-steps x 24 + 96 f32 matrix instructions + ~80 vector / LDS / memory instructions a block, issue-bound at two waves per SIMD, plus ~25 us of '
+                'k_lbs_prep + k_lbs_still + kernel boundaries per call (DESIGN.md section 6)')
             del solver_mesh
         except Exception as e:   # the LBS leg must never take the headline number down
             result['roofline_lbs'] = {'error': repr(e)}

@@ -200,15 +200,66 @@ __global__ __launch_bounds__(256) void k_lbs_f32_v0(ModelDev md, Lbs32Model lm, 
 // Rodrigues started); Rodrigues; then the kinematic chain level by level with the parent's world transform fetched ACROSS LANES
 // (ds_bpermute, 12 values a level) instead of through LDS arrays with a wave barrier per level (~770 cycles a level).  LDS holds
 // only the four frames' f16 feature rows, from which 16-byte fragment pieces leave.
-__global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ Jf, const float* __restrict__ hcompf,
-                                                   const float* __restrict__ hmeanf, int F, int KS, int KJ,
+// per-joint constants of k_lbs_prep, packed so that a lane fetches everything it needs about its joint in ONE round of loads:
+//   jtab[j] = 16 dwords: {parent (-1: root), rows n <= 16 of the hand-component window, i0, i1 | J_j | J_j - J_parent (root: J_0) | hands_mean of the
+//             joint's three coordinates, is-hand-joint};   hcj[j][u] = {comps[i0 + u][3 columns of joint j], 0}, u < 16, zero beyond the window
+__global__ void k_pack_jtab(ModelDev md, const float* __restrict__ Jf, const float* __restrict__ hcompf, const float* __restrict__ hmeanf,
+                            float* __restrict__ jtab, float* __restrict__ hcj) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= md.K) return;
+    int* ji = reinterpret_cast<int*>(jtab + j * 16);
+    float* jf = jtab + j * 16;
+    const int p = j > 0 ? md.parents[j] : -1;
+    const int c0 = 3 * j, bd = md.body_dof, hd = md.hand_dof, nhf = md.nhand_full;
+    int i0 = 0, i1 = 0, hand = 0;
+    float hm[3] = {0.0f, 0.0f, 0.0f};
+    if (c0 >= bd && hd > 0) {
+        const int h = c0 - bd;
+        hand = 1;
+        i0 = min(min(md.col_lo[h], md.col_lo[h + 1]), md.col_lo[h + 2]);
+        i1 = max(max(md.col_hi[h], md.col_hi[h + 1]), md.col_hi[h + 2]);
+        if (i1 < i0) i1 = i0;
+        for (int c = 0; c < 3; ++c) hm[c] = hmeanf[h + c];
+        for (int u = 0; u < 16; ++u)
+            for (int c = 0; c < 4; ++c) hcj[(j * 16 + u) * 4 + c] = (c < 3 && i0 + u < i1) ? hcompf[(size_t)(i0 + u) * nhf + h + c] : 0.0f;
+    } else {
+        for (int u = 0; u < 64; ++u) hcj[j * 64 + u] = 0.0f;
+    }
+    ji[0] = p; ji[1] = min(i1 - i0, 16); ji[2] = i0; ji[3] = i1;
+    for (int i = 0; i < 3; ++i) {
+        jf[4 + i] = Jf[j * 3 + i];
+        jf[8 + i] = Jf[j * 3 + i] - (p >= 0 ? Jf[p * 3 + i] : 0.0f);
+        jf[12 + i] = hm[i];
+    }
+    jf[7] = 0.0f; jf[11] = 0.0f; ji[15] = hand;
+}
+
+// sine in the export's preparation: the hardware instruction on the device (v_sin_f32 on t / 2 pi: absolute error ~1e-6 over the rotation
+// angles a pose holds, below the f16 quantisation of the features it feeds; the library routine's exact range reduction costs ~50
+// instructions a call in a kernel that 4 000 waves run at once), the library's in the host build of the emulation
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LBS_SIN(x) __sinf(x)
+#define LX_KEEP_F(x) __asm__ __volatile__("" : : "v"(x))
+#define LX_KEEP_U(x) __asm__ __volatile__("" : : "v"(x))
+#else
+#define LBS_SIN(x) sinf(x)
+#define LX_KEEP_F(x)
+#define LX_KEEP_U(x)
+#endif
+__global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ jtab, const float* __restrict__ hcj, const float* __restrict__ hcompf,
+                                                   int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
                                                    float* __restrict__ Atr, _Float16* __restrict__ featF, int* __restrict__ varflag, int epoch,
                                                    long long* __restrict__ stamps) {
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
     const int K = md.K, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
-    const int fw = blockIdx.x * 4 + wv;          // this wave's frame; the last workgroup's spare waves redo frame F - 1 and write nothing
+    // Workgroup -> frames: the hardware deals consecutive workgroups to consecutive XCDs, whose L2s are not coherent with each other.  A
+    // 16-frame block of the outputs (768-byte runs of a joint's transforms, 1 KB feature records) is therefore given to ONE XCD -- its
+    // four workgroups are 8 ids apart -- so that the block's lines are completed in one L2 and leave it as whole lines (dealt out four
+    // frames to consecutive ids, every line was written piecewise from four L2s).
+    const int fbase = (((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7)) * 16 + (((int)blockIdx.x >> 3) & 3) * 4;
+    const int fw = fbase + wv;                   // this wave's frame; spare waves behind the last frame redo frame F - 1 and write nothing
     const int f = __builtin_amdgcn_readfirstlane(min(fw, F - 1));
     PREP_STAMP(0)
     for (int q = tid; q < 16 * 32; q += 64) s_feat[wv][q] = (_Float16)0.0f;
@@ -220,60 +271,80 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
     const int bd = md.body_dof, nhf = md.nhand_full, hd = md.hand_dof;
     const int j = min(tid, K - 1);               // (lanes beyond the joints shadow joint K - 1 and write nothing)
     const bool act = tid < K;
-    const int lvl_of = act ? md.depth[j] : -1;
-    const int p = (act && j > 0) ? md.parents[j] : 0;
-    float Jme[3], Jd[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { Jme[i] = Jf[j * 3 + i]; Jd[i] = Jme[i] - Jf[p * 3 + i]; }
-    // ---- which joints MOVE in this call: varflag[j] = epoch as soon as one frame's inputs of joint j differ (bitwise) from frame 0's.
-    // A joint nobody marks has the same rotation -- the same nine pose features -- in every frame; the export kernel evaluates the
-    // k-steps behind the last moving joint for ONE frame block instead of eight (a body-only solve leaves the 30 hand joints of
-    // SMPL-H at the hand prior's mean: chmosh.py:626-647 with optimize_fingers off, the reference's default).  The hand joints share
-    // one answer: their rotation vectors depend on the hand-pose variables only.
+    // ---- ONE round of independent loads: the joint's record, its window of the hand components, the lane's pose variables of this
+    //      frame and of frame 0 (a dependent round trip costs 1-2 000 cycles with 4 000 waves starting at once; round 5 made thirty,
+    //      this kernel's first form two)
+    const f32x4* jt = reinterpret_cast<const f32x4*>(jtab) + j * 4;
+    const f32x4 q0 = jt[0], q1 = jt[1], q2 = jt[2], q3 = jt[3];
     const unsigned* psb = reinterpret_cast<const unsigned*>(ps);
     const unsigned* p0b = reinterpret_cast<const unsigned*>(pose);
-    const bool hand_lane_differs = tid < hd && psb[bd + min(tid, max(hd - 1, 0))] != p0b[bd + min(tid, max(hd - 1, 0))];
-    bool hands_differ = __ballot(hand_lane_differs) != 0ull;
+    const int c0 = 3 * j, cb = min(c0, max(bd - 3, 0));
+    unsigned bv[3], b0[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { bv[i] = psb[cb + i]; b0[i] = p0b[cb + i]; }
+    const int hl = bd + min(tid, max(hd - 1, 0));
+    const unsigned phb = hd > 0 ? psb[hl] : 0u, ph0 = hd > 0 ? p0b[hl] : 0u;
+    // (the elements are copied to scalars first: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 in the host build)
+    const float q0x = q0.x, q0z = q0.z, q0w = q0.w, q3w = q3.w;
+    const bool hand = __builtin_bit_cast(int, q3w) != 0;
+    f32x4 cv[16];
+    if (hand) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cv[u] = reinterpret_cast<const f32x4*>(hcj)[j * 16 + u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cv[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const int p = __builtin_bit_cast(int, q0x), i0 = __builtin_bit_cast(int, q0z), i1 = __builtin_bit_cast(int, q0w);
+    const float Jme[3] = {q1.x, q1.y, q1.z}, Jd[3] = {q2.x, q2.y, q2.z};
+    // ---- which joints MOVE in this call: varflag[j] = epoch as soon as one frame's inputs of joint j differ (bitwise) from frame 0's.
+    // A joint nobody marks has the same rotation -- the same nine pose features -- in every frame: its correctives are a constant of the
+    // call (k_lbs_still; a body-only solve leaves the 30 hand joints of SMPL-H at the hand prior's mean: chmosh.py:626-647 with
+    // optimize_fingers off, the reference's default).  The hand joints share one answer: their rotation vectors depend on the
+    // hand-pose variables only.
+    if (stamps != nullptr) {   // (development: which of the first loads the wave waits for)
+        LX_KEEP_F(q0.x); PREP_STAMP(6)
+        LX_KEEP_U(bv[0]); LX_KEEP_U(phb); PREP_STAMP(7)
+        LX_KEEP_U(b0[0]); LX_KEEP_U(ph0); PREP_STAMP(8)
+        LX_KEEP_F(cv[15].x); PREP_STAMP(9)
+    }
+    bool hands_differ = __ballot(tid < hd && phb != ph0) != 0ull;
     for (int base = 64; base < hd; base += 64) {   // (hand spaces of more than 64 variables: the same, 64 at a time)
         const int i = min(base + tid, hd - 1);
         hands_differ = hands_differ || __ballot(psb[bd + i] != p0b[bd + i]) != 0ull;
     }
-    // ---- the lane's rotation vector
+    // ---- the lane's rotation vector: the pose variables themselves (body joints), or hands_mean + pose_hand . components over the
+    //      joint's window of component rows, the pose variables fetched across lanes (lane i holds hand variable i)
     float rv[3];
-    const int c0 = 3 * j;
-    if (c0 < bd) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rv[i] = ps[c0 + i];
-        if (act && (psb[c0] != p0b[c0] || psb[c0 + 1] != p0b[c0 + 1] || psb[c0 + 2] != p0b[c0 + 2])) varflag[j] = epoch;
-    } else {
-        if (act && hands_differ) varflag[j] = epoch;
-        // fullpose = hands_mean + pose_hand . components (block diagonal for two hands: this joint's columns are non-zero in rows
-        // [i0, i1) only -- md.col_lo / col_hi); the first 16 rows of the range in one batch of loads, any further ones plainly
-        const int h = c0 - bd;
-        const int i0 = min(min(md.col_lo[h], md.col_lo[h + 1]), md.col_lo[h + 2]);
-        const int i1 = max(max(md.col_hi[h], md.col_hi[h + 1]), md.col_hi[h + 2]);
-        float pv[16], cv[16][3];
+    const float phf = __builtin_bit_cast(float, phb);
+    {
+        float hv[3] = {q3.x, q3.y, q3.z};
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int i = min(i0 + u, hd - 1);
-            pv[u] = ps[bd + i];
+            const float pu = __shfl(phf, min(i0 + u, 63));       // (every lane takes part; rows past the window have zero components)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) cv[u][c] = hcompf[(size_t)i * nhf + h + c];
+            for (int c = 0; c < 3; ++c) hv[c] = fmaf(pu, cv[u][c], hv[c]);
+        }
+        if (hand) {
+            for (int i = max(i0 + 16, 0); i < i1; ++i) {          // (windows of more than 16 rows, hand spaces beyond 64 variables: the rest, plainly)
+                const float pu = ps[bd + i];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hv[c] = fmaf(pu, hcompf[(size_t)i * nhf + (c0 - bd) + c], hv[c]);
+            }
+            if (hd > 64) {      // (the shuffle above reached variables 0 .. 63 only: redo the first 16 rows from memory)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hv[c] = (c == 0 ? q3.x : c == 1 ? q3.y : q3.z);
+                for (int i = i0; i < i1; ++i) {
+                    const float pu = ps[bd + i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) hv[c] = fmaf(pu, hcompf[(size_t)i * nhf + (c0 - bd) + c], hv[c]);
+                }
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rv[c] = hmeanf[h + c];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const float pu = (i0 + u < i1) ? pv[u] : 0.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rv[c] = fmaf(pu, cv[u][c], rv[c]);
-        }
-        for (int i = i0 + 16; i < i1; ++i) {
-            const float pu = ps[bd + i];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rv[c] = fmaf(pu, hcompf[(size_t)i * nhf + h + c], rv[c]);
-        }
+        for (int i = 0; i < 3; ++i) rv[i] = hand ? hv[i] : __builtin_bit_cast(float, bv[i]);
     }
+    if (act && (hand ? hands_differ : (bv[0] != b0[0] || bv[1] != b0[1] || bv[2] != b0[2]))) varflag[j] = epoch;
     PREP_STAMP(1)
     // ---- Rodrigues: the local rotation Rl, and R - I (without the cancellation) as f16 features
     float Rl[9];
@@ -282,7 +353,7 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
         const float t2 = x * x + y * y + z * z;
         float a, b;
         if (t2 < 1e-6f) { a = 1.0f - t2 / 6.0f; b = 0.5f - t2 / 24.0f; }
-        else { const float t = sqrtf(t2); a = sinf(t) / t; b = (1.0f - cosf(t)) / t2; }
+        else { const float t = sqrtf(t2); a = LBS_SIN(t) / t; const float sh = LBS_SIN(0.5f * t); b = 2.0f * sh * sh / t2; }   // (1 - cos t = 2 sin^2 (t / 2): no cancellation at small angles)
         const float K2[9] = {x * x - t2, x * y, x * z, x * y, y * y - t2, y * z, x * z, y * z, z * z - t2};
         const float Km[9] = {0.0f, -z, y, z, 0.0f, -x, -y, x, 0.0f};
 #pragma unroll
@@ -294,25 +365,37 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
         }
     }
     PREP_STAMP(2)
-    // ---- kinematic chain: one tree level per step, the parent's world transform from the parent's lane
+    // ---- kinematic chain by pointer jumping: every lane holds the transform (R, t) from its joint's frame to the frame of an ANCHOR
+    // ancestor -- at first its parent: (Rl_j, J_j - J_parent); the root: (Rl_0, J_0), no anchor -- and in every round composes it with the
+    // anchor's own (fetched across lanes: 12 values + the anchor's anchor) and adopts the anchor's anchor: the distance doubles, so
+    // ceil(log2(depth + 1)) rounds (4 for the 10 levels of SMPL-H) replace one round per tree level
     float Rw[9], tw[3];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];                          // (the root's local rotation is its world rotation)
+    for (int e = 0; e < 9; ++e) Rw[e] = Rl[e];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) tw[i] = Jme[i];                         // (meaningful in the root's lane; every other lane's is set at its level)
-    for (int lvl = 1; lvl <= md.maxdepth; ++lvl) {
+    for (int i = 0; i < 3; ++i) tw[i] = Jd[i];
+    int anchor = act ? p : -1;
+    for (int reach = 1; reach <= md.maxdepth; reach *= 2) {
+        const int src = max(anchor, 0);
         float pr[9], pt[3];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) pr[e] = __shfl(Rw[e], p);
+        for (int e = 0; e < 9; ++e) pr[e] = __shfl(Rw[e], src);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pt[i] = __shfl(tw[i], p);
-        if (lvl_of == lvl) {
+        for (int i = 0; i < 3; ++i) pt[i] = __shfl(tw[i], src);
+        const int pa = __shfl(anchor, src);
+        if (anchor >= 0) {
+            float Rn[9], tn[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Rw[i * 3 + c] = pr[i * 3 + 0] * Rl[c] + pr[i * 3 + 1] * Rl[3 + c] + pr[i * 3 + 2] * Rl[6 + c];
-                tw[i] = pr[i * 3 + 0] * Jd[0] + pr[i * 3 + 1] * Jd[1] + pr[i * 3 + 2] * Jd[2] + pt[i];
+                for (int c = 0; c < 3; ++c) Rn[i * 3 + c] = pr[i * 3 + 0] * Rw[c] + pr[i * 3 + 1] * Rw[3 + c] + pr[i * 3 + 2] * Rw[6 + c];
+                tn[i] = pr[i * 3 + 0] * tw[0] + pr[i * 3 + 1] * tw[1] + pr[i * 3 + 2] * tw[2] + pt[i];
             }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Rw[e] = Rn[e];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tw[i] = tn[i];
+            anchor = pa;
         }
     }
     PREP_STAMP(3)
@@ -333,7 +416,7 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
     // requests per call, the waves a third of their time at the issue stage behind them).
     __syncthreads();
     {
-        const int fi = threadIdx.x & 3, g = threadIdx.x >> 2, fo = blockIdx.x * 4 + fi;
+        const int fi = threadIdx.x & 3, g = threadIdx.x >> 2, fo = fbase + fi;
         if (g < KS * 4 && fo < F) {
             const f32x4 piece = *reinterpret_cast<const f32x4*>(&s_feat[fi][g * 8]);
             _Float16* dst = featF + ((((size_t)(fo >> 7) * KS + (g >> 2)) * 8 + ((fo >> 4) & 7)) * 64 + (fo & 15) + 16 * (g & 3)) * 8;
@@ -369,6 +452,9 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
                              // on 16 distinct even banks
 #endif
 #define LX_JR 4              // joints per blend round
+#ifndef LX_STAUX
+#define LX_STAUX 2           // cache policy of the row stores: 2 = nt (streaming)
+#endif
 #ifndef LX_NRMAX
 #define LX_NRMAX 6           // rounds per group the kernel's LDS tables hold (24 joints per 16 vertices; else the plain kernel runs)
 #endif
@@ -404,7 +490,7 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
 // export kernel would read, against frame 0's features -- and writes  pscale x (rest + still correctives)  in the layout of the rest
 // positions (tab_vsc): the start value of the export kernel's accumulators, whose k-loop then ends at kseff.  A body-only Stage-II
 // result (the reference's default: optimize_fingers off) keeps the 30 hand joints of SMPL-H still: 9 of 15 k-steps.
-__global__ __launch_bounds__(64) void k_lbs_still(Lbs32Model lm, const int* __restrict__ varflag, int epoch, int all_move) {
+__global__ __launch_bounds__(64, 1) void k_lbs_still(Lbs32Model lm, const int* __restrict__ varflag, int epoch, int all_move) {
     const int lane = threadIdx.x, g = blockIdx.x, KS = lm.KS, q4 = lane >> 4, fl = lane & 15;
     int kseff = KS;
     if (!all_move) {
@@ -422,10 +508,11 @@ __global__ __launch_bounds__(64) void k_lbs_still(Lbs32Model lm, const int* __re
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] = f32x4{vs[0][c], vs[1][c], vs[2][c], vs[3][c]};
     const unsigned ap = (unsigned)(g * 3 * KS) * 1024u;
-    for (int kc = kseff; kc < KS; kc += 4) {     // (straight-line batches of four steps; past the last step the last one again with a zero B operand)
-        half8 ca[4][3], cb[4];
+    for (int kc = kseff; kc < KS; kc += 10) {    // (straight-line batches of ten steps -- one round trip for the nine still steps of a body-only
+                                                 //  SMPL-H export; past the last step the last one again with a zero B operand)
+        half8 ca[10][3], cb[10];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 10; ++u) {
             const unsigned kk = (unsigned)min(kc + u, KS - 1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) ca[u][c] = (half8)__builtin_amdgcn_raw_buffer_load_b128(rs_pf, lane * 16u, ap + (c * (unsigned)KS + kk) * 1024u, 0);
@@ -434,7 +521,7 @@ __global__ __launch_bounds__(64) void k_lbs_still(Lbs32Model lm, const int* __re
             cb[u] = (half8)(braw & u32x4{keep, keep, keep, keep});
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 10; ++u)
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca[u][c], cb[u], acc[c], 0, 0, 0);
     }
@@ -515,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     };
     const int* ljt = reinterpret_cast<const int*>(lds_raw + LX_OFF_J) + wv * NRM * LX_JR;   // this group's joint list in LDS
     half8 aS[3][3], bS[8];
-    f32x4 gS[3][2];
+    f32x4 gS[2][2];
 #define LX_LD_A(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), kseff - 1); _Pragma("unroll") for (int c = 0; c < 3; ++c) \
         aS[SET][c] = (half8)__builtin_amdgcn_raw_buffer_load_b128(rs_pf, lane * 16u, ap + (c * (unsigned)KS + kk_) * 1024u, 0); __builtin_amdgcn_sched_barrier(0); }
 #define LX_LD_G(SET, KSTEP) { const unsigned kk_ = (unsigned)min((KSTEP), kseff - 1); gS[SET][0] = (f32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_feat, tid * 16u, fp + kk_ * LX_CHUNK, 0); \
@@ -535,16 +622,13 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
     // B fragments of chunk t, drop chunk t + 2 (fetched two steps ago) into the slot chunk t - 1 occupied, fetch chunk t + 4 and the posedirs
     // fragments of step t + 2; the memory instructions sit BETWEEN the step's 24 MFMAs (a load does not leave the issue stage while the
     // address unit is busy with other waves' loads).
-    // Ring bookkeeping, period 3 in everything (chunk c lives in ring slot c % 3, posedirs fragments of step s in register set s % 3, a
-    // chunk fetched at step s in staging set s % 3): at step s the wave reads chunk s, drops chunk s + 2 (fetched at step s - 2: staging
-    // set (s + 1) % 3) into the slot chunk s - 1 occupied, fetches chunk s + 4 and the posedirs fragments of step s + 2.
 #define LX_STEP(S, KSTEP) { \
         LBS_LDS_BARRIER(); \
         LX_LD_B((S) % 3) __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 0) LX_LD_B1((S) % 3, 4) \
-        if ((KSTEP) + 2 < kseff) { LX_ST_G(((S) + 1) % 3, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
+        if ((KSTEP) + 2 < kseff) { LX_ST_G((S) % 2, ((S) + 2) % 3) } __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 1) LX_LD_B1((S) % 3, 5) \
-        if ((KSTEP) + 4 < kseff) { LX_LD_G((S) % 3, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0); \
+        if ((KSTEP) + 4 < kseff) { LX_LD_G((S) % 2, (KSTEP) + 4) } __builtin_amdgcn_sched_barrier(0); \
         LX_MMA_T((S) % 3, 2) LX_LD_B1((S) % 3, 6) \
         if ((KSTEP) + 2 < kseff) LX_LD_A(((S) + 2) % 3, (KSTEP) + 2) \
         LX_MMA_T((S) % 3, 3) LX_LD_B1((S) % 3, 7) __builtin_amdgcn_sched_barrier(0); \
@@ -584,13 +668,18 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         if (kseff > 0) {
             LX_LD_G(0, 0) LX_LD_G(1, 1) LX_LD_A(0, 0) LX_LD_A(1, 1)
             LX_ST_G(0, 0) LX_ST_G(1, 1)
-            LX_LD_G(1, 2) LX_LD_G(2, 3)
+            LX_LD_G(0, 2) LX_LD_G(1, 3)
         }
         LX_STAMP(1)
         int ks = 0;
-        for (; ks + 3 <= kseff; ks += 3) { LX_STEP(0, ks) LX_STEP(1, ks + 1) LX_STEP(2, ks + 2) }
+        for (; ks + 6 <= kseff; ks += 6) {
+            LX_STEP(0, ks) LX_STEP(1, ks + 1) LX_STEP(2, ks + 2) LX_STEP(3, ks + 3) LX_STEP(4, ks + 4) LX_STEP(5, ks + 5)
+        }
         if (ks < kseff) { LX_STEP(0, ks) ++ks; }
         if (ks < kseff) { LX_STEP(1, ks) ++ks; }
+        if (ks < kseff) { LX_STEP(2, ks) ++ks; }
+        if (ks < kseff) { LX_STEP(3, ks) ++ks; }
+        if (ks < kseff) { LX_STEP(4, ks) ++ks; }
         LX_STAMP(2)
         // what only the epilogue needs is fetched behind the k-loop (held across it these 19 registers were spilled; the first item of a
         // tile waits for them -- the CU's other workgroup runs meanwhile): the lane's exchange columns, its offsets in a round-0 block
@@ -662,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
                 // re-reads from L2).  (Round 5's form decided per store and per debug flag: ~15 scalar branches per block, and a taken
                 // branch costs the wave ~30 cycles: the three stores took 480 cycles to issue.)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, 2);
+                for (int s = 0; s < 3; ++s) __builtin_amdgcn_raw_buffer_store_b128((u32x4)rv[s], rs_out, voff[s], soff, LX_STAUX);
             } else if (wmode == 2) {
 #pragma nounroll
                 for (int s = 0; s < 3; ++s) {
@@ -694,6 +783,16 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
             T[c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32((WS), sg[c].z, (CIN) ? zero4 : T[c][2], 0, 0, 0); \
             T[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32((WP), sg[c].w, (CIN) ? zero4 : T[c][3], 0, 0, 0); \
         } }
+        // apply: out_v = T_v . (p_v, 1), p_v = pscale x (rest + corrective) out of the accumulators (1 / pscale rides in the rotation entries'
+        // weights); into the exchange at the vertex's column.  (Packed FMAs -- two vertices an instruction -- measured: no faster.)
+#define LX_APPLY(TT) { \
+        unsigned fl_o = (unsigned)fl; LX_OPAQUE(fl_o);   /* (not a tile-loop invariant to be parked in a register: recomputed per block) */ \
+        char* sx = Sx + ((TT) & 1) * LX_SXBYTES + fl_o * (LX_XP * 4); \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
+            const float px = acc[TT][0][r], py = acc[TT][1][r], pz = acc[TT][2][r]; \
+            float* so = reinterpret_cast<float*>(sx + xo[r]); \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) so[c] = fmaf(T[c][0][r], px, fmaf(T[c][1][r], py, fmaf(T[c][2][r], pz, T[c][3][r]))); \
+        } }
 #define LX_BLOCK(TT) { \
         constexpr int t = (TT); \
         __builtin_amdgcn_s_waitcnt(0x0F70); \
@@ -720,18 +819,15 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
             __builtin_amdgcn_sched_barrier(0); \
         } \
         if (t == 3) LX_STAMP(14) \
-        /* ---- apply: out_v = T_v . (p_v, 1), p_v = pscale x (rest + corrective) out of the accumulators (1 / pscale rides in the rotation \
-           entries' weights); into the exchange at the vertex's column */ \
-        char* sx = Sx + (t & 1) * LX_SXBYTES + fl * (LX_XP * 4); \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
-            const float px = acc[t][0][r], py = acc[t][1][r], pz = acc[t][2][r]; \
-            float* so = reinterpret_cast<float*>(sx + xo[r]); \
-            _Pragma("unroll") for (int c = 0; c < 3; ++c) so[c] = fmaf(T[c][0][r], px, fmaf(T[c][1][r], py, fmaf(T[c][2][r], pz, T[c][3][r]))); \
-        } \
+        LX_APPLY(TT) \
         if (t == 3) LX_STAMP(15) \
         LBS_LDS_BARRIER(); \
         LX_STAMP(3 + t) }
+        // (A branch-free variant of the block for one-round groups on interior tiles -- the same steps as straight-line code, ~60 instructions
+        //  instead of ~75 and a dozen scalar branches -- was measured slower, 170-178 against 151 us per call, with and without spills in
+        //  its steady state, with counted or full waits: not kept.)
         LX_BLOCK(0) LX_BLOCK(1) LX_BLOCK(2) LX_BLOCK(3) LX_BLOCK(4) LX_BLOCK(5) LX_BLOCK(6) LX_BLOCK(7)
+#undef LX_APPLY
 #undef LX_BLEND
 #undef LX_BLOCK
         __builtin_amdgcn_s_waitcnt(0x0F70); LX_KEEP(rv[0]); LX_KEEP(rv[1]); LX_KEEP(rv[2]);
@@ -761,7 +857,7 @@ extern "C" void moshii_lbs32_free(void* l32) {
     Lbs32Model* lm = (Lbs32Model*)l32;
     free_ptr(lm->v_shaped); free_ptr(lm->posedirs_t); free_ptr(lm->weights); free_ptr(lm->J);
     free_ptr(lm->Pfrag); free_ptr(lm->perm); free_ptr(lm->tables); free_ptr(lm->dbgbuf);
-    free_ptr(lm->Atr); free_ptr(lm->featF); free_ptr(lm->hcompf); free_ptr(lm->hmeanf); free_ptr(lm->varflag);
+    free_ptr(lm->Atr); free_ptr(lm->featF); free_ptr(lm->hcompf); free_ptr(lm->hmeanf); free_ptr(lm->varflag); free_ptr(lm->jtab); free_ptr(lm->hcj);
     memset(lm, 0, sizeof(*lm));
 }
 
@@ -929,6 +1025,7 @@ extern "C" int moshii_lbs32_prepare(moshii_model_t m) {
     }
     hipLaunchKernelGGL(k_cvt_vsh, dim3((V * 3 + 255) / 256), dim3(256), 0, 0, V * 3, moshii_internal_vsh(m), lm->v_shaped);
     hipLaunchKernelGGL(k_cvt_vsh, dim3(1), dim3(256), 0, 0, K * 3, moshii_internal_J(m), lm->J);
+    lm->jtab_valid = 0;
     if (lm->mfma_ok)   // rest positions in group order, x pscale (the accumulators start there)
         hipLaunchKernelGGL(k_pack_vsh, dim3((lm->NVT * LX_TV + 255) / 256), dim3(256), 0, 0, lm->NVT * LX_TV, lm->pscale, lm->perm, moshii_internal_vsh(m), reinterpret_cast<float*>(lm->tables + lm->tab_vshs));
     if (hipDeviceSynchronize() != hipSuccess) return MOSHII_ERR_HIP;
@@ -952,6 +1049,22 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
         const size_t lds = (size_t)(md->P + md->K * 30) * sizeof(float);
         hipLaunchKernelGGL(k_lbs_f32_v0, dim3((md->V + 255) / 256, F), dim3(256), lds, stream, *md, lm, pose, trans, verts);
         return hipGetLastError();
+    }
+    // The export kernel addresses the per-call scratch through buffer resources (2^31 - 1 bytes, 32-bit offsets; a load beyond the range
+    // returns zeros, silently): a call that would pass that is cut into sub-calls of whole frame tiles (SMPL-H: 860 000 frames a piece).
+    {
+        const long long per16 = (long long)lmp->KJ * LX_JBYTES, per128 = (long long)lmp->KS * LX_CHUNK;
+        long long fmax = std::min(((0x7fffffffLL - 4096) / per16) * 16, ((0x7fffffffLL - 4096) / per128) * LX_TF);
+        if (const char* es = getenv("MOSHII_LBS_FMAX")) fmax = std::min(fmax, (long long)std::max(LX_TF, atoi(es)));   // (tests: a small limit)
+        fmax = fmax / LX_TF * LX_TF;
+        if ((long long)F > fmax) {
+            for (long long f0 = 0; f0 < F; f0 += fmax) {
+                const int n = (int)std::min<long long>(fmax, F - f0);
+                hipError_t e = moshii_launch_lbs_f32(stream, md, n, pose + (size_t)f0 * md->NP, trans + (size_t)f0 * 3, verts + (size_t)f0 * md->V * 3, lbs32);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
     }
     const int Fpad = (F + LX_TF - 1) / LX_TF * LX_TF;
     if (Fpad > lmp->Fcap) {   // per-call scratch grows to the largest F seen (not stream-ordered: sync first)
@@ -989,10 +1102,21 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
         lmp->epoch = 0;
     }
     lmp->epoch = lmp->epoch >= 0x7ffffff0 ? 1 : lmp->epoch + 1;
+    if (!lmp->jtab) {
+        hipError_t e = hipMalloc((void**)&lmp->jtab, 64 * 16 * sizeof(float));
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&lmp->hcj, 64 * 64 * sizeof(float));
+        if (e != hipSuccess) return e;
+        lmp->jtab_valid = 0;
+    }
+    if (!lmp->jtab_valid) {   // (the joints move with the betas: moshii_lbs32_prepare clears the mark)
+        hipLaunchKernelGGL(k_pack_jtab, dim3(1), dim3(64), 0, stream, *md, lmp->J, lmp->hcompf, lmp->hmeanf, lmp->jtab, lmp->hcj);
+        lmp->jtab_valid = 1;
+    }
     const Lbs32Model lm = *lmp;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 127;   // (development: phase timing by truncation / clock stamps; incomplete output)
-    hipLaunchKernelGGL(k_lbs_prep, dim3((F + 3) / 4), dim3(256), 0, stream, *md, lm.J, lm.hcompf, lm.hmeanf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF, lm.varflag, lm.epoch,
+    hipLaunchKernelGGL(k_lbs_prep, dim3(((F + 127) / 128) * 32), dim3(256), 0, stream, *md, lm.jtab, lm.hcj, lm.hcompf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF, lm.varflag, lm.epoch,
                        (dbg & 16) ? lm.dbgbuf + 8 * 24 : (long long*)nullptr);
     hipLaunchKernelGGL(k_lbs_still, dim3(lm.NVT * 4), dim3(64), 0, stream, lm, lm.varflag, lm.epoch, (dbg & 8) ? 1 : 0);
     const int NVT = lm.NVT, NFT = Fpad / LX_TF;

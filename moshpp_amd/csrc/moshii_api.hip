@@ -4,6 +4,7 @@
 #include "stagei_views.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -703,11 +704,10 @@ struct LaunchCfg {
 // Set once a cooperative group has broken up in this process (a rank did not become resident within the wait limit: the device is
 // shared with another process, or CUs are masked): from then on the library's OWN choice is plain chains -- every further call would
 // pay the wait limit and the repeated solve again.  An explicit MOSHII_COOP_GROUP(g) / MOSHII_COOP=g request is still honoured.
-static bool g_coop_broke_once = false;
+static std::atomic<bool> g_coop_broke_once{false};   // (process-wide and sticky; solves may run on several host threads)
 static void note_coop_broken(const char* where) {
-    if (!g_coop_broke_once) fprintf(stderr, "[moshii] %s: a cooperative group broke up (the device is shared?); the call is repeated with plain chains, "
+    if (!g_coop_broke_once.exchange(true)) fprintf(stderr, "[moshii] %s: a cooperative group broke up (the device is shared?); the call is repeated with plain chains, "
                                             "and the library's own choice is plain chains for the rest of this process\n", where);
-    g_coop_broke_once = true;
 }
 // test aid: MOSHII_COOP_SKEW=seed (read at every call) -> CoopDev::skew, the ranks' arrival order at the exchanges randomised
 int coop_skew_env() {
@@ -722,10 +722,10 @@ int coop_request(uint32_t flags, const char* env) {
 #ifdef MOSHII_EMULATION   // (the CPU emulation runs workgroups one after another unless told otherwise: a group would wait for itself)
             return 0;
 #else
-            return g_coop_broke_once ? 0 : -1;
+            return g_coop_broke_once.load() ? 0 : -1;
 #endif
         }
-        if (!strcmp(e, "auto")) return g_coop_broke_once ? 0 : -1;   // (the library's choice, spelled out -- also how the emulation reaches it)
+        if (!strcmp(e, "auto")) return g_coop_broke_once.load() ? 0 : -1;   // (the library's choice, spelled out -- also how the emulation reaches it)
         g = atoi(e);
         if (g == 0) return 0;
     }

@@ -217,6 +217,9 @@ struct Lbs32Model {
     float* J;              // [K][3]
     float* hcompf;         // [hand_dof][nhand_full] f32 copy of the hand-pose components (k_lbs_prep), made at the first export
     float* hmeanf;         // [nhand_full]
+    float* jtab;           // [K][16] per-joint record of k_lbs_prep (k_pack_jtab), rebuilt when the joints change (jtab_valid)
+    float* hcj;            // [K][16][4] the joint's window of hand-component rows
+    int jtab_valid;
     int* varflag;          // [64] varflag[j] == epoch: joint j moves in the current export call (k_lbs_prep writes, k_lbs_export reads)
     int epoch;             // the export call's number
     int Vp;                // V padded to 64

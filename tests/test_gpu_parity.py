@@ -442,6 +442,25 @@ def test_lbs_f32_joints_that_do_not_move(gpu_lib, model_type, M, still):
     assert w1 < 2e-5 and w2 < 2e-5 and w3 < 2e-5
 
 
+def test_lbs_f32_long_exports_are_cut_into_sub_calls(gpu_lib):
+    """The export kernel's buffer resources span 2^31 - 1 bytes of per-call scratch (SMPL-H: 860 000 frames); a longer export is cut into
+    sub-calls of whole frame tiles.  With the limit lowered to 256 frames (MOSHII_LBS_FMAX) a 700-frame export = 3 sub-calls gives the
+    bits of the one-call export (the still-joint marks are per sub-call: every joint moves here)."""
+    case = oracle_case('smplh', F=4, M=53, seed=77)
+    dev = device_case(case)
+    rng = np.random.default_rng(3)
+    F = 700
+    pose = rng.normal(0, 0.4, (F, case['m']['NP']))
+    trans = rng.normal(0, 1.5, (F, 3))
+    whole = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+    os.environ['MOSHII_LBS_FMAX'] = '256'
+    try:
+        cut = dev['model'].lbs_forward(pose, trans, dtype=np.float32)
+    finally:
+        del os.environ['MOSHII_LBS_FMAX']
+    np.testing.assert_array_equal(cut, whole)
+
+
 def test_lbs_f32_soak_random_frame_counts(gpu_lib):
     """Soak of the export kernel: 24 seeded frame counts between 1 and 1500 (partial frame tiles of every size, one to twelve frame tiles,
     workgroups with and without a second tile), fresh random poses each, against the float64 kernel; every call repeated once and

@@ -54,7 +54,9 @@ if int(os.environ.get('MOSHII_LBS_STOP', '0')) & 16:
     lib.moshii_internal_lbs_debug_times(lib.moshii_internal_l32(solver.dev.handle), buf_)
     raw = np.array(buf_[:], dtype=np.int64)
     st = raw[:192].reshape(8, 24)
-    ps = raw[192:198]
+    ps = raw[192:202]
+    if ps[6]:
+        print(f'prep first loads (cycles after start): joint record {int(ps[6] - ps[0])}, this frame\'s pose variables {int(ps[7] - ps[0])}, frame 0\'s {int(ps[8] - ps[0])}, component window {int(ps[9] - ps[0])}')
     print('prep (workgroup 0, wave 0): ' + ' | '.join(f'{n} +{int(ps[k + 1] - ps[k])}' for k, n in enumerate(['hand PCA -> fullpose', 'Rodrigues + features', 'chain', 'transform rows out', 'feature pieces out'])))
     names = ['start', 'tables + first loads issued', 'k-loop done'] + [f'block {h} done' for h in range(8)] + ['rows out']
     for ti in range(7):
