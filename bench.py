@@ -52,7 +52,7 @@ F64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (AMD spec sheet; half the 15
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-LINE_LIMIT = 4096   # bytes: the driver keeps the tail of stdout; the round-5 line (20 KB) was cut and could not be parsed
+LINE_LIMIT = 3600   # bytes (the driver keeps the last 4-8 KB of stdout; round 6's first line came to 3968): the driver keeps the tail of stdout; the round-5 line (20 KB) was cut and could not be parsed
 
 
 def _pick(d, keys):
@@ -66,25 +66,28 @@ def compact_line(full):
                        'vs_baseline', 'dtype', 'data'))
     cfg = full.get('config', {})
     out['config'] = dict(_pick(cfg, ('mode', 'frames_per_gpu', 'markers', 'free_vars_step1', 'free_vars_step2', 'sequences_per_gpu', 'parallelism')),
-                         workload=str(cfg.get('workload', ''))[:200])
+                         workload=str(cfg.get('workload', ''))[:140])
     out['config'] = {'workload': out['config'].pop('workload'), **out['config']}
     if 'rccl' in full:
         out['rccl'] = full['rccl']
     rf = full.get('roofline')
     if isinstance(rf, dict):
-        out['roofline'] = _pick(rf, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_is', 'step_ms_hip_events',
+        out['roofline'] = _pick(rf, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'step_ms_hip_events',
                                      'algorithmic_gflop_per_step'))
+        out['roofline']['traffic_is'] = str(rf.get('traffic_is', ''))[:48]
     cb = full.get('cpu_baseline')
     if isinstance(cb, dict):
-        out['cpu_baseline'] = dict(_pick(cb, ('value', 'unit', 'cores', 'kind')), sample=str(cb.get('sample', ''))[:120])
+        out['cpu_baseline'] = dict(_pick(cb, ('value', 'unit', 'cores', 'kind')), sample=str(cb.get('sample', ''))[:80])
         if isinstance(cb.get('reference_cost'), dict):
             out['cpu_baseline']['reference_cost'] = cb['reference_cost'].get('value')
         if isinstance(cb.get('all_cores'), dict) and 'value' in cb['all_cores']:
             out['cpu_baseline']['all_cores'] = _pick(cb['all_cores'], ('value', 'cores'))
     rl = full.get('roofline_lbs')
     if isinstance(rl, dict):
-        out['roofline_lbs'] = _pick(rl, ('kernel', 'bound', 'body', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_is', 'kernel_ms',
+        out['roofline_lbs'] = _pick(rl, ('kernel', 'bound', 'body', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel_ms',
                                          'algorithmic_bytes', 'error'))
+        if 'traffic_is' in rl:
+            out['roofline_lbs']['traffic_is'] = str(rl['traffic_is'])[:48]
         for leg in ('all_joints_moving', 'shuffled_vertex_ids', 'shuffled_vertex_ids_all_joints_moving'):
             if isinstance(rl.get(leg), dict):
                 out['roofline_lbs'][leg] = _pick(rl[leg], ('frac', 'kernel_ms', 'traffic'))
@@ -249,7 +252,7 @@ def strong_job_shares(n_sequences, frames, world):
 
 
 def load_pmc(path, lib_hash):
-    """PMC numbers collected by tools/r05_collect.sh, or (None, why): never numbers of another build."""
+    """PMC numbers collected by tools/r06_collect.sh, or (None, why): never numbers of another build."""
     try:
         with open(path) as fh:
             d = json.load(fh)
@@ -289,8 +292,8 @@ def main():
     ap.add_argument('--config3-sequences', type=int, default=32)
     ap.add_argument('--config3-frames', type=int, default=4000)
     ap.add_argument('--lbs-frames', type=int, default=4000)   # the whole solved sequence: that is what a mesh export writes
-    ap.add_argument('--pmc-file', default=os.path.join(ROOT, 'profiles', 'r05_pmc.json'),
-                    help='HBM traffic from rocprofv3 PMC passes (tools/r05_collect.sh); used only if its source hash is the loaded library\'s')
+    ap.add_argument('--pmc-file', default=os.path.join(ROOT, 'profiles', 'r06_pmc.json'),
+                    help='HBM traffic from rocprofv3 PMC passes (tools/r06_collect.sh); used only if its source hash is the loaded library\'s')
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
@@ -616,7 +619,7 @@ def main():
             'kernel': name, 'bound': 'valu_f64',
             'bound_note': 'neither hbm nor mfma: float64 vector pipe, instruction-count / latency-bound small dense solves with one wave per SIMD; memory side 45 KB/frame for a one-workgroup chain alone, ~476 KB/frame (mostly scratch write-back) with a chain on every CU, 1.6 MB/frame for a cooperative chain (write-through exchanges) (PMC)',
             'achieved': round(ach, 5), 'peak': F64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F64_VALU_PEAK_TFLOPS, 6),
-            # HBM traffic: PMC passes of tools/r05_collect.sh over one seed-1000 step (--pmc-file), split into the pass-1 launch (bytes per
+            # HBM traffic: PMC passes of tools/r06_collect.sh over one seed-1000 step (--pmc-file), split into the pass-1 launch (bytes per
             # frame it solves: chunks x (chunk + warm-up) frames) and the cooperative repair rounds of that step; null when the file was
             # collected on another build of the library
             'traffic': (int(pmc['chain']['pass1_bytes_per_solved_frame'] * (F + (rep['n_chunks'] * rep['warmup'] if rep else 0)) + (pmc['chain']['repair_bytes_per_step'] if rep else 0))
@@ -835,7 +838,7 @@ def main():
             trans32 = ds.trans[:Fl].to(torch.float32).contiguous()
             stream = torch.cuda.current_stream().cuda_stream
 
-            def lbs_leg(slv, tag, pose_t, what):
+            def lbs_leg(slv, tag, pose_t, what, pmc_tag=None):
                 smv = slv.sm if hasattr(slv, 'sm') else sm
                 verts = torch.empty((Fl, smv.V, 3), dtype=torch.float32, device=dev)
                 for _ in range(2):
@@ -859,7 +862,7 @@ def main():
                 model_bytes = 12 * smv.V * (1 + 9 * (Kj - 1)) + 4 * smv.V * Kj
                 bytes_alg = Fl * (12 * smv.V + 4 * smv.NP + 12) + model_bytes
                 bytes_f16 = Fl * (12 * smv.V + 4 * smv.NP + 12) + 6 * smv.V * 9 * (Kj - 1) + 16 * smv.V
-                pm = pmc.get('lbs', {}).get(tag) if pmc else None
+                pm = pmc.get('lbs', {}).get(pmc_tag or tag) if pmc else None
                 return {'kernel': 'k_lbs_export (+ k_lbs_prep, k_lbs_still)', 'bound': 'hbm', 'body': tag, 'poses': what,
                         'dtype': 'f32 out; f16-operand / f32-accumulate MFMA correctives, f32 blend on the f32 matrix instruction',
                         'achieved': round(bytes_alg / lt / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_alg / lt / 1e9 / HBM_PEAK_GBS, 4),
@@ -881,9 +884,9 @@ def main():
             job_mesh = workload.make_job('smplh', n_frames=8, n_markers=M, seed=seeds[0], dd=dd_mesh)
             solver_mesh = workload.make_solver(job_mesh)
             result['roofline_lbs'] = lbs_leg(solver_mesh, 'mesh_order', pose32, what_a)
-            result['roofline_lbs']['all_joints_moving'] = lbs_leg(solver_mesh, 'mesh_order', pose_mv, what_b)
+            result['roofline_lbs']['all_joints_moving'] = lbs_leg(solver_mesh, 'mesh_order', pose_mv, what_b, 'mesh_order_moving')
             result['roofline_lbs']['shuffled_vertex_ids'] = lbs_leg(solver, 'shuffled_ids', pose32, what_a)
-            result['roofline_lbs']['shuffled_vertex_ids_all_joints_moving'] = lbs_leg(solver, 'shuffled_ids', pose_mv, what_b)
+            result['roofline_lbs']['shuffled_vertex_ids_all_joints_moving'] = lbs_leg(solver, 'shuffled_ids', pose_mv, what_b, 'shuffled_ids_moving')
             result['roofline_lbs']['limit_note'] = (
                 'round 6: the blend runs on v_mfma_f32_16x16x4_f32 (12 matrix instructions a 16-frame block and round of four joints; the packed FMAs of round 5 '
                 'could not overlap the matrix pipe at all: profiles/r06_ubench_valu.txt), still joints leave the k-loop; what remains per 64 x 128 tile and wave is '

@@ -22,7 +22,7 @@ scripts under tests/golden/, checked by tests/test_ref_golden.py and tests/test_
   * stageii_chain (the Stage-II schedule: first-frame rigid init and annealed rounds, Step 1 / Step 2 free sets, weights,
     velocity target, empty frames, result terms) and the way `minimize_dogleg` is driven  <- the reference's own
     `mosh_stageii` function (chmosh.py:468-741) EXECUTED under a lazy chumpy stand-in with the reference's node classes
-    (tests/golden/make_ref_stageii_golden.py -> tests/golden/ref_stageii.npz; 3 cases incl. fingers): <= 5e-9 rad, equal
+    (tests/golden/make_ref_stageii_golden.py -> tests/golden/ref_stageii.npz; 7 cases: body, SMPL, fingers, toes, MANO, face + expressions, DMPL): <= 5e-9 rad, equal
     dogleg iteration counts on every solve
 UNPINNED (third-party code absent): the LBS arithmetic of psbody.smpl (forward + pose Jacobian) and the internals of
 chumpy's `minimize_dogleg` (radius rules, stops, the solve).  These restate the *published* algorithms (SMPL's public

@@ -30,7 +30,7 @@ def _strict(line):
 
 def test_line_is_short_strict_json_with_the_contract_keys(full):
     line = bench.compact_line(bench._finite(full))
-    assert len(line.encode()) < bench.LINE_LIMIT <= 4096 and '\n' not in line
+    assert len(line.encode()) < bench.LINE_LIMIT <= 3600 and '\n' not in line
     d = _strict(line)
     for k in CONTRACT:
         assert k in d, k
