@@ -246,19 +246,27 @@ __global__ void k_pack_jtab(ModelDev md, const float* __restrict__ Jf, const flo
 #define LX_KEEP_F(x)
 #define LX_KEEP_U(x)
 #endif
-__global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* __restrict__ jtab, const float* __restrict__ hcj, const float* __restrict__ hcompf,
+#ifndef LBS_PREP_WAVES
+#define LBS_PREP_WAVES 16      // frames (= waves) per workgroup of k_lbs_prep: a whole 16-frame block
+#endif
+__global__ __launch_bounds__(64 * LBS_PREP_WAVES, LBS_PREP_WAVES == 16 ? 1 : 4) void k_lbs_prep(ModelDev md, const float* __restrict__ jtab, const float* __restrict__ hcj, const float* __restrict__ hcompf,
                                                    int F, int KS, int KJ,
                                                    const float* __restrict__ pose, const float* __restrict__ trans,
                                                    float* __restrict__ Atr, _Float16* __restrict__ featF, int* __restrict__ varflag, int epoch,
                                                    long long* __restrict__ stamps) {
 #define PREP_STAMP(K) { if (stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamps[K] = clock64(); }
-    __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][16 * 32];   // the four frames' feature rows (KS <= 16 k-steps of 32), zero padded
+    __shared__ __attribute__((aligned(16))) _Float16 s_feat[LBS_PREP_WAVES][16 * 32];   // the workgroup's frames' feature rows (KS <= 16 k-steps of 32), zero padded
     const int K = md.K, wv = threadIdx.x >> 6, tid = threadIdx.x & 63;
-    // Workgroup -> frames: the hardware deals consecutive workgroups to consecutive XCDs, whose L2s are not coherent with each other.  A
-    // 16-frame block of the outputs (768-byte runs of a joint's transforms, 1 KB feature records) is therefore given to ONE XCD -- its
-    // four workgroups are 8 ids apart -- so that the block's lines are completed in one L2 and leave it as whole lines (dealt out four
-    // frames to consecutive ids, every line was written piecewise from four L2s).
+    // Workgroup -> frames: a workgroup is 16 waves = one whole 16-frame block of the outputs (768-byte runs of a joint's transforms, 1 KB
+    // feature records), completed by one CU in one L2 and leaving it as whole lines.  (What bounds the kernel is the instruction count:
+    // 4 000 waves are four a SIMD, and a SIMD issues one vector instruction per ~4.5 cycles whichever wave it comes from -- an empty
+    // kernel of this shape takes 2.2 us, one with 2 000 dependent FMAs a wave 16.4 us, tools/ubench_dispatch.hip; this one, ~700 vector +
+    // ~300 other instructions a wave, 18-19 us.  Four or sixteen waves a workgroup: the same.)
+#if LBS_PREP_WAVES == 16
+    const int fbase = (int)blockIdx.x * 16;
+#else
     const int fbase = (((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7)) * 16 + (((int)blockIdx.x >> 3) & 3) * 4;
+#endif
     const int fw = fbase + wv;                   // this wave's frame; spare waves behind the last frame redo frame F - 1 and write nothing
     const int f = __builtin_amdgcn_readfirstlane(min(fw, F - 1));
     PREP_STAMP(0)
@@ -411,12 +419,12 @@ __global__ __launch_bounds__(256, 4) void k_lbs_prep(ModelDev md, const float* _
     }
     PREP_STAMP(4)
     // B fragments of v_mfma_f32_16x16x32_f16: features 8 g .. 8 g + 7 of frame f are the 16 bytes of record (f / 128, g / 4,
-    // (f / 16) % 8), lane (f % 16) + 16 (g % 4).  The workgroup's four frames are four consecutive lanes: thread (g, frame) writes
-    // one 16-byte piece, four threads a 64-byte run (the first version wrote every feature as a 2-byte store of its own: 2.4 M write
+    // (f / 16) % 8), lane (f % 16) + 16 (g % 4).  The workgroup's frames are consecutive lanes: thread (g, frame) writes
+    // one 16-byte piece, the frames' threads one contiguous run (the first version wrote every feature as a 2-byte store of its own: 2.4 M write
     // requests per call, the waves a third of their time at the issue stage behind them).
     __syncthreads();
     {
-        const int fi = threadIdx.x & 3, g = threadIdx.x >> 2, fo = fbase + fi;
+        const int fi = threadIdx.x & (LBS_PREP_WAVES - 1), g = threadIdx.x / LBS_PREP_WAVES, fo = fbase + fi;
         if (g < KS * 4 && fo < F) {
             const f32x4 piece = *reinterpret_cast<const f32x4*>(&s_feat[fi][g * 8]);
             _Float16* dst = featF + ((((size_t)(fo >> 7) * KS + (g >> 2)) * 8 + ((fo >> 4) & 7)) * 64 + (fo & 15) + 16 * (g & 3)) * 8;
@@ -1116,7 +1124,7 @@ extern "C" hipError_t moshii_launch_lbs_f32(hipStream_t stream, const ModelDev* 
     const Lbs32Model lm = *lmp;
     int dbg = 0;
     if (const char* es = getenv("MOSHII_LBS_STOP")) dbg = atoi(es) & 127;   // (development: phase timing by truncation / clock stamps; incomplete output)
-    hipLaunchKernelGGL(k_lbs_prep, dim3(((F + 127) / 128) * 32), dim3(256), 0, stream, *md, lm.jtab, lm.hcj, lm.hcompf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF, lm.varflag, lm.epoch,
+    hipLaunchKernelGGL(k_lbs_prep, dim3(LBS_PREP_WAVES == 16 ? (F + 15) / 16 : ((F + 127) / 128) * 32), dim3(64 * LBS_PREP_WAVES), 0, stream, *md, lm.jtab, lm.hcj, lm.hcompf, F, lm.KS, lm.KJ, pose, trans, lm.Atr, lm.featF, lm.varflag, lm.epoch,
                        (dbg & 16) ? lm.dbgbuf + 8 * 24 : (long long*)nullptr);
     hipLaunchKernelGGL(k_lbs_still, dim3(lm.NVT * 4), dim3(64), 0, stream, lm, lm.varflag, lm.epoch, (dbg & 8) ? 1 : 0);
     const int NVT = lm.NVT, NFT = Fpad / LX_TF;
