@@ -784,7 +784,7 @@ def main():
             except Exception as e:
                 result['config3'] = {'error': repr(e)}
         # ---- BASELINE configs 3, 4, 5 at their stated lengths against the committed ORACLE trajectories + envelopes (the GPU tier's
-        #      test_config{3,4,5}_*_against_the_oracle; here as numbers on the line): capture 7000 of the config-3 subject (4000 frames, 194
+        #      test_config{3,4,5}_*_against_the_oracle; here as numbers on the line): captures 7000 and 7001 of the config-3 subject (4000 frames, 194
         #      unknowns), one MANO hand (10 000 frames), the first 8000 frames of the 50 000-frame config-5 capture
         if extras and not args.no_cpu and 'parity_every_frame' in result:
             cfgs = {}
@@ -801,11 +801,12 @@ def main():
                                                     'max_dev_on_well_conditioned_frames_rad', 'max_dev_on_parted_frames_rad', 'max_oracle_spread_rad',
                                                     'marker_rmse_vs_oracle_m', 'worst_frame_marker_rmse_vs_oracle_m')}, ok=pe.ok(r))
                 if not args.no_config3:
-                    c3 = case_inputs('config3_7000')
-                    s3 = workload.make_solver(c3['job'])
-                    o3 = capi.chain_solve_host(s3.dev, s3.prior, s3.opts, [dict(attach=s3.attach, obs=c3['obs'], vis=c3['vis'], first=True)])[0]
-                    cfgs['config3_capture_7000_4000_frames'] = envelope('config3_7000', o3, c3['vis'], (c3['m'], c3['closest'], c3['coef']), shape=True)
-                    del s3
+                    for cap3 in (7000, 7001):   # (7000: the perturbed oracle runs part on 628 frames, by up to 0.68 rad; 7001: well conditioned throughout)
+                        c3 = case_inputs(f'config3_{cap3}')
+                        s3 = workload.make_solver(c3['job'])
+                        o3 = capi.chain_solve_host(s3.dev, s3.prior, s3.opts, [dict(attach=s3.attach, obs=c3['obs'], vis=c3['vis'], first=True)])[0]
+                        cfgs[f'config3_capture_{cap3}_4000_frames'] = envelope(f'config3_{cap3}', o3, c3['vis'], (c3['m'], c3['closest'], c3['coef']), shape=True)
+                        del s3
                 c4 = case_inputs('mano_72')
                 s4 = workload.make_solver(c4['job'])
                 o4 = s4.solve(c4['job']['obs'], c4['job']['vis'], chain_mode='sequential')

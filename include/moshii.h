@@ -125,9 +125,12 @@ int moshii_model_get_joints(moshii_model_t m, double* J_out);
 /* Full-mesh LBS forward, SmplModelLBS.r (smpl_fast_derivatives.py:206-218,243-244 -> psbody
  * verts_decorated): pose[F][NP] (pose *variables*), trans[F][3] -> verts[F][V][3].
  * _f64: reference-precision path (used for the canonical body of TransformedCoeffs, chmosh.py:502).
- * _f32: batched export kernel: the pose-corrective contraction (3V x 9(K-1) x F) on the f16 matrix pipe (f32 accumulate), the skinning
- *       blend on the vector pipe over per-group joint lists -- a vertex depends on <= 4-8 of the K joints, so the dense W x A product
- *       the matrix pipe would need is 4-10x the sparse work.  |error| <= 2e-5 m against _f64.
+ * _f32: batched export kernels: the pose-corrective contraction (3V x 9(K-1) x F) on the f16 matrix pipe (f32 accumulate), the skinning
+ *       blend over per-group joint lists on the f32 matrix instruction.  |error| <= 2e-5 m against _f64.
+ *       Joints whose pose variables are bitwise the same in every frame of a call (a body-only Stage-II result keeps the hand pose of
+ *       SMPL-H / SMPL-X fixed) are noticed per call and their correctives evaluated once instead of per frame -- same result to
+ *       round-off, nothing assumed about the input.  Any F: exports beyond the kernels' 2 GiB addressing range of per-call scratch
+ *       (SMPL-H: 860 000 frames) are cut into sub-calls.  One export per model handle at a time (the per-call scratch belongs to the model).
  *       Buffers host or device per flags. */
 int moshii_lbs_forward_f64(moshii_model_t m, int32_t F, const double* pose, const double* trans,
                            double* verts, uint32_t flags, void* stream);

@@ -833,7 +833,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_export(Lbs32Model lm, int V, int
         LX_STAMP(3 + t) }
         // (A branch-free variant of the block for one-round groups on interior tiles -- the same steps as straight-line code, ~60 instructions
         //  instead of ~75 and a dozen scalar branches -- was measured slower, 170-178 against 151 us per call, with and without spills in
-        //  its steady state, with counted or full waits: not kept.)
+        //  its steady state, with counted or full waits: not kept.  Where in the block the previous block's rows are read and stored --
+        //  behind the matrix instructions, behind the apply, or the read ahead of them -- makes no difference: 149-154 us all three.)
         LX_BLOCK(0) LX_BLOCK(1) LX_BLOCK(2) LX_BLOCK(3) LX_BLOCK(4) LX_BLOCK(5) LX_BLOCK(6) LX_BLOCK(7)
 #undef LX_APPLY
 #undef LX_BLEND

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- the full-length ORACLE trajectories (+ sensitivity envelopes) of BASELINE configs 3, 4 and 5, the companions of
 make_oracle_trajectories.py (config 2's six bench seeds):
 
-  config3_7000   capture 7000 of the config-3 subject (workload.make_face_job: SMPL-X, 89 markers incl. face / hand vertices, fingers +
+  config3_7000 / _7001   captures 7000 and 7001 of the config-3 subject (workload.make_face_job: SMPL-X, 89 markers incl. face / hand vertices, fingers +
                  jaw + 80 expression coefficients free = 194 unknowns per Step-2 solve; chmosh.py:560-567, 681-705), all 4000 frames
   mano_72 / _73  the two MANO hands of config 4 (34 / 33 markers, hand-PCA coefficients free, no pose prior), all 10 000 frames
   config5_1000   the first 8000 frames of config 5's 50 000-frame SMPL-H capture (seed 1000)
@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 K = 3
 EPS = 1e-13
-CASES = ('config3_7000', 'mano_72', 'mano_73', 'config5_1000')
+CASES = ('config3_7000', 'config3_7001', 'mano_72', 'mano_73', 'config5_1000')
 
 
 def case_inputs(name):

@@ -226,8 +226,9 @@ def test_config5_first_8000_frames_against_the_oracle(gpu_lib):
     assert pe.ok(rs) and rs['frames_over_1e-4_rad'] <= OVER_TOL_BUDGET, rs
 
 
-def test_config3_capture_7000_every_frame_against_the_oracle(gpu_lib):
-    """BASELINE configs[2]: the 4000-frame capture 7000 of the config-3 subject (SMPL-X, 89 markers, fingers + jaw + 80 expression
+@pytest.mark.parametrize('case', ['config3_7000', 'config3_7001'])
+def test_config3_capture_every_frame_against_the_oracle(gpu_lib, case):
+    """BASELINE configs[2]: the 4000-frame captures 7000 and 7001 of the config-3 subject (SMPL-X, 89 markers, fingers + jaw + 80 expression
     coefficients free: 194 unknowns) as the library runs it (cooperative chain) and as one workgroup, EVERY frame against the committed
     oracle trajectory + envelope -- pose variables, translation, expression coefficients, dogleg iteration counts, simulated markers.
     (Round 4's profiles/r04_config3_full_parity.txt: the device parts from the oracle at frame ~2380 by 0.39 rad.  The oracle's own runs
@@ -236,15 +237,15 @@ def test_config3_capture_7000_every_frame_against_the_oracle(gpu_lib):
     from moshpp_amd import capi, workload
     from tests import parity_envelope as pe
     from tests.golden.make_oracle_trajectories_configs import case_inputs
-    c = case_inputs('config3_7000')
+    c = case_inputs(case)
     solver = workload.make_solver(c['job'])
     assert np.array_equal(c['closest'], solver.tc.closest) and np.abs(c['coef'] - solver.tc.coef).max() < 1e-12
     ch = [dict(attach=solver.attach, obs=c['obs'], vis=c['vis'], first=True)]
     for coop in (0, 1):
         o = capi.chain_solve_host(solver.dev, solver.prior, solver.opts, ch, coop=coop)[0]
         assert np.all(o['status'] <= 0) and (o['status'] != 0).mean() < 2e-3
-        rep = _envelope_report('config3_7000', o, c['vis'], (c['m'], c['closest'], c['coef']), shape=True)
-        print(f'config 3 capture 7000 ({capi.last_launch_info()[0]}) vs oracle over {rep["frames"]} frames: {rep}')
+        rep = _envelope_report(case, o, c['vis'], (c['m'], c['closest'], c['coef']), shape=True)
+        print(f'config 3 {case} ({capi.last_launch_info()[0]}) vs oracle over {rep["frames"]} frames: {rep}')
         assert rep['frames'] == 4000 and pe.ok(rep), rep
 
 
