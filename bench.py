@@ -96,7 +96,7 @@ def compact_line(full):
         out['parity'] = _pick(pe, ('frames_checked', 'frames_outside_tolerance', 'frames_parted_on_a_knife_edge', 'frames_over_1e-4_rad',
                                    'max_dev_on_well_conditioned_frames_rad', 'worst_sequence_marker_rmse_vs_oracle_m', 'all_ok'))
         if isinstance(pe.get('configs'), dict):
-            out['parity']['configs'] = {k: (_pick(v, ('frames', 'frames_outside_tolerance', 'frames_over_1e-4_rad', 'marker_rmse_vs_oracle_m', 'ok')) if isinstance(v, dict) else str(v)[:120])
+            out['parity']['configs'] = {k.replace('_4000_frames', '').replace('_frames', ''): (_pick(v, ('frames', 'frames_outside_tolerance', 'frames_over_1e-4_rad', 'marker_rmse_vs_oracle_m', 'ok')) if isinstance(v, dict) else str(v)[:120])
                                         for k, v in pe['configs'].items()}
     pl = full.get('parity')
     if isinstance(pl, dict):
@@ -131,15 +131,27 @@ def compact_line(full):
     if isinstance(full.get('seeds'), dict):
         out['seeds_frames_per_s'] = {k: v.get('frames_per_s') for k, v in full['seeds'].items() if isinstance(v, dict)}
     out['detail'] = full.get('detail_file', 'bench_detail.json (+ stderr)')
+
+    def short(x, key=None):   # six significant digits on the line (the detail file keeps every digit); the contract's own numbers untouched
+        if isinstance(x, dict):
+            return {k: short(v, k) for k, v in x.items()}
+        if isinstance(x, list):
+            return [short(v) for v in x]
+        if isinstance(x, float) and key not in ('value', 'ms_per_step'):
+            return float(f'{x:.6g}')
+        return x
+    out = short(out)
     line = json.dumps(out, allow_nan=False, default=float)
     # never over the limit: drop the optional blocks, least important first
-    for k in ('seeds_frames_per_s', 'stagei', 'strong', 'parity_live_oracle', 'sequential_chain', 'incl_host_staging_frames_per_s',
-              'many_sequences', 'config3'):
-        if len(line) >= LINE_LIMIT and k == 'seeds_frames_per_s' and isinstance(out.get('parity'), dict):
-            out['parity'].pop('configs', None)
+    for k in ('seeds_frames_per_s', 'stagei', 'strong', 'parity_live_oracle', 'incl_host_staging_frames_per_s', 'sequential_chain',
+              ('parity', 'configs'), 'many_sequences', 'config3'):
         if len(line) < LINE_LIMIT:
             break
-        out.pop(k, None)
+        if isinstance(k, tuple):
+            if isinstance(out.get(k[0]), dict):
+                out[k[0]].pop(k[1], None)
+        else:
+            out.pop(k, None)
         line = json.dumps(out, allow_nan=False, default=float)
     assert len(line) < LINE_LIMIT, len(line)
     return line
