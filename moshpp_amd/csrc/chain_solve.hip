@@ -3104,8 +3104,32 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
     const long long _wall0 = wall_clock64();
 #endif
 
+    bool tail_cut = false;
     for (int t = 0; t <= F; ++t) {
         PROF_T(_tf);
+        if constexpr (!COOP && !XT) {   // (armed for body / finger solves only: moshii_sequence_solve runs extended solves without cooperative sweeps)
+            // the tail of a pass-1 launch (ChainDev::tail_done): most of the other chunks are done and this one is far from it -- give the chunk up
+            if (chp->tail_done != nullptr && chp->tail_can_cut != 0 && t < F && F - t > chp->tail_left) {
+                if (tid == 0) cx.scal[S_ABORT] = (double)__hip_atomic_load(chp->tail_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const bool cut = cx.scal[S_ABORT] >= (double)chp->tail_quota;
+                __syncthreads();
+                if (cut) {
+                    // finite states whose flag word matches nothing: this chunk and the next fail the verification
+                    auto spoil = [&](double* so, double flag) {
+                        for (int i = tid; i < NP; i += MOSHII_TPB) { so[i] = cx.pose[i]; so[NP + i] = cx.pose_prev[i]; }
+                        if (tid < 3) so[2 * NP + tid] = cx.trans[tid];
+                        if (tid == 3) so[2 * NP + 3] = flag;
+                        if (tid == 4) so[2 * NP + 4] = 0.0;
+                    };
+                    spoil(chp->entry_state, -1.0);      // (both slots exist for every chain of a chunked solve's first launch)
+                    spoil(chp->final_state, -2.0);
+                    if (tid == 0 && chp->tail_mark != nullptr) *chp->tail_mark = 0x7fffffff;   // (no sweep re-joins inside this chunk: its rows are a mix)
+                    tail_cut = true;
+                    break;
+                }
+            }
+        }
         if constexpr (COOP) {
             // A cooperative REPAIR chain of a chunked solve (moshii_sequence_solve's host rounds).  Everything that depends on memory other
             // chains write -- the stop request of an upstream sweep, the negotiation at a chunk boundary, whether the last two frames
@@ -3527,6 +3551,13 @@ __global__ __launch_bounds__(MOSHII_TPB, MINW) void k_chain_solve(const ChainDev
         if (tid == 0) {
             __threadfence();
             __hip_atomic_store(&chp->baton[2 * chp->chunk0], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (!COOP && !XT) {
+        if (chp->tail_done != nullptr) {   // this chain is done (or has given its chunk up: tail_cut): the others may count on it
+            (void)tail_cut;
+            __syncthreads();
+            if (tid == 0) { __threadfence(); atomicAdd(chp->tail_done, 1); }
         }
     }
     PROF_LAP(12);

@@ -985,6 +985,8 @@ __global__ void k_verify_chunks(int n, int NP, int E, const int* __restrict__ pr
             d = fmax(d, v);
         }
         if (nan) d = 2e300;          // a NaN state: reported as MOSHII_ERR_NUMERIC by the caller
+        else if (a[2 * NP + 3] == -1.0 && b[2 * NP + 3] != -2.0) d = 5e299;   // this chunk's pass-1 chain gave the chunk up (ChainDev::tail_done): re-solve it, nothing else is wrong
+        else if (b[2 * NP + 3] == -2.0) d = 4e299;                             // the predecessor was given up: its sweep hands over at the boundary
         else if (!flags_ok) d = 1e300;
     }
     red[threadIdx.x] = d;
@@ -1335,6 +1337,24 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             cd.chunk0 = c + 1;
             cd.rejoin_tol = tol;
         }
+    // The tail of pass 1 (ChainDev::tail_done): with cooperative repair sweeps the first launch's chains do not carry on, so the launch lasts as
+    // long as its slowest chunk while the CUs of the others idle.  Once all but a fifth of a chip's worth of chains have ended, a chain with
+    // more than a few frames to go gives its chunk up to the sweeps (which re-solve 16 frames in 2.5 ms).  MOSHII_TAIL_CUT=0 switches it off.
+    int n_tail_cut_armed = 0;
+    {
+        static const int tail_env = []{ const char* e = getenv("MOSHII_TAIL_CUT"); return e ? atoi(e) : -1; }();
+        const int spare = tail_env > 0 ? tail_env : std::max(8, n_cu / 5);     // (a tenth of the chip: 65.4 k frames/s on the bench's six sequences; a fifth: 65.9 k; none: 63.4 k)
+        if (!fuse && coop_rep >= 2 && rejoin && tail_env != 0 && NC >= 4 * spare)
+            for (int c = 0; c < NC; ++c) {
+                ChainDev& cd = cds[c];
+                cd.tail_done = d_fuse_count;                // (the carry-on counter: unused without the carry-on protocol, zeroed below)
+                cd.tail_quota = NC - spare;
+                cd.tail_left = 3;
+                cd.tail_can_cut = chunks[c].pred >= 0 ? 1 : 0;
+                cd.tail_mark = d_abort_at + c;
+                n_tail_cut_armed += cd.tail_can_cut;
+            }
+    }
     HIP_TRY(hipMemcpyAsync(d_pass1, cds.data(), sizeof(ChainDev) * NC, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_pred, pred.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
     {
@@ -1399,7 +1419,13 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
                 if (chunks[c].seq != seq) { seq = chunks[c].seq; in_span = false; }
                 if (!failing[c]) continue;
                 const int p = chunks[c].pred;
-                const bool g = rejoin && hdev[c] > gross_dev, pg = rejoin && failing[p] && hdev[p] > gross_dev;
+                // Chunks a pass-1 chain gave up in the launch's tail (5e299: ChainDev::tail_done) are re-solved like gross misses -- they
+                // are the hard stretches, their sweeps run 30-70 frames -- but neither they nor their successors (4e299: the entry state
+                // stands against a spoiled end state; the sweep hands over at the boundary) say anything about the chunks behind them:
+                // as predecessors they do not hold back a gross miss's chain (they did: a cascade of one round per territory).
+                const bool aftercut = hdev[c] == 4e299, p_given_up = failing[p] && hdev[p] >= 1e299 && hdev[p] < 1e300;
+                const bool g = rejoin && hdev[c] > gross_dev, pg = rejoin && failing[p] && hdev[p] > gross_dev && !p_given_up;
+                if (rejoin && aftercut) continue;
                 if (!rejoin) { if (!failing[p]) { todo.push_back(c); todo_gross.push_back(0); } continue; }
                 if (g) { if (!pg) { todo.push_back(c); todo_gross.push_back(1); in_span = true; span_start = chunks[c].s; } }
                 else if (!in_span || (far_frames > 0 && chunks[c].s - span_start >= far_frames && !failing[p])) { todo.push_back(c); todo_gross.push_back(0); }

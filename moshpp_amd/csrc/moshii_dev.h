@@ -168,6 +168,16 @@ struct ChainDev {
     int* fuse_count;            // device: number of chains that carried on
     double fuse_tol;
     CoopDev coop;               // cooperative chains only (G >= 2 ... or 1 for tests); zero otherwise
+    // Pass-1 chains of a chunked solve whose repairs are cooperative sweeps (round 6): the launch ends with its SLOWEST chunk -- 250 chunks of
+    // the bench sequence: 154 .. 222 dogleg iterations, the launch takes 21.8 ms where the median chunk needs 13.4 (tools/first_frame.py) --
+    // with nine CUs in ten idle at the end.  Every chain counts itself in tail_done when it ends; a chain that finds tail_quota others done
+    // while it has more than tail_left frames to go gives up: it leaves spoiled (finite, never-matching) entry / final states and a mark that
+    // no sweep may re-join inside its chunk, so that the host's rounds re-solve the chunk from its predecessor's end state -- a cooperative
+    // sweep of 16 frames costs 2.5 ms beside the sweeps that run anyway.
+    int* tail_done;             // device counter, or null
+    int tail_quota, tail_left;
+    int tail_can_cut;           // 0: this chain only counts (a sequence's first chunk has no predecessor to be re-solved from)
+    int* tail_mark;             // device: abort_at slot of this chain's chunk
 };
 
 // LDS layout of the chain kernel: offsets in doubles from the dynamic-LDS base (all multiples of 2).

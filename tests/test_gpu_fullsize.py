@@ -504,6 +504,39 @@ def test_chunked_solve_is_exact_under_gpu_contention(gpu_lib):
 
 
 @pytest.mark.gpu
+def test_chunks_given_up_in_the_tail_of_the_first_launch_are_resolved_exactly(gpu_lib):
+    """Round 6: the first launch of a chunked solve used to last as long as its slowest chunk (250 chunks of the bench sequence: the median
+    needs 13.4 ms, the launch took 21.8).  Now a chain that still has frames to go when all but a fifth of a chip's worth of the others
+    have ended gives its chunk up (ChainDev::tail_done): spoiled hand-off states, a mark that no sweep re-joins inside the chunk, and the
+    host's rounds re-solve it from its predecessor's end state.  Here with the quota forced low (MOSHII_TAIL_CUT=62: chains give up as soon
+    as 188 of 250 are done -- a fifth of the chunks), in a process of its own (the variable is read once): the repair trace must show
+    given-up chunks (deviation code 5e+299), and the stitched result must be the sequential chain's as always."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys\nsys.path.insert(0, '.')\nimport numpy as np\nfrom moshpp_amd import workload\n"
+            "worst = 0.0\n"
+            "for seed in (1000, 5):\n"
+            "    job = workload.make_job('smplh', 4000, 53, seed=seed); solver = workload.make_solver(job)\n"
+            "    seq = solver.solve(job['obs'], job['vis'], chain_mode='sequential')\n"
+            "    for _ in range(2):\n"
+            "        chk = solver.solve(job['obs'], job['vis'], chain_mode='chunked', verify_tol=1e-9)\n"
+            "        assert np.array_equal(chk['status'], seq['status']) and np.array_equal(chk['iters'][:, 0] > 0, seq['iters'][:, 0] > 0)\n"
+            "        worst = max(worst, float(np.abs(chk['fullpose'] - seq['fullpose']).max()), float(np.abs(chk['trans'] - seq['trans']).max()))\n"
+            "        print('REPORT', seed, chk['chunk_report']['n_repaired'], chk['chunk_report']['repair_rounds'], chk['chunk_report']['max_handoff_dev'], flush=True)\n"
+            "print('WORST', worst, flush=True)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOSHII_TAIL_CUT='62', MOSHII_TRACE_REPAIR='1')
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    worst = float([l for l in p.stdout.splitlines() if l.startswith('WORST')][0].split()[1])
+    given_up = p.stderr.count(':5e+299:')
+    print(p.stdout.strip().replace('\n', ' | '), f'| chunks given up (trace): {given_up}')
+    assert given_up >= 8, p.stderr[-2000:]          # the path was taken, many times
+    assert worst < 5e-9, worst
+
+
+@pytest.mark.gpu
 def test_default_cooperative_chain_beside_a_competing_process(gpu_lib):
     """The drop-in default -- ONE sequential chain on six workgroups that wait for each other through device memory -- while another
     process keeps the GPU busy (how the reference is deployed: one process per capture, several per device, mosh_head.py:584-589):
