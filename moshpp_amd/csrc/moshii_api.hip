@@ -1344,7 +1344,13 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     {
         static const int tail_env = []{ const char* e = getenv("MOSHII_TAIL_CUT"); return e ? atoi(e) : -1; }();
         const int spare = tail_env > 0 ? tail_env : std::max(8, n_cu / 5);     // (a tenth of the chip: 65.4 k frames/s on the bench's six sequences; a fifth: 65.9 k; none: 63.4 k)
-        if (!fuse && coop_rep >= 2 && rejoin && tail_env != 0 && NC >= 4 * spare)
+        // Only where it pays: every chunk on a CU of its own from the start (one wave of workgroups: the order of finishing is the order of
+        // speed -- with 2 048 chunks the last to finish are simply the last to have started: measured 867 -> 617 k frames/s on the
+        // 256-sequence job when armed there) and chunks so short that re-solving one costs less than the wait it ends (a 16-frame chunk:
+        // 2.5 ms of a cooperative sweep; the 195-frame chunks of a 50 000-frame sequence: 30 ms -- 372 -> 226 k frames/s when armed).
+        int longest = 0;
+        for (int c = 0; c < NC; ++c) longest = std::max(longest, chunks[c].e - chunks[c].s);
+        if (!fuse && coop_rep >= 2 && rejoin && tail_env != 0 && NC >= 4 * spare && NC <= n_cu && longest <= 32)
             for (int c = 0; c < NC; ++c) {
                 ChainDev& cd = cds[c];
                 cd.tail_done = d_fuse_count;                // (the carry-on counter: unused without the carry-on protocol, zeroed below)
