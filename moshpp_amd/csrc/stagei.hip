@@ -258,24 +258,43 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
     for (int i = TID; i < 3 * d.K; i += NT) sJb[i] = Jb[i];
     for (int i = TID; i < d.K; i += NT) spar[i] = p.parents[i];
     SYNC();
-    if (TID == 0) {
-        for (int i = 0; i < 9; ++i) sRw[i] = sRl[i];
-        for (int a = 0; a < 3; ++a) stw[a] = sJb[a];
-        for (int j = 1; j < d.K; ++j) {
-            int pa = spar[j];
-            matmul3(sRw + 9 * pa, sRl + 9 * j, sRw + 9 * j);
-            double dj[3] = {sJb[3 * j] - sJb[3 * pa], sJb[3 * j + 1] - sJb[3 * pa + 1], sJb[3 * j + 2] - sJb[3 * pa + 2]}, o[3];
-            matvec3(sRw + 9 * pa, dj, o);
-            for (int a = 0; a < 3; ++a) stw[3 * j + a] = o[a] + stw[3 * pa + a];
-        }
+    // the tree level by level, one thread per joint of the level (thread 0 walking all K joints through LDS was a quarter of this kernel)
+    SHARED int sdep[64]; SHARED int smaxd;
+    for (int j = TID; j < d.K; j += NT) {
+        int dep = 0;
+        for (int a = j; a > 0; a = spar[a]) ++dep;
+        sdep[j] = dep;
     }
     SYNC();
+    if (TID == 0) { int m = 0; for (int j = 0; j < d.K; ++j) m = (sdep[j] > m) ? sdep[j] : m; smaxd = m; }
+    SYNC();
+    const int maxd = smaxd;
+    for (int lvl = 0; lvl <= maxd; ++lvl) {
+        for (int j = TID; j < d.K; j += NT) {
+            if (sdep[j] != lvl) continue;
+            if (j == 0) {
+                for (int i = 0; i < 9; ++i) sRw[i] = sRl[i];
+                for (int a = 0; a < 3; ++a) stw[a] = sJb[a];
+            } else {
+                int pa = spar[j];
+                matmul3(sRw + 9 * pa, sRl + 9 * j, sRw + 9 * j);
+                double dj[3] = {sJb[3 * j] - sJb[3 * pa], sJb[3 * j + 1] - sJb[3 * pa + 1], sJb[3 * j + 2] - sJb[3 * pa + 2]}, o[3];
+                matvec3(sRw + 9 * pa, dj, o);
+                for (int a = 0; a < 3; ++a) stw[3 * j + a] = o[a] + stw[3 * pa + a];
+            }
+        }
+        SYNC();
+    }
     for (int i = TID; i < 9 * d.K; i += NT) Rw[i] = sRw[i];
     for (int i = TID; i < 3 * d.K; i += NT) tw[i] = stw[i];
     SYNC();
-    // q_je = dt_je - Rw_j JS_je, dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par): one thread per coefficient walks the tree
-    for (int e = TID; e < d.nb; e += NT) {
-        for (int j = 0; j < d.K; ++j) {
+    // q_je = dt_je - Rw_j JS_je, dt_0 = JS_0, dt_j = dt_par + Rw_par (JS_j - JS_par): level by level, one thread per (joint, coefficient); the
+    // parent's q is read back from global memory behind the level's barrier (one thread per coefficient walking the whole tree waited for a
+    // round trip to the L2 at every joint: ~50 of this kernel's 67 us)
+    for (int lvl = 0; lvl <= maxd; ++lvl) {
+        for (int it = TID; it < d.K * d.nb; it += NT) {
+            const int j = it / d.nb, e = it - j * d.nb;
+            if (sdep[j] != lvl) continue;
             const double* js = p.JS + ((size_t)j * d.nb + e) * 3;
             double dt[3];
             if (j == 0) { for (int a = 0; a < 3; ++a) dt[a] = js[a]; }
@@ -292,6 +311,7 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
             matvec3(sRw + 9 * j, js, rj);
             for (int a = 0; a < 3; ++a) q[((size_t)j * d.nb + e) * 3 + a] = dt[a] - rj[a];
         }
+        SYNC();
     }
     for (int i = TID; i < d.nfeat; i += NT) {
         int k = 1 + i / 9, c = i % 9;
@@ -325,11 +345,13 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
 // vertex evaluation: grid (ceil(nlist / S1_TPB), number of poses); pose index z = zbase + BY, list = vlist[z], nlist entries.
 // mode 0: positions only into `out` [nlist][3] (canonical full mesh); 1: v; 2: v + dvs; 3: v + dvs + dv (pose Jacobian)
 // ---------------------------------------------------------------------------------------------------------------------------
-KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out, int full_mesh) {
+// vl: lanes that share one vertex's pose-corrective dot products (S1_VL; 1 for the canonical full mesh, whose pose has none: 6 890 vertices on
+// one lane in 64 were 80 us per evaluation)
+KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out, int full_mesh, int vl) {
     SHARED double part[S1_TPB * 3];
     int z = zbase + BY;
-    const int lane = TID % S1_VL, wv = TID / S1_VL;
-    int a = (BX * NT + TID) / S1_VL;
+    const int lane = TID % vl, wv = TID / vl;
+    int a = (BX * NT + TID) / vl;
     const bool valid = a < nlist;
     int v = 0;
     const double* Rw = p.Rw + (size_t)z * d.K * 9; const double* tw = p.tw + (size_t)z * d.K * 3;
@@ -347,7 +369,7 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
             vs[c] = sacc;
             const double* pd = p.posedirs + ((size_t)v * 3 + c) * d.nfeat;
             double t = 0;
-            if (!fz) for (int i = lane; i < d.nfeat; i += S1_VL) t += pd[i] * feat[i];      // lanes split the 9(K-1) features
+            if (!fz) for (int i = lane; i < d.nfeat; i += vl) t += pd[i] * feat[i];      // lanes split the 9(K-1) features
             part[TID * 3 + c] = t;
         }
     }
@@ -355,7 +377,7 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
     if (!valid || lane != 0) return;
     for (int c = 0; c < 3; ++c) {
         double t = 0;
-        for (int l = 0; l < S1_VL; ++l) t += part[(wv * S1_VL + l) * 3 + c];
+        for (int l = 0; l < vl; ++l) t += part[(wv * vl + l) * 3 + c];
         vp[c] = vs[c] + t;
     }
     int jj[S1_NWMAX]; double wj[S1_NWMAX], xj[S1_NWMAX][3];
@@ -830,17 +852,12 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
     SYNC();
     int o0 = p.obs_off[f], nobs = p.obs_off[f + 1] - o0;
     const int colbase = d.o_pose + f * npid;
-    // residual
-    for (int i = TID; i < 3 * nobs; i += NT) {
-        int k = i / 3, a = i % 3, m = p.obs_ids[o0 + k];
-        const double* v0 = vv + 9 * m; const double* Fp = Lb + 36 * m + 27; const double* c = p.coef + 3 * m;
-        double sim = v0[a] + c[0] * Fp[a] + c[1] * Fp[3 + a] + c[2] * Fp[6 + a];
-        p.r[d.r_data + 3 * o0 + i] = (p.obs[3 * (size_t)(o0 + k) + a] - sim) * p.w_data;
-    }
-    if (want_J) {
+    // The pose columns of the data rows -- nobs x NP items of nine strided loads each, 24 a thread on one workgroup: 70 of a Jacobian call's 130 us
+    // -- are dealt over the workgroups (frame, BY = 0 .. gridDim.y - 1); everything else is workgroup (frame, 0)'s.
+    const int part = BY, nparts = (int)gridDim.y;
+    auto pose_columns = [&]() {
         const double* dv = p.dv + (size_t)f * 3 * M * 3 * d.P;
-        // pose columns
-        for (int it = TID; it < nobs * d.NP; it += NT) {
+        for (int it = part * NT + TID; it < nobs * d.NP; it += NT * nparts) {
             int k = it / d.NP, pid = it % d.NP, col = p.colmap[pid];
             if (col < 0) continue;
             int m = p.obs_ids[o0 + k];
@@ -859,6 +876,17 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
             }
             for (int a = 0; a < 3; ++a) p.Jm[(size_t)(d.r_data + 3 * (o0 + k) + a) * d.ldn + colbase + col] = -p.w_data * o[a];
         }
+    };
+    if (part != 0) { if (want_J) pose_columns(); return; }
+    // residual
+    for (int i = TID; i < 3 * nobs; i += NT) {
+        int k = i / 3, a = i % 3, m = p.obs_ids[o0 + k];
+        const double* v0 = vv + 9 * m; const double* Fp = Lb + 36 * m + 27; const double* c = p.coef + 3 * m;
+        double sim = v0[a] + c[0] * Fp[a] + c[1] * Fp[3 + a] + c[2] * Fp[6 + a];
+        p.r[d.r_data + 3 * o0 + i] = (p.obs[3 * (size_t)(o0 + k) + a] - sim) * p.w_data;
+    }
+    if (want_J) {
+        pose_columns();
         // trans, latent marker, betas
         for (int it = TID; it < nobs * 3; it += NT) {
             int k = it / 3, a = it % 3, m = p.obs_ids[o0 + k];
@@ -949,6 +977,7 @@ KERNEL k_s1_nzflags(const double* Jm, int R, int n, int ldn, int* flags) {
     if (TID == 0) { int a = 0; for (int t = 0; t < NT; ++t) a |= any[t]; flags[rc * ((n + S1_T - 1) / S1_T) + cb] = a; }
 }
 
+#define S1_SYRK_CHUNKS 1024   // row chunks whose flags a tile keeps in LDS (32 768 rows; beyond: read one by one)
 // A = J^T J, lower tiles (grid (nt, nt), tile (BX >= BY)); 256 threads, 2 x 2 outputs each; mirrored on write
 KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A, const int* flags) {
     int ti = BX, tj = BY;
@@ -957,22 +986,47 @@ KERNEL k_s1_syrk(const double* Jm, int R, int n, int ldn, double* A, const int* 
     int tx = TID % 16, ty = TID / 16;
     double acc[2][2] = {{0, 0}, {0, 0}};
     const int ncb = (n + S1_T - 1) / S1_T;
-    for (int r0 = 0; r0 < R; r0 += S1_T) {
-        const int* fl = flags + (r0 / S1_T) * ncb;
-        if (!fl[ti] || !fl[tj]) continue;               // uniform over the workgroup
-        for (int e = TID; e < S1_T * S1_T; e += NT) {
-            int rr = e / S1_T, cc = e % S1_T;
-            int r = r0 + rr, ci = ti * S1_T + cc, cj = tj * S1_T + cc;
-            Si[rr][cc] = (r < R && ci < n) ? Jm[(size_t)r * ldn + ci] : 0.0;
-            Sj[rr][cc] = (r < R && cj < n) ? Jm[(size_t)r * ldn + cj] : 0.0;
+    // which row chunks hold anything for this tile: fetched by all threads at once, so that the loop below knows its next chunk ahead of time
+    SHARED unsigned char use[S1_SYRK_CHUNKS];
+    const int nrc = (R + S1_T - 1) / S1_T;
+    for (int rc = TID; rc < nrc && rc < S1_SYRK_CHUNKS; rc += NT) use[rc] = (flags[rc * ncb + ti] && flags[rc * ncb + tj]) ? 1 : 0;
+    __syncthreads();
+    // the next chunk's entries are fetched into registers while this one's products are formed (one chunk at a time the tile waited ~1.5 us for
+    // every chunk's loads: 60-94 chunks on the shared columns' tiles)
+    auto used = [&](int rc) -> bool {
+        if (rc < S1_SYRK_CHUNKS) return use[rc] != 0;
+        const int* fl = flags + rc * ncb; return fl[ti] && fl[tj];
+    };
+    auto next_used = [&](int rc) { while (rc < nrc && !used(rc)) ++rc; return rc; };
+    constexpr int PER = S1_T * S1_T / 256;      // (launched with 256 threads)
+    double ri[PER], rj[PER];
+    auto fetch = [&](int rc) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = TID + u * 256, rr = e / S1_T, cc = e % S1_T;
+            const int r = rc * S1_T + rr, ci = ti * S1_T + cc, cj = tj * S1_T + cc;
+            ri[u] = (r < R && ci < n) ? Jm[(size_t)r * ldn + ci] : 0.0;
+            rj[u] = (r < R && cj < n) ? Jm[(size_t)r * ldn + cj] : 0.0;
+        }
+    };
+    int rc = next_used(0);
+    if (rc < nrc) fetch(rc);
+    while (rc < nrc) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = TID + u * 256, rr = e / S1_T, cc = e % S1_T;
+            Si[rr][cc] = ri[u]; Sj[rr][cc] = rj[u];
         }
         __syncthreads();
+        const int nx = next_used(rc + 1);
+        if (nx < nrc) fetch(nx);
 #pragma unroll 8
         for (int rr = 0; rr < S1_T; ++rr) {
             double a0 = Si[rr][ty], a1 = Si[rr][ty + 16], b0 = Sj[rr][tx], b1 = Sj[rr][tx + 16];
             acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
         }
         __syncthreads();
+        rc = nx;
     }
     for (int u = 0; u < 2; ++u) for (int w = 0; w < 2; ++w) {
         int i = ti * S1_T + ty + 16 * u, j = tj * S1_T + tx + 16 * w;
@@ -1009,6 +1063,18 @@ KERNEL k_s1_gemv(const double* Mx, const double* x, int n, int ld, double* y) {
     if (TID == 0) { double t = 0; for (int k = 0; k < NT; ++k) t += red[k]; y[r] = t; }
 }
 
+// the value lane `src` (a compile-time constant after unrolling) holds, in every lane: two v_readlane into a scalar pair (a handful of cycles;
+// __shfl goes through ds_bpermute: ~2 500 of them made k_s1_chol_diag a 69 us kernel).  The CPU emulation keeps the shuffle.
+DEVFN double s1_bcast(double v, int src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+#else
+    return __shfl(v, src);
+#endif
+}
+
 // Blocked right-looking Cholesky of A[n][n] (lower), panel width S1_PB.  Per panel: k_s1_chol_diag (one workgroup: the diagonal
 // block is factored and inverted in LDS), k_s1_chol_trsm (every row below: its 32 entries times the inverse) and k_s1_chol_update (one 32 x 32 tile of the
 // trailing matrix per workgroup: A_ik -= L_i L_k^T).  status[1] = 1 if a pivot is not positive.
@@ -1023,14 +1089,14 @@ __global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, d
     int bad = 0;
 #pragma unroll
     for (int c = 0; c < S1_PB; ++c) {
-        double piv = __shfl(a[c], c);
+        double piv = s1_bcast(a[c], c);
         if (!(piv > 0)) { bad = 1; piv = 1.0; }
         const double dd = sqrt(piv);
         a[c] = (r == c) ? dd : a[c] / dd;            // rows above the diagonal hold zeros here
         const double lrc = a[c];
 #pragma unroll
         for (int k = c + 1; k < S1_PB; ++k) {
-            const double lkc = __shfl(a[c], k);
+            const double lkc = s1_bcast(a[c], k);
             if (r >= k) a[k] -= lrc * lkc;
         }
     }
@@ -1045,8 +1111,8 @@ __global__ void __launch_bounds__(64) k_s1_chol_diag(double* A, int n, int j0, d
     for (int rr = 0; rr < S1_PB; ++rr) {
         double sacc = (rr == r) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < S1_PB; ++k) if (k < rr) sacc -= __shfl(a[k], rr) * x[k];
-        const double lrr = __shfl(a[rr], rr);   // (taken by every lane: the lanes left of the diagonal do not need it, but a shuffle inside
+        for (int k = 0; k < S1_PB; ++k) if (k < rr) sacc -= s1_bcast(a[k], rr) * x[k];
+        const double lrr = s1_bcast(a[rr], rr);   // (taken by every lane: the lanes left of the diagonal do not need it, but a shuffle inside
         x[rr] = (rr < r) ? 0.0 : sacc / lrr;    //  the conditional is a divergent collective to the CPU emulation of this file)
     }
     double* Di = dinv + (size_t)(j0 / S1_PB) * S1_PB * S1_PB;
@@ -1160,60 +1226,110 @@ KERNEL k_s1_tri_solve(const double* L, int n, const double* dinv, const double* 
 // ~30), and every frame back-substitutes d_f = L_f^{-T} (z_f - Y_f d_s).
 // ---------------------------------------------------------------------------------------------------------------------------
 KERNEL k_s1_elim(const double* A, int n, const double* g, const int* fcols, int fs, const int* scols, int ns, int nsp,
-                 double* Linv, double* Y, double* z, int* status, int fbase) {       // grid frames, dynamic LDS (fs (fs + 1) + fs) doubles
+                 double* Linv, double* Y, double* z, int* status, int fbase) {       // grid frames, dynamic LDS (fs (fs + 1) + 2 fs) doubles
     DYN_LDS(lds);
     const int f = fbase + BX, ld = fs + 1;
-    double* Lm = lds; double* tmp = lds + (size_t)fs * ld;
+    double* Lm = lds; double* Bb = lds + (size_t)fs * ld;      // Bb: two columns of fs doubles
     const int* fc = fcols + (size_t)f * fs;
     for (int e = TID; e < fs * fs; e += NT) { int i = e / fs, j = e % fs; Lm[i * ld + j] = (j <= i) ? A[(size_t)fc[i] * n + fc[j]] : 0.0; }
     SYNC();
-    for (int c = 0; c < fs; ++c) {                       // Cholesky, right-looking, in LDS
-        if (TID == 0) { double v = Lm[c * ld + c]; if (!(v > 0)) { status[1] = 1; v = 1.0; } Lm[c * ld + c] = sqrt(v); }
-        SYNC();
-        const double ip = 1.0 / Lm[c * ld + c];
-        for (int r = c + 1 + TID; r < fs; r += NT) Lm[r * ld + c] *= ip;
-        SYNC();
-        const int rem = fs - c - 1;
-        for (int e = TID; e < rem * rem; e += NT) {
-            int r = c + 1 + e / rem, k = c + 1 + e % rem;
-            if (k <= r) Lm[r * ld + k] -= Lm[r * ld + c] * Lm[k * ld + c];
+    // Cholesky, right-looking, in LDS.  ONE barrier a column (there were three: pivot, column scaling, update): every thread forms the pivot's
+    // root and reciprocal for itself, the update multiplies the column's entries by it on the fly, and the column gets its final values during the
+    // NEXT column's step, when nobody reads it any more.  The same operations on the same operands as before: the same bits.
+    double ip_prev = 0.0, d_prev = 0.0;
+    for (int c = 0; c < fs; ++c) {
+        double v = Lm[c * ld + c];
+        if (!(v > 0)) { if (TID == 0) status[1] = 1; v = 1.0; }
+        const double dd = sqrt(v), ip = 1.0 / dd;
+        if (c > 0) {
+            for (int r = c + TID; r < fs; r += NT) Lm[r * ld + c - 1] *= ip_prev;
+            if (TID == 0) Lm[(c - 1) * ld + c - 1] = d_prev;
         }
+        for (int r = c + 1 + TID / 16; r < fs; r += NT / 16) {      // (entries (r, k <= r) dealt 16 columns wide: no index division, no idle upper half)
+            const double lr = Lm[r * ld + c] * ip;
+            for (int k = c + 1 + TID % 16; k <= r; k += 16) { const double lk = Lm[k * ld + c] * ip; Lm[r * ld + k] -= lr * lk; }
+        }
+        ip_prev = ip; d_prev = dd;
         SYNC();
     }
-    for (int j = fs - 1; j >= 0; --j) {                  // in-place inverse of the lower factor (column by column, last first)
-        if (TID == 0) Lm[j * ld + j] = 1.0 / Lm[j * ld + j];
-        for (int i = j + 1 + TID; i < fs; i += NT) tmp[i] = Lm[i * ld + j];
-        SYNC();
-        const double ajj = Lm[j * ld + j];
-        for (int i = j + 1 + TID; i < fs; i += NT) {     // (trailing inverse) . column, trailing block already inverted
+    if (TID == 0) Lm[(fs - 1) * ld + fs - 1] = d_prev;
+    SYNC();
+    // in-place inverse of the lower factor, column by column, last first: (trailing inverse) . column.  One barrier a column (there were two): a
+    // step leaves its column in a buffer, from which the next step reads it while it writes it into the matrix.
+    for (int j = fs - 1; j >= 0; --j) {
+        double* Bc = Bb + (size_t)(j & 1) * fs;
+        const double* Bn = Bb + (size_t)((j + 1) & 1) * fs;     // column j + 1 of the inverse (rows j + 1 ..), the previous step's
+        const double ajj = 1.0 / Lm[j * ld + j];
+        for (int i = j + 1 + TID; i < fs; i += NT) {
             double sacc = 0;
-            for (int k = j + 1; k <= i; ++k) sacc += Lm[i * ld + k] * tmp[k];
-            Lm[i * ld + j] = -ajj * sacc;
+            sacc += Bn[i] * Lm[(j + 1) * ld + j];
+            int k = j + 2;
+            for (; k + 3 <= i; k += 4) {     // (four terms' operands in flight; the sum in k order as before)
+                const double a0 = Lm[i * ld + k], a1 = Lm[i * ld + k + 1], a2 = Lm[i * ld + k + 2], a3 = Lm[i * ld + k + 3];
+                const double b0 = Lm[k * ld + j], b1 = Lm[(k + 1) * ld + j], b2 = Lm[(k + 2) * ld + j], b3 = Lm[(k + 3) * ld + j];
+                sacc += a0 * b0; sacc += a1 * b1; sacc += a2 * b2; sacc += a3 * b3;
+            }
+            for (; k <= i; ++k) sacc += Lm[i * ld + k] * Lm[k * ld + j];
+            Bc[i] = -ajj * sacc;
         }
+        if (TID == 0) Bc[j] = ajj;
+        if (j + 1 < fs) for (int i = j + 1 + TID; i < fs; i += NT) Lm[i * ld + j + 1] = Bn[i];
         SYNC();
     }
+    for (int i = TID; i < fs; i += NT) Lm[i * ld] = Bb[i];
+    SYNC();
     double* Lg = Linv + (size_t)f * fs * fs;
     for (int e = TID; e < fs * fs; e += NT) { int i = e / fs, j = e % fs; Lg[e] = (j <= i) ? Lm[i * ld + j] : 0.0; }
-    // Y_f = L^{-1} A_fs (+ the gradient as one more column -> z_f)
-    for (int e = TID; e < fs * (ns + 1); e += NT) {
-        int i = e / (ns + 1), c = e % (ns + 1);
+}
+// Y_f = L_f^{-1} A_fs (+ the gradient as one more column -> z_f) with the inverse factors k_s1_elim left in Linv.  grid (frames, ceil((ns + 1) / 32)):
+// a workgroup stages the inverse factor and its 32 columns of A_fs in LDS (dynamic: fs (fs + 1) + 32 fs doubles); thread = (column, rows i = TID / 32
+// mod NT / 32); the sums run over k ascending as they did inside k_s1_elim (where this was 44 items a thread on one workgroup per frame, operands from L2).
+#define S1_YC 32
+KERNEL k_s1_elim_y(const double* A, int n, const double* g, const int* fcols, int fs, const int* scols, int ns, int nsp,
+                   const double* Linv, double* Y, double* z, int fbase) {
+    DYN_LDS(lds);
+    const int f = fbase + BX, ld = fs + 1, c0 = BY * S1_YC;
+    double* Lm = lds; double* As = lds + (size_t)fs * ld;      // As[k][32]
+    const int* fc = fcols + (size_t)f * fs;
+    const double* Lg = Linv + (size_t)f * fs * fs;
+    for (int e = TID; e < fs * fs; e += NT) { int i = e / fs, j = e % fs; Lm[i * ld + j] = Lg[e]; }
+    for (int e = TID; e < fs * S1_YC; e += NT) {
+        const int k = e / S1_YC, c = c0 + e % S1_YC;
+        As[e] = (c < ns) ? A[(size_t)fc[k] * n + scols[c]] : (c == ns ? g[fc[k]] : 0.0);
+    }
+    SYNC();
+    const int cl = TID % S1_YC, c = c0 + cl;
+    if (c > ns) return;
+    for (int i = TID / S1_YC; i < fs; i += NT / S1_YC) {
         double sacc = 0;
-        if (c < ns) { const int sc = scols[c]; for (int k = 0; k <= i; ++k) sacc += Lm[i * ld + k] * A[(size_t)fc[k] * n + sc]; }
-        else for (int k = 0; k <= i; ++k) sacc += Lm[i * ld + k] * g[fc[k]];
+        for (int k = 0; k <= i; ++k) sacc += Lm[i * ld + k] * As[k * S1_YC + cl];
         if (c < ns) Y[((size_t)f * fs + i) * nsp + c] = sacc; else z[(size_t)f * fs + i] = sacc;
     }
 }
 
 // S = A_ss - T (T = Y^T Y from the tiled SYRK), h = g_s - Y^T z                                  grid ceil(ns / S1_TPB)
+// grid ns: workgroup c writes row c of S along the row (one thread per row and a loop over its ns entries was 270 us of strided stores);
+// the first ceil(ns / NT) workgroups also form h, one column per thread, rows in order as before
 KERNEL k_s1_schur_sub(const double* A, int n, const double* g, const int* scols, int ns, const double* T, const double* Y, int nsp,
                       const double* z, int rows, double* S, double* h) {
-    int c = BX * NT + TID;
+    {
+        const int c = BX;
+        const size_t arow = (size_t)scols[c] * n;
+        for (int k = TID; k < ns; k += NT) S[(size_t)c * ns + k] = A[arow + scols[k]] - T[(size_t)c * ns + k];
+    }
+    const int c = BX * NT + TID;
     if (c >= ns) return;
-    const int sc = scols[c];
-    for (int k = 0; k < ns; ++k) S[(size_t)c * ns + k] = A[(size_t)sc * n + scols[k]] - T[(size_t)c * ns + k];
     double sacc = 0;
-    for (int r = 0; r < rows; ++r) sacc += Y[(size_t)r * nsp + c] * z[r];
-    h[c] = g[sc] - sacc;
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {      // eight rows' operands in flight, the sum in row order as before
+        double yv[8], zv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { yv[u] = Y[(size_t)(r + u) * nsp + c]; zv[u] = z[r + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += yv[u] * zv[u];
+    }
+    for (; r < rows; ++r) sacc += Y[(size_t)r * nsp + c] * z[r];
+    h[c] = g[scols[c]] - sacc;
 }
 
 // d_f = L_f^{-T} (z_f - Y_f d_s), scattered into the full step; block 0 also scatters d_s                        grid F
@@ -1403,8 +1519,14 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     }
     p.wt_init = pool.put(wt_init_eff.data(), M, st);
     hipStreamSynchronize(st);
-    p.pose = pool.get<double>((size_t)d.NPZ * NP); p.trans = pool.get<double>((size_t)d.NPZ * 3);
-    p.ml = pool.get<double>(3 * M); p.betas = pool.get<double>((size_t)std::max(1, nb) * (d.per_frame ? d.NPZ : 1));
+    // the evaluation point in ONE allocation (pose | trans | latent markers | betas, each part on a 128-byte boundary): one copy per trial point
+    // instead of four (565 small copies a solve were ~3 ms of host time)
+    const size_t pt_pose = (size_t)d.NPZ * NP, pt_trans = (size_t)d.NPZ * 3, pt_ml = (size_t)3 * M, pt_betas = (size_t)std::max(1, nb) * (d.per_frame ? d.NPZ : 1);
+    auto up16 = [](size_t c) { return (c + 15) & ~(size_t)15; };
+    const size_t pt_o_trans = up16(pt_pose), pt_o_ml = pt_o_trans + up16(pt_trans), pt_o_betas = pt_o_ml + up16(pt_ml), pt_total = pt_o_betas + up16(pt_betas);
+    double* d_point = pool.get<double>(pt_total);
+    p.pose = d_point; p.trans = d_point ? d_point + pt_o_trans : nullptr;
+    p.ml = d_point ? d_point + pt_o_ml : nullptr; p.betas = d_point ? d_point + pt_o_betas : nullptr;
     p.J0 = pool.get<double>(3 * K); p.JS = pool.get<double>((size_t)std::max(1, K * nb * 3));
     p.fp = pool.get<double>((size_t)d.NPZ * d.P); p.Rl = pool.get<double>((size_t)d.NPZ * K * 9); p.Jl = pool.get<double>((size_t)d.NPZ * K * 9);
     p.Rw = pool.get<double>((size_t)d.NPZ * K * 9); p.tw = pool.get<double>((size_t)d.NPZ * K * 3); p.feat = pool.get<double>((size_t)d.NPZ * d.nfeat);
@@ -1453,15 +1575,17 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
     if (ds->betas_init && !d.per_frame) for (int e = 0; e < nb; ++e) betas[e] = ds->betas_init[e];
     std::vector<int> pose_ids, finger_ids, colmap(NP, -1);
 
+    std::vector<double> hpoint(pt_total, 0.0);
     auto upload_point = [&]() {
-        hipMemcpyAsync(p.pose, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, st);
-        hipMemcpyAsync(p.trans, trans.data(), trans.size() * 8, hipMemcpyHostToDevice, st);
-        hipMemcpyAsync(p.ml, ml.data(), ml.size() * 8, hipMemcpyHostToDevice, st);
-        hipMemcpyAsync(p.betas, betas.data(), betas.size() * 8, hipMemcpyHostToDevice, st);
+        memcpy(hpoint.data(), pose.data(), std::min(pose.size(), pt_pose) * 8);
+        memcpy(hpoint.data() + pt_o_trans, trans.data(), std::min(trans.size(), pt_trans) * 8);
+        memcpy(hpoint.data() + pt_o_ml, ml.data(), std::min(ml.size(), pt_ml) * 8);
+        memcpy(hpoint.data() + pt_o_betas, betas.data(), std::min(betas.size(), pt_betas) * 8);
+        hipMemcpyAsync(d_point, hpoint.data(), pt_total * 8, hipMemcpyHostToDevice, st);
     };
     auto canonical = [&]() {   // pose kernels + canonical mesh at the uploaded point
         LAUNCH(k_s1_pose, d.NPZ, 1, S1_TPB, st, d, p);
-        LAUNCH(k_s1_verts, (d.V * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.V, 0, p.can, 1);
+        LAUNCH(k_s1_verts, (d.V + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.V, 0, p.can, 1, 1);
     };
     // evaluation of residual (and Jacobian) at the uploaded point
     int shared_rows_on = 1;   // 0 during the extra rigid adjustment: the init / beta / surf / head rows are not part of its objective
@@ -1471,14 +1595,14 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         LAUNCH(k_s1_pick3, 1, 1, S1_TPB, st, d, p, p.cl8, p.cl);
         LAUNCH(k_s1_surface, M, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_lists, (3 * M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p);
-        LAUNCH(k_s1_verts, (d.ncan * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0);
-        if (nown > 0) LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0);
+        LAUNCH(k_s1_verts, (d.ncan * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0, S1_VL);
+        if (nown > 0) LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0, S1_VL);
         if (want_J && nown > 0) LAUNCH(k_s1_vjac, (3 * M * K + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo);
         if (want_J) hipMemsetAsync(p.Jm, 0, (size_t)d.R * d.ldn * 8, st);
         if (shard || !shared_rows_on) hipMemsetAsync(p.r, 0, (size_t)d.R * 8, st);          // rows of frames other ranks own (or switched off) stay zero here
         LAUNCH(k_s1_shared, (M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, want_J, own_shared && shared_rows_on);
         if (d.nhead_rows && own_shared && shared_rows_on) LAUNCH(k_s1_head, 1, 1, S1_TPB, st, d, p, want_J);
-        if (nown > 0) LAUNCH(k_s1_rows, nown, 1, S1_TPB, st, d, p, want_J, f_lo);
+        if (nown > 0) LAUNCH(k_s1_rows, nown, want_J ? 4 : 1, S1_TPB, st, d, p, want_J, f_lo);
     };
     auto fetch = [&](std::vector<double>& h, const double* dev, size_t count) {
         h.resize(count);
@@ -1660,15 +1784,20 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
                 if (nsd >= delta) { ddl = dsd; for (double& t : ddl) t *= delta / nsd; }
                 else {
                     if (!have_gn && schur) {
-                        const size_t lds_bytes = ((size_t)fs * (fs + 1) + fs) * sizeof(double);
+                        const size_t lds_bytes = ((size_t)fs * (fs + 1) + 2 * (size_t)fs) * sizeof(double);
                         hipMemsetAsync(d_Y, 0, (size_t)F * fs * nsp * 8, st);
                         hipMemsetAsync(d_z, 0, (size_t)F * fs * 8, st);
                         hipFuncSetAttribute(reinterpret_cast<const void*>(k_s1_elim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                         // (sharded: every rank eliminates its own frames -- their rows live only here, so A_ff, A_fs and g_f are complete --
                         //  and contributes A_ss,r - Y_r^T Y_r and g_s,r - Y_r^T z_r; the sum over ranks is the Schur system: ns^2 + ns doubles)
                         if (nown > 0) LAUNCH_LDS(k_s1_elim, nown, 1, S1_TPB, lds_bytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, p.status, f_lo);
+                        if (nown > 0) {
+                            const size_t ybytes = ((size_t)fs * (fs + 1) + (size_t)S1_YC * fs) * sizeof(double);
+                            hipFuncSetAttribute(reinterpret_cast<const void*>(k_s1_elim_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ybytes);
+                            LAUNCH_LDS(k_s1_elim_y, nown, (ns + 1 + S1_YC - 1) / S1_YC, S1_TPB, ybytes, st, d_A, n, d_g, d_fcols, fs, d_scols, ns, nsp, d_Linv, d_Y, d_z, f_lo);
+                        }
                         { int nt = (ns + S1_T - 1) / S1_T; LAUNCH(k_s1_syrk, nt, nt, 256, st, d_Y, F * fs, ns, nsp, d_T, d_ones); }
-                        LAUNCH(k_s1_schur_sub, (ns + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d_A, n, d_g, d_scols, ns, d_T, d_Y, nsp, d_z, F * fs, d_S, d_h);
+                        LAUNCH(k_s1_schur_sub, ns, 1, S1_TPB, st, d_A, n, d_g, d_scols, ns, d_T, d_Y, nsp, d_z, F * fs, d_S, d_h);
                         if (shard) {   // the only matrix that crosses ranks: the Schur system of the shared block, in place on the device
                             reduce_dev(d_S, (long long)ns * ns);
                             reduce_dev(d_h, ns);
