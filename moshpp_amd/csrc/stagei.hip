@@ -32,6 +32,7 @@
 #define S1_TPB 256
 #endif
 #define S1_CHOL_TPB 1024
+#define S1_SURF_TPB (S1_TPB >= 256 ? 1024 : S1_TPB)
 #define DYN_LDS(name) extern __shared__ double name[]
 #define LAUNCH_LDS(k, gx, gy, nt, bytes, stream, ...) hipLaunchKernelGGL(k, dim3(gx, gy), dim3(nt), bytes, stream, __VA_ARGS__)
 #define S1_TRSM_TPB 64
@@ -383,15 +384,22 @@ KERNEL k_s1_verts(S1Dims d, S1Ptr p, int zbase, int nlist, int mode, double* out
     int jj[S1_NWMAX]; double wj[S1_NWMAX], xj[S1_NWMAX][3];
     int nw = 0;
     const double* wrow = p.weights + (size_t)v * d.K;
-    for (int j = 0; j < d.K; ++j) {
-        double w = wrow[j];
-        if (w == 0.0) continue;
-        if (nw >= S1_NWMAX) { p.status[0] = 3; return; }
-        jj[nw] = j; wj[nw] = w;
-        double df[3] = {vp[0] - Jb[3 * j], vp[1] - Jb[3 * j + 1], vp[2] - Jb[3 * j + 2]}, o[3];
-        matvec3(Rw + 9 * j, df, o);
-        for (int c = 0; c < 3; ++c) xj[nw][c] = o[c] + tw[3 * j + c];
-        ++nw;
+    for (int j0 = 0; j0 < d.K; j0 += 8) {      // eight weights in flight (read one at a time in front of the branch, the row's K loads were a
+        double w8[8];                           //  chain of K round trips: 20 of this kernel's 21-33 us); the joints in order as before
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w8[u] = (j0 + u < d.K) ? wrow[j0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double w = w8[u];
+            const int j = j0 + u;
+            if (w == 0.0) continue;
+            if (nw >= S1_NWMAX) { p.status[0] = 3; return; }
+            jj[nw] = j; wj[nw] = w;
+            double df[3] = {vp[0] - Jb[3 * j], vp[1] - Jb[3 * j + 1], vp[2] - Jb[3 * j + 2]}, o[3];
+            matvec3(Rw + 9 * j, df, o);
+            for (int c = 0; c < 3; ++c) xj[nw][c] = o[c] + tw[3 * j + c];
+            ++nw;
+        }
     }
     double pos[3] = {tr[0], tr[1], tr[2]}, Trot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < nw; ++s) {
@@ -564,8 +572,10 @@ DEVFN void vertex_normal(const S1Ptr& p, int v, double* n) {
     for (int a = 0; a < 3; ++a) n[a] *= s;
 }
 
+// (launched with S1_SURF_TPB threads: every thread's triangles are a chain of dependent gathers -- 59 of them at 256 threads were 40 of the
+//  kernel's 47 us)
 KERNEL k_s1_surface(S1Dims d, S1Ptr p) {
-    SHARED double bd[256]; SHARED int bi[256];
+    SHARED double bd[S1_SURF_TPB]; SHARED int bi[S1_SURF_TPB];
     int m = BX;
     const double* x = p.ml + 3 * m;
     double best = 1e300; int besti = 0x7fffffff;
@@ -1593,7 +1603,7 @@ int moshii_stagei_core(const S1ModelView* mv, const S1PriorView* pv, const moshi
         canonical();
         LAUNCH(k_s1_knn, M, 1, S1_TPB, st, d, p, p.cl8);
         LAUNCH(k_s1_pick3, 1, 1, S1_TPB, st, d, p, p.cl8, p.cl);
-        LAUNCH(k_s1_surface, M, 1, S1_TPB, st, d, p);
+        LAUNCH(k_s1_surface, M, 1, S1_SURF_TPB, st, d, p);
         LAUNCH(k_s1_lists, (3 * M + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p);
         LAUNCH(k_s1_verts, (d.ncan * S1_VL + S1_TPB - 1) / S1_TPB, 1, S1_TPB, st, d, p, F, d.ncan, want_J ? 2 : 1, (double*)nullptr, 0, S1_VL);
         if (nown > 0) LAUNCH(k_s1_verts, (3 * M * S1_VL + S1_TPB - 1) / S1_TPB, nown, S1_TPB, st, d, p, f_lo, 3 * M, want_J ? 3 : 1, (double*)nullptr, 0, S1_VL);
