@@ -143,7 +143,7 @@ def compact_line(full):
     out = short(out)
     line = json.dumps(out, allow_nan=False, default=float)
     # never over the limit: drop the optional blocks, least important first
-    for k in ('seeds_frames_per_s', 'stagei', 'strong', 'parity_live_oracle', 'incl_host_staging_frames_per_s', 'sequential_chain',
+    for k in ('seeds_frames_per_s', 'parity_live_oracle', 'incl_host_staging_frames_per_s', 'stagei', 'strong', 'sequential_chain',
               ('parity', 'configs'), 'many_sequences', 'config3'):
         if len(line) < LINE_LIMIT:
             break

@@ -122,6 +122,10 @@ json.dump(out, open(f'{O}/r06_pmc.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY
 rm -rf $O/pmc_chain_* $O/pmc_lbs_*
+# ---- Stage-I: per-kernel split of three solves of the bench problem
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/s1prof -o s1 -- python /root/repo/tools/stagei_time.py 3 > /root/repo/$O/stagei_time.txt 2>&1)
+{ echo "# rocprofv3 --kernel-trace -- python tools/stagei_time.py 3 (three Stage-I solves of the bench problem: 12 frames, 53 markers, 10 betas, 925 unknowns, 36 dogleg iterations each), per kernel and launch shape (tools/stagei_trace_summary.py)"; grep '^rep' $O/stagei_time.txt | cut -c1-48; python tools/stagei_trace_summary.py $O/s1prof/s1_kernel_trace.csv 3 60; } > $O/stagei_kernel_summary.txt 2>&1
+rm -rf $O/s1prof $O/stagei_time.txt
 # ---- the bench line LAST, with the counters just collected on this very build in place
 cp $O/r06_pmc.json profiles/r06_pmc.json
 timeout 1800 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt

@@ -1,3 +1,5 @@
+"""Per kernel and launch shape: calls, mean duration, ms per solve, share -- from a rocprofv3 --kernel-trace csv of tools/stagei_time.py.
+usage: python tools/stagei_trace_summary.py <kernel_trace.csv> [solves=3] [rows=22]"""
 import csv, collections, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.defaultdict(list)
