@@ -72,6 +72,7 @@ struct moshii_model_s {
     int shape_start = 0, nshape = 0;
     Scratch qscratch;                   // per-chain shape-derivative scratch of the extended chain kernel
     Scratch coopbuf;                    // exchange slots + flags of cooperative chains (moshii_dev.h: CoopDev)
+    Scratch handoff;                    // entry / final states and hand-off deviations of a chunked solve's chunks
     int *d_parents = nullptr, *d_depth = nullptr, *d_comp_lo = nullptr, *d_comp_hi = nullptr, *d_col_lo = nullptr, *d_col_hi = nullptr;
     unsigned long long* d_anc = nullptr;
     bool betas_set = false;
@@ -1087,10 +1088,9 @@ int moshii_chain_solve(moshii_model_t m, moshii_prior_t prior, const moshii_solv
     HIP_TRY(hipStreamSynchronize(stream));   // hostbuf is pageable and goes out of scope
     if ((rc = launch_chains(cfg, n_chains, (const ChainDev*)dbase, stream))) return rc;
     if (coop_g > 0) {   // did every group stay whole?  (the call synchronises: a broken group has to be reported, not left in the rows)
-        std::vector<unsigned> ab(n_chains, 0u);
-        for (int c = 0; c < n_chains; ++c)
-            HIP_TRY(hipMemcpyAsync(&ab[c], m->coopbuf.ptr + coop_bytes_per_chain * c + (size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + coop_g * sizeof(unsigned),
-                                   sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        std::vector<unsigned> ab(n_chains, 0u);   // (one strided copy for all chains)
+        HIP_TRY(hipMemcpy2DAsync(ab.data(), sizeof(unsigned), m->coopbuf.ptr + (size_t)2 * coop_g * cfg.coop_slot_doubles * sizeof(unsigned long long) + coop_g * sizeof(unsigned),
+                                 coop_bytes_per_chain, sizeof(unsigned), (size_t)n_chains, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         bool broken = false;
         for (int c = 0; c < n_chains; ++c) broken |= ab[c] != 0u;
@@ -1218,10 +1218,12 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
     }
     // device buffers of this call: released on EVERY way out of the function (error returns included)
     struct Owned { std::vector<void*> p; ~Owned() { for (void* q : p) if (q) hipFree(q); } } owned;
-    double *d_entry = nullptr, *d_final = nullptr, *d_dev = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_entry, (size_t)NC * S * sizeof(double))); owned.p.push_back(d_entry);
-    HIP_TRY(hipMalloc((void**)&d_final, (size_t)NC * S * sizeof(double))); owned.p.push_back(d_final);
-    HIP_TRY(hipMalloc((void**)&d_dev, (size_t)NC * sizeof(double))); owned.p.push_back(d_dev);
+    // (kept with the model between calls: three hipMalloc / hipFree pairs a call were ~0.3 ms of a 37 ms step)
+    if ((rc = m->handoff.reserve(((size_t)2 * NC * S + NC) * sizeof(double)))) return rc;
+    m->handoff.used = true; m->handoff.last_stream = stream;
+    double* d_entry = (double*)m->handoff.ptr;
+    double* d_final = d_entry + (size_t)NC * S;
+    double* d_dev = d_final + (size_t)NC * S;
     // start states of sequences that continue a chain (moshii_sequence_desc.init_*): [pose][pose_prev][trans][has_prev][first = 0]
     double* d_init = nullptr;
     {
@@ -1362,17 +1364,12 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
             }
     }
     HIP_TRY(hipMemcpyAsync(d_pass1, cds.data(), sizeof(ChainDev) * NC, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(d_pred, pred.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
-    {
-        std::vector<int> cstart(NC);
-        for (int c = 0; c < NC; ++c) cstart[c] = chunks[c].s;
-        HIP_TRY(hipMemcpyAsync(d_bnd, cstart.data(), sizeof(int) * NC, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync(d_abort_at, 0xff, sizeof(int) * NC, stream));   // -1: no mark
-        HIP_TRY(hipMemsetAsync(d_baton, 0, sizeof(int) * 2 * NC, stream));
-        HIP_TRY(hipMemsetAsync(d_fuse, 0, sizeof(int) * (3 * NC + 1), stream));
-        HIP_TRY(hipStreamSynchronize(stream));   // (cstart goes out of scope)
+    {   // the control words behind the descriptors in ONE copy: [pred][chunk starts][done][baton x 2 = 0][abort_at = -1: no mark][fuse flags x 3, fuse count = 0]
+        std::vector<int> words((size_t)10 * NC + 1, 0);
+        for (int c = 0; c < NC; ++c) { words[c] = pred[c]; words[(size_t)NC + c] = chunks[c].s; words[(size_t)5 * NC + c] = -1; }
+        HIP_TRY(hipMemcpyAsync(d_pred, words.data(), sizeof(int) * words.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // (`words` goes out of scope)
     }
-    HIP_TRY(hipStreamSynchronize(stream));
     if ((rc = launch_chains(cfg, NC, d_pass1, stream))) { cleanup(); return rc; }
     // ---- verify the hand-offs; re-solve (exactly, from the predecessor's final state) the chunks that fail
     std::vector<double> hdev(NC, 0.0);
@@ -1499,10 +1496,9 @@ int moshii_sequence_solve(moshii_model_t m, moshii_prior_t prior, const moshii_s
         if ((rc = launch_chains(*use, (int)rep.size(), d_repair, stream))) { cleanup(); return rc; }
         if (g_round >= 2) {   // did every group stay whole?
             const size_t per = ((size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + (size_t)(2 * g_round + 2) * sizeof(unsigned) + 255) & ~size_t(255);
-            std::vector<unsigned> ab(rep.size(), 0u);
-            for (size_t i = 0; i < rep.size(); ++i)
-                HIP_TRY(hipMemcpyAsync(&ab[i], m->coopbuf.ptr + per * i + (size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + g_round * sizeof(unsigned),
-                                       sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            std::vector<unsigned> ab(rep.size(), 0u);   // (one strided copy: a copy per chain was 22 us a chain, 0.5-1 ms a round)
+            HIP_TRY(hipMemcpy2DAsync(ab.data(), sizeof(unsigned), m->coopbuf.ptr + (size_t)2 * g_round * use->coop_slot_doubles * sizeof(unsigned long long) + g_round * sizeof(unsigned),
+                                     per, sizeof(unsigned), rep.size(), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             bool broken = false;
             for (size_t i = 0; i < rep.size(); ++i) broken |= ab[i] != 0u;

@@ -330,16 +330,14 @@ KERNEL k_s1_pose(S1Dims d, S1Ptr p) {
         matmul3(Sk, Rl + 9 * k, Bm + 27 * k + 9 * c);
     }
     // a pose without any rotation away from the rest pose (the canonical one) has no corrective offsets
-    SHARED int nzf[S1_TPB];
+    SHARED int nzany;     // (every thread that sees a non-zero feature stores the same 1: no reduction)
+    if (TID == 0) nzany = 0;
+    SYNC();
     int mine = 0;
     for (int i = TID; i < d.nfeat; i += NT) if (sRl[9 * (1 + i / 9) + i % 9] - ((i % 9 == 0 || i % 9 == 4 || i % 9 == 8) ? 1.0 : 0.0) != 0.0) mine = 1;
-    nzf[TID] = mine;
+    if (mine) nzany = 1;
     SYNC();
-    if (TID == 0) {
-        int any = 0;
-        for (int t = 0; t < NT; ++t) any |= nzf[t];
-        p.featzero[z] = any ? 0 : 1;
-    }
+    if (TID == 0) p.featzero[z] = nzany ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -478,9 +476,24 @@ KERNEL k_s1_vjac(S1Dims d, S1Ptr p, int zbase) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // (value, index) minimum over the workgroup, lowest index on ties, left in bd[0] / bi[0]: a halving tree (NT is a power of two; the
 // emulation build has NT = 1) -- thread 0 walking all 256 entries cost more than the search it finished
+// (distance, index) minimum of the workgroup into bd[0] / bi[0], ties to the lower index -- so the result does not depend on the order of the
+// comparisons: inside a wavefront by lane shuffles, across the wavefronts through their first words (the LDS tree it replaces took log2(NT)
+// barriers a search, 8 searches a marker in k_s1_knn)
 #define S1_BLOCK_ARGMIN(bd, bi) \
-    for (int s_ = NT >> 1; s_ > 0; s_ >>= 1) { \
-        if (TID < s_ && (bd[TID + s_] < bd[TID] || (bd[TID + s_] == bd[TID] && bi[TID + s_] < bi[TID]))) { bd[TID] = bd[TID + s_]; bi[TID] = bi[TID + s_]; } \
+    { \
+        double vd_ = bd[TID]; int vi_ = bi[TID]; \
+        for (int o_ = 32; o_ > 0; o_ >>= 1) { \
+            const double od_ = __shfl_down(vd_, o_); const int oi_ = __shfl_down(vi_, o_); \
+            if (od_ < vd_ || (od_ == vd_ && oi_ < vi_)) { vd_ = od_; vi_ = oi_; } \
+        } \
+        SYNC(); \
+        if ((TID & 63) == 0) { bd[TID >> 6] = vd_; bi[TID >> 6] = vi_; } \
+        SYNC(); \
+        if (TID == 0) { \
+            for (int w_ = 1; w_ < (NT + 63) / 64; ++w_) \
+                if (bd[w_] < vd_ || (bd[w_] == vd_ && bi[w_] < vi_)) { vd_ = bd[w_]; vi_ = bi[w_]; } \
+            bd[0] = vd_; bi[0] = vi_; \
+        } \
         SYNC(); \
     }
 
@@ -976,15 +989,17 @@ KERNEL k_s1_rows(S1Dims d, S1Ptr p, int want_J, int fbase) {
 // flags[row chunk][column block] = 1 iff that 32 x 32 block of J holds a non-zero (most do not: a frame's pose columns appear only
 // in that frame's rows)                                                    grid (ceil(R / 32), ceil(n / 32))
 KERNEL k_s1_nzflags(const double* Jm, int R, int n, int ldn, int* flags) {
-    SHARED int any[256];
+    SHARED int any;
     int rc = BX, cb = BY, mine = 0;
+    if (TID == 0) any = 0;
+    SYNC();
     for (int e = TID; e < S1_T * S1_T; e += NT) {
         int r = rc * S1_T + e / S1_T, c = cb * S1_T + e % S1_T;
         if (r < R && c < n && Jm[(size_t)r * ldn + c] != 0.0) mine = 1;
     }
-    any[TID] = mine;
+    if (mine) any = 1;
     SYNC();
-    if (TID == 0) { int a = 0; for (int t = 0; t < NT; ++t) a |= any[t]; flags[rc * ((n + S1_T - 1) / S1_T) + cb] = a; }
+    if (TID == 0) flags[rc * ((n + S1_T - 1) / S1_T) + cb] = any;
 }
 
 #define S1_SYRK_CHUNKS 1024   // row chunks whose flags a tile keeps in LDS (32 768 rows; beyond: read one by one)
