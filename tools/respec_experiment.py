@@ -27,6 +27,15 @@ def dev_at(outs, metas):
 metas = [(st - W, st + C) for st in starts]
 fresh = dev_at(run([dict(attach=s.attach, obs=obs[a:b], vis=vis[a:b], first=True) for a, b in metas]), metas)
 print('seed', seed, 'W', W, 'chunks', len(starts), 'fresh-start misses (>1e-9):', int((fresh > 1e-9).sum()), 'gross (>1e-6):', int((fresh > 1e-6).sum()), flush=True)
+# which of the two local solutions is the better one, and where they differ
+fo = run([dict(attach=s.attach, obs=obs[a:b], vis=vis[a:b], first=True) for a, b in metas])
+g = fresh > 1e-6
+ef = np.array([o['errs'][-1][:4].sum() for o in fo]); et = np.array([true['errs'][b - 1][:4].sum() for a, b in metas])
+dp = np.array([np.abs(o['pose'][-1] - P[b - 1]) for o, (a, b) in zip(fo, metas)])[g]
+top = np.argsort(-np.median(dp, 0))[:6]
+print(f'   of the {int(g.sum())} gross misses the fresh solution has the lower objective (data + prior + velocity + hand) in {int((ef[g] < et[g]).sum())}, the higher in {int((ef[g] > et[g]).sum())}; '
+      f'median objective {np.median(ef[g]):.4g} (fresh) vs {np.median(et[g]):.4g} (sequential); pose variables with the largest median difference: '
+      f'{[(int(i), round(float(np.median(dp[:, i])), 3)) for i in top]}', flush=True)
 for lag in (0, 16, 48, 96, 192, 384):
     ch, mt = [], []
     for st in starts:
